@@ -1,0 +1,763 @@
+// libgauss_hip.so -- C ABI, planner and job orchestration (see include/gauss_hip.h).
+//
+// A job is a batch of independent windows that share every launch: one pack, one Gram, one
+// epilogue, nblk factor steps and one solve launch serve all windows of the job, so the chip is
+// filled by work items of many windows at once (the per-window matrices are too small to fill
+// 256 CUs on their own) and the latency-bound factor steps are amortised over the batch.
+#include "gauss_internal.h"
+#include "../../include/gauss_hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace gauss;
+
+namespace gauss {
+void launch_jacobi_clamp(const Prob* d_probs, int prob, const Prob& hp, double* d_work, hipStream_t s);
+}
+
+// ------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(GAUSS_E_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                  \
+    } while (0)
+
+struct gauss_ctx {
+    int device;
+    hipStream_t stream;
+};
+
+static inline size_t rup(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Host-side plan of one problem
+struct Plan {
+    Prob p;                                  // device descriptor (pointers filled at layout time)
+    std::vector<int> pop_raw_off, pop_pk_off, seg_pop, seg_k0, seg_k1, pop_seg0;
+    std::vector<int> pair_ti, pair_tj, pair_lut;
+    std::vector<double> pop_w, z1;
+    std::vector<uint8_t> word_pop;
+    std::vector<int> gene_off;
+    std::vector<long long> gene_out_off;
+    // user pointers
+    const uint8_t* h_geno_m = nullptr;
+    const uint8_t* h_geno_u = nullptr;
+    long long user_ld = 0;
+    double* out_z = nullptr;
+    double* out_info = nullptr;
+    int32_t* out_status = nullptr;
+    double* out_b11 = nullptr;
+    double* out_b21 = nullptr;
+    double* out_ld_user = nullptr;           // ld_only / gene outputs
+    size_t out_ld_count = 0;
+    double* d_b11_copy = nullptr;
+    size_t res_off = 0;                      // offset (in doubles) of this problem's z in the result block
+};
+
+struct ProfSlot { hipEvent_t a, b; int kernel; };
+
+struct gauss_job {
+    gauss_ctx* ctx = nullptr;
+    int n = 0;
+    int on_device = 0;
+    std::vector<Plan> plans;
+    char* d_tab = nullptr;      size_t tab_bytes = 0;     // tables (host mirrored)
+    char* d_ws = nullptr;       size_t ws_bytes = 0;      // workspace
+    std::vector<char> h_tab;
+    Prob* d_probs = nullptr;
+    Item* d_items = nullptr;    int n_items = 0;
+    int2* d_rowmap = nullptr;   int n_rows = 0;
+    int2* d_tilemap = nullptr;  int n_tiles = 0;
+    int2* d_panelmap = nullptr; int n_panels = 0;
+    int max_nblk = 0;
+    int* d_status = nullptr;                               // [n][4]
+    double* d_results = nullptr; size_t n_results = 0;     // z then info per problem
+    double* h_results = nullptr;                           // pinned
+    int* h_status = nullptr;                               // pinned
+    bool prof = false;
+    std::vector<ProfSlot> slots;
+    double prof_ms[5] = {0, 0, 0, 0, 0};
+    long long prof_n[5] = {0, 0, 0, 0, 0};
+    bool ran = false;
+};
+
+// ------------------------------------------------------------------------------------------
+// planning
+// ------------------------------------------------------------------------------------------
+struct WinSpec {
+    int mode, n_pop;
+    const int32_t* pop_off;
+    const double* pop_wgt;
+    int M, U;
+    const uint8_t* geno_m;
+    const uint8_t* geno_u;
+    long long ld;
+    const double* z1;
+    double lambda, eps, diag;
+    int ld_only;
+    const int32_t* gene_off;
+    int n_gene;
+};
+
+static int plan_problem(const WinSpec& w, Plan& pl)
+{
+    if (w.mode != GAUSS_MODE_POOLED && w.mode != GAUSS_MODE_WEIGHTED) return fail(GAUSS_E_INVALID, "bad mode %d", w.mode);
+    if (w.n_pop < 1 || w.n_pop > 64) return fail(GAUSS_E_INVALID, "n_pop must be in 1..64 (got %d)", w.n_pop);
+    if (!w.pop_off) return fail(GAUSS_E_INVALID, "pop_off is NULL");
+    if (w.M < 1) return fail(GAUSS_E_INVALID, "need at least one measured SNP row (got %d)", w.M);
+    if (w.U < 0) return fail(GAUSS_E_INVALID, "negative n_unmeasured");
+    if (w.mode == GAUSS_MODE_WEIGHTED && !w.pop_wgt) return fail(GAUSS_E_INVALID, "pop_wgt is NULL in weighted mode");
+    if (!w.geno_m || (w.U > 0 && !w.geno_u)) return fail(GAUSS_E_INVALID, "genotype pointer is NULL");
+    for (int p = 0; p < w.n_pop; p++)
+        if (w.pop_off[p + 1] < w.pop_off[p]) return fail(GAUSS_E_INVALID, "pop_off must be non-decreasing");
+    if (w.pop_off[0] != 0) return fail(GAUSS_E_INVALID, "pop_off[0] must be 0");
+    const int N = w.pop_off[w.n_pop];
+    if (N < 1) return fail(GAUSS_E_INVALID, "no samples");
+    if (w.ld < N) return fail(GAUSS_E_INVALID, "ld (%lld) < n_samples (%d)", w.ld, N);
+    if (!w.ld_only && w.U > 0 && !w.z1) return fail(GAUSS_E_INVALID, "z1 is NULL");
+
+    Prob& p = pl.p;
+    memset(&p, 0, sizeof(p));
+    p.mode = w.mode;
+    p.M = w.M; p.U = w.U; p.N = N;
+    p.lambda = w.lambda; p.eps = w.eps; p.diag = w.diag;
+    p.ld_only = w.ld_only;
+    p.max_code = 15;
+    if (w.mode == GAUSS_MODE_POOLED) {
+        // CalCor pools every selected population (util.cpp:53-64): one pseudo-population
+        p.P = 1;
+        pl.pop_raw_off = {0, N};
+        pl.pop_w = {1.0};
+    } else {
+        p.P = w.n_pop;
+        pl.pop_raw_off.assign(w.pop_off, w.pop_off + w.n_pop + 1);
+        pl.pop_w.assign(w.pop_wgt, w.pop_wgt + w.n_pop);
+    }
+    const int P = p.P;
+    pl.pop_pk_off.assign(P + 1, 0);
+    for (int q = 0; q < P; q++) {
+        const int m = pl.pop_raw_off[q + 1] - pl.pop_raw_off[q];
+        pl.pop_pk_off[q + 1] = pl.pop_pk_off[q] + (int)rup((size_t)m, KC);
+    }
+    p.Kp = pl.pop_pk_off[P];
+    pl.word_pop.assign(p.Kp / 16, 0);
+    pl.pop_seg0.assign(P + 1, 0);
+    for (int q = 0; q < P; q++) {
+        for (int b = pl.pop_pk_off[q] / 16; b < pl.pop_pk_off[q + 1] / 16; b++) pl.word_pop[b] = (uint8_t)q;
+        const int chunks = (pl.pop_pk_off[q + 1] - pl.pop_pk_off[q]) / KC;
+        pl.pop_seg0[q] = (int)pl.seg_pop.size();
+        if (chunks > 0) {
+            const int max_chunks = SEG_MAX / KC;
+            const int ns = (chunks + max_chunks - 1) / max_chunks;
+            const int per = (chunks + ns - 1) / ns;
+            for (int c = 0; c < chunks; c += per) {
+                const int c1 = std::min(chunks, c + per);
+                pl.seg_pop.push_back(q);
+                pl.seg_k0.push_back(pl.pop_pk_off[q] + c * KC);
+                pl.seg_k1.push_back(pl.pop_pk_off[q] + c1 * KC);
+            }
+        }
+    }
+    pl.pop_seg0[P] = (int)pl.seg_pop.size();
+    p.nseg = (int)pl.seg_pop.size();
+
+    p.Mp = (int)rup((size_t)w.M, TILE);
+    p.Up = (int)rup((size_t)w.U, TILE);
+    p.Sp = p.Mp + p.Up;
+    p.nT = p.Sp / TILE;
+    const int mt = p.Mp / TILE;
+    pl.pair_lut.assign((size_t)p.nT * p.nT, -1);
+    auto add_pair = [&](int ti, int tj) {
+        if (pl.pair_lut[(size_t)ti * p.nT + tj] >= 0) return;
+        const int id = (int)pl.pair_ti.size();
+        pl.pair_ti.push_back(ti); pl.pair_tj.push_back(tj);
+        pl.pair_lut[(size_t)ti * p.nT + tj] = id;
+        pl.pair_lut[(size_t)tj * p.nT + ti] = id;
+    };
+    if (w.gene_off) {
+        // LD is only needed inside genes (gene.cpp:305-315): tile pairs touched by some gene
+        pl.gene_off.assign(w.gene_off, w.gene_off + w.n_gene + 1);
+        long long off = 0;
+        for (int g = 0; g < w.n_gene; g++) {
+            const int r0 = pl.gene_off[g], r1 = pl.gene_off[g + 1];
+            if (r0 < 0 || r1 < r0 || r1 > w.M) return fail(GAUSS_E_INVALID, "gene_off out of range at gene %d", g);
+            pl.gene_out_off.push_back(off);
+            off += (long long)(r1 - r0) * (r1 - r0);
+            if (r1 > r0)
+                for (int ti = r0 / TILE; ti <= (r1 - 1) / TILE; ti++)
+                    for (int tj = ti; tj <= (r1 - 1) / TILE; tj++) add_pair(ti, tj);
+        }
+        pl.out_ld_count = (size_t)off;
+        p.n_gene = w.n_gene;
+    } else {
+        for (int ti = 0; ti < mt; ti++)
+            for (int tj = ti; tj < mt; tj++) add_pair(ti, tj);          // B11 (upper tiles)
+        for (int tu = mt; tu < p.nT; tu++)
+            for (int tj = 0; tj < mt; tj++) add_pair(tu, tj);           // B21
+        if (w.ld_only) pl.out_ld_count = (size_t)w.M * w.M;
+    }
+    p.npair = (int)pl.pair_ti.size();
+    p.Mld = (int)rup((size_t)w.M, NB);
+    p.nblk = p.Mld / NB;
+    p.npanel = w.ld_only ? 0 : (w.U + NRU - 1) / NRU;
+    if (w.z1) pl.z1.assign(w.z1, w.z1 + w.M);
+    pl.h_geno_m = w.geno_m; pl.h_geno_u = w.geno_u; pl.user_ld = w.ld;
+    return GAUSS_OK;
+}
+
+// Arena layout helper
+struct Arena {
+    size_t off = 0;
+    size_t take(size_t bytes) { size_t o = off; off = rup(off + bytes, 256); return o; }
+};
+
+template <typename T>
+static size_t put(std::vector<char>& blob, Arena& a, const std::vector<T>& v)
+{
+    const size_t bytes = std::max<size_t>(v.size() * sizeof(T), 1);
+    const size_t o = a.take(bytes);
+    if (blob.size() < a.off) blob.resize(a.off);
+    if (!v.empty()) memcpy(blob.data() + o, v.data(), v.size() * sizeof(T));
+    return o;
+}
+
+static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_device, gauss_job** out)
+{
+    gauss_job* job = new gauss_job();
+    job->ctx = ctx;
+    job->n = (int)specs.size();
+    job->on_device = on_device;
+    job->plans.resize(job->n);
+    for (int i = 0; i < job->n; i++) {
+        int rc = plan_problem(specs[i], job->plans[i]);
+        if (rc) { delete job; return rc; }
+    }
+    HIPCHK(hipSetDevice(ctx->device));
+
+    // ---- table arena (host mirrored) ----
+    Arena ta;
+    std::vector<char>& blob = job->h_tab;
+    struct TabOff { size_t raw_off, pk_off, w, seg_pop, k0, k1, seg0, ti, tj, lut, wp, z1, goff, gout; };
+    std::vector<TabOff> to(job->n);
+    for (int i = 0; i < job->n; i++) {
+        Plan& pl = job->plans[i];
+        to[i].raw_off = put(blob, ta, pl.pop_raw_off);
+        to[i].pk_off = put(blob, ta, pl.pop_pk_off);
+        to[i].w = put(blob, ta, pl.pop_w);
+        to[i].seg_pop = put(blob, ta, pl.seg_pop);
+        to[i].k0 = put(blob, ta, pl.seg_k0);
+        to[i].k1 = put(blob, ta, pl.seg_k1);
+        to[i].seg0 = put(blob, ta, pl.pop_seg0);
+        to[i].ti = put(blob, ta, pl.pair_ti);
+        to[i].tj = put(blob, ta, pl.pair_tj);
+        to[i].lut = put(blob, ta, pl.pair_lut);
+        to[i].wp = put(blob, ta, pl.word_pop);
+        to[i].z1 = put(blob, ta, pl.z1);
+        to[i].goff = put(blob, ta, pl.gene_off);
+        to[i].gout = put(blob, ta, pl.gene_out_off);
+    }
+    // work lists
+    std::vector<Item> items;
+    std::vector<int2> rowmap, tilemap, panelmap;
+    job->max_nblk = 0;
+    for (int i = 0; i < job->n; i++) {
+        const Prob& p = job->plans[i].p;
+        for (int pr = 0; pr < p.npair; pr++)
+            for (int s = 0; s < p.nseg; s++)
+                items.push_back(Item{i, pr, s, job->plans[i].seg_k1[s] - job->plans[i].seg_k0[s]});
+        for (int r = 0; r < p.M + p.U; r++) rowmap.push_back(make_int2(i, r));
+        if (!p.n_gene)
+            for (int pr = 0; pr < p.npair; pr++) tilemap.push_back(make_int2(i, pr));
+        for (int pn = 0; pn < p.npanel; pn++) panelmap.push_back(make_int2(i, pn));
+        if (p.npanel > 0) job->max_nblk = std::max(job->max_nblk, p.nblk);
+    }
+    // longest segments first: the tail of the launch is then made of short items
+    std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.len > b.len; });
+    const size_t o_items = put(blob, ta, items);
+    const size_t o_rowmap = put(blob, ta, rowmap);
+    const size_t o_tilemap = put(blob, ta, tilemap);
+    const size_t o_panelmap = put(blob, ta, panelmap);
+    const size_t o_probs = ta.take(sizeof(Prob) * job->n);
+    blob.resize(ta.off);
+    job->n_items = (int)items.size();
+    job->n_rows = (int)rowmap.size();
+    job->n_tiles = (int)tilemap.size();
+    job->n_panels = (int)panelmap.size();
+
+    // ---- workspace arena ----
+    Arena wa;
+    struct WsOff { size_t raw_m, raw_u, packed, sx, sxx, slab, sd, wm, mu, wmu, A, Linv, B21, V, ld, b11c; long long ldraw; };
+    std::vector<WsOff> wo(job->n);
+    size_t res = 0;
+    for (int i = 0; i < job->n; i++) {
+        Plan& pl = job->plans[i];
+        Prob& p = pl.p;
+        WsOff& w = wo[i];
+        if (!on_device) {
+            w.ldraw = (long long)rup((size_t)p.N, 16);
+            w.raw_m = wa.take((size_t)p.M * w.ldraw);
+            w.raw_u = wa.take((size_t)std::max(p.U, 1) * w.ldraw);
+        } else {
+            w.ldraw = pl.user_ld;
+        }
+        w.packed = wa.take((size_t)p.Sp * p.Kp);
+        w.sx = wa.take((size_t)p.Sp * p.P * sizeof(int));
+        w.sxx = wa.take((size_t)p.Sp * p.P * sizeof(int));
+        w.slab = wa.take((size_t)p.npair * p.nseg * TILE * TILE * sizeof(float));
+        w.sd = wa.take((size_t)p.Sp * sizeof(double));
+        w.wm = wa.take((size_t)p.Sp * sizeof(double));
+        w.mu = wa.take((size_t)p.Sp * p.P * sizeof(double));
+        w.wmu = wa.take((size_t)p.Sp * p.P * sizeof(double));
+        if (p.npanel > 0) {
+            w.A = wa.take((size_t)4 * p.Mld * p.Mld * sizeof(double));
+            w.Linv = wa.take((size_t)2 * p.nblk * NB * NB * sizeof(double));
+            w.B21 = wa.take((size_t)p.U * p.Mld * sizeof(double));
+            w.V = wa.take((size_t)p.npanel * p.Mld * NR * sizeof(double));
+            w.b11c = wa.take((size_t)p.Mld * p.Mld * sizeof(double));
+        }
+        w.ld = wa.take(std::max<size_t>(pl.out_ld_count, 1) * sizeof(double));
+        pl.res_off = res;
+        res += 2 * (size_t)p.U;
+    }
+    const size_t o_status = wa.take(sizeof(int) * 4 * job->n);
+    const size_t o_results = wa.take(sizeof(double) * std::max<size_t>(res, 1));
+    job->n_results = res;
+    job->ws_bytes = wa.off;
+    job->tab_bytes = blob.size();
+
+    hipError_t e = hipMalloc((void**)&job->d_ws, job->ws_bytes);
+    if (e != hipSuccess) { delete job; return fail(GAUSS_E_NOMEM, "hipMalloc(%zu bytes workspace) failed: %s", wa.off, hipGetErrorString(e)); }
+    e = hipMalloc((void**)&job->d_tab, job->tab_bytes);
+    if (e != hipSuccess) { hipFree(job->d_ws); delete job; return fail(GAUSS_E_NOMEM, "hipMalloc(%zu bytes tables) failed", blob.size()); }
+
+    hipStream_t st = ctx->stream;
+    // zero once: operand padding, B21 padding and the solve matrices rely on it
+    HIPCHK(hipMemsetAsync(job->d_ws, 0, job->ws_bytes, st));
+
+    job->d_status = (int*)(job->d_ws + o_status);
+    job->d_results = (double*)(job->d_ws + o_results);
+    for (int i = 0; i < job->n; i++) {
+        Plan& pl = job->plans[i];
+        Prob& p = pl.p;
+        const WsOff& w = wo[i];
+        char* T = job->d_tab;
+        char* W = job->d_ws;
+        p.ld_raw = w.ldraw;
+        if (on_device) { p.raw_m = pl.h_geno_m; p.raw_u = pl.h_geno_u; }
+        else { p.raw_m = (const uint8_t*)(W + w.raw_m); p.raw_u = (const uint8_t*)(W + w.raw_u); }
+        p.packed = (uint8_t*)(W + w.packed);
+        p.sx = (int*)(W + w.sx); p.sxx = (int*)(W + w.sxx);
+        p.pop_raw_off = (const int*)(T + to[i].raw_off);
+        p.pop_pk_off = (const int*)(T + to[i].pk_off);
+        p.pop_w = (const double*)(T + to[i].w);
+        p.seg_pop = (const int*)(T + to[i].seg_pop);
+        p.seg_k0 = (const int*)(T + to[i].k0);
+        p.seg_k1 = (const int*)(T + to[i].k1);
+        p.pop_seg0 = (const int*)(T + to[i].seg0);
+        p.pair_ti = (const int*)(T + to[i].ti);
+        p.pair_tj = (const int*)(T + to[i].tj);
+        p.pair_lut = (const int*)(T + to[i].lut);
+        p.word_pop = (const uint8_t*)(T + to[i].wp);
+        p.slab = (float*)(W + w.slab);
+        p.rt_sd = (double*)(W + w.sd); p.rt_wm = (double*)(W + w.wm);
+        p.rt_mu = (double*)(W + w.mu); p.rt_wmu = (double*)(W + w.wmu);
+        p.z1 = (const double*)(T + to[i].z1);
+        if (p.npanel > 0) {
+            p.A = (double*)(W + w.A); p.Linv = (double*)(W + w.Linv);
+            p.B21 = (double*)(W + w.B21); p.V = (double*)(W + w.V);
+            pl.d_b11_copy = (double*)(W + w.b11c);
+        }
+        p.out_z = job->d_results + pl.res_off;
+        p.out_info = job->d_results + pl.res_off + p.U;
+        p.status = job->d_status + 4 * i;
+        p.out_ld = (double*)(W + w.ld);
+        p.gene_off = p.n_gene ? (const int*)(T + to[i].goff) : nullptr;
+        p.gene_out_off = p.n_gene ? (long long*)(T + to[i].gout) : nullptr;
+        memcpy(blob.data() + o_probs + sizeof(Prob) * i, &p, sizeof(Prob));
+        if (!on_device) {
+            HIPCHK(hipMemcpy2DAsync(W + w.raw_m, (size_t)w.ldraw, pl.h_geno_m, (size_t)pl.user_ld,
+                                    (size_t)p.N, (size_t)p.M, hipMemcpyHostToDevice, st));
+            if (p.U > 0)
+                HIPCHK(hipMemcpy2DAsync(W + w.raw_u, (size_t)w.ldraw, pl.h_geno_u, (size_t)pl.user_ld,
+                                        (size_t)p.N, (size_t)p.U, hipMemcpyHostToDevice, st));
+        }
+    }
+    HIPCHK(hipMemcpyAsync(job->d_tab, blob.data(), blob.size(), hipMemcpyHostToDevice, st));
+    job->d_probs = (Prob*)(job->d_tab + o_probs);
+    job->d_items = (Item*)(job->d_tab + o_items);
+    job->d_rowmap = (int2*)(job->d_tab + o_rowmap);
+    job->d_tilemap = (int2*)(job->d_tab + o_tilemap);
+    job->d_panelmap = (int2*)(job->d_tab + o_panelmap);
+    HIPCHK(hipHostMalloc((void**)&job->h_results, sizeof(double) * std::max<size_t>(res, 1), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void**)&job->h_status, sizeof(int) * 4 * job->n, hipHostMallocDefault));
+    HIPCHK(hipStreamSynchronize(st));   // uploads from pageable user memory are complete
+    *out = job;
+    return GAUSS_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// profiling helpers
+// ------------------------------------------------------------------------------------------
+static void prof_begin(gauss_job* job, int kernel)
+{
+    if (!job->prof) return;
+    ProfSlot s;
+    s.kernel = kernel;
+    hipEventCreate(&s.a);
+    hipEventCreate(&s.b);
+    hipEventRecord(s.a, job->ctx->stream);
+    job->slots.push_back(s);
+}
+static void prof_end(gauss_job* job)
+{
+    if (!job->prof) return;
+    hipEventRecord(job->slots.back().b, job->ctx->stream);
+}
+static void prof_collect(gauss_job* job)
+{
+    for (ProfSlot& s : job->slots) {
+        hipEventSynchronize(s.b);
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, s.a, s.b);
+        job->prof_ms[s.kernel] += ms;
+        job->prof_n[s.kernel] += 1;
+        hipEventDestroy(s.a);
+        hipEventDestroy(s.b);
+    }
+    job->slots.clear();
+}
+
+// ------------------------------------------------------------------------------------------
+static int job_run(gauss_job* job, bool solve)
+{
+    hipStream_t st = job->ctx->stream;
+    HIPCHK(hipSetDevice(job->ctx->device));
+    HIPCHK(hipMemsetAsync(job->d_status, 0, sizeof(int) * 4 * job->n, st));
+    prof_begin(job, 1);
+    launch_pack_stats(job->d_probs, job->d_rowmap, job->n_rows, st);
+    launch_row_stats(job->d_probs, job->d_rowmap, job->n_rows, st);
+    prof_end(job);
+    prof_begin(job, 0);
+    launch_gram(job->d_probs, job->d_items, job->n_items, st);
+    prof_end(job);
+    prof_begin(job, 2);
+    launch_epilogue(job->d_probs, job->d_tilemap, job->n_tiles, st);
+    for (int i = 0; i < job->n; i++)
+        if (job->plans[i].p.n_gene) launch_gene_epilogue(job->d_probs, i, job->plans[i].p.n_gene, st);
+    prof_end(job);
+    if (solve && job->n_panels > 0) {
+        for (int i = 0; i < job->n; i++) {
+            Plan& pl = job->plans[i];
+            if (pl.out_b11 && pl.p.npanel > 0)
+                HIPCHK(hipMemcpyAsync(pl.d_b11_copy, pl.p.A, sizeof(double) * pl.p.Mld * pl.p.Mld, hipMemcpyDeviceToDevice, st));
+        }
+        prof_begin(job, 3);
+        for (int s = 0; s < job->max_nblk; s++) launch_factor_step(job->d_probs, job->n, s, job->max_nblk, st);
+        prof_end(job);
+        prof_begin(job, 4);
+        launch_solve(job->d_probs, job->d_panelmap, job->n_panels, st);
+        prof_end(job);
+    }
+    HIPCHK(hipGetLastError());
+    job->ran = true;
+    return GAUSS_OK;
+}
+
+// Rare path: MakePosDef would have modified B11 (util.cpp:310-317).  Rebuild B11 from the
+// epilogue, clamp its spectrum on the device (Jacobi), refactor and re-solve this window alone.
+static int job_clamp_window(gauss_job* job, int i, int* status_bits)
+{
+    hipStream_t st = job->ctx->stream;
+    Plan& pl = job->plans[i];
+    Prob& p = pl.p;
+    // Re-run the epilogue for this problem only to restore A[0] (the factorisation overwrote it)
+    std::vector<int2> tm;
+    for (int pr = 0; pr < p.npair; pr++) tm.push_back(make_int2(i, pr));
+    int2* d_tm = nullptr;
+    HIPCHK(hipMalloc((void**)&d_tm, sizeof(int2) * tm.size()));
+    HIPCHK(hipMemcpyAsync(d_tm, tm.data(), sizeof(int2) * tm.size(), hipMemcpyHostToDevice, st));
+    launch_epilogue(job->d_probs, d_tm, (int)tm.size(), st);
+    double* d_work = nullptr;
+    const size_t n = (size_t)p.Mld;
+    HIPCHK(hipMalloc((void**)&d_work, sizeof(double) * (2 * n * n + 4 * n)));
+    HIPCHK(hipMemsetAsync(p.status, 0, sizeof(int) * 4, st));
+    launch_jacobi_clamp(job->d_probs, i, p, d_work, st);
+    // refactor (both matrices are factored again; only matrix 0 is used) and solve this window
+    std::vector<int2> pm;
+    for (int pn = 0; pn < p.npanel; pn++) pm.push_back(make_int2(i, pn));
+    int2* d_pm = nullptr;
+    HIPCHK(hipMalloc((void**)&d_pm, sizeof(int2) * pm.size()));
+    HIPCHK(hipMemcpyAsync(d_pm, pm.data(), sizeof(int2) * pm.size(), hipMemcpyHostToDevice, st));
+    if (pl.out_b11) HIPCHK(hipMemcpyAsync(pl.d_b11_copy, p.A, sizeof(double) * n * n, hipMemcpyDeviceToDevice, st));
+    for (int s = 0; s < p.nblk; s++) {
+        // launch over all problems would redo the others; use a single-problem launch instead
+        launch_factor_step(job->d_probs + i, 1, s, p.nblk, st);
+    }
+    launch_solve(job->d_probs, d_pm, (int)pm.size(), st);
+    int h_status[4];
+    HIPCHK(hipMemcpyAsync(h_status, p.status, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(job->h_results + pl.res_off, job->d_results + pl.res_off, sizeof(double) * 2 * p.U, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    hipFree(d_tm); hipFree(d_pm); hipFree(d_work);
+    *status_bits = (h_status[2] || h_status[0]) ? GAUSS_ST_NONFINITE : GAUSS_ST_CLAMPED;
+    return GAUSS_OK;
+}
+
+static int job_fetch(gauss_job* job)
+{
+    if (!job->ran) return fail(GAUSS_E_INVALID, "gauss_job_fetch before gauss_job_run");
+    hipStream_t st = job->ctx->stream;
+    HIPCHK(hipSetDevice(job->ctx->device));
+    if (job->n_results)
+        HIPCHK(hipMemcpyAsync(job->h_results, job->d_results, sizeof(double) * job->n_results, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(job->h_status, job->d_status, sizeof(int) * 4 * job->n, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (int i = 0; i < job->n; i++) {
+        Plan& pl = job->plans[i];
+        const Prob& p = pl.p;
+        int bits = 0;
+        if (p.npanel > 0 && (job->h_status[4 * i + 0] || job->h_status[4 * i + 1])) {
+            int rc = job_clamp_window(job, i, &bits);
+            if (rc) return rc;
+        }
+        if (p.npanel > 0) {
+            if (bits & GAUSS_ST_NONFINITE) {
+                // the reference's eigen-solver / LU propagate non-finite values to every output
+                for (int u = 0; u < 2 * p.U; u++) job->h_results[pl.res_off + u] = NAN;
+            }
+            if (pl.out_z) memcpy(pl.out_z, job->h_results + pl.res_off, sizeof(double) * p.U);
+            if (pl.out_info) memcpy(pl.out_info, job->h_results + pl.res_off + p.U, sizeof(double) * p.U);
+            if (pl.out_b11)
+                HIPCHK(hipMemcpy2D(pl.out_b11, sizeof(double) * p.M, pl.d_b11_copy, sizeof(double) * p.Mld,
+                                   sizeof(double) * p.M, p.M, hipMemcpyDeviceToHost));
+            if (pl.out_b21 && p.U > 0)
+                HIPCHK(hipMemcpy2D(pl.out_b21, sizeof(double) * p.M, p.B21, sizeof(double) * p.Mld,
+                                   sizeof(double) * p.M, p.U, hipMemcpyDeviceToHost));
+        }
+        if (pl.out_status) *pl.out_status = bits;
+        if (pl.out_ld_user && pl.out_ld_count)
+            HIPCHK(hipMemcpy(pl.out_ld_user, p.out_ld, sizeof(double) * pl.out_ld_count, hipMemcpyDeviceToHost));
+    }
+    if (job->prof) prof_collect(job);
+    return GAUSS_OK;
+}
+
+static void job_free(gauss_job* job)
+{
+    if (!job) return;
+    if (job->ctx) hipSetDevice(job->ctx->device);
+    for (ProfSlot& s : job->slots) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
+    if (job->d_ws) hipFree(job->d_ws);
+    if (job->d_tab) hipFree(job->d_tab);
+    if (job->h_results) hipHostFree(job->h_results);
+    if (job->h_status) hipHostFree(job->h_status);
+    delete job;
+}
+
+static WinSpec spec_from_desc(const gauss_window_desc& d)
+{
+    WinSpec w;
+    w.mode = d.mode; w.n_pop = d.n_pop; w.pop_off = d.pop_off; w.pop_wgt = d.pop_wgt;
+    w.M = d.n_measured; w.U = d.n_unmeasured; w.geno_m = d.geno_m; w.geno_u = d.geno_u; w.ld = d.ld;
+    w.z1 = d.z1; w.lambda = d.lambda; w.eps = d.min_abs_eig; w.diag = 1.0; w.ld_only = 0;
+    w.gene_off = nullptr; w.n_gene = 0;
+    return w;
+}
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* gauss_last_error(void) { return g_err.c_str(); }
+const char* gauss_hip_version(void) { return "gauss_hip 0.1 (gfx950)"; }
+
+int gauss_hip_init(int device, gauss_ctx** out_ctx)
+{
+    if (!out_ctx) return fail(GAUSS_E_INVALID, "out_ctx is NULL");
+    int n = 0;
+    HIPCHK(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return fail(GAUSS_E_INVALID, "device %d out of range (have %d)", device, n);
+    HIPCHK(hipSetDevice(device));
+    gauss_ctx* c = new gauss_ctx();
+    c->device = device;
+    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    *out_ctx = c;
+    return GAUSS_OK;
+}
+
+void gauss_hip_destroy(gauss_ctx* ctx)
+{
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int gauss_job_create(gauss_ctx* ctx, const gauss_window_desc* wins, int n_win, int on_device, gauss_job** out_job)
+{
+    if (!ctx || !wins || n_win < 1 || !out_job) return fail(GAUSS_E_INVALID, "bad arguments to gauss_job_create");
+    std::vector<WinSpec> specs;
+    for (int i = 0; i < n_win; i++) {
+        if (wins[i].n_unmeasured < 1) return fail(GAUSS_E_INVALID, "window %d has no unmeasured SNPs", i);
+        specs.push_back(spec_from_desc(wins[i]));
+    }
+    gauss_job* job = nullptr;
+    int rc = job_build(ctx, specs, on_device, &job);
+    if (rc) return rc;
+    for (int i = 0; i < n_win; i++) {
+        Plan& pl = job->plans[i];
+        pl.out_z = wins[i].out_z; pl.out_info = wins[i].out_info; pl.out_status = wins[i].out_status;
+        pl.out_b11 = wins[i].out_b11; pl.out_b21 = wins[i].out_b21;
+    }
+    *out_job = job;
+    return GAUSS_OK;
+}
+
+int gauss_job_run(gauss_job* job) { return job ? job_run(job, true) : fail(GAUSS_E_INVALID, "job is NULL"); }
+int gauss_job_fetch(gauss_job* job) { return job ? job_fetch(job) : fail(GAUSS_E_INVALID, "job is NULL"); }
+void gauss_job_destroy(gauss_job* job) { job_free(job); }
+
+int gauss_job_profile(gauss_job* job, int enable)
+{
+    if (!job) return fail(GAUSS_E_INVALID, "job is NULL");
+    if (job->prof && !enable) prof_collect(job);
+    job->prof = enable != 0;
+    if (enable) { for (int k = 0; k < 5; k++) { job->prof_ms[k] = 0; job->prof_n[k] = 0; } }
+    return GAUSS_OK;
+}
+
+int gauss_job_profile_get(gauss_job* job, int kernel, double* out_ms, int64_t* out_launches)
+{
+    if (!job || kernel < 0 || kernel > 4) return fail(GAUSS_E_INVALID, "bad arguments");
+    hipStreamSynchronize(job->ctx->stream);
+    prof_collect(job);
+    if (out_ms) *out_ms = job->prof_ms[kernel];
+    if (out_launches) *out_launches = job->prof_n[kernel];
+    return GAUSS_OK;
+}
+
+int gauss_job_work(gauss_job* job, double* out_ld_flops, double* out_solve_flops, double* out_bytes, int64_t* out_imputed)
+{
+    if (!job) return fail(GAUSS_E_INVALID, "job is NULL");
+    double ldf = 0, sf = 0, by = 0;
+    int64_t imp = 0;
+    for (const Plan& pl : job->plans) {
+        const double M = pl.p.M, U = pl.p.U, N = pl.p.N;
+        ldf += N * M * (M + 1) + 2.0 * N * U * M;            // symmetric half of B11 + B21
+        sf += M * M * M / 3.0 + 2.0 * U * M * M + 4.0 * U * M;
+        by += (M + U) * N + (M * M + U * M) * 8.0;
+        imp += pl.p.U;
+    }
+    if (out_ld_flops) *out_ld_flops = ldf;
+    if (out_solve_flops) *out_solve_flops = sf;
+    if (out_bytes) *out_bytes = by;
+    if (out_imputed) *out_imputed = imp;
+    return GAUSS_OK;
+}
+
+int gauss_impute_window(gauss_ctx* ctx, const gauss_window_desc* win)
+{
+    if (!ctx || !win) return fail(GAUSS_E_INVALID, "bad arguments to gauss_impute_window");
+    gauss_job* job = nullptr;
+    int rc = gauss_job_create(ctx, win, 1, 0, &job);
+    if (rc) return rc;
+    rc = job_run(job, true);
+    if (!rc) rc = job_fetch(job);
+    job_free(job);
+    return rc;
+}
+
+static int ld_common(gauss_ctx* ctx, int mode, const uint8_t* geno, int n_snp, int64_t ld,
+                     const int32_t* pop_off, const double* pop_wgt, int n_pop, double diag,
+                     const int32_t* gene_off, int n_gene, double* out, int64_t* out_counts, int n_samples)
+{
+    if (!ctx || !geno || (!out && !out_counts)) return fail(GAUSS_E_INVALID, "bad arguments");
+    WinSpec w;
+    int32_t off1[2] = {0, n_samples};
+    w.mode = mode; w.n_pop = out_counts ? 1 : n_pop; w.pop_off = out_counts ? off1 : pop_off; w.pop_wgt = pop_wgt;
+    w.M = n_snp; w.U = 0; w.geno_m = geno; w.geno_u = nullptr; w.ld = ld; w.z1 = nullptr;
+    w.lambda = 0; w.eps = 0; w.diag = diag; w.ld_only = 1; w.gene_off = gene_off; w.n_gene = n_gene;
+    gauss_job* job = nullptr;
+    std::vector<WinSpec> specs{w};
+    int rc = job_build(ctx, specs, 0, &job);
+    if (rc) return rc;
+    if (!out_counts) job->plans[0].out_ld_user = out;
+    rc = job_run(job, false);
+    if (!rc && out_counts) {
+        long long* d_cnt = nullptr;
+        const size_t bytes = sizeof(long long) * (size_t)n_snp * n_snp;
+        hipError_t e = hipMalloc((void**)&d_cnt, bytes);
+        if (e != hipSuccess) { job_free(job); return fail(GAUSS_E_NOMEM, "hipMalloc counts failed"); }
+        launch_counts(job->d_probs, 0, job->plans[0].p.npair, d_cnt, ctx->stream);
+        e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess) e = hipMemcpy(out_counts, d_cnt, bytes, hipMemcpyDeviceToHost);
+        hipFree(d_cnt);
+        if (e != hipSuccess) { job_free(job); return fail(GAUSS_E_DEVICE, "counts: %s", hipGetErrorString(e)); }
+    }
+    if (!rc) rc = job_fetch(job);
+    job_free(job);
+    return rc;
+}
+
+int gauss_ld(gauss_ctx* ctx, int mode, const uint8_t* geno, int n_snp, int64_t ld, const int32_t* pop_off,
+             const double* pop_wgt, int n_pop, double diag, double* out_cor)
+{
+    return ld_common(ctx, mode, geno, n_snp, ld, pop_off, pop_wgt, n_pop, diag, nullptr, 0, out_cor, nullptr, 0);
+}
+
+int gauss_gene_ld_batch(gauss_ctx* ctx, int mode, const uint8_t* geno, int n_snp, int64_t ld,
+                        const int32_t* pop_off, const double* pop_wgt, int n_pop,
+                        const int32_t* gene_off, int n_gene, double diag, double* out_blocks)
+{
+    if (!gene_off || n_gene < 1) return fail(GAUSS_E_INVALID, "gene_off is NULL or n_gene < 1");
+    return ld_common(ctx, mode, geno, n_snp, ld, pop_off, pop_wgt, n_pop, diag, gene_off, n_gene, out_blocks, nullptr, 0);
+}
+
+int gauss_gram_counts(gauss_ctx* ctx, const uint8_t* geno, int n_snp, int n_samples, int64_t ld, int64_t* out_counts)
+{
+    if (!out_counts) return fail(GAUSS_E_INVALID, "out_counts is NULL");
+    return ld_common(ctx, GAUSS_MODE_POOLED, geno, n_snp, ld, nullptr, nullptr, 1, 1.0, nullptr, 0, nullptr,
+                     out_counts, n_samples);
+}
+
+int gauss_synth_device(gauss_ctx* ctx, uint8_t* d_out, int n_snp, int64_t ld, const int32_t* pop_off, int n_pop,
+                       const float* thr, const float* rho, uint64_t seed)
+{
+    if (!ctx || !d_out || !pop_off || !thr || !rho || n_snp < 1 || n_pop < 1) return fail(GAUSS_E_INVALID, "bad arguments");
+    HIPCHK(hipSetDevice(ctx->device));
+    const int N = pop_off[n_pop];
+    int* d_off = nullptr; float* d_thr = nullptr; float* d_rho = nullptr;
+    HIPCHK(hipMalloc((void**)&d_off, sizeof(int) * (n_pop + 1)));
+    HIPCHK(hipMalloc((void**)&d_thr, sizeof(float) * (size_t)n_snp * n_pop));
+    HIPCHK(hipMalloc((void**)&d_rho, sizeof(float) * n_snp));
+    HIPCHK(hipMemcpy(d_off, pop_off, sizeof(int) * (n_pop + 1), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_thr, thr, sizeof(float) * (size_t)n_snp * n_pop, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_rho, rho, sizeof(float) * n_snp, hipMemcpyHostToDevice));
+    launch_synth(d_out, n_snp, ld, d_off, n_pop, N, d_thr, d_rho, seed, ctx->stream);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    hipFree(d_off); hipFree(d_thr); hipFree(d_rho);
+    return GAUSS_OK;
+}
+
+}  // extern "C"

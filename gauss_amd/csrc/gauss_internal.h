@@ -1,0 +1,93 @@
+// Internal declarations shared by the HIP translation units of libgauss_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gauss {
+
+constexpr int TILE = 128;      // Gram output tile edge per workgroup (4 waves x 64x64)
+constexpr int KC = 64;         // packed K chunk in bytes (= samples); pops are padded to it
+constexpr int SEG_MAX = 2048;  // max samples per K segment (split-K granularity)
+constexpr int NB = 64;         // fp64 factor / solve block edge
+constexpr int NR = 32;         // right-hand sides per solve panel (31 SNPs + the z1 column)
+constexpr int NRU = 31;
+
+// Pointers stored inside a Prob are loaded from memory, so the compiler could not infer their
+// address space and would emit flat_* accesses.  Everything a Prob points to is device global
+// memory: in the device pass the members are declared address_space(1) (same size and layout).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GP(T) T __attribute__((address_space(1)))*
+#else
+#define GP(T) T*
+#endif
+
+// Device-visible description of one window ("problem").  Built on the host by the planner,
+// uploaded once per job.  All pointers are device pointers.
+struct Prob {
+    int mode, P;            // P = populations as seen by the kernels (1 pseudo-pop when pooled)
+    int M, U;               // measured / unmeasured SNP rows
+    int Mp, Up, Sp;         // row counts padded to TILE; Sp = Mp + Up
+    int N;                  // samples (sum of population sizes)
+    int Kp;                 // packed row length in bytes (multiple of KC)
+    int nseg, npair, nT;    // K segments, tile pairs, row tiles (Sp / TILE)
+    int Mld, nblk;          // solve leading dimension (M padded to NB) and block count
+    int npanel;             // solve panels (ceil(U / NRU)), 0 for LD-only problems
+    int ld_only;            // 1: write out_ld (S x S) instead of B11/B21
+    int max_code;           // largest genotype code admitted by the range check
+    double lambda, eps, diag;
+    long long ld_raw;
+    GP(const uint8_t) raw_m;   // [M x ld_raw]
+    GP(const uint8_t) raw_u;   // [U x ld_raw]
+    GP(uint8_t) packed;        // [Sp x Kp]
+    GP(int) sx;                // [Sp x P] per-population sum x
+    GP(int) sxx;               // [Sp x P] per-population sum x^2
+    GP(const int) pop_raw_off; // [P+1]
+    GP(const int) pop_pk_off;  // [P+1] packed column offsets (multiples of KC)
+    GP(const double) pop_w;    // [P]
+    GP(const int) seg_pop;     // [nseg]
+    GP(const int) seg_k0;      // [nseg] packed byte range
+    GP(const int) seg_k1;
+    GP(const int) pop_seg0;    // [P+1] segment range per population
+    GP(const int) pair_ti;     // [npair]
+    GP(const int) pair_tj;
+    GP(const int) pair_lut;    // [nT x nT] -> pair index or -1
+    GP(const uint8_t) word_pop;// [Kp/16] population of each packed 16-byte word
+    GP(float) slab;            // [npair*nseg][TILE*TILE] exact integer partial Grams
+    GP(double) rt_sd;          // [Sp] weighted: sqrt(self cov); pooled: sqrt(n*Sxx - Sx^2)
+    GP(double) rt_wm;          // [Sp] weighted: sum_p w_p mu_p ; pooled: Sx (as double)
+    GP(double) rt_mu;          // [Sp x P] Sx_p / m_p
+    GP(double) rt_wmu;         // [Sp x P] w_p * mu_p
+    GP(const double) z1;       // [M]
+    GP(double) A;              // [4][Mld x Mld] row-major: B11, B11 - eps*I, and their factors L0, L1
+    GP(double) Linv;           // [2][nblk][NB x NB] inverses of the diagonal Cholesky blocks
+    GP(double) B21;            // [Upad x Mld] row-major (Upad = npanel*NRU rounded)
+    GP(double) V;              // [npanel][Mld][NR]
+    GP(double) out_z;          // [U]
+    GP(double) out_info;       // [U]
+    GP(int) status;            // [4]: [0] fail flag matrix 0, [1] fail flag matrix 1, [2] nonfinite
+    GP(double) out_ld;         // [S x S] for ld_only
+    GP(const int) gene_off;    // gene batches: [n_gene+1], else null
+    int n_gene;
+    GP(long long) gene_out_off;// [n_gene] offsets into out_ld
+};
+
+struct Item { int prob, pair, seg, len; };
+
+template <typename T> using gptr = T __attribute__((address_space(1)))*;
+template <typename T> __device__ __forceinline__ gptr<T> G(T* p) { return (gptr<T>)p; }
+template <typename T> __device__ __forceinline__ gptr<T> G(gptr<T> p) { return p; }
+
+// ---- launchers (host functions defined in the .hip files) ----
+void launch_pack_stats(const Prob* d_probs, const int2* d_rowmap, int n_rows, hipStream_t s);
+void launch_row_stats(const Prob* d_probs, const int2* d_rowmap, int n_rows, hipStream_t s);
+void launch_gram(const Prob* d_probs, const Item* d_items, int n_items, hipStream_t s);
+void launch_epilogue(const Prob* d_probs, const int2* d_tilemap, int n_tiles, hipStream_t s);
+void launch_gene_epilogue(const Prob* d_probs, int prob, int n_gene, hipStream_t s);
+void launch_factor_step(const Prob* d_probs, int n_prob, int step, int max_nblk, hipStream_t s);
+void launch_solve(const Prob* d_probs, const int2* d_panelmap, int n_panels, hipStream_t s);
+void launch_counts(const Prob* d_probs, int prob, int npair, long long* d_out, hipStream_t s);
+void launch_synth(uint8_t* d_out, int n_snp, long long ld, const int* d_pop_off, int n_pop,
+                  int n_samples, const float* d_thr, const float* d_rho, uint64_t seed,
+                  hipStream_t s);
+
+}  // namespace gauss

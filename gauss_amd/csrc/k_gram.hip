@@ -1,0 +1,141 @@
+// K2/K3: the LD GEMM.  Exact integer Gram partials  S_xy = sum_n x_i[n] * x_j[n]  on the
+// fp32 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+// Replaces the `sumxy` accumulation of CalCor / CalWgtCov (util.cpp:62, util.cpp:114), which
+// the reference re-runs for every SNP pair (dist.cpp:174,189; distmix.cpp:195,213;
+// computeLD.cpp:111; gene.cpp:309,581).  Here all pairs of a 128 x 128 tile are formed at once.
+//
+// Exactness: operands are genotype codes (0..15 admitted, 0..2 in practice); a segment spans at
+// most SEG_MAX = 2048 samples, so every partial sum is an integer < 2^24 and the f32 MFMA
+// accumulation (bitwise a k-ordered fmaf chain) is exact in any summation order.  The k order
+// inside a chunk is therefore permuted freely to make the LDS reads wide.
+//
+// Work item = (tile pair, K segment).  Workgroup = 256 threads = 4 waves, each wave owns a
+// 64 x 64 sub-tile = 2 x 2 MFMA tiles of 32 x 32 (four independent accumulators keep the
+// 64-cycle MFMA pipe issuing back to back).  K is walked in chunks of KC = 64 bytes staged
+// through LDS with register prefetch (global -> VGPR -> LDS, write after the barrier).
+//
+// LDS image: [128 rows][80 bytes] per operand (64 data + 16 pad).  A ds_read_b128 is served in
+// groups of 16 lanes that hold 16 different rows; with an 80-byte (= 16 x 5) row stride those
+// 16 sixteen-byte slots are distinct modulo the 256-byte bank row: conflict-free.
+#include "gauss_internal.h"
+
+namespace gauss {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int LROW = 80;                   // LDS row stride in bytes
+constexpr int LTILE = TILE * LROW;         // bytes per operand tile image
+
+__device__ __forceinline__ float ub(uint32_t w, int b) { return (float)((w >> (8 * b)) & 0xffu); }
+
+__global__ __launch_bounds__(256, 2) void gram_kernel(const Prob* __restrict__ probs,
+                                                      const Item* __restrict__ items)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds[2 * 2 * LTILE];
+
+    const Item it = items[blockIdx.x];
+    const Prob& pb = probs[it.prob];
+    const int Kp = pb.Kp;
+    const int ti = G(pb.pair_ti)[it.pair], tj = G(pb.pair_tj)[it.pair];
+    const int k0 = G(pb.seg_k0)[it.seg], k1 = G(pb.seg_k1)[it.seg];
+    const gptr<const uint8_t> Ag = G((const uint8_t*)pb.packed) + (size_t)ti * TILE * Kp;
+    const gptr<const uint8_t> Bg = G((const uint8_t*)pb.packed) + (size_t)tj * TILE * Kp;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+
+    // staging map: 512 sixteen-byte pieces per operand tile, two per thread
+    const int srow0 = tid >> 2, scol = (tid & 3) << 4;       // rows 0..63
+    const int srow1 = srow0 + 64;                            // rows 64..127
+    const size_t g0 = (size_t)srow0 * Kp + scol, g1 = (size_t)srow1 * Kp + scol;
+    const int l0 = srow0 * LROW + scol, l1 = srow1 * LROW + scol;
+
+    f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
+
+    u32x4 pa0, pa1, pb0, pb1;
+    pa0 = *(gptr<const u32x4>)(Ag + g0 + k0);
+    pa1 = *(gptr<const u32x4>)(Ag + g1 + k0);
+    pb0 = *(gptr<const u32x4>)(Bg + g0 + k0);
+    pb1 = *(gptr<const u32x4>)(Bg + g1 + k0);
+    int cur = 0;
+    {
+        uint8_t* la = lds;
+        uint8_t* lb = lds + LTILE;
+        *reinterpret_cast<u32x4*>(la + l0) = pa0;
+        *reinterpret_cast<u32x4*>(la + l1) = pa1;
+        *reinterpret_cast<u32x4*>(lb + l0) = pb0;
+        *reinterpret_cast<u32x4*>(lb + l1) = pb1;
+    }
+    __syncthreads();
+
+    const int arow = (wr * 64 + li) * LROW + lh * 16;
+    const int brow = (wc * 64 + li) * LROW + lh * 16;
+
+    for (int k = k0; k < k1; k += KC) {
+        const bool more = (k + KC) < k1;
+        if (more) {
+            pa0 = *(gptr<const u32x4>)(Ag + g0 + k + KC);
+            pa1 = *(gptr<const u32x4>)(Ag + g1 + k + KC);
+            pb0 = *(gptr<const u32x4>)(Bg + g0 + k + KC);
+            pb1 = *(gptr<const u32x4>)(Bg + g1 + k + KC);
+        }
+        const uint8_t* la = lds + cur * 2 * LTILE;
+        const uint8_t* lb = la + LTILE;
+#pragma unroll
+        for (int g = 0; g < 2; g++) {
+            const u32x4 a0 = *reinterpret_cast<const u32x4*>(la + arow + g * 32);
+            const u32x4 a1 = *reinterpret_cast<const u32x4*>(la + arow + 32 * LROW + g * 32);
+            const u32x4 b0 = *reinterpret_cast<const u32x4*>(lb + brow + g * 32);
+            const u32x4 b1 = *reinterpret_cast<const u32x4*>(lb + brow + 32 * LROW + g * 32);
+            const uint32_t aw0[4] = {a0.x, a0.y, a0.z, a0.w};
+            const uint32_t aw1[4] = {a1.x, a1.y, a1.z, a1.w};
+            const uint32_t bw0[4] = {b0.x, b0.y, b0.z, b0.w};
+            const uint32_t bw1[4] = {b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    const float fa0 = ub(aw0[q], b), fa1 = ub(aw1[q], b);
+                    const float fb0 = ub(bw0[q], b), fb1 = ub(bw1[q], b);
+                    acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0, fb0, acc00, 0, 0, 0);
+                    acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0, fb1, acc01, 0, 0, 0);
+                    acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1, fb0, acc10, 0, 0, 0);
+                    acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1, fb1, acc11, 0, 0, 0);
+                }
+            }
+        }
+        if (more) {
+            uint8_t* wa = lds + (cur ^ 1) * 2 * LTILE;
+            uint8_t* wb = wa + LTILE;
+            *reinterpret_cast<u32x4*>(wa + l0) = pa0;
+            *reinterpret_cast<u32x4*>(wa + l1) = pa1;
+            *reinterpret_cast<u32x4*>(wb + l0) = pb0;
+            *reinterpret_cast<u32x4*>(wb + l1) = pb1;
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    const gptr<float> out = G(pb.slab) + ((size_t)it.pair * pb.nseg + it.seg) * (TILE * TILE);
+    const int orow = wr * 64 + 4 * lh, ocol = wc * 64 + li;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int row = orow + (r & 3) + 8 * (r >> 2);
+        out[(size_t)row * TILE + ocol] = acc00[r];
+        out[(size_t)row * TILE + ocol + 32] = acc01[r];
+        out[(size_t)(row + 32) * TILE + ocol] = acc10[r];
+        out[(size_t)(row + 32) * TILE + ocol + 32] = acc11[r];
+    }
+}
+
+void launch_gram(const Prob* d_probs, const Item* d_items, int n_items, hipStream_t s)
+{
+    if (n_items > 0) hipLaunchKernelGGL(gram_kernel, dim3(n_items), dim3(256), 0, s, d_probs, d_items);
+}
+
+}  // namespace gauss

@@ -1,0 +1,193 @@
+// Rare-path MakePosDef on the device (one-sided Jacobi eigen-clamp) and the synthetic panel
+// generator used by bench.py.
+#include "gauss_internal.h"
+
+namespace gauss {
+
+// ------------------------------------------------------------------------------------------
+// MakePosDef(m1, min_abs_eig)  (util.cpp:302-318) for the rare case that B11 has an eigenvalue
+// below min_abs_eig:   B11 <- V max(Lambda, eps) V^T  =  B11 + sum_{lambda_j < eps} (eps - lambda_j) v_j v_j^T
+// Eigenpairs by one-sided (Hestenes) Jacobi on G = B11 V: plane rotations make the columns of G
+// mutually orthogonal; at convergence g_j = lambda_j v_j and lambda_j = v_j . g_j (sign kept).
+// Rotations of a round act on disjoint column pairs (round-robin schedule), one workgroup each.
+// G and V are n x n column-major in d_work; n is even (multiple of NB).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double block_sum(double v, double* red, int tid)
+{
+    red[tid] = v;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) red[tid] += red[tid + s];
+        __syncthreads();
+    }
+    const double r = red[0];
+    __syncthreads();
+    return r;
+}
+
+__global__ __launch_bounds__(256) void jacobi_init_kernel(const double* __restrict__ A, double* __restrict__ G,
+                                                          double* __restrict__ V, int n, int* __restrict__ status)
+{
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)n * n) return;
+    const int r = (int)(idx % n), c = (int)(idx / n);
+    const double a = A[(size_t)r * n + c];      // A is symmetric: row-major == column-major
+    G[idx] = a;
+    V[idx] = (r == c) ? 1.0 : 0.0;
+    if (!isfinite(a)) status[2] = 1;
+}
+
+__global__ __launch_bounds__(256) void jacobi_round_kernel(double* __restrict__ G, double* __restrict__ V, int n,
+                                                           int round, unsigned int* __restrict__ n_rot,
+                                                           const int* __restrict__ status)
+{
+    __shared__ double red[256];
+    if (status[2]) return;
+    const int i = blockIdx.x;            // pair index within the round, 0 .. n/2-1
+    const int m = n - 1;
+    int p, q;
+    if (i == 0) { p = m; q = round % m; }
+    else { p = (round + i) % m; q = (round - i + m) % m; }
+    if (p > q) { const int t = p; p = q; q = t; }
+    double* gp = G + (size_t)p * n;
+    double* gq = G + (size_t)q * n;
+    const int tid = threadIdx.x;
+    double a = 0, b = 0, g = 0;
+    for (int k = tid; k < n; k += 256) {
+        const double x = gp[k], y = gq[k];
+        a = fma(x, x, a); b = fma(y, y, b); g = fma(x, y, g);
+    }
+    a = block_sum(a, red, tid);
+    b = block_sum(b, red, tid);
+    g = block_sum(g, red, tid);
+    if (!(fabs(g) > 1e-15 * sqrt(a * b)) || g == 0.0) return;      // already orthogonal
+    const double zeta = (b - a) / (2.0 * g);
+    const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+    const double c = 1.0 / sqrt(1.0 + t * t);
+    const double s = c * t;
+    double* vp = V + (size_t)p * n;
+    double* vq = V + (size_t)q * n;
+    for (int k = tid; k < n; k += 256) {
+        const double x = gp[k], y = gq[k];
+        gp[k] = c * x - s * y;
+        gq[k] = s * x + c * y;
+        const double u = vp[k], w = vq[k];
+        vp[k] = c * u - s * w;
+        vq[k] = s * u + c * w;
+    }
+    if (tid == 0) atomicAdd(n_rot, 1u);
+}
+
+// lam[j] = v_j . g_j ; delta[j] = max(eps - lam_j, 0)
+__global__ __launch_bounds__(256) void jacobi_lambda_kernel(const double* __restrict__ G, const double* __restrict__ V,
+                                                            int n, double eps, double* __restrict__ delta,
+                                                            int* __restrict__ status)
+{
+    __shared__ double red[256];
+    const int j = blockIdx.x, tid = threadIdx.x;
+    double s = 0;
+    for (int k = tid; k < n; k += 256) s = fma(V[(size_t)j * n + k], G[(size_t)j * n + k], s);
+    s = block_sum(s, red, tid);
+    if (tid == 0) {
+        delta[j] = (s < eps) ? (eps - s) : 0.0;
+        if (!isfinite(s)) status[2] = 1;
+    }
+}
+
+// A[r][c] += sum_j delta_j V[r][j] V[c][j]   (row-major A, column-major V)
+__global__ __launch_bounds__(256) void jacobi_apply_kernel(double* __restrict__ A, const double* __restrict__ V,
+                                                           const double* __restrict__ delta, int n)
+{
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)n * n) return;
+    const int r = (int)(idx / n), c = (int)(idx % n);
+    double s = 0.0;
+    for (int j = 0; j < n; j++) {
+        const double d = delta[j];
+        if (d != 0.0) s = fma(d * V[(size_t)j * n + r], V[(size_t)j * n + c], s);
+    }
+    A[idx] += s;
+}
+
+void launch_jacobi_clamp(const Prob* d_probs, int prob, const Prob& hp, double* d_work, hipStream_t st)
+{
+    (void)d_probs; (void)prob;
+    const int n = hp.Mld;
+    double* G = d_work;
+    double* V = G + (size_t)n * n;
+    double* delta = V + (size_t)n * n;
+    unsigned int* d_rot = reinterpret_cast<unsigned int*>(delta + 2 * (size_t)n);
+    const int nb2 = (int)(((size_t)n * n + 255) / 256);
+    hipLaunchKernelGGL(jacobi_init_kernel, dim3(nb2), dim3(256), 0, st, hp.A, G, V, n, hp.status);
+    for (int sweep = 0; sweep < 30; sweep++) {
+        hipMemsetAsync(d_rot, 0, sizeof(unsigned int), st);
+        for (int r = 0; r < n - 1; r++)
+            hipLaunchKernelGGL(jacobi_round_kernel, dim3(n / 2), dim3(256), 0, st, G, V, n, r, d_rot, hp.status);
+        unsigned int h_rot = 0;
+        hipMemcpyAsync(&h_rot, d_rot, sizeof(unsigned int), hipMemcpyDeviceToHost, st);
+        hipStreamSynchronize(st);
+        if (h_rot == 0) break;
+    }
+    hipLaunchKernelGGL(jacobi_lambda_kernel, dim3(n), dim3(256), 0, st, G, V, n, hp.eps, delta, hp.status);
+    hipLaunchKernelGGL(jacobi_apply_kernel, dim3(nb2), dim3(256), 0, st, hp.A, V, delta, n);
+}
+
+// ------------------------------------------------------------------------------------------
+// Synthetic panel generator (bench plumbing).  One thread per sample walks along the SNPs with
+// two AR(1) latent haplotypes; allele = latent < thr[snp][population]; genotype = sum of the two.
+// Same model as gauss_amd/synth.py (Gaussian-copula AR(1) LD, Balding-Nichols thresholds come
+// from the host), with a counter-based hash RNG so the output depends only on (seed, snp, sample).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t mix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+__device__ __forceinline__ void normal2(uint64_t key, float& n0, float& n1)
+{
+    const uint64_t h = mix64(key);
+    const float u0 = ((float)(uint32_t)(h >> 40) + 0.5f) * (1.0f / 16777216.0f);
+    const float u1 = ((float)(uint32_t)((h >> 8) & 0xFFFFFFu) + 0.5f) * (1.0f / 16777216.0f);
+    const float r = sqrtf(-2.0f * __logf(u0));
+    float sn, cs;
+    __sincosf(6.28318530718f * u1, &sn, &cs);
+    n0 = r * cs;
+    n1 = r * sn;
+}
+
+__global__ __launch_bounds__(256) void synth_kernel(uint8_t* __restrict__ out, int n_snp, long long ld,
+                                                    const int* __restrict__ pop_off, int n_pop, int n_samples,
+                                                    const float* __restrict__ thr, const float* __restrict__ rho,
+                                                    uint64_t seed)
+{
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= n_samples) return;
+    int pop = 0;
+    while (pop + 1 < n_pop && n >= pop_off[pop + 1]) pop++;
+    float z0, z1;
+    normal2(seed * 0x100000001B3ull + (uint64_t)n, z0, z1);
+    for (int s = 0; s < n_snp; s++) {
+        if (s) {
+            const float r = rho[s];
+            const float q = sqrtf(fmaxf(0.0f, 1.0f - r * r));
+            float e0, e1;
+            normal2((seed ^ ((uint64_t)s << 32)) + (uint64_t)n * 0x9E3779B1ull + 7ull, e0, e1);
+            z0 = r * z0 + q * e0;
+            z1 = r * z1 + q * e1;
+        }
+        const float t = thr[(size_t)s * n_pop + pop];
+        out[(size_t)s * ld + n] = (uint8_t)((z0 < t) + (z1 < t));
+    }
+}
+
+void launch_synth(uint8_t* d_out, int n_snp, long long ld, const int* d_pop_off, int n_pop, int n_samples,
+                  const float* d_thr, const float* d_rho, uint64_t seed, hipStream_t s)
+{
+    hipLaunchKernelGGL(synth_kernel, dim3((n_samples + 255) / 256), dim3(256), 0, s, d_out, n_snp, ld, d_pop_off,
+                       n_pop, n_samples, d_thr, d_rho, seed);
+}
+
+}  // namespace gauss

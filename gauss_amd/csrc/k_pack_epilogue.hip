@@ -1,0 +1,275 @@
+// K1 pack_stats, K1b row_stats, K4 LD epilogue (fp64, reference operation order).
+//
+// This translation unit is compiled with -ffp-contract=off: the fp64 tails below follow the
+// reference's CalCor / CalWgtCov tails operation by operation (util.cpp:66-68, 117-123;
+// distmix.cpp:181-182,195-196), and a fused multiply-add would round differently from the
+// reference's separately rounded x86-64 multiply and add.
+#include "gauss_internal.h"
+
+namespace gauss {
+
+// ------------------------------------------------------------------------------------------
+// K1: raw genotype bytes (ASCII digits or 0..2) -> packed u8 operand rows + per-population
+// integer sums.  Replaces the per-pair recomputation of sumx / sumxsq inside CalCor
+// (util.cpp:58-61) and the allele count of MakeSnpVec (gauss.cpp:581-583).
+// One workgroup per SNP row; a thread handles 16 packed bytes at a time.
+// Packed layout: population p occupies bytes [pop_pk_off[p], pop_pk_off[p]+m_p), zero padded
+// up to the next multiple of KC, so a K chunk never straddles two populations and zero padding
+// contributes nothing to any sum.
+// ------------------------------------------------------------------------------------------
+struct __attribute__((packed)) U32u { uint32_t v; };
+
+__global__ __launch_bounds__(256) void pack_stats_kernel(const Prob* __restrict__ probs,
+                                                         const int2* __restrict__ rowmap)
+{
+    const int2 rm = rowmap[blockIdx.x];
+    const Prob& pb = probs[rm.x];
+    const int r = rm.y;
+    const uint8_t* src;
+    int prow;
+    if (r < pb.M) { src = pb.raw_m + (size_t)r * pb.ld_raw; prow = r; }
+    else { src = pb.raw_u + (size_t)(r - pb.M) * pb.ld_raw; prow = pb.Mp + (r - pb.M); }
+    uint4* dst = reinterpret_cast<uint4*>(pb.packed + (size_t)prow * pb.Kp);
+
+    __shared__ int s_sx[64];
+    __shared__ int s_sxx[64];
+    if (threadIdx.x < 64) { s_sx[threadIdx.x] = 0; s_sxx[threadIdx.x] = 0; }
+    __syncthreads();
+
+    const int nwords = pb.Kp >> 4;
+    for (int w = threadIdx.x; w < nwords; w += 256) {
+        const int p = pb.word_pop[w];
+        const int o = (w << 4) - pb.pop_pk_off[p];
+        const int m = pb.pop_raw_off[p + 1] - pb.pop_raw_off[p];
+        int valid = m - o;
+        valid = valid < 0 ? 0 : (valid > 16 ? 16 : valid);
+        uint32_t v[4] = {0u, 0u, 0u, 0u};
+        const uint8_t* s = src + pb.pop_raw_off[p] + o;
+        if (valid == 16) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) v[q] = reinterpret_cast<const U32u*>(s + 4 * q)->v;
+        } else {
+            for (int b = 0; b < valid; b++) v[b >> 2] |= (uint32_t)s[b] << (8 * (b & 3));
+        }
+        int sx = 0, sxx = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            uint32_t x = v[q] & 0x0F0F0F0Fu;   // '0'..'9' and 0..15 both decode as byte & 0x0F
+            v[q] = x;
+            sx = __builtin_amdgcn_udot4(x, 0x01010101u, sx, false);
+            sxx = __builtin_amdgcn_udot4(x, x, sxx, false);
+        }
+        dst[w] = make_uint4(v[0], v[1], v[2], v[3]);
+        if (sx) { atomicAdd(&s_sx[p], sx); atomicAdd(&s_sxx[p], sxx); }
+    }
+    __syncthreads();
+    if (threadIdx.x < pb.P) {
+        pb.sx[(size_t)prow * pb.P + threadIdx.x] = s_sx[threadIdx.x];
+        pb.sxx[(size_t)prow * pb.P + threadIdx.x] = s_sxx[threadIdx.x];
+    }
+}
+
+void launch_pack_stats(const Prob* d_probs, const int2* d_rowmap, int n_rows, hipStream_t s)
+{
+    if (n_rows > 0) hipLaunchKernelGGL(pack_stats_kernel, dim3(n_rows), dim3(256), 0, s, d_probs, d_rowmap);
+}
+
+// ------------------------------------------------------------------------------------------
+// K1b: per-row fp64 tables.
+//  weighted (CalWgtCov(x,x), distmix.cpp:180-187 / computeLD.cpp:100-103):
+//     rt_mu[p]  = sumx_p / m_p            rt_wmu[p] = w_p * (sumx_p / m_p)
+//     rt_wm     = sum_p w_p * mu_p        rt_sd     = sqrt(CalWgtCov(x,x))
+//  pooled (CalCor, util.cpp:66-67):
+//     rt_wm = sumx (all samples)          rt_sd = sqrt(n*sumxsq - sumx*sumx)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void row_stats_kernel(const Prob* __restrict__ probs,
+                                                        const int2* __restrict__ rowmap, int n_rows)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n_rows) return;
+    const int2 rm = rowmap[idx];
+    const Prob& pb = probs[rm.x];
+    const int r = rm.y;
+    const int prow = (r < pb.M) ? r : pb.Mp + (r - pb.M);
+    const int P = pb.P;
+    const int* sx = pb.sx + (size_t)prow * P;
+    const int* sxx = pb.sxx + (size_t)prow * P;
+    if (pb.mode == 0) {
+        double sumx = 0, sumxsq = 0;
+        int num_samples = 0;
+        for (int p = 0; p < P; p++) {
+            sumx += (double)sx[p];
+            sumxsq += (double)sxx[p];
+            num_samples += pb.pop_raw_off[p + 1] - pb.pop_raw_off[p];
+        }
+        pb.rt_wm[prow] = sumx;
+        pb.rt_sd[prow] = sqrt((num_samples) * sumxsq - sumx * sumx);
+    } else {
+        double wsumcov = 0, wsum_mi_mj = 0, wsum_mi = 0;
+        for (int p = 0; p < P; p++) {
+            const int m = pb.pop_raw_off[p + 1] - pb.pop_raw_off[p];
+            const double wgt_val = pb.pop_w[p];
+            const double sumx = (double)sx[p];
+            const double sumxy = (double)sxx[p];
+            const double factor = ((double)m) / (m - 1);
+            wsumcov += wgt_val * factor * (m * sumxy - sumx * sumx);
+            const double mu = sumx / m;
+            const double wmu = wgt_val * mu;
+            wsum_mi_mj += wmu * mu;
+            wsum_mi += wmu;
+            pb.rt_mu[(size_t)prow * P + p] = mu;
+            pb.rt_wmu[(size_t)prow * P + p] = wmu;
+        }
+        pb.rt_wm[prow] = wsum_mi;
+        pb.rt_sd[prow] = sqrt(wsumcov + wsum_mi_mj - wsum_mi * wsum_mi);
+    }
+}
+
+void launch_row_stats(const Prob* d_probs, const int2* d_rowmap, int n_rows, hipStream_t s)
+{
+    if (n_rows > 0)
+        hipLaunchKernelGGL(row_stats_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, s, d_probs, d_rowmap, n_rows);
+}
+
+// ------------------------------------------------------------------------------------------
+// Correlation of packed rows (ri, rj) from the exact per-segment Gram partials of one tile.
+// `x` is the first argument of CalCor / CalWgtCov (row ri), `y` the second (row rj).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double cor_entry(const Prob& pb, const float* __restrict__ tile_slab,
+                                            int off, int ri, int rj)
+{
+    const int P = pb.P;
+    const size_t seg_stride = (size_t)TILE * TILE;
+    if (pb.mode == 0) {
+        double sumxy = 0;
+        for (int s = 0; s < pb.nseg; s++) sumxy += (double)tile_slab[s * seg_stride + off];
+        const int num_samples = pb.N;
+        const double numer = num_samples * sumxy - pb.rt_wm[ri] * pb.rt_wm[rj];   // util.cpp:66
+        const double denor = pb.rt_sd[ri] * pb.rt_sd[rj];                         // util.cpp:67
+        return numer / denor;                                                     // util.cpp:68
+    }
+    double wsumcov = 0, wsum_mi_mj = 0;
+    const int* sxi = pb.sx + (size_t)ri * P;
+    const int* sxj = pb.sx + (size_t)rj * P;
+    const double* wmui = pb.rt_wmu + (size_t)ri * P;
+    const double* muj = pb.rt_mu + (size_t)rj * P;
+    for (int p = 0; p < P; p++) {
+        double sumxy = 0;
+        for (int s = pb.pop_seg0[p]; s < pb.pop_seg0[p + 1]; s++)
+            sumxy += (double)tile_slab[s * seg_stride + off];
+        const int m = pb.pop_raw_off[p + 1] - pb.pop_raw_off[p];
+        const double factor = ((double)m) / (m - 1);                               // util.cpp:117
+        const double sumx = (double)sxi[p], sumy = (double)sxj[p];
+        wsumcov += pb.pop_w[p] * factor * (m * sumxy - sumx * sumy);               // util.cpp:118
+        wsum_mi_mj += wmui[p] * muj[p];                                            // util.cpp:119
+    }
+    const double cov = wsumcov + wsum_mi_mj - pb.rt_wm[ri] * pb.rt_wm[rj];        // util.cpp:123
+    return cov / (pb.rt_sd[ri] * pb.rt_sd[rj]);                                   // distmix.cpp:196
+}
+
+// ------------------------------------------------------------------------------------------
+// K4: LD epilogue.  One workgroup per tile pair.  Turns the exact integer Gram partials into
+// fp64 correlations and scatters them into
+//   - A[0] = B11 (diag 1+lambda), A[1] = B11 - eps*I, both row-major Mld x Mld, identity padded
+//   - B21 (U x Mld row-major), zero padded
+// or, for LD-only problems, into out_ld (S x S, diag = pb.diag).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void epilogue_kernel(const Prob* __restrict__ probs,
+                                                       const int2* __restrict__ tilemap)
+{
+    const int2 tm = tilemap[blockIdx.x];
+    const Prob& pb = probs[tm.x];
+    const int pair = tm.y;
+    const int ti = pb.pair_ti[pair], tj = pb.pair_tj[pair];
+    const float* tile_slab = pb.slab + (size_t)pair * pb.nseg * TILE * TILE;
+    const int mt = pb.Mp / TILE;        // number of measured row tiles
+    const bool sym = (ti < mt);         // measured x measured tile (ti <= tj < mt)
+    const int Mld = pb.Mld;
+    for (int e = threadIdx.x; e < TILE * TILE; e += 256) {
+        const int ii = e / TILE, jj = e % TILE;
+        const int ri = ti * TILE + ii, rj = tj * TILE + jj;   // packed row indices
+        if (sym) {
+            if (ri > rj) continue;                            // mirror handles the lower part
+            if (pb.ld_only) {
+                if (ri >= pb.M || rj >= pb.M) continue;
+                double v = (ri == rj) ? pb.diag : cor_entry(pb, tile_slab, e, ri, rj);
+                pb.out_ld[(size_t)ri * pb.M + rj] = v;
+                pb.out_ld[(size_t)rj * pb.M + ri] = v;
+                continue;
+            }
+            if (ri >= Mld || rj >= Mld) continue;
+            double v0, v1;
+            if (ri >= pb.M || rj >= pb.M) { v0 = v1 = (ri == rj) ? 1.0 : 0.0; }
+            else if (ri == rj) { v0 = 1.0 + pb.lambda; v1 = v0 - pb.eps; }   // dist.cpp:172
+            else { v0 = v1 = cor_entry(pb, tile_slab, e, ri, rj); }           // dist.cpp:174-177
+            double* A0 = pb.A;
+            double* A1 = pb.A + (size_t)Mld * Mld;
+            A0[(size_t)ri * Mld + rj] = v0; A0[(size_t)rj * Mld + ri] = v0;
+            A1[(size_t)ri * Mld + rj] = v1; A1[(size_t)rj * Mld + ri] = v1;
+        } else {
+            const int u = ri - pb.Mp;                         // unmeasured row (x), measured col (y)
+            if (u >= pb.U || rj >= pb.M) continue;
+            pb.B21[(size_t)u * Mld + rj] = cor_entry(pb, tile_slab, e, ri, rj);   // dist.cpp:188-191
+        }
+    }
+}
+
+void launch_epilogue(const Prob* d_probs, const int2* d_tilemap, int n_tiles, hipStream_t s)
+{
+    if (n_tiles > 0) hipLaunchKernelGGL(epilogue_kernel, dim3(n_tiles), dim3(256), 0, s, d_probs, d_tilemap);
+}
+
+// Gene batches (gene.cpp:305-315, 571-586): block g is n_g x n_g with pb.diag on the diagonal.
+__global__ __launch_bounds__(256) void gene_epilogue_kernel(const Prob* __restrict__ probs, int prob)
+{
+    const Prob& pb = probs[prob];
+    const int g = blockIdx.x;
+    const int r0 = pb.gene_off[g];
+    const int n = pb.gene_off[g + 1] - r0;
+    double* out = pb.out_ld + pb.gene_out_off[g];
+    for (int e = threadIdx.x; e < n * n; e += 256) {
+        const int a = e / n, b = e % n;
+        if (a > b) continue;
+        double v;
+        if (a == b) v = pb.diag;
+        else {
+            const int ri = r0 + a, rj = r0 + b;
+            const int ti = ri / TILE, tj = rj / TILE;
+            const int pair = pb.pair_lut[ti * pb.nT + tj];
+            const float* tile_slab = pb.slab + (size_t)pair * pb.nseg * TILE * TILE;
+            v = cor_entry(pb, tile_slab, (ri % TILE) * TILE + (rj % TILE), ri, rj);
+        }
+        out[(size_t)a * n + b] = v;
+        out[(size_t)b * n + a] = v;
+    }
+}
+
+void launch_gene_epilogue(const Prob* d_probs, int prob, int n_gene, hipStream_t s)
+{
+    if (n_gene > 0) hipLaunchKernelGGL(gene_epilogue_kernel, dim3(n_gene), dim3(256), 0, s, d_probs, prob);
+}
+
+// Exact integer counts (integer parity hook): out[i][j] = sum over all segments of the slab.
+__global__ __launch_bounds__(256) void counts_kernel(const Prob* __restrict__ probs, int prob,
+                                                     long long* __restrict__ out)
+{
+    const Prob& pb = probs[prob];
+    const int pair = blockIdx.x;
+    const int ti = pb.pair_ti[pair], tj = pb.pair_tj[pair];
+    const float* tile_slab = pb.slab + (size_t)pair * pb.nseg * TILE * TILE;
+    for (int e = threadIdx.x; e < TILE * TILE; e += 256) {
+        const int ri = ti * TILE + e / TILE, rj = tj * TILE + e % TILE;
+        if (ri >= pb.M || rj >= pb.M) continue;
+        long long s = 0;
+        for (int g = 0; g < pb.nseg; g++) s += (long long)tile_slab[(size_t)g * TILE * TILE + e];
+        out[(size_t)ri * pb.M + rj] = s;
+        out[(size_t)rj * pb.M + ri] = s;
+    }
+}
+
+void launch_counts(const Prob* d_probs, int prob, int npair, long long* d_out, hipStream_t s)
+{
+    if (npair > 0) hipLaunchKernelGGL(counts_kernel, dim3(npair), dim3(256), 0, s, d_probs, prob, d_out);
+}
+
+}  // namespace gauss

@@ -1,0 +1,204 @@
+"""numpy-level front end of the C ABI (include/gauss_hip.h) -- the numeric hot path on the GPU.
+
+Each function is a thin marshalling layer over one C entry point; all arithmetic happens in
+libgauss_hip.so on the device.  Names follow the reference functions they replace.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import MODE_POOLED, MODE_WEIGHTED, WindowDesc, check  # noqa: F401
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+
+
+class Context:
+    """One HIP device context (gauss_hip_init / gauss_hip_destroy)."""
+
+    def __init__(self, device=0):
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        check(self.lib.gauss_hip_init(int(device), C.byref(h)))
+        self.handle = h
+        self.device = device
+
+    def close(self):
+        if self.handle:
+            self.lib.gauss_hip_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx = None
+
+
+def default_context():
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0)
+    return _default_ctx
+
+
+def _pops(pop_off, pop_wgt):
+    po = np.ascontiguousarray(pop_off, dtype=np.int32)
+    w = None if pop_wgt is None else np.ascontiguousarray(pop_wgt, dtype=np.float64)
+    return po, w
+
+
+def gram_counts(geno, ctx=None):
+    """Exact integer sum_n x_i[n] x_j[n] (util.cpp:62,114 `sumxy`), int64 (S, S)."""
+    ctx = ctx or default_context()
+    g = _lib.as_u8(geno)
+    S, N = g.shape
+    out = np.zeros((S, S), dtype=np.int64)
+    check(ctx.lib.gauss_gram_counts(ctx.handle, g.ctypes.data, S, N, g.strides[0],
+                                    out.ctypes.data_as(C.POINTER(C.c_int64))))
+    return out
+
+
+def ld_matrix(geno, pop_off, pop_wgt=None, mode=MODE_WEIGHTED, diag=1.0, ctx=None):
+    """LD matrix among the rows of `geno`.
+
+    mode=MODE_WEIGHTED, diag=1.0  -> computeLD core (computeLD.cpp:95-116)
+    mode=MODE_POOLED, diag=1+lambda -> CorG of jepeg (gene.cpp:305-315)
+    """
+    ctx = ctx or default_context()
+    g = _lib.as_u8(geno)
+    S = g.shape[0]
+    po, w = _pops(pop_off, pop_wgt)
+    out = np.zeros((S, S), dtype=np.float64)
+    check(ctx.lib.gauss_ld(ctx.handle, int(mode), g.ctypes.data, S, g.strides[0],
+                           po.ctypes.data_as(_ip), _lib.ptr(w, _dp), len(po) - 1, float(diag),
+                           out.ctypes.data_as(_dp)))
+    return out
+
+
+def gene_ld_batch(geno, pop_off, gene_off, pop_wgt=None, mode=MODE_POOLED, diag=1.1, ctx=None):
+    """LD blocks of all genes in one launch; returns a list of (n_g, n_g) arrays."""
+    ctx = ctx or default_context()
+    g = _lib.as_u8(geno)
+    S = g.shape[0]
+    po, w = _pops(pop_off, pop_wgt)
+    go = np.ascontiguousarray(gene_off, dtype=np.int32)
+    sizes = np.diff(go).astype(np.int64)
+    out = np.zeros(int((sizes * sizes).sum()), dtype=np.float64)
+    check(ctx.lib.gauss_gene_ld_batch(ctx.handle, int(mode), g.ctypes.data, S, g.strides[0],
+                                      po.ctypes.data_as(_ip), _lib.ptr(w, _dp), len(po) - 1,
+                                      go.ctypes.data_as(_ip), len(go) - 1, float(diag),
+                                      out.ctypes.data_as(_dp)))
+    blocks, o = [], 0
+    for n in sizes:
+        blocks.append(out[o:o + n * n].reshape(n, n))
+        o += n * n
+    return blocks
+
+
+class _Win:
+    """Keeps the numpy buffers of one window alive next to its C descriptor."""
+
+    def __init__(self, desc, mode, geno_m, geno_u, pop_off, pop_wgt, z1, lam, min_abs_eig,
+                 want_mats, dev_ptrs=None):
+        self.po, self.w = _pops(pop_off, pop_wgt)
+        self.z1 = np.ascontiguousarray(z1, dtype=np.float64)
+        if dev_ptrs is None:
+            self.gm = _lib.as_u8(geno_m)
+            self.gu = _lib.as_u8(geno_u)
+            M, U = self.gm.shape[0], self.gu.shape[0]
+            pm, pu, ld = self.gm.ctypes.data, self.gu.ctypes.data, self.gm.strides[0]
+            if U and self.gu.strides[0] != ld:
+                raise ValueError("geno_m and geno_u must share a row stride")
+        else:
+            pm, pu, M, U, ld = dev_ptrs
+        self.M, self.U = M, U
+        self.z = np.zeros(U)
+        self.info = np.zeros(U)
+        self.status = np.zeros(1, dtype=np.int32)
+        self.b11 = np.zeros((M, M)) if want_mats else None
+        self.b21 = np.zeros((U, M)) if want_mats else None
+        desc.mode = int(mode)
+        desc.n_pop = len(self.po) - 1
+        desc.pop_off = self.po.ctypes.data_as(_ip)
+        desc.pop_wgt = _lib.ptr(self.w, _dp)
+        desc.n_measured, desc.n_unmeasured = M, U
+        desc.geno_m, desc.geno_u, desc.ld = pm, pu, ld
+        desc.z1 = self.z1.ctypes.data_as(_dp)
+        desc.lambda_, desc.min_abs_eig = float(lam), float(min_abs_eig)
+        desc.out_z = self.z.ctypes.data_as(_dp)
+        desc.out_info = self.info.ctypes.data_as(_dp)
+        desc.out_status = self.status.ctypes.data_as(_ip)
+        desc.out_b11 = _lib.ptr(self.b11, _dp)
+        desc.out_b21 = _lib.ptr(self.b21, _dp)
+
+    def result(self):
+        out = dict(z=self.z, info=self.info, status=int(self.status[0]))
+        if self.b11 is not None:
+            out["b11"], out["b21"] = self.b11, self.b21
+        return out
+
+
+def impute_window(mode, geno_m, geno_u, pop_off, pop_wgt, z1, lam=0.1, min_abs_eig=1e-5,
+                  want_mats=False, ctx=None):
+    """run_dist (mode 0, dist.cpp:129-227) / run_distmix (mode 1, distmix.cpp:138-253)."""
+    ctx = ctx or default_context()
+    desc = WindowDesc()
+    win = _Win(desc, mode, geno_m, geno_u, pop_off, pop_wgt, z1, lam, min_abs_eig, want_mats)
+    check(ctx.lib.gauss_impute_window(ctx.handle, C.byref(desc)))
+    return win.result()
+
+
+class Job:
+    """A batch of windows sharing every launch (gauss_job_*)."""
+
+    def __init__(self, windows, ctx=None, on_device=False, want_mats=False):
+        """windows: list of dicts(mode, geno_m, geno_u, pop_off, pop_wgt, z1[, lam, min_abs_eig])
+        or, with on_device=True, dicts carrying dev=(ptr_m, ptr_u, M, U, ld) instead of arrays."""
+        self.ctx = ctx or default_context()
+        n = len(windows)
+        self.descs = (WindowDesc * n)()
+        self.wins = []
+        for i, w in enumerate(windows):
+            self.wins.append(_Win(self.descs[i], w["mode"], w.get("geno_m"), w.get("geno_u"),
+                                  w["pop_off"], w.get("pop_wgt"), w["z1"], w.get("lam", 0.1),
+                                  w.get("min_abs_eig", 1e-5), want_mats, w.get("dev")))
+        h = C.c_void_p()
+        check(self.ctx.lib.gauss_job_create(self.ctx.handle, self.descs, n, 1 if on_device else 0,
+                                            C.byref(h)))
+        self.handle = h
+
+    def run(self):
+        check(self.ctx.lib.gauss_job_run(self.handle))
+
+    def fetch(self):
+        check(self.ctx.lib.gauss_job_fetch(self.handle))
+        return [w.result() for w in self.wins]
+
+    def profile(self, enable=True):
+        check(self.ctx.lib.gauss_job_profile(self.handle, 1 if enable else 0))
+
+    def profile_get(self, kernel=0):
+        ms, n = C.c_double(), C.c_int64()
+        check(self.ctx.lib.gauss_job_profile_get(self.handle, kernel, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def work(self):
+        a, b, c, d = C.c_double(), C.c_double(), C.c_double(), C.c_int64()
+        check(self.ctx.lib.gauss_job_work(self.handle, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return dict(ld_flops=a.value, solve_flops=b.value, bytes=c.value, imputed_snps=d.value)
+
+    def close(self):
+        if self.handle:
+            self.ctx.lib.gauss_job_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

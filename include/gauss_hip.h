@@ -1,0 +1,146 @@
+/*
+ * gauss_hip.h -- C ABI of libgauss_hip.so: the MI355X (gfx950) replacement for the numeric
+ * hot path of statsleelab/gauss (LD matrix + DIST/DISTMIX Z-score imputation + JEPEG LD step).
+ *
+ * Boundary: the Rcpp entry points computeLD()/dist()/distmix()/jepeg()/
+ * jepegmix() keep their signatures (R/RcppExports.R:28,57,74,88,102).  Inside the drivers, the
+ * code between "genotype strings are in memory" (ReadGenotype, src/gauss.cpp:720-785) and
+ * "z / info / cormat doubles" is replaced by one call into this library:
+ *
+ *   reference code being replaced                          entry point here
+ *   -----------------------------------------------------  ---------------------------------
+ *   computeLD.cpp:95-116  (CalWgtCov pair loops)           gauss_ld(mode=WEIGHTED, diag=1.0)
+ *   dist.cpp:129-227      run_dist                         gauss_impute_window(mode=POOLED)
+ *   distmix.cpp:138-253   run_distmix                      gauss_impute_window(mode=WEIGHTED)
+ *   gene.cpp:305-315      CorG via CalCor   (jepeg)        gauss_gene_ld_batch(mode=POOLED)
+ *   gene.cpp:571-586      CorG via CalWgtCov (jepegmix)    gauss_gene_ld_batch(mode=WEIGHTED)
+ *   util.cpp:49-70,103-124 (sumxy accumulation)            gauss_gram_counts (integer parity)
+ *
+ * Conventions
+ *   - plain C types only; no exceptions cross the boundary.  Every call returns 0 on success
+ *     or a negative GAUSS_E_* code; gauss_last_error() gives a thread-local message.  The
+ *     Rcpp driver turns non-zero into Rcpp::stop(msg) (reference convention, dist.cpp:150).
+ *   - the caller owns every input and output buffer; the library keeps nothing past return
+ *     except inside handles it created (contexts, jobs).
+ *   - genotype matrices are SNP-major: one SNP = one row of n_samples bytes, row stride `ld`
+ *     bytes.  A byte is either the ASCII digit the reference stores ('0','1','2';
+ *     Snp::genotype_vec_, src/snp.h:109) or the raw count 0..2; both decode as (byte & 0x0F).
+ *     A row is the concatenation, in panel order, of the per-population strings of the
+ *     selected populations: population p occupies columns [pop_off[p], pop_off[p+1]).
+ *   - host-pointer calls are blocking (R's .Call semantics); the *_dev / job API is
+ *     asynchronous on the context's streams and is what the multi-window farm uses.
+ */
+#ifndef GAUSS_HIP_H
+#define GAUSS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GAUSS_MODE_POOLED   0  /* CalCor, util.cpp:49-70   (dist, jepeg)                 */
+#define GAUSS_MODE_WEIGHTED 1  /* CalWgtCov, util.cpp:103-124 (distmix, computeLD, jepegmix) */
+
+#define GAUSS_OK            0
+#define GAUSS_E_INVALID    -1  /* bad argument                                   */
+#define GAUSS_E_DEVICE     -2  /* HIP runtime error                              */
+#define GAUSS_E_NOMEM      -3  /* host or device allocation failed               */
+#define GAUSS_E_RANGE      -4  /* exact-integer Gram range would be exceeded     */
+
+/* per-window status bits returned in out_status */
+#define GAUSS_ST_CLAMPED    1  /* MakePosDef rebuilt B11 (some eigenvalue < min_abs_eig, util.cpp:310) */
+#define GAUSS_ST_NONFINITE  2  /* B11 not finite / not factorisable: outputs are NaN like the reference's */
+
+typedef struct gauss_ctx gauss_ctx;
+typedef struct gauss_job gauss_job;
+
+/* One imputation window (one R call of dist()/distmix()).  geno_m/geno_u may be host or
+ * device pointers (see gauss_job_create's `on_device`). */
+typedef struct gauss_window_desc {
+    int mode;                 /* GAUSS_MODE_*                                                      */
+    int n_pop;                /* P: selected populations (pooled mode may pass 1)                  */
+    const int32_t* pop_off;   /* [P+1] column ranges; pop_off[P] = n_samples                       */
+    const double* pop_wgt;    /* [P] weights in the same order (ignored for POOLED; may be NULL)   */
+    int n_measured;           /* M: type-1 SNPs of the extended window (dist.cpp:137-138)          */
+    int n_unmeasured;         /* U: type-0 SNPs of the prediction window (dist.cpp:135-136); 0 = LD only */
+    const uint8_t* geno_m;    /* [M x ld] measured genotypes                                       */
+    const uint8_t* geno_u;    /* [U x ld] unmeasured genotypes                                     */
+    int64_t ld;               /* row stride in bytes (>= n_samples)                                */
+    const double* z1;         /* [M] measured z-scores (host pointer, always)                      */
+    double lambda;            /* ridge added to diag(B11): Arguments::lambda = 0.1 (gauss.cpp:20)  */
+    double min_abs_eig;       /* MakePosDef floor: 1e-5 (gauss.cpp:21)                             */
+    double* out_z;            /* [U] imputed z / sqrt(info)    (dist.cpp:200)  host pointer        */
+    double* out_info;         /* [U] info = |b21 B11^-1 b12|   (dist.cpp:198)  host pointer        */
+    int32_t* out_status;      /* [1] GAUSS_ST_* bits                           host pointer        */
+    double* out_b11;          /* optional [M x M] B11 incl. lambda (symmetric)  host pointer / NULL */
+    double* out_b21;          /* optional [U x M] row-major                     host pointer / NULL */
+} gauss_window_desc;
+
+/* ---- context ------------------------------------------------------------------------------- */
+int gauss_hip_init(int device, gauss_ctx** out_ctx);
+void gauss_hip_destroy(gauss_ctx* ctx);
+const char* gauss_last_error(void);
+const char* gauss_hip_version(void);
+
+/* ---- blocking host-pointer calls (what the Rcpp drivers bind) ------------------------------ */
+
+/* LD matrix among S SNPs.  mode WEIGHTED + diag 1.0 = computeLD.cpp:95-116;
+ * mode POOLED + diag 1+lambda = CorG of gene.cpp:305-315.  out_cor: S x S doubles (symmetric,
+ * so column-major == row-major; fits an Rcpp::NumericMatrix directly). */
+int gauss_ld(gauss_ctx* ctx, int mode, const uint8_t* geno, int n_snp, int64_t ld,
+             const int32_t* pop_off, const double* pop_wgt, int n_pop, double diag,
+             double* out_cor);
+
+/* One window: run_dist (POOLED) / run_distmix (WEIGHTED).  Blocking. */
+int gauss_impute_window(gauss_ctx* ctx, const gauss_window_desc* win);
+
+/* LD blocks of many genes in one launch: gene g owns SNP rows [gene_off[g], gene_off[g+1]).
+ * out_blocks receives the n_g x n_g blocks back to back (block g at sum_{h<g} n_h^2), each
+ * with `diag` on its diagonal. */
+int gauss_gene_ld_batch(gauss_ctx* ctx, int mode, const uint8_t* geno, int n_snp, int64_t ld,
+                        const int32_t* pop_off, const double* pop_wgt, int n_pop,
+                        const int32_t* gene_off, int n_gene, double diag, double* out_blocks);
+
+/* Exact co-occurrence counts sum_n x_i[n] x_j[n] over all columns -- the integer the reference
+ * accumulates as `sumxy` (util.cpp:62,114).  out: S x S int64, row-major.  Integer parity hook. */
+int gauss_gram_counts(gauss_ctx* ctx, const uint8_t* geno, int n_snp, int n_samples, int64_t ld,
+                      int64_t* out_counts);
+
+/* ---- asynchronous multi-window jobs (farm harness, bench) ----------------------------------- */
+
+/* Build a job of n_win windows.  If on_device != 0, geno_m/geno_u are device pointers that stay
+ * resident for the life of the job; otherwise they are host pointers and are uploaded once here.
+ * All windows of a job run through the same batched launches. */
+int gauss_job_create(gauss_ctx* ctx, const gauss_window_desc* wins, int n_win, int on_device,
+                     gauss_job** out_job);
+/* Enqueue one full pass (pack -> Gram -> LD epilogue -> factor -> solve) on the job's stream. */
+int gauss_job_run(gauss_job* job);
+/* Wait for the last run and copy z / info / status (and optional b11/b21) to the host pointers
+ * of each window descriptor. */
+int gauss_job_fetch(gauss_job* job);
+void gauss_job_destroy(gauss_job* job);
+
+/* Profiling hooks for bench.py: HIP events are recorded around every launch of the Gram kernel
+ * on the job's own stream while enabled. */
+int gauss_job_profile(gauss_job* job, int enable);
+/* kernel 0 = gram (LD GEMM), 1 = pack/stats, 2 = LD epilogue, 3 = factor, 4 = solve.
+ * Returns accumulated milliseconds and launch count since profiling was enabled. */
+int gauss_job_profile_get(gauss_job* job, int kernel, double* out_ms, int64_t* out_launches);
+/* Algorithmic work of one run of the job (SURVEY.md section 8d definitions). */
+int gauss_job_work(gauss_job* job, double* out_ld_flops, double* out_solve_flops,
+                   double* out_bytes, int64_t* out_imputed_snps);
+
+/* Synthetic genotype generator on the device (bench plumbing; mirrors gauss_amd/synth.py's
+ * model with a counter-based RNG).  Writes n_snp rows of n_samples bytes {0,1,2} at d_out with
+ * row stride ld.  thr is a host array [n_snp x n_pop] of per-population latent thresholds,
+ * rho a host array [n_snp] of AR(1) coefficients. */
+int gauss_synth_device(gauss_ctx* ctx, uint8_t* d_out, int n_snp, int64_t ld,
+                       const int32_t* pop_off, int n_pop, const float* thr, const float* rho,
+                       uint64_t seed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GAUSS_HIP_H */

@@ -1,0 +1,99 @@
+"""Independent numpy/scipy (LAPACK) cross-implementation of the oracle -- test infrastructure only.
+
+Written in *Gram form* (matrix products, ``eigh``, ``inv``, ``scipy.stats``), i.e. deliberately
+NOT loop-literal, so that agreement with ``gauss_oracle.c`` (loop-literal, hand-written eigen/LU)
+checks both the restatement and its dense helpers.  Reference lines: util.cpp:49-70, 103-124,
+298-318; dist.cpp:156-202; distmix.cpp:165-228; computeLD.cpp:95-116; gene.cpp:288-550.
+"""
+import numpy as np
+from scipy import stats
+
+
+def _num(g):
+    g = np.asarray(g)
+    if g.dtype == np.uint8 and g.size and g.max() >= 48:
+        g = g - 48
+    return g.astype(np.float64)
+
+
+def pooled_cor(ga, gb=None):
+    """Pearson r over all columns (CalCor util.cpp:49-70), Gram form. Returns (Sa, Sb)."""
+    a = _num(ga)
+    b = a if gb is None else _num(gb)
+    n = a.shape[1]
+    sxy = a @ b.T
+    sa, sb = a.sum(1), b.sum(1)
+    saa, sbb = (a * a).sum(1), (b * b).sum(1)
+    numer = n * sxy - np.outer(sa, sb)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        denor = np.outer(np.sqrt(n * saa - sa * sa), np.sqrt(n * sbb - sb * sb))
+        return numer / denor
+
+
+def weighted_cov(ga, gb, pop_off, w):
+    """CalWgtCov (util.cpp:103-124) for all pairs, Gram form."""
+    a = _num(ga)
+    b = a if gb is None else _num(gb)
+    cov = np.zeros((a.shape[0], b.shape[0]))
+    wmi = np.zeros(a.shape[0])
+    wmj = np.zeros(b.shape[0])
+    for p in range(len(pop_off) - 1):
+        c0, c1 = pop_off[p], pop_off[p + 1]
+        m = c1 - c0
+        ap, bp = a[:, c0:c1], b[:, c0:c1]
+        sx, sy = ap.sum(1), bp.sum(1)
+        sxy = ap @ bp.T
+        cov += w[p] * (m / (m - 1.0)) * (m * sxy - np.outer(sx, sy))
+        cov += w[p] * np.outer(sx / m, sy / m)
+        wmi += w[p] * sx / m
+        wmj += w[p] * sy / m
+    return cov - np.outer(wmi, wmj)
+
+
+def weighted_cor(ga, gb, pop_off, w):
+    cov = weighted_cov(ga, gb, pop_off, w)
+    a = _num(ga)
+    b = a if gb is None else _num(gb)
+    va = np.array([weighted_cov(a[i:i + 1], None, pop_off, w)[0, 0] for i in range(a.shape[0])])
+    vb = va if gb is None else np.array(
+        [weighted_cov(b[i:i + 1], None, pop_off, w)[0, 0] for i in range(b.shape[0])])
+    with np.errstate(invalid="ignore", divide="ignore"):
+        return cov / np.outer(np.sqrt(va), np.sqrt(vb))
+
+
+def compute_ld(g, pop_off, w):
+    r = weighted_cor(g, None, pop_off, w)
+    np.fill_diagonal(r, 1.0)
+    return r
+
+
+def make_pos_def(a, min_abs_eig=1e-5):
+    vals, vecs = np.linalg.eigh(a)
+    if vals.min() < min_abs_eig:
+        vals = np.maximum(vals, min_abs_eig)
+        return (vecs * vals) @ vecs.T, 1
+    return a, 0
+
+
+def run_impute(mode, gm, gu, pop_off, w, z1, lam=0.1, min_abs_eig=1e-5):
+    if mode == 0:
+        b11 = pooled_cor(gm)
+        b21 = pooled_cor(gu, gm)
+    else:
+        b11 = weighted_cor(gm, None, pop_off, w)
+        b21 = weighted_cor(gu, gm, pop_off, w)
+    np.fill_diagonal(b11, 1.0 + lam)
+    b11, mpd = make_pos_def(b11, min_abs_eig)
+    inv = np.linalg.inv(b11)
+    y = b21 @ inv
+    z = y @ np.asarray(z1, dtype=np.float64)
+    info = np.abs(np.einsum("ij,ij->i", y, b21))
+    return dict(z=z / np.sqrt(info), info=info, mpd=mpd, b11=b11, b21=b21)
+
+
+def pnorm_upper(x):
+    return stats.norm.sf(x)
+
+
+def pchisq_upper(x, df):
+    return stats.chi2.sf(x, df)

@@ -1,0 +1,44 @@
+"""CPU suite: the C-ABI library loads and exports every symbol include/gauss_hip.h declares.
+No compute calls here (there is no GPU in the CPU test environment)."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "gauss_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(gauss_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_header_symbols_are_all_bound_and_exported():
+    from gauss_amd import _lib, build
+    build.build_hip()
+    lib = _lib.load()
+    declared = _declared_symbols()
+    assert len(declared) >= 14
+    assert sorted(_lib.SYMBOLS) == declared
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert b"gfx950" in lib.gauss_hip_version()
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from gauss_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", os.path.join(ROOT, "gauss_amd", "lib", "nope.so"))
+    with pytest.raises(_lib.GaussHipError):
+        _lib.load()
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "gauss_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text, f
+                assert "liboracle" not in text, f

@@ -1,0 +1,181 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Bars (BASELINE.json north_star): integer Gram counts bit-exact; LD values, z and info within
+1e-5 relative of the fp64 reference path.  The tolerances asserted here are far tighter because
+the design keeps the integer part exact and does every floating-point tail in fp64.
+"""
+import numpy as np
+import pytest
+
+import oracle
+from gauss_amd import hotpath
+from helpers import relerr, small_panel, split_window
+
+pytestmark = pytest.mark.gpu
+
+LD_TOL = 1e-12      # LD entries: reference operation order in fp64 -> expected bit-exact
+Z_TOL = 1e-8        # z / info: Cholesky vs the reference's LU inverse, both fp64
+
+
+def test_gram_counts_bit_exact(ctx):
+    p = small_panel(n_snp=150, scale=0.03)
+    G = p["G"]
+    got = hotpath.gram_counts(G, ctx=ctx)
+    want = oracle.gram_counts(G)
+    assert got.dtype == np.int64
+    assert np.array_equal(got, want)
+
+
+def test_gram_counts_ascii_and_ragged_stride(ctx):
+    p = small_panel(n_snp=40, scale=0.01, n_pops=5)
+    G = p["G"]
+    S, N = G.shape
+    buf = np.zeros((S, N + 13), dtype=np.uint8)       # row stride != N, N not a multiple of 64
+    buf[:, :N] = G + ord("0")                           # ASCII digits as the reference stores them
+    got = hotpath.gram_counts(buf[:, :N], ctx=ctx)
+    assert np.array_equal(got, oracle.gram_counts(G))
+
+
+def test_compute_ld_weighted_matches_oracle(ctx):
+    p = small_panel(n_snp=140, scale=0.02)
+    got = hotpath.ld_matrix(p["G"], p["off"], p["w"], mode=hotpath.MODE_WEIGHTED, diag=1.0, ctx=ctx)
+    want = oracle.compute_ld(p["G"], p["off"], p["w"])
+    assert np.allclose(got, got.T, rtol=0, atol=0)
+    assert np.all(np.diag(got) == 1.0)
+    assert np.max(np.abs(got - want)) <= LD_TOL
+    # the fp64 tails follow the reference's operation order: expect identical bits
+    assert np.mean(got == want) > 0.999
+
+
+def test_ld_pooled_matches_oracle(ctx):
+    p = small_panel(n_snp=90, scale=0.02, n_pops=6)
+    got = hotpath.ld_matrix(p["G"], p["off"], None, mode=hotpath.MODE_POOLED, diag=1.1, ctx=ctx)
+    want = oracle.ld_pooled(p["G"], p["off"], 1.1)
+    assert np.max(np.abs(got - want)) <= LD_TOL
+    assert np.mean(got == want) > 0.999
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("shape", [(11, 11), (60, 90), (150, 170)])
+def test_impute_window_matches_oracle(ctx, mode, shape):
+    M, U = shape
+    p = small_panel(n_snp=M + U + 30, scale=0.02, seed=11 + M)
+    G = p["G"][: M + U]
+    gm, gu, z1 = split_window(dict(G=G), M)
+    got = hotpath.impute_window(mode, gm, gu, p["off"], p["w"], z1, want_mats=True, ctx=ctx)
+    want = oracle.run_impute(mode, gm, gu, p["off"], p["w"], z1, want_mats=True)
+    assert want["mpd"] == 0 and got["status"] == 0
+    assert np.max(np.abs(got["b11"] - want["b11"])) <= LD_TOL
+    assert np.max(np.abs(got["b21"] - want["b21"])) <= LD_TOL
+    assert relerr(got["info"], want["info"]) <= Z_TOL
+    assert np.max(np.abs(got["z"] - want["z"]) / np.maximum(1.0, np.abs(want["z"]))) <= Z_TOL
+
+
+def test_segmented_population_over_2048_samples(ctx):
+    # one population larger than SEG_MAX forces several K segments per population
+    from gauss_amd import synth
+    pops = [("AAA", 2500, "X"), ("BBB", 70, "X"), ("CCC", 1, "Y"), ("DDD", 333, "Y")]
+    rng = np.random.default_rng(5)
+    bp = np.sort(rng.choice(np.arange(1, 200000), size=48, replace=False))
+    G, _ = synth.synth_genotypes(bp, pops, seed=9)
+    G = G[G.min(1) != G.max(1)]
+    off = synth.pop_offsets([q[1] for q in pops])
+    assert np.array_equal(hotpath.gram_counts(G, ctx=ctx), oracle.gram_counts(G))
+    # a population of one sample makes the reference's m/(m-1) infinite: reproduce, do not "fix"
+    w = np.array([0.5, 0.2, 0.0, 0.3])
+    got = hotpath.ld_matrix(G, off, w, ctx=ctx)
+    want = oracle.compute_ld(G, off, w)
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    pops3 = [pops[0], pops[1], pops[3]]
+    keep = np.r_[0:2570, 2571:2904]
+    G3 = np.ascontiguousarray(G[:, keep])
+    off3 = synth.pop_offsets([q[1] for q in pops3])
+    w3 = np.array([0.5, 0.2, 0.3])
+    got = hotpath.ld_matrix(G3, off3, w3, ctx=ctx)
+    want = oracle.compute_ld(G3, off3, w3)
+    assert np.max(np.abs(got - want)) <= LD_TOL
+
+
+def test_heterozygous_only_snp_gives_nan_like_reference(ctx):
+    # a SNP whose genotypes are all '1' passes the AF filter (af = 0.5) but has zero variance:
+    # the reference's CalCor returns 0/0 and every output of the window becomes NaN.
+    p = small_panel(n_snp=60, scale=0.01, n_pops=4)
+    gm, gu, z1 = split_window(p, 25)
+    gm = gm.copy()
+    gm[3, :] = 1
+    got = hotpath.impute_window(0, gm, gu, p["off"], None, z1, ctx=ctx)
+    want = oracle.run_impute(0, gm, gu, p["off"], None, z1)
+    assert np.all(np.isnan(want["z"]))
+    assert np.all(np.isnan(got["z"])) and np.all(np.isnan(got["info"]))
+    assert got["status"] & 2
+
+
+def test_makeposdef_clamp_path(ctx):
+    # duplicated measured SNPs with lambda = 0 make B11 singular: MakePosDef (util.cpp:310-317)
+    # lifts the zero eigenvalues to 1e-5.  The GPU detects this through the shifted factorisation
+    # and clamps the spectrum on the device.
+    p = small_panel(n_snp=70, scale=0.02, n_pops=6, seed=21)
+    gm, gu, z1 = split_window(p, 30)
+    gm = np.ascontiguousarray(np.vstack([gm, gm[:3]]))
+    z1 = np.concatenate([z1, z1[:3]])
+    got = hotpath.impute_window(0, gm, gu, p["off"], None, z1, lam=0.0, want_mats=True, ctx=ctx)
+    want = oracle.run_impute(0, gm, gu, p["off"], None, z1, lam=0.0, want_mats=True)
+    assert want["mpd"] == 1
+    assert got["status"] & 1
+    assert np.max(np.abs(got["b11"] - want["b11"])) <= 1e-9
+    assert relerr(got["info"], want["info"]) <= 1e-5
+    assert np.max(np.abs(got["z"] - want["z"]) / np.maximum(1.0, np.abs(want["z"]))) <= 1e-5
+
+
+def test_gene_ld_batch(ctx):
+    p = small_panel(n_snp=330, scale=0.01, n_pops=8, seed=4)
+    G = p["G"]
+    S = G.shape[0]
+    rng = np.random.default_rng(8)
+    cuts = np.sort(rng.choice(np.arange(1, S), size=40, replace=False))
+    gene_off = np.r_[0, cuts, S].astype(np.int32)          # includes genes straddling tile edges
+    for mode, w, fn in ((0, None, lambda g: oracle.ld_pooled(g, p["off"], 1.1)),
+                        (1, p["w"], None)):
+        blocks = hotpath.gene_ld_batch(G, p["off"], gene_off, pop_wgt=w, mode=mode, diag=1.1, ctx=ctx)
+        assert len(blocks) == len(gene_off) - 1
+        for g, blk in enumerate(blocks):
+            rows = G[gene_off[g]:gene_off[g + 1]]
+            if mode == 0:
+                want = fn(rows)
+            else:
+                want = oracle.compute_ld(rows, p["off"], p["w"])
+                np.fill_diagonal(want, 1.1)
+            assert blk.shape == want.shape
+            assert np.max(np.abs(blk - want)) <= LD_TOL
+
+
+def test_job_batches_heterogeneous_windows(ctx):
+    p = small_panel(n_snp=260, scale=0.02, seed=31)
+    wins, wants = [], []
+    for k, (mode, M, U) in enumerate([(0, 40, 55), (1, 130, 20), (1, 12, 140), (0, 75, 75)]):
+        G = p["G"][k * 5: k * 5 + M + U]
+        gm, gu, z1 = split_window(dict(G=G), M, seed=k)
+        wins.append(dict(mode=mode, geno_m=gm, geno_u=gu, pop_off=p["off"], pop_wgt=p["w"], z1=z1))
+        wants.append(oracle.run_impute(mode, gm, gu, p["off"], p["w"], z1))
+    job = hotpath.Job(wins, ctx=ctx)
+    for _ in range(2):                                     # a job can be re-run (bench does)
+        job.run()
+        res = job.fetch()
+    for got, want in zip(res, wants):
+        assert got["status"] == 0
+        assert relerr(got["info"], want["info"]) <= Z_TOL
+        assert np.max(np.abs(got["z"] - want["z"]) / np.maximum(1.0, np.abs(want["z"]))) <= Z_TOL
+    work = job.work()
+    assert work["imputed_snps"] == 55 + 20 + 140 + 75
+    job.close()
+
+
+def test_invalid_arguments_are_reported(ctx):
+    p = small_panel(n_snp=30, scale=0.01, n_pops=3)
+    with pytest.raises(Exception) as ei:
+        hotpath.ld_matrix(p["G"], p["off"], None, mode=hotpath.MODE_WEIGHTED, ctx=ctx)
+    assert "pop_wgt" in str(ei.value)
+    bad = p["off"].copy()
+    bad[1] = bad[2] + 5
+    with pytest.raises(Exception):
+        hotpath.ld_matrix(p["G"], bad, p["w"], ctx=ctx)

@@ -1,0 +1,156 @@
+"""CPU suite: the C oracle against the independent numpy/scipy implementation + invariants.
+
+The reference ships no tests or golden vectors for this path, so the oracle is
+cross-validated here and then frozen into tests/golden/ (see tests/golden/make_golden.py).
+"""
+import numpy as np
+import pytest
+from scipy import stats
+
+import oracle
+from oracle import oracle_np as onp
+from helpers import relerr, small_panel, split_window
+
+
+def test_calcor_and_calwgtcov_match_gram_form():
+    p = small_panel(n_snp=50, scale=0.01, n_pops=7)
+    G, off, w = p["G"], p["off"], p["w"]
+    r = onp.pooled_cor(G)
+    c = onp.weighted_cov(G, None, off, w)
+    for i, j in [(0, 1), (3, 17), (20, 20), (41, 2)]:
+        assert abs(oracle.calcor(G[i], G[j], off) - r[i, j]) <= 1e-14
+        assert abs(oracle.calwgtcov(G[i], G[j], off, w) - c[i, j]) <= 1e-12 * max(1.0, abs(c[i, j]))
+
+
+def test_compute_ld_invariants_and_cross_check():
+    p = small_panel(n_snp=70, scale=0.02)
+    ld = oracle.compute_ld(p["G"], p["off"], p["w"])
+    assert np.array_equal(ld, ld.T)
+    assert np.all(np.diag(ld) == 1.0)
+    assert np.max(np.abs(ld - onp.compute_ld(p["G"], p["off"], p["w"]))) <= 1e-13
+    assert np.linalg.eigvalsh(ld).min() > -1e-8          # a correlation matrix
+
+
+def test_population_permutation_invariance():
+    # CalWgtCov sums over populations: permuting populations (with their weights) changes nothing
+    p = small_panel(n_snp=30, scale=0.02, n_pops=6)
+    G, off, w = p["G"], p["off"], p["w"]
+    perm = [3, 0, 5, 1, 4, 2]
+    cols = np.concatenate([np.arange(off[k], off[k + 1]) for k in perm])
+    sizes = [off[k + 1] - off[k] for k in perm]
+    off2 = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    a = oracle.compute_ld(G, off, w)
+    b = oracle.compute_ld(np.ascontiguousarray(G[:, cols]), off2, w[perm])
+    assert np.max(np.abs(a - b)) <= 1e-13
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_run_impute_c_vs_numpy(mode):
+    p = small_panel(n_snp=110, scale=0.02, seed=5)
+    gm, gu, z1 = split_window(p, 45)
+    a = oracle.run_impute(mode, gm, gu, p["off"], p["w"], z1, want_mats=True)
+    b = onp.run_impute(mode, gm, gu, p["off"], p["w"], z1)
+    assert a["mpd"] == b["mpd"] == 0
+    assert np.max(np.abs(a["b11"] - b["b11"])) <= 1e-13
+    assert relerr(a["info"], b["info"]) <= 1e-10
+    assert np.max(np.abs(a["z"] - b["z"])) <= 1e-10
+    assert np.all(a["info"] > 0) and np.all(a["info"] < 1.0 + 1e-9)
+
+
+def test_allele_flip_flips_imputed_z():
+    # recoding an unmeasured SNP 0<->2 negates its correlations, hence its imputed z; info unchanged
+    p = small_panel(n_snp=60, scale=0.02, n_pops=5)
+    gm, gu, z1 = split_window(p, 25)
+    a = oracle.run_impute(0, gm, gu, p["off"], None, z1)
+    gu2 = gu.copy()
+    gu2[4] = 2 - gu2[4]
+    b = oracle.run_impute(0, gm, gu2, p["off"], None, z1)
+    assert abs(a["z"][4] + b["z"][4]) <= 1e-10 and abs(a["info"][4] - b["info"][4]) <= 1e-12
+    assert np.max(np.abs(np.delete(a["z"], 4) - np.delete(b["z"], 4))) == 0.0
+
+
+def test_make_pos_def_and_inverse():
+    rng = np.random.default_rng(0)
+    for n in (1, 2, 6, 37):
+        a = rng.standard_normal((n, n))
+        a = a @ a.T / n - 0.4 * np.eye(n)
+        got, rc = oracle.make_pos_def(a)
+        want, rc2 = onp.make_pos_def(a)
+        assert rc == rc2
+        assert np.max(np.abs(got - want)) <= 1e-12
+        b = want + 0.1 * np.eye(n)
+        assert np.max(np.abs(oracle.inv_mat(b) - np.linalg.inv(b))) <= 1e-10
+    a = np.eye(5) * 2.0
+    got, rc = oracle.make_pos_def(a)
+    assert rc == 0 and np.array_equal(got, a)            # untouched when already positive definite
+
+
+def test_tails_match_scipy():
+    for x in (0.0, 0.3, 1.96, 3.7785313, 6.5, 12.0):
+        assert abs(oracle.pnorm_upper(x) / stats.norm.sf(x) - 1) <= 1e-12
+        for df in range(1, 7):
+            want = stats.chi2.sf(x, df)
+            assert abs(oracle.pchisq_upper(x, df) - want) <= 1e-13 * max(want, 1e-300) + 1e-300
+    assert abs(oracle.pchisq_upper(38.41841, 1) / stats.chi2.sf(38.41841, 1) - 1) <= 1e-10
+
+
+def _jepeg_tail_np(corg, z, info, has, wgt, min_abs_eig=1e-5, cutoff=0.8, denorm=3):
+    """Independent numpy restatement of gene.cpp:317-550 for the cross-check."""
+    cats = [c for c in range(6) if has[:, c].any()]
+    k = len(cats)
+    W = (wgt[:, cats] * np.sqrt(info)[:, None]).T
+    WWt = W @ W.T
+    CovU = W @ corg @ W.T
+    d = np.sqrt(np.diag(CovU))
+    CorU = CovU / np.outer(d, d)
+    U = W @ z
+    pvals = 2 * stats.norm.sf(np.abs(U / d))
+    rmv = np.zeros(k, dtype=bool)
+    for j in range(k - 1, 0, -1):
+        if np.any(np.abs(CorU[:j, j]) > cutoff):
+            rmv[j] = True
+    rmv |= np.diag(CovU) < np.diag(WWt) / denorm
+    df = int(k - rmv.sum())
+    out = dict(df=df, chisq=-1.0, jepeg_pval=-1.0)
+    if df:
+        X = U[~rmv]
+        CovX, _ = onp.make_pos_def(CovU[np.ix_(~rmv, ~rmv)], min_abs_eig)
+        out["chisq"] = float(X @ np.linalg.inv(CovX) @ X)
+        out["jepeg_pval"] = float(stats.chi2.sf(out["chisq"], df))
+        top = 0
+        for i in range(k):
+            if pvals[top] > pvals[i] and not rmv[i]:
+                top = i
+        out["top_categ"] = cats[top]
+        out["top_categ_pval"] = float(pvals[top])
+        out["top_snp"] = int(np.argmax(np.abs(z)))
+    return out
+
+
+def test_jepeg_gene_tail_c_vs_numpy():
+    rng = np.random.default_rng(3)
+    p = small_panel(n_snp=40, scale=0.02, n_pops=5)
+    for trial in range(20):
+        n = int(rng.integers(1, 12))
+        rows = p["G"][rng.choice(p["G"].shape[0], n, replace=False)]
+        corg = oracle.ld_pooled(rows, p["off"], 1.1)
+        z = rng.standard_normal(n) * 2
+        info = np.ones(n)
+        has = (rng.random((n, 6)) < 0.35).astype(np.int32)
+        has[rng.integers(0, n), rng.integers(0, 6)] = 1
+        wgt = np.where(has, rng.uniform(0.1, 2.0, (n, 6)), 0.0)
+        a = oracle.jepeg_gene_tail(corg, z, info, has, wgt)
+        b = _jepeg_tail_np(corg, z, info, has, wgt)
+        assert a["df"] == b["df"] and a["num_snp"] == n
+        if b["df"]:
+            assert abs(a["chisq"] - b["chisq"]) <= 1e-9 * max(1.0, abs(b["chisq"]))
+            assert abs(a["jepeg_pval"] - b["jepeg_pval"]) <= 1e-9 * b["jepeg_pval"] + 1e-300
+            assert a["top_categ"] == b["top_categ"] and a["top_snp"] == b["top_snp"]
+        else:
+            assert a["chisq"] == -1.0 and a["jepeg_pval"] == -1.0 and a["top_categ"] == -1
+
+
+def test_gram_counts_match_numpy():
+    p = small_panel(n_snp=25, scale=0.01, n_pops=4)
+    G = p["G"].astype(np.int64)
+    assert np.array_equal(oracle.gram_counts(p["G"]), G @ G.T)
