@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""bench.py -- imputed SNPs/sec of the DISTMIX hot path on synthetic chr22-scale input.
+
+One "step" = one full pass of the hot path (pack/stats -> fp32-MFMA LD Gram -> fp64 LD epilogue
+-> Cholesky -> solve) over every 1 Mb window of one synthetic chromosome that is already
+resident in HBM (BASELINE.json configs[3]: distmix, PGC2 weights, ~100k SNPs x 32 147 samples,
+500 kb wings).  With N GPUs every rank owns one such chromosome (independent windows, no
+data-path collective): weak scaling, value = all ranks' imputed SNPs / max-over-ranks time.
+
+Prints ONE JSON line (rank 0).  Extra keys: "roofline" for the LD GEMM kernel (HIP events
+recorded by the library on its own stream around every launch) and "cpu_baseline" (the CPU
+oracle timed on a bounded sample and scaled to the workload's pair count).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+
+def make_chromosome(args, seed):
+    """Positions, measured mask, thresholds: host-side description of one synthetic chromosome."""
+    from scipy.stats import norm
+    from gauss_amd import synth
+    rng = np.random.default_rng(seed)
+    pops = [p for p in synth.POPS_33KG if p[0] in synth.PGC2_WEIGHTS]      # 21 populations, N = 32 147
+    if args.sample_scale != 1.0:
+        pops = [(a, max(30, int(n * args.sample_scale)), s) for a, n, s in pops]
+    w = np.array([synth.PGC2_WEIGHTS[p[0]] for p in pops])
+    off = synth.pop_offsets([p[1] for p in pops])
+    lo, hi = 16_050_000, 51_210_000                                        # chr22 span of the PGC2 file
+    bp = np.sort(rng.choice(np.arange(lo, hi), size=args.snps, replace=False))
+    measured = np.zeros(args.snps, dtype=bool)
+    measured[rng.choice(args.snps, size=int(round(args.snps * 0.13362)), replace=False)] = True
+    # Balding-Nichols frequencies (as gauss_amd/synth.py), kept inside (0.02, 0.98)
+    p0 = rng.uniform(0.03, 0.5, args.snps)
+    p0 = np.where(rng.random(args.snps) < 0.5, 1 - p0, p0)
+    sups = sorted(set(p[2] for p in pops))
+
+    def bn(p, f):
+        return np.clip(rng.beta(p * (1 - f) / f, (1 - p) * (1 - f) / f), 0.02, 0.98)
+    psup = {s: bn(p0, 0.15) for s in sups}
+    ppop = np.stack([bn(psup[p[2]], 0.05) for p in pops], axis=1)
+    thr = norm.ppf(ppop).astype(np.float32)
+    rho = np.ones(args.snps, dtype=np.float32)
+    rho[1:] = np.exp(-np.diff(bp) / 50e3)
+    z = rng.standard_normal(args.snps) * 1.5
+    return dict(pops=pops, w=w, off=off, bp=bp, measured=measured, thr=thr, rho=rho, z=z)
+
+
+def windows_of(ch, args):
+    """1 Mb prediction windows with 500 kb wings (dist.cpp:135-139 membership rules)."""
+    bp, meas = ch["bp"], ch["measured"]
+    out = []
+    start = (int(bp[0]) // 1_000_000) * 1_000_000 + 1
+    while start <= bp[-1]:
+        end = start + 1_000_000 - 1
+        ext = (bp >= start - args.wing) & (bp <= end + args.wing)
+        pred = (bp >= start) & (bp <= end)
+        mi = np.nonzero(ext & meas)[0]
+        ui = np.nonzero(pred & ~meas)[0]
+        if len(mi) > 10 and len(ui) > 10:                                  # dist.cpp:145-146
+            out.append((mi, ui))
+        start += 1_000_000
+    if args.windows:
+        out = out[: args.windows]
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--snps", type=int, default=100_000)
+    ap.add_argument("--windows", type=int, default=0, help="limit the number of windows (0 = all)")
+    ap.add_argument("--wing", type=int, default=500_000)
+    ap.add_argument("--sample-scale", type=float, default=1.0, help="shrink every population (debug)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world)   # RCCL; used for timing barriers only
+
+    from gauss_amd import _lib, hotpath
+    ctx = hotpath.Context(local)
+    lib = ctx.lib
+
+    # ---- synthetic chromosome, generated straight into HBM --------------------------------
+    ch = make_chromosome(args, seed=20260213 + 3 + rank)
+    N = int(ch["off"][-1])
+    ld = (N + 63) // 64 * 64
+    panel = torch.empty((args.snps, ld), dtype=torch.uint8, device="cuda")
+    thr = np.ascontiguousarray(ch["thr"])
+    import ctypes as C
+    _lib.check(lib.gauss_synth_device(ctx.handle, panel.data_ptr(), args.snps, ld,
+                                      ch["off"].ctypes.data_as(C.POINTER(C.c_int32)), len(ch["pops"]),
+                                      thr.ctypes.data_as(C.POINTER(C.c_float)),
+                                      ch["rho"].ctypes.data_as(C.POINTER(C.c_float)),
+                                      C.c_uint64(20260213 + rank)))
+    wins = windows_of(ch, args)
+    keep, descs = [], []
+    for mi, ui in wins:
+        gm = panel.index_select(0, torch.from_numpy(mi).cuda())
+        gu = panel.index_select(0, torch.from_numpy(ui).cuda())
+        keep.append((gm, gu))
+        descs.append(dict(mode=hotpath.MODE_WEIGHTED, pop_off=ch["off"], pop_wgt=ch["w"], z1=ch["z"][mi],
+                          dev=(gm.data_ptr(), gu.data_ptr(), len(mi), len(ui), ld)))
+    torch.cuda.synchronize()
+    job = hotpath.Job(descs, ctx=ctx, on_device=True)
+    work = job.work()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        job.run()
+        return job.fetch()
+
+    for _ in range(args.warmup):
+        step()
+    job.profile(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    gram_ms, gram_n = job.profile_get(0)
+    stage_ms = {k: job.profile_get(i)[0] / max(1, args.steps) for i, k in
+                enumerate(["gram", "pack_stats", "ld_epilogue", "factor", "solve"])}
+    job.profile(False)
+
+    bad = sum(int(r["status"] != 0) for r in res)
+    finite = all(np.all(np.isfinite(r["z"])) and np.all(np.isfinite(r["info"])) for r in res)
+
+    tmax, snps = dt, float(work["imputed_snps"])
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        s = torch.tensor([snps], dtype=torch.float64, device="cuda")
+        dist.all_reduce(s, op=dist.ReduceOp.SUM)
+        tmax, snps = float(t.item()), float(s.item())
+
+    out = None
+    if rank == 0:
+        ms_per_step = tmax / args.steps * 1e3
+        avg_gram_s = gram_ms / max(1, gram_n) * 1e-3
+        achieved = work["ld_flops"] / avg_gram_s / 1e12 if avg_gram_s > 0 else 0.0
+        out = {
+            "metric": "imputed SNPs/sec (whole node); LD-GEMM MFMA TFLOP/s vs peak",
+            "value": snps / (tmax / args.steps),
+            "unit": "imputed SNPs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 MFMA (exact integer Gram) + f64 epilogue/solve",
+            "data": "synthetic",
+            "config": {
+                "workload": "distmix() synthetic chr22-scale (BASELINE.json configs[3]): "
+                            f"{args.snps} SNPs x {N} samples (21 PGC2 populations), {len(wins)} windows of 1 Mb, "
+                            f"{args.wing // 1000} kb wings, one chromosome per GPU",
+                "windows_per_gpu": len(wins), "snps": args.snps, "samples": N,
+                "imputed_snps_per_gpu": int(work["imputed_snps"]),
+                "mean_measured": float(np.mean([len(m) for m, _ in wins])),
+                "mean_unmeasured": float(np.mean([len(u) for _, u in wins])),
+                "windows_flagged": bad, "all_finite": bool(finite),
+            },
+            "roofline": {
+                "kernel": "gram_kernel (LD GEMM, v_mfma_f32_32x32x2_f32)",
+                "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
+                "traffic": None,
+                "algorithmic_flops_per_launch": work["ld_flops"],
+                "avg_launch_ms": gram_ms / max(1, gram_n), "launches": int(gram_n),
+            },
+            "stage_ms_per_step": stage_ms,
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(ch, wins, keep, work)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    job.close()
+    return out
+
+
+def cpu_baseline(ch, wins, keep, work):
+    """The loop-literal CPU oracle (1 thread, like the reference) on a bounded sample, scaled to
+    the workload by its pair count: the reference's cost is N inner iterations per SNP pair
+    (util.cpp:103-124), M(M+1)/2 + U + U*M pairs per window (distmix.cpp:180-217)."""
+    import oracle
+    ms_, us_ = 176, 176
+    gm, gu = keep[0]
+    mi, ui = wins[0]
+    N = int(ch["off"][-1])
+    gm_h = np.ascontiguousarray(gm[:ms_, :N].cpu().numpy())
+    gu_h = np.ascontiguousarray(gu[:us_, :N].cpu().numpy())
+    z1 = ch["z"][mi][:ms_]
+    t0 = time.perf_counter()
+    oracle.run_impute(1, gm_h, gu_h, ch["off"], ch["w"], z1)
+    t = time.perf_counter() - t0
+    m, u = gm_h.shape[0], gu_h.shape[0]
+    pairs_sample = m * (m + 1) / 2 + u + u * m
+    pairs_total = sum(len(a) * (len(a) + 1) / 2 + len(b) + len(a) * len(b) for a, b in wins)
+    est = t * pairs_total / pairs_sample
+    return {
+        "value": work["imputed_snps"] / est, "unit": "imputed SNPs/s", "cores": 1, "kind": "port",
+        "host_cores": os.cpu_count(),
+        "sample": f"oracle run_distmix on a sub-window of window 0 (M={m}, U={u}, N={N}): {t:.2f} s for "
+                  f"{pairs_sample:.0f} SNP pairs; scaled by the workload's {pairs_total:.3g} pairs "
+                  f"(estimated {est:.0f} s per chromosome, dense tail of the full-size windows not included)",
+    }
+
+
+if __name__ == "__main__":
+    main()
