@@ -211,7 +211,7 @@ def cpu_baseline(ch, wins, keep, work):
     the workload by its pair count: the reference's cost is N inner iterations per SNP pair
     (util.cpp:103-124), M(M+1)/2 + U + U*M pairs per window (distmix.cpp:180-217)."""
     import oracle
-    ms_, us_ = 176, 176
+    ms_, us_ = 600, 600
     gm, gu = keep[0]
     mi, ui = wins[0]
     N = int(ch["off"][-1])

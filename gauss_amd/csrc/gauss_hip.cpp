@@ -55,7 +55,7 @@ struct Plan {
     Prob p;                                  // device descriptor (pointers filled at layout time)
     std::vector<int> pop_raw_off, pop_pk_off, seg_pop, seg_k0, seg_k1, pop_seg0;
     std::vector<int> pair_ti, pair_tj, pair_lut;
-    std::vector<double> pop_w, z1;
+    std::vector<double> pop_w, pop_wf, pop_md, z1;
     std::vector<uint8_t> word_pop;
     std::vector<int> gene_off;
     std::vector<long long> gene_out_off;
@@ -119,7 +119,13 @@ struct WinSpec {
     int n_gene;
 };
 
-static int plan_problem(const WinSpec& w, Plan& pl)
+// K segment length: short segments give a single window enough work items to fill 256 CUs;
+// a batch of windows has plenty of items already, and longer segments mean fewer partial slabs
+// for the epilogue to read back.  Either way a partial sum stays an exact f32 integer
+// (15 * 15 * 8192 < 2^24).
+static int seg_max_for(size_t n_windows) { return n_windows >= 4 ? 8192 : SEG_MAX; }
+
+static int plan_problem(const WinSpec& w, Plan& pl, int seg_max)
 {
     if (w.mode != GAUSS_MODE_POOLED && w.mode != GAUSS_MODE_WEIGHTED) return fail(GAUSS_E_INVALID, "bad mode %d", w.mode);
     if (w.n_pop < 1 || w.n_pop > 64) return fail(GAUSS_E_INVALID, "n_pop must be in 1..64 (got %d)", w.n_pop);
@@ -154,6 +160,12 @@ static int plan_problem(const WinSpec& w, Plan& pl)
         pl.pop_w.assign(w.pop_wgt, w.pop_wgt + w.n_pop);
     }
     const int P = p.P;
+    for (int q = 0; q < P; q++) {
+        const int m = pl.pop_raw_off[q + 1] - pl.pop_raw_off[q];
+        const double factor = ((double)m) / (m - 1);           // util.cpp:117 (inf for m == 1, like the reference)
+        pl.pop_wf.push_back(pl.pop_w[q] * factor);             // util.cpp:118: wgt_val*factor*(...) groups left to right
+        pl.pop_md.push_back((double)m);
+    }
     pl.pop_pk_off.assign(P + 1, 0);
     for (int q = 0; q < P; q++) {
         const int m = pl.pop_raw_off[q + 1] - pl.pop_raw_off[q];
@@ -167,7 +179,7 @@ static int plan_problem(const WinSpec& w, Plan& pl)
         const int chunks = (pl.pop_pk_off[q + 1] - pl.pop_pk_off[q]) / KC;
         pl.pop_seg0[q] = (int)pl.seg_pop.size();
         if (chunks > 0) {
-            const int max_chunks = SEG_MAX / KC;
+            const int max_chunks = seg_max / KC;
             const int ns = (chunks + max_chunks - 1) / max_chunks;
             const int per = (chunks + ns - 1) / ns;
             for (int c = 0; c < chunks; c += per) {
@@ -249,7 +261,7 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
     job->on_device = on_device;
     job->plans.resize(job->n);
     for (int i = 0; i < job->n; i++) {
-        int rc = plan_problem(specs[i], job->plans[i]);
+        int rc = plan_problem(specs[i], job->plans[i], seg_max_for(specs.size()));
         if (rc) { delete job; return rc; }
     }
     HIPCHK(hipSetDevice(ctx->device));
@@ -257,13 +269,15 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
     // ---- table arena (host mirrored) ----
     Arena ta;
     std::vector<char>& blob = job->h_tab;
-    struct TabOff { size_t raw_off, pk_off, w, seg_pop, k0, k1, seg0, ti, tj, lut, wp, z1, goff, gout; };
+    struct TabOff { size_t raw_off, pk_off, w, wf, md, seg_pop, k0, k1, seg0, ti, tj, lut, wp, z1, goff, gout; };
     std::vector<TabOff> to(job->n);
     for (int i = 0; i < job->n; i++) {
         Plan& pl = job->plans[i];
         to[i].raw_off = put(blob, ta, pl.pop_raw_off);
         to[i].pk_off = put(blob, ta, pl.pop_pk_off);
         to[i].w = put(blob, ta, pl.pop_w);
+        to[i].wf = put(blob, ta, pl.pop_wf);
+        to[i].md = put(blob, ta, pl.pop_md);
         to[i].seg_pop = put(blob, ta, pl.seg_pop);
         to[i].k0 = put(blob, ta, pl.seg_k0);
         to[i].k1 = put(blob, ta, pl.seg_k1);
@@ -370,6 +384,8 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
         p.pop_raw_off = (const int*)(T + to[i].raw_off);
         p.pop_pk_off = (const int*)(T + to[i].pk_off);
         p.pop_w = (const double*)(T + to[i].w);
+        p.pop_wf = (const double*)(T + to[i].wf);
+        p.pop_md = (const double*)(T + to[i].md);
         p.seg_pop = (const int*)(T + to[i].seg_pop);
         p.seg_k0 = (const int*)(T + to[i].k0);
         p.seg_k1 = (const int*)(T + to[i].k1);

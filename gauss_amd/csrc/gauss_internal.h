@@ -44,6 +44,8 @@ struct Prob {
     GP(const int) pop_raw_off; // [P+1]
     GP(const int) pop_pk_off;  // [P+1] packed column offsets (multiples of KC)
     GP(const double) pop_w;    // [P]
+    GP(const double) pop_wf;   // [P] wgt_val * ((double)m / (m - 1))   (util.cpp:117-118)
+    GP(const double) pop_md;   // [P] (double)m
     GP(const int) seg_pop;     // [nseg]
     GP(const int) seg_k0;      // [nseg] packed byte range
     GP(const int) seg_k1;

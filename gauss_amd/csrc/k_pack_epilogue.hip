@@ -157,10 +157,9 @@ __device__ __forceinline__ double cor_entry(const Prob& pb, const float* __restr
         double sumxy = 0;
         for (int s = pb.pop_seg0[p]; s < pb.pop_seg0[p + 1]; s++)
             sumxy += (double)tile_slab[s * seg_stride + off];
-        const int m = pb.pop_raw_off[p + 1] - pb.pop_raw_off[p];
-        const double factor = ((double)m) / (m - 1);                               // util.cpp:117
         const double sumx = (double)sxi[p], sumy = (double)sxj[p];
-        wsumcov += pb.pop_w[p] * factor * (m * sumxy - sumx * sumy);               // util.cpp:118
+        // pop_wf = wgt_val * factor, factor = (double)m/(m-1) (util.cpp:117), pop_md = (double)m
+        wsumcov += pb.pop_wf[p] * (pb.pop_md[p] * sumxy - sumx * sumy);            // util.cpp:118
         wsum_mi_mj += wmui[p] * muj[p];                                            // util.cpp:119
     }
     const double cov = wsumcov + wsum_mi_mj - pb.rt_wm[ri] * pb.rt_wm[rj];        // util.cpp:123
@@ -173,50 +172,142 @@ __device__ __forceinline__ double cor_entry(const Prob& pb, const float* __restr
 //   - A[0] = B11 (diag 1+lambda), A[1] = B11 - eps*I, both row-major Mld x Mld, identity padded
 //   - B21 (U x Mld row-major), zero padded
 // or, for LD-only problems, into out_ld (S x S, diag = pb.diag).
+// HBM-bound: it reads every partial once (nseg floats per entry) and writes one double.
+// Thread t owns column jj = t & 127 and rows ii = (t >> 7) + 2r: a wave reads 64 consecutive
+// floats of a partial row (coalesced).  The per-population row/column tables of the tile live
+// in LDS; rows are handled four at a time to keep several partial loads in flight.
 // ------------------------------------------------------------------------------------------
+constexpr int EPI_MAXP = 32;     // LDS table capacity (33KG has 29 populations); beyond: global tables
+
+struct EpiOut { double v0, v1; };
+
 __global__ __launch_bounds__(256) void epilogue_kernel(const Prob* __restrict__ probs,
                                                        const int2* __restrict__ tilemap)
 {
+    extern __shared__ __attribute__((aligned(16))) char esm[];
     const int2 tm = tilemap[blockIdx.x];
     const Prob& pb = probs[tm.x];
     const int pair = tm.y;
     const int ti = pb.pair_ti[pair], tj = pb.pair_tj[pair];
-    const float* tile_slab = pb.slab + (size_t)pair * pb.nseg * TILE * TILE;
+    const int P = pb.P, nseg = pb.nseg;
+    const auto tile_slab = pb.slab + (size_t)pair * nseg * TILE * TILE;
+    const size_t seg_stride = (size_t)TILE * TILE;
     const int mt = pb.Mp / TILE;        // number of measured row tiles
     const bool sym = (ti < mt);         // measured x measured tile (ti <= tj < mt)
     const int Mld = pb.Mld;
-    for (int e = threadIdx.x; e < TILE * TILE; e += 256) {
-        const int ii = e / TILE, jj = e % TILE;
-        const int ri = ti * TILE + ii, rj = tj * TILE + jj;   // packed row indices
-        if (sym) {
-            if (ri > rj) continue;                            // mirror handles the lower part
-            if (pb.ld_only) {
-                if (ri >= pb.M || rj >= pb.M) continue;
-                double v = (ri == rj) ? pb.diag : cor_entry(pb, tile_slab, e, ri, rj);
-                pb.out_ld[(size_t)ri * pb.M + rj] = v;
-                pb.out_ld[(size_t)rj * pb.M + ri] = v;
-                continue;
+    const int tid = threadIdx.x;
+    const bool weighted = pb.mode != 0;
+    const bool lds_tables = weighted && P <= EPI_MAXP;
+
+    double* s_wmui = reinterpret_cast<double*>(esm);          // [P][128]  w_p * mu_p(row i)
+    double* s_muj = s_wmui + EPI_MAXP * TILE;                 // [P][128]  mu_p(col j)
+    int* s_sxi = reinterpret_cast<int*>(s_muj + EPI_MAXP * TILE);   // [P][128]
+    int* s_sxj = s_sxi + EPI_MAXP * TILE;                     // [P][128]
+    if (lds_tables) {
+        for (int idx = tid; idx < P * TILE; idx += 256) {
+            const int r = idx / P, p = idx % P;               // consecutive threads: consecutive p of a row
+            s_wmui[p * TILE + r] = pb.rt_wmu[(size_t)(ti * TILE + r) * P + p];
+            s_sxi[p * TILE + r] = pb.sx[(size_t)(ti * TILE + r) * P + p];
+            s_muj[p * TILE + r] = pb.rt_mu[(size_t)(tj * TILE + r) * P + p];
+            s_sxj[p * TILE + r] = pb.sx[(size_t)(tj * TILE + r) * P + p];
+        }
+        __syncthreads();
+    }
+
+    const int jj = tid & (TILE - 1), half = tid >> 7;
+    const int rj = tj * TILE + jj;
+    const double sd_j = pb.rt_sd[rj], wm_j = pb.rt_wm[rj];
+    const int num_samples = pb.N;
+
+    for (int r4 = 0; r4 < TILE / 8; r4++) {
+        double cov[4];
+        int rows[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) rows[q] = half + 2 * (4 * r4 + q);
+        if (!weighted) {
+            // CalCor tail (util.cpp:66-68): r = (n*sxy - sx*sy) / (sqrt(..x..) * sqrt(..y..))
+            double sumxy[4] = {0, 0, 0, 0};
+            for (int s = 0; s < nseg; s++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) sumxy[q] += (double)tile_slab[s * seg_stride + rows[q] * TILE + jj];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int ri = ti * TILE + rows[q];
+                const double numer = num_samples * sumxy[q] - pb.rt_wm[ri] * wm_j;
+                const double denor = pb.rt_sd[ri] * sd_j;
+                cov[q] = numer / denor;
             }
-            if (ri >= Mld || rj >= Mld) continue;
-            double v0, v1;
-            if (ri >= pb.M || rj >= pb.M) { v0 = v1 = (ri == rj) ? 1.0 : 0.0; }
-            else if (ri == rj) { v0 = 1.0 + pb.lambda; v1 = v0 - pb.eps; }   // dist.cpp:172
-            else { v0 = v1 = cor_entry(pb, tile_slab, e, ri, rj); }           // dist.cpp:174-177
-            double* A0 = pb.A;
-            double* A1 = pb.A + (size_t)Mld * Mld;
-            A0[(size_t)ri * Mld + rj] = v0; A0[(size_t)rj * Mld + ri] = v0;
-            A1[(size_t)ri * Mld + rj] = v1; A1[(size_t)rj * Mld + ri] = v1;
+        } else if (lds_tables) {
+            // CalWgtCov (util.cpp:103-124) in the reference's population order
+            double wsumcov[4] = {0, 0, 0, 0}, wmm[4] = {0, 0, 0, 0};
+            for (int p = 0; p < P; p++) {
+                double sumxy[4] = {0, 0, 0, 0};
+                for (int s = pb.pop_seg0[p]; s < pb.pop_seg0[p + 1]; s++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) sumxy[q] += (double)tile_slab[s * seg_stride + rows[q] * TILE + jj];
+                const double md = pb.pop_md[p], wf = pb.pop_wf[p];
+                const double sumy = (double)s_sxj[p * TILE + jj];
+                const double mu_y = s_muj[p * TILE + jj];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const double sumx = (double)s_sxi[p * TILE + rows[q]];
+                    wsumcov[q] += wf * (md * sumxy[q] - sumx * sumy);          // util.cpp:118
+                    wmm[q] += s_wmui[p * TILE + rows[q]] * mu_y;               // util.cpp:119
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int ri = ti * TILE + rows[q];
+                const double c = wsumcov[q] + wmm[q] - pb.rt_wm[ri] * wm_j;    // util.cpp:123
+                cov[q] = c / (pb.rt_sd[ri] * sd_j);                            // distmix.cpp:196
+            }
         } else {
-            const int u = ri - pb.Mp;                         // unmeasured row (x), measured col (y)
-            if (u >= pb.U || rj >= pb.M) continue;
-            pb.B21[(size_t)u * Mld + rj] = cor_entry(pb, tile_slab, e, ri, rj);   // dist.cpp:188-191
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                cov[q] = cor_entry(pb, (const float*)tile_slab, rows[q] * TILE + jj, ti * TILE + rows[q], rj);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int ri = ti * TILE + rows[q];
+            if (sym) {
+                if (ri > rj) continue;                            // mirror handles the lower part
+                if (pb.ld_only) {
+                    if (ri >= pb.M || rj >= pb.M) continue;
+                    const double v = (ri == rj) ? pb.diag : cov[q];
+                    pb.out_ld[(size_t)ri * pb.M + rj] = v;
+                    pb.out_ld[(size_t)rj * pb.M + ri] = v;
+                    continue;
+                }
+                if (ri >= Mld || rj >= Mld) continue;
+                double v0, v1;
+                if (ri >= pb.M || rj >= pb.M) { v0 = v1 = (ri == rj) ? 1.0 : 0.0; }
+                else if (ri == rj) { v0 = 1.0 + pb.lambda; v1 = v0 - pb.eps; }   // dist.cpp:172
+                else { v0 = v1 = cov[q]; }                                        // dist.cpp:174-177
+                const auto A0 = pb.A;
+                const auto A1 = pb.A + (size_t)Mld * Mld;
+                A0[(size_t)ri * Mld + rj] = v0; A0[(size_t)rj * Mld + ri] = v0;
+                A1[(size_t)ri * Mld + rj] = v1; A1[(size_t)rj * Mld + ri] = v1;
+            } else {
+                const int u = ri - pb.Mp;                         // unmeasured row (x), measured col (y)
+                if (u >= pb.U || rj >= pb.M) continue;
+                pb.B21[(size_t)u * Mld + rj] = cov[q];            // dist.cpp:188-191
+            }
         }
     }
 }
 
+static const size_t EPI_SMEM = (size_t)EPI_MAXP * TILE * (2 * sizeof(double) + 2 * sizeof(int));
+
 void launch_epilogue(const Prob* d_probs, const int2* d_tilemap, int n_tiles, hipStream_t s)
 {
-    if (n_tiles > 0) hipLaunchKernelGGL(epilogue_kernel, dim3(n_tiles), dim3(256), 0, s, d_probs, d_tilemap);
+    if (n_tiles <= 0) return;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(epilogue_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)EPI_SMEM);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(epilogue_kernel, dim3(n_tiles), dim3(256), EPI_SMEM, s, d_probs, d_tilemap);
 }
 
 // Gene batches (gene.cpp:305-315, 571-586): block g is n_g x n_g with pb.diag on the diagonal.
