@@ -126,6 +126,7 @@ def main():
     torch.cuda.synchronize()
     job = hotpath.Job(descs, ctx=ctx, on_device=True)
     work = job.work()
+    stats = job.stats()
 
     def barrier():
         torch.cuda.synchronize()
@@ -193,6 +194,9 @@ def main():
                 "traffic": None,
                 "algorithmic_flops_per_launch": work["ld_flops"],
                 "avg_launch_ms": gram_ms / max(1, gram_n), "launches": int(gram_n),
+                "issued_flops_per_launch": stats["executed_flops"],
+                "issued_tflops": stats["executed_flops"] / avg_gram_s / 1e12 if avg_gram_s > 0 else 0.0,
+                "work_items": stats["items"], "partial_slab_bytes": stats["slab_bytes"],
             },
             "stage_ms_per_step": stage_ms,
         }

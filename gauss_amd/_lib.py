@@ -43,7 +43,7 @@ SYMBOLS = [
     "gauss_hip_init", "gauss_hip_destroy", "gauss_last_error", "gauss_hip_version", "gauss_ld",
     "gauss_impute_window", "gauss_gene_ld_batch", "gauss_gram_counts", "gauss_job_create",
     "gauss_job_run", "gauss_job_fetch", "gauss_job_destroy", "gauss_job_profile",
-    "gauss_job_profile_get", "gauss_job_work", "gauss_synth_device",
+    "gauss_job_profile_get", "gauss_job_work", "gauss_job_stats", "gauss_synth_device",
 ]
 
 
@@ -81,6 +81,7 @@ def load():
     lib.gauss_job_profile.argtypes = [C.c_void_p, C.c_int]
     lib.gauss_job_profile_get.argtypes = [C.c_void_p, C.c_int, _dp, C.POINTER(C.c_int64)]
     lib.gauss_job_work.argtypes = [C.c_void_p, _dp, _dp, _dp, C.POINTER(C.c_int64)]
+    lib.gauss_job_stats.argtypes = [C.c_void_p, _dp]
     lib.gauss_synth_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, _ip, C.c_int,
                                        C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint64]
     _lib = lib

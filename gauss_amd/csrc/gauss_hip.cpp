@@ -692,6 +692,31 @@ int gauss_job_work(gauss_job* job, double* out_ld_flops, double* out_solve_flops
     return GAUSS_OK;
 }
 
+int gauss_job_stats(gauss_job* job, double* out4)
+{
+    if (!job || !out4) return fail(GAUSS_E_INVALID, "bad arguments");
+    double flops = 0, slab = 0;
+    for (const Plan& pl : job->plans) {
+        const Prob& p = pl.p;
+        const int mt = p.Mp / TILE;
+        auto rows = [&](int t) { int left = (t < mt) ? p.M - t * TILE : p.U - (t - mt) * TILE; return left > TILE ? TILE : left; };
+        auto halves = [](int r, int w) { int n = (r - w * 64 + 31) / 32; return n < 0 ? 0 : (n > 2 ? 2 : n); };
+        for (int pr = 0; pr < p.npair; pr++) {
+            const int ti = pl.pair_ti[pr], tj = pl.pair_tj[pr];
+            double tiles32 = 0;
+            for (int wr = 0; wr < 2; wr++)
+                for (int wc = 0; wc < 2; wc++) {
+                    if (ti == tj && wr == 1 && wc == 0) continue;
+                    tiles32 += halves(rows(ti), wr) * halves(rows(tj), wc);
+                }
+            flops += tiles32 * 32.0 * 32.0 * 2.0 * p.Kp;
+        }
+        slab += (double)p.npair * p.nseg * TILE * TILE * sizeof(float);
+    }
+    out4[0] = job->n_items; out4[1] = flops; out4[2] = slab; out4[3] = (double)job->ws_bytes;
+    return GAUSS_OK;
+}
+
 int gauss_impute_window(gauss_ctx* ctx, const gauss_window_desc* win)
 {
     if (!ctx || !win) return fail(GAUSS_E_INVALID, "bad arguments to gauss_impute_window");

@@ -30,22 +30,65 @@ constexpr int LTILE = TILE * LROW;         // bytes per operand tile image
 
 __device__ __forceinline__ float ub(uint32_t w, int b) { return (float)((w >> (8 * b)) & 0xffu); }
 
-__global__ __launch_bounds__(256, 2) void gram_kernel(const Prob* __restrict__ probs,
-                                                      const Item* __restrict__ items)
+// One K chunk (64 samples) of a wave's 64 x 64 sub-tile.  NA / NB = number of live 32-row halves
+// of the wave's A / B rows (rows past the problem's real row count are zero padding: their
+// products are never read, so their MFMAs are not issued at all).
+template <int NA, int NB>
+__device__ __forceinline__ void chunk_mfma(const uint8_t* __restrict__ la, const uint8_t* __restrict__ lb,
+                                           int arow, int brow, f32x16& acc00, f32x16& acc01,
+                                           f32x16& acc10, f32x16& acc11)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[2 * 2 * LTILE];
+#pragma unroll
+    for (int g = 0; g < 2; g++) {
+        const u32x4 a0 = *reinterpret_cast<const u32x4*>(la + arow + g * 32);
+        const u32x4 b0 = *reinterpret_cast<const u32x4*>(lb + brow + g * 32);
+        u32x4 a1 = a0, b1 = b0;
+        if (NA > 1) a1 = *reinterpret_cast<const u32x4*>(la + arow + 32 * LROW + g * 32);
+        if (NB > 1) b1 = *reinterpret_cast<const u32x4*>(lb + brow + 32 * LROW + g * 32);
+        const uint32_t aw0[4] = {a0.x, a0.y, a0.z, a0.w};
+        const uint32_t aw1[4] = {a1.x, a1.y, a1.z, a1.w};
+        const uint32_t bw0[4] = {b0.x, b0.y, b0.z, b0.w};
+        const uint32_t bw1[4] = {b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const float fa0 = ub(aw0[q], b), fb0 = ub(bw0[q], b);
+                acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0, fb0, acc00, 0, 0, 0);
+                if (NB > 1) {
+                    const float fb1 = ub(bw1[q], b);
+                    acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0, fb1, acc01, 0, 0, 0);
+                }
+                if (NA > 1) {
+                    const float fa1 = ub(aw1[q], b);
+                    acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1, fb0, acc10, 0, 0, 0);
+                    if (NB > 1) {
+                        const float fb1 = ub(bw1[q], b);
+                        acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1, fb1, acc11, 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+}
 
-    const Item it = items[blockIdx.x];
-    const Prob& pb = probs[it.prob];
+__device__ __forceinline__ int tile_rows(const Prob& pb, int t)
+{
+    const int mt = pb.Mp / TILE;
+    const int left = (t < mt) ? pb.M - t * TILE : pb.U - (t - mt) * TILE;
+    return left > TILE ? TILE : left;
+}
+
+// The K loop of one work item for a wave with NA x NB live 32-row halves (NA = 0: staging only).
+template <int NA, int NB>
+__device__ __forceinline__ void run_item(const Prob& pb, const Item& it, uint8_t* lds, int ti, int tj, int wr, int wc)
+{
     const int Kp = pb.Kp;
-    const int ti = G(pb.pair_ti)[it.pair], tj = G(pb.pair_tj)[it.pair];
-    const int k0 = G(pb.seg_k0)[it.seg], k1 = G(pb.seg_k1)[it.seg];
+    const int k0 = pb.seg_k0[it.seg], k1 = pb.seg_k1[it.seg];
     const gptr<const uint8_t> Ag = G((const uint8_t*)pb.packed) + (size_t)ti * TILE * Kp;
     const gptr<const uint8_t> Bg = G((const uint8_t*)pb.packed) + (size_t)tj * TILE * Kp;
-
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int lane = tid & 63;
     const int li = lane & 31, lh = lane >> 5;
 
     // staging map: 512 sixteen-byte pieces per operand tile, two per thread
@@ -85,29 +128,7 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(const Prob* __restrict__ p
         }
         const uint8_t* la = lds + cur * 2 * LTILE;
         const uint8_t* lb = la + LTILE;
-#pragma unroll
-        for (int g = 0; g < 2; g++) {
-            const u32x4 a0 = *reinterpret_cast<const u32x4*>(la + arow + g * 32);
-            const u32x4 a1 = *reinterpret_cast<const u32x4*>(la + arow + 32 * LROW + g * 32);
-            const u32x4 b0 = *reinterpret_cast<const u32x4*>(lb + brow + g * 32);
-            const u32x4 b1 = *reinterpret_cast<const u32x4*>(lb + brow + 32 * LROW + g * 32);
-            const uint32_t aw0[4] = {a0.x, a0.y, a0.z, a0.w};
-            const uint32_t aw1[4] = {a1.x, a1.y, a1.z, a1.w};
-            const uint32_t bw0[4] = {b0.x, b0.y, b0.z, b0.w};
-            const uint32_t bw1[4] = {b1.x, b1.y, b1.z, b1.w};
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-#pragma unroll
-                for (int b = 0; b < 4; b++) {
-                    const float fa0 = ub(aw0[q], b), fa1 = ub(aw1[q], b);
-                    const float fb0 = ub(bw0[q], b), fb1 = ub(bw1[q], b);
-                    acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0, fb0, acc00, 0, 0, 0);
-                    acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0, fb1, acc01, 0, 0, 0);
-                    acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1, fb0, acc10, 0, 0, 0);
-                    acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1, fb1, acc11, 0, 0, 0);
-                }
-            }
-        }
+        if (NA > 0) chunk_mfma<NA, NB>(la, lb, arow, brow, acc00, acc01, acc10, acc11);
         if (more) {
             uint8_t* wa = lds + (cur ^ 1) * 2 * LTILE;
             uint8_t* wb = wa + LTILE;
@@ -119,18 +140,46 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(const Prob* __restrict__ p
         __syncthreads();
         cur ^= 1;
     }
+    if (NA == 0) return;
 
     // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-    const gptr<float> out = G(pb.slab) + ((size_t)it.pair * pb.nseg + it.seg) * (TILE * TILE);
+    const gptr<float> out = G((float*)pb.slab) + ((size_t)it.pair * pb.nseg + it.seg) * (TILE * TILE);
     const int orow = wr * 64 + 4 * lh, ocol = wc * 64 + li;
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         const int row = orow + (r & 3) + 8 * (r >> 2);
         out[(size_t)row * TILE + ocol] = acc00[r];
-        out[(size_t)row * TILE + ocol + 32] = acc01[r];
-        out[(size_t)(row + 32) * TILE + ocol] = acc10[r];
-        out[(size_t)(row + 32) * TILE + ocol + 32] = acc11[r];
+        if (NB > 1) out[(size_t)row * TILE + ocol + 32] = acc01[r];
+        if (NA > 1) {
+            out[(size_t)(row + 32) * TILE + ocol] = acc10[r];
+            if (NB > 1) out[(size_t)(row + 32) * TILE + ocol + 32] = acc11[r];
+        }
     }
+}
+
+__global__ __launch_bounds__(256, 4) void gram_kernel(const Prob* __restrict__ probs,
+                                                      const Item* __restrict__ items)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds[2 * 2 * LTILE];
+
+    const Item it = items[blockIdx.x];
+    const Prob& pb = probs[it.prob];
+    const int ti = pb.pair_ti[it.pair], tj = pb.pair_tj[it.pair];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+
+    // live 32-row halves of this wave's A rows / B rows (wave-uniform)
+    int na = (tile_rows(pb, ti) - wr * 64 + 31) / 32;
+    int nb = (tile_rows(pb, tj) - wc * 64 + 31) / 32;
+    na = na < 0 ? 0 : (na > 2 ? 2 : na);
+    nb = nb < 0 ? 0 : (nb > 2 ? 2 : nb);
+    // diagonal tile: the lower-left 64 x 64 quadrant mirrors the upper-right one and is never read
+    if (ti == tj && wr == 1 && wc == 0) na = 0;
+    if (na == 0 || nb == 0) run_item<0, 0>(pb, it, lds, ti, tj, wr, wc);
+    else if (na == 2 && nb == 2) run_item<2, 2>(pb, it, lds, ti, tj, wr, wc);
+    else if (na == 2) run_item<2, 1>(pb, it, lds, ti, tj, wr, wc);
+    else if (nb == 2) run_item<1, 2>(pb, it, lds, ti, tj, wr, wc);
+    else run_item<1, 1>(pb, it, lds, ti, tj, wr, wc);
 }
 
 void launch_gram(const Prob* d_probs, const Item* d_items, int n_items, hipStream_t s)

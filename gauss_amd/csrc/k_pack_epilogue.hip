@@ -351,6 +351,7 @@ __global__ __launch_bounds__(256) void counts_kernel(const Prob* __restrict__ pr
     for (int e = threadIdx.x; e < TILE * TILE; e += 256) {
         const int ri = ti * TILE + e / TILE, rj = tj * TILE + e % TILE;
         if (ri >= pb.M || rj >= pb.M) continue;
+        if (ti == tj && ri > rj) continue;      // diagonal tile: the Gram kernel skips the mirrored quadrant
         long long s = 0;
         for (int g = 0; g < pb.nseg; g++) s += (long long)tile_slab[(size_t)g * TILE * TILE + e];
         out[(size_t)ri * pb.M + rj] = s;

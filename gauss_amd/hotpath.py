@@ -192,6 +192,11 @@ class Job:
         check(self.ctx.lib.gauss_job_work(self.handle, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
         return dict(ld_flops=a.value, solve_flops=b.value, bytes=c.value, imputed_snps=d.value)
 
+    def stats(self):
+        out = (C.c_double * 4)()
+        check(self.ctx.lib.gauss_job_stats(self.handle, out))
+        return dict(items=int(out[0]), executed_flops=out[1], slab_bytes=out[2], workspace_bytes=out[3])
+
     def close(self):
         if self.handle:
             self.ctx.lib.gauss_job_destroy(self.handle)

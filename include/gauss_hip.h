@@ -132,6 +132,11 @@ int gauss_job_profile_get(gauss_job* job, int kernel, double* out_ms, int64_t* o
 int gauss_job_work(gauss_job* job, double* out_ld_flops, double* out_solve_flops,
                    double* out_bytes, int64_t* out_imputed_snps);
 
+/* Launch geometry of the job: out[0] = Gram work items, out[1] = MFMA flops actually issued per run
+ * (padding included, skipped padding halves excluded), out[2] = bytes of partial-Gram slabs,
+ * out[3] = device workspace bytes.  Diagnostic only. */
+int gauss_job_stats(gauss_job* job, double* out4);
+
 /* Synthetic genotype generator on the device (bench plumbing; mirrors gauss_amd/synth.py's
  * model with a counter-based RNG).  Writes n_snp rows of n_samples bytes {0,1,2} at d_out with
  * row stride ld.  thr is a host array [n_snp x n_pop] of per-population latent thresholds,
