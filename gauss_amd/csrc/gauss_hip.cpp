@@ -90,6 +90,7 @@ struct gauss_job {
     int2* d_tilemap = nullptr;  int n_tiles = 0;
     int2* d_panelmap = nullptr; int n_panels = 0;
     int max_nblk = 0;
+    int max_pop = 1;
     int* d_status = nullptr;                               // [n][4]
     double* d_results = nullptr; size_t n_results = 0;     // z then info per problem
     double* h_results = nullptr;                           // pinned
@@ -304,6 +305,7 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
             for (int pr = 0; pr < p.npair; pr++) tilemap.push_back(make_int2(i, pr));
         for (int pn = 0; pn < p.npanel; pn++) panelmap.push_back(make_int2(i, pn));
         if (p.npanel > 0) job->max_nblk = std::max(job->max_nblk, p.nblk);
+        if (p.mode != 0) job->max_pop = std::max(job->max_pop, p.P);
     }
     // longest segments first: the tail of the launch is then made of short items
     std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.len > b.len; });
@@ -477,7 +479,7 @@ static int job_run(gauss_job* job, bool solve)
     launch_gram(job->d_probs, job->d_items, job->n_items, st);
     prof_end(job);
     prof_begin(job, 2);
-    launch_epilogue(job->d_probs, job->d_tilemap, job->n_tiles, st);
+    launch_epilogue(job->d_probs, job->d_tilemap, job->n_tiles, job->max_pop, st);
     for (int i = 0; i < job->n; i++)
         if (job->plans[i].p.n_gene) launch_gene_epilogue(job->d_probs, i, job->plans[i].p.n_gene, st);
     prof_end(job);
@@ -512,7 +514,7 @@ static int job_clamp_window(gauss_job* job, int i, int* status_bits)
     int2* d_tm = nullptr;
     HIPCHK(hipMalloc((void**)&d_tm, sizeof(int2) * tm.size()));
     HIPCHK(hipMemcpyAsync(d_tm, tm.data(), sizeof(int2) * tm.size(), hipMemcpyHostToDevice, st));
-    launch_epilogue(job->d_probs, d_tm, (int)tm.size(), st);
+    launch_epilogue(job->d_probs, d_tm, (int)tm.size(), job->max_pop, st);
     double* d_work = nullptr;
     const size_t n = (size_t)p.Mld;
     HIPCHK(hipMalloc((void**)&d_work, sizeof(double) * (2 * n * n + 4 * n)));

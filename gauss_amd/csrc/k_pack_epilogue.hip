@@ -181,8 +181,8 @@ constexpr int EPI_MAXP = 32;     // LDS table capacity (33KG has 29 populations)
 
 struct EpiOut { double v0, v1; };
 
-__global__ __launch_bounds__(256) void epilogue_kernel(const Prob* __restrict__ probs,
-                                                       const int2* __restrict__ tilemap)
+__global__ __launch_bounds__(1024) void epilogue_kernel(const Prob* __restrict__ probs,
+                                                        const int2* __restrict__ tilemap, int lds_pop_cap)
 {
     extern __shared__ __attribute__((aligned(16))) char esm[];
     const int2 tm = tilemap[blockIdx.x];
@@ -197,14 +197,14 @@ __global__ __launch_bounds__(256) void epilogue_kernel(const Prob* __restrict__ 
     const int Mld = pb.Mld;
     const int tid = threadIdx.x;
     const bool weighted = pb.mode != 0;
-    const bool lds_tables = weighted && P <= EPI_MAXP;
+    const bool lds_tables = weighted && P <= lds_pop_cap;
 
     double* s_wmui = reinterpret_cast<double*>(esm);          // [P][128]  w_p * mu_p(row i)
-    double* s_muj = s_wmui + EPI_MAXP * TILE;                 // [P][128]  mu_p(col j)
-    int* s_sxi = reinterpret_cast<int*>(s_muj + EPI_MAXP * TILE);   // [P][128]
-    int* s_sxj = s_sxi + EPI_MAXP * TILE;                     // [P][128]
+    double* s_muj = s_wmui + P * TILE;                        // [P][128]  mu_p(col j)
+    int* s_sxi = reinterpret_cast<int*>(s_muj + P * TILE);    // [P][128]
+    int* s_sxj = s_sxi + P * TILE;                            // [P][128]
     if (lds_tables) {
-        for (int idx = tid; idx < P * TILE; idx += 256) {
+        for (int idx = tid; idx < P * TILE; idx += 1024) {
             const int r = idx / P, p = idx % P;               // consecutive threads: consecutive p of a row
             s_wmui[p * TILE + r] = pb.rt_wmu[(size_t)(ti * TILE + r) * P + p];
             s_sxi[p * TILE + r] = pb.sx[(size_t)(ti * TILE + r) * P + p];
@@ -214,16 +214,16 @@ __global__ __launch_bounds__(256) void epilogue_kernel(const Prob* __restrict__ 
         __syncthreads();
     }
 
-    const int jj = tid & (TILE - 1), half = tid >> 7;
+    const int jj = tid & (TILE - 1), sub = tid >> 7;          // 8 row phases
     const int rj = tj * TILE + jj;
     const double sd_j = pb.rt_sd[rj], wm_j = pb.rt_wm[rj];
     const int num_samples = pb.N;
 
-    for (int r4 = 0; r4 < TILE / 8; r4++) {
+    for (int r4 = 0; r4 < TILE / 32; r4++) {
         double cov[4];
         int rows[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) rows[q] = half + 2 * (4 * r4 + q);
+        for (int q = 0; q < 4; q++) rows[q] = sub + 8 * (4 * r4 + q);
         if (!weighted) {
             // CalCor tail (util.cpp:66-68): r = (n*sxy - sx*sy) / (sqrt(..x..) * sqrt(..y..))
             double sumxy[4] = {0, 0, 0, 0};
@@ -296,18 +296,18 @@ __global__ __launch_bounds__(256) void epilogue_kernel(const Prob* __restrict__ 
     }
 }
 
-static const size_t EPI_SMEM = (size_t)EPI_MAXP * TILE * (2 * sizeof(double) + 2 * sizeof(int));
-
-void launch_epilogue(const Prob* d_probs, const int2* d_tilemap, int n_tiles, hipStream_t s)
+void launch_epilogue(const Prob* d_probs, const int2* d_tilemap, int n_tiles, int max_pop, hipStream_t s)
 {
     if (n_tiles <= 0) return;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(epilogue_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)EPI_SMEM);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(epilogue_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)((size_t)EPI_MAXP * TILE * (2 * sizeof(double) + 2 * sizeof(int))));
         attr_set = true;
     }
-    hipLaunchKernelGGL(epilogue_kernel, dim3(n_tiles), dim3(256), EPI_SMEM, s, d_probs, d_tilemap);
+    const int cap = max_pop > EPI_MAXP ? EPI_MAXP : (max_pop < 1 ? 1 : max_pop);   // P > cap: tables stay in global memory
+    const size_t smem = (size_t)cap * TILE * (2 * sizeof(double) + 2 * sizeof(int));
+    hipLaunchKernelGGL(epilogue_kernel, dim3(n_tiles), dim3(1024), smem, s, d_probs, d_tilemap, cap);
 }
 
 // Gene batches (gene.cpp:305-315, 571-586): block g is n_g x n_g with pb.diag on the diagonal.

@@ -87,45 +87,55 @@ __device__ __forceinline__ void tile_store(double* __restrict__ g, int ld, const
 
 // In-place Cholesky of the 64x64 LDS tile D (lower triangle result, upper zeroed), followed by
 // the inverse of the factor into X.  Returns (block-uniform) 1 if a pivot was not positive.
-// s_diag: 64 doubles of LDS scratch, s_flag: one int of LDS.
+// The factorisation is a dependency chain of 64 columns: it is run by ONE wave (lane = row), which
+// needs no workgroup barriers -- LDS operations of a wave complete in order -- so a column costs
+// one dot-product sweep instead of two barriers.  Left-looking:
+//     s_i = a_ij - sum_{k<j} l_ik l_jk ;  l_jj = sqrt(s_j) ;  l_ij = s_i / l_jj
+// then X = L^-1 by forward substitution, lane = column of X.
+#define WAVE_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
 __device__ int tile_chol_inv(double* __restrict__ D, double* __restrict__ X, int tid,
                              double* s_diag, int* s_flag)
 {
+    (void)s_diag;
     if (tid == 0) *s_flag = 0;
-    for (int j = 0; j < NB; j++) {
-        __syncthreads();                          // trailing update of column j-1 is complete
-        const double d = D[j * LDB + j];          // untouched during this phase (see s_diag)
-        const double sd = sqrt(d);
-        if (tid == 0 && !(d > 0.0)) *s_flag = 1;
-        if (tid < NB) {
-            if (tid == j) s_diag[j] = sd;
-            else if (tid > j) D[tid * LDB + j] = D[tid * LDB + j] / sd;
-            else D[tid * LDB + j] = 0.0;          // strictly upper part of column j
+    __syncthreads();
+    if (tid < NB) {
+        const int i = tid;
+        int bad = 0;
+        for (int j = 0; j < NB; j++) {
+            double s0 = D[i * LDB + j], s1 = 0.0;
+            int k = 0;
+            for (; k + 1 < j; k += 2) {
+                s0 = fma(-D[i * LDB + k], D[j * LDB + k], s0);
+                s1 = fma(-D[i * LDB + k + 1], D[j * LDB + k + 1], s1);
+            }
+            if (k < j) s0 = fma(-D[i * LDB + k], D[j * LDB + k], s0);
+            const double s = s0 + s1;
+            const double piv = __shfl(s, j);
+            if (!(piv > 0.0)) bad = 1;
+            const double d = sqrt(piv);
+            const double l = (i == j) ? d : ((i > j) ? s / d : 0.0);
+            WAVE_LDS_SYNC();                       // every lane has finished reading column/row data
+            D[i * LDB + j] = l;
+            WAVE_LDS_SYNC();                       // column j visible to the whole wave
         }
-        __syncthreads();                          // column j scaled
-        // trailing rank-1 update of the lower triangle: (r, c) with j < c <= r
-        const int n = NB - 1 - j;
-        for (int e = tid; e < n * n; e += 256) {
-            const int r = j + 1 + e / n, c = j + 1 + e % n;
-            if (c <= r) D[r * LDB + c] -= D[r * LDB + j] * D[c * LDB + j];
+        // X = L^-1 : lane c owns column c
+        const int c = tid;
+        for (int r = 0; r < NB; r++) {
+            double s0 = (r == c) ? 1.0 : 0.0, s1 = 0.0;
+            int k = 0;
+            for (; k + 1 < r; k += 2) {
+                s0 = fma(-D[r * LDB + k], X[k * LDB + c], s0);
+                s1 = fma(-D[r * LDB + k + 1], X[(k + 1) * LDB + c], s1);
+            }
+            if (k < r) s0 = fma(-D[r * LDB + k], X[k * LDB + c], s0);
+            const double x = (r >= c) ? (s0 + s1) / D[r * LDB + r] : 0.0;
+            X[r * LDB + c] = x;                    // only this lane ever reads column c of X
         }
+        if (bad) *s_flag = 1;
     }
     __syncthreads();
-    if (tid < NB) D[tid * LDB + tid] = s_diag[tid];
-    // X = D^-1 (lower triangular), right-looking over rows
-    for (int e = tid; e < NB * NB; e += 256) X[(e >> 6) * LDB + (e & 63)] = ((e >> 6) == (e & 63)) ? 1.0 : 0.0;
-    __syncthreads();
-    for (int k = 0; k < NB; k++) {
-        const double dk = D[k * LDB + k];
-        if (tid <= k) X[k * LDB + tid] = X[k * LDB + tid] / dk;
-        __syncthreads();
-        const int nr = NB - 1 - k, nc = k + 1;
-        for (int e = tid; e < nr * nc; e += 256) {
-            const int r = k + 1 + e / nc, c = e % nc;
-            X[r * LDB + c] -= D[r * LDB + k] * X[k * LDB + c];
-        }
-        __syncthreads();
-    }
     return *s_flag;
 }
 
