@@ -1,0 +1,296 @@
+"""The reference's R-level entry points, same names and argument lists (R/RcppExports.R:28-104).
+
+    computeLD(chr, start_bp, end_bp, pop_wgt_df, input_file, reference_index_file,
+              reference_data_file, reference_pop_desc_file, af1_cutoff=None)
+    dist(chr, start_bp, end_bp, wing_size, study_pop, input_file, ...)
+    distmix(chr, start_bp, end_bp, wing_size, pop_wgt_df, input_file, ...)
+    jepeg(study_pop, input_file, annotation_file, ...)
+    jepegmix(pop_wgt_df, input_file, annotation_file, ...)
+
+Each is a thin ctypes call into libgauss_host.so (C++ host data layer) which delegates the numeric
+hot path to libgauss_hip.so (HIP).  A ``pop_wgt_df`` is anything with two columns (population
+names, weights): a pandas DataFrame, a dict, or a (names, weights) pair.  Results come back as
+pandas DataFrames with the reference's column names; computeLD returns
+``{"snplist": DataFrame, "cormat": ndarray}`` like the reference's R list.  Errors the reference
+raises with Rcpp::stop surface as ``GaussError`` with the same text.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib, hotpath
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HOST_LIB_PATH = os.path.join(_HERE, "lib", "libgauss_host.so")
+
+KIND_COMPUTELD, KIND_DIST, KIND_DISTMIX, KIND_JEPEG, KIND_JEPEGMIX = range(5)
+
+HOST_SYMBOLS = [
+    "gauss_host_last_error", "gauss_table_nrow", "gauss_table_ncol", "gauss_table_colname",
+    "gauss_table_coltype", "gauss_table_str", "gauss_table_int", "gauss_table_dbl", "gauss_table_matrix",
+    "gauss_table_free", "gauss_host_computeLD", "gauss_host_dist", "gauss_host_distmix", "gauss_host_jepeg",
+    "gauss_host_jepegmix", "gauss_host_prepare", "gauss_prepared_snps", "gauss_prepared_counts",
+    "gauss_prepared_measured_rows", "gauss_prepared_unmeasured_rows", "gauss_prepared_geno_m",
+    "gauss_prepared_geno_u", "gauss_prepared_pop_off", "gauss_prepared_pop_wgt", "gauss_prepared_z1",
+    "gauss_prepared_gene_off", "gauss_prepared_window_desc", "gauss_prepared_finish", "gauss_prepared_free",
+    "gauss_host_bgzf_copy",
+]
+
+
+class GaussError(RuntimeError):
+    pass
+
+
+_host = None
+_vp, _cp, _i64, _dbl = C.c_void_p, C.c_char_p, C.c_int64, C.c_double
+_strs = C.POINTER(C.c_char_p)
+_dp = C.POINTER(C.c_double)
+
+
+def load_host():
+    global _host
+    if _host is not None:
+        return _host
+    _lib.load()       # libgauss_host.so links against libgauss_hip.so: fail loudly if that is missing
+    if not os.path.exists(HOST_LIB_PATH):
+        raise GaussError(f"{HOST_LIB_PATH} not found: build it with `python -m gauss_amd.build`")
+    h = C.CDLL(HOST_LIB_PATH)
+    for s in HOST_SYMBOLS:
+        if not hasattr(h, s):
+            raise GaussError(f"libgauss_host.so does not export {s}")
+    h.gauss_host_last_error.restype = _cp
+    h.gauss_table_colname.restype = _cp
+    h.gauss_table_colname.argtypes = [_vp, C.c_int]
+    h.gauss_table_str.restype = _cp
+    h.gauss_table_str.argtypes = [_vp, C.c_int, C.c_int]
+    h.gauss_table_int.restype = C.POINTER(C.c_int32)
+    h.gauss_table_int.argtypes = [_vp, C.c_int]
+    h.gauss_table_dbl.restype = _dp
+    h.gauss_table_dbl.argtypes = [_vp, C.c_int]
+    h.gauss_table_matrix.restype = _dp
+    h.gauss_table_matrix.argtypes = [_vp, C.POINTER(C.c_int)]
+    for f in ("gauss_table_nrow", "gauss_table_ncol"):
+        getattr(h, f).argtypes = [_vp]
+    h.gauss_table_coltype.argtypes = [_vp, C.c_int]
+    h.gauss_table_free.argtypes = [_vp]
+    h.gauss_table_free.restype = None
+    files4 = [_cp, _cp, _cp, _cp]
+    h.gauss_host_computeLD.argtypes = [_vp, C.c_int, _i64, _i64, _strs, _dp, C.c_int] + files4 + [_dbl, C.POINTER(_vp)]
+    h.gauss_host_dist.argtypes = [_vp, C.c_int, _i64, _i64, _i64, _cp] + files4 + [_dbl, C.POINTER(_vp)]
+    h.gauss_host_distmix.argtypes = [_vp, C.c_int, _i64, _i64, _i64, _strs, _dp, C.c_int] + files4 + [_dbl, C.POINTER(_vp)]
+    h.gauss_host_jepeg.argtypes = [_vp, _cp, _cp] + files4 + [_dbl, C.POINTER(_vp)]
+    h.gauss_host_jepegmix.argtypes = [_vp, _strs, _dp, C.c_int, _cp] + files4 + [_dbl, C.POINTER(_vp)]
+    h.gauss_host_prepare.argtypes = [C.c_int, C.c_int, _i64, _i64, _i64, _cp, _strs, _dp, C.c_int, _cp, _cp, _cp, _cp, _cp,
+                                     _dbl, C.POINTER(_vp)]
+    h.gauss_prepared_snps.restype = _vp
+    h.gauss_prepared_snps.argtypes = [_vp]
+    h.gauss_prepared_counts.argtypes = [_vp] + [C.POINTER(C.c_int)] * 5
+    for f in ("gauss_prepared_measured_rows", "gauss_prepared_unmeasured_rows", "gauss_prepared_pop_off",
+              "gauss_prepared_gene_off"):
+        getattr(h, f).restype = C.POINTER(C.c_int32)
+        getattr(h, f).argtypes = [_vp]
+    for f in ("gauss_prepared_pop_wgt", "gauss_prepared_z1"):
+        getattr(h, f).restype = _dp
+        getattr(h, f).argtypes = [_vp]
+    for f in ("gauss_prepared_geno_m", "gauss_prepared_geno_u"):
+        getattr(h, f).restype = C.POINTER(C.c_uint8)
+        getattr(h, f).argtypes = [_vp, C.POINTER(_i64)]
+    h.gauss_prepared_window_desc.argtypes = [_vp, C.POINTER(_lib.WindowDesc)]
+    h.gauss_prepared_finish.argtypes = [_vp, C.POINTER(_vp)]
+    h.gauss_prepared_free.argtypes = [_vp]
+    h.gauss_prepared_free.restype = None
+    h.gauss_host_bgzf_copy.restype = _i64
+    h.gauss_host_bgzf_copy.argtypes = [_cp, _cp]
+    _host = h
+    return h
+
+
+def _hcheck(rc):
+    if rc != 0:
+        raise GaussError(load_host().gauss_host_last_error().decode())
+
+
+def _enc(s):
+    return None if s is None else os.fspath(s).encode()
+
+
+def _pop_wgt(pop_wgt_df):
+    """(names, weights) from a DataFrame / dict / pair; first column names, second weights."""
+    if hasattr(pop_wgt_df, "iloc"):
+        names, w = list(pop_wgt_df.iloc[:, 0]), list(pop_wgt_df.iloc[:, 1])
+    elif isinstance(pop_wgt_df, dict):
+        names, w = list(pop_wgt_df.keys()), list(pop_wgt_df.values())
+    else:
+        names, w = list(pop_wgt_df[0]), list(pop_wgt_df[1])
+    arr = (C.c_char_p * len(names))(*[str(n).encode() for n in names])
+    wv = np.ascontiguousarray(w, dtype=np.float64)
+    return arr, wv, len(names)
+
+
+def _table(h, t, free=True):
+    """gauss_table -> pandas DataFrame (or dict of columns when pandas is unavailable)."""
+    cols = {}
+    n = h.gauss_table_nrow(t)
+    for c in range(h.gauss_table_ncol(t)):
+        name = h.gauss_table_colname(t, c).decode()
+        ty = h.gauss_table_coltype(t, c)
+        if ty == 0:
+            cols[name] = [h.gauss_table_str(t, c, r).decode() for r in range(n)]
+        elif ty == 1:
+            cols[name] = np.ctypeslib.as_array(h.gauss_table_int(t, c), shape=(n,)).copy() if n else np.zeros(0, np.int32)
+        else:
+            cols[name] = np.ctypeslib.as_array(h.gauss_table_dbl(t, c), shape=(n,)).copy() if n else np.zeros(0)
+    nn = C.c_int()
+    mp = h.gauss_table_matrix(t, C.byref(nn))
+    mat = np.ctypeslib.as_array(mp, shape=(nn.value, nn.value)).copy() if mp else None
+    if free:
+        h.gauss_table_free(t)
+    try:
+        import pandas as pd
+        df = pd.DataFrame(cols)
+    except ImportError:       # pragma: no cover
+        df = cols
+    return df, mat
+
+
+def _af(af1_cutoff):
+    return float("nan") if af1_cutoff is None else float(af1_cutoff)
+
+
+def _ctx(ctx):
+    return (ctx or hotpath.default_context()).handle
+
+
+def computeLD(chr, start_bp, end_bp, pop_wgt_df, input_file, reference_index_file, reference_data_file,
+              reference_pop_desc_file, af1_cutoff=None, ctx=None):
+    h = load_host()
+    names, w, n = _pop_wgt(pop_wgt_df)
+    out = _vp()
+    _hcheck(h.gauss_host_computeLD(_ctx(ctx), int(chr), int(start_bp), int(end_bp), names, w.ctypes.data_as(_dp), n,
+                                   _enc(input_file), _enc(reference_index_file), _enc(reference_data_file),
+                                   _enc(reference_pop_desc_file), _af(af1_cutoff), C.byref(out)))
+    df, mat = _table(h, out)
+    return {"snplist": df, "cormat": mat}
+
+
+def dist(chr, start_bp, end_bp, wing_size, study_pop, input_file, reference_index_file, reference_data_file,
+         reference_pop_desc_file, af1_cutoff=None, ctx=None):
+    h = load_host()
+    out = _vp()
+    _hcheck(h.gauss_host_dist(_ctx(ctx), int(chr), int(start_bp), int(end_bp), int(wing_size), _enc(study_pop),
+                              _enc(input_file), _enc(reference_index_file), _enc(reference_data_file),
+                              _enc(reference_pop_desc_file), _af(af1_cutoff), C.byref(out)))
+    return _table(h, out)[0]
+
+
+def distmix(chr, start_bp, end_bp, wing_size, pop_wgt_df, input_file, reference_index_file, reference_data_file,
+            reference_pop_desc_file, af1_cutoff=None, ctx=None):
+    h = load_host()
+    names, w, n = _pop_wgt(pop_wgt_df)
+    out = _vp()
+    _hcheck(h.gauss_host_distmix(_ctx(ctx), int(chr), int(start_bp), int(end_bp), int(wing_size), names,
+                                 w.ctypes.data_as(_dp), n, _enc(input_file), _enc(reference_index_file),
+                                 _enc(reference_data_file), _enc(reference_pop_desc_file), _af(af1_cutoff), C.byref(out)))
+    return _table(h, out)[0]
+
+
+def jepeg(study_pop, input_file, annotation_file, reference_index_file, reference_data_file, reference_pop_desc_file,
+          af1_cutoff=None, ctx=None):
+    h = load_host()
+    out = _vp()
+    _hcheck(h.gauss_host_jepeg(_ctx(ctx), _enc(study_pop), _enc(input_file), _enc(annotation_file),
+                               _enc(reference_index_file), _enc(reference_data_file), _enc(reference_pop_desc_file),
+                               _af(af1_cutoff), C.byref(out)))
+    return _table(h, out)[0]
+
+
+def jepegmix(pop_wgt_df, input_file, annotation_file, reference_index_file, reference_data_file,
+             reference_pop_desc_file, af1_cutoff=None, ctx=None):
+    h = load_host()
+    names, w, n = _pop_wgt(pop_wgt_df)
+    out = _vp()
+    _hcheck(h.gauss_host_jepegmix(_ctx(ctx), names, w.ctypes.data_as(_dp), n, _enc(input_file), _enc(annotation_file),
+                                  _enc(reference_index_file), _enc(reference_data_file), _enc(reference_pop_desc_file),
+                                  _af(af1_cutoff), C.byref(out)))
+    return _table(h, out)[0]
+
+
+class Prepared:
+    """Host data layer output for one window / gene set (no GPU involved): gauss_host_prepare."""
+
+    def __init__(self, kind, chr=0, start_bp=0, end_bp=0, wing_size=0, study_pop=None, pop_wgt_df=None, input_file=None,
+                 annotation_file=None, reference_index_file=None, reference_data_file=None, reference_pop_desc_file=None,
+                 af1_cutoff=None):
+        self.h = load_host()
+        names, w, n = (None, None, 0) if pop_wgt_df is None else _pop_wgt(pop_wgt_df)
+        self._keep = (names, w)
+        out = _vp()
+        _hcheck(self.h.gauss_host_prepare(int(kind), int(chr), int(start_bp), int(end_bp), int(wing_size), _enc(study_pop),
+                                          names, None if w is None else w.ctypes.data_as(_dp), n, _enc(input_file),
+                                          _enc(annotation_file), _enc(reference_index_file), _enc(reference_data_file),
+                                          _enc(reference_pop_desc_file), _af(af1_cutoff), C.byref(out)))
+        self.handle = out
+        c = [C.c_int() for _ in range(5)]
+        self.h.gauss_prepared_counts(out, *[C.byref(x) for x in c])
+        self.M, self.U, self.N, self.P, self.n_gene = [x.value for x in c]
+
+    def snps(self):
+        return _table(self.h, self.h.gauss_prepared_snps(self.handle), free=False)[0]
+
+    def _arr(self, fn, n, dtype):
+        p = fn(self.handle)
+        return np.ctypeslib.as_array(p, shape=(n,)).astype(dtype).copy() if (n and p) else np.zeros(0, dtype)
+
+    def measured_rows(self):
+        return self._arr(self.h.gauss_prepared_measured_rows, self.M, np.int32)
+
+    def unmeasured_rows(self):
+        return self._arr(self.h.gauss_prepared_unmeasured_rows, self.U, np.int32)
+
+    def pop_off(self):
+        return self._arr(self.h.gauss_prepared_pop_off, self.P + 1, np.int32)
+
+    def pop_wgt(self):
+        return self._arr(self.h.gauss_prepared_pop_wgt, self.P, np.float64)
+
+    def z1(self):
+        return self._arr(self.h.gauss_prepared_z1, self.M, np.float64)
+
+    def gene_off(self):
+        return self._arr(self.h.gauss_prepared_gene_off, self.n_gene + 1 if self.n_gene else 0, np.int32)
+
+    def _geno(self, fn, rows):
+        ld = _i64()
+        p = fn(self.handle, C.byref(ld))
+        if not rows:
+            return np.zeros((0, self.N), dtype=np.uint8)
+        a = np.ctypeslib.as_array(p, shape=(rows, ld.value))
+        return a[:, : self.N]          # a view: keep `self` alive while using it
+
+    def geno_m(self):
+        return self._geno(self.h.gauss_prepared_geno_m, self.M)
+
+    def geno_u(self):
+        return self._geno(self.h.gauss_prepared_geno_u, self.U)
+
+    def window_desc(self):
+        d = _lib.WindowDesc()
+        _hcheck(self.h.gauss_prepared_window_desc(self.handle, C.byref(d)))
+        return d
+
+    def finish(self):
+        out = _vp()
+        _hcheck(self.h.gauss_prepared_finish(self.handle, C.byref(out)))
+        return _table(self.h, out)[0]
+
+    def close(self):
+        if self.handle:
+            self.h.gauss_prepared_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -63,5 +63,24 @@ def build_hip(force=False, verbose=False):
     return so
 
 
+def build_host(force=False, verbose=False):
+    """libgauss_host.so: host data layer + the five reference entry points (plain g++, zlib)."""
+    os.makedirs(OBJDIR, exist_ok=True)
+    hip_so = build_hip(force=False, verbose=verbose)
+    hdir = os.path.join(CSRC, "host")
+    srcs = [os.path.join(hdir, f) for f in ("gauss_host.cpp", "bgzf_io.cpp")]
+    deps = srcs + [os.path.join(hdir, "bgzf_io.h"), os.path.join(HERE, "..", "include", "gauss_host.h"),
+                   os.path.join(HERE, "..", "include", "gauss_hip.h"), hip_so]
+    so = os.path.join(LIBDIR, "libgauss_host.so")
+    if force or _newer(so, deps):
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", so] + srcs + [
+            "-L" + LIBDIR, "-lgauss_hip", "-Wl,-rpath,$ORIGIN", "-lz"]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    return so
+
+
 if __name__ == "__main__":
     print(build_hip(force="--force" in sys.argv, verbose=True))
+    print(build_host(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,948 @@
+// libgauss_host.so -- host data layer + the five reference entry points (include/gauss_host.h).
+//
+// Restates, in plain C++ without Rcpp, the reference's feeder semantics:
+//   Arguments defaults          src/gauss.cpp:18-35
+//   ReadInputZ                  src/gauss.cpp:121-190
+//   ReadReferenceIndex / ...All src/gauss.cpp:293-399 / 431-518
+//   MakeSnpVec / MakeSnpVecMix  src/gauss.cpp:543-604 / 631-693
+//   ReadGenotype                src/gauss.cpp:720-785
+//   read_ref_desc               src/gauss.cpp:951-993
+//   init_pop_flag_vec / _wgt_   src/gauss.cpp:1019-1066 / 1093-1117
+//   ReadAnnotation              src/gauss.cpp:1275-1361
+//   MakeGeneStartEndVec         src/gauss.cpp:1383-1439
+//   SNP ordering (MapKey)       src/gauss.h:72-99
+// and the drivers computeLD.cpp:26-166, dist.cpp:30-126, distmix.cpp:30-135, jepeg.cpp:28-153,
+// jepegmix.cpp:26-161 with the numeric hot path delegated to libgauss_hip.so.
+#include "../../../include/gauss_host.h"
+
+#include <algorithm>
+#include <cctype>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <memory>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "bgzf_io.h"
+
+using gauss_host::BgzfReader;
+
+// ------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int herr(const char* fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return -1;
+}
+
+// ------------------------------------------------------------------------------------------
+// tables
+// ------------------------------------------------------------------------------------------
+struct Column {
+    std::string name;
+    int type;
+    std::vector<std::string> s;
+    std::vector<int32_t> i;
+    std::vector<double> d;
+};
+
+struct gauss_table {
+    std::vector<Column> cols;
+    std::vector<double> matrix;
+    int matrix_n = 0;
+    int nrow() const
+    {
+        if (cols.empty()) return 0;
+        const Column& c = cols[0];
+        return (int)(c.type == GAUSS_COL_STR ? c.s.size() : c.type == GAUSS_COL_INT ? c.i.size() : c.d.size());
+    }
+    Column& add(const char* name, int type) { cols.push_back(Column{name, type, {}, {}, {}}); return cols.back(); }
+};
+
+// ------------------------------------------------------------------------------------------
+// data model (src/snp.h:14-110, src/gauss.h:18-99)
+// ------------------------------------------------------------------------------------------
+struct Snp {
+    std::string rsid = ".";
+    int chr = -1;
+    long long bp = -1;
+    std::string a1 = ".", a2 = ".";
+    double af1mix = -1.0, af1ref = -1.0;
+    double z = 0.0, info = -1.0;
+    int type = -1;                 // 0 panel only, 1 GWAS and panel, 2 GWAS only (snp.h:61)
+    long long fpos = -1;
+    std::string geneid = ".";
+    std::map<int, double> categ;   // Snp::categ_map_
+    std::string line;              // cached panel data line (read once instead of twice)
+    bool have_line = false;
+    std::vector<std::pair<const char*, int>> geno;   // selected populations' genotype strings (into `line`)
+};
+
+struct MapKey {
+    int chr; long long bp; std::string a1, a2;
+    bool operator<(const MapKey& r) const     // gauss.h:77-91
+    {
+        if (chr == r.chr) {
+            if (bp == r.bp) {
+                if (a1 == r.a1) return a2 < r.a2;
+                return a1 < r.a1;
+            }
+            return bp < r.bp;
+        }
+        return chr < r.chr;
+    }
+};
+typedef std::map<MapKey, std::unique_ptr<Snp>> SnpMap;
+
+struct Args {                       // Arguments, gauss.h:18-69 with the defaults of gauss.cpp:18-35
+    int chr = 0;
+    long long start_bp = 0, end_bp = 0, wing_size = 0;
+    std::string study_pop, input_file, reference_index_file, reference_data_file, reference_pop_desc_file, annotation_file;
+    std::vector<std::string> ref_pop_vec, ref_sup_pop_vec;
+    std::vector<int> ref_pop_size_vec;
+    double lambda = 0.1, min_abs_eig = 1e-5;
+    std::vector<int> pop_flag_vec;
+    std::vector<double> pop_wgt_vec;
+    std::map<std::string, double> pop_wgt_map;
+    int num_pops = 0, num_samples = 0;
+    double af1_cutoff = 0.01;
+    int min_num_measured_snp = 10, min_num_unmeasured_snp = 10;
+    int total_num_categ = 6;
+    double categ_cor_cutoff = 0.8;
+    int denorm_norm_w = 3;
+};
+
+// whitespace tokeniser with the semantics of `istringstream >> a >> b ...` for well-formed lines
+struct Tok {
+    const char* p; const char* e;
+    explicit Tok(const std::string& s) : p(s.data()), e(s.data() + s.size()) {}
+    bool next(const char*& b, int& n)
+    {
+        while (p < e && isspace((unsigned char)*p)) p++;
+        if (p >= e) return false;
+        b = p;
+        while (p < e && !isspace((unsigned char)*p)) p++;
+        n = (int)(p - b);
+        return true;
+    }
+    bool str(std::string& out) { const char* b; int n; if (!next(b, n)) return false; out.assign(b, n); return true; }
+    bool i64(long long& out) { std::string t; if (!str(t)) return false; char* q; out = strtoll(t.c_str(), &q, 10); return q != t.c_str(); }
+    bool i32(int& out) { long long v; if (!i64(v)) return false; out = (int)v; return true; }
+    bool dbl(double& out) { std::string t; if (!str(t)) return false; char* q; out = strtod(t.c_str(), &q); return q != t.c_str(); }
+};
+
+// read_ref_desc (gauss.cpp:951-993)
+static int read_ref_desc(Args& a)
+{
+    std::ifstream in(a.reference_pop_desc_file.c_str());
+    if (!in) return herr("ERROR: can't open reference population description file '%s'", a.reference_pop_desc_file.c_str());
+    std::string line, pop, sup;
+    int n = 0;
+    std::getline(in, line);   // header
+    while (std::getline(in, line)) {
+        Tok t(line);
+        if (!t.str(pop)) continue;
+        t.i32(n); t.str(sup);
+        a.ref_pop_vec.push_back(pop);
+        a.ref_pop_size_vec.push_back(n);
+        a.ref_sup_pop_vec.push_back(sup);
+    }
+    a.num_pops = (int)a.ref_pop_vec.size();
+    return 0;
+}
+
+// init_pop_flag_vec (gauss.cpp:1019-1066): study_pop names a population or a super population
+static int init_pop_flag_vec(Args& a)
+{
+    const int in_pop = (int)std::count(a.ref_pop_vec.begin(), a.ref_pop_vec.end(), a.study_pop);
+    const int in_sup = (int)std::count(a.ref_sup_pop_vec.begin(), a.ref_sup_pop_vec.end(), a.study_pop);
+    const std::vector<std::string>* pv = nullptr;
+    if (in_pop != 0 && in_sup == 0) pv = &a.ref_pop_vec;
+    if (in_pop == 0 && in_sup != 0) pv = &a.ref_sup_pop_vec;
+    if (in_pop == 0 && in_sup == 0) return herr("ERROR: invalid population name '%s'", a.study_pop.c_str());
+    if (!pv) return herr("ERROR: population name '%s' is both a population and a super population", a.study_pop.c_str());
+    int cnt = 0;
+    for (int i = 0; i < a.num_pops; i++) {
+        if ((*pv)[i] == a.study_pop) { a.pop_flag_vec.push_back(1); cnt += a.ref_pop_size_vec[i]; }
+        else a.pop_flag_vec.push_back(0);
+    }
+    a.num_samples = cnt;
+    return 0;
+}
+
+// init_pop_flag_wgt_vec (gauss.cpp:1093-1117): weights re-ordered into panel order, unknown names ignored
+static void init_pop_flag_wgt_vec(Args& a)
+{
+    for (int i = 0; i < a.num_pops; i++) {
+        auto it = a.pop_wgt_map.find(a.ref_pop_vec[i]);
+        if (it != a.pop_wgt_map.end()) { a.pop_flag_vec.push_back(1); a.pop_wgt_vec.push_back(it->second); }
+        else a.pop_flag_vec.push_back(0);
+    }
+}
+
+static void set_pop_wgt_map(Args& a, const char* const* names, const double* w, int n)
+{
+    for (int i = 0; i < n; i++) {       // distmix.cpp:48-54: names upper-cased
+        std::string pop = names[i];
+        std::transform(pop.begin(), pop.end(), pop.begin(), ::toupper);
+        a.pop_wgt_map[pop] = w[i];
+    }
+}
+
+// ReadInputZ (gauss.cpp:121-190)
+static int ReadInputZ(SnpMap& m, const Args& a, bool All)
+{
+    std::ifstream in(a.input_file.c_str());
+    if (!in) return herr("ERROR: can't open input file '%s'", a.input_file.c_str());
+    std::string line, rsid, a1, a2;
+    int chr = 0; long long bp = 0; double z = 0;
+    std::getline(in, line);   // header
+    while (std::getline(in, line)) {
+        Tok t(line);
+        if (t.str(rsid) && t.i32(chr) && t.i64(bp) && t.str(a1) && t.str(a2)) t.dbl(z);
+        if (!All) {
+            if ((a.chr > 0) && (a.chr != chr)) continue;
+            if ((a.start_bp - a.wing_size) > bp || (a.end_bp + a.wing_size) < bp) continue;
+        }
+        std::unique_ptr<Snp> s(new Snp());
+        s->rsid = rsid; s->chr = chr; s->bp = bp; s->a1 = a1; s->a2 = a2; s->z = z;
+        s->info = 1.0;     // gauss.cpp:142
+        s->type = 2;       // gauss.cpp:176
+        m[MapKey{chr, bp, a1, a2}] = std::move(s);
+    }
+    return 0;
+}
+
+// ReadReferenceIndex (gauss.cpp:293-399) and ReadReferenceIndexAll (gauss.cpp:431-518)
+static int ReadReferenceIndex(SnpMap& m, const Args& a, bool All)
+{
+    BgzfReader fp;
+    if (!fp.open(a.reference_index_file)) return herr("ERROR: can't open reference index file '%s'", a.reference_index_file.c_str());
+    std::string line, rsid, a1, a2;
+    int chr = 0; double af1ref = 0; long long bp = 0, fpos = 0;
+    for (;;) {
+        const int last = fp.getline(line);
+        if (last == -2) return herr("Error: can't read reference index file '%s'", a.reference_index_file.c_str());
+        if (last == -1) break;
+        Tok t(line);
+        if (t.str(rsid) && t.i32(chr) && t.i64(bp) && t.str(a1) && t.str(a2) && t.dbl(af1ref)) t.i64(fpos);
+        if (!All) {
+            if ((a.chr > 0) && (a.chr != chr)) continue;
+            if ((a.start_bp - a.wing_size) > bp || (a.end_bp + a.wing_size) < bp) continue;
+        }
+        auto it1 = m.find(MapKey{chr, bp, a1, a2});
+        auto it2 = m.find(MapKey{chr, bp, a2, a1});
+        if (it1 != m.end() && it2 == m.end()) {
+            it1->second->rsid = rsid; it1->second->type = 1; it1->second->fpos = fpos;
+        } else if (it1 == m.end() && it2 != m.end()) {
+            // GWAS alleles are swapped relative to the panel: adopt the panel's order, flip z
+            std::unique_ptr<Snp> s = std::move(it2->second);
+            m.erase(it2);
+            s->rsid = rsid; s->a1 = a1; s->a2 = a2; s->z = s->z * (-1); s->type = 1; s->fpos = fpos;
+            m[MapKey{chr, bp, a1, a2}] = std::move(s);
+        } else if (it1 == m.end() && it2 == m.end()) {
+            if (!All) {       // gauss.cpp:373-385; ReadReferenceIndexAll never adds unmeasured SNPs
+                std::unique_ptr<Snp> s(new Snp());
+                s->rsid = rsid; s->chr = chr; s->bp = bp; s->a1 = a1; s->a2 = a2; s->type = 0; s->fpos = fpos;
+                m[MapKey{chr, bp, a1, a2}] = std::move(s);
+            }
+        } else {
+            return herr("ERROR: input file contains duplicates");
+        }
+    }
+    return 0;
+}
+
+// Read the panel data line of a SNP once and split it into the P genotype strings and P
+// allele frequencies (gauss.cpp:755-763 and 660-674 parse the same line twice).
+static void load_line(BgzfReader& fp, Snp& s, const Args& a, std::vector<double>* af_out)
+{
+    if (!s.have_line) {
+        fp.seek(s.fpos);
+        fp.getline(s.line);     // a seek past EOF (fpos = -1) yields an empty line, like the reference
+        s.have_line = true;
+    }
+    s.geno.clear();
+    Tok t(s.line);
+    for (int k = 0; k < a.num_pops; k++) {
+        const char* b = nullptr; int n = 0;
+        if (!t.next(b, n)) { b = s.line.data() + s.line.size(); n = 0; }
+        if (a.pop_flag_vec[k]) s.geno.push_back(std::make_pair(b, n));
+    }
+    if (af_out) {
+        af_out->clear();
+        for (int k = 0; k < a.num_pops; k++) {
+            double af = 0.0;            // a failed extraction leaves 0 (C++11 num_get)
+            t.dbl(af);
+            if (a.pop_flag_vec[k]) af_out->push_back(af);
+        }
+    }
+}
+
+// MakeSnpVec (gauss.cpp:543-604)
+static int MakeSnpVec(std::vector<Snp*>& v, SnpMap& m, const Args& a)
+{
+    BgzfReader fp;
+    if (!fp.open(a.reference_data_file)) return herr("ERROR: can't open reference data file '%s'", a.reference_data_file.c_str());
+    for (auto& kv : m) {
+        Snp& s = *kv.second;
+        load_line(fp, s, a, nullptr);
+        double allele_counter = 0, num_subj = 0;
+        for (auto& g : s.geno) {
+            num_subj += g.second;
+            for (int i = 0; i < g.second; i++) allele_counter += (double)(g.first[i] - '0');
+        }
+        double af1ref = allele_counter / (2 * num_subj);
+        af1ref = std::ceil(af1ref * 100000.0) / 100000.0;      // gauss.cpp:591
+        s.af1ref = af1ref;
+        if ((af1ref > a.af1_cutoff) && (af1ref < (1 - a.af1_cutoff))) v.push_back(&s);
+    }
+    return 0;
+}
+
+// MakeSnpVecMix (gauss.cpp:631-693)
+static int MakeSnpVecMix(std::vector<Snp*>& v, SnpMap& m, const Args& a)
+{
+    BgzfReader fp;
+    if (!fp.open(a.reference_data_file)) return herr("ERROR: can't open reference data file '%s'", a.reference_data_file.c_str());
+    std::vector<double> af1_vec;
+    for (auto& kv : m) {
+        Snp& s = *kv.second;
+        load_line(fp, s, a, &af1_vec);
+        double af1_mix = 0;
+        for (size_t k = 0; k < af1_vec.size(); k++) af1_mix += af1_vec[k] * a.pop_wgt_vec[k];
+        if ((af1_mix > a.af1_cutoff) && (af1_mix < (1 - a.af1_cutoff))) {
+            s.af1mix = af1_mix;
+            v.push_back(&s);
+        }
+    }
+    return 0;
+}
+
+// ReadAnnotation (gauss.cpp:1275-1361)
+static int ReadAnnotation(SnpMap& m, const Args& a)
+{
+    std::ifstream in(a.annotation_file.c_str());
+    if (!in) return herr("ERROR: can't open snp annotation data file '%s'", a.annotation_file.c_str());
+    std::string line, rsid, a1, a2, geneid, categ;
+    int chr = 0, categ_num = 0; long long bp = 0; double wgt = 0;
+    std::getline(in, line);
+    while (std::getline(in, line)) {
+        Tok t(line);
+        if (t.str(rsid) && t.i32(chr) && t.i64(bp) && t.str(a1) && t.str(a2) && t.str(geneid) && t.str(categ)) t.dbl(wgt);
+        auto it1 = m.find(MapKey{chr, bp, a1, a2});
+        auto it2 = m.find(MapKey{chr, bp, a2, a1});
+        if (categ == "PROTEIN") categ_num = 0;
+        else if (categ == "TFBS") categ_num = 1;
+        else if (categ == "WTH_HAIR") categ_num = 2;
+        else if (categ == "WTH_TARGET") categ_num = 3;
+        else if (categ == "CIS_EQTL") categ_num = 4;
+        else if (categ == "TRANS_EQTL") categ_num = 5;      // unknown names keep the previous number (gauss.cpp:1319-1330)
+        if (it1 != m.end() && it2 == m.end()) {
+            it1->second->geneid = geneid;
+            it1->second->categ[categ_num] = wgt;
+        } else if (it1 == m.end() && it2 != m.end()) {
+            std::unique_ptr<Snp> s = std::move(it2->second);
+            m.erase(it2);
+            s->a1 = a1; s->a2 = a2;
+            s->af1ref = 1 - s->af1ref;
+            s->z = s->z * (-1);
+            s->geneid = geneid;
+            s->categ[categ_num] = wgt;
+            m[MapKey{chr, bp, a1, a2}] = std::move(s);
+        }
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// prepared window / gene set
+// ------------------------------------------------------------------------------------------
+struct gauss_prepared {
+    int kind = 0;
+    Args args;
+    SnpMap snp_map;
+    std::vector<Snp*> snp_vec;                 // after the AF filter, map order
+    std::vector<Snp*> measured, unmeasured;    // matrix row order
+    std::vector<int32_t> measured_rows, unmeasured_rows;
+    std::vector<uint8_t> gm, gu;
+    int64_t ld = 0;
+    int N = 0;
+    std::vector<int32_t> pop_off;
+    std::vector<double> pop_wgt, z1;
+    std::vector<int32_t> gene_off;
+    std::vector<double> out_z, out_info;
+    int32_t status = 0;
+    gauss_table snps;
+    bool snps_built = false;
+};
+
+static void fill_matrix(std::vector<uint8_t>& G, const std::vector<Snp*>& rows, int64_t ld)
+{
+    G.assign((size_t)std::max<size_t>(rows.size(), 1) * ld, (uint8_t)'0');
+    for (size_t r = 0; r < rows.size(); r++) {
+        uint8_t* dst = G.data() + r * ld;
+        for (auto& g : rows[r]->geno) { memcpy(dst, g.first, (size_t)g.second); dst += g.second; }
+    }
+}
+
+static void build_snp_table(gauss_prepared& p)
+{
+    gauss_table& t = p.snps;
+    t.cols.clear();
+    const bool mix = (p.kind == GAUSS_KIND_COMPUTELD || p.kind == GAUSS_KIND_DISTMIX || p.kind == GAUSS_KIND_JEPEGMIX);
+    Column& rsid = t.add("rsid", GAUSS_COL_STR);
+    for (Snp* s : p.snp_vec) rsid.s.push_back(s->rsid);
+    Column& chr = t.add("chr", GAUSS_COL_INT);
+    for (Snp* s : p.snp_vec) chr.i.push_back(s->chr);
+    Column& bp = t.add("bp", GAUSS_COL_INT);
+    for (Snp* s : p.snp_vec) bp.i.push_back((int)s->bp);
+    Column& a1 = t.add("a1", GAUSS_COL_STR);
+    for (Snp* s : p.snp_vec) a1.s.push_back(s->a1);
+    Column& a2 = t.add("a2", GAUSS_COL_STR);
+    for (Snp* s : p.snp_vec) a2.s.push_back(s->a2);
+    Column& af = t.add(mix ? "af1mix" : "af1ref", GAUSS_COL_DBL);
+    for (Snp* s : p.snp_vec) af.d.push_back(mix ? s->af1mix : s->af1ref);
+    Column& z = t.add("z", GAUSS_COL_DBL);
+    for (Snp* s : p.snp_vec) z.d.push_back(s->z);
+    Column& info = t.add("info", GAUSS_COL_DBL);
+    for (Snp* s : p.snp_vec) info.d.push_back(s->info);
+    Column& type = t.add("type", GAUSS_COL_INT);
+    for (Snp* s : p.snp_vec) type.i.push_back(s->type);
+    Column& fpos = t.add("fpos", GAUSS_COL_DBL);
+    for (Snp* s : p.snp_vec) fpos.d.push_back((double)s->fpos);
+    Column& gid = t.add("geneid", GAUSS_COL_STR);
+    for (Snp* s : p.snp_vec) gid.s.push_back(s->geneid);
+    p.snps_built = true;
+}
+
+static int prepare(gauss_prepared& p)
+{
+    Args& a = p.args;
+    const int kind = p.kind;
+    const bool mix = (kind == GAUSS_KIND_COMPUTELD || kind == GAUSS_KIND_DISTMIX || kind == GAUSS_KIND_JEPEGMIX);
+    const bool gene = (kind == GAUSS_KIND_JEPEG || kind == GAUSS_KIND_JEPEGMIX);
+    if (read_ref_desc(a)) return -1;
+    if (mix) init_pop_flag_wgt_vec(a);
+    else if (init_pop_flag_vec(a)) return -1;
+    if (ReadInputZ(p.snp_map, a, gene)) return -1;
+    if (ReadReferenceIndex(p.snp_map, a, gene)) return -1;
+    if (gene && ReadAnnotation(p.snp_map, a)) return -1;
+    if (mix) { if (MakeSnpVecMix(p.snp_vec, p.snp_map, a)) return -1; }
+    else if (MakeSnpVec(p.snp_vec, p.snp_map, a)) return -1;
+
+    // populations selected, in panel order; N = sum of their sizes as found in the panel lines
+    p.pop_off.assign(1, 0);
+    for (int k = 0; k < a.num_pops; k++)
+        if (a.pop_flag_vec[k]) p.pop_off.push_back(p.pop_off.back() + a.ref_pop_size_vec[k]);
+    p.N = p.pop_off.back();
+    p.ld = ((int64_t)p.N + 15) / 16 * 16;
+    if (mix) p.pop_wgt = a.pop_wgt_vec;
+    else p.pop_wgt.assign(p.pop_off.size() - 1, 1.0);
+
+    if (kind == GAUSS_KIND_DIST || kind == GAUSS_KIND_DISTMIX) {
+        for (size_t r = 0; r < p.snp_vec.size(); r++) {        // dist.cpp:132-140
+            Snp* s = p.snp_vec[r];
+            if (s->type == 0 && (s->bp >= a.start_bp && s->bp <= a.end_bp)) { p.unmeasured.push_back(s); p.unmeasured_rows.push_back((int32_t)r); }
+            else if (s->type == 1) { p.measured.push_back(s); p.measured_rows.push_back((int32_t)r); }
+        }
+    } else if (kind == GAUSS_KIND_COMPUTELD) {
+        for (size_t r = 0; r < p.snp_vec.size(); r++)          // computeLD.cpp:80-86
+            if (p.snp_vec[r]->type == 1) { p.measured.push_back(p.snp_vec[r]); p.measured_rows.push_back((int32_t)r); }
+    } else {
+        // jepeg.cpp:73-87: measured SNPs with a gene id, sorted by gene id with std::sort
+        std::vector<std::pair<Snp*, int32_t>> gv;
+        for (size_t r = 0; r < p.snp_vec.size(); r++)
+            if (p.snp_vec[r]->geneid != "." && p.snp_vec[r]->type == 1) gv.push_back(std::make_pair(p.snp_vec[r], (int32_t)r));
+        std::sort(gv.begin(), gv.end(), [](const std::pair<Snp*, int32_t>& x, const std::pair<Snp*, int32_t>& y) {
+            return x.first->geneid < y.first->geneid;          // LessThanGeneid, snp.h:131-135
+        });
+        for (auto& g : gv) { p.measured.push_back(g.first); p.measured_rows.push_back(g.second); }
+        // MakeGeneStartEndVec (gauss.cpp:1383-1439): runs of equal gene id
+        p.gene_off.clear();
+        for (size_t i = 0; i < p.measured.size(); i++)
+            if (i == 0 || p.measured[i]->geneid != p.measured[i - 1]->geneid) p.gene_off.push_back((int32_t)i);
+        p.gene_off.push_back((int32_t)p.measured.size());
+    }
+    // every selected population string must have its panel length, otherwise the matrix is ragged
+    for (Snp* s : p.measured) {
+        int n = 0;
+        for (auto& g : s->geno) n += g.second;
+        if (n != p.N) return herr("ERROR: genotype line of %s has %d samples, population table says %d", s->rsid.c_str(), n, p.N);
+    }
+    for (Snp* s : p.unmeasured) {
+        int n = 0;
+        for (auto& g : s->geno) n += g.second;
+        if (n != p.N) return herr("ERROR: genotype line of %s has %d samples, population table says %d", s->rsid.c_str(), n, p.N);
+    }
+    fill_matrix(p.gm, p.measured, p.ld);                       // ReadGenotype, gauss.cpp:720-785
+    fill_matrix(p.gu, p.unmeasured, p.ld);
+    p.z1.clear();
+    for (Snp* s : p.measured) p.z1.push_back(s->z);
+    build_snp_table(p);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// small dense helpers for the JEPEG k x k tail (k <= 6): gene.cpp:317-550
+// ------------------------------------------------------------------------------------------
+static double pnorm_upper(double x) { return 0.5 * erfc(x / 1.4142135623730951); }   // R::pnorm5(x,0,1,0,0)
+
+static double pchisq_upper(double x, int df)                                            // R::pchisq(x,df,0,0)
+{
+    if (df <= 0) return NAN;
+    if (!(x > 0.0)) return (x != x) ? NAN : 1.0;
+    const double h = 0.5 * x;
+    if ((df & 1) == 0) {
+        double term = 1.0, sum = 1.0;
+        for (int k = 1; k < df / 2; k++) { term *= h / k; sum += term; }
+        return exp(-h) * sum;
+    }
+    double q = erfc(sqrt(h));
+    if (df > 1) {
+        double term = sqrt(h) / 0.886226925452758, sum = term;
+        for (int k = 2; k <= (df - 1) / 2; k++) { term *= h / (k - 0.5); sum += term; }
+        q += exp(-h) * sum;
+    }
+    return q;
+}
+
+// cyclic Jacobi for symmetric k x k (k <= 6); V columns are eigenvectors
+static void jacobi_small(int n, double* A, double* V, double* d)
+{
+    for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) V[i * n + j] = (i == j);
+    for (int sweep = 0; sweep < 60; sweep++) {
+        double off = 0;
+        for (int i = 0; i < n; i++) for (int j = i + 1; j < n; j++) off += A[i * n + j] * A[i * n + j];
+        if (off < 1e-300) break;
+        for (int p = 0; p < n; p++)
+            for (int q = p + 1; q < n; q++) {
+                const double apq = A[p * n + q];
+                if (apq == 0.0) continue;
+                const double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < n; k++) {
+                    const double akp = A[k * n + p], akq = A[k * n + q];
+                    A[k * n + p] = c * akp - s * akq; A[k * n + q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < n; k++) {
+                    const double apk = A[p * n + k], aqk = A[q * n + k];
+                    A[p * n + k] = c * apk - s * aqk; A[q * n + k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < n; k++) {
+                    const double vkp = V[k * n + p], vkq = V[k * n + q];
+                    V[k * n + p] = c * vkp - s * vkq; V[k * n + q] = s * vkp + c * vkq;
+                }
+            }
+    }
+    for (int i = 0; i < n; i++) d[i] = A[i * n + i];
+}
+
+static void make_pos_def_small(int n, double* M, double min_abs_eig)      // util.cpp:302-318
+{
+    double A[36], V[36], d[6];
+    memcpy(A, M, sizeof(double) * n * n);
+    jacobi_small(n, A, V, d);
+    double mn = d[0];
+    for (int i = 1; i < n; i++) mn = std::min(mn, d[i]);
+    if (!(mn < min_abs_eig)) return;
+    for (int i = 0; i < n; i++) if (d[i] < min_abs_eig) d[i] = min_abs_eig;
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) {
+            double s = 0;
+            for (int k = 0; k < n; k++) s += V[i * n + k] * d[k] * V[j * n + k];
+            M[i * n + j] = s;
+        }
+}
+
+static void inv_small(int n, const double* Min, double* inv)               // util.cpp:298-300 (full pivoting)
+{
+    double A[36];
+    int rp[6], cp[6];
+    memcpy(A, Min, sizeof(double) * n * n);
+    for (int k = 0; k < n; k++) {
+        int pi = k, pj = k; double best = -1;
+        for (int i = k; i < n; i++) for (int j = k; j < n; j++) if (fabs(A[i * n + j]) > best) { best = fabs(A[i * n + j]); pi = i; pj = j; }
+        rp[k] = pi; cp[k] = pj;
+        if (pi != k) for (int j = 0; j < n; j++) std::swap(A[k * n + j], A[pi * n + j]);
+        if (pj != k) for (int i = 0; i < n; i++) std::swap(A[i * n + k], A[i * n + pj]);
+        for (int i = k + 1; i < n; i++) A[i * n + k] /= A[k * n + k];
+        for (int i = k + 1; i < n; i++) for (int j = k + 1; j < n; j++) A[i * n + j] -= A[i * n + k] * A[k * n + j];
+    }
+    for (int c = 0; c < n; c++) {
+        double col[6];
+        for (int i = 0; i < n; i++) col[i] = (i == c);
+        for (int k = 0; k < n; k++) if (rp[k] != k) std::swap(col[k], col[rp[k]]);
+        for (int k = 0; k < n; k++) for (int i = k + 1; i < n; i++) col[i] -= A[i * n + k] * col[k];
+        for (int k = n - 1; k >= 0; k--) { col[k] /= A[k * n + k]; for (int i = 0; i < k; i++) col[i] -= A[i * n + k] * col[k]; }
+        for (int k = n - 1; k >= 0; k--) if (cp[k] != k) std::swap(col[k], col[cp[k]]);
+        for (int i = 0; i < n; i++) inv[i * n + c] = col[i];
+    }
+}
+
+struct GeneResult {
+    std::string geneid = ".", top_categ = ".", top_snp = ".";
+    double chisq = -1.0, jepeg_pval = -1.0, top_categ_pval = -1.0, top_snp_pval = -1.0;
+    int df = 0, num_snp = 0;
+};
+
+static const char* categ_name(int c)       // Categ::GetName, gene.cpp:17-33
+{
+    static const char* nm[6] = {"PFS", "TFB", "STR", "TAR", "CIS", "TRN"};
+    return (c >= 0 && c < 6) ? nm[c] : "";
+}
+
+// Gene::RunJepeg + CalJepegPval tail (gene.cpp:88-185, 317-550) given CorG (n x n row-major)
+static GeneResult jepeg_tail(const std::vector<Snp*>& gs, const double* CorG, const Args& a)
+{
+    GeneResult r;
+    const int n = (int)gs.size();
+    r.num_snp = n;
+    int count[6] = {0, 0, 0, 0, 0, 0};
+    for (Snp* s : gs) for (auto& kv : s->categ) if (kv.first >= 0 && kv.first < 6) count[kv.first]++;
+    int cat[6], k = 0;
+    for (int c = 0; c < 6; c++) if (count[c]) cat[k++] = c;
+    if (n == 0 || k == 0) return r;
+    std::vector<double> W((size_t)k * n), WC((size_t)k * n);
+    for (int s = 0; s < n; s++)
+        for (int i = 0; i < k; i++) {
+            auto it = gs[s]->categ.find(cat[i]);
+            const double w = (it != gs[s]->categ.end()) ? it->second : 0.0;     // Snp::GetCategWgt
+            W[(size_t)i * n + s] = w * sqrt(gs[s]->info);                       // gene.cpp:871
+        }
+    double WWt[36], CovU[36], CorU[36], U[6], pv[6]; bool rmv[6];
+    for (int i = 0; i < k; i++) for (int j = 0; j < k; j++) {
+        double s = 0; for (int t = 0; t < n; t++) s += W[(size_t)i * n + t] * W[(size_t)j * n + t];
+        WWt[i * k + j] = s;
+    }
+    for (int i = 0; i < k; i++) for (int s = 0; s < n; s++) {
+        double v = 0; for (int t = 0; t < n; t++) v += W[(size_t)i * n + t] * CorG[(size_t)t * n + s];
+        WC[(size_t)i * n + s] = v;
+    }
+    for (int i = 0; i < k; i++) for (int j = 0; j < k; j++) {
+        double s = 0; for (int t = 0; t < n; t++) s += WC[(size_t)i * n + t] * W[(size_t)j * n + t];
+        CovU[i * k + j] = s;
+    }
+    for (int i = 0; i < k; i++) for (int j = i; j < k; j++) {          // CnvrtCovToCor, util.cpp:284-296
+        const double c = CovU[i * k + j] / (sqrt(CovU[i * k + i]) * sqrt(CovU[j * k + j]));
+        CorU[i * k + j] = c; CorU[j * k + i] = c;
+    }
+    for (int i = 0; i < k; i++) {
+        double s = 0; for (int t = 0; t < n; t++) s += W[(size_t)i * n + t] * gs[t]->z;
+        U[i] = s;
+        pv[i] = 2 * pnorm_upper(fabs(U[i] / sqrt(CovU[i * k + i])));      // gene.cpp:372-377
+        rmv[i] = false;
+    }
+    for (int j = k - 1; j > 0; j--)                                      // gene.cpp:391-399
+        for (int i = 0; i < j; i++) if (fabs(CorU[i * k + j]) > a.categ_cor_cutoff) { rmv[j] = true; break; }
+    for (int i = 0; i < k; i++) if (CovU[i * k + i] < WWt[i * k + i] / a.denorm_norm_w) rmv[i] = true;   // gene.cpp:408-414
+    int df = 0;
+    for (int i = 0; i < k; i++) if (!rmv[i]) df++;
+    r.df = df;
+    if (!df) return r;
+    double X[6], CovX[36], Inv[36];
+    int ii = 0;
+    for (int i = 0; i < k; i++) if (!rmv[i]) X[ii++] = U[i];
+    int nn = 0;
+    for (int i = 0; i < k; i++) { if (rmv[i]) continue; int mm = 0; for (int j = 0; j < k; j++) { if (rmv[j]) continue; CovX[nn * df + mm] = CovU[i * k + j]; mm++; } nn++; }
+    make_pos_def_small(df, CovX, a.min_abs_eig);                        // gene.cpp:493
+    inv_small(df, CovX, Inv);                                           // gene.cpp:494
+    double cs = 0;
+    for (int c = 0; c < df; c++) { double t = 0; for (int q = 0; q < df; q++) t += X[q] * Inv[q * df + c]; cs += t * X[c]; }
+    r.chisq = cs;
+    r.jepeg_pval = pchisq_upper(cs, df);                                // gene.cpp:509
+    int top = 0;                                                        // GetTopCateg, gene.cpp:880-891
+    for (int i = 0; i < k; i++) if ((pv[top] > pv[i]) & !rmv[i]) top = i;
+    r.top_categ = categ_name(cat[top]);
+    r.top_categ_pval = pv[top];
+    int ts = 0;                                                         // GetTopSNP, gene.cpp:894-904
+    for (int i = 0; i < n; i++) if (fabs(gs[ts]->z) < fabs(gs[i]->z)) ts = i;
+    r.top_snp = gs[ts]->rsid;
+    r.top_snp_pval = 2 * pnorm_upper(fabs(gs[ts]->z));
+    r.geneid = gs[0]->geneid;                                           // gene.cpp:524 (only when df > 0)
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------
+// outputs
+// ------------------------------------------------------------------------------------------
+static gauss_table* dist_output(gauss_prepared& p)     // dist.cpp:91-124 / distmix.cpp:100-133
+{
+    const Args& a = p.args;
+    const bool mix = p.kind == GAUSS_KIND_DISTMIX;
+    gauss_table* t = new gauss_table();
+    Column rsid{"rsid", GAUSS_COL_STR, {}, {}, {}}, chr{"chr", GAUSS_COL_INT, {}, {}, {}}, bp{"bp", GAUSS_COL_INT, {}, {}, {}};
+    Column a1{"a1", GAUSS_COL_STR, {}, {}, {}}, a2{"a2", GAUSS_COL_STR, {}, {}, {}};
+    Column af{mix ? "af1mix" : "af1ref", GAUSS_COL_DBL, {}, {}, {}}, z{"z", GAUSS_COL_DBL, {}, {}, {}};
+    Column pval{"pval", GAUSS_COL_DBL, {}, {}, {}}, info{"info", GAUSS_COL_DBL, {}, {}, {}}, type{"type", GAUSS_COL_INT, {}, {}, {}};
+    for (Snp* s : p.snp_vec) {
+        const int ibp = (int)s->bp;                               // dist.cpp:92
+        if (ibp >= a.start_bp && ibp <= a.end_bp) {
+            rsid.s.push_back(s->rsid); chr.i.push_back(s->chr); bp.i.push_back(ibp);
+            a1.s.push_back(s->a1); a2.s.push_back(s->a2);
+            af.d.push_back(mix ? s->af1mix : s->af1ref);
+            z.d.push_back(s->z);
+            pval.d.push_back(2 * pnorm_upper(fabs(s->z)));        // dist.cpp:101
+            info.d.push_back(s->info); type.i.push_back(s->type);
+        }
+    }
+    t->cols = {rsid, chr, bp, a1, a2, af, z, pval, info, type};
+    return t;
+}
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* gauss_host_last_error(void) { return g_err.c_str(); }
+
+int gauss_table_nrow(const gauss_table* t) { return t ? t->nrow() : 0; }
+int gauss_table_ncol(const gauss_table* t) { return t ? (int)t->cols.size() : 0; }
+const char* gauss_table_colname(const gauss_table* t, int c) { return (t && c >= 0 && c < (int)t->cols.size()) ? t->cols[c].name.c_str() : nullptr; }
+int gauss_table_coltype(const gauss_table* t, int c) { return (t && c >= 0 && c < (int)t->cols.size()) ? t->cols[c].type : -1; }
+const char* gauss_table_str(const gauss_table* t, int c, int r)
+{
+    if (!t || c < 0 || c >= (int)t->cols.size() || t->cols[c].type != GAUSS_COL_STR || r < 0 || r >= (int)t->cols[c].s.size()) return nullptr;
+    return t->cols[c].s[r].c_str();
+}
+const int32_t* gauss_table_int(const gauss_table* t, int c) { return (t && c >= 0 && c < (int)t->cols.size() && t->cols[c].type == GAUSS_COL_INT) ? t->cols[c].i.data() : nullptr; }
+const double* gauss_table_dbl(const gauss_table* t, int c) { return (t && c >= 0 && c < (int)t->cols.size() && t->cols[c].type == GAUSS_COL_DBL) ? t->cols[c].d.data() : nullptr; }
+const double* gauss_table_matrix(const gauss_table* t, int* n) { if (!t || t->matrix.empty()) { if (n) *n = 0; return nullptr; } if (n) *n = t->matrix_n; return t->matrix.data(); }
+void gauss_table_free(gauss_table* t) { delete t; }
+
+// Re-block a BGZF text file line by line (exercises reader + writer; used by tests and by tools that
+// rewrite panels).  Returns the number of lines copied, or -1.
+int64_t gauss_host_bgzf_copy(const char* in_path, const char* out_path)
+{
+    BgzfReader r;
+    if (!in_path || !out_path || !r.open(in_path)) return herr("can't open '%s'", in_path ? in_path : "(null)");
+    gauss_host::BgzfWriter w;
+    if (!w.open(out_path)) return herr("can't create '%s'", out_path);
+    std::string line;
+    int64_t n = 0;
+    for (;;) {
+        const int last = r.getline(line);
+        if (last == -2) return herr("codec error in '%s'", in_path);
+        if (last == -1 && line.empty()) break;
+        line.push_back('\n');
+        if (!w.write(line.data(), line.size())) return herr("write error");
+        n++;
+        if (last == -1) break;
+    }
+    if (!w.close()) return herr("write error");
+    return n;
+}
+
+int gauss_host_prepare(int kind, int chr, int64_t start_bp, int64_t end_bp, int64_t wing_size, const char* study_pop,
+                       const char* const* pop_names, const double* pop_wgts, int n_pop_wgt, const char* input_file,
+                       const char* annotation_file, const char* reference_index_file, const char* reference_data_file,
+                       const char* reference_pop_desc_file, double af1_cutoff, gauss_prepared** out)
+{
+    if (!out) return herr("out is NULL");
+    if (kind < 0 || kind > 4) return herr("bad kind %d", kind);
+    if (!input_file || !reference_index_file || !reference_data_file || !reference_pop_desc_file) return herr("file name is NULL");
+    std::unique_ptr<gauss_prepared> p(new gauss_prepared());
+    p->kind = kind;
+    Args& a = p->args;
+    a.chr = chr; a.start_bp = start_bp; a.end_bp = end_bp;
+    a.wing_size = (kind == GAUSS_KIND_COMPUTELD) ? 0 : wing_size;       // computeLD.cpp:40
+    if (study_pop) a.study_pop = study_pop;
+    a.input_file = input_file; a.reference_index_file = reference_index_file;
+    a.reference_data_file = reference_data_file; a.reference_pop_desc_file = reference_pop_desc_file;
+    if (annotation_file) a.annotation_file = annotation_file;
+    a.af1_cutoff = std::isnan(af1_cutoff) ? 0.01 : af1_cutoff;          // dist.cpp:53-57
+    const bool mix = (kind == GAUSS_KIND_COMPUTELD || kind == GAUSS_KIND_DISTMIX || kind == GAUSS_KIND_JEPEGMIX);
+    if (mix) {
+        if (!pop_names || !pop_wgts || n_pop_wgt < 1) return herr("pop_wgt_df is empty");
+        set_pop_wgt_map(a, pop_names, pop_wgts, n_pop_wgt);
+    } else if (!study_pop) return herr("study_pop is NULL");
+    if ((kind == GAUSS_KIND_JEPEG || kind == GAUSS_KIND_JEPEGMIX) && !annotation_file) return herr("annotation_file is NULL");
+    if (prepare(*p)) return -1;
+    *out = p.release();
+    return 0;
+}
+
+const gauss_table* gauss_prepared_snps(const gauss_prepared* p) { return p ? &p->snps : nullptr; }
+int gauss_prepared_counts(const gauss_prepared* p, int* m, int* u, int* n, int* np, int* ng)
+{
+    if (!p) return herr("prepared is NULL");
+    if (m) *m = (int)p->measured.size();
+    if (u) *u = (int)p->unmeasured.size();
+    if (n) *n = p->N;
+    if (np) *np = (int)p->pop_off.size() - 1;
+    if (ng) *ng = p->gene_off.empty() ? 0 : (int)p->gene_off.size() - 1;
+    return 0;
+}
+const int32_t* gauss_prepared_measured_rows(const gauss_prepared* p) { return p ? p->measured_rows.data() : nullptr; }
+const int32_t* gauss_prepared_unmeasured_rows(const gauss_prepared* p) { return p ? p->unmeasured_rows.data() : nullptr; }
+const uint8_t* gauss_prepared_geno_m(const gauss_prepared* p, int64_t* ld) { if (!p) return nullptr; if (ld) *ld = p->ld; return p->gm.data(); }
+const uint8_t* gauss_prepared_geno_u(const gauss_prepared* p, int64_t* ld) { if (!p) return nullptr; if (ld) *ld = p->ld; return p->gu.data(); }
+const int32_t* gauss_prepared_pop_off(const gauss_prepared* p) { return p ? p->pop_off.data() : nullptr; }
+const double* gauss_prepared_pop_wgt(const gauss_prepared* p) { return p ? p->pop_wgt.data() : nullptr; }
+const double* gauss_prepared_z1(const gauss_prepared* p) { return p ? p->z1.data() : nullptr; }
+const int32_t* gauss_prepared_gene_off(const gauss_prepared* p) { return (p && !p->gene_off.empty()) ? p->gene_off.data() : nullptr; }
+void gauss_prepared_free(gauss_prepared* p) { delete p; }
+
+int gauss_prepared_window_desc(gauss_prepared* p, gauss_window_desc* d)
+{
+    if (!p || !d) return herr("bad arguments");
+    if (p->kind != GAUSS_KIND_DIST && p->kind != GAUSS_KIND_DISTMIX) return herr("not an imputation window");
+    const Args& a = p->args;
+    const int M = (int)p->measured.size(), U = (int)p->unmeasured.size();
+    if (M <= a.min_num_measured_snp || U <= a.min_num_unmeasured_snp)      // dist.cpp:145-151
+        return herr("Not enough number of SNPs loaded - %s not performed (measured %d, unmeasured %d)",
+                    p->kind == GAUSS_KIND_DIST ? "DIST" : "DISTMIX", M, U);
+    p->out_z.assign(U, 0.0); p->out_info.assign(U, 0.0);
+    memset(d, 0, sizeof(*d));
+    d->mode = (p->kind == GAUSS_KIND_DIST) ? GAUSS_MODE_POOLED : GAUSS_MODE_WEIGHTED;
+    d->n_pop = (int)p->pop_off.size() - 1;
+    d->pop_off = p->pop_off.data(); d->pop_wgt = p->pop_wgt.data();
+    d->n_measured = M; d->n_unmeasured = U;
+    d->geno_m = p->gm.data(); d->geno_u = p->gu.data(); d->ld = p->ld;
+    d->z1 = p->z1.data(); d->lambda = a.lambda; d->min_abs_eig = a.min_abs_eig;
+    d->out_z = p->out_z.data(); d->out_info = p->out_info.data(); d->out_status = &p->status;
+    return 0;
+}
+
+int gauss_prepared_finish(gauss_prepared* p, gauss_table** out)
+{
+    if (!p || !out) return herr("bad arguments");
+    for (size_t i = 0; i < p->unmeasured.size() && i < p->out_z.size(); i++) {   // dist.cpp:200-202
+        p->unmeasured[i]->z = p->out_z[i];
+        p->unmeasured[i]->info = p->out_info[i];
+    }
+    *out = dist_output(*p);
+    return 0;
+}
+
+static int run_impute(gauss_ctx* ctx, int kind, int chr, int64_t start_bp, int64_t end_bp, int64_t wing, const char* study_pop,
+                      const char* const* names, const double* wgts, int nw, const char* input, const char* index,
+                      const char* data, const char* desc, double af1_cutoff, gauss_table** out)
+{
+    if (!ctx || !out) return herr("bad arguments");
+    gauss_prepared* p = nullptr;
+    if (gauss_host_prepare(kind, chr, start_bp, end_bp, wing, study_pop, names, wgts, nw, input, nullptr, index, data, desc, af1_cutoff, &p)) return -1;
+    std::unique_ptr<gauss_prepared> hold(p);
+    gauss_window_desc d;
+    if (gauss_prepared_window_desc(p, &d)) return -1;
+    if (gauss_impute_window(ctx, &d) != 0) return herr("%s", gauss_last_error());
+    return gauss_prepared_finish(p, out);
+}
+
+int gauss_host_dist(gauss_ctx* ctx, int chr, int64_t start_bp, int64_t end_bp, int64_t wing_size, const char* study_pop,
+                    const char* input_file, const char* reference_index_file, const char* reference_data_file,
+                    const char* reference_pop_desc_file, double af1_cutoff, gauss_table** out)
+{
+    return run_impute(ctx, GAUSS_KIND_DIST, chr, start_bp, end_bp, wing_size, study_pop, nullptr, nullptr, 0, input_file,
+                      reference_index_file, reference_data_file, reference_pop_desc_file, af1_cutoff, out);
+}
+
+int gauss_host_distmix(gauss_ctx* ctx, int chr, int64_t start_bp, int64_t end_bp, int64_t wing_size,
+                       const char* const* pop_names, const double* pop_wgts, int n_pop_wgt, const char* input_file,
+                       const char* reference_index_file, const char* reference_data_file, const char* reference_pop_desc_file,
+                       double af1_cutoff, gauss_table** out)
+{
+    return run_impute(ctx, GAUSS_KIND_DISTMIX, chr, start_bp, end_bp, wing_size, nullptr, pop_names, pop_wgts, n_pop_wgt,
+                      input_file, reference_index_file, reference_data_file, reference_pop_desc_file, af1_cutoff, out);
+}
+
+int gauss_host_computeLD(gauss_ctx* ctx, int chr, int64_t start_bp, int64_t end_bp, const char* const* pop_names,
+                         const double* pop_wgts, int n_pop_wgt, const char* input_file, const char* reference_index_file,
+                         const char* reference_data_file, const char* reference_pop_desc_file, double af1_cutoff,
+                         gauss_table** out)
+{
+    if (!ctx || !out) return herr("bad arguments");
+    gauss_prepared* p = nullptr;
+    if (gauss_host_prepare(GAUSS_KIND_COMPUTELD, chr, start_bp, end_bp, 0, nullptr, pop_names, pop_wgts, n_pop_wgt, input_file,
+                           nullptr, reference_index_file, reference_data_file, reference_pop_desc_file, af1_cutoff, &p)) return -1;
+    std::unique_ptr<gauss_prepared> hold(p);
+    const int M = (int)p->measured.size();
+    if (M <= p->args.min_num_measured_snp)                               // computeLD.cpp:89-93
+        return herr("Not enough number of SNPs loaded - computeLD not performed (measured %d)", M);
+    std::unique_ptr<gauss_table> t(new gauss_table());
+    t->matrix.assign((size_t)M * M, 0.0);
+    t->matrix_n = M;
+    if (gauss_ld(ctx, GAUSS_MODE_WEIGHTED, p->gm.data(), M, p->ld, p->pop_off.data(), p->pop_wgt.data(),
+                 (int)p->pop_off.size() - 1, 1.0, t->matrix.data()) != 0) return herr("%s", gauss_last_error());
+    Column rsid{"rsid", GAUSS_COL_STR, {}, {}, {}}, chrc{"chr", GAUSS_COL_INT, {}, {}, {}}, bp{"bp", GAUSS_COL_INT, {}, {}, {}};
+    Column a1{"a1", GAUSS_COL_STR, {}, {}, {}}, a2{"a2", GAUSS_COL_STR, {}, {}, {}}, af{"af1mix", GAUSS_COL_DBL, {}, {}, {}};
+    for (Snp* s : p->measured) {                                        // computeLD.cpp:134-149
+        rsid.s.push_back(s->rsid); chrc.i.push_back(s->chr); bp.i.push_back((int)s->bp);
+        a1.s.push_back(s->a1); a2.s.push_back(s->a2); af.d.push_back(s->af1mix);
+    }
+    t->cols = {rsid, chrc, bp, a1, a2, af};
+    *out = t.release();
+    return 0;
+}
+
+static int run_jepeg(gauss_ctx* ctx, int kind, const char* study_pop, const char* const* names, const double* wgts, int nw,
+                     const char* input, const char* annotation, const char* index, const char* data, const char* desc,
+                     double af1_cutoff, gauss_table** out)
+{
+    if (!ctx || !out) return herr("bad arguments");
+    gauss_prepared* p = nullptr;
+    if (gauss_host_prepare(kind, 0, 0, 0, 0, study_pop, names, wgts, nw, input, annotation, index, data, desc, af1_cutoff, &p)) return -1;
+    std::unique_ptr<gauss_prepared> hold(p);
+    const Args& a = p->args;
+    const int S = (int)p->measured.size();
+    const int ng = p->gene_off.empty() ? 0 : (int)p->gene_off.size() - 1;
+    std::vector<double> blocks;
+    std::vector<size_t> boff;
+    size_t tot = 0;
+    for (int g = 0; g < ng; g++) { boff.push_back(tot); const size_t n = p->gene_off[g + 1] - p->gene_off[g]; tot += n * n; }
+    blocks.assign(std::max<size_t>(tot, 1), 0.0);
+    if (S > 0 && ng > 0) {
+        // CorG of every gene in one launch, diagonal 1 + lambda (gene.cpp:306-315 / 576-586)
+        const int mode = (kind == GAUSS_KIND_JEPEG) ? GAUSS_MODE_POOLED : GAUSS_MODE_WEIGHTED;
+        if (gauss_gene_ld_batch(ctx, mode, p->gm.data(), S, p->ld, p->pop_off.data(), p->pop_wgt.data(),
+                                (int)p->pop_off.size() - 1, p->gene_off.data(), ng, 1.0 + a.lambda, blocks.data()) != 0)
+            return herr("%s", gauss_last_error());
+    }
+    std::unique_ptr<gauss_table> t(new gauss_table());
+    Column geneid{"geneid", GAUSS_COL_STR, {}, {}, {}}, chisq{"chisq", GAUSS_COL_DBL, {}, {}, {}}, df{"df", GAUSS_COL_INT, {}, {}, {}};
+    Column jp{"jepeg_pval", GAUSS_COL_DBL, {}, {}, {}}, ns{"num_snp", GAUSS_COL_INT, {}, {}, {}}, tc{"top_categ", GAUSS_COL_STR, {}, {}, {}};
+    Column tcp{"top_categ_pval", GAUSS_COL_DBL, {}, {}, {}}, ts{"top_snp", GAUSS_COL_STR, {}, {}, {}}, tsp{"top_snp_pval", GAUSS_COL_DBL, {}, {}, {}};
+    for (int g = 0; g < ng; g++) {
+        std::vector<Snp*> gs(p->measured.begin() + p->gene_off[g], p->measured.begin() + p->gene_off[g + 1]);
+        const GeneResult r = jepeg_tail(gs, blocks.data() + boff[g], a);
+        geneid.s.push_back(r.geneid); chisq.d.push_back(r.chisq); df.i.push_back(r.df); jp.d.push_back(r.jepeg_pval);
+        ns.i.push_back(r.num_snp); tc.s.push_back(r.top_categ); tcp.d.push_back(r.top_categ_pval);
+        ts.s.push_back(r.top_snp); tsp.d.push_back(r.top_snp_pval);
+    }
+    t->cols = {geneid, chisq, df, jp, ns, tc, tcp, ts, tsp};          // jepeg.cpp:143-151
+    *out = t.release();
+    return 0;
+}
+
+int gauss_host_jepeg(gauss_ctx* ctx, const char* study_pop, const char* input_file, const char* annotation_file,
+                     const char* reference_index_file, const char* reference_data_file, const char* reference_pop_desc_file,
+                     double af1_cutoff, gauss_table** out)
+{
+    return run_jepeg(ctx, GAUSS_KIND_JEPEG, study_pop, nullptr, nullptr, 0, input_file, annotation_file, reference_index_file,
+                     reference_data_file, reference_pop_desc_file, af1_cutoff, out);
+}
+
+int gauss_host_jepegmix(gauss_ctx* ctx, const char* const* pop_names, const double* pop_wgts, int n_pop_wgt,
+                        const char* input_file, const char* annotation_file, const char* reference_index_file,
+                        const char* reference_data_file, const char* reference_pop_desc_file, double af1_cutoff,
+                        gauss_table** out)
+{
+    return run_jepeg(ctx, GAUSS_KIND_JEPEGMIX, nullptr, pop_names, pop_wgts, n_pop_wgt, input_file, annotation_file,
+                     reference_index_file, reference_data_file, reference_pop_desc_file, af1_cutoff, out);
+}
+
+}  // extern "C"

@@ -1,0 +1,144 @@
+"""Writers for the reference's on-disk formats, used to build synthetic panels.
+
+* population description: header + ``pop_abbr n_subj super_pop``           (gauss.cpp:970-984)
+* panel data  (BGZF text): one line per SNP = P genotype strings + P allele frequencies
+                                                                          (gauss.cpp:755-763, 660-674)
+* panel index (BGZF text): ``rsid chr bp a1 a2 af1ref fpos``, fpos = BGZF virtual offset of the
+  SNP's data line                                                          (gauss.cpp:328-330)
+* GWAS input: header + ``rsid chr bp a1 a2 z``                            (gauss.cpp:146-152)
+* annotation: header + ``rsid chr bp a1 a2 geneid categ wgt``             (gauss.cpp:1308)
+
+BGZF = concatenated gzip members (<= 64 KiB each) with a "BC" extra field; a virtual offset is
+(member file offset << 16) | offset inside the member (bgzf.c:702-727).
+"""
+import struct
+import zlib
+
+import numpy as np
+
+_BLOCK = 0xFF00
+
+
+class BgzfTextWriter:
+    def __init__(self, path, level=6):
+        self.f = open(path, "wb")
+        self.level = level
+        self.buf = bytearray()
+        self.addr = 0
+
+    def tell(self):
+        return (self.addr << 16) | len(self.buf)
+
+    def write(self, data: bytes):
+        mv = memoryview(data)
+        while len(mv):
+            room = _BLOCK - len(self.buf)
+            take = min(room, len(mv))
+            self.buf += mv[:take]
+            mv = mv[take:]
+            if len(self.buf) == _BLOCK:
+                self._flush()
+
+    def _flush(self):
+        raw = bytes(self.buf)
+        co = zlib.compressobj(self.level, zlib.DEFLATED, -15)
+        comp = co.compress(raw) + co.flush()
+        total = len(comp) + 26
+        hdr = struct.pack("<BBBBIBBHBBHH", 31, 139, 8, 4, 0, 0, 255, 6, 66, 67, 2, total - 1)
+        self.f.write(hdr + comp + struct.pack("<II", zlib.crc32(raw) & 0xFFFFFFFF, len(raw)))
+        self.addr += total
+        self.buf = bytearray()
+
+    def close(self):
+        if self.buf:
+            self._flush()
+        self._flush()          # empty member = BGZF end-of-file marker
+        self.f.close()
+
+
+def write_pop_desc(path, pops):
+    with open(path, "w") as f:
+        f.write("Population_Abbreviation Number_of_Subjects Super_Population\n")
+        for abbr, n, sup in pops:
+            f.write(f"{abbr} {n} {sup}\n")
+
+
+def write_panel(index_path, data_path, rsid, chr_, bp, a1, a2, G, af, pop_sizes):
+    """G: uint8 [S, N] genotypes over ALL panel populations (panel order); af: [S, P]."""
+    off = np.concatenate([[0], np.cumsum(pop_sizes)]).astype(int)
+    dw = BgzfTextWriter(data_path)
+    iw = BgzfTextWriter(index_path)
+    asc = (np.asarray(G, dtype=np.uint8) + ord("0"))
+    for s in range(len(rsid)):
+        fpos = dw.tell()
+        row = asc[s].tobytes()
+        parts = [row[off[k]:off[k + 1]] for k in range(len(pop_sizes))]
+        line = b" ".join(parts) + b" " + " ".join(repr(float(x)) for x in af[s]).encode() + b"\n"
+        dw.write(line)
+        af1ref = float(np.asarray(G[s], dtype=np.float64).sum() / (2.0 * G.shape[1]))
+        iw.write(f"{rsid[s]} {chr_[s]} {bp[s]} {a1[s]} {a2[s]} {af1ref:.6f} {fpos}\n".encode())
+    dw.close()
+    iw.close()
+
+
+def write_gwas(path, rsid, chr_, bp, a1, a2, z):
+    with open(path, "w") as f:
+        f.write("rsid chr bp a1 a2 z\n")
+        for i in range(len(rsid)):
+            f.write(f"{rsid[i]} {chr_[i]} {bp[i]} {a1[i]} {a2[i]} {float(z[i])!r}\n")
+
+
+def write_annotation(path, rows):
+    """rows: iterable of (rsid, chr, bp, a1, a2, geneid, categ, wgt)."""
+    with open(path, "w") as f:
+        f.write("rsid chr bp a1 a2 geneid categ wgt\n")
+        for r in rows:
+            f.write(" ".join(str(x) if not isinstance(x, float) else repr(x) for x in r) + "\n")
+
+
+CATEGS = ["PROTEIN", "TFBS", "WTH_HAIR", "WTH_TARGET", "CIS_EQTL", "TRANS_EQTL"]
+
+
+def make_synthetic_study(outdir, pops, n_snp=400, chr_=22, bp_lo=1_000_000, bp_hi=3_000_000, frac_measured=0.35,
+                         frac_swapped=0.1, frac_not_in_panel=0.02, n_genes=0, seed=11, prefix="syn"):
+    """Write a complete synthetic study (panel + GWAS [+ annotation]) and return its description."""
+    import os
+    from . import synth
+    rng = np.random.default_rng(seed)
+    bp = np.sort(rng.choice(np.arange(bp_lo, bp_hi), size=n_snp, replace=False))
+    G, af = synth.synth_genotypes(bp, pops, seed=seed + 1)
+    alle = np.array(list("ACGT"))
+    a1 = alle[rng.integers(0, 4, n_snp)]
+    a2 = alle[(np.searchsorted(alle, a1) + rng.integers(1, 4, n_snp)) % 4]
+    rsid = np.array([f"rs{100000 + i}" for i in range(n_snp)])
+    chrs = np.full(n_snp, chr_)
+    sizes = [p[1] for p in pops]
+    paths = {k: os.path.join(outdir, f"{prefix}_{k}") for k in ("desc.txt", "index.gz", "data.gz", "gwas.txt", "annot.txt")}
+    write_pop_desc(paths["desc.txt"], pops)
+    write_panel(paths["index.gz"], paths["data.gz"], rsid, chrs, bp, a1, a2, G, af, sizes)
+    meas = np.nonzero(rng.random(n_snp) < frac_measured)[0]
+    z = rng.standard_normal(len(meas)) * 2.0
+    g_rsid, g_chr, g_bp, g_a1, g_a2 = rsid[meas].copy(), chrs[meas].copy(), bp[meas].copy(), a1[meas].copy(), a2[meas].copy()
+    swap = rng.random(len(meas)) < frac_swapped          # GWAS reports the alleles the other way round
+    g_a1[swap], g_a2[swap] = a2[meas][swap], a1[meas][swap]
+    n_extra = int(round(len(meas) * frac_not_in_panel))  # GWAS SNPs the panel does not have (type 2)
+    if n_extra:
+        ebp = rng.choice(np.setdiff1d(np.arange(bp_lo, bp_hi), bp), size=n_extra, replace=False)
+        g_rsid = np.concatenate([g_rsid, [f"rsX{i}" for i in range(n_extra)]])
+        g_chr = np.concatenate([g_chr, np.full(n_extra, chr_)])
+        g_bp = np.concatenate([g_bp, ebp])
+        g_a1 = np.concatenate([g_a1, np.full(n_extra, "A")])
+        g_a2 = np.concatenate([g_a2, np.full(n_extra, "G")])
+        z = np.concatenate([z, rng.standard_normal(n_extra)])
+    order = rng.permutation(len(g_rsid))                 # GWAS files are not position sorted
+    write_gwas(paths["gwas.txt"], g_rsid[order], g_chr[order], g_bp[order], g_a1[order], g_a2[order], z[order])
+    annot = []
+    if n_genes:
+        for g in range(n_genes):
+            k = int(rng.integers(1, 9))
+            for s in rng.choice(meas, size=min(k, len(meas)), replace=False):
+                for c in rng.choice(6, size=int(rng.integers(1, 3)), replace=False):
+                    annot.append((rsid[s], int(chrs[s]), int(bp[s]), a1[s], a2[s], f"GENE{g:03d}", CATEGS[c],
+                                  float(np.round(rng.uniform(0.2, 2.0), 3))))
+        write_annotation(paths["annot.txt"], annot)
+    return dict(paths=paths, bp=bp, rsid=rsid, a1=a1, a2=a2, G=G, af=af, pops=pops, measured=meas, annot=annot)

@@ -1,0 +1,125 @@
+/*
+ * gauss_host.h -- C ABI of libgauss_host.so: the host side of the hot path, i.e. the five
+ * reference entry points with their reference argument lists, in plain C.
+ *
+ *   reference (Rcpp, src/RcppExports.cpp:335-340)          here
+ *   -----------------------------------------------------  ------------------------------
+ *   computeLD(chr,start_bp,end_bp,pop_wgt_df,input_file,    gauss_host_computeLD
+ *             reference_index_file,reference_data_file,
+ *             reference_pop_desc_file,af1_cutoff)           computeLD.cpp:26-166
+ *   dist(chr,start_bp,end_bp,wing_size,study_pop,...)       gauss_host_dist      dist.cpp:30-126
+ *   distmix(chr,start_bp,end_bp,wing_size,pop_wgt_df,...)   gauss_host_distmix   distmix.cpp:30-135
+ *   jepeg(study_pop,input_file,annotation_file,...)         gauss_host_jepeg     jepeg.cpp:28-153
+ *   jepegmix(pop_wgt_df,input_file,annotation_file,...)     gauss_host_jepegmix  jepegmix.cpp:26-161
+ *
+ * Same argument meaning, same defaults (af1_cutoff NaN = R's NULL -> 0.01, dist.cpp:53-57), same
+ * row order (std::map order on (chr,bp,a1,a2), gauss.h:72-99), same column names and types as
+ * the reference's DataFrames, same error texts (returned through gauss_host_last_error instead of
+ * Rcpp::stop).  A pop_wgt_df is passed as two parallel arrays (names, weights).
+ *
+ * The host data layer (text + BGZF readers, allele matching, AF filters, window partition:
+ * src/gauss.cpp:121-190, 293-399, 431-518, 543-604, 631-693, 720-785, 951-1117, 1275-1439) is
+ * restated here in C++; the numeric part is delegated to libgauss_hip.so (include/gauss_hip.h).
+ * The *_prepare functions run the host part alone (no GPU needed) and expose what would be handed
+ * to the GPU; the farm harness and the CPU tests use them.
+ */
+#ifndef GAUSS_HOST_H
+#define GAUSS_HOST_H
+
+#include <stdint.h>
+
+#include "gauss_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gauss_table gauss_table;     /* a result DataFrame (column store)            */
+typedef struct gauss_prepared gauss_prepared; /* one window/gene set after the host data layer */
+
+#define GAUSS_COL_STR 0
+#define GAUSS_COL_INT 1
+#define GAUSS_COL_DBL 2
+
+#define GAUSS_KIND_COMPUTELD 0
+#define GAUSS_KIND_DIST      1
+#define GAUSS_KIND_DISTMIX   2
+#define GAUSS_KIND_JEPEG     3
+#define GAUSS_KIND_JEPEGMIX  4
+
+const char* gauss_host_last_error(void);
+
+/* ---- result tables --------------------------------------------------------------------------- */
+int gauss_table_nrow(const gauss_table* t);
+int gauss_table_ncol(const gauss_table* t);
+const char* gauss_table_colname(const gauss_table* t, int col);
+int gauss_table_coltype(const gauss_table* t, int col);
+const char* gauss_table_str(const gauss_table* t, int col, int row);
+const int32_t* gauss_table_int(const gauss_table* t, int col);
+const double* gauss_table_dbl(const gauss_table* t, int col);
+/* computeLD's `cormat` (n x n, symmetric); NULL for the other tables */
+const double* gauss_table_matrix(const gauss_table* t, int* n);
+void gauss_table_free(gauss_table* t);
+
+/* ---- the five entry points (blocking; ctx from gauss_hip_init) -------------------------------- */
+int gauss_host_computeLD(gauss_ctx* ctx, int chr, int64_t start_bp, int64_t end_bp,
+                         const char* const* pop_names, const double* pop_wgts, int n_pop_wgt,
+                         const char* input_file, const char* reference_index_file,
+                         const char* reference_data_file, const char* reference_pop_desc_file,
+                         double af1_cutoff, gauss_table** out);
+int gauss_host_dist(gauss_ctx* ctx, int chr, int64_t start_bp, int64_t end_bp, int64_t wing_size,
+                    const char* study_pop, const char* input_file, const char* reference_index_file,
+                    const char* reference_data_file, const char* reference_pop_desc_file,
+                    double af1_cutoff, gauss_table** out);
+int gauss_host_distmix(gauss_ctx* ctx, int chr, int64_t start_bp, int64_t end_bp, int64_t wing_size,
+                       const char* const* pop_names, const double* pop_wgts, int n_pop_wgt,
+                       const char* input_file, const char* reference_index_file,
+                       const char* reference_data_file, const char* reference_pop_desc_file,
+                       double af1_cutoff, gauss_table** out);
+int gauss_host_jepeg(gauss_ctx* ctx, const char* study_pop, const char* input_file,
+                     const char* annotation_file, const char* reference_index_file,
+                     const char* reference_data_file, const char* reference_pop_desc_file,
+                     double af1_cutoff, gauss_table** out);
+int gauss_host_jepegmix(gauss_ctx* ctx, const char* const* pop_names, const double* pop_wgts,
+                        int n_pop_wgt, const char* input_file, const char* annotation_file,
+                        const char* reference_index_file, const char* reference_data_file,
+                        const char* reference_pop_desc_file, double af1_cutoff, gauss_table** out);
+
+/* Re-block a BGZF text file line by line (reader + writer round trip); returns lines copied or -1. */
+int64_t gauss_host_bgzf_copy(const char* in_path, const char* out_path);
+
+/* ---- host data layer only (no GPU) ----------------------------------------------------------- */
+/* Runs everything up to and including ReadGenotype + the measured/unmeasured partition.
+ * kind = GAUSS_KIND_*; arguments that a kind does not take are ignored (pass 0/NULL). */
+int gauss_host_prepare(int kind, int chr, int64_t start_bp, int64_t end_bp, int64_t wing_size,
+                       const char* study_pop, const char* const* pop_names, const double* pop_wgts,
+                       int n_pop_wgt, const char* input_file, const char* annotation_file,
+                       const char* reference_index_file, const char* reference_data_file,
+                       const char* reference_pop_desc_file, double af1_cutoff,
+                       gauss_prepared** out);
+/* SNP list after the AF filter (snp_vec of the reference), columns:
+ * rsid chr bp a1 a2 af1 z info type fpos geneid */
+const gauss_table* gauss_prepared_snps(const gauss_prepared* p);
+int gauss_prepared_counts(const gauss_prepared* p, int* n_measured, int* n_unmeasured,
+                          int* n_samples, int* n_pop, int* n_gene);
+/* row indices (into the SNP list) of the measured / unmeasured SNPs, in matrix row order */
+const int32_t* gauss_prepared_measured_rows(const gauss_prepared* p);
+const int32_t* gauss_prepared_unmeasured_rows(const gauss_prepared* p);
+/* genotype matrices exactly as they go to gauss_impute_window / gauss_ld (ASCII digits) */
+const uint8_t* gauss_prepared_geno_m(const gauss_prepared* p, int64_t* ld);
+const uint8_t* gauss_prepared_geno_u(const gauss_prepared* p, int64_t* ld);
+const int32_t* gauss_prepared_pop_off(const gauss_prepared* p);
+const double* gauss_prepared_pop_wgt(const gauss_prepared* p);
+const double* gauss_prepared_z1(const gauss_prepared* p);
+const int32_t* gauss_prepared_gene_off(const gauss_prepared* p);
+/* Fill a window descriptor for gauss_job_create from a prepared dist/distmix window; the outputs
+ * point into the prepared object and are written back into its SNP list by gauss_prepared_finish. */
+int gauss_prepared_window_desc(gauss_prepared* p, gauss_window_desc* out);
+/* After the GPU results are in: build the reference's output DataFrame (dist.cpp:91-124). */
+int gauss_prepared_finish(gauss_prepared* p, gauss_table** out);
+void gauss_prepared_free(gauss_prepared* p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GAUSS_HOST_H */

@@ -1,0 +1,344 @@
+"""Python restatement of the reference's host data layer + drivers -- TEST INFRASTRUCTURE ONLY.
+
+Follows src/gauss.cpp (ReadInputZ 121-190, ReadReferenceIndex 293-399, ReadReferenceIndexAll
+431-518, MakeSnpVec 543-604, MakeSnpVecMix 631-693, ReadGenotype 720-785, read_ref_desc 951-993,
+init_pop_flag_vec 1019-1066, init_pop_flag_wgt_vec 1093-1117, ReadAnnotation 1275-1361,
+MakeGeneStartEndVec 1383-1439) and the drivers (computeLD.cpp, dist.cpp, distmix.cpp, jepeg.cpp,
+jepegmix.cpp); the numeric part calls the C oracle.  Written independently of
+gauss_amd/csrc/host (C++), so agreement between the two checks both.
+"""
+import math
+import struct
+import zlib
+
+import numpy as np
+
+from . import oracle_c as oc
+
+
+class Bgzf:
+    """Minimal BGZF text reader with virtual-offset seek (bgzf.c:702-727 convention)."""
+
+    def __init__(self, path):
+        self.f = open(path, "rb")
+        self.addr = None
+        self.data = b""
+        self.next = 0
+
+    def _load(self, addr):
+        self.f.seek(addr)
+        hdr = self.f.read(12)
+        if len(hdr) < 12:
+            self.addr, self.data, self.next = addr, b"", addr
+            return
+        xlen = struct.unpack("<H", hdr[10:12])[0]
+        extra = self.f.read(xlen)
+        bsize, p = None, 0
+        while p + 4 <= xlen:
+            slen = struct.unpack("<H", extra[p + 2:p + 4])[0]
+            if extra[p:p + 2] == b"BC":
+                bsize = struct.unpack("<H", extra[p + 4:p + 6])[0]
+            p += 4 + slen
+        total = bsize + 1
+        comp = self.f.read(total - 12 - xlen - 8)
+        self.f.read(8)
+        self.addr, self.data, self.next = addr, zlib.decompress(comp, -15), addr + total
+
+    def line_at(self, voff):
+        """The text line starting at virtual offset voff ('' past EOF, like the reference)."""
+        if voff < 0:
+            return ""
+        addr, off = voff >> 16, voff & 0xFFFF
+        if self.addr != addr:
+            self._load(addr)
+        out = b""
+        while True:
+            if not self.data:
+                return out.decode()
+            i = self.data.find(b"\n", off)
+            if i >= 0:
+                return (out + self.data[off:i]).decode()
+            out += self.data[off:]
+            self._load(self.next)
+            off = 0
+
+    def lines(self):
+        addr = 0
+        buf = b""
+        while True:
+            self._load(addr)
+            if not self.data:
+                break
+            buf += self.data
+            addr = self.next
+        text = buf.decode()
+        return text.split("\n")[:-1] if text.endswith("\n") else text.split("\n")
+
+
+class Snp:
+    def __init__(self):
+        self.rsid, self.chr, self.bp, self.a1, self.a2 = ".", -1, -1, ".", "."
+        self.af1mix = self.af1ref = -1.0
+        self.z, self.info, self.type, self.fpos = 0.0, -1.0, -1, -1
+        self.geneid, self.categ, self.geno = ".", {}, None
+
+
+class Args:
+    lam, min_abs_eig = 0.1, 1e-5
+    min_measured = min_unmeasured = 10
+    categ_cor_cutoff, denorm_norm_w = 0.8, 3
+
+
+def read_ref_desc(path):
+    pops = []
+    with open(path) as f:
+        f.readline()
+        for line in f:
+            t = line.split()
+            if len(t) >= 3:
+                pops.append((t[0], int(t[1]), t[2]))
+    return pops
+
+
+def pop_flags(pops, study_pop):
+    names, sups = [p[0] for p in pops], [p[2] for p in pops]
+    in_pop, in_sup = names.count(study_pop), sups.count(study_pop)
+    if in_pop == 0 and in_sup == 0:
+        raise ValueError(f"ERROR: invalid population name '{study_pop}'")
+    pv = names if in_pop else sups
+    return [1 if x == study_pop else 0 for x in pv]
+
+
+def pop_flags_wgt(pops, names, wgts):
+    m = {str(n).upper(): float(w) for n, w in zip(names, wgts)}
+    flags, w = [], []
+    for p in pops:
+        if p[0] in m:
+            flags.append(1)
+            w.append(m[p[0]])
+        else:
+            flags.append(0)
+    return flags, w
+
+
+def read_input_z(path, chr_, lo, hi, All):
+    m = {}
+    with open(path) as f:
+        f.readline()
+        for line in f:
+            t = line.split()
+            if len(t) < 6:
+                continue
+            rsid, c, bp, a1, a2, z = t[0], int(t[1]), int(t[2]), t[3], t[4], float(t[5])
+            if not All:
+                if chr_ > 0 and chr_ != c:
+                    continue
+                if lo > bp or hi < bp:
+                    continue
+            s = Snp()
+            s.rsid, s.chr, s.bp, s.a1, s.a2, s.z, s.info, s.type = rsid, c, bp, a1, a2, z, 1.0, 2
+            m[(c, bp, a1, a2)] = s
+    return m
+
+
+def read_reference_index(m, path, chr_, lo, hi, All):
+    for line in Bgzf(path).lines():
+        t = line.split()
+        if len(t) < 7:
+            continue
+        rsid, c, bp, a1, a2, fpos = t[0], int(t[1]), int(t[2]), t[3], t[4], int(t[6])
+        if not All:
+            if chr_ > 0 and chr_ != c:
+                continue
+            if lo > bp or hi < bp:
+                continue
+        k1, k2 = (c, bp, a1, a2), (c, bp, a2, a1)
+        i1, i2 = k1 in m, k2 in m
+        if i1 and not i2:
+            s = m[k1]
+            s.rsid, s.type, s.fpos = rsid, 1, fpos
+        elif i2 and not i1:
+            s = m.pop(k2)
+            s.rsid, s.a1, s.a2, s.z, s.type, s.fpos = rsid, a1, a2, -s.z, 1, fpos
+            m[k1] = s
+        elif not i1 and not i2:
+            if not All:
+                s = Snp()
+                s.rsid, s.chr, s.bp, s.a1, s.a2, s.type, s.fpos = rsid, c, bp, a1, a2, 0, fpos
+                m[k1] = s
+        else:
+            raise ValueError("ERROR: input file contains duplicates")
+
+
+CATEG = {"PROTEIN": 0, "TFBS": 1, "WTH_HAIR": 2, "WTH_TARGET": 3, "CIS_EQTL": 4, "TRANS_EQTL": 5}
+
+
+def read_annotation(m, path):
+    num = 0
+    with open(path) as f:
+        f.readline()
+        for line in f:
+            t = line.split()
+            if len(t) < 8:
+                continue
+            c, bp, a1, a2, geneid, categ, wgt = int(t[1]), int(t[2]), t[3], t[4], t[5], t[6], float(t[7])
+            num = CATEG.get(categ, num)
+            k1, k2 = (c, bp, a1, a2), (c, bp, a2, a1)
+            if k1 in m and k2 not in m:
+                m[k1].geneid = geneid
+                m[k1].categ[num] = wgt
+            elif k1 not in m and k2 in m:
+                s = m.pop(k2)
+                s.a1, s.a2, s.af1ref, s.z, s.geneid = a1, a2, 1 - s.af1ref, -s.z, geneid
+                s.categ[num] = wgt
+                m[k1] = s
+
+
+def _parse_line(line, flags):
+    t = line.split()
+    P = len(flags)
+    geno = [t[k] if k < len(t) else "" for k in range(P)]
+    afs = [float(t[P + k]) if P + k < len(t) else 0.0 for k in range(P)]
+    return [g for g, f in zip(geno, flags) if f], [a for a, f in zip(afs, flags) if f]
+
+
+def make_snp_vec(m, data_path, flags, cutoff, wgt=None):
+    """MakeSnpVec (wgt None) / MakeSnpVecMix; also caches the genotype strings (ReadGenotype)."""
+    bg = Bgzf(data_path)
+    out = []
+    for key in sorted(m.keys()):
+        s = m[key]
+        geno, afs = _parse_line(bg.line_at(s.fpos), flags)
+        s.geno = geno
+        if wgt is None:
+            n = sum(len(g) for g in geno)
+            cnt = float(sum(sum(ord(ch) - 48 for ch in g) for g in geno))
+            af = cnt / (2 * n) if n else float("nan")
+            af = math.ceil(af * 100000.0) / 100000.0 if af == af else af
+            s.af1ref = af
+            if af > cutoff and af < 1 - cutoff:
+                out.append(s)
+        else:
+            af = 0.0
+            for a, w in zip(afs, wgt):
+                af += a * w
+            if af > cutoff and af < 1 - cutoff:
+                s.af1mix = af
+                out.append(s)
+    return out
+
+
+def _matrix(snps):
+    if not snps:
+        return np.zeros((0, 0), dtype=np.uint8)
+    return np.array([np.frombuffer("".join(s.geno).encode(), dtype=np.uint8) for s in snps])
+
+
+def _selected_off(pops, flags):
+    off = [0]
+    for p, f in zip(pops, flags):
+        if f:
+            off.append(off[-1] + p[1])
+    return np.array(off, dtype=np.int32)
+
+
+def _impute(kind_mix, chr_, start_bp, end_bp, wing, study_pop, pop_wgt, files, af1_cutoff):
+    input_file, index, data, desc = files
+    cutoff = 0.01 if af1_cutoff is None else af1_cutoff
+    pops = read_ref_desc(desc)
+    if kind_mix:
+        flags, w = pop_flags_wgt(pops, *pop_wgt)
+    else:
+        flags, w = pop_flags(pops, study_pop), None
+    lo, hi = start_bp - wing, end_bp + wing
+    m = read_input_z(input_file, chr_, lo, hi, False)
+    read_reference_index(m, index, chr_, lo, hi, False)
+    vec = make_snp_vec(m, data, flags, cutoff, w)
+    meas = [s for s in vec if s.type == 1]
+    unme = [s for s in vec if s.type == 0 and start_bp <= s.bp <= end_bp]
+    if len(meas) <= Args.min_measured or len(unme) <= Args.min_unmeasured:
+        raise ValueError("Not enough number of SNPs loaded")
+    off = _selected_off(pops, flags)
+    res = oc.run_impute(1 if kind_mix else 0, _matrix(meas), _matrix(unme), off, w, [s.z for s in meas],
+                        Args.lam, Args.min_abs_eig)
+    for s, z, info in zip(unme, res["z"], res["info"]):
+        s.z, s.info = float(z), float(info)
+    rows = [s for s in vec if start_bp <= s.bp <= end_bp]
+    return dict(rsid=[s.rsid for s in rows], chr=[s.chr for s in rows], bp=[s.bp for s in rows],
+                a1=[s.a1 for s in rows], a2=[s.a2 for s in rows],
+                af=[(s.af1mix if kind_mix else s.af1ref) for s in rows], z=[s.z for s in rows],
+                pval=[2 * oc.pnorm_upper(abs(s.z)) for s in rows], info=[s.info for s in rows],
+                type=[s.type for s in rows], n_measured=len(meas), n_unmeasured=len(unme), mpd=res["mpd"])
+
+
+def dist(chr_, start_bp, end_bp, wing, study_pop, input_file, index, data, desc, af1_cutoff=None):
+    return _impute(False, chr_, start_bp, end_bp, wing, study_pop, None, (input_file, index, data, desc), af1_cutoff)
+
+
+def distmix(chr_, start_bp, end_bp, wing, pop_wgt, input_file, index, data, desc, af1_cutoff=None):
+    return _impute(True, chr_, start_bp, end_bp, wing, None, pop_wgt, (input_file, index, data, desc), af1_cutoff)
+
+
+def computeLD(chr_, start_bp, end_bp, pop_wgt, input_file, index, data, desc, af1_cutoff=None):
+    cutoff = 0.01 if af1_cutoff is None else af1_cutoff
+    pops = read_ref_desc(desc)
+    flags, w = pop_flags_wgt(pops, *pop_wgt)
+    m = read_input_z(input_file, chr_, start_bp, end_bp, False)
+    read_reference_index(m, index, chr_, start_bp, end_bp, False)
+    vec = make_snp_vec(m, data, flags, cutoff, w)
+    meas = [s for s in vec if s.type == 1]
+    if len(meas) <= Args.min_measured:
+        raise ValueError("Not enough number of SNPs loaded")
+    cor = oc.compute_ld(_matrix(meas), _selected_off(pops, flags), w)
+    return dict(rsid=[s.rsid for s in meas], bp=[s.bp for s in meas], a1=[s.a1 for s in meas],
+                a2=[s.a2 for s in meas], af1mix=[s.af1mix for s in meas], cormat=cor)
+
+
+def _jepeg(kind_mix, study_pop, pop_wgt, input_file, annot, index, data, desc, af1_cutoff):
+    cutoff = 0.01 if af1_cutoff is None else af1_cutoff
+    pops = read_ref_desc(desc)
+    if kind_mix:
+        flags, w = pop_flags_wgt(pops, *pop_wgt)
+    else:
+        flags, w = pop_flags(pops, study_pop), None
+    m = read_input_z(input_file, 0, 0, 0, True)
+    read_reference_index(m, index, 0, 0, 0, True)
+    read_annotation(m, annot)
+    vec = make_snp_vec(m, data, flags, cutoff, w)
+    gsnps = [s for s in vec if s.geneid != "." and s.type == 1]
+    gsnps.sort(key=lambda s: s.geneid)      # std::sort is unstable: order inside a gene may differ
+    off = _selected_off(pops, flags)
+    out = []
+    i = 0
+    while i < len(gsnps):
+        j = i
+        while j < len(gsnps) and gsnps[j].geneid == gsnps[i].geneid:
+            j += 1
+        gs = gsnps[i:j]
+        G = _matrix(gs)
+        if kind_mix:
+            corg = oc.compute_ld(G, off, w)
+            np.fill_diagonal(corg, 1.0 + Args.lam)
+        else:
+            corg = oc.ld_pooled(G, off, 1.0 + Args.lam)
+        has = np.zeros((len(gs), 6), dtype=np.int32)
+        wg = np.zeros((len(gs), 6))
+        for r, s in enumerate(gs):
+            for c, v in s.categ.items():
+                has[r, c], wg[r, c] = 1, v
+        r = oc.jepeg_gene_tail(corg, [s.z for s in gs], [s.info for s in gs], has, wg, Args.min_abs_eig,
+                               Args.categ_cor_cutoff, Args.denorm_norm_w)
+        r["geneid"] = gs[0].geneid if r["df"] else "."
+        r["snps"] = sorted(s.rsid for s in gs)
+        r["top_snp_id"] = gs[r["top_snp"]].rsid if r["top_snp"] >= 0 else "."
+        out.append(r)
+        i = j
+    return out
+
+
+def jepeg(study_pop, input_file, annot, index, data, desc, af1_cutoff=None):
+    return _jepeg(False, study_pop, None, input_file, annot, index, data, desc, af1_cutoff)
+
+
+def jepegmix(pop_wgt, input_file, annot, index, data, desc, af1_cutoff=None):
+    return _jepeg(True, None, pop_wgt, input_file, annot, index, data, desc, af1_cutoff)

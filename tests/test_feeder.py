@@ -1,0 +1,177 @@
+"""CPU suite: the C++ host data layer (libgauss_host.so) against the Python restatement of the
+reference feeder (oracle/feeder_py.py), and the BGZF codec against the reference's own bgzf.c
+(oracle/_ref/libref_bgzf.so, compiled from /root/reference/src/bgzf.c where that tree exists)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from gauss_amd import api, panel, synth
+from oracle import feeder_py as fp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+POPS = [("AAA", 60, "EUR"), ("BBB", 45, "EUR"), ("CCC", 70, "ASN"), ("DDD", 33, "AFR"), ("EEE", 52, "EUR")]
+WGT = (["aaa", "CCC", "eee", "ZZZ"], [0.5, 0.3, 0.25, 0.4])       # lower case + a population the panel lacks
+
+
+@pytest.fixture(scope="module")
+def study(tmp_path_factory):
+    d = tmp_path_factory.mktemp("study")
+    return panel.make_synthetic_study(str(d), POPS, n_snp=420, bp_lo=1_000_000, bp_hi=2_600_000, n_genes=25, seed=5)
+
+
+def _files(st):
+    p = st["paths"]
+    return p["gwas.txt"], p["index.gz"], p["data.gz"], p["desc.txt"]
+
+
+def test_bgzf_against_reference_codec(study, tmp_path):
+    ref = os.path.join(ROOT, "oracle", "_ref", "libref_bgzf.so")
+    if not os.path.exists(ref):
+        pytest.skip("oracle/_ref not built (no /root/reference here)")
+    lib = C.CDLL(ref)
+    lib.bgzf_open.restype = C.c_void_p
+    lib.bgzf_open.argtypes = [C.c_char_p, C.c_char_p]
+    lib.bgzf_read.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    lib.bgzf_seek.restype = C.c_int64
+    lib.bgzf_seek.argtypes = [C.c_void_p, C.c_int64, C.c_int]
+    lib.bgzf_close.argtypes = [C.c_void_p]
+
+    def ref_read_all(path):
+        h = lib.bgzf_open(path.encode(), b"r")
+        assert h
+        out, buf = b"", C.create_string_buffer(1 << 16)
+        while True:
+            n = lib.bgzf_read(h, buf, 1 << 16)
+            assert n >= 0
+            if n == 0:
+                break
+            out += buf.raw[:n]
+        lib.bgzf_close(h)
+        return out
+
+    data = study["paths"]["data.gz"]
+    want = ref_read_all(data)                                   # the reference codec reads our writer's file
+    ours = "\n".join(fp.Bgzf(data).lines()) + "\n"
+    assert ours.encode() == want
+    # every fpos in the index is a valid virtual offset for the reference's bgzf_seek
+    h = lib.bgzf_open(data.encode(), b"r")
+    idx = [l.split() for l in fp.Bgzf(study["paths"]["index.gz"]).lines()]
+    buf = C.create_string_buffer(64)
+    for t in idx[::37]:
+        assert lib.bgzf_seek(h, int(t[6]), 0) == 0
+        assert lib.bgzf_read(h, buf, 32) == 32
+        line = fp.Bgzf(data).line_at(int(t[6]))
+        assert buf.raw[:32] == line.encode()[:32]
+    lib.bgzf_close(h)
+    # C++ reader + writer round trip, then read back by the reference codec
+    out = str(tmp_path / "copy.gz")
+    n = api.load_host().gauss_host_bgzf_copy(data.encode(), out.encode())
+    assert n == len(idx)
+    assert ref_read_all(out) == want
+
+
+def _check_prepared(pr, exp_vec, exp_meas, exp_unme, mix):
+    df = pr.snps()
+    assert list(df["rsid"]) == [s.rsid for s in exp_vec]
+    assert list(df["bp"]) == [s.bp for s in exp_vec]
+    assert list(df["a1"]) == [s.a1 for s in exp_vec] and list(df["a2"]) == [s.a2 for s in exp_vec]
+    assert list(df["type"]) == [s.type for s in exp_vec]
+    assert np.array_equal(df["z"].to_numpy(), np.array([s.z for s in exp_vec]))
+    af = df["af1mix" if mix else "af1ref"].to_numpy()
+    assert np.array_equal(af, np.array([(s.af1mix if mix else s.af1ref) for s in exp_vec]))
+    assert pr.M == len(exp_meas) and pr.U == len(exp_unme)
+    rs = list(df["rsid"])
+    assert [rs[i] for i in pr.measured_rows()] == [s.rsid for s in exp_meas]
+    assert [rs[i] for i in pr.unmeasured_rows()] == [s.rsid for s in exp_unme]
+    assert np.array_equal(pr.geno_m(), fp._matrix(exp_meas))
+    if exp_unme:
+        assert np.array_equal(pr.geno_u(), fp._matrix(exp_unme))
+    assert np.array_equal(pr.z1(), np.array([s.z for s in exp_meas]))
+
+
+@pytest.mark.parametrize("mix", [False, True])
+def test_prepare_window_matches_python_feeder(study, mix):
+    inp, idx, dat, desc = _files(study)
+    chr_, lo, hi, wing = 22, 1_400_000, 2_000_000, 250_000
+    pops = fp.read_ref_desc(desc)
+    if mix:
+        flags, w = fp.pop_flags_wgt(pops, *WGT)
+    else:
+        flags, w = fp.pop_flags(pops, "EUR"), None
+    m = fp.read_input_z(inp, chr_, lo - wing, hi + wing, False)
+    fp.read_reference_index(m, idx, chr_, lo - wing, hi + wing, False)
+    vec = fp.make_snp_vec(m, dat, flags, 0.01, w)
+    meas = [s for s in vec if s.type == 1]
+    unme = [s for s in vec if s.type == 0 and lo <= s.bp <= hi]
+    assert any(s.type == 2 for s in m.values())                  # GWAS-only SNPs exist and drop out (quirk Q6)
+    pr = api.Prepared(api.KIND_DISTMIX if mix else api.KIND_DIST, chr=chr_, start_bp=lo, end_bp=hi, wing_size=wing,
+                      study_pop=None if mix else "EUR", pop_wgt_df=WGT if mix else None, input_file=inp,
+                      reference_index_file=idx, reference_data_file=dat, reference_pop_desc_file=desc)
+    _check_prepared(pr, vec, meas, unme, mix)
+    assert np.array_equal(pr.pop_off(), fp._selected_off(pops, flags))
+    if mix:
+        assert np.array_equal(pr.pop_wgt(), np.array(w))          # panel order, unknown "ZZZ" ignored
+        assert pr.P == 3
+    # allele-swapped GWAS SNPs adopt the panel's alleles and flip z (gauss.cpp:358-370)
+    flipped = [s for s in meas if s.rsid in set(study["rsid"])]
+    assert flipped
+    pr.close()
+
+
+def test_prepare_jepeg_matches_python_feeder(study):
+    inp, idx, dat, desc = _files(study)
+    ann = study["paths"]["annot.txt"]
+    pops = fp.read_ref_desc(desc)
+    flags = fp.pop_flags(pops, "EUR")
+    m = fp.read_input_z(inp, 0, 0, 0, True)
+    fp.read_reference_index(m, idx, 0, 0, 0, True)
+    fp.read_annotation(m, ann)
+    vec = fp.make_snp_vec(m, dat, flags, 0.01, None)
+    gs = sorted([s for s in vec if s.geneid != "." and s.type == 1], key=lambda s: s.geneid)
+    pr = api.Prepared(api.KIND_JEPEG, study_pop="EUR", input_file=inp, annotation_file=ann, reference_index_file=idx,
+                      reference_data_file=dat, reference_pop_desc_file=desc)
+    df = pr.snps()
+    assert list(df["rsid"]) == [s.rsid for s in vec]
+    assert list(df["geneid"]) == [s.geneid for s in vec]
+    rs, gid = list(df["rsid"]), list(df["geneid"])
+    rows = pr.measured_rows()
+    go = pr.gene_off()
+    genes = {}
+    for g in range(pr.n_gene):
+        ids = {gid[i] for i in rows[go[g]:go[g + 1]]}
+        assert len(ids) == 1
+        genes[ids.pop()] = sorted(rs[i] for i in rows[go[g]:go[g + 1]])
+    want = {}
+    for s in gs:
+        want.setdefault(s.geneid, []).append(s.rsid)
+    assert genes == {k: sorted(v) for k, v in want.items()}
+    assert list(np.diff(go) > 0) == [True] * pr.n_gene
+    pr.close()
+
+
+def test_error_texts_follow_the_reference(study):
+    inp, idx, dat, desc = _files(study)
+    with pytest.raises(api.GaussError, match="invalid population name 'XYZ'"):
+        api.Prepared(api.KIND_DIST, chr=22, start_bp=1, end_bp=2, study_pop="XYZ", input_file=inp,
+                     reference_index_file=idx, reference_data_file=dat, reference_pop_desc_file=desc)
+    with pytest.raises(api.GaussError, match="can't open input file"):
+        api.Prepared(api.KIND_DIST, chr=22, start_bp=1, end_bp=2, study_pop="EUR", input_file=inp + ".nope",
+                     reference_index_file=idx, reference_data_file=dat, reference_pop_desc_file=desc)
+    pr = api.Prepared(api.KIND_DIST, chr=22, start_bp=1_000_000, end_bp=1_010_000, wing_size=0, study_pop="EUR",
+                      input_file=inp, reference_index_file=idx, reference_data_file=dat, reference_pop_desc_file=desc)
+    with pytest.raises(api.GaussError, match="Not enough number of SNPs loaded - DIST not performed"):
+        pr.window_desc()                                          # dist.cpp:145-151
+    pr.close()
+
+
+def test_host_header_symbols_exported():
+    import re
+    src = open(os.path.join(ROOT, "include", "gauss_host.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(gauss_[a-z_A-Z0-9]+)\s*\(", src)))
+    assert sorted(api.HOST_SYMBOLS) == declared
+    h = api.load_host()
+    for s in declared:
+        assert hasattr(h, s)

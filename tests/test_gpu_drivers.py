@@ -1,0 +1,98 @@
+"""GPU: the five reference entry points end to end (files -> C++ host layer -> HIP -> table) against
+the Python restatement of the reference drivers running the CPU oracle on the same files."""
+import numpy as np
+import pytest
+
+from gauss_amd import api, panel
+from oracle import feeder_py as fp
+
+pytestmark = pytest.mark.gpu
+
+POPS = [("AAA", 160, "EUR"), ("BBB", 145, "EUR"), ("CCC", 170, "ASN"), ("DDD", 133, "AFR"), ("EEE", 152, "EUR"),
+        ("FFF", 90, "ASN")]
+WGT = (["aaa", "CCC", "eee", "FFF", "zzz"], [0.45, 0.2, 0.25, 0.161, 0.3])
+
+
+@pytest.fixture(scope="module")
+def study(tmp_path_factory):
+    d = tmp_path_factory.mktemp("study")
+    return panel.make_synthetic_study(str(d), POPS, n_snp=700, bp_lo=1_000_000, bp_hi=2_400_000, n_genes=40,
+                                      frac_measured=0.3, seed=17)
+
+
+def _files(st):
+    p = st["paths"]
+    return p["gwas.txt"], p["index.gz"], p["data.gz"], p["desc.txt"]
+
+
+def _cmp_impute(df, want, afcol):
+    assert list(df.columns) == ["rsid", "chr", "bp", "a1", "a2", afcol, "z", "pval", "info", "type"]
+    assert list(df["rsid"]) == want["rsid"] and list(df["bp"]) == want["bp"]
+    assert list(df["a1"]) == want["a1"] and list(df["a2"]) == want["a2"] and list(df["type"]) == want["type"]
+    assert np.array_equal(df[afcol].to_numpy(), np.array(want["af"]))
+    z, wz = df["z"].to_numpy(), np.array(want["z"])
+    assert np.max(np.abs(z - wz) / np.maximum(1.0, np.abs(wz))) <= 1e-8
+    assert np.max(np.abs(df["info"].to_numpy() - np.array(want["info"])) / np.array(want["info"])) <= 1e-8
+    wp = np.array(want["pval"])
+    assert np.max(np.abs(df["pval"].to_numpy() - wp) / wp) <= 1e-6
+    meas = df["type"].to_numpy() == 1
+    assert np.all(df["info"].to_numpy()[meas] == 1.0)              # measured SNPs keep info 1 (gauss.cpp:142)
+    assert (df["type"].to_numpy() == 0).sum() == want["n_unmeasured"]
+
+
+def test_dist_end_to_end(ctx, study):
+    args = (22, 1_500_000, 2_000_000, 300_000, "EUR") + _files(study)
+    df = api.dist(*args, ctx=ctx)
+    _cmp_impute(df, fp.dist(*args), "af1ref")
+
+
+def test_distmix_end_to_end(ctx, study):
+    args = (22, 1_500_000, 2_000_000, 300_000, WGT) + _files(study)
+    df = api.distmix(*args, af1_cutoff=0.02, ctx=ctx)
+    _cmp_impute(df, fp.distmix(*args, af1_cutoff=0.02), "af1mix")
+
+
+def test_computeLD_end_to_end(ctx, study):
+    args = (22, 1_200_000, 2_300_000, WGT) + _files(study)
+    got = api.computeLD(*args, ctx=ctx)
+    want = fp.computeLD(*args)
+    sl = got["snplist"]
+    assert list(sl.columns) == ["rsid", "chr", "bp", "a1", "a2", "af1mix"]
+    assert list(sl["rsid"]) == want["rsid"] and np.array_equal(sl["af1mix"].to_numpy(), np.array(want["af1mix"]))
+    assert got["cormat"].shape == want["cormat"].shape
+    assert np.max(np.abs(got["cormat"] - want["cormat"])) <= 1e-12
+    assert np.all(np.diag(got["cormat"]) == 1.0)
+
+
+@pytest.mark.parametrize("mix", [False, True])
+def test_jepeg_end_to_end(ctx, study, mix):
+    inp, idx, dat, desc = _files(study)
+    ann = study["paths"]["annot.txt"]
+    if mix:
+        df = api.jepegmix(WGT, inp, ann, idx, dat, desc, ctx=ctx)
+        want = fp.jepegmix(WGT, inp, ann, idx, dat, desc)
+    else:
+        df = api.jepeg("EUR", inp, ann, idx, dat, desc, ctx=ctx)
+        want = fp.jepeg("EUR", inp, ann, idx, dat, desc)
+    assert list(df.columns) == ["geneid", "chisq", "df", "jepeg_pval", "num_snp", "top_categ", "top_categ_pval",
+                                "top_snp", "top_snp_pval"]
+    assert len(df) == len(want) and len(df) > 10
+    names = ["PFS", "TFB", "STR", "TAR", "CIS", "TRN"]
+    for i, w in enumerate(want):
+        r = df.iloc[i]
+        assert r["num_snp"] == w["num_snp"] and r["df"] == w["df"] and r["geneid"] == w["geneid"]
+        if w["df"]:
+            assert abs(r["chisq"] - w["chisq"]) <= 1e-8 * max(1.0, abs(w["chisq"]))
+            assert abs(r["jepeg_pval"] - w["jepeg_pval"]) <= 1e-7 * w["jepeg_pval"] + 1e-300
+            assert r["top_categ"] == names[w["top_categ"]]
+            assert abs(r["top_categ_pval"] - w["top_categ_pval"]) <= 1e-7 * w["top_categ_pval"] + 1e-300
+            assert r["top_snp"] == w["top_snp_id"]
+        else:
+            assert r["chisq"] == -1.0 and r["jepeg_pval"] == -1.0 and r["top_categ"] == "." and r["top_snp"] == "."
+
+
+def test_not_enough_snps_is_an_error(ctx, study):
+    with pytest.raises(api.GaussError, match="Not enough number of SNPs loaded - DISTMIX not performed"):
+        api.distmix(22, 1_000_000, 1_005_000, 0, WGT, *_files(study), ctx=ctx)
+    with pytest.raises(api.GaussError, match="Not enough number of SNPs loaded - computeLD not performed"):
+        api.computeLD(22, 1_000_000, 1_005_000, WGT, *_files(study), ctx=ctx)
