@@ -1,0 +1,141 @@
+"""Window farm: tile a chromosome into prediction windows and spread them over the GPUs of a node.
+
+The reference imputes one window per R call (dist.cpp:30-126 builds and destroys everything per
+call); the caller-level loop over windows is not part of it.  Windows are independent units
+(SURVEY.md section 8e), so the farm shards them across ranks with no data-path collective: one
+process per GPU, every rank runs its windows as one batched job, and only the finished tables are
+gathered (torch.distributed, RCCL/gloo) and concatenated in window order on rank 0.
+"""
+import numpy as np
+
+from . import api, hotpath
+
+
+def make_windows(start_bp, end_bp, window_size=1_000_000):
+    """Prediction windows [s, s + window_size - 1] covering [start_bp, end_bp]."""
+    out = []
+    s = int(start_bp)
+    while s <= end_bp:
+        out.append((s, min(int(end_bp), s + int(window_size) - 1)))
+        s += int(window_size)
+    return out
+
+
+def assign_windows(costs, world_size):
+    """Longest-processing-time assignment of windows to ranks; deterministic on every rank.
+    Returns a list (len = n windows) of owning ranks."""
+    order = sorted(range(len(costs)), key=lambda i: (-costs[i], i))
+    load = [0.0] * world_size
+    owner = [0] * len(costs)
+    for i in order:
+        r = min(range(world_size), key=lambda k: (load[k], k))
+        owner[i] = r
+        load[r] += costs[i]
+    return owner
+
+
+def window_cost(n_samples, m, u):
+    """Pair-loop cost of one window: N * (M(M+1)/2 + U*M)."""
+    return float(n_samples) * (m * (m + 1) / 2.0 + float(u) * m)
+
+
+def gpu_compute(prepared_list, ctx=None):
+    """Run the prepared windows as ONE batched job on this rank's GPU; returns one table per window."""
+    if not prepared_list:
+        return []
+    ctx = ctx or hotpath.default_context()
+    lib = ctx.lib
+    import ctypes as C
+    descs = (hotpath.WindowDesc * len(prepared_list))()
+    for i, p in enumerate(prepared_list):
+        d = p.window_desc()
+        C.memmove(C.byref(descs[i]), C.byref(d), C.sizeof(d))
+    h = C.c_void_p()
+    hotpath.check(lib.gauss_job_create(ctx.handle, descs, len(prepared_list), 0, C.byref(h)))
+    try:
+        hotpath.check(lib.gauss_job_run(h))
+        hotpath.check(lib.gauss_job_fetch(h))
+    finally:
+        lib.gauss_job_destroy(h)
+    return [p.finish() for p in prepared_list]
+
+
+def impute_chromosome(kind, chr, start_bp, end_bp, wing_size, input_file, reference_index_file, reference_data_file,
+                      reference_pop_desc_file, study_pop=None, pop_wgt_df=None, af1_cutoff=None,
+                      window_size=1_000_000, compute=gpu_compute, group=None):
+    """dist()/distmix() over every window of [start_bp, end_bp], sharded across the ranks of `group`.
+
+    kind: api.KIND_DIST or api.KIND_DISTMIX.  Returns on rank 0 (or the single process) a dict
+    {"table": DataFrame of all windows in window order, "skipped": [(window, reason), ...]};
+    other ranks return None.  Windows that fail the reference's ">10 measured / >10 unmeasured"
+    guard (dist.cpp:145-151) are reported in "skipped" instead of aborting the run.
+    """
+    import pandas as pd
+    dist = None
+    rank, world = 0, 1
+    try:
+        import torch.distributed as dist_mod
+        if dist_mod.is_available() and dist_mod.is_initialized():
+            dist = dist_mod
+            rank, world = dist.get_rank(group), dist.get_world_size(group)
+    except ImportError:     # pragma: no cover
+        pass
+
+    windows = make_windows(start_bp, end_bp, window_size)
+    # cheap, rank-independent cost estimate from the GWAS file alone (measured SNP density)
+    bp = _gwas_positions(input_file, chr)
+    costs = []
+    for s, e in windows:
+        m = int(np.count_nonzero((bp >= s - wing_size) & (bp <= e + wing_size)))
+        costs.append(m * m + 1.0)
+    owner = assign_windows(costs, world)
+
+    mine = [i for i in range(len(windows)) if owner[i] == rank]
+    prepared, ok_idx, skipped = [], [], []
+    for i in mine:
+        s, e = windows[i]
+        try:
+            p = api.Prepared(kind, chr=chr, start_bp=s, end_bp=e, wing_size=wing_size, study_pop=study_pop,
+                             pop_wgt_df=pop_wgt_df, input_file=input_file, reference_index_file=reference_index_file,
+                             reference_data_file=reference_data_file, reference_pop_desc_file=reference_pop_desc_file,
+                             af1_cutoff=af1_cutoff)
+            if p.M <= 10 or p.U <= 10:
+                skipped.append((i, f"Not enough number of SNPs loaded (measured {p.M}, unmeasured {p.U})"))
+                p.close()
+                continue
+            prepared.append(p)
+            ok_idx.append(i)
+        except api.GaussError as ex:
+            skipped.append((i, str(ex)))
+    tables = compute(prepared)
+    for p in prepared:
+        p.close()
+    local = {"tables": dict(zip(ok_idx, tables)), "skipped": skipped}
+
+    if dist is not None and world > 1:
+        gathered = [None] * world if rank == 0 else None
+        dist.gather_object(local, gathered, dst=0, group=group)
+        if rank != 0:
+            return None
+        parts = gathered
+    else:
+        parts = [local]
+    by_window, skipped_all = {}, []
+    for part in parts:
+        by_window.update(part["tables"])
+        skipped_all += part["skipped"]
+    frames = [by_window[i] for i in sorted(by_window)]
+    table = pd.concat(frames, ignore_index=True) if frames else pd.DataFrame()
+    return {"table": table, "skipped": sorted((windows[i], why) for i, why in skipped_all),
+            "windows": windows, "owner": owner}
+
+
+def _gwas_positions(path, chr):
+    bp = []
+    with open(path) as f:
+        f.readline()
+        for line in f:
+            t = line.split()
+            if len(t) >= 3 and (chr <= 0 or int(t[1]) == chr):
+                bp.append(int(t[2]))
+    return np.array(bp, dtype=np.int64)

@@ -1,0 +1,122 @@
+"""Window farm: sharding plan, and the N > 1 path under gloo on CPU (world_size 2).
+
+The CPU ranks cannot run the HIP library, so the farm's `compute` hook is replaced by the CPU
+oracle here (allowed: tests may use the oracle as the checker); what is under test is the
+sharding, the per-rank batching and the gather/concatenate step -- the part that differs between
+1 and N ranks.  The GPU compute itself is covered by test_gpu_farm_single_rank (-m gpu)."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from gauss_amd import api, farm, panel
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+POPS = [("AAA", 120, "EUR"), ("BBB", 95, "EUR"), ("CCC", 110, "ASN"), ("DDD", 83, "AFR")]
+WGT = (["AAA", "CCC", "DDD"], [0.5, 0.3, 0.261])
+
+
+def oracle_compute(prepared_list):
+    import oracle
+    out = []
+    for p in prepared_list:
+        d = p.window_desc()
+        mode = d.mode
+        res = oracle.run_impute(mode, p.geno_m(), p.geno_u(), p.pop_off(), p.pop_wgt(), p.z1())
+        C.memmove(d.out_z, res["z"].ctypes.data, 8 * p.U)
+        C.memmove(d.out_info, res["info"].ctypes.data, 8 * p.U)
+        out.append(p.finish())
+    return out
+
+
+def make_study(d):
+    return panel.make_synthetic_study(str(d), POPS, n_snp=900, bp_lo=1_000_000, bp_hi=4_000_000, frac_measured=0.3, seed=23)
+
+
+def test_assign_windows_is_balanced_and_deterministic():
+    costs = [9.0, 1.0, 8.0, 2.0, 7.0, 3.0, 6.0, 4.0]
+    own = farm.assign_windows(costs, 2)
+    assert own == farm.assign_windows(list(costs), 2)
+    load = [sum(c for c, o in zip(costs, own) if o == r) for r in (0, 1)]
+    assert abs(load[0] - load[1]) <= 2.0
+    assert farm.make_windows(1, 2_500_000, 1_000_000) == [(1, 1_000_000), (1_000_001, 2_000_000), (2_000_001, 2_500_000)]
+
+
+def test_farm_single_process_matches_per_window_calls(tmp_path):
+    st = make_study(tmp_path)
+    p = st["paths"]
+    files = dict(input_file=p["gwas.txt"], reference_index_file=p["index.gz"], reference_data_file=p["data.gz"],
+                 reference_pop_desc_file=p["desc.txt"])
+    res = farm.impute_chromosome(api.KIND_DISTMIX, 22, 1_000_001, 4_000_000, 200_000, pop_wgt_df=WGT,
+                                 compute=oracle_compute, **files)
+    tab = res["table"]
+    assert len(res["windows"]) == 3 and not res["skipped"]
+    assert list(tab["bp"]) == sorted(tab["bp"])                   # window order = position order
+    from oracle import feeder_py as fp
+    want_bp = []
+    for s, e in res["windows"]:
+        w = fp.distmix(22, s, e, 200_000, WGT, p["gwas.txt"], p["index.gz"], p["data.gz"], p["desc.txt"])
+        want_bp += w["bp"]
+    assert list(tab["bp"]) == want_bp
+
+
+WORKER = r"""
+import os, sys, pickle
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import torch.distributed as dist
+from gauss_amd import api, farm
+from test_farm import oracle_compute, WGT
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:{port}", rank=int(sys.argv[1]), world_size=2)
+files = pickle.load(open({files!r}, "rb"))
+res = farm.impute_chromosome(api.KIND_DISTMIX, 22, 1_000_001, 4_000_000, 200_000, pop_wgt_df=WGT,
+                             compute=oracle_compute, window_size=500_000, **files)
+if dist.get_rank() == 0:
+    pickle.dump(dict(bp=list(res["table"]["bp"]), z=list(res["table"]["z"]), owner=res["owner"],
+                     skipped=res["skipped"]), open({out!r}, "wb"))
+else:
+    assert res is None
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_farm_two_ranks_gloo_equals_one_rank(tmp_path):
+    import pickle
+    st = make_study(tmp_path)
+    p = st["paths"]
+    files = dict(input_file=p["gwas.txt"], reference_index_file=p["index.gz"], reference_data_file=p["data.gz"],
+                 reference_pop_desc_file=p["desc.txt"])
+    one = farm.impute_chromosome(api.KIND_DISTMIX, 22, 1_000_001, 4_000_000, 200_000, pop_wgt_df=WGT,
+                                 compute=oracle_compute, window_size=500_000, **files)
+    fpath, opath = str(tmp_path / "files.pkl"), str(tmp_path / "out.pkl")
+    pickle.dump(files, open(fpath, "wb"))
+    port = 29500 + (os.getpid() % 2000)
+    script = str(tmp_path / "worker.py")
+    open(script, "w").write(WORKER.format(root=ROOT, port=port, files=fpath, out=opath))
+    procs = [subprocess.Popen([sys.executable, script, str(r)]) for r in range(2)]
+    for pr in procs:
+        assert pr.wait(timeout=300) == 0
+    two = pickle.load(open(opath, "rb"))
+    assert sorted(set(two["owner"])) == [0, 1]                    # both ranks really had windows
+    assert two["bp"] == list(one["table"]["bp"])
+    assert np.array_equal(np.array(two["z"]), one["table"]["z"].to_numpy())
+    assert two["skipped"] == one["skipped"]
+
+
+@pytest.mark.gpu
+def test_gpu_farm_single_rank(ctx, tmp_path):
+    st = make_study(tmp_path)
+    p = st["paths"]
+    files = dict(input_file=p["gwas.txt"], reference_index_file=p["index.gz"], reference_data_file=p["data.gz"],
+                 reference_pop_desc_file=p["desc.txt"])
+    res = farm.impute_chromosome(api.KIND_DISTMIX, 22, 1_000_001, 4_000_000, 200_000, pop_wgt_df=WGT,
+                                 window_size=500_000, compute=lambda pl: farm.gpu_compute(pl, ctx), **files)
+    want = farm.impute_chromosome(api.KIND_DISTMIX, 22, 1_000_001, 4_000_000, 200_000, pop_wgt_df=WGT,
+                                  window_size=500_000, compute=oracle_compute, **files)
+    a, b = res["table"], want["table"]
+    assert list(a["rsid"]) == list(b["rsid"])
+    assert np.max(np.abs(a["z"].to_numpy() - b["z"].to_numpy()) / np.maximum(1, np.abs(b["z"].to_numpy()))) <= 1e-8
+    assert np.max(np.abs(a["info"].to_numpy() - b["info"].to_numpy())) <= 1e-8
