@@ -33,7 +33,7 @@ def main():
     gm = np.ascontiguousarray(G[np.sort(idx[:42])])
     gu = np.ascontiguousarray(G[np.sort(idx[42:])])
     z1 = np.round(rng.standard_normal(gm.shape[0]) * 2, 6)
-    out = dict(gm=gm, gu=gu, off=off, w=w, z1=z1)
+    out = dict(gm=gm, gu=gu, off=off, w=w, zin=z1)
     for mode in (0, 1):
         r = oracle.run_impute(mode, gm, gu, off, w, z1, want_mats=True)
         out[f"z{mode}"], out[f"info{mode}"], out[f"b11_{mode}"], out[f"b21_{mode}"] = r["z"], r["info"], r["b11"], r["b21"]

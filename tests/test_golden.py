@@ -12,7 +12,7 @@ G = np.load(os.path.join(os.path.dirname(__file__), "golden", "window_small.npz"
 
 def test_oracle_reproduces_golden():
     for mode in (0, 1):
-        r = oracle.run_impute(mode, G["gm"], G["gu"], G["off"], G["w"], G["z1"], want_mats=True)
+        r = oracle.run_impute(mode, G["gm"], G["gu"], G["off"], G["w"], G["zin"], want_mats=True)
         assert np.array_equal(r["b11"], G[f"b11_{mode}"]) and np.array_equal(r["b21"], G[f"b21_{mode}"])
         assert np.max(np.abs(r["z"] - G[f"z{mode}"])) <= 1e-12 and np.max(np.abs(r["info"] - G[f"info{mode}"])) <= 1e-13
     assert np.array_equal(oracle.compute_ld(G["gm"], G["off"], G["w"]), G["ld_weighted"])
@@ -26,7 +26,7 @@ def test_hip_matches_golden(ctx):
     assert np.max(np.abs(hotpath.ld_matrix(G["gm"], G["off"], G["w"], ctx=ctx) - G["ld_weighted"])) <= 1e-12
     assert np.max(np.abs(hotpath.ld_matrix(G["gm"], G["off"], None, mode=0, diag=1.1, ctx=ctx) - G["ld_pooled"])) <= 1e-12
     for mode in (0, 1):
-        r = hotpath.impute_window(mode, G["gm"], G["gu"], G["off"], G["w"], G["z1"], want_mats=True, ctx=ctx)
+        r = hotpath.impute_window(mode, G["gm"], G["gu"], G["off"], G["w"], G["zin"], want_mats=True, ctx=ctx)
         assert np.max(np.abs(r["b11"] - G[f"b11_{mode}"])) <= 1e-12
         assert np.max(np.abs(r["z"] - G[f"z{mode}"]) / np.maximum(1, np.abs(G[f"z{mode}"]))) <= 1e-8
         assert np.max(np.abs(r["info"] - G[f"info{mode}"]) / G[f"info{mode}"]) <= 1e-8
