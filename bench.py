@@ -191,7 +191,7 @@ def main():
                 "kernel": "gram_kernel (LD GEMM, v_mfma_f32_32x32x2_f32)",
                 "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
-                "traffic": None,
+                "traffic": pmc_traffic() if (len(wins) == 36 and args.snps == 100_000) else None,
                 "algorithmic_flops_per_launch": work["ld_flops"],
                 "avg_launch_ms": gram_ms / max(1, gram_n), "launches": int(gram_n),
                 "issued_flops_per_launch": stats["executed_flops"],
@@ -208,6 +208,20 @@ def main():
         dist.destroy_process_group()
     job.close()
     return out
+
+
+def pmc_traffic(kernel="gauss::gram_kernel"):
+    """HBM-side bytes per launch of the Gram kernel from the committed rocprofv3 PMC passes
+    (profiles/*_pmc_traffic.csv: separate FETCH_SIZE / WRITE_SIZE runs of this same command,
+    gfx950 correction applied).  PMC counters cannot be collected from inside the timed run."""
+    import csv
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.csv"))):
+        for r in csv.DictReader(open(f)):
+            if r["kernel"] == kernel:
+                best = float(r["hbm_bytes_per_launch_corrected"])
+    return best
 
 
 def cpu_baseline(ch, wins, keep, work):
