@@ -59,6 +59,7 @@ struct Plan {
     std::vector<uint8_t> word_pop;
     std::vector<int> gene_off;
     std::vector<long long> gene_out_off;
+    std::vector<std::pair<int, int>> groups;   // runs of consecutive segments handled by one work item
     // user pointers
     const uint8_t* h_geno_m = nullptr;
     const uint8_t* h_geno_u = nullptr;
@@ -125,8 +126,11 @@ struct WinSpec {
 // for the epilogue to read back.  Either way a partial sum stays an exact f32 integer
 // (15 * 15 * 8192 < 2^24).
 static int seg_max_for(size_t n_windows) { return n_windows >= 4 ? 8192 : SEG_MAX; }
+// Consecutive segments are chained into one work item until the run reaches this many samples
+// (a fresh item costs a pipeline fill: descriptor, first operand tiles, barrier).  0 = no chaining.
+static int group_target_for(size_t n_windows) { return n_windows >= 4 ? 4096 : 0; }
 
-static int plan_problem(const WinSpec& w, Plan& pl, int seg_max)
+static int plan_problem(const WinSpec& w, Plan& pl, int seg_max, int group_target)
 {
     if (w.mode != GAUSS_MODE_POOLED && w.mode != GAUSS_MODE_WEIGHTED) return fail(GAUSS_E_INVALID, "bad mode %d", w.mode);
     if (w.n_pop < 1 || w.n_pop > 64) return fail(GAUSS_E_INVALID, "n_pop must be in 1..64 (got %d)", w.n_pop);
@@ -193,6 +197,13 @@ static int plan_problem(const WinSpec& w, Plan& pl, int seg_max)
     }
     pl.pop_seg0[P] = (int)pl.seg_pop.size();
     p.nseg = (int)pl.seg_pop.size();
+    for (int s0 = 0; s0 < p.nseg;) {
+        int s1 = s0 + 1;
+        int len = pl.seg_k1[s0] - pl.seg_k0[s0];
+        while (s1 < p.nseg && len < group_target) { len += pl.seg_k1[s1] - pl.seg_k0[s1]; s1++; }
+        pl.groups.push_back(std::make_pair(s0, s1));
+        s0 = s1;
+    }
 
     p.Mp = (int)rup((size_t)w.M, TILE);
     p.Up = (int)rup((size_t)w.U, TILE);
@@ -262,7 +273,7 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
     job->on_device = on_device;
     job->plans.resize(job->n);
     for (int i = 0; i < job->n; i++) {
-        int rc = plan_problem(specs[i], job->plans[i], seg_max_for(specs.size()));
+        int rc = plan_problem(specs[i], job->plans[i], seg_max_for(specs.size()), group_target_for(specs.size()));
         if (rc) { delete job; return rc; }
     }
     HIPCHK(hipSetDevice(ctx->device));
@@ -292,14 +303,17 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
         to[i].gout = put(blob, ta, pl.gene_out_off);
     }
     // work lists
-    std::vector<Item> items;
+    struct ItemH { int prob, pair, group, len; };
+    std::vector<ItemH> items;
     std::vector<int2> rowmap, tilemap, panelmap;
     job->max_nblk = 0;
     for (int i = 0; i < job->n; i++) {
         const Prob& p = job->plans[i].p;
         for (int pr = 0; pr < p.npair; pr++)
-            for (int s = 0; s < p.nseg; s++)
-                items.push_back(Item{i, pr, s, job->plans[i].seg_k1[s] - job->plans[i].seg_k0[s]});
+            for (size_t g = 0; g < job->plans[i].groups.size(); g++) {
+                const std::pair<int, int>& gr = job->plans[i].groups[g];
+                items.push_back(ItemH{i, pr, (int)g, job->plans[i].seg_k1[gr.second - 1] - job->plans[i].seg_k0[gr.first]});
+            }
         for (int r = 0; r < p.M + p.U; r++) rowmap.push_back(make_int2(i, r));
         if (!p.n_gene)
             for (int pr = 0; pr < p.npair; pr++) tilemap.push_back(make_int2(i, pr));
@@ -308,8 +322,8 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
         if (p.mode != 0) job->max_pop = std::max(job->max_pop, p.P);
     }
     // longest segments first: the tail of the launch is then made of short items
-    std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.len > b.len; });
-    const size_t o_items = put(blob, ta, items);
+    std::stable_sort(items.begin(), items.end(), [](const ItemH& a, const ItemH& b) { return a.len > b.len; });
+    const size_t o_items = ta.take(sizeof(Item) * std::max<size_t>(items.size(), 1));
     const size_t o_rowmap = put(blob, ta, rowmap);
     const size_t o_tilemap = put(blob, ta, tilemap);
     const size_t o_panelmap = put(blob, ta, panelmap);
@@ -420,6 +434,24 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
                                         (size_t)p.N, (size_t)p.U, hipMemcpyHostToDevice, st));
         }
     }
+    // device work items: every pointer is resolved here so the kernel starts loading operands at once
+    for (size_t n = 0; n < items.size(); n++) {
+        const ItemH& h = items[n];
+        const Plan& pl = job->plans[h.prob];
+        const Prob& p = pl.p;
+        const std::pair<int, int>& gr = pl.groups[h.group];
+        const int ti = pl.pair_ti[h.pair], tj = pl.pair_tj[h.pair];
+        const int mt = p.Mp / TILE;
+        auto rows = [&](int t) { int left = (t < mt) ? p.M - t * TILE : p.U - (t - mt) * TILE; return left > TILE ? TILE : left; };
+        Item it;
+        it.a = p.packed + (size_t)ti * TILE * p.Kp;
+        it.b = p.packed + (size_t)tj * TILE * p.Kp;
+        it.slab = p.slab + ((size_t)h.pair * p.nseg + gr.first) * (TILE * TILE);
+        it.seg_k1 = p.seg_k1 + gr.first;
+        it.Kp = p.Kp; it.k0 = pl.seg_k0[gr.first]; it.nseg = gr.second - gr.first;
+        it.rows_a = rows(ti); it.rows_b = rows(tj); it.diag = (ti == tj); it.len = h.len; it.pad = 0;
+        memcpy(blob.data() + o_items + sizeof(Item) * n, &it, sizeof(Item));
+    }
     HIPCHK(hipMemcpyAsync(job->d_tab, blob.data(), blob.size(), hipMemcpyHostToDevice, st));
     job->d_probs = (Prob*)(job->d_tab + o_probs);
     job->d_items = (Item*)(job->d_tab + o_items);
@@ -476,7 +508,7 @@ static int job_run(gauss_job* job, bool solve)
     launch_row_stats(job->d_probs, job->d_rowmap, job->n_rows, st);
     prof_end(job);
     prof_begin(job, 0);
-    launch_gram(job->d_probs, job->d_items, job->n_items, st);
+    launch_gram(job->d_items, job->n_items, st);
     prof_end(job);
     prof_begin(job, 2);
     launch_epilogue(job->d_probs, job->d_tilemap, job->n_tiles, job->max_pop, st);

@@ -73,7 +73,23 @@ struct Prob {
     GP(long long) gene_out_off;// [n_gene] offsets into out_ld
 };
 
-struct Item { int prob, pair, seg, len; };
+// One unit of Gram work: a 128 x 128 tile pair times a run of consecutive K segments.  The kernel
+// streams the whole run without draining its load pipeline and flushes the accumulators into one
+// partial slab per segment.  Self-contained (64 bytes, fetched with scalar loads): no pointer
+// chasing through the Prob before the first operand load.
+struct Item {
+    GP(const uint8_t) a;     // packed rows of tile ti (row 0, column 0)
+    GP(const uint8_t) b;     // packed rows of tile tj
+    GP(float) slab;          // slab of (pair, first segment of the run); later segments follow
+    GP(const int) seg_k1;    // end column of each segment of the run
+    int Kp;                  // packed row stride
+    int k0;                  // first column of the run
+    int nseg;                // segments in the run
+    int rows_a, rows_b;      // live rows of the two tiles (the rest is zero padding)
+    int diag;                // ti == tj
+    int len;                 // columns in the run (sort key)
+    int pad;
+};
 
 template <typename T> using gptr = T __attribute__((address_space(1)))*;
 template <typename T> __device__ __forceinline__ gptr<T> G(T* p) { return (gptr<T>)p; }
@@ -82,7 +98,7 @@ template <typename T> __device__ __forceinline__ gptr<T> G(gptr<T> p) { return p
 // ---- launchers (host functions defined in the .hip files) ----
 void launch_pack_stats(const Prob* d_probs, const int2* d_rowmap, int n_rows, hipStream_t s);
 void launch_row_stats(const Prob* d_probs, const int2* d_rowmap, int n_rows, hipStream_t s);
-void launch_gram(const Prob* d_probs, const Item* d_items, int n_items, hipStream_t s);
+void launch_gram(const Item* d_items, int n_items, hipStream_t s);
 void launch_epilogue(const Prob* d_probs, const int2* d_tilemap, int n_tiles, int max_pop, hipStream_t s);
 void launch_gene_epilogue(const Prob* d_probs, int prob, int n_gene, hipStream_t s);
 void launch_factor_step(const Prob* d_probs, int n_prob, int step, int max_nblk, hipStream_t s);

@@ -19,6 +19,7 @@
 // groups of 16 lanes that hold 16 different rows; with an 80-byte (= 16 x 5) row stride those
 // 16 sixteen-byte slots are distinct modulo the 256-byte bank row: conflict-free.
 #include "gauss_internal.h"
+#include <cstdlib>
 
 namespace gauss {
 
@@ -28,16 +29,36 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr int LROW = 80;                   // LDS row stride in bytes
 constexpr int LTILE = TILE * LROW;         // bytes per operand tile image
 
-__device__ __forceinline__ float ub(uint32_t w, int b) { return (float)((w >> (8 * b)) & 0xffu); }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // One K chunk (64 samples) of a wave's 64 x 64 sub-tile.  NA / NB = number of live 32-row halves
 // of the wave's A / B rows (rows past the problem's real row count are zero padding: their
 // products are never read, so their MFMAs are not issued at all).
+// Operand bytes are genotype codes in OCP e4m3 (0 -> 0x00, 1 -> 0x38, 2 -> 0x40, written by
+// pack_stats_kernel): v_cvt_pk_f32_fp8 expands TWO of them per VALU instruction, exactly.  VALU
+// issue is not free next to the fp32 MFMA (each VALU op costs about 6 cycles of matrix-pipe time on
+// gfx950, measured), so halving the converts is worth ~5 % of the kernel.
 template <int NA, int NB>
 __device__ __forceinline__ void chunk_mfma(const uint8_t* __restrict__ la, const uint8_t* __restrict__ lb,
                                            int arow, int brow, f32x16& acc00, f32x16& acc01,
                                            f32x16& acc10, f32x16& acc11)
 {
+#define GAUSS_MFMA_PAIR(AW0, AW1, BW0, BW1, HI)                                                       \
+    {                                                                                                  \
+        const f32x2 fa0 = __builtin_amdgcn_cvt_pk_f32_fp8((int)(AW0), HI);                             \
+        const f32x2 fb0 = __builtin_amdgcn_cvt_pk_f32_fp8((int)(BW0), HI);                             \
+        f32x2 fa1 = fa0, fb1 = fb0;                                                                    \
+        if (NA > 1) fa1 = __builtin_amdgcn_cvt_pk_f32_fp8((int)(AW1), HI);                             \
+        if (NB > 1) fb1 = __builtin_amdgcn_cvt_pk_f32_fp8((int)(BW1), HI);                             \
+        _Pragma("unroll") for (int e = 0; e < 2; e++) {                                              \
+            acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[e], fb0[e], acc00, 0, 0, 0);              \
+            if (NB > 1) acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[e], fb1[e], acc01, 0, 0, 0);  \
+            if (NA > 1) {                                                                              \
+                acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[e], fb0[e], acc10, 0, 0, 0);          \
+                if (NB > 1) acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[e], fb1[e], acc11, 0, 0, 0); \
+            }                                                                                          \
+        }                                                                                              \
+    }
 #pragma unroll
     for (int g = 0; g < 2; g++) {
         const u32x4 a0 = *reinterpret_cast<const u32x4*>(la + arow + g * 32);
@@ -51,42 +72,22 @@ __device__ __forceinline__ void chunk_mfma(const uint8_t* __restrict__ la, const
         const uint32_t bw1[4] = {b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-#pragma unroll
-            for (int b = 0; b < 4; b++) {
-                const float fa0 = ub(aw0[q], b), fb0 = ub(bw0[q], b);
-                acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0, fb0, acc00, 0, 0, 0);
-                if (NB > 1) {
-                    const float fb1 = ub(bw1[q], b);
-                    acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0, fb1, acc01, 0, 0, 0);
-                }
-                if (NA > 1) {
-                    const float fa1 = ub(aw1[q], b);
-                    acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1, fb0, acc10, 0, 0, 0);
-                    if (NB > 1) {
-                        const float fb1 = ub(bw1[q], b);
-                        acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1, fb1, acc11, 0, 0, 0);
-                    }
-                }
-            }
+            GAUSS_MFMA_PAIR(aw0[q], aw1[q], bw0[q], bw1[q], false)
+            GAUSS_MFMA_PAIR(aw0[q], aw1[q], bw0[q], bw1[q], true)
         }
     }
+#undef GAUSS_MFMA_PAIR
 }
 
-__device__ __forceinline__ int tile_rows(const Prob& pb, int t)
-{
-    const int mt = pb.Mp / TILE;
-    const int left = (t < mt) ? pb.M - t * TILE : pb.U - (t - mt) * TILE;
-    return left > TILE ? TILE : left;
-}
-
-// The K loop of one work item for a wave with NA x NB live 32-row halves (NA = 0: staging only).
+// One work item for a wave with NA x NB live 32-row halves (NA = 0: staging and barriers only).
+// The K loop runs over the whole run of segments without draining the prefetch pipeline; at each
+// segment end the accumulators are flushed to that segment's slab and cleared.
 template <int NA, int NB>
-__device__ __forceinline__ void run_item(const Prob& pb, const Item& it, uint8_t* lds, int ti, int tj, int wr, int wc)
+__device__ __forceinline__ void run_item(const Item& it, uint8_t* lds, int wr, int wc)
 {
-    const int Kp = pb.Kp;
-    const int k0 = pb.seg_k0[it.seg], k1 = pb.seg_k1[it.seg];
-    const gptr<const uint8_t> Ag = G((const uint8_t*)pb.packed) + (size_t)ti * TILE * Kp;
-    const gptr<const uint8_t> Bg = G((const uint8_t*)pb.packed) + (size_t)tj * TILE * Kp;
+    const int Kp = it.Kp;
+    const auto Ag = it.a;
+    const auto Bg = it.b;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int li = lane & 31, lh = lane >> 5;
@@ -98,6 +99,12 @@ __device__ __forceinline__ void run_item(const Prob& pb, const Item& it, uint8_t
     const int l0 = srow0 * LROW + scol, l1 = srow1 * LROW + scol;
 
     f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
+
+    const int k0 = it.k0;
+    const int nseg = it.nseg;
+    const int klast = it.seg_k1[nseg - 1];
+    auto out = it.slab;
+    const int obase = (wr * 64 + 4 * lh) * TILE + wc * 64 + li;
 
     u32x4 pa0, pa1, pb0, pb1;
     pa0 = *(gptr<const u32x4>)(Ag + g0 + k0);
@@ -118,73 +125,85 @@ __device__ __forceinline__ void run_item(const Prob& pb, const Item& it, uint8_t
     const int arow = (wr * 64 + li) * LROW + lh * 16;
     const int brow = (wc * 64 + li) * LROW + lh * 16;
 
-    for (int k = k0; k < k1; k += KC) {
-        const bool more = (k + KC) < k1;
-        if (more) {
-            pa0 = *(gptr<const u32x4>)(Ag + g0 + k + KC);
-            pa1 = *(gptr<const u32x4>)(Ag + g1 + k + KC);
-            pb0 = *(gptr<const u32x4>)(Bg + g0 + k + KC);
-            pb1 = *(gptr<const u32x4>)(Bg + g1 + k + KC);
+    int k = k0;
+    for (int seg = 0; seg < nseg; seg++) {
+        const int kend = it.seg_k1[seg];
+        for (; k < kend; k += KC) {
+            const bool more = (k + KC) < klast;          // the prefetch runs across segment ends
+            if (more) {
+                pa0 = *(gptr<const u32x4>)(Ag + g0 + k + KC);
+                pa1 = *(gptr<const u32x4>)(Ag + g1 + k + KC);
+                pb0 = *(gptr<const u32x4>)(Bg + g0 + k + KC);
+                pb1 = *(gptr<const u32x4>)(Bg + g1 + k + KC);
+            }
+            const uint8_t* la = lds + cur * 2 * LTILE;
+            const uint8_t* lb = la + LTILE;
+            if (NA > 0) chunk_mfma<NA, NB>(la, lb, arow, brow, acc00, acc01, acc10, acc11);
+            if (more) {
+                uint8_t* wa = lds + (cur ^ 1) * 2 * LTILE;
+                uint8_t* wb = wa + LTILE;
+                *reinterpret_cast<u32x4*>(wa + l0) = pa0;
+                *reinterpret_cast<u32x4*>(wa + l1) = pa1;
+                *reinterpret_cast<u32x4*>(wb + l0) = pb0;
+                *reinterpret_cast<u32x4*>(wb + l1) = pb1;
+            }
+            __syncthreads();
+            cur ^= 1;
         }
-        const uint8_t* la = lds + cur * 2 * LTILE;
-        const uint8_t* lb = la + LTILE;
-        if (NA > 0) chunk_mfma<NA, NB>(la, lb, arow, brow, acc00, acc01, acc10, acc11);
-        if (more) {
-            uint8_t* wa = lds + (cur ^ 1) * 2 * LTILE;
-            uint8_t* wb = wa + LTILE;
-            *reinterpret_cast<u32x4*>(wa + l0) = pa0;
-            *reinterpret_cast<u32x4*>(wa + l1) = pa1;
-            *reinterpret_cast<u32x4*>(wb + l0) = pb0;
-            *reinterpret_cast<u32x4*>(wb + l1) = pb1;
-        }
-        __syncthreads();
-        cur ^= 1;
-    }
-    if (NA == 0) return;
-
-    // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-    const gptr<float> out = G((float*)pb.slab) + ((size_t)it.pair * pb.nseg + it.seg) * (TILE * TILE);
-    const int orow = wr * 64 + 4 * lh, ocol = wc * 64 + li;
+        // end of a segment: flush its exact partial sums, start the next segment from zero.
+        // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+        if (NA > 0) {
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-        const int row = orow + (r & 3) + 8 * (r >> 2);
-        out[(size_t)row * TILE + ocol] = acc00[r];
-        if (NB > 1) out[(size_t)row * TILE + ocol + 32] = acc01[r];
-        if (NA > 1) {
-            out[(size_t)(row + 32) * TILE + ocol] = acc10[r];
-            if (NB > 1) out[(size_t)(row + 32) * TILE + ocol + 32] = acc11[r];
+            for (int r = 0; r < 16; r++) {
+                const int o = obase + ((r & 3) + 8 * (r >> 2)) * TILE;
+                out[o] = acc00[r];
+                if (NB > 1) out[o + 32] = acc01[r];
+                if (NA > 1) {
+                    out[o + 32 * TILE] = acc10[r];
+                    if (NB > 1) out[o + 32 * TILE + 32] = acc11[r];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) { acc00[r] = 0.f; acc01[r] = 0.f; acc10[r] = 0.f; acc11[r] = 0.f; }
         }
+        out += TILE * TILE;
     }
 }
 
-__global__ __launch_bounds__(256, 4) void gram_kernel(const Prob* __restrict__ probs,
-                                                      const Item* __restrict__ items)
+__global__ __launch_bounds__(256, 4) void gram_kernel(const Item* __restrict__ items)
 {
     __shared__ __attribute__((aligned(16))) uint8_t lds[2 * 2 * LTILE];
 
-    const Item it = items[blockIdx.x];
-    const Prob& pb = probs[it.prob];
-    const int ti = pb.pair_ti[it.pair], tj = pb.pair_tj[it.pair];
+    const Item& it = items[blockIdx.x];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = wave >> 1, wc = wave & 1;
 
     // live 32-row halves of this wave's A rows / B rows (wave-uniform)
-    int na = (tile_rows(pb, ti) - wr * 64 + 31) / 32;
-    int nb = (tile_rows(pb, tj) - wc * 64 + 31) / 32;
+    int na = (it.rows_a - wr * 64 + 31) / 32;
+    int nb = (it.rows_b - wc * 64 + 31) / 32;
     na = na < 0 ? 0 : (na > 2 ? 2 : na);
     nb = nb < 0 ? 0 : (nb > 2 ? 2 : nb);
     // diagonal tile: the lower-left 64 x 64 quadrant mirrors the upper-right one and is never read
-    if (ti == tj && wr == 1 && wc == 0) na = 0;
-    if (na == 0 || nb == 0) run_item<0, 0>(pb, it, lds, ti, tj, wr, wc);
-    else if (na == 2 && nb == 2) run_item<2, 2>(pb, it, lds, ti, tj, wr, wc);
-    else if (na == 2) run_item<2, 1>(pb, it, lds, ti, tj, wr, wc);
-    else if (nb == 2) run_item<1, 2>(pb, it, lds, ti, tj, wr, wc);
-    else run_item<1, 1>(pb, it, lds, ti, tj, wr, wc);
+    if (it.diag && wr == 1 && wc == 0) na = 0;
+    if (na == 0 || nb == 0) run_item<0, 0>(it, lds, wr, wc);
+    else if (na == 2 && nb == 2) run_item<2, 2>(it, lds, wr, wc);
+    else if (na == 2) run_item<2, 1>(it, lds, wr, wc);
+    else if (nb == 2) run_item<1, 2>(it, lds, wr, wc);
+    else run_item<1, 1>(it, lds, wr, wc);
 }
 
-void launch_gram(const Prob* d_probs, const Item* d_items, int n_items, hipStream_t s)
+void launch_gram(const Item* d_items, int n_items, hipStream_t s)
 {
-    if (n_items > 0) hipLaunchKernelGGL(gram_kernel, dim3(n_items), dim3(256), 0, s, d_probs, d_items);
+    if (n_items <= 0) return;
+    // tuning hook: GAUSS_GRAM_EXTRA_LDS=<bytes> pads the workgroup's LDS request to lower occupancy
+    static int extra = -1;
+    if (extra < 0) {
+        const char* e = getenv("GAUSS_GRAM_EXTRA_LDS");
+        extra = e ? atoi(e) : 0;
+        if (extra > 0)
+            hipFuncSetAttribute(reinterpret_cast<const void*>(gram_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, extra);
+    }
+    hipLaunchKernelGGL(gram_kernel, dim3(n_items), dim3(256), (size_t)extra, s, d_items);
 }
 
 }  // namespace gauss

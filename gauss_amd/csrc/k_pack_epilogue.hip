@@ -9,7 +9,7 @@
 namespace gauss {
 
 // ------------------------------------------------------------------------------------------
-// K1: raw genotype bytes (ASCII digits or 0..2) -> packed u8 operand rows + per-population
+// K1: raw genotype bytes (ASCII digits or 0..2) -> packed operand rows (one e4m3 byte per code) + per-population
 // integer sums.  Replaces the per-pair recomputation of sumx / sumxsq inside CalCor
 // (util.cpp:58-61) and the allele count of MakeSnpVec (gauss.cpp:581-583).
 // One workgroup per SNP row; a thread handles 16 packed bytes at a time.
@@ -54,10 +54,25 @@ __global__ __launch_bounds__(256) void pack_stats_kernel(const Prob* __restrict_
         int sx = 0, sxx = 0;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            uint32_t x = v[q] & 0x0F0F0F0Fu;   // '0'..'9' and 0..15 both decode as byte & 0x0F
-            v[q] = x;
+            const uint32_t x = v[q] & 0x0F0F0F0Fu;   // '0'..'9' and 0..15 both decode as byte & 0x0F
             sx = __builtin_amdgcn_udot4(x, 0x01010101u, sx, false);
             sxx = __builtin_amdgcn_udot4(x, x, sxx, false);
+            // operand encoding for the Gram kernel: the code as an OCP e4m3 byte (exact for 0..15)
+            uint32_t c;
+            if ((x & 0x0C0C0C0Cu) == 0 && (x & (x >> 1) & 0x01010101u) == 0) {
+                // every byte in {0,1,2}: 1 -> 0x38, 2 -> 0x40
+                c = (x & 0x01010101u) * 0x38u + ((x >> 1) & 0x01010101u) * 0x40u;
+            } else {
+                c = 0;
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    const uint32_t t = (x >> (8 * b)) & 0xFu;
+                    // e4m3: 0, 1=0x38, 2=0x40, 3=0x44, 4..7 = 0x48 + 2(t-4), 8..15 = 0x50 + (t-8)
+                    const uint32_t e = t == 0 ? 0u : t == 1 ? 0x38u : t < 4 ? 0x40u + 4u * (t - 2) : t < 8 ? 0x48u + 2u * (t - 4) : 0x50u + (t - 8);
+                    c |= e << (8 * b);
+                }
+            }
+            v[q] = c;
         }
         dst[w] = make_uint4(v[0], v[1], v[2], v[3]);
         if (sx) { atomicAdd(&s_sx[p], sx); atomicAdd(&s_sxx[p], sxx); }
