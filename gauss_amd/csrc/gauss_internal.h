@@ -9,8 +9,8 @@ constexpr int TILE = 128;      // Gram output tile edge per workgroup (4 waves x
 constexpr int KC = 64;         // packed K chunk in bytes (= samples); pops are padded to it
 constexpr int SEG_MAX = 2048;  // max samples per K segment (split-K granularity)
 constexpr int NB = 64;         // fp64 factor / solve block edge
-constexpr int NR = 32;         // right-hand sides per solve panel (31 SNPs + the z1 column)
-constexpr int NRU = 31;
+constexpr int NR = 64;         // right-hand sides per solve panel (63 SNPs + the z1 column)
+constexpr int NRU = 63;
 
 // Pointers stored inside a Prob are loaded from memory, so the compiler could not infer their
 // address space and would emit flat_* accesses.  Everything a Prob points to is device global

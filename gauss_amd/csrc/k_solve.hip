@@ -1,4 +1,4 @@
-// K5 blocked Cholesky (fp64), K6/K7 forward solve + imputation finalize.
+// K5 blocked Cholesky (fp64), K6/K7 forward solve + imputation finalize -- fp64 matrix cores.
 //
 // Replaces  MakePosDef + InvMat + per-SNP MpMatMat  of run_dist / run_distmix
 // (dist.cpp:181-202, distmix.cpp:203-228, util.cpp:262-264,298-318):
@@ -14,124 +14,114 @@
 // A[1] = B11 - min_abs_eig*I alongside A[0] = B11: the shifted factorisation succeeds iff every
 // eigenvalue exceeds min_abs_eig (then MakePosDef is the identity map).  If it fails, status[1]
 // is raised and the host driver reruns the window through the Jacobi eigen-clamp path.
+//
+// All block products run on v_mfma_f64_16x16x4_f64 (one f64 A and one f64 B value per lane; result
+// rows (lane>>4) + 4*reg, column lane&15).  A workgroup is 4 waves; wave w owns rows 16w..16w+15
+// of a 64-row block.
 #include "gauss_internal.h"
 
 namespace gauss {
 
-constexpr int LDB = NB + 1;   // padded LDS leading dimension (doubles)
+typedef double f64x4 __attribute__((ext_vector_type(4)));
 
-// ---- 64x64 tile helpers; 256 threads; LDS tiles are [NB][LDB] doubles -----------------------
+constexpr int LDT = NB + 2;    // LDS leading dimension of a 64 x 64 [row][k] tile: 66 doubles = 528 B;
+                               // 528 mod 256 = 16 puts the 32 lanes of a ds_read_b64 group on distinct banks
+constexpr int LDV = 80;        // LDS leading dimension of a 64 x 64 [k][col] tile: 640 B, 640 mod 256 = 128
 
-// C -= A * B^T   (all 64x64).  Thread t owns rows r0 = (t>>4)*4.. +3, cols c0 = (t&15)*4.. +3.
-__device__ __forceinline__ void tile_gemm_nt_sub(double* __restrict__ C, const double* __restrict__ A,
-                                                 const double* __restrict__ B, int tid)
+#define WAVE_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+// acc[n] += sign * A(rows 16w.., K=64) * B^T, A and B both [row][k] tiles with leading dimension LDT.
+template <int NT, bool NEG>
+__device__ __forceinline__ void mfma_nt(f64x4 (&acc)[NT], const double* __restrict__ A, const double* __restrict__ B,
+                                        int wave, int lane)
 {
-    const int r0 = (tid >> 4) << 2, c0 = (tid & 15) << 2;
-    double acc[4][4];
+    const double* ap = A + (16 * wave + (lane & 15)) * LDT + (lane >> 4);
+    const double* bp = B + (lane & 15) * LDT + (lane >> 4);
+#pragma unroll 4
+    for (int k0 = 0; k0 < NB; k0 += 4) {
+        double a = ap[k0];
+        if (NEG) a = -a;
 #pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = 0.0;
-    for (int k = 0; k < NB; k++) {
-        double a[4], b[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) a[i] = A[(r0 + i) * LDB + k];
-#pragma unroll
-        for (int j = 0; j < 4; j++) b[j] = B[(c0 + j) * LDB + k];
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) acc[i][j] = fma(a[i], b[j], acc[i][j]);
+        for (int n = 0; n < NT; n++) acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bp[n * 16 * LDT + k0], acc[n], 0, 0, 0);
     }
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) C[(r0 + i) * LDB + c0 + j] -= acc[i][j];
 }
 
-// C = A * B^T  (64x64), B lower/any.
-__device__ __forceinline__ void tile_gemm_nt_set(double* __restrict__ C, const double* __restrict__ A,
-                                                 const double* __restrict__ B, int tid)
+// acc[n] += sign * A(rows 16w.., K=64, [row][k], LDT) * V ([k][col], leading dimension LDV)
+template <int NT, bool NEG>
+__device__ __forceinline__ void mfma_nn(f64x4 (&acc)[NT], const double* __restrict__ A, const double* __restrict__ V,
+                                        int wave, int lane)
 {
-    const int r0 = (tid >> 4) << 2, c0 = (tid & 15) << 2;
-    double acc[4][4];
+    const double* ap = A + (16 * wave + (lane & 15)) * LDT + (lane >> 4);
+    const double* vp = V + (lane >> 4) * LDV + (lane & 15);
+#pragma unroll 4
+    for (int k0 = 0; k0 < NB; k0 += 4) {
+        double a = ap[k0];
+        if (NEG) a = -a;
 #pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = 0.0;
-    for (int k = 0; k < NB; k++) {
-        double a[4], b[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) a[i] = A[(r0 + i) * LDB + k];
-#pragma unroll
-        for (int j = 0; j < 4; j++) b[j] = B[(c0 + j) * LDB + k];
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) acc[i][j] = fma(a[i], b[j], acc[i][j]);
+        for (int n = 0; n < NT; n++) acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, vp[k0 * LDV + n * 16], acc[n], 0, 0, 0);
     }
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) C[(r0 + i) * LDB + c0 + j] = acc[i][j];
 }
 
-__device__ __forceinline__ void tile_load(double* __restrict__ T, const double* __restrict__ g, int ld, int tid)
+// accumulator tile element (reg r of tile n) -> (row, col) inside the 64 x (16 NT) block
+__device__ __forceinline__ int acc_row(int wave, int lane, int r) { return 16 * wave + (lane >> 4) + 4 * r; }
+__device__ __forceinline__ int acc_col(int lane, int n) { return 16 * n + (lane & 15); }
+
+template <typename P>
+__device__ __forceinline__ void tile_load(double* __restrict__ T, P g, int ld, int tid)
 {
-    for (int e = tid; e < NB * NB; e += 256) T[(e >> 6) * LDB + (e & 63)] = g[(size_t)(e >> 6) * ld + (e & 63)];
+    for (int e = tid; e < NB * NB; e += 256) T[(e >> 6) * LDT + (e & 63)] = g[(size_t)(e >> 6) * ld + (e & 63)];
 }
-__device__ __forceinline__ void tile_store(double* __restrict__ g, int ld, const double* __restrict__ T, int tid)
+template <typename P>
+__device__ __forceinline__ void tile_store(P g, int ld, const double* __restrict__ T, int tid)
 {
-    for (int e = tid; e < NB * NB; e += 256) g[(size_t)(e >> 6) * ld + (e & 63)] = T[(e >> 6) * LDB + (e & 63)];
+    for (int e = tid; e < NB * NB; e += 256) g[(size_t)(e >> 6) * ld + (e & 63)] = T[(e >> 6) * LDT + (e & 63)];
 }
 
 // In-place Cholesky of the 64x64 LDS tile D (lower triangle result, upper zeroed), followed by
-// the inverse of the factor into X.  Returns (block-uniform) 1 if a pivot was not positive.
-// The factorisation is a dependency chain of 64 columns: it is run by ONE wave (lane = row), which
-// needs no workgroup barriers -- LDS operations of a wave complete in order -- so a column costs
-// one dot-product sweep instead of two barriers.  Left-looking:
-//     s_i = a_ij - sum_{k<j} l_ik l_jk ;  l_jj = sqrt(s_j) ;  l_ij = s_i / l_jj
+// the inverse of the factor into X (both [row][col] with leading dimension LDT).  Returns
+// (block-uniform) 1 if a pivot was not positive.  A dependency chain of 64 columns: run by ONE
+// wave (lane = row) that needs no workgroup barriers -- the LDS operations of a wave complete in
+// order.  Left-looking:  s_i = a_ij - sum_{k<j} l_ik l_jk ;  l_jj = sqrt(s_j) ;  l_ij = s_i / l_jj
 // then X = L^-1 by forward substitution, lane = column of X.
-#define WAVE_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-
-__device__ int tile_chol_inv(double* __restrict__ D, double* __restrict__ X, int tid,
-                             double* s_diag, int* s_flag)
+__device__ int tile_chol_inv(double* __restrict__ D, double* __restrict__ X, int tid, int* s_flag)
 {
-    (void)s_diag;
     if (tid == 0) *s_flag = 0;
     __syncthreads();
     if (tid < NB) {
         const int i = tid;
         int bad = 0;
         for (int j = 0; j < NB; j++) {
-            double s0 = D[i * LDB + j], s1 = 0.0;
+            double s0 = D[i * LDT + j], s1 = 0.0, s2 = 0.0, s3 = 0.0;
             int k = 0;
-            for (; k + 1 < j; k += 2) {
-                s0 = fma(-D[i * LDB + k], D[j * LDB + k], s0);
-                s1 = fma(-D[i * LDB + k + 1], D[j * LDB + k + 1], s1);
+            for (; k + 3 < j; k += 4) {
+                s0 = fma(-D[i * LDT + k], D[j * LDT + k], s0);
+                s1 = fma(-D[i * LDT + k + 1], D[j * LDT + k + 1], s1);
+                s2 = fma(-D[i * LDT + k + 2], D[j * LDT + k + 2], s2);
+                s3 = fma(-D[i * LDT + k + 3], D[j * LDT + k + 3], s3);
             }
-            if (k < j) s0 = fma(-D[i * LDB + k], D[j * LDB + k], s0);
-            const double s = s0 + s1;
+            for (; k < j; k++) s0 = fma(-D[i * LDT + k], D[j * LDT + k], s0);
+            const double s = (s0 + s1) + (s2 + s3);
             const double piv = __shfl(s, j);
             if (!(piv > 0.0)) bad = 1;
             const double d = sqrt(piv);
             const double l = (i == j) ? d : ((i > j) ? s / d : 0.0);
             WAVE_LDS_SYNC();                       // every lane has finished reading column/row data
-            D[i * LDB + j] = l;
+            D[i * LDT + j] = l;
             WAVE_LDS_SYNC();                       // column j visible to the whole wave
         }
-        // X = L^-1 : lane c owns column c
-        const int c = tid;
+        const int c = tid;                         // X = L^-1 : lane c owns column c
         for (int r = 0; r < NB; r++) {
-            double s0 = (r == c) ? 1.0 : 0.0, s1 = 0.0;
+            double s0 = (r == c) ? 1.0 : 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
             int k = 0;
-            for (; k + 1 < r; k += 2) {
-                s0 = fma(-D[r * LDB + k], X[k * LDB + c], s0);
-                s1 = fma(-D[r * LDB + k + 1], X[(k + 1) * LDB + c], s1);
+            for (; k + 3 < r; k += 4) {
+                s0 = fma(-D[r * LDT + k], X[k * LDT + c], s0);
+                s1 = fma(-D[r * LDT + k + 1], X[(k + 1) * LDT + c], s1);
+                s2 = fma(-D[r * LDT + k + 2], X[(k + 2) * LDT + c], s2);
+                s3 = fma(-D[r * LDT + k + 3], X[(k + 3) * LDT + c], s3);
             }
-            if (k < r) s0 = fma(-D[r * LDB + k], X[k * LDB + c], s0);
-            const double x = (r >= c) ? (s0 + s1) / D[r * LDB + r] : 0.0;
-            X[r * LDB + c] = x;                    // only this lane ever reads column c of X
+            for (; k < r; k++) s0 = fma(-D[r * LDT + k], X[k * LDT + c], s0);
+            const double x = (r >= c) ? ((s0 + s1) + (s2 + s3)) / D[r * LDT + r] : 0.0;
+            X[r * LDT + c] = x;                    // only this lane ever reads column c of X
         }
         if (bad) *s_flag = 1;
     }
@@ -139,196 +129,216 @@ __device__ int tile_chol_inv(double* __restrict__ D, double* __restrict__ X, int
     return *s_flag;
 }
 
+// Layout of the factor workspace of one problem: pb.A = [A0 | A1 | L0 | L1], each Mld x Mld
+// row-major; pb.Linv = [2][nblk][NB x NB] inverses of the diagonal blocks of L.
+
 // ------------------------------------------------------------------------------------------
-// K5: one step of the right-looking blocked Cholesky with one-column look-ahead.
-// Launch `step` = s does, for every problem and both matrices:
-//   * every block (bi,bj), s <= bj <= bi:   A_bibj -= L_{bi,s-1} L_{bj,s-1}^T      (s > 0)
-//   * blocks of column s additionally finish their column: each recomputes the updated diagonal
-//     block, factors it (redundantly -- no inter-workgroup traffic inside a launch), and
-//     L_{bi,s} = A_{bi,s} Linv_ss^T.  L overwrites the lower triangle of A; the diagonal
-//     block of column s is written by the (s,s) workgroup only, and nobody reads it in the same
-//     launch from A: column workgroups read A_ss *before* ... see note below.
-// Note on the in-launch hazard: workgroup (s,s) must not overwrite A_ss while workgroups
-// (bi,s) still read it, so L blocks are written to the separate array Lm (row-major like A)
-// and A is only ever updated in place by the block's own workgroup.
-// grid.x enumerates (bi,bj) pairs of the remaining trailing matrix, grid.y = problem*2+matrix.
+// K5a: factor the first diagonal block of both matrices of every problem.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void factor_step_kernel(const Prob* __restrict__ probs, int step)
+__global__ __launch_bounds__(256) void factor_init_kernel(const Prob* __restrict__ probs)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    double* T0 = smem;                 // the block being updated (kept until the end)
-    double* T1 = T0 + NB * LDB;        // L_{bi,s-1}, then the diagonal block / L_ss, then the result
-    double* T2 = T1 + NB * LDB;        // L_{bj,s-1}, then Linv_ss
-    double* s_diag = T2 + NB * LDB;    // [NB]
+    double* TD = smem;
+    double* TX = TD + NB * LDT;
+    __shared__ int s_flag;
+    const Prob& pb = probs[blockIdx.x >> 1];
+    const int mat = blockIdx.x & 1;
+    if (pb.ld_only || pb.npanel == 0) return;
+    const int tid = threadIdx.x, ld = pb.Mld;
+    const auto A = pb.A + (size_t)mat * ld * ld;
+    const auto Lm = pb.A + (size_t)(2 + mat) * ld * ld;
+    tile_load(TD, A, ld, tid);
+    const int fail = tile_chol_inv(TD, TX, tid, &s_flag);
+    tile_store(Lm, ld, TD, tid);
+    const auto Li = pb.Linv + (size_t)mat * pb.nblk * NB * NB;
+    for (int e = tid; e < NB * NB; e += 256) Li[e] = TX[(e >> 6) * LDT + (e & 63)];
+    if (fail && tid == 0) pb.status[mat] = 1;
+}
+
+// ------------------------------------------------------------------------------------------
+// K5b: block column s of L (left-looking), for every problem and both matrices.
+//   workgroup bi (s < bi < nblk):
+//       C        = A[bi][s] - sum_{j<s} L[bi][j] L[s][j]^T
+//       L[bi][s] = C * Linv_ss^T
+//   the workgroup bi = s+1 then also finishes the next diagonal block, so that the next launch
+//   finds L[s+1][s+1] and its inverse ready and no workgroup ever waits on another one:
+//       D = A[s+1][s+1] - sum_{j<=s} L[s+1][j] L[s+1][j]^T ;  D = L_d L_d^T ;  Linv_{s+1} = L_d^-1
+// grid.x = max_nblk - 1 - s, grid.y = problem * 2 + matrix.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void factor_col_kernel(const Prob* __restrict__ probs, int s)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* TA = smem;                 // L[bi][j]           | C            | L_new  | X
+    double* TB = TA + NB * LDT;        // L[s][j]            | Linv_ss      | D
     __shared__ int s_flag;
 
     const Prob& pb = probs[blockIdx.y >> 1];
     const int mat = blockIdx.y & 1;
     if (pb.ld_only || pb.npanel == 0) return;
     const int nb = pb.nblk;
-    const int rem = nb - step;
-    if (rem <= 0) return;
-    // decode blockIdx.x -> (bi, bj) in the remaining lower triangle (row-major enumeration)
-    const int t = blockIdx.x;
-    if (t >= rem * (rem + 1) / 2) return;
-    int bi = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
-    while (bi * (bi + 1) / 2 > t) bi--;
-    while ((bi + 1) * (bi + 2) / 2 <= t) bi++;
-    int bj = t - bi * (bi + 1) / 2;
-    bi += step; bj += step;
+    const int bi = s + 1 + blockIdx.x;
+    if (bi >= nb) return;
+    const bool next_diag = (bi == s + 1);
 
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ld = pb.Mld;
-    double* A = pb.A + (size_t)mat * ld * ld;
-    double* Lm = pb.A + (size_t)(2 + mat) * ld * ld;
-    double* Ablk = A + (size_t)bi * NB * ld + (size_t)bj * NB;
+    const auto A = pb.A + (size_t)mat * ld * ld;
+    const auto Lm = pb.A + (size_t)(2 + mat) * ld * ld;
 
-    tile_load(T0, Ablk, ld, tid);
-    if (step > 0) {
-        tile_load(T1, Lm + (size_t)bi * NB * ld + (size_t)(step - 1) * NB, ld, tid);
-        tile_load(T2, Lm + (size_t)bj * NB * ld + (size_t)(step - 1) * NB, ld, tid);
-        __syncthreads();
-        tile_gemm_nt_sub(T0, T1, T2, tid);
-    }
-    __syncthreads();
-    if (bj != step) {                  // plain trailing block: write back and finish
-        tile_store(Ablk, ld, T0, tid);
-        return;
-    }
-    // column `step`: T1 <- updated diagonal block A_ss
-    if (bi == step) {
-        for (int e = tid; e < NB * LDB; e += 256) T1[e] = T0[e];
-    } else {
-        tile_load(T1, A + (size_t)step * NB * ld + (size_t)step * NB, ld, tid);
-        if (step > 0) {
-            __syncthreads();
-            tile_gemm_nt_sub(T1, T2, T2, tid);      // T2 = L_{step,step-1} because bj == step
+    f64x4 acc[4], accd[4];
+#pragma unroll
+    for (int n = 0; n < 4; n++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = acc_row(wave, lane, r), col = acc_col(lane, n);
+            acc[n][r] = A[(size_t)(bi * NB + row) * ld + s * NB + col];
+            accd[n][r] = next_diag ? A[(size_t)(bi * NB + row) * ld + bi * NB + col] : 0.0;
         }
+    for (int j = 0; j < s; j++) {
+        __syncthreads();
+        tile_load(TA, Lm + (size_t)bi * NB * ld + (size_t)j * NB, ld, tid);
+        tile_load(TB, Lm + (size_t)s * NB * ld + (size_t)j * NB, ld, tid);
+        __syncthreads();
+        mfma_nt<4, true>(acc, TA, TB, wave, lane);
+        if (next_diag) mfma_nt<4, true>(accd, TA, TA, wave, lane);
     }
     __syncthreads();
-    const int fail = tile_chol_inv(T1, T2, tid, s_diag, &s_flag);   // T1 = L_ss, T2 = Linv_ss
-    if (bi == step) {
-        tile_store(Lm + (size_t)step * NB * ld + (size_t)step * NB, ld, T1, tid);
-        double* Li = pb.Linv + ((size_t)mat * nb + step) * NB * NB;
-        for (int e = tid; e < NB * NB; e += 256) Li[e] = T2[(e >> 6) * LDB + (e & 63)];
-        if (fail && tid == 0) pb.status[mat] = 1;
-    } else {
-        tile_gemm_nt_set(T1, T0, T2, tid);          // L_{bi,s} = A_{bi,s} * Linv_ss^T
-        __syncthreads();
-        tile_store(Lm + (size_t)bi * NB * ld + (size_t)step * NB, ld, T1, tid);
+    // TA <- C, TB <- Linv_ss
+#pragma unroll
+    for (int n = 0; n < 4; n++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) TA[acc_row(wave, lane, r) * LDT + acc_col(lane, n)] = acc[n][r];
+    {
+        const auto Li = pb.Linv + ((size_t)mat * nb + s) * NB * NB;
+        for (int e = tid; e < NB * NB; e += 256) TB[(e >> 6) * LDT + (e & 63)] = Li[e];
     }
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < 4; n++) acc[n] = f64x4{0.0, 0.0, 0.0, 0.0};
+    mfma_nt<4, false>(acc, TA, TB, wave, lane);              // L[bi][s] = C * Linv_ss^T
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < 4; n++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = acc_row(wave, lane, r), col = acc_col(lane, n);
+            Lm[(size_t)(bi * NB + row) * ld + s * NB + col] = acc[n][r];
+            TA[row * LDT + col] = acc[n][r];
+        }
+    if (!next_diag) return;
+    __syncthreads();
+    mfma_nt<4, true>(accd, TA, TA, wave, lane);              // D -= L[s+1][s] L[s+1][s]^T
+#pragma unroll
+    for (int n = 0; n < 4; n++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) TB[acc_row(wave, lane, r) * LDT + acc_col(lane, n)] = accd[n][r];
+    __syncthreads();
+    const int fail = tile_chol_inv(TB, TA, tid, &s_flag);    // TB = L_dd, TA = its inverse
+    tile_store(Lm + (size_t)bi * NB * ld + (size_t)bi * NB, ld, TB, tid);
+    const auto Li = pb.Linv + ((size_t)mat * nb + bi) * NB * NB;
+    for (int e = tid; e < NB * NB; e += 256) Li[e] = TA[(e >> 6) * LDT + (e & 63)];
+    if (fail && tid == 0) pb.status[mat] = 1;
 }
 
-static const size_t FACTOR_SMEM = ((size_t)3 * NB * LDB + NB) * sizeof(double);
+static const size_t FACTOR_SMEM = (size_t)2 * NB * LDT * sizeof(double);
 
-void launch_factor_step(const Prob* d_probs, int n_prob, int step, int max_nblk, hipStream_t s)
+// step 0 factors the first diagonal block; step s >= 1 builds block column s-1
+void launch_factor_step(const Prob* d_probs, int n_prob, int step, int max_nblk, hipStream_t st)
 {
-    const int rem = max_nblk - step;
-    if (rem <= 0 || n_prob <= 0) return;
+    if (n_prob <= 0 || step >= max_nblk) return;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(factor_step_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)FACTOR_SMEM);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(factor_init_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FACTOR_SMEM);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(factor_col_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FACTOR_SMEM);
         attr_set = true;
     }
-    hipLaunchKernelGGL(factor_step_kernel, dim3(rem * (rem + 1) / 2, n_prob * 2), dim3(256), FACTOR_SMEM, s, d_probs, step);
+    if (step == 0) {
+        hipLaunchKernelGGL(factor_init_kernel, dim3(n_prob * 2), dim3(256), FACTOR_SMEM, st, d_probs);
+        return;
+    }
+    const int s = step - 1;
+    const int rows = max_nblk - 1 - s;
+    if (rows <= 0) return;
+    hipLaunchKernelGGL(factor_col_kernel, dim3(rows, n_prob * 2), dim3(256), FACTOR_SMEM, st, d_probs, s);
 }
 
 // ------------------------------------------------------------------------------------------
-// K6/K7: forward substitution for one panel of NR = 32 right-hand sides (31 unmeasured SNPs'
-// b21 rows + the z1 column), left-looking over the NB-blocks of L, then z / info.
+// K6/K7: forward substitution for one panel of NR = 64 right-hand sides (63 unmeasured SNPs'
+// b21 rows + the z1 column), left-looking over the 64-blocks of L, then z / info.
 // One workgroup per panel; panels are independent (no inter-workgroup traffic).
 //   V_k = Linv_kk * (B_k - sum_{j<k} L_kj V_j)
-// V blocks are kept in the problem's V scratch ([panel][Mld][NR]) for reuse by later blocks.
+// V blocks live in the problem's V scratch ([panel][Mld][NR]) for reuse by later blocks.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void solve_kernel(const Prob* __restrict__ probs,
                                                     const int2* __restrict__ panelmap)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    double* TL = smem;                       // [NB][LDB]  L_kj or Linv_kk
-    double* TV = TL + NB * LDB;              // [NB][NR+1] V_j
-    double* TX = TV + NB * (NR + 1);         // [NB][NR+1] running rhs / result
-    double* red = TX + NB * (NR + 1);        // [2][256] reduction scratch
-    constexpr int LV = NR + 1;
+    double* TL = smem;                       // [64][LDT]   L_kj, then Linv_kk
+    double* TV = TL + NB * LDT;              // [64][LDV]   V_j, then the rhs block X, then V_k
+    double* red = TV + NB * LDV;             // [2][256]
 
     const int2 pm = panelmap[blockIdx.x];
     const Prob& pb = probs[pm.x];
     const int panel = pm.y;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ld = pb.Mld, nb = pb.nblk;
-    const double* Lm = pb.A + (size_t)2 * ld * ld;            // factor of A[0]
-    const double* Linv = pb.Linv;                             // matrix 0
-    double* V = pb.V + (size_t)panel * ld * NR;
+    const auto Lm = pb.A + (size_t)2 * ld * ld;               // factor of A[0]
+    const auto Linv = pb.Linv;                                // matrix 0
+    const auto V = pb.V + (size_t)panel * ld * NR;
     const int u0 = panel * NRU;
 
-    // thread -> (row pair, col quad) of a 64 x 32 tile: rows r0, r0+1; cols c0..c0+3
-    const int r0 = (tid >> 3) << 1, c0 = (tid & 7) << 2;
-    // reduction ownership: column cc = tid & 31, row group rg = tid >> 5 (8 rows each)
-    const int cc = tid & 31, rg = tid >> 5;
+    const int cc = tid & 63, rg = tid >> 6;                   // reduction: column cc, rows 16 rg ..
     double zsum = 0.0, isum = 0.0;
 
     for (int kb = 0; kb < nb; kb++) {
-        // TX <- B block: rhs c < 31: B21[u0+c][kb*64 + r]; c == 31: z1 (zero padded)
+        f64x4 acc[4];
+#pragma unroll
+        for (int n = 0; n < 4; n++) acc[n] = f64x4{0.0, 0.0, 0.0, 0.0};
+        for (int jb = 0; jb < kb; jb++) {
+            __syncthreads();
+            tile_load(TL, Lm + (size_t)kb * NB * ld + (size_t)jb * NB, ld, tid);
+            for (int e = tid; e < NB * NR; e += 256) TV[(e >> 6) * LDV + (e & 63)] = V[(size_t)(jb * NB + (e >> 6)) * NR + (e & 63)];
+            __syncthreads();
+            mfma_nn<4, true>(acc, TL, TV, wave, lane);        // acc = - sum_j L_kj V_j
+        }
+        __syncthreads();
+        // TV <- rhs block: column c < 63: B21[u0+c][kb*64 + r]; column 63: z1 (zero padded)
         for (int e = tid; e < NB * NR; e += 256) {
-            const int c = e >> 6, r = e & 63;          // r fastest: coalesced along a B21 row
+            const int c = e >> 6, r = e & 63;                 // r fastest: coalesced along a B21 row
             const int k = kb * NB + r;
             double v = 0.0;
             if (c < NRU) { const int u = u0 + c; if (u < pb.U) v = pb.B21[(size_t)u * ld + k]; }
             else if (k < pb.M) v = pb.z1[k];
-            TX[r * LV + c] = v;
+            TV[r * LDV + c] = v;
         }
-        double acc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-        for (int jb = 0; jb < kb; jb++) {
-            __syncthreads();
-            tile_load(TL, Lm + (size_t)kb * NB * ld + (size_t)jb * NB, ld, tid);
-            for (int e = tid; e < NB * NR; e += 256) TV[(e >> 5) * LV + (e & 31)] = V[(size_t)(jb * NB + (e >> 5)) * NR + (e & 31)];
-            __syncthreads();
-            for (int k = 0; k < NB; k++) {
-                const double a0 = TL[r0 * LDB + k], a1 = TL[(r0 + 1) * LDB + k];
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const double b = TV[k * LV + c0 + j];
-                    acc[0][j] = fma(a0, b, acc[0][j]);
-                    acc[1][j] = fma(a1, b, acc[1][j]);
-                }
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            TX[r0 * LV + c0 + j] -= acc[0][j];
-            TX[(r0 + 1) * LV + c0 + j] -= acc[1][j];
-        }
-        // TL <- Linv_kk ; V_k = Linv_kk * TX
         {
-            const double* Li = Linv + (size_t)kb * NB * NB;
-            for (int e = tid; e < NB * NB; e += 256) TL[(e >> 6) * LDB + (e & 63)] = Li[e];
+            const auto Li = Linv + (size_t)kb * NB * NB;
+            for (int e = tid; e < NB * NB; e += 256) TL[(e >> 6) * LDT + (e & 63)] = Li[e];
         }
         __syncthreads();
-        double v[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-        for (int k = 0; k <= r0 + 1; k++) {
-            const double a0 = TL[r0 * LDB + k], a1 = TL[(r0 + 1) * LDB + k];
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const double b = TX[k * LV + c0 + j];
-                v[0][j] = fma(a0, b, v[0][j]);
-                v[1][j] = fma(a1, b, v[1][j]);
+        for (int n = 0; n < 4; n++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) TV[acc_row(wave, lane, r) * LDV + acc_col(lane, n)] += acc[n][r];
+        __syncthreads();
+#pragma unroll
+        for (int n = 0; n < 4; n++) acc[n] = f64x4{0.0, 0.0, 0.0, 0.0};
+        mfma_nn<4, false>(acc, TL, TV, wave, lane);           // V_k = Linv_kk * X
+        __syncthreads();
+#pragma unroll
+        for (int n = 0; n < 4; n++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = acc_row(wave, lane, r), col = acc_col(lane, n);
+                TV[row * LDV + col] = acc[n][r];
+                V[(size_t)(kb * NB + row) * NR + col] = acc[n][r];
             }
-        }
         __syncthreads();
+        // accumulate z and info for column cc over this block's rows 16 rg .. 16 rg + 15
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            TV[r0 * LV + c0 + j] = v[0][j];
-            TV[(r0 + 1) * LV + c0 + j] = v[1][j];
-            V[(size_t)(kb * NB + r0) * NR + c0 + j] = v[0][j];
-            V[(size_t)(kb * NB + r0 + 1) * NR + c0 + j] = v[1][j];
-        }
-        __syncthreads();
-        // accumulate z and info for column cc over this block's rows rg*8 .. rg*8+7
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const double x = TV[(rg * 8 + r) * LV + cc];
-            const double y = TV[(rg * 8 + r) * LV + NRU];
+        for (int r = 0; r < 16; r++) {
+            const double x = TV[(rg * 16 + r) * LDV + cc];
+            const double y = TV[(rg * 16 + r) * LDV + NRU];
             zsum = fma(x, y, zsum);
             isum = fma(x, x, isum);
         }
@@ -339,7 +349,7 @@ __global__ __launch_bounds__(256) void solve_kernel(const Prob* __restrict__ pro
     __syncthreads();
     if (tid < NRU) {
         double z = 0.0, info = 0.0;
-        for (int g = 0; g < 8; g++) { z += red[g * 32 + tid]; info += red[256 + g * 32 + tid]; }
+        for (int g = 0; g < 4; g++) { z += red[g * 64 + tid]; info += red[256 + g * 64 + tid]; }
         const int u = u0 + tid;
         if (u < pb.U) {
             info = fabs(info);                         // dist.cpp:198
@@ -352,11 +362,10 @@ __global__ __launch_bounds__(256) void solve_kernel(const Prob* __restrict__ pro
 void launch_solve(const Prob* d_probs, const int2* d_panelmap, int n_panels, hipStream_t s)
 {
     if (n_panels <= 0) return;
-    const size_t sh = ((size_t)NB * LDB + 2 * (size_t)NB * (NR + 1) + 512) * sizeof(double);
+    const size_t sh = ((size_t)NB * LDT + (size_t)NB * LDV + 512) * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(solve_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
         attr_set = true;
     }
     hipLaunchKernelGGL(solve_kernel, dim3(n_panels), dim3(256), sh, s, d_probs, d_panelmap);
