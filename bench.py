@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--wing", type=int, default=500_000)
     ap.add_argument("--sample-scale", type=float, default=1.0, help="shrink every population (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=1, help="split the windows over this many jobs/streams")
     args = ap.parse_args()
 
     import torch
@@ -93,11 +94,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP hot path has no CPU fallback")
+    # rehearsal hook: several ranks on ONE card (gloo instead of RCCL, which refuses duplicate devices)
+    rehearsal = os.environ.get("GAUSS_BENCH_SHARED_DEVICE") == "1"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world)   # RCCL; used for timing barriers only
+        # RCCL ("nccl" on ROCm); used for the timing barriers and two scalar reductions only
+        dist.init_process_group("gloo" if rehearsal else "nccl", rank=rank, world_size=world)
+    red_dev = "cpu" if rehearsal else "cuda"
 
     from gauss_amd import _lib, hotpath
     ctx = hotpath.Context(local)
@@ -124,9 +131,14 @@ def main():
         descs.append(dict(mode=hotpath.MODE_WEIGHTED, pop_off=ch["off"], pop_wgt=ch["w"], z1=ch["z"][mi],
                           dev=(gm.data_ptr(), gu.data_ptr(), len(mi), len(ui), ld)))
     torch.cuda.synchronize()
-    job = hotpath.Job(descs, ctx=ctx, on_device=True)
-    work = job.work()
-    stats = job.stats()
+    if args.streams > 1:
+        jobs = [hotpath.Job(descs[i::args.streams], ctx=(ctx if i == 0 else hotpath.Context(local)), on_device=True)
+                for i in range(args.streams)]
+    else:
+        jobs = [hotpath.Job(descs, ctx=ctx, on_device=True)]
+    job = jobs[0]
+    work = {k: sum(j.work()[k] for j in jobs) for k in job.work()}
+    stats = {k: sum(j.stats()[k] for j in jobs) for k in job.stats()}
 
     def barrier():
         torch.cuda.synchronize()
@@ -135,8 +147,12 @@ def main():
         torch.cuda.synchronize()
 
     def step():
-        job.run()
-        return job.fetch()
+        for j in jobs:
+            j.run()
+        out = []
+        for j in jobs:
+            out += j.fetch()
+        return out
 
     for _ in range(args.warmup):
         step()
@@ -157,9 +173,9 @@ def main():
 
     tmax, snps = dt, float(work["imputed_snps"])
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        s = torch.tensor([snps], dtype=torch.float64, device="cuda")
+        s = torch.tensor([snps], dtype=torch.float64, device=red_dev)
         dist.all_reduce(s, op=dist.ReduceOp.SUM)
         tmax, snps = float(t.item()), float(s.item())
 
