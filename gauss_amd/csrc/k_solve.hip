@@ -77,6 +77,32 @@ __device__ __forceinline__ void tile_store(P g, int ld, const double* __restrict
     for (int e = tid; e < NB * NB; e += 256) g[(size_t)(e >> 6) * ld + (e & 63)] = T[(e >> 6) * LDT + (e & 63)];
 }
 
+// Register-staged tile transfer: fetch() issues the global loads of a 64 x 64 tile (8 x 16 bytes per
+// thread) and returns at once; commit() stores them into an LDS image later, so the loads fly while
+// the matrix cores work on the previous tile.
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+struct TileRegs { f64x2 v[8]; };
+
+template <typename P>
+__device__ __forceinline__ void tile_fetch(TileRegs& t, P g, int ld, int tid)
+{
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const int e = tid + 256 * q;                 // 2048 pairs: row e / 32, columns 2 (e % 32)
+        const auto p = g + (size_t)(e >> 5) * ld + ((e & 31) << 1);
+        t.v[q] = f64x2{p[0], p[1]};
+    }
+}
+template <int LD>
+__device__ __forceinline__ void tile_commit(double* __restrict__ T, const TileRegs& t, int tid)
+{
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const int e = tid + 256 * q;
+        *reinterpret_cast<f64x2*>(T + (e >> 5) * LD + ((e & 31) << 1)) = t.v[q];
+    }
+}
+
 // In-place Cholesky of the 64x64 LDS tile D (lower triangle result, upper zeroed), followed by
 // the inverse of the factor into X (both [row][col] with leading dimension LDT).  Returns
 // (block-uniform) 1 if a pivot was not positive.  A dependency chain of 64 columns: run by ONE
@@ -194,11 +220,20 @@ __global__ __launch_bounds__(256) void factor_col_kernel(const Prob* __restrict_
             acc[n][r] = A[(size_t)(bi * NB + row) * ld + s * NB + col];
             accd[n][r] = next_diag ? A[(size_t)(bi * NB + row) * ld + bi * NB + col] : 0.0;
         }
+    TileRegs ra, rb;
+    if (s > 0) {
+        tile_fetch(ra, Lm + (size_t)bi * NB * ld, ld, tid);
+        tile_fetch(rb, Lm + (size_t)s * NB * ld, ld, tid);
+    }
     for (int j = 0; j < s; j++) {
+        __syncthreads();                              // previous tiles are no longer being read
+        tile_commit<LDT>(TA, ra, tid);
+        tile_commit<LDT>(TB, rb, tid);
         __syncthreads();
-        tile_load(TA, Lm + (size_t)bi * NB * ld + (size_t)j * NB, ld, tid);
-        tile_load(TB, Lm + (size_t)s * NB * ld + (size_t)j * NB, ld, tid);
-        __syncthreads();
+        if (j + 1 < s) {                              // next tiles fly during the products
+            tile_fetch(ra, Lm + (size_t)bi * NB * ld + (size_t)(j + 1) * NB, ld, tid);
+            tile_fetch(rb, Lm + (size_t)s * NB * ld + (size_t)(j + 1) * NB, ld, tid);
+        }
         mfma_nt<4, true>(acc, TA, TB, wave, lane);
         if (next_diag) mfma_nt<4, true>(accd, TA, TA, wave, lane);
     }
@@ -294,11 +329,20 @@ __global__ __launch_bounds__(256) void solve_kernel(const Prob* __restrict__ pro
         f64x4 acc[4];
 #pragma unroll
         for (int n = 0; n < 4; n++) acc[n] = f64x4{0.0, 0.0, 0.0, 0.0};
+        TileRegs rl, rv;
+        if (kb > 0) {
+            tile_fetch(rl, Lm + (size_t)kb * NB * ld, ld, tid);
+            tile_fetch(rv, V, NR, tid);
+        }
         for (int jb = 0; jb < kb; jb++) {
+            __syncthreads();                                  // previous tiles are no longer being read
+            tile_commit<LDT>(TL, rl, tid);
+            tile_commit<LDV>(TV, rv, tid);
             __syncthreads();
-            tile_load(TL, Lm + (size_t)kb * NB * ld + (size_t)jb * NB, ld, tid);
-            for (int e = tid; e < NB * NR; e += 256) TV[(e >> 6) * LDV + (e & 63)] = V[(size_t)(jb * NB + (e >> 6)) * NR + (e & 63)];
-            __syncthreads();
+            if (jb + 1 < kb) {                                // next tiles fly during the product
+                tile_fetch(rl, Lm + (size_t)kb * NB * ld + (size_t)(jb + 1) * NB, ld, tid);
+                tile_fetch(rv, V + (size_t)(jb + 1) * NB * NR, NR, tid);
+            }
             mfma_nn<4, true>(acc, TL, TV, wave, lane);        // acc = - sum_j L_kj V_j
         }
         __syncthreads();

@@ -10,7 +10,28 @@ __global__ __launch_bounds__(256) void probe(const unsigned* __restrict__ in, fl
     f32x16 a00 = {0}, a01 = {0}, a10 = {0}, a11 = {0};
     unsigned w0 = in[threadIdx.x], w1 = in[threadIdx.x + 256], w2 = in[threadIdx.x + 512], w3 = in[threadIdx.x + 768];
     for (int it = 0; it < iters; it++) {
-        if (VARIANT == 0) {
+        if (VARIANT == 4) {
+            // operands as f32 in LDS: 16 ds_read_b128 per 64 MFMAs, zero VALU
+            __shared__ float lds[4096 + 64];
+            if (it == 0) { for (int q = threadIdx.x; q < 4096; q += 256) lds[q] = (float)(q & 1); __syncthreads(); }
+            const float* base = lds + (threadIdx.x & 63) * 36 + ((it & 3) << 2);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float4 fa0 = *reinterpret_cast<const float4*>(base + j * 8);
+                const float4 fa1 = *reinterpret_cast<const float4*>(base + j * 8 + 1152);
+                const float4 fb0 = *reinterpret_cast<const float4*>(base + j * 8 + 576);
+                const float4 fb1 = *reinterpret_cast<const float4*>(base + j * 8 + 1728);
+                const float a0[4] = {fa0.x, fa0.y, fa0.z, fa0.w}, a1[4] = {fa1.x, fa1.y, fa1.z, fa1.w};
+                const float b0[4] = {fb0.x, fb0.y, fb0.z, fb0.w}, b1[4] = {fb1.x, fb1.y, fb1.z, fb1.w};
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    a00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], b0[t], a00, 0, 0, 0);
+                    a01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], b1[t], a01, 0, 0, 0);
+                    a10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], b0[t], a10, 0, 0, 0);
+                    a11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], b1[t], a11, 0, 0, 0);
+                }
+            }
+        } else if (VARIANT == 0) {
             float fa0 = __uint_as_float(w0), fa1 = __uint_as_float(w1), fb0 = __uint_as_float(w2), fb1 = __uint_as_float(w3);
 #pragma unroll
             for (int t = 0; t < 16; t++) {
@@ -65,7 +86,7 @@ int main()
     hipMalloc(&in, 4096); hipMemset(in, 0x38, 4096);
     const int iters = 2000;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int variant = 0; variant < 4; variant++)
+    for (int variant = 3; variant < 5; variant++)
         for (int wg_per_cu = 1; wg_per_cu <= 4; wg_per_cu++) {
             const int blocks = 256 * wg_per_cu;
             hipMalloc(&out, (size_t)blocks * 256 * 4);
@@ -73,6 +94,7 @@ int main()
                 hipEventRecord(e0);
                 if (variant == 0) hipLaunchKernelGGL(probe<0>, dim3(blocks), dim3(256), 0, 0, in, out, iters);
                 if (variant == 1) hipLaunchKernelGGL(probe<1>, dim3(blocks), dim3(256), 0, 0, in, out, iters);
+                if (variant == 4) hipLaunchKernelGGL(probe<4>, dim3(blocks), dim3(256), 0, 0, in, out, iters);
                 if (variant == 3) hipLaunchKernelGGL(probe<3>, dim3(blocks), dim3(256), 0, 0, in, out, iters);
                 if (variant == 2) hipLaunchKernelGGL(probe<2>, dim3(blocks), dim3(256), 0, 0, in, out, iters);
                 hipEventRecord(e1); hipEventSynchronize(e1);
