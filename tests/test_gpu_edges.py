@@ -1,0 +1,202 @@
+"""GPU edge cases: tile / block / panel boundaries, tiny and ragged inputs, many populations, large
+genotype codes, error reporting, and size-independent properties at the BASELINE sizes."""
+import numpy as np
+import pytest
+
+import oracle
+from gauss_amd import hotpath, synth
+from helpers import relerr
+
+pytestmark = pytest.mark.gpu
+
+
+def rand_geno(rng, rows, n, lo=0.05, hi=0.95):
+    af = rng.uniform(lo, hi, size=(rows, 1))
+    g = (rng.random((rows, n)) < af).astype(np.uint8) + (rng.random((rows, n)) < af).astype(np.uint8)
+    for r in range(rows):                      # no monomorphic rows
+        if g[r].min() == g[r].max():
+            g[r, 0], g[r, 1] = 0, 2
+    return g
+
+
+def check_window(ctx, mode, gm, gu, off, w, z1, tol=1e-8):
+    got = hotpath.impute_window(mode, gm, gu, off, w, z1, want_mats=True, ctx=ctx)
+    want = oracle.run_impute(mode, gm, gu, off, w, z1, want_mats=True)
+    assert got["status"] == 0 and want["mpd"] == 0
+    assert np.max(np.abs(got["b11"] - want["b11"])) <= 1e-12
+    assert np.max(np.abs(got["b21"] - want["b21"])) <= 1e-12
+    assert relerr(got["info"], want["info"]) <= tol
+    assert np.max(np.abs(got["z"] - want["z"]) / np.maximum(1.0, np.abs(want["z"]))) <= tol
+
+
+@pytest.mark.parametrize("M,U", [(1, 1), (2, 3), (63, 62), (64, 63), (65, 64), (127, 126), (128, 127), (129, 128),
+                                 (192, 130), (257, 5)])
+def test_tile_block_and_panel_boundaries(ctx, M, U):
+    rng = np.random.default_rng(M * 1000 + U)
+    N = 333                                     # not a multiple of 16 or 64
+    off = np.array([0, 100, 101 + 30, 333], dtype=np.int32)
+    w = np.array([0.3, 0.5, 0.261])
+    G = rand_geno(rng, M + U, N)
+    z1 = rng.standard_normal(M)
+    for mode in (0, 1):
+        check_window(ctx, mode, G[:M], G[M:], off, w, z1)
+
+
+def test_tiny_populations_and_row_stride(ctx):
+    rng = np.random.default_rng(3)
+    sizes = [2, 3, 2, 17, 2]
+    off = synth.pop_offsets(sizes)
+    N = int(off[-1])
+    buf = np.zeros((40, N + 7), dtype=np.uint8)          # ld > N
+    buf[:, :N] = rand_geno(rng, 40, N, 0.2, 0.8)
+    gm, gu = buf[:15, :N], buf[15:, :N]                   # non-contiguous views keep the parent stride
+    w = np.array([0.2, 0.2, 0.2, 0.3, 0.161])
+    z1 = rng.standard_normal(15)
+    got = hotpath.impute_window(1, np.ascontiguousarray(gm), np.ascontiguousarray(gu), off, w, z1, want_mats=True, ctx=ctx)
+    want = oracle.run_impute(1, gm, gu, off, w, z1, want_mats=True)
+    ok = np.isfinite(want["b11"])
+    assert np.array_equal(np.isfinite(got["b11"]), ok)
+    assert np.max(np.abs(got["b11"][ok] - want["b11"][ok])) <= 1e-12
+
+
+@pytest.mark.parametrize("P", [33, 64])
+def test_many_populations_use_the_global_table_path(ctx, P):
+    rng = np.random.default_rng(P)
+    sizes = rng.integers(20, 60, size=P)
+    off = synth.pop_offsets(sizes)
+    w = rng.uniform(0.5, 1.5, P)
+    w *= 1.061 / w.sum()
+    G = rand_geno(rng, 70, int(off[-1]))
+    got = hotpath.ld_matrix(G, off, w, ctx=ctx)
+    want = oracle.compute_ld(G, off, w)
+    assert np.max(np.abs(got - want)) <= 1e-12
+    check_window(ctx, 1, G[:30], G[30:], off, w, rng.standard_normal(30))
+
+
+def test_codes_up_to_15_and_ascii_digits(ctx):
+    rng = np.random.default_rng(9)
+    G = rng.integers(0, 16, size=(37, 500)).astype(np.uint8)
+    want = G.astype(np.int64) @ G.astype(np.int64).T
+    assert np.array_equal(hotpath.gram_counts(G, ctx=ctx), want)
+    D = rng.integers(0, 10, size=(20, 300)).astype(np.uint8)
+    assert np.array_equal(hotpath.gram_counts(D + ord("0"), ctx=ctx), D.astype(np.int64) @ D.astype(np.int64).T)
+
+
+def test_ld_only_shapes(ctx):
+    rng = np.random.default_rng(4)
+    off = np.array([0, 150, 400], dtype=np.int32)
+    w = np.array([0.4, 0.661])
+    for S in (1, 2, 127, 128, 129, 300):
+        G = rand_geno(rng, S, 400)
+        got = hotpath.ld_matrix(G, off, w, ctx=ctx)
+        want = oracle.compute_ld(G, off, w)
+        assert got.shape == (S, S) and np.max(np.abs(got - want)) <= 1e-12
+
+
+def test_gene_batch_sizes_one_to_many_tiles(ctx):
+    rng = np.random.default_rng(6)
+    off = np.array([0, 200, 520], dtype=np.int32)
+    sizes = [1, 0, 3, 140, 1, 1, 260, 2]                   # empty gene, genes larger than one / two tiles
+    gene_off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    G = rand_geno(rng, int(gene_off[-1]), 520)
+    blocks = hotpath.gene_ld_batch(G, off, gene_off, mode=0, diag=1.1, ctx=ctx)
+    for g, n in enumerate(sizes):
+        assert blocks[g].shape == (n, n)
+        if n:
+            want = oracle.ld_pooled(G[gene_off[g]:gene_off[g + 1]], off, 1.1)
+            assert np.max(np.abs(blocks[g] - want)) <= 1e-12
+
+
+def test_clamped_window_inside_a_batch(ctx):
+    rng = np.random.default_rng(12)
+    off = np.array([0, 300], dtype=np.int32)
+    wins, wants = [], []
+    for k in range(3):
+        G = rand_geno(rng, 60, 300)
+        gm, gu = G[:25], G[25:]
+        lam = 0.1
+        if k == 1:                                         # duplicated SNPs + lambda 0: singular B11 -> MakePosDef acts
+            gm = np.vstack([gm, gm[:2]])
+            lam = 0.0
+        z1 = rng.standard_normal(gm.shape[0])
+        wins.append(dict(mode=0, geno_m=np.ascontiguousarray(gm), geno_u=np.ascontiguousarray(gu), pop_off=off, z1=z1, lam=lam))
+        wants.append(oracle.run_impute(0, gm, gu, off, None, z1, lam=lam))
+    job = hotpath.Job(wins, ctx=ctx)
+    job.run()
+    res = job.fetch()
+    job.close()
+    assert [r["status"] for r in res] == [0, 1, 0] and [w["mpd"] for w in wants] == [0, 1, 0]
+    for r, w in zip(res, wants):
+        assert relerr(r["info"], w["info"]) <= 1e-5
+        assert np.max(np.abs(r["z"] - w["z"]) / np.maximum(1.0, np.abs(w["z"]))) <= 1e-5
+
+
+def test_bad_arguments(ctx):
+    rng = np.random.default_rng(1)
+    G = rand_geno(rng, 12, 100)
+    with pytest.raises(Exception, match="n_pop"):
+        hotpath.ld_matrix(G, np.arange(0, 66, dtype=np.int32), np.ones(65), ctx=ctx)
+    with pytest.raises(Exception, match="pop_off"):
+        hotpath.ld_matrix(G, np.array([5, 100], dtype=np.int32), np.ones(1), ctx=ctx)
+    with pytest.raises(Exception, match="ld"):
+        hotpath.ld_matrix(G, np.array([0, 200], dtype=np.int32), np.ones(1), ctx=ctx)
+    with pytest.raises(Exception, match="unmeasured"):
+        hotpath.Job([dict(mode=0, geno_m=G, geno_u=G[:0], pop_off=[0, 100], z1=np.zeros(12))], ctx=ctx)
+
+
+def test_full_size_properties_at_baseline_shape(ctx):
+    """DISTMIX at the BASELINE shape (21 PGC2 populations, N = 32 147, M ~ 740, U ~ 2 400): properties that
+    do not need the oracle at full size, plus an oracle spot check of individual LD entries."""
+    pops = [p for p in synth.POPS_33KG if p[0] in synth.PGC2_WEIGHTS]
+    off = synth.pop_offsets([p[1] for p in pops])
+    w = np.array([synth.PGC2_WEIGHTS[p[0]] for p in pops])
+    N = int(off[-1])
+    assert N == 32147
+    rng = np.random.default_rng(77)
+    M, U = 737, 2407
+    base = rand_geno(rng, 160, N)                          # LD structure: rows are noisy copies of a few bases
+    src = rng.integers(0, 160, size=M + U)
+    G = base[src].copy()
+    noise = rng.random(G.shape) < 0.35
+    G[noise] = rand_geno(rng, 1, N)[0][np.nonzero(noise)[1]]
+    gm, gu = np.ascontiguousarray(G[:M]), np.ascontiguousarray(G[M:])
+    z1 = rng.standard_normal(M) * 2
+    r = hotpath.impute_window(1, gm, gu, off, w, z1, want_mats=True, ctx=ctx)
+    assert r["status"] == 0
+    b11, b21 = r["b11"], r["b21"]
+    assert np.array_equal(b11, b11.T) and np.all(np.diag(b11) == 1.1)
+    assert np.all(np.abs(b21) <= 1 + 1e-9) and np.all(np.isfinite(r["z"]))
+    assert np.all(r["info"] > 0) and np.all(r["info"] < 1 + 1e-9)
+    assert np.linalg.eigvalsh(b11).min() > 0.09            # R is PSD, B11 = R + 0.1 I
+    # integer Gram diagonal = sum x^2, exactly
+    cnt = hotpath.gram_counts(gm[:200], ctx=ctx)
+    assert np.array_equal(np.diag(cnt), (gm[:200].astype(np.int64) ** 2).sum(1))
+    # spot-check entries against the loop-literal oracle pair function
+    def std(row):
+        return np.sqrt(oracle.calwgtcov(row, row, off, w))
+    for (i, j) in [(0, 1), (5, 700), (300, 301), (736, 2)]:
+        want = oracle.calwgtcov(gm[i], gm[j], off, w) / (std(gm[i]) * std(gm[j]))
+        assert abs(b11[i, j] - want) <= 1e-13
+    for (u, j) in [(0, 0), (2406, 736), (1200, 17)]:
+        want = oracle.calwgtcov(gu[u], gm[j], off, w) / (std(gu[u]) * std(gm[j]))
+        assert abs(b21[u, j] - want) <= 1e-13
+    # the solve agrees with numpy's inverse on the GPU's own B11 / B21
+    y = b21 @ np.linalg.inv(b11)
+    info = np.abs(np.einsum("ij,ij->i", y, b21))
+    assert relerr(r["info"], info) <= 1e-9
+    assert np.max(np.abs(r["z"] - (y @ z1) / np.sqrt(info))) <= 1e-8
+    # recoding an unmeasured SNP (0 <-> 2) flips its z and keeps its info.  Exact for the pooled Pearson
+    # estimator only: CalWgtCov with weights that do not sum to 1 (PGC2: 1.061, quirk Q2) is not
+    # antisymmetric under x -> 2 - x, in the reference as here.
+    p0 = hotpath.impute_window(0, gm, gu, off, None, z1, ctx=ctx)
+    gu2 = gu.copy()
+    gu2[10] = 2 - gu2[10]
+    p1 = hotpath.impute_window(0, gm, gu2, off, None, z1, ctx=ctx)
+    assert abs(p1["z"][10] + p0["z"][10]) <= 1e-9 and abs(p1["info"][10] - p0["info"][10]) <= 1e-12
+    assert np.max(np.abs(np.delete(p1["z"], 10) - np.delete(p0["z"], 10))) == 0.0
+    # permuting populations (with their weights) changes nothing beyond rounding
+    perm = rng.permutation(len(pops))
+    cols = np.concatenate([np.arange(off[k], off[k + 1]) for k in perm])
+    off2 = synth.pop_offsets([pops[k][1] for k in perm])
+    r3 = hotpath.impute_window(1, np.ascontiguousarray(gm[:, cols]), np.ascontiguousarray(gu[:, cols]), off2, w[perm], z1, ctx=ctx)
+    assert np.max(np.abs(r3["z"] - r["z"])) <= 1e-8 and relerr(r3["info"], r["info"]) <= 1e-9
