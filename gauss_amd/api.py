@@ -34,7 +34,7 @@ HOST_SYMBOLS = [
     "gauss_prepared_measured_rows", "gauss_prepared_unmeasured_rows", "gauss_prepared_geno_m",
     "gauss_prepared_geno_u", "gauss_prepared_pop_off", "gauss_prepared_pop_wgt", "gauss_prepared_z1",
     "gauss_prepared_gene_off", "gauss_prepared_window_desc", "gauss_prepared_finish", "gauss_prepared_free",
-    "gauss_host_bgzf_copy",
+    "gauss_host_bgzf_copy", "gauss_host_set_threads",
 ]
 
 
@@ -100,10 +100,17 @@ def load_host():
     h.gauss_prepared_finish.argtypes = [_vp, C.POINTER(_vp)]
     h.gauss_prepared_free.argtypes = [_vp]
     h.gauss_prepared_free.restype = None
+    h.gauss_host_set_threads.argtypes = [C.c_int]
+    h.gauss_host_set_threads.restype = None
     h.gauss_host_bgzf_copy.restype = _i64
     h.gauss_host_bgzf_copy.argtypes = [_cp, _cp]
     _host = h
     return h
+
+
+def set_host_threads(n):
+    """Threads used inside one prepare call to inflate/split panel lines (gauss_host_set_threads)."""
+    load_host().gauss_host_set_threads(int(n))
 
 
 def _hcheck(rc):

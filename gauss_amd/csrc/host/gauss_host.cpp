@@ -26,7 +26,9 @@
 #include <map>
 #include <memory>
 #include <sstream>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "bgzf_io.h"
@@ -291,14 +293,43 @@ static void load_line(BgzfReader& fp, Snp& s, const Args& a, std::vector<double>
     }
 }
 
+// Panel lines are independent: inflate + split them on several host threads, each with its own reader
+// (the reference reads them one by one through a single BGZF handle, gauss.cpp:546-566).
+static std::atomic<int> g_host_threads{4};
+
+static int preload_lines(SnpMap& m, const Args& a, bool want_af, std::vector<std::vector<double>>* afs)
+{
+    std::vector<Snp*> v;
+    v.reserve(m.size());
+    for (auto& kv : m) v.push_back(kv.second.get());
+    if (afs) afs->assign(v.size(), std::vector<double>());
+    const int nt = std::max(1, std::min<int>(g_host_threads.load(), (int)(v.size() / 64) + 1));
+    std::atomic<size_t> next{0};
+    std::atomic<int> failed{0};
+    auto work = [&]() {
+        BgzfReader fp;
+        if (!fp.open(a.reference_data_file)) { failed = 1; return; }
+        for (;;) {
+            const size_t i0 = next.fetch_add(32);
+            if (i0 >= v.size()) break;
+            for (size_t i = i0; i < std::min(v.size(), i0 + 32); i++)
+                load_line(fp, *v[i], a, (want_af && afs) ? &(*afs)[i] : nullptr);
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; t++) th.emplace_back(work);
+    work();
+    for (auto& t : th) t.join();
+    if (failed) return herr("ERROR: can't open reference data file '%s'", a.reference_data_file.c_str());
+    return 0;
+}
+
 // MakeSnpVec (gauss.cpp:543-604)
 static int MakeSnpVec(std::vector<Snp*>& v, SnpMap& m, const Args& a)
 {
-    BgzfReader fp;
-    if (!fp.open(a.reference_data_file)) return herr("ERROR: can't open reference data file '%s'", a.reference_data_file.c_str());
+    if (preload_lines(m, a, false, nullptr)) return -1;
     for (auto& kv : m) {
         Snp& s = *kv.second;
-        load_line(fp, s, a, nullptr);
         double allele_counter = 0, num_subj = 0;
         for (auto& g : s.geno) {
             num_subj += g.second;
@@ -315,12 +346,12 @@ static int MakeSnpVec(std::vector<Snp*>& v, SnpMap& m, const Args& a)
 // MakeSnpVecMix (gauss.cpp:631-693)
 static int MakeSnpVecMix(std::vector<Snp*>& v, SnpMap& m, const Args& a)
 {
-    BgzfReader fp;
-    if (!fp.open(a.reference_data_file)) return herr("ERROR: can't open reference data file '%s'", a.reference_data_file.c_str());
-    std::vector<double> af1_vec;
+    std::vector<std::vector<double>> afs;
+    if (preload_lines(m, a, true, &afs)) return -1;
+    size_t idx = 0;
     for (auto& kv : m) {
         Snp& s = *kv.second;
-        load_line(fp, s, a, &af1_vec);
+        const std::vector<double>& af1_vec = afs[idx++];
         double af1_mix = 0;
         for (size_t k = 0; k < af1_vec.size(); k++) af1_mix += af1_vec[k] * a.pop_wgt_vec[k];
         if ((af1_mix > a.af1_cutoff) && (af1_mix < (1 - a.af1_cutoff))) {
@@ -746,6 +777,8 @@ int64_t gauss_host_bgzf_copy(const char* in_path, const char* out_path)
     if (!w.close()) return herr("write error");
     return n;
 }
+
+void gauss_host_set_threads(int n) { g_host_threads = n < 1 ? 1 : (n > 64 ? 64 : n); }
 
 int gauss_host_prepare(int kind, int chr, int64_t start_bp, int64_t end_bp, int64_t wing_size, const char* study_pop,
                        const char* const* pop_names, const double* pop_wgts, int n_pop_wgt, const char* input_file,

@@ -36,13 +36,17 @@ __global__ __launch_bounds__(256) void pack_stats_kernel(const Prob* __restrict_
     if (threadIdx.x < 64) { s_sx[threadIdx.x] = 0; s_sxx[threadIdx.x] = 0; }
     __syncthreads();
 
-    const int nwords = pb.Kp >> 4;
-    for (int w = threadIdx.x; w < nwords; w += 256) {
+    const int nwords = pb.Kp >> 4;                 // a multiple of 4 (Kp is a multiple of 64)
+    const int nloop = (nwords + 255) & ~255;
+    for (int w0 = threadIdx.x; w0 < nloop; w0 += 256) {
+        const bool live = w0 < nwords;                // keep whole waves in the loop for the cross-lane sums
+        const int w = live ? w0 : nwords - 1;
         const int p = pb.word_pop[w];
         const int o = (w << 4) - pb.pop_pk_off[p];
         const int m = pb.pop_raw_off[p + 1] - pb.pop_raw_off[p];
         int valid = m - o;
         valid = valid < 0 ? 0 : (valid > 16 ? 16 : valid);
+        if (!live) valid = 0;
         uint32_t v[4] = {0u, 0u, 0u, 0u};
         const uint8_t* s = src + pb.pop_raw_off[p] + o;
         if (valid == 16) {
@@ -74,8 +78,17 @@ __global__ __launch_bounds__(256) void pack_stats_kernel(const Prob* __restrict_
             }
             v[q] = c;
         }
-        dst[w] = make_uint4(v[0], v[1], v[2], v[3]);
-        if (sx) { atomicAdd(&s_sx[p], sx); atomicAdd(&s_sxx[p], sxx); }
+        if (live) dst[w] = make_uint4(v[0], v[1], v[2], v[3]);
+        // per-population sums: the 64 lanes of a wave cover 1 KiB of one row, almost always inside one
+        // population -- reduce across the wave first instead of 64 colliding LDS atomics
+        const int p0 = __builtin_amdgcn_readfirstlane(p);
+        if (__all(p == p0)) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { sx += __shfl_xor(sx, o); sxx += __shfl_xor(sxx, o); }
+            if ((threadIdx.x & 63) == 0 && sx) { atomicAdd(&s_sx[p0], sx); atomicAdd(&s_sxx[p0], sxx); }
+        } else if (sx) {
+            atomicAdd(&s_sx[p], sx); atomicAdd(&s_sxx[p], sxx);
+        }
     }
     __syncthreads();
     if (threadIdx.x < pb.P) {

@@ -6,6 +6,8 @@ call); the caller-level loop over windows is not part of it.  Windows are indepe
 process per GPU, every rank runs its windows as one batched job, and only the finished tables are
 gathered (torch.distributed, RCCL/gloo) and concatenated in window order on rank 0.
 """
+import os
+
 import numpy as np
 
 from . import api, hotpath
@@ -62,7 +64,7 @@ def gpu_compute(prepared_list, ctx=None):
 
 def impute_chromosome(kind, chr, start_bp, end_bp, wing_size, input_file, reference_index_file, reference_data_file,
                       reference_pop_desc_file, study_pop=None, pop_wgt_df=None, af1_cutoff=None,
-                      window_size=1_000_000, compute=gpu_compute, group=None):
+                      window_size=1_000_000, compute=gpu_compute, group=None, threads=None, timings=None):
     """dist()/distmix() over every window of [start_bp, end_bp], sharded across the ranks of `group`.
 
     kind: api.KIND_DIST or api.KIND_DISTMIX.  Returns on rank 0 (or the single process) a dict
@@ -90,24 +92,44 @@ def impute_chromosome(kind, chr, start_bp, end_bp, wing_size, input_file, refere
         costs.append(m * m + 1.0)
     owner = assign_windows(costs, world)
 
+    import time
+    from concurrent.futures import ThreadPoolExecutor
     mine = [i for i in range(len(windows)) if owner[i] == rank]
     prepared, ok_idx, skipped = [], [], []
-    for i in mine:
+
+    def prep(i):
+        # the host data layer of one window (BGZF inflate + parse + AF filter + partition) is plain C++
+        # behind ctypes, which releases the GIL: windows decode in parallel on the host cores
         s, e = windows[i]
         try:
-            p = api.Prepared(kind, chr=chr, start_bp=s, end_bp=e, wing_size=wing_size, study_pop=study_pop,
-                             pop_wgt_df=pop_wgt_df, input_file=input_file, reference_index_file=reference_index_file,
-                             reference_data_file=reference_data_file, reference_pop_desc_file=reference_pop_desc_file,
-                             af1_cutoff=af1_cutoff)
-            if p.M <= 10 or p.U <= 10:
-                skipped.append((i, f"Not enough number of SNPs loaded (measured {p.M}, unmeasured {p.U})"))
-                p.close()
-                continue
+            return i, api.Prepared(kind, chr=chr, start_bp=s, end_bp=e, wing_size=wing_size, study_pop=study_pop,
+                                   pop_wgt_df=pop_wgt_df, input_file=input_file,
+                                   reference_index_file=reference_index_file, reference_data_file=reference_data_file,
+                                   reference_pop_desc_file=reference_pop_desc_file, af1_cutoff=af1_cutoff), None
+        except api.GaussError as ex:
+            return i, None, str(ex)
+
+    t0 = time.perf_counter()
+    cores = max(1, (os.cpu_count() or 2) // max(1, world))
+    nthreads = threads or min(16, cores, max(1, len(mine)))
+    api.set_host_threads(max(1, min(16, cores) // nthreads))      # windows x lines-per-window parallelism
+    with ThreadPoolExecutor(max_workers=nthreads) as pool:
+        results = list(pool.map(prep, mine))
+    for i, p, err in results:
+        if err is not None:
+            skipped.append((i, err))
+        elif p.M <= 10 or p.U <= 10:
+            skipped.append((i, f"Not enough number of SNPs loaded (measured {p.M}, unmeasured {p.U})"))
+            p.close()
+        else:
             prepared.append(p)
             ok_idx.append(i)
-        except api.GaussError as ex:
-            skipped.append((i, str(ex)))
+    t1 = time.perf_counter()
     tables = compute(prepared)
+    t2 = time.perf_counter()
+    if timings is not None:
+        timings.update(feeder_s=t1 - t0, compute_s=t2 - t1, windows=len(prepared), threads=nthreads,
+                       imputed=int(sum(p.U for p in prepared)))
     for p in prepared:
         p.close()
     local = {"tables": dict(zip(ok_idx, tables)), "skipped": skipped}

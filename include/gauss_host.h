@@ -88,6 +88,9 @@ int gauss_host_jepegmix(gauss_ctx* ctx, const char* const* pop_names, const doub
 /* Re-block a BGZF text file line by line (reader + writer round trip); returns lines copied or -1. */
 int64_t gauss_host_bgzf_copy(const char* in_path, const char* out_path);
 
+/* Host threads used to inflate and split panel lines inside one prepare call (default 4). */
+void gauss_host_set_threads(int n);
+
 /* ---- host data layer only (no GPU) ----------------------------------------------------------- */
 /* Runs everything up to and including ReadGenotype + the measured/unmeasured partition.
  * kind = GAUSS_KIND_*; arguments that a kind does not take are ignored (pass 0/NULL). */
