@@ -85,6 +85,9 @@ def main():
     ap.add_argument("--wing", type=int, default=500_000)
     ap.add_argument("--sample-scale", type=float, default=1.0, help="shrink every population (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gram-dtype", choices=["f32", "i8"], default="f32",
+                    help="LD Gram arithmetic of the headline run (f32 MFMA = north star; i8 MFMA = exact fast variant)")
+    ap.add_argument("--no-i8-variant", action="store_true", help="skip the extra timing of the exact int8 variant")
     ap.add_argument("--streams", type=int, default=1, help="split the windows over this many jobs/streams")
     args = ap.parse_args()
 
@@ -131,6 +134,7 @@ def main():
         descs.append(dict(mode=hotpath.MODE_WEIGHTED, pop_off=ch["off"], pop_wgt=ch["w"], z1=ch["z"][mi],
                           dev=(gm.data_ptr(), gu.data_ptr(), len(mi), len(ui), ld)))
     torch.cuda.synchronize()
+    ctx.set_gram_dtype(args.gram_dtype)
     if args.streams > 1:
         jobs = [hotpath.Job(descs[i::args.streams], ctx=(ctx if i == 0 else hotpath.Context(local)), on_device=True)
                 for i in range(args.streams)]
@@ -167,6 +171,29 @@ def main():
     stage_ms = {k: job.profile_get(i)[0] / max(1, args.steps) for i, k in
                 enumerate(["gram", "pack_stats", "ld_epilogue", "factor", "solve"])}
     job.profile(False)
+
+    # the same job with the LD Gram on the int8 matrix cores (identical integers, identical outputs):
+    # reported next to the headline, never as `value`
+    i8_variant = None
+    if args.gram_dtype == "f32" and not args.no_i8_variant and args.streams == 1:
+        ctx.set_gram_dtype("i8")
+        j8 = hotpath.Job(descs, ctx=ctx, on_device=True)
+        ctx.set_gram_dtype("f32")
+        for _ in range(max(1, args.warmup)):
+            j8.run(); r8 = j8.fetch()
+        j8.profile(True)
+        barrier()
+        t8 = time.perf_counter()
+        for _ in range(args.steps):
+            j8.run(); r8 = j8.fetch()
+        torch.cuda.synchronize()
+        dt8 = time.perf_counter() - t8
+        g8, n8 = j8.profile_get(0)
+        same = all(np.array_equal(a["z"], b["z"]) and np.array_equal(a["info"], b["info"]) for a, b in zip(res, r8))
+        i8_variant = {"ms_per_step": dt8 / args.steps * 1e3, "imputed_snps_per_s_this_rank": work["imputed_snps"] / (dt8 / args.steps),
+                      "gram_ms": g8 / max(1, n8), "gram_tops_algorithmic": work["ld_flops"] / (g8 / max(1, n8) * 1e-3) / 1e12,
+                      "kernel": "gram_kernel<i32x16> (v_mfma_i32_32x32x32_i8)", "bit_identical_to_f32_path": bool(same)}
+        j8.close()
 
     bad = sum(int(r["status"] != 0) for r in res)
     finite = all(np.all(np.isfinite(r["z"])) and np.all(np.isfinite(r["info"])) for r in res)
@@ -216,6 +243,8 @@ def main():
             },
             "stage_ms_per_step": stage_ms,
         }
+        if i8_variant is not None:
+            out["int8_exact_variant"] = i8_variant
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ch, wins, keep, work)
         print(json.dumps(out), flush=True)

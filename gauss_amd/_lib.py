@@ -16,6 +16,8 @@ MODE_POOLED = 0
 MODE_WEIGHTED = 1
 ST_CLAMPED = 1
 ST_NONFINITE = 2
+GRAM_F32 = 0
+GRAM_I8 = 1
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
@@ -40,7 +42,7 @@ _lib = None
 
 # every symbol include/gauss_hip.h declares
 SYMBOLS = [
-    "gauss_hip_init", "gauss_hip_destroy", "gauss_last_error", "gauss_hip_version", "gauss_ld",
+    "gauss_hip_init", "gauss_hip_destroy", "gauss_last_error", "gauss_hip_version", "gauss_hip_set_gram_dtype", "gauss_ld",
     "gauss_impute_window", "gauss_gene_ld_batch", "gauss_gram_counts", "gauss_job_create",
     "gauss_job_run", "gauss_job_fetch", "gauss_job_destroy", "gauss_job_profile",
     "gauss_job_profile_get", "gauss_job_work", "gauss_job_stats", "gauss_synth_device",
@@ -65,6 +67,7 @@ def load():
     lib.gauss_hip_init.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
     lib.gauss_hip_destroy.argtypes = [C.c_void_p]
     lib.gauss_hip_destroy.restype = None
+    lib.gauss_hip_set_gram_dtype.argtypes = [C.c_void_p, C.c_int]
     lib.gauss_ld.argtypes = [C.c_void_p, C.c_int, _u8p, C.c_int, C.c_int64, _ip, _dp, C.c_int,
                              C.c_double, _dp]
     lib.gauss_impute_window.argtypes = [C.c_void_p, C.POINTER(WindowDesc)]

@@ -46,6 +46,7 @@ static int fail(int code, const char* fmt, ...)
 struct gauss_ctx {
     int device;
     hipStream_t stream;
+    int gram_i8 = 0;
 };
 
 static inline size_t rup(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -92,6 +93,7 @@ struct gauss_job {
     int2* d_panelmap = nullptr; int n_panels = 0;
     int max_nblk = 0;
     int max_pop = 1;
+    int gram_i8 = 0;
     int* d_status = nullptr;                               // [n][4]
     double* d_results = nullptr; size_t n_results = 0;     // z then info per problem
     double* h_results = nullptr;                           // pinned
@@ -153,7 +155,6 @@ static int plan_problem(const WinSpec& w, Plan& pl, int seg_max, int group_targe
     p.M = w.M; p.U = w.U; p.N = N;
     p.lambda = w.lambda; p.eps = w.eps; p.diag = w.diag;
     p.ld_only = w.ld_only;
-    p.max_code = 15;
     if (w.mode == GAUSS_MODE_POOLED) {
         // CalCor pools every selected population (util.cpp:53-64): one pseudo-population
         p.P = 1;
@@ -271,10 +272,12 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
     job->ctx = ctx;
     job->n = (int)specs.size();
     job->on_device = on_device;
+    job->gram_i8 = ctx->gram_i8;
     job->plans.resize(job->n);
     for (int i = 0; i < job->n; i++) {
         int rc = plan_problem(specs[i], job->plans[i], seg_max_for(specs.size()), group_target_for(specs.size()));
         if (rc) { delete job; return rc; }
+        job->plans[i].p.gram_i8 = job->gram_i8;
     }
     HIPCHK(hipSetDevice(ctx->device));
 
@@ -508,7 +511,7 @@ static int job_run(gauss_job* job, bool solve)
     launch_row_stats(job->d_probs, job->d_rowmap, job->n_rows, st);
     prof_end(job);
     prof_begin(job, 0);
-    launch_gram(job->d_items, job->n_items, st);
+    launch_gram(job->d_items, job->n_items, job->gram_i8, st);
     prof_end(job);
     prof_begin(job, 2);
     launch_epilogue(job->d_probs, job->d_tilemap, job->n_tiles, job->max_pop, st);
@@ -651,6 +654,8 @@ int gauss_hip_init(int device, gauss_ctx** out_ctx)
     HIPCHK(hipSetDevice(device));
     gauss_ctx* c = new gauss_ctx();
     c->device = device;
+    const char* e = getenv("GAUSS_GRAM_DTYPE");
+    c->gram_i8 = (e && (strcmp(e, "i8") == 0 || strcmp(e, "int8") == 0)) ? 1 : 0;
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     *out_ctx = c;
     return GAUSS_OK;
@@ -662,6 +667,13 @@ void gauss_hip_destroy(gauss_ctx* ctx)
     hipSetDevice(ctx->device);
     hipStreamDestroy(ctx->stream);
     delete ctx;
+}
+
+int gauss_hip_set_gram_dtype(gauss_ctx* ctx, int dtype)
+{
+    if (!ctx || (dtype != GAUSS_GRAM_F32 && dtype != GAUSS_GRAM_I8)) return fail(GAUSS_E_INVALID, "bad gram dtype %d", dtype);
+    ctx->gram_i8 = (dtype == GAUSS_GRAM_I8);
+    return GAUSS_OK;
 }
 
 int gauss_job_create(gauss_ctx* ctx, const gauss_window_desc* wins, int n_win, int on_device, gauss_job** out_job)

@@ -33,7 +33,7 @@ struct Prob {
     int Mld, nblk;          // solve leading dimension (M padded to NB) and block count
     int npanel;             // solve panels (ceil(U / NRU)), 0 for LD-only problems
     int ld_only;            // 1: write out_ld (S x S) instead of B11/B21
-    int max_code;           // largest genotype code admitted by the range check
+    int gram_i8;            // 1: operands are raw codes and slabs hold int32 (i8 MFMA path); 0: e4m3 codes, f32 slabs
     double lambda, eps, diag;
     long long ld_raw;
     GP(const uint8_t) raw_m;   // [M x ld_raw]
@@ -98,7 +98,7 @@ template <typename T> __device__ __forceinline__ gptr<T> G(gptr<T> p) { return p
 // ---- launchers (host functions defined in the .hip files) ----
 void launch_pack_stats(const Prob* d_probs, const int2* d_rowmap, int n_rows, hipStream_t s);
 void launch_row_stats(const Prob* d_probs, const int2* d_rowmap, int n_rows, hipStream_t s);
-void launch_gram(const Item* d_items, int n_items, hipStream_t s);
+void launch_gram(const Item* d_items, int n_items, int dtype_i8, hipStream_t s);
 void launch_epilogue(const Prob* d_probs, const int2* d_tilemap, int n_tiles, int max_pop, hipStream_t s);
 void launch_gene_epilogue(const Prob* d_probs, int prob, int n_gene, hipStream_t s);
 void launch_factor_step(const Prob* d_probs, int n_prob, int step, int max_nblk, hipStream_t s);

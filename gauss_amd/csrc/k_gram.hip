@@ -79,10 +79,44 @@ __device__ __forceinline__ void chunk_mfma(const uint8_t* __restrict__ la, const
 #undef GAUSS_MFMA_PAIR
 }
 
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// The same chunk on the int8 matrix cores (v_mfma_i32_32x32x32_i8): operands are the raw genotype
+// codes, 16 bytes per lane and MFMA, sums are exact int32.  The 16 bytes a lane reads for A and for B
+// cover the same k positions, so the products line up whatever the instruction's internal k order is.
+template <int NA, int NB>
+__device__ __forceinline__ void chunk_mfma(const uint8_t* __restrict__ la, const uint8_t* __restrict__ lb,
+                                           int arow, int brow, i32x16& acc00, i32x16& acc01,
+                                           i32x16& acc10, i32x16& acc11)
+{
+#pragma unroll
+    for (int g = 0; g < 2; g++) {
+        const i32x4 a0 = *reinterpret_cast<const i32x4*>(la + arow + g * 32);
+        const i32x4 b0 = *reinterpret_cast<const i32x4*>(lb + brow + g * 32);
+        acc00 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b0, acc00, 0, 0, 0);
+        if (NB > 1) {
+            const i32x4 b1 = *reinterpret_cast<const i32x4*>(lb + brow + 32 * LROW + g * 32);
+            acc01 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b1, acc01, 0, 0, 0);
+            if (NA > 1) {
+                const i32x4 a1 = *reinterpret_cast<const i32x4*>(la + arow + 32 * LROW + g * 32);
+                acc10 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b0, acc10, 0, 0, 0);
+                acc11 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b1, acc11, 0, 0, 0);
+            }
+        } else if (NA > 1) {
+            const i32x4 a1 = *reinterpret_cast<const i32x4*>(la + arow + 32 * LROW + g * 32);
+            acc10 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b0, acc10, 0, 0, 0);
+        }
+    }
+}
+
+__device__ __forceinline__ float slab_bits(float v) { return v; }
+__device__ __forceinline__ float slab_bits(int v) { return __int_as_float(v); }
+
 // One work item for a wave with NA x NB live 32-row halves (NA = 0: staging and barriers only).
 // The K loop runs over the whole run of segments without draining the prefetch pipeline; at each
 // segment end the accumulators are flushed to that segment's slab and cleared.
-template <int NA, int NB>
+template <int NA, int NB, typename ACC>
 __device__ __forceinline__ void run_item(const Item& it, uint8_t* lds, int wr, int wc)
 {
     const int Kp = it.Kp;
@@ -98,7 +132,7 @@ __device__ __forceinline__ void run_item(const Item& it, uint8_t* lds, int wr, i
     const size_t g0 = (size_t)srow0 * Kp + scol, g1 = (size_t)srow1 * Kp + scol;
     const int l0 = srow0 * LROW + scol, l1 = srow1 * LROW + scol;
 
-    f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
+    ACC acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
 
     const int k0 = it.k0;
     const int nseg = it.nseg;
@@ -156,20 +190,21 @@ __device__ __forceinline__ void run_item(const Item& it, uint8_t* lds, int wr, i
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int o = obase + ((r & 3) + 8 * (r >> 2)) * TILE;
-                out[o] = acc00[r];
-                if (NB > 1) out[o + 32] = acc01[r];
+                out[o] = slab_bits(acc00[r]);
+                if (NB > 1) out[o + 32] = slab_bits(acc01[r]);
                 if (NA > 1) {
-                    out[o + 32 * TILE] = acc10[r];
-                    if (NB > 1) out[o + 32 * TILE + 32] = acc11[r];
+                    out[o + 32 * TILE] = slab_bits(acc10[r]);
+                    if (NB > 1) out[o + 32 * TILE + 32] = slab_bits(acc11[r]);
                 }
             }
 #pragma unroll
-            for (int r = 0; r < 16; r++) { acc00[r] = 0.f; acc01[r] = 0.f; acc10[r] = 0.f; acc11[r] = 0.f; }
+            for (int r = 0; r < 16; r++) { acc00[r] = 0; acc01[r] = 0; acc10[r] = 0; acc11[r] = 0; }
         }
         out += TILE * TILE;
     }
 }
 
+template <typename ACC>
 __global__ __launch_bounds__(256, 4) void gram_kernel(const Item* __restrict__ items)
 {
     __shared__ __attribute__((aligned(16))) uint8_t lds[2 * 2 * LTILE];
@@ -185,25 +220,18 @@ __global__ __launch_bounds__(256, 4) void gram_kernel(const Item* __restrict__ i
     nb = nb < 0 ? 0 : (nb > 2 ? 2 : nb);
     // diagonal tile: the lower-left 64 x 64 quadrant mirrors the upper-right one and is never read
     if (it.diag && wr == 1 && wc == 0) na = 0;
-    if (na == 0 || nb == 0) run_item<0, 0>(it, lds, wr, wc);
-    else if (na == 2 && nb == 2) run_item<2, 2>(it, lds, wr, wc);
-    else if (na == 2) run_item<2, 1>(it, lds, wr, wc);
-    else if (nb == 2) run_item<1, 2>(it, lds, wr, wc);
-    else run_item<1, 1>(it, lds, wr, wc);
+    if (na == 0 || nb == 0) run_item<0, 0, ACC>(it, lds, wr, wc);
+    else if (na == 2 && nb == 2) run_item<2, 2, ACC>(it, lds, wr, wc);
+    else if (na == 2) run_item<2, 1, ACC>(it, lds, wr, wc);
+    else if (nb == 2) run_item<1, 2, ACC>(it, lds, wr, wc);
+    else run_item<1, 1, ACC>(it, lds, wr, wc);
 }
 
-void launch_gram(const Item* d_items, int n_items, hipStream_t s)
+void launch_gram(const Item* d_items, int n_items, int dtype_i8, hipStream_t s)
 {
     if (n_items <= 0) return;
-    // tuning hook: GAUSS_GRAM_EXTRA_LDS=<bytes> pads the workgroup's LDS request to lower occupancy
-    static int extra = -1;
-    if (extra < 0) {
-        const char* e = getenv("GAUSS_GRAM_EXTRA_LDS");
-        extra = e ? atoi(e) : 0;
-        if (extra > 0)
-            hipFuncSetAttribute(reinterpret_cast<const void*>(gram_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, extra);
-    }
-    hipLaunchKernelGGL(gram_kernel, dim3(n_items), dim3(256), (size_t)extra, s, d_items);
+    if (dtype_i8) hipLaunchKernelGGL(gram_kernel<i32x16>, dim3(n_items), dim3(256), 0, s, d_items);
+    else hipLaunchKernelGGL(gram_kernel<f32x16>, dim3(n_items), dim3(256), 0, s, d_items);
 }
 
 }  // namespace gauss

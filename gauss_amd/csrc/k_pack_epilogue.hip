@@ -63,7 +63,9 @@ __global__ __launch_bounds__(256) void pack_stats_kernel(const Prob* __restrict_
             sxx = __builtin_amdgcn_udot4(x, x, sxx, false);
             // operand encoding for the Gram kernel: the code as an OCP e4m3 byte (exact for 0..15)
             uint32_t c;
-            if ((x & 0x0C0C0C0Cu) == 0 && (x & (x >> 1) & 0x01010101u) == 0) {
+            if (pb.gram_i8) {
+                c = x;                                   // i8 MFMA path: operands are the raw codes
+            } else if ((x & 0x0C0C0C0Cu) == 0 && (x & (x >> 1) & 0x01010101u) == 0) {
                 // every byte in {0,1,2}: 1 -> 0x38, 2 -> 0x40
                 c = (x & 0x01010101u) * 0x38u + ((x >> 1) & 0x01010101u) * 0x40u;
             } else {
@@ -163,6 +165,9 @@ void launch_row_stats(const Prob* d_probs, const int2* d_rowmap, int n_rows, hip
 // Correlation of packed rows (ri, rj) from the exact per-segment Gram partials of one tile.
 // `x` is the first argument of CalCor / CalWgtCov (row ri), `y` the second (row rj).
 // ------------------------------------------------------------------------------------------
+// A partial slab holds exact integers, as f32 (f32 MFMA path) or int32 (i8 MFMA path).
+__device__ __forceinline__ double slab_val(float v, int is_int) { return is_int ? (double)__float_as_int(v) : (double)v; }
+
 __device__ __forceinline__ double cor_entry(const Prob& pb, const float* __restrict__ tile_slab,
                                             int off, int ri, int rj)
 {
@@ -170,7 +175,7 @@ __device__ __forceinline__ double cor_entry(const Prob& pb, const float* __restr
     const size_t seg_stride = (size_t)TILE * TILE;
     if (pb.mode == 0) {
         double sumxy = 0;
-        for (int s = 0; s < pb.nseg; s++) sumxy += (double)tile_slab[s * seg_stride + off];
+        for (int s = 0; s < pb.nseg; s++) sumxy += slab_val(tile_slab[s * seg_stride + off], pb.gram_i8);
         const int num_samples = pb.N;
         const double numer = num_samples * sumxy - pb.rt_wm[ri] * pb.rt_wm[rj];   // util.cpp:66
         const double denor = pb.rt_sd[ri] * pb.rt_sd[rj];                         // util.cpp:67
@@ -184,7 +189,7 @@ __device__ __forceinline__ double cor_entry(const Prob& pb, const float* __restr
     for (int p = 0; p < P; p++) {
         double sumxy = 0;
         for (int s = pb.pop_seg0[p]; s < pb.pop_seg0[p + 1]; s++)
-            sumxy += (double)tile_slab[s * seg_stride + off];
+            sumxy += slab_val(tile_slab[s * seg_stride + off], pb.gram_i8);
         const double sumx = (double)sxi[p], sumy = (double)sxj[p];
         // pop_wf = wgt_val * factor, factor = (double)m/(m-1) (util.cpp:117), pop_md = (double)m
         wsumcov += pb.pop_wf[p] * (pb.pop_md[p] * sumxy - sumx * sumy);            // util.cpp:118
@@ -225,6 +230,7 @@ __global__ __launch_bounds__(1024) void epilogue_kernel(const Prob* __restrict__
     const int Mld = pb.Mld;
     const int tid = threadIdx.x;
     const bool weighted = pb.mode != 0;
+    const int isint = pb.gram_i8;
     const bool lds_tables = weighted && P <= lds_pop_cap;
 
     double* s_wmui = reinterpret_cast<double*>(esm);          // [P][128]  w_p * mu_p(row i)
@@ -257,7 +263,7 @@ __global__ __launch_bounds__(1024) void epilogue_kernel(const Prob* __restrict__
             double sumxy[4] = {0, 0, 0, 0};
             for (int s = 0; s < nseg; s++)
 #pragma unroll
-                for (int q = 0; q < 4; q++) sumxy[q] += (double)tile_slab[s * seg_stride + rows[q] * TILE + jj];
+                for (int q = 0; q < 4; q++) sumxy[q] += slab_val(tile_slab[s * seg_stride + rows[q] * TILE + jj], isint);
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const int ri = ti * TILE + rows[q];
@@ -272,7 +278,7 @@ __global__ __launch_bounds__(1024) void epilogue_kernel(const Prob* __restrict__
                 double sumxy[4] = {0, 0, 0, 0};
                 for (int s = pb.pop_seg0[p]; s < pb.pop_seg0[p + 1]; s++)
 #pragma unroll
-                    for (int q = 0; q < 4; q++) sumxy[q] += (double)tile_slab[s * seg_stride + rows[q] * TILE + jj];
+                    for (int q = 0; q < 4; q++) sumxy[q] += slab_val(tile_slab[s * seg_stride + rows[q] * TILE + jj], isint);
                 const double md = pb.pop_md[p], wf = pb.pop_wf[p];
                 const double sumy = (double)s_sxj[p * TILE + jj];
                 const double mu_y = s_muj[p * TILE + jj];
@@ -381,7 +387,7 @@ __global__ __launch_bounds__(256) void counts_kernel(const Prob* __restrict__ pr
         if (ri >= pb.M || rj >= pb.M) continue;
         if (ti == tj && ri > rj) continue;      // diagonal tile: the Gram kernel skips the mirrored quadrant
         long long s = 0;
-        for (int g = 0; g < pb.nseg; g++) s += (long long)tile_slab[(size_t)g * TILE * TILE + e];
+        for (int g = 0; g < pb.nseg; g++) s += (long long)slab_val(tile_slab[(size_t)g * TILE * TILE + e], pb.gram_i8);
         out[(size_t)ri * pb.M + rj] = s;
         out[(size_t)rj * pb.M + ri] = s;
     }

@@ -24,6 +24,11 @@ class Context:
         self.handle = h
         self.device = device
 
+    def set_gram_dtype(self, dtype):
+        """'f32' (default, v_mfma_f32_32x32x2_f32) or 'i8' (v_mfma_i32_32x32x32_i8); same exact integers."""
+        code = {"f32": _lib.GRAM_F32, "i8": _lib.GRAM_I8}[dtype] if isinstance(dtype, str) else int(dtype)
+        check(self.lib.gauss_hip_set_gram_dtype(self.handle, code))
+
     def close(self):
         if self.handle:
             self.lib.gauss_hip_destroy(self.handle)

@@ -84,6 +84,14 @@ void gauss_hip_destroy(gauss_ctx* ctx);
 const char* gauss_last_error(void);
 const char* gauss_hip_version(void);
 
+/* Arithmetic of the LD Gram kernel for jobs created afterwards on this context.
+ *   GAUSS_GRAM_F32 (default): v_mfma_f32_32x32x2_f32 on e4m3-coded operands, exact f32 integer sums.
+ *   GAUSS_GRAM_I8           : v_mfma_i32_32x32x32_i8 on the raw codes, exact int32 sums.
+ * Both produce bit-identical LD, z and info (the partial sums are the same integers). */
+#define GAUSS_GRAM_F32 0
+#define GAUSS_GRAM_I8  1
+int gauss_hip_set_gram_dtype(gauss_ctx* ctx, int dtype);
+
 /* ---- blocking host-pointer calls (what the Rcpp drivers bind) ------------------------------ */
 
 /* LD matrix among S SNPs.  mode WEIGHTED + diag 1.0 = computeLD.cpp:95-116;

@@ -179,3 +179,30 @@ def test_invalid_arguments_are_reported(ctx):
     bad[1] = bad[2] + 5
     with pytest.raises(Exception):
         hotpath.ld_matrix(p["G"], bad, p["w"], ctx=ctx)
+
+
+def test_int8_gram_path_is_bit_identical_to_f32_path(ctx):
+    """The optional i8-MFMA Gram kernel accumulates the same exact integers, so LD, z and info must be
+    bit-identical to the default f32-MFMA path (and the counts bit-exact against the oracle)."""
+    p = small_panel(n_snp=420, scale=0.03, seed=41)
+    G = p["G"]
+    gm, gu, z1 = split_window(dict(G=G[:330]), 140)
+    base = {}
+    try:
+        for dt in ("f32", "i8"):
+            ctx.set_gram_dtype(dt)
+            cnt = hotpath.gram_counts(G[:200], ctx=ctx)
+            assert np.array_equal(cnt, oracle.gram_counts(G[:200]))
+            ld = hotpath.ld_matrix(G[:300], p["off"], p["w"], ctx=ctx)
+            r0 = hotpath.impute_window(0, gm, gu, p["off"], None, z1, want_mats=True, ctx=ctx)
+            r1 = hotpath.impute_window(1, gm, gu, p["off"], p["w"], z1, want_mats=True, ctx=ctx)
+            base[dt] = (ld, r0, r1)
+    finally:
+        ctx.set_gram_dtype("f32")
+    (lda, a0, a1), (ldb, b0, b1) = base["f32"], base["i8"]
+    assert np.array_equal(lda, ldb)
+    for a, b in ((a0, b0), (a1, b1)):
+        for k in ("b11", "b21", "z", "info"):
+            assert np.array_equal(a[k], b[k]), k
+    want = oracle.run_impute(1, gm, gu, p["off"], p["w"], z1)
+    assert relerr(b1["info"], want["info"]) <= Z_TOL
