@@ -200,3 +200,38 @@ def test_full_size_properties_at_baseline_shape(ctx):
     off2 = synth.pop_offsets([pops[k][1] for k in perm])
     r3 = hotpath.impute_window(1, np.ascontiguousarray(gm[:, cols]), np.ascontiguousarray(gu[:, cols]), off2, w[perm], z1, ctx=ctx)
     assert np.max(np.abs(r3["z"] - r["z"])) <= 1e-8 and relerr(r3["info"], r["info"]) <= 1e-9
+
+
+def test_randomized_shapes_against_oracle(ctx):
+    """Fuzz: random (M, U, population layout, mode) batches through one job each, against the oracle."""
+    rng = np.random.default_rng(2026)
+    for trial in range(6):
+        P = int(rng.integers(1, 9))
+        sizes = rng.integers(2, 400, size=P)
+        if rng.random() < 0.3:
+            sizes[rng.integers(0, P)] = int(rng.integers(2100, 2600))      # a population split into several segments
+        off = synth.pop_offsets(sizes)
+        N = int(off[-1])
+        w = rng.uniform(0.05, 1.0, P)
+        w *= (1.0 if rng.random() < 0.5 else 1.061) / w.sum()
+        wins, wants = [], []
+        for k in range(int(rng.integers(1, 6))):
+            M, U = int(rng.integers(1, 200)), int(rng.integers(1, 220))
+            mode = int(rng.integers(0, 2))
+            G = rand_geno(rng, M + U, N, 0.1, 0.9)
+            z1 = rng.standard_normal(M)
+            gm, gu = np.ascontiguousarray(G[:M]), np.ascontiguousarray(G[M:])
+            wins.append(dict(mode=mode, geno_m=gm, geno_u=gu, pop_off=off, pop_wgt=w, z1=z1))
+            wants.append(oracle.run_impute(mode, gm, gu, off, w, z1, want_mats=True))
+        job = hotpath.Job(wins, ctx=ctx, want_mats=True)
+        job.run()
+        res = job.fetch()
+        job.close()
+        for got, want in zip(res, wants):
+            if want["mpd"] != 0 or not np.all(np.isfinite(want["z"])):
+                continue
+            assert got["status"] == 0
+            assert np.max(np.abs(got["b11"] - want["b11"])) <= 1e-12
+            assert np.max(np.abs(got["b21"] - want["b21"])) <= 1e-12
+            assert relerr(got["info"], want["info"]) <= 1e-7
+            assert np.max(np.abs(got["z"] - want["z"]) / np.maximum(1.0, np.abs(want["z"]))) <= 1e-7
