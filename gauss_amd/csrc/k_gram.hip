@@ -26,7 +26,7 @@ namespace gauss {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int LROW = 80;                   // LDS row stride in bytes
+constexpr int LROW = 64;                   // LDS row stride in bytes (unpadded; conflict-free through the XOR swizzle)
 constexpr int LTILE = TILE * LROW;         // bytes per operand tile image
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -40,7 +40,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // gfx950, measured), so halving the converts is worth ~5 % of the kernel.
 template <int NA, int NB>
 __device__ __forceinline__ void chunk_mfma(const uint8_t* __restrict__ la, const uint8_t* __restrict__ lb,
-                                           int arow, int brow, f32x16& acc00, f32x16& acc01,
+                                           const int (&aoff)[2], const int (&boff)[2], f32x16& acc00, f32x16& acc01,
                                            f32x16& acc10, f32x16& acc11)
 {
 #define GAUSS_MFMA_PAIR(AW0, AW1, BW0, BW1, HI)                                                       \
@@ -61,11 +61,11 @@ __device__ __forceinline__ void chunk_mfma(const uint8_t* __restrict__ la, const
     }
 #pragma unroll
     for (int g = 0; g < 2; g++) {
-        const u32x4 a0 = *reinterpret_cast<const u32x4*>(la + arow + g * 32);
-        const u32x4 b0 = *reinterpret_cast<const u32x4*>(lb + brow + g * 32);
+        const u32x4 a0 = *reinterpret_cast<const u32x4*>(la + aoff[g]);
+        const u32x4 b0 = *reinterpret_cast<const u32x4*>(lb + boff[g]);
         u32x4 a1 = a0, b1 = b0;
-        if (NA > 1) a1 = *reinterpret_cast<const u32x4*>(la + arow + 32 * LROW + g * 32);
-        if (NB > 1) b1 = *reinterpret_cast<const u32x4*>(lb + brow + 32 * LROW + g * 32);
+        if (NA > 1) a1 = *reinterpret_cast<const u32x4*>(la + aoff[g] + 32 * LROW);
+        if (NB > 1) b1 = *reinterpret_cast<const u32x4*>(lb + boff[g] + 32 * LROW);
         const uint32_t aw0[4] = {a0.x, a0.y, a0.z, a0.w};
         const uint32_t aw1[4] = {a1.x, a1.y, a1.z, a1.w};
         const uint32_t bw0[4] = {b0.x, b0.y, b0.z, b0.w};
@@ -87,24 +87,24 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 // cover the same k positions, so the products line up whatever the instruction's internal k order is.
 template <int NA, int NB>
 __device__ __forceinline__ void chunk_mfma(const uint8_t* __restrict__ la, const uint8_t* __restrict__ lb,
-                                           int arow, int brow, i32x16& acc00, i32x16& acc01,
+                                           const int (&aoff)[2], const int (&boff)[2], i32x16& acc00, i32x16& acc01,
                                            i32x16& acc10, i32x16& acc11)
 {
 #pragma unroll
     for (int g = 0; g < 2; g++) {
-        const i32x4 a0 = *reinterpret_cast<const i32x4*>(la + arow + g * 32);
-        const i32x4 b0 = *reinterpret_cast<const i32x4*>(lb + brow + g * 32);
+        const i32x4 a0 = *reinterpret_cast<const i32x4*>(la + aoff[g]);
+        const i32x4 b0 = *reinterpret_cast<const i32x4*>(lb + boff[g]);
         acc00 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b0, acc00, 0, 0, 0);
         if (NB > 1) {
-            const i32x4 b1 = *reinterpret_cast<const i32x4*>(lb + brow + 32 * LROW + g * 32);
+            const i32x4 b1 = *reinterpret_cast<const i32x4*>(lb + boff[g] + 32 * LROW);
             acc01 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b1, acc01, 0, 0, 0);
             if (NA > 1) {
-                const i32x4 a1 = *reinterpret_cast<const i32x4*>(la + arow + 32 * LROW + g * 32);
+                const i32x4 a1 = *reinterpret_cast<const i32x4*>(la + aoff[g] + 32 * LROW);
                 acc10 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b0, acc10, 0, 0, 0);
                 acc11 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b1, acc11, 0, 0, 0);
             }
         } else if (NA > 1) {
-            const i32x4 a1 = *reinterpret_cast<const i32x4*>(la + arow + 32 * LROW + g * 32);
+            const i32x4 a1 = *reinterpret_cast<const i32x4*>(la + aoff[g] + 32 * LROW);
             acc10 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b0, acc10, 0, 0, 0);
         }
     }
@@ -126,11 +126,19 @@ __device__ __forceinline__ void run_item(const Item& it, uint8_t* lds, int wr, i
     const int lane = tid & 63;
     const int li = lane & 31, lh = lane >> 5;
 
-    // staging map: 512 sixteen-byte pieces per operand tile, two per thread
-    const int srow0 = tid >> 2, scol = (tid & 3) << 4;       // rows 0..63
-    const int srow1 = srow0 + 64;                            // rows 64..127
-    const size_t g0 = (size_t)srow0 * Kp + scol, g1 = (size_t)srow1 * Kp + scol;
-    const int l0 = srow0 * LROW + scol, l1 = srow1 * LROW + scol;
+    // Staging by LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 bytes land contiguously in LDS, no
+    // VGPR round trip, no ds_write).  One wave-instruction carries 16 rows x 64 bytes of a tile chunk;
+    // each wave issues two per operand.  The image has unpadded 64-byte rows; bank conflicts of the
+    // ds_read_b128 fragment reads are avoided by an XOR swizzle applied to the SOURCE address here and
+    // to the read address below (the same involution): piece c of row r sits at slot c ^ ((r >> 2) & 3).
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int srow = lane >> 2;                                   // row inside the 16-row group
+    const int spiece = (lane & 3) ^ ((lane >> 4) & 3);            // swizzled source piece
+    size_t gsrc[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) gsrc[j] = (size_t)(16 * (wave * 2 + j) + srow) * Kp + 16 * spiece;
+    typedef __attribute__((address_space(3))) uint8_t* lds_ptr;
+    typedef __attribute__((address_space(1))) const uint8_t* glb_ptr;
 
     ACC acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
 
@@ -140,50 +148,40 @@ __device__ __forceinline__ void run_item(const Item& it, uint8_t* lds, int wr, i
     auto out = it.slab;
     const int obase = (wr * 64 + 4 * lh) * TILE + wc * 64 + li;
 
-    u32x4 pa0, pa1, pb0, pb1;
-    pa0 = *(gptr<const u32x4>)(Ag + g0 + k0);
-    pa1 = *(gptr<const u32x4>)(Ag + g1 + k0);
-    pb0 = *(gptr<const u32x4>)(Bg + g0 + k0);
-    pb1 = *(gptr<const u32x4>)(Bg + g1 + k0);
-    int cur = 0;
-    {
-        uint8_t* la = lds;
-        uint8_t* lb = lds + LTILE;
-        *reinterpret_cast<u32x4*>(la + l0) = pa0;
-        *reinterpret_cast<u32x4*>(la + l1) = pa1;
-        *reinterpret_cast<u32x4*>(lb + l0) = pb0;
-        *reinterpret_cast<u32x4*>(lb + l1) = pb1;
+#define GAUSS_STAGE(BUF, KOFF)                                                                                   \
+    {                                                                                                            \
+        _Pragma("unroll") for (int j = 0; j < 2; j++) {                                                        \
+            const int t = wave * 2 + j;                                                                          \
+            __builtin_amdgcn_global_load_lds((glb_ptr)Ag + gsrc[j] + (KOFF), (lds_ptr)(lds + (BUF) * 2 * LTILE + t * 1024), 16, 0, 0);          \
+            __builtin_amdgcn_global_load_lds((glb_ptr)Bg + gsrc[j] + (KOFF), (lds_ptr)(lds + (BUF) * 2 * LTILE + LTILE + t * 1024), 16, 0, 0);  \
+        }                                                                                                        \
     }
-    __syncthreads();
+    int cur = 0;
+    GAUSS_STAGE(0, k0)
+    __syncthreads();                                              // waits for the DMA (vmcnt) and the other waves
 
-    const int arow = (wr * 64 + li) * LROW + lh * 16;
-    const int brow = (wc * 64 + li) * LROW + lh * 16;
+    // fragment read offsets: logical piece 2g + lh of rows wr*64 + li (+32 has the same swizzle)
+    const int sw = (li >> 2) & 3;
+    int aoff[2], boff[2];
+#pragma unroll
+    for (int g = 0; g < 2; g++) {
+        aoff[g] = (wr * 64 + li) * LROW + 16 * ((2 * g + lh) ^ sw);
+        boff[g] = (wc * 64 + li) * LROW + 16 * ((2 * g + lh) ^ sw);
+    }
 
     int k = k0;
     for (int seg = 0; seg < nseg; seg++) {
         const int kend = it.seg_k1[seg];
         for (; k < kend; k += KC) {
             const bool more = (k + KC) < klast;          // the prefetch runs across segment ends
-            if (more) {
-                pa0 = *(gptr<const u32x4>)(Ag + g0 + k + KC);
-                pa1 = *(gptr<const u32x4>)(Ag + g1 + k + KC);
-                pb0 = *(gptr<const u32x4>)(Bg + g0 + k + KC);
-                pb1 = *(gptr<const u32x4>)(Bg + g1 + k + KC);
-            }
+            if (more) GAUSS_STAGE(cur ^ 1, k + KC)
             const uint8_t* la = lds + cur * 2 * LTILE;
             const uint8_t* lb = la + LTILE;
-            if (NA > 0) chunk_mfma<NA, NB>(la, lb, arow, brow, acc00, acc01, acc10, acc11);
-            if (more) {
-                uint8_t* wa = lds + (cur ^ 1) * 2 * LTILE;
-                uint8_t* wb = wa + LTILE;
-                *reinterpret_cast<u32x4*>(wa + l0) = pa0;
-                *reinterpret_cast<u32x4*>(wa + l1) = pa1;
-                *reinterpret_cast<u32x4*>(wb + l0) = pb0;
-                *reinterpret_cast<u32x4*>(wb + l1) = pb1;
-            }
-            __syncthreads();
+            if (NA > 0) chunk_mfma<NA, NB>(la, lb, aoff, boff, acc00, acc01, acc10, acc11);
+            __syncthreads();                             // DMA of the next chunk landed; everyone is done reading
             cur ^= 1;
         }
+#undef GAUSS_STAGE
         // end of a segment: flush its exact partial sums, start the next segment from zero.
         // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
         if (NA > 0) {
