@@ -16,6 +16,8 @@ MODE_POOLED = 0
 MODE_WEIGHTED = 1
 ST_CLAMPED = 1
 ST_NONFINITE = 2
+WIN_IMPUTE = 0
+WIN_QCAT = 1
 GRAM_F32 = 0
 GRAM_I8 = 1
 
@@ -31,6 +33,8 @@ class WindowDesc(C.Structure):
         ("geno_m", _u8p), ("geno_u", _u8p), ("ld", C.c_int64), ("z1", _dp),
         ("lambda_", C.c_double), ("min_abs_eig", C.c_double),
         ("out_z", _dp), ("out_info", _dp), ("out_status", _ip), ("out_b11", _dp), ("out_b21", _dp),
+        ("kind", C.c_int), ("n_head_measured", C.c_int), ("n_pred_measured", C.c_int), ("eig_cutoff", C.c_double),
+        ("out_r", _dp), ("out_num_eig", _ip),
     ]
 
 

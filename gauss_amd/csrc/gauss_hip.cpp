@@ -18,7 +18,7 @@
 using namespace gauss;
 
 namespace gauss {
-void launch_jacobi_clamp(const Prob* d_probs, int prob, const Prob& hp, double* d_work, hipStream_t s);
+void launch_jacobi_clamp(const Prob* d_probs, int prob, const Prob& hp, double* d_work, bool apply, hipStream_t s);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -70,6 +70,8 @@ struct Plan {
     int32_t* out_status = nullptr;
     double* out_b11 = nullptr;
     double* out_b21 = nullptr;
+    double* out_r = nullptr;
+    int32_t* out_num_eig = nullptr;
     double* out_ld_user = nullptr;           // ld_only / gene outputs
     size_t out_ld_count = 0;
     double* d_b11_copy = nullptr;
@@ -121,6 +123,8 @@ struct WinSpec {
     int ld_only;
     const int32_t* gene_off;
     int n_gene;
+    int kind = 0, n_head = 0, n_predm = 0;   // QCAT windows (qcat.cpp:134-262)
+    double eig_cutoff = 0.01;
 };
 
 // K segment length: short segments give a single window enough work items to fill 256 CUs;
@@ -147,14 +151,22 @@ static int plan_problem(const WinSpec& w, Plan& pl, int seg_max, int group_targe
     const int N = w.pop_off[w.n_pop];
     if (N < 1) return fail(GAUSS_E_INVALID, "no samples");
     if (w.ld < N) return fail(GAUSS_E_INVALID, "ld (%lld) < n_samples (%d)", w.ld, N);
-    if (!w.ld_only && w.U > 0 && !w.z1) return fail(GAUSS_E_INVALID, "z1 is NULL");
+    if (!w.ld_only && (w.U > 0 || w.kind == GAUSS_WIN_QCAT) && !w.z1) return fail(GAUSS_E_INVALID, "z1 is NULL");
+    if (w.kind != GAUSS_WIN_IMPUTE && w.kind != GAUSS_WIN_QCAT) return fail(GAUSS_E_INVALID, "bad window kind %d", w.kind);
+    if (w.kind == GAUSS_WIN_QCAT && (w.n_head < 0 || w.n_predm < 0 || w.n_head + w.n_predm > w.M))
+        return fail(GAUSS_E_INVALID, "QCAT: n_head_measured + n_pred_measured exceeds n_measured");
 
     Prob& p = pl.p;
     memset(&p, 0, sizeof(p));
     p.mode = w.mode;
     p.M = w.M; p.U = w.U; p.N = N;
-    p.lambda = w.lambda; p.eps = w.eps; p.diag = w.diag;
+    p.lambda = w.lambda; p.diag = w.diag;
     p.ld_only = w.ld_only;
+    p.kind = w.kind; p.n_head = w.n_head; p.n_predm = w.n_predm;
+    // the shifted factorisation tests lambda_min against MakePosDef's floor (imputation, util.cpp:310)
+    // or against CountPC's cutoff (QCAT, util.cpp:379)
+    p.eps = (w.kind == GAUSS_WIN_QCAT) ? w.eig_cutoff : w.eps;
+    p.n_rhs = (w.kind == GAUSS_WIN_QCAT) ? w.n_predm + w.U : w.U;
     if (w.mode == GAUSS_MODE_POOLED) {
         // CalCor pools every selected population (util.cpp:53-64): one pseudo-population
         p.P = 1;
@@ -244,7 +256,7 @@ static int plan_problem(const WinSpec& w, Plan& pl, int seg_max, int group_targe
     p.npair = (int)pl.pair_ti.size();
     p.Mld = (int)rup((size_t)w.M, NB);
     p.nblk = p.Mld / NB;
-    p.npanel = w.ld_only ? 0 : (w.U + NRU - 1) / NRU;
+    p.npanel = w.ld_only ? 0 : (p.n_rhs + NRU - 1) / NRU;
     if (w.z1) pl.z1.assign(w.z1, w.z1 + w.M);
     pl.h_geno_m = w.geno_m; pl.h_geno_u = w.geno_u; pl.user_ld = w.ld;
     return GAUSS_OK;
@@ -364,13 +376,13 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
         if (p.npanel > 0) {
             w.A = wa.take((size_t)4 * p.Mld * p.Mld * sizeof(double));
             w.Linv = wa.take((size_t)2 * p.nblk * NB * NB * sizeof(double));
-            w.B21 = wa.take((size_t)p.U * p.Mld * sizeof(double));
+            w.B21 = wa.take((size_t)std::max(p.U, 1) * p.Mld * sizeof(double));
             w.V = wa.take((size_t)p.npanel * p.Mld * NR * sizeof(double));
             w.b11c = wa.take((size_t)p.Mld * p.Mld * sizeof(double));
         }
         w.ld = wa.take(std::max<size_t>(pl.out_ld_count, 1) * sizeof(double));
         pl.res_off = res;
-        res += 2 * (size_t)p.U;
+        res += 2 * (size_t)p.n_rhs;
     }
     const size_t o_status = wa.take(sizeof(int) * 4 * job->n);
     const size_t o_results = wa.take(sizeof(double) * std::max<size_t>(res, 1));
@@ -423,7 +435,7 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
             pl.d_b11_copy = (double*)(W + w.b11c);
         }
         p.out_z = job->d_results + pl.res_off;
-        p.out_info = job->d_results + pl.res_off + p.U;
+        p.out_info = job->d_results + pl.res_off + p.n_rhs;
         p.status = job->d_status + 4 * i;
         p.out_ld = (double*)(W + w.ld);
         p.gene_off = p.n_gene ? (const int*)(T + to[i].goff) : nullptr;
@@ -554,7 +566,7 @@ static int job_clamp_window(gauss_job* job, int i, int* status_bits)
     const size_t n = (size_t)p.Mld;
     HIPCHK(hipMalloc((void**)&d_work, sizeof(double) * (2 * n * n + 4 * n)));
     HIPCHK(hipMemsetAsync(p.status, 0, sizeof(int) * 4, st));
-    launch_jacobi_clamp(job->d_probs, i, p, d_work, st);
+    launch_jacobi_clamp(job->d_probs, i, p, d_work, true, st);
     // refactor (both matrices are factored again; only matrix 0 is used) and solve this window
     std::vector<int2> pm;
     for (int pn = 0; pn < p.npanel; pn++) pm.push_back(make_int2(i, pn));
@@ -569,10 +581,31 @@ static int job_clamp_window(gauss_job* job, int i, int* status_bits)
     launch_solve(job->d_probs, d_pm, (int)pm.size(), st);
     int h_status[4];
     HIPCHK(hipMemcpyAsync(h_status, p.status, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(job->h_results + pl.res_off, job->d_results + pl.res_off, sizeof(double) * 2 * p.U, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(job->h_results + pl.res_off, job->d_results + pl.res_off, sizeof(double) * 2 * p.n_rhs, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     hipFree(d_tm); hipFree(d_pm); hipFree(d_work);
     *status_bits = (h_status[2] || h_status[0]) ? GAUSS_ST_NONFINITE : GAUSS_ST_CLAMPED;
+    return GAUSS_OK;
+}
+
+// CountPC (util.cpp:355-388) when the smallest eigenvalue of B11 is below the cutoff: eigenvalues by the
+// device Jacobi sweep, counted on the host (the matrix itself is left alone).
+static int job_count_small_eigs(gauss_job* job, int i, int* num_eig)
+{
+    hipStream_t st = job->ctx->stream;
+    Plan& pl = job->plans[i];
+    Prob& p = pl.p;
+    const size_t n = (size_t)p.Mld;
+    double* d_work = nullptr;
+    HIPCHK(hipMalloc((void**)&d_work, sizeof(double) * (2 * n * n + 4 * n)));
+    launch_jacobi_clamp(job->d_probs, i, p, d_work, false, st);
+    std::vector<double> delta(n);
+    HIPCHK(hipMemcpyAsync(delta.data(), d_work + 2 * n * n, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    hipFree(d_work);
+    int small = 0;
+    for (size_t k = 0; k < n; k++) if (delta[k] > 0.0) small++;
+    *num_eig = p.M - small;
     return GAUSS_OK;
 }
 
@@ -589,6 +622,24 @@ static int job_fetch(gauss_job* job)
         Plan& pl = job->plans[i];
         const Prob& p = pl.p;
         int bits = 0;
+        if (p.kind == GAUSS_WIN_QCAT) {
+            // QCAT never repairs B11 (MakePosDef is commented out, qcat.cpp:206); CountPC only counts
+            int num_eig = p.M;
+            if (job->h_status[4 * i + 0]) bits = GAUSS_ST_NONFINITE;          // B11 has no Cholesky factor
+            else if (job->h_status[4 * i + 1]) { int rc = job_count_small_eigs(job, i, &num_eig); if (rc) return rc; }
+            if (bits & GAUSS_ST_NONFINITE)
+                for (int u = 0; u < 2 * p.n_rhs; u++) job->h_results[pl.res_off + u] = NAN;
+            if (pl.out_r) memcpy(pl.out_r, job->h_results + pl.res_off, sizeof(double) * p.n_rhs);
+            if (pl.out_num_eig) *pl.out_num_eig = num_eig;
+            if (pl.out_status) *pl.out_status = bits;
+            if (pl.out_b11)
+                HIPCHK(hipMemcpy2D(pl.out_b11, sizeof(double) * p.M, pl.d_b11_copy, sizeof(double) * p.Mld,
+                                   sizeof(double) * p.M, p.M, hipMemcpyDeviceToHost));
+            if (pl.out_b21 && p.U > 0)
+                HIPCHK(hipMemcpy2D(pl.out_b21, sizeof(double) * p.M, p.B21, sizeof(double) * p.Mld,
+                                   sizeof(double) * p.M, p.U, hipMemcpyDeviceToHost));
+            continue;
+        }
         if (p.npanel > 0 && (job->h_status[4 * i + 0] || job->h_status[4 * i + 1])) {
             int rc = job_clamp_window(job, i, &bits);
             if (rc) return rc;
@@ -634,6 +685,7 @@ static WinSpec spec_from_desc(const gauss_window_desc& d)
     w.M = d.n_measured; w.U = d.n_unmeasured; w.geno_m = d.geno_m; w.geno_u = d.geno_u; w.ld = d.ld;
     w.z1 = d.z1; w.lambda = d.lambda; w.eps = d.min_abs_eig; w.diag = 1.0; w.ld_only = 0;
     w.gene_off = nullptr; w.n_gene = 0;
+    w.kind = d.kind; w.n_head = d.n_head_measured; w.n_predm = d.n_pred_measured; w.eig_cutoff = d.eig_cutoff;
     return w;
 }
 
@@ -681,7 +733,8 @@ int gauss_job_create(gauss_ctx* ctx, const gauss_window_desc* wins, int n_win, i
     if (!ctx || !wins || n_win < 1 || !out_job) return fail(GAUSS_E_INVALID, "bad arguments to gauss_job_create");
     std::vector<WinSpec> specs;
     for (int i = 0; i < n_win; i++) {
-        if (wins[i].n_unmeasured < 1) return fail(GAUSS_E_INVALID, "window %d has no unmeasured SNPs", i);
+        if (wins[i].n_unmeasured < 1 && !(wins[i].kind == GAUSS_WIN_QCAT && wins[i].n_pred_measured > 0))
+            return fail(GAUSS_E_INVALID, "window %d has no unmeasured SNPs", i);
         specs.push_back(spec_from_desc(wins[i]));
     }
     gauss_job* job = nullptr;
@@ -691,6 +744,7 @@ int gauss_job_create(gauss_ctx* ctx, const gauss_window_desc* wins, int n_win, i
         Plan& pl = job->plans[i];
         pl.out_z = wins[i].out_z; pl.out_info = wins[i].out_info; pl.out_status = wins[i].out_status;
         pl.out_b11 = wins[i].out_b11; pl.out_b21 = wins[i].out_b21;
+        pl.out_r = wins[i].out_r; pl.out_num_eig = wins[i].out_num_eig;
     }
     *out_job = job;
     return GAUSS_OK;

@@ -11,6 +11,7 @@ constexpr int SEG_MAX = 2048;  // max samples per K segment (split-K granularity
 constexpr int NB = 64;         // fp64 factor / solve block edge
 constexpr int NR = 64;         // right-hand sides per solve panel (63 SNPs + the z1 column)
 constexpr int NRU = 63;
+constexpr int WIN_QCAT = 1;          // gauss_window_desc.kind == GAUSS_WIN_QCAT
 
 // Pointers stored inside a Prob are loaded from memory, so the compiler could not infer their
 // address space and would emit flat_* accesses.  Everything a Prob points to is device global
@@ -33,6 +34,9 @@ struct Prob {
     int Mld, nblk;          // solve leading dimension (M padded to NB) and block count
     int npanel;             // solve panels (ceil(U / NRU)), 0 for LD-only problems
     int ld_only;            // 1: write out_ld (S x S) instead of B11/B21
+    int kind;               // 0 imputation (z, info), 1 QCAT (correlation of whitened vectors)
+    int n_head, n_predm;    // QCAT: measured rows before / inside the prediction window
+    int n_rhs;              // right-hand sides of the solve: U (imputation) or n_predm + U (QCAT)
     int gram_i8;            // 1: operands are raw codes and slabs hold int32 (i8 MFMA path); 0: e4m3 codes, f32 slabs
     double lambda, eps, diag;
     long long ld_raw;

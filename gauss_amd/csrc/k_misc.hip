@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void jacobi_apply_kernel(double* __restrict__ 
     A[idx] += s;
 }
 
-void launch_jacobi_clamp(const Prob* d_probs, int prob, const Prob& hp, double* d_work, hipStream_t st)
+void launch_jacobi_clamp(const Prob* d_probs, int prob, const Prob& hp, double* d_work, bool apply, hipStream_t st)
 {
     (void)d_probs; (void)prob;
     const int n = hp.Mld;
@@ -129,7 +129,7 @@ void launch_jacobi_clamp(const Prob* d_probs, int prob, const Prob& hp, double* 
         if (h_rot == 0) break;
     }
     hipLaunchKernelGGL(jacobi_lambda_kernel, dim3(n), dim3(256), 0, st, G, V, n, hp.eps, delta, hp.status);
-    hipLaunchKernelGGL(jacobi_apply_kernel, dim3(nb2), dim3(256), 0, st, hp.A, V, delta, n);
+    if (apply) hipLaunchKernelGGL(jacobi_apply_kernel, dim3(nb2), dim3(256), 0, st, hp.A, V, delta, n);
 }
 
 // ------------------------------------------------------------------------------------------

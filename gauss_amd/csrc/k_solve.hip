@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256) void solve_kernel(const Prob* __restrict__ pro
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* TL = smem;                       // [64][LDT]   L_kj, then Linv_kk
     double* TV = TL + NB * LDT;              // [64][LDV]   V_j, then the rhs block X, then V_k
-    double* red = TV + NB * LDV;             // [2][256]
+    double* red = TV + NB * LDV;             // [3][256]
 
     const int2 pm = panelmap[blockIdx.x];
     const Prob& pb = probs[pm.x];
@@ -321,9 +321,14 @@ __global__ __launch_bounds__(256) void solve_kernel(const Prob* __restrict__ pro
     const auto Linv = pb.Linv;                                // matrix 0
     const auto V = pb.V + (size_t)panel * ld * NR;
     const int u0 = panel * NRU;
+    const bool qcat = pb.kind == WIN_QCAT;
+    const int n_predm = pb.n_predm;
+    // QCAT right-hand sides (qcat.cpp:216-243): first the B11 columns of the tested measured SNPs
+    // (rows n_head .. of the symmetric A[0], which the factorisation leaves intact), then the B21 rows
+    const auto Brow = pb.A + (size_t)pb.n_head * ld;
 
     const int cc = tid & 63, rg = tid >> 6;                   // reduction: column cc, rows 16 rg ..
-    double zsum = 0.0, isum = 0.0;
+    double zsum = 0.0, isum = 0.0, vsum = 0.0;
 
     for (int kb = 0; kb < nb; kb++) {
         f64x4 acc[4];
@@ -351,7 +356,11 @@ __global__ __launch_bounds__(256) void solve_kernel(const Prob* __restrict__ pro
             const int c = e >> 6, r = e & 63;                 // r fastest: coalesced along a B21 row
             const int k = kb * NB + r;
             double v = 0.0;
-            if (c < NRU) { const int u = u0 + c; if (u < pb.U) v = pb.B21[(size_t)u * ld + k]; }
+            if (c < NRU) {
+                const int u = u0 + c;
+                if (qcat && u < n_predm) v = Brow[(size_t)u * ld + k];
+                else if (u - (qcat ? n_predm : 0) < pb.U) v = pb.B21[(size_t)(u - (qcat ? n_predm : 0)) * ld + k];
+            }
             else if (k < pb.M) v = pb.z1[k];
             TV[r * LDV + c] = v;
         }
@@ -385,17 +394,36 @@ __global__ __launch_bounds__(256) void solve_kernel(const Prob* __restrict__ pro
             const double y = TV[(rg * 16 + r) * LDV + NRU];
             zsum = fma(x, y, zsum);
             isum = fma(x, x, isum);
+            vsum += x;
         }
     }
     __syncthreads();
     red[tid] = zsum;
     red[256 + tid] = isum;
+    red[512 + tid] = vsum;
     __syncthreads();
     if (tid < NRU) {
         double z = 0.0, info = 0.0;
         for (int g = 0; g < 4; g++) { z += red[g * 64 + tid]; info += red[256 + g * 64 + tid]; }
         const int u = u0 + tid;
-        if (u < pb.U) {
+        if (qcat) {
+            // r = CalCor(Linv z1, Linv b)  (util.cpp:72-101; qcat.cpp:221,239), vectors of length M
+            double sv = 0.0, sy = 0.0, syy = 0.0;
+            for (int g = 0; g < 4; g++) {
+                sv += red[512 + g * 64 + tid];
+                sy += red[512 + g * 64 + NRU];
+                syy += red[256 + g * 64 + NRU];
+            }
+            if (u < pb.n_rhs) {
+                const double n = (double)pb.M;
+                const double mx = sy / n, mv = sv / n;
+                const double cxx = syy - n * mx * mx;
+                const double cvv = info - n * mv * mv;
+                const double cxv = z - n * mx * mv;
+                pb.out_z[u] = cxv / sqrt(cxx * cvv);
+                pb.out_info[u] = cvv;
+            }
+        } else if (u < pb.U) {
             info = fabs(info);                         // dist.cpp:198
             pb.out_z[u] = z / sqrt(info);              // dist.cpp:200
             pb.out_info[u] = info;                     // dist.cpp:202
@@ -406,7 +434,7 @@ __global__ __launch_bounds__(256) void solve_kernel(const Prob* __restrict__ pro
 void launch_solve(const Prob* d_probs, const int2* d_panelmap, int n_panels, hipStream_t s)
 {
     if (n_panels <= 0) return;
-    const size_t sh = ((size_t)NB * LDT + (size_t)NB * LDV + 512) * sizeof(double);
+    const size_t sh = ((size_t)NB * LDT + (size_t)NB * LDV + 768) * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);

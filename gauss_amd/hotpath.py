@@ -109,12 +109,12 @@ class _Win:
     """Keeps the numpy buffers of one window alive next to its C descriptor."""
 
     def __init__(self, desc, mode, geno_m, geno_u, pop_off, pop_wgt, z1, lam, min_abs_eig,
-                 want_mats, dev_ptrs=None):
+                 want_mats, dev_ptrs=None, qcat=None):
         self.po, self.w = _pops(pop_off, pop_wgt)
         self.z1 = np.ascontiguousarray(z1, dtype=np.float64)
         if dev_ptrs is None:
             self.gm = _lib.as_u8(geno_m)
-            self.gu = _lib.as_u8(geno_u)
+            self.gu = _lib.as_u8(geno_u) if geno_u is not None and len(geno_u) else np.zeros((0, 1), np.uint8)
             M, U = self.gm.shape[0], self.gu.shape[0]
             pm, pu, ld = self.gm.ctypes.data, self.gu.ctypes.data, self.gm.strides[0]
             if U and self.gu.strides[0] != ld:
@@ -140,8 +140,24 @@ class _Win:
         desc.out_status = self.status.ctypes.data_as(_ip)
         desc.out_b11 = _lib.ptr(self.b11, _dp)
         desc.out_b21 = _lib.ptr(self.b21, _dp)
+        self.qcat = qcat
+        if qcat is not None:
+            n_head, n_pred, eig_cutoff = qcat
+            self.r = np.zeros(n_pred + U)
+            self.num_eig = np.zeros(1, dtype=np.int32)
+            desc.kind = _lib.WIN_QCAT
+            desc.n_head_measured, desc.n_pred_measured = int(n_head), int(n_pred)
+            desc.eig_cutoff = float(eig_cutoff)
+            desc.out_r = self.r.ctypes.data_as(_dp)
+            desc.out_num_eig = self.num_eig.ctypes.data_as(_ip)
+            desc.out_z = desc.out_info = None
 
     def result(self):
+        if self.qcat is not None:
+            out = dict(r=self.r, num_eig=int(self.num_eig[0]), status=int(self.status[0]))
+            if self.b11 is not None:
+                out["b11"], out["b21"] = self.b11, self.b21
+            return out
         out = dict(z=self.z, info=self.info, status=int(self.status[0]))
         if self.b11 is not None:
             out["b11"], out["b21"] = self.b11, self.b21
@@ -154,6 +170,19 @@ def impute_window(mode, geno_m, geno_u, pop_off, pop_wgt, z1, lam=0.1, min_abs_e
     ctx = ctx or default_context()
     desc = WindowDesc()
     win = _Win(desc, mode, geno_m, geno_u, pop_off, pop_wgt, z1, lam, min_abs_eig, want_mats)
+    check(ctx.lib.gauss_impute_window(ctx.handle, C.byref(desc)))
+    return win.result()
+
+
+def qcat_window(mode, geno_m, geno_u, pop_off, pop_wgt, z1, n_head, n_pred, lam=0.1, eig_cutoff=0.01,
+                want_mats=False, ctx=None):
+    """run_qcat (mode 0, qcat.cpp:134-262) / run_qcatmix (mode 1, qcatmix.cpp): correlation r between the
+    whitened measured Z-scores and the whitened LD column of every tested SNP -- first the n_pred measured
+    SNPs that follow the n_head left-wing ones, then the unmeasured SNPs -- plus CountPC's num_eig."""
+    ctx = ctx or default_context()
+    desc = WindowDesc()
+    win = _Win(desc, mode, geno_m, geno_u, pop_off, pop_wgt, z1, lam, 1e-5, want_mats,
+               qcat=(n_head, n_pred, eig_cutoff))
     check(ctx.lib.gauss_impute_window(ctx.handle, C.byref(desc)))
     return win.result()
 
@@ -171,7 +200,7 @@ class Job:
         for i, w in enumerate(windows):
             self.wins.append(_Win(self.descs[i], w["mode"], w.get("geno_m"), w.get("geno_u"),
                                   w["pop_off"], w.get("pop_wgt"), w["z1"], w.get("lam", 0.1),
-                                  w.get("min_abs_eig", 1e-5), want_mats, w.get("dev")))
+                                  w.get("min_abs_eig", 1e-5), want_mats, w.get("dev"), w.get("qcat")))
         h = C.c_void_p()
         check(self.ctx.lib.gauss_job_create(self.ctx.handle, self.descs, n, 1 if on_device else 0,
                                             C.byref(h)))

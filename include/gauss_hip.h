@@ -12,6 +12,8 @@
  *   computeLD.cpp:95-116  (CalWgtCov pair loops)           gauss_ld(mode=WEIGHTED, diag=1.0)
  *   dist.cpp:129-227      run_dist                         gauss_impute_window(mode=POOLED)
  *   distmix.cpp:138-253   run_distmix                      gauss_impute_window(mode=WEIGHTED)
+ *   qcat.cpp:134-262      run_qcat                         gauss_impute_window(kind=QCAT, POOLED)
+ *   qcatmix.cpp:145-286   run_qcatmix                      gauss_impute_window(kind=QCAT, WEIGHTED)
  *   gene.cpp:305-315      CorG via CalCor   (jepeg)        gauss_gene_ld_batch(mode=POOLED)
  *   gene.cpp:571-586      CorG via CalWgtCov (jepegmix)    gauss_gene_ld_batch(mode=WEIGHTED)
  *   util.cpp:49-70,103-124 (sumxy accumulation)            gauss_gram_counts (integer parity)
@@ -76,7 +78,20 @@ typedef struct gauss_window_desc {
     int32_t* out_status;      /* [1] GAUSS_ST_* bits                           host pointer        */
     double* out_b11;          /* optional [M x M] B11 incl. lambda (symmetric)  host pointer / NULL */
     double* out_b21;          /* optional [U x M] row-major                     host pointer / NULL */
+    /* ---- QCAT / QCATMIX windows (run_qcat qcat.cpp:134-262, run_qcatmix qcatmix.cpp:145-286) ----
+     * kind = GAUSS_WIN_QCAT tests, for the n_pred_measured measured SNPs of the prediction window
+     * (rows n_head_measured .. of geno_m) and then the U unmeasured ones, the Pearson correlation
+     * between L^-1 Z1 and L^-1 b (b = their row of B11 / B21; L = Cholesky factor of B11). */
+    int kind;                 /* GAUSS_WIN_IMPUTE (0, default) or GAUSS_WIN_QCAT                    */
+    int n_head_measured;      /* measured SNPs with bp < start_bp (qcat.cpp:146-147)               */
+    int n_pred_measured;      /* measured SNPs inside the prediction window (qcat.cpp:148-149)     */
+    double eig_cutoff;        /* CountPC cutoff: Arguments::eig_cutoff = 0.01 (gauss.cpp:22)       */
+    double* out_r;            /* [n_pred_measured + U] correlations, measured first   host pointer */
+    int32_t* out_num_eig;     /* [1] CountPC(B11, eig_cutoff)                          host pointer */
 } gauss_window_desc;
+
+#define GAUSS_WIN_IMPUTE 0
+#define GAUSS_WIN_QCAT   1
 
 /* ---- context ------------------------------------------------------------------------------- */
 int gauss_hip_init(int device, gauss_ctx** out_ctx);

@@ -476,6 +476,125 @@ ORC_API int orc_run_impute(int mode, const char* geno_m, int M, const char* geno
 }
 
 /* ------------------------------------------------------------------------- */
+/* n1. run_qcat / run_qcatmix core          src/qcat.cpp:166-245 (mode 0)      */
+/*                                          src/qcatmix.cpp:179-277 (mode 1)   */
+/*   B11 (+lambda on the diagonal) and B21 as in DIST / DISTMIX; then          */
+/*     num_eig = CountPC(B11, eig_cutoff)               util.cpp:355-388       */
+/*     L = LLT(B11).matrixL()                           util.cpp:271-274       */
+/*     LInv = L.fullPivLu().inverse()                   util.cpp:298-300       */
+/*     r_i  = CalCor(LInv Z1, LInv b_i)                 util.cpp:194-203       */
+/*   b_i: rows n_head .. n_head+n_predm-1 of B11 (tested measured SNPs), then  */
+/*   the U rows of B21.  out_r has n_predm + U entries.  The t score, chi^2    */
+/*   and p-value are scalar tails of (num_eig, r) formed by the caller.        */
+/*   MakePosDef is commented out in the reference (qcat.cpp:206) -- not run.   */
+/* ------------------------------------------------------------------------- */
+static double vec_cor(const double* x, const double* y, int n)              /* util.cpp:194-203 */
+{
+    double mx = 0.0, my = 0.0;
+    for (int i = 0; i < n; i++) { mx += x[i]; my += y[i]; }
+    mx /= n; my /= n;
+    double sxx = 0.0, syy = 0.0, sxy = 0.0;
+    for (int i = 0; i < n; i++) {
+        double dx = x[i] - mx, dy = y[i] - my;
+        sxx += dx * dx; syy += dy * dy; sxy += dx * dy;
+    }
+    return sxy / sqrt(sxx * syy);
+}
+
+ORC_API int orc_count_pc(const double* A, int n, double eig_cutoff)         /* util.cpp:355-388 */
+{
+    if (n <= 0) return 0;
+    double* V = (double*)malloc(sizeof(double) * (size_t)n * n);
+    double* d = (double*)malloc(sizeof(double) * n);
+    double* e = (double*)malloc(sizeof(double) * n);
+    memcpy(V, A, sizeof(double) * (size_t)n * n);
+    int num_eig = n;
+    if (sym_eig(n, V, d, e) == 0) {
+        double mn = d[0];
+        for (int i = 1; i < n; i++) if (d[i] < mn) mn = d[i];
+        if (mn < eig_cutoff)
+            for (int i = 0; i < n; i++) if (d[i] < eig_cutoff) num_eig--;
+    }
+    free(V); free(d); free(e);
+    return num_eig;
+}
+
+ORC_API int orc_run_qcat(int mode, const char* geno_m, int M, const char* geno_u, int U, long ld,
+                         const int* pop_off, int P, const double* pop_wgt, const double* z1,
+                         double lambda, double eig_cutoff, int n_head, int n_predm,
+                         double* out_r, int* out_num_eig, double* b11_out, double* b21_out)
+{
+    size_t MM = (size_t)M * M;
+    double* B11 = (double*)calloc(MM ? MM : 1, sizeof(double));
+    double* L = (double*)calloc(MM ? MM : 1, sizeof(double));
+    double* LInv = (double*)calloc(MM ? MM : 1, sizeof(double));
+    double* b = (double*)calloc(M ? M : 1, sizeof(double));
+    double* wz = (double*)calloc(M ? M : 1, sizeof(double));
+    double* wb = (double*)calloc(M ? M : 1, sizeof(double));
+    double* sd = (double*)calloc((size_t)(M + U) ? (size_t)(M + U) : 1, sizeof(double));
+
+    if (mode == 1) {                                                        /* qcatmix.cpp:197-204 */
+        for (int i = 0; i < M; i++)
+            sd[i] = sqrt(orc_calwgtcov(geno_m + (size_t)i * ld, geno_m + (size_t)i * ld, pop_off, P, pop_wgt));
+        for (int i = 0; i < U; i++)
+            sd[M + i] = sqrt(orc_calwgtcov(geno_u + (size_t)i * ld, geno_u + (size_t)i * ld, pop_off, P, pop_wgt));
+    }
+    for (int i = 0; i < M; i++) {                                           /* qcat.cpp:185-192 / qcatmix.cpp:207-217 */
+        B11[(size_t)i * M + i] = 1.0 + lambda;
+        for (int j = i + 1; j < M; j++) {
+            double v;
+            if (mode == 0) v = orc_calcor(geno_m + (size_t)i * ld, geno_m + (size_t)j * ld, pop_off, P);
+            else v = orc_calwgtcov(geno_m + (size_t)i * ld, geno_m + (size_t)j * ld, pop_off, P, pop_wgt) / (sd[i] * sd[j]);
+            B11[(size_t)j * M + i] = v;
+            B11[(size_t)i * M + j] = v;
+        }
+    }
+    if (b11_out) memcpy(b11_out, B11, sizeof(double) * MM);
+    *out_num_eig = orc_count_pc(B11, M, eig_cutoff);                        /* qcat.cpp:203 */
+
+    /* Eigen::LLT lower factor, column-major L(i,j) = L[j*M+i]              util.cpp:271-274 */
+#define LL(i, j) L[(size_t)(j) * M + (i)]
+    for (int j = 0; j < M; j++) {
+        double s = B11[(size_t)j * M + j];
+        for (int k = 0; k < j; k++) s -= LL(j, k) * LL(j, k);
+        double dj = sqrt(s);
+        LL(j, j) = dj;
+        for (int i = j + 1; i < M; i++) {
+            double t = B11[(size_t)j * M + i];
+            for (int k = 0; k < j; k++) t -= LL(i, k) * LL(j, k);
+            LL(i, j) = t / dj;
+        }
+    }
+#undef LL
+    orc_inv_mat(LInv, L, M);                                                /* qcat.cpp:207 */
+    for (int i = 0; i < M; i++) {                                           /* qcat.cpp:208 */
+        double s = 0.0;
+        for (int k = 0; k < M; k++) s += LInv[(size_t)k * M + i] * z1[k];
+        wz[i] = s;
+    }
+    for (int t = 0; t < n_predm + U; t++) {
+        if (t < n_predm) {                                                  /* qcat.cpp:217-221 */
+            for (int j = 0; j < M; j++) b[j] = B11[(size_t)j * M + (t + n_head)];
+        } else {                                                            /* qcat.cpp:176-184, 235-239 */
+            int i = t - n_predm;
+            for (int j = 0; j < M; j++) {
+                if (mode == 0) b[j] = orc_calcor(geno_u + (size_t)i * ld, geno_m + (size_t)j * ld, pop_off, P);
+                else b[j] = orc_calwgtcov(geno_u + (size_t)i * ld, geno_m + (size_t)j * ld, pop_off, P, pop_wgt) / (sd[M + i] * sd[j]);
+            }
+            if (b21_out) memcpy(b21_out + (size_t)i * M, b, sizeof(double) * M);
+        }
+        for (int i = 0; i < M; i++) {
+            double s = 0.0;
+            for (int k = 0; k < M; k++) s += LInv[(size_t)k * M + i] * b[k];
+            wb[i] = s;
+        }
+        out_r[t] = vec_cor(wz, wb, M);
+    }
+    free(B11); free(L); free(LInv); free(b); free(wz); free(wb); free(sd);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
 /* a9. Gene::CalJepegPval / CalJepegmixPval tail      src/gene.cpp:317-550    */
 /*  Inputs for one gene with n SNPs:                                          */
 /*    CorG     n x n col-major LD among the gene SNPs, diag = 1+lambda        */

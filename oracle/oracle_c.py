@@ -123,6 +123,41 @@ def run_impute(mode, geno_m, geno_u, pop_off, pop_wgt, z1, lam=0.1, min_abs_eig=
     return out
 
 
+def run_qcat(mode, geno_m, geno_u, pop_off, pop_wgt, z1, n_head, n_pred, lam=0.1, eig_cutoff=0.01,
+             want_mats=False):
+    """run_qcat (mode 0, qcat.cpp:166-245) / run_qcatmix (mode 1). Returns dict(r, num_eig[, b11, b21]);
+    r lists the n_pred tested measured SNPs first, then the unmeasured ones."""
+    lib = load()
+    gm = _geno(geno_m)
+    M, N = gm.shape
+    gu = _geno(geno_u) if geno_u is not None and len(geno_u) else np.zeros((0, N), dtype=gm.dtype)
+    U = gu.shape[0]
+    po = _off(pop_off)
+    P = len(po) - 1
+    w = np.ascontiguousarray(pop_wgt if pop_wgt is not None else np.ones(P), dtype=np.float64)
+    z1 = np.ascontiguousarray(z1, dtype=np.float64)
+    r = np.zeros(n_pred + U)
+    num_eig = C.c_int(0)
+    b11 = np.zeros((M, M)) if want_mats else None
+    b21 = np.zeros((max(U, 1), M)) if want_mats else None
+    lib.orc_run_qcat(C.c_int(mode), gm.ctypes.data_as(C.c_char_p), C.c_int(M),
+                     gu.ctypes.data_as(C.c_char_p), C.c_int(U), C.c_long(N),
+                     _cp(po, _ip), C.c_int(P), _cp(w, _dp), _cp(z1, _dp),
+                     C.c_double(lam), C.c_double(eig_cutoff), C.c_int(n_head), C.c_int(n_pred),
+                     _cp(r, _dp), C.byref(num_eig),
+                     _cp(b11, _dp) if want_mats else None, _cp(b21, _dp) if want_mats else None)
+    out = dict(r=r, num_eig=num_eig.value)
+    if want_mats:
+        out["b11"], out["b21"] = b11, b21[:U]
+    return out
+
+
+def count_pc(a, eig_cutoff=0.01):
+    lib = load()
+    a = np.array(a, dtype=np.float64, order="F")
+    return lib.orc_count_pc(_cp(a, _dp), C.c_int(a.shape[0]), C.c_double(eig_cutoff))
+
+
 def make_pos_def(a, min_abs_eig=1e-5):
     lib = load()
     a = np.array(a, dtype=np.float64, order="F")

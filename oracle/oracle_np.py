@@ -91,6 +91,27 @@ def run_impute(mode, gm, gu, pop_off, w, z1, lam=0.1, min_abs_eig=1e-5):
     return dict(z=z / np.sqrt(info), info=info, mpd=mpd, b11=b11, b21=b21)
 
 
+def run_qcat(mode, gm, gu, pop_off, w, z1, n_head, n_pred, lam=0.1, eig_cutoff=0.01):
+    """Independent statement of run_qcat / run_qcatmix (qcat.cpp:166-245): numpy Cholesky + solve."""
+    if mode == 0:
+        b11 = pooled_cor(gm)
+        b21 = pooled_cor(gu, gm) if len(gu) else np.zeros((0, len(gm)))
+    else:
+        b11 = weighted_cor(gm, None, pop_off, w)
+        b21 = weighted_cor(gu, gm, pop_off, w) if len(gu) else np.zeros((0, len(gm)))
+    np.fill_diagonal(b11, 1.0 + lam)
+    vals = np.linalg.eigvalsh(b11)
+    num_eig = len(vals) - (int(np.sum(vals < eig_cutoff)) if vals[0] < eig_cutoff else 0)
+    L = np.linalg.cholesky(b11)
+    rhs = np.vstack([b11[n_head:n_head + n_pred], b21]).T          # M x (n_pred + U)
+    wz = np.linalg.solve(L, np.asarray(z1, dtype=np.float64))
+    wb = np.linalg.solve(L, rhs)
+    wz = wz - wz.mean()
+    wb = wb - wb.mean(0)
+    r = (wz @ wb) / np.sqrt((wz @ wz) * np.einsum("ij,ij->j", wb, wb))
+    return dict(r=r, num_eig=num_eig, b11=b11, b21=b21)
+
+
 def pnorm_upper(x):
     return stats.norm.sf(x)
 

@@ -206,3 +206,58 @@ def test_int8_gram_path_is_bit_identical_to_f32_path(ctx):
             assert np.array_equal(a[k], b[k]), k
     want = oracle.run_impute(1, gm, gu, p["off"], p["w"], z1)
     assert relerr(b1["info"], want["info"]) <= Z_TOL
+
+
+R_TOL = 1e-9        # QCAT r: one-pass moments after the MFMA triangular solve vs the reference's two-pass CalCor
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("shape", [(11, 0, 2, 9), (70, 90, 10, 50), (150, 130, 0, 150), (130, 64, 60, 63)])
+def test_qcat_window_matches_oracle(ctx, mode, shape):
+    """run_qcat / run_qcatmix core (qcat.cpp:166-245, qcatmix.cpp:179-277)."""
+    M, U, n_head, n_pred = shape
+    p = small_panel(n_snp=M + U + 30, scale=0.02, seed=17 + M)
+    G = p["G"][: M + U]
+    gm, gu, z1 = split_window(dict(G=G), M)
+    got = hotpath.qcat_window(mode, gm, gu if U else None, p["off"], p["w"], z1, n_head, n_pred,
+                              want_mats=True, ctx=ctx)
+    want = oracle.run_qcat(mode, gm, gu if U else None, p["off"], p["w"], z1, n_head, n_pred, want_mats=True)
+    assert got["status"] == 0
+    assert got["num_eig"] == want["num_eig"] == M
+    assert np.max(np.abs(got["b11"] - want["b11"])) <= LD_TOL
+    if U:
+        assert np.max(np.abs(got["b21"] - want["b21"])) <= LD_TOL
+    assert got["r"].shape == want["r"].shape == (n_pred + U,)
+    assert np.max(np.abs(got["r"] - want["r"])) <= R_TOL
+
+
+def test_qcat_counts_eigenvalues_below_cutoff(ctx):
+    # duplicated measured SNPs with a ridge below eig_cutoff: CountPC (util.cpp:355-388) drops them from
+    # num_eig while the Cholesky factor still exists (lambda > 0)
+    p = small_panel(n_snp=80, scale=0.02, n_pops=6, seed=23)
+    gm, gu, z1 = split_window(p, 36)
+    gm = np.ascontiguousarray(np.vstack([gm, gm[:5]]))
+    z1 = np.concatenate([z1, z1[:5]])
+    got = hotpath.qcat_window(0, gm, gu, p["off"], None, z1, 4, 20, lam=0.004, ctx=ctx)
+    want = oracle.run_qcat(0, gm, gu, p["off"], None, z1, 4, 20, lam=0.004)
+    assert want["num_eig"] <= len(gm) - 5
+    assert got["num_eig"] == want["num_eig"]
+    assert np.max(np.abs(got["r"] - want["r"])) <= 1e-7
+
+
+def test_qcat_and_impute_windows_share_a_job(ctx):
+    p = small_panel(n_snp=260, scale=0.02, seed=33)
+    gm, gu, z1 = split_window(dict(G=p["G"][:200]), 120)
+    wins = [dict(mode=1, geno_m=gm, geno_u=gu, pop_off=p["off"], pop_wgt=p["w"], z1=z1),
+            dict(mode=1, geno_m=gm, geno_u=gu, pop_off=p["off"], pop_wgt=p["w"], z1=z1, qcat=(20, 70, 0.01)),
+            dict(mode=0, geno_m=gm[:40], geno_u=gu[:30], pop_off=p["off"], pop_wgt=None, z1=z1[:40], qcat=(0, 40, 0.01))]
+    job = hotpath.Job(wins, ctx=ctx)
+    job.run()
+    res = job.fetch()
+    job.close()
+    a = oracle.run_impute(1, gm, gu, p["off"], p["w"], z1)
+    b = oracle.run_qcat(1, gm, gu, p["off"], p["w"], z1, 20, 70)
+    c = oracle.run_qcat(0, gm[:40], gu[:30], p["off"], None, z1[:40], 0, 40)
+    assert relerr(res[0]["info"], a["info"]) <= Z_TOL
+    assert np.max(np.abs(res[1]["r"] - b["r"])) <= R_TOL and res[1]["num_eig"] == b["num_eig"]
+    assert np.max(np.abs(res[2]["r"] - c["r"])) <= R_TOL and res[2]["num_eig"] == c["num_eig"]

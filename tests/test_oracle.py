@@ -57,6 +57,36 @@ def test_run_impute_c_vs_numpy(mode):
     assert np.all(a["info"] > 0) and np.all(a["info"] < 1.0 + 1e-9)
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+def test_run_qcat_c_vs_numpy(mode):
+    # qcat.cpp:166-245 / qcatmix.cpp:179-277: restatement (LLT + full-pivot LU inverse) against an
+    # independent numpy Cholesky solve
+    p = small_panel(n_snp=120, scale=0.02, seed=6)
+    gm, gu, z1 = split_window(p, 50)
+    a = oracle.run_qcat(mode, gm, gu, p["off"], p["w"], z1, n_head=7, n_pred=30, want_mats=True)
+    b = onp.run_qcat(mode, gm, gu, p["off"], p["w"], z1, 7, 30)
+    assert a["num_eig"] == b["num_eig"] == 50
+    assert np.max(np.abs(a["b11"] - b["b11"])) <= 1e-13
+    assert a["r"].shape == (30 + len(gu),)
+    assert np.max(np.abs(a["r"] - b["r"])) <= 1e-10
+    assert np.all(np.abs(a["r"]) <= 1.0)
+    # no unmeasured SNPs (qcat only guards on the measured count, qcat.cpp:157)
+    c = oracle.run_qcat(mode, gm, None, p["off"], p["w"], z1, n_head=7, n_pred=30)
+    assert np.array_equal(c["r"], a["r"][:30])
+
+
+def test_count_pc_counts_small_eigenvalues():
+    # CountPC (util.cpp:355-388): duplicated SNPs with lambda = 0 give exact zero eigenvalues
+    p = small_panel(n_snp=60, scale=0.02, n_pops=5, seed=3)
+    gm, gu, z1 = split_window(p, 24)
+    gm = np.ascontiguousarray(np.vstack([gm, gm[:4]]))
+    z1 = np.concatenate([z1, z1[:4]])
+    b11 = onp.pooled_cor(gm)
+    assert oracle.count_pc(b11) == len(gm) - int(np.sum(np.linalg.eigvalsh(b11) < 0.01))
+    assert oracle.count_pc(b11) <= len(gm) - 4
+    assert oracle.count_pc(b11 + 0.1 * np.eye(len(gm))) == len(gm)
+
+
 def test_allele_flip_flips_imputed_z():
     # recoding an unmeasured SNP 0<->2 negates its correlations, hence its imputed z; info unchanged
     p = small_panel(n_snp=60, scale=0.02, n_pops=5)
