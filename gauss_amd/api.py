@@ -24,13 +24,13 @@ from . import _lib, hotpath
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HOST_LIB_PATH = os.path.join(_HERE, "lib", "libgauss_host.so")
 
-KIND_COMPUTELD, KIND_DIST, KIND_DISTMIX, KIND_JEPEG, KIND_JEPEGMIX = range(5)
+KIND_COMPUTELD, KIND_DIST, KIND_DISTMIX, KIND_JEPEG, KIND_JEPEGMIX, KIND_QCAT, KIND_QCATMIX = range(7)
 
 HOST_SYMBOLS = [
     "gauss_host_last_error", "gauss_table_nrow", "gauss_table_ncol", "gauss_table_colname",
     "gauss_table_coltype", "gauss_table_str", "gauss_table_int", "gauss_table_dbl", "gauss_table_matrix",
     "gauss_table_free", "gauss_host_computeLD", "gauss_host_dist", "gauss_host_distmix", "gauss_host_jepeg",
-    "gauss_host_jepegmix", "gauss_host_prepare", "gauss_prepared_snps", "gauss_prepared_counts",
+    "gauss_host_jepegmix", "gauss_host_qcat", "gauss_host_qcatmix", "gauss_prepared_qcat_counts", "gauss_host_prepare", "gauss_prepared_snps", "gauss_prepared_counts",
     "gauss_prepared_measured_rows", "gauss_prepared_unmeasured_rows", "gauss_prepared_geno_m",
     "gauss_prepared_geno_u", "gauss_prepared_pop_off", "gauss_prepared_pop_wgt", "gauss_prepared_z1",
     "gauss_prepared_gene_off", "gauss_prepared_window_desc", "gauss_prepared_finish", "gauss_prepared_free",
@@ -81,6 +81,9 @@ def load_host():
     h.gauss_host_distmix.argtypes = [_vp, C.c_int, _i64, _i64, _i64, _strs, _dp, C.c_int] + files4 + [_dbl, C.POINTER(_vp)]
     h.gauss_host_jepeg.argtypes = [_vp, _cp, _cp] + files4 + [_dbl, C.POINTER(_vp)]
     h.gauss_host_jepegmix.argtypes = [_vp, _strs, _dp, C.c_int, _cp] + files4 + [_dbl, C.POINTER(_vp)]
+    h.gauss_host_qcat.argtypes = h.gauss_host_dist.argtypes
+    h.gauss_host_qcatmix.argtypes = h.gauss_host_distmix.argtypes
+    h.gauss_prepared_qcat_counts.argtypes = [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     h.gauss_host_prepare.argtypes = [C.c_int, C.c_int, _i64, _i64, _i64, _cp, _strs, _dp, C.c_int, _cp, _cp, _cp, _cp, _cp,
                                      _dbl, C.POINTER(_vp)]
     h.gauss_prepared_snps.restype = _vp
@@ -202,6 +205,29 @@ def distmix(chr, start_bp, end_bp, wing_size, pop_wgt_df, input_file, reference_
     return _table(h, out)[0]
 
 
+def qcat(chr, start_bp, end_bp, wing_size, study_pop, input_file, reference_index_file, reference_data_file,
+         reference_pop_desc_file, af1_cutoff=None, ctx=None):
+    """qcat() of the reference (qcat.cpp:30-132); af1_cutoff None -> 0.05."""
+    h = load_host()
+    out = _vp()
+    _hcheck(h.gauss_host_qcat(_ctx(ctx), int(chr), int(start_bp), int(end_bp), int(wing_size), _enc(study_pop),
+                              _enc(input_file), _enc(reference_index_file), _enc(reference_data_file),
+                              _enc(reference_pop_desc_file), _af(af1_cutoff), C.byref(out)))
+    return _table(h, out)[0]
+
+
+def qcatmix(chr, start_bp, end_bp, wing_size, pop_wgt_df, input_file, reference_index_file, reference_data_file,
+            reference_pop_desc_file, af1_cutoff=None, ctx=None):
+    """qcatmix() of the reference (qcatmix.cpp:30-140); af1_cutoff None -> 0.01."""
+    h = load_host()
+    names, w, n = _pop_wgt(pop_wgt_df)
+    out = _vp()
+    _hcheck(h.gauss_host_qcatmix(_ctx(ctx), int(chr), int(start_bp), int(end_bp), int(wing_size), names,
+                                 w.ctypes.data_as(_dp), n, _enc(input_file), _enc(reference_index_file),
+                                 _enc(reference_data_file), _enc(reference_pop_desc_file), _af(af1_cutoff), C.byref(out)))
+    return _table(h, out)[0]
+
+
 def jepeg(study_pop, input_file, annotation_file, reference_index_file, reference_data_file, reference_pop_desc_file,
           af1_cutoff=None, ctx=None):
     h = load_host()
@@ -241,6 +267,9 @@ class Prepared:
         c = [C.c_int() for _ in range(5)]
         self.h.gauss_prepared_counts(out, *[C.byref(x) for x in c])
         self.M, self.U, self.N, self.P, self.n_gene = [x.value for x in c]
+        a, b = C.c_int(), C.c_int()
+        self.h.gauss_prepared_qcat_counts(out, C.byref(a), C.byref(b))
+        self.n_head, self.n_pred = a.value, b.value
 
     def snps(self):
         return _table(self.h, self.h.gauss_prepared_snps(self.handle), free=False)[0]

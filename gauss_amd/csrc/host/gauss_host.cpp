@@ -83,6 +83,8 @@ struct Snp {
     std::string a1 = ".", a2 = ".";
     double af1mix = -1.0, af1ref = -1.0;
     double z = 0.0, info = -1.0;
+    int qcat_m = 0;                // snp.cpp:26-28
+    double qcat_t = 0.0, qcat_chisq = 0.0;
     int type = -1;                 // 0 panel only, 1 GWAS and panel, 2 GWAS only (snp.h:61)
     long long fpos = -1;
     std::string geneid = ".";
@@ -114,7 +116,7 @@ struct Args {                       // Arguments, gauss.h:18-69 with the default
     std::string study_pop, input_file, reference_index_file, reference_data_file, reference_pop_desc_file, annotation_file;
     std::vector<std::string> ref_pop_vec, ref_sup_pop_vec;
     std::vector<int> ref_pop_size_vec;
-    double lambda = 0.1, min_abs_eig = 1e-5;
+    double lambda = 0.1, min_abs_eig = 1e-5, eig_cutoff = 0.01;
     std::vector<int> pop_flag_vec;
     std::vector<double> pop_wgt_vec;
     std::map<std::string, double> pop_wgt_map;
@@ -414,7 +416,9 @@ struct gauss_prepared {
     std::vector<int32_t> pop_off;
     std::vector<double> pop_wgt, z1;
     std::vector<int32_t> gene_off;
-    std::vector<double> out_z, out_info;
+    std::vector<double> out_z, out_info, out_r;
+    int n_head = 0, n_predm = 0;               // QCAT: measured SNPs left of / inside the prediction window
+    int32_t num_eig = 0;
     int32_t status = 0;
     gauss_table snps;
     bool snps_built = false;
@@ -433,7 +437,8 @@ static void build_snp_table(gauss_prepared& p)
 {
     gauss_table& t = p.snps;
     t.cols.clear();
-    const bool mix = (p.kind == GAUSS_KIND_COMPUTELD || p.kind == GAUSS_KIND_DISTMIX || p.kind == GAUSS_KIND_JEPEGMIX);
+    const bool mix = (p.kind == GAUSS_KIND_COMPUTELD || p.kind == GAUSS_KIND_DISTMIX || p.kind == GAUSS_KIND_JEPEGMIX ||
+                      p.kind == GAUSS_KIND_QCATMIX);
     Column& rsid = t.add("rsid", GAUSS_COL_STR);
     for (Snp* s : p.snp_vec) rsid.s.push_back(s->rsid);
     Column& chr = t.add("chr", GAUSS_COL_INT);
@@ -463,8 +468,10 @@ static int prepare(gauss_prepared& p)
 {
     Args& a = p.args;
     const int kind = p.kind;
-    const bool mix = (kind == GAUSS_KIND_COMPUTELD || kind == GAUSS_KIND_DISTMIX || kind == GAUSS_KIND_JEPEGMIX);
+    const bool mix = (kind == GAUSS_KIND_COMPUTELD || kind == GAUSS_KIND_DISTMIX || kind == GAUSS_KIND_JEPEGMIX ||
+                      kind == GAUSS_KIND_QCATMIX);
     const bool gene = (kind == GAUSS_KIND_JEPEG || kind == GAUSS_KIND_JEPEGMIX);
+    const bool qcat = (kind == GAUSS_KIND_QCAT || kind == GAUSS_KIND_QCATMIX);
     if (read_ref_desc(a)) return -1;
     if (mix) init_pop_flag_wgt_vec(a);
     else if (init_pop_flag_vec(a)) return -1;
@@ -483,11 +490,15 @@ static int prepare(gauss_prepared& p)
     if (mix) p.pop_wgt = a.pop_wgt_vec;
     else p.pop_wgt.assign(p.pop_off.size() - 1, 1.0);
 
-    if (kind == GAUSS_KIND_DIST || kind == GAUSS_KIND_DISTMIX) {
-        for (size_t r = 0; r < p.snp_vec.size(); r++) {        // dist.cpp:132-140
+    if (kind == GAUSS_KIND_DIST || kind == GAUSS_KIND_DISTMIX || qcat) {
+        for (size_t r = 0; r < p.snp_vec.size(); r++) {        // dist.cpp:132-140, qcat.cpp:140-152
             Snp* s = p.snp_vec[r];
             if (s->type == 0 && (s->bp >= a.start_bp && s->bp <= a.end_bp)) { p.unmeasured.push_back(s); p.unmeasured_rows.push_back((int32_t)r); }
-            else if (s->type == 1) { p.measured.push_back(s); p.measured_rows.push_back((int32_t)r); }
+            else if (s->type == 1) {
+                p.measured.push_back(s); p.measured_rows.push_back((int32_t)r);
+                if (s->bp < a.start_bp) p.n_head++;
+                else if (s->bp <= a.end_bp) p.n_predm++;
+            }
         }
     } else if (kind == GAUSS_KIND_COMPUTELD) {
         for (size_t r = 0; r < p.snp_vec.size(); r++)          // computeLD.cpp:80-86
@@ -734,6 +745,33 @@ static gauss_table* dist_output(gauss_prepared& p)     // dist.cpp:91-124 / dist
     return t;
 }
 
+static gauss_table* qcat_output(gauss_prepared& p)     // qcat.cpp:94-131 / qcatmix.cpp:102-139
+{
+    const Args& a = p.args;
+    const bool mix = p.kind == GAUSS_KIND_QCATMIX;
+    gauss_table* t = new gauss_table();
+    Column rsid{"rsid", GAUSS_COL_STR, {}, {}, {}}, chr{"chr", GAUSS_COL_INT, {}, {}, {}}, bp{"bp", GAUSS_COL_INT, {}, {}, {}};
+    Column a1{"a1", GAUSS_COL_STR, {}, {}, {}}, a2{"a2", GAUSS_COL_STR, {}, {}, {}};
+    Column af{mix ? "af1mix" : "af1ref", GAUSS_COL_DBL, {}, {}, {}}, z{"z", GAUSS_COL_DBL, {}, {}, {}};
+    Column qm{"qcat_m", GAUSS_COL_INT, {}, {}, {}}, qt{"qcat_t", GAUSS_COL_DBL, {}, {}, {}};
+    Column qc{"qcat_chisq", GAUSS_COL_DBL, {}, {}, {}}, qp{"qcat_pval", GAUSS_COL_DBL, {}, {}, {}};
+    Column type{"type", GAUSS_COL_INT, {}, {}, {}};
+    for (Snp* s : p.snp_vec) {
+        const int ibp = (int)s->bp;                               // qcat.cpp:95
+        if (ibp >= a.start_bp && ibp <= a.end_bp) {
+            rsid.s.push_back(s->rsid); chr.i.push_back(s->chr); bp.i.push_back(ibp);
+            a1.s.push_back(s->a1); a2.s.push_back(s->a2);
+            af.d.push_back(mix ? s->af1mix : s->af1ref);
+            z.d.push_back(s->z);
+            qm.i.push_back(s->qcat_m); qt.d.push_back(s->qcat_t); qc.d.push_back(s->qcat_chisq);
+            qp.d.push_back(pchisq_upper(s->qcat_chisq, 1));       // qcat.cpp:107
+            type.i.push_back(s->type);
+        }
+    }
+    t->cols = {rsid, chr, bp, a1, a2, af, z, qm, qt, qc, qp, type};
+    return t;
+}
+
 // ------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------
@@ -786,7 +824,7 @@ int gauss_host_prepare(int kind, int chr, int64_t start_bp, int64_t end_bp, int6
                        const char* reference_pop_desc_file, double af1_cutoff, gauss_prepared** out)
 {
     if (!out) return herr("out is NULL");
-    if (kind < 0 || kind > 4) return herr("bad kind %d", kind);
+    if (kind < 0 || kind > GAUSS_KIND_QCATMIX) return herr("bad kind %d", kind);
     if (!input_file || !reference_index_file || !reference_data_file || !reference_pop_desc_file) return herr("file name is NULL");
     std::unique_ptr<gauss_prepared> p(new gauss_prepared());
     p->kind = kind;
@@ -797,8 +835,9 @@ int gauss_host_prepare(int kind, int chr, int64_t start_bp, int64_t end_bp, int6
     a.input_file = input_file; a.reference_index_file = reference_index_file;
     a.reference_data_file = reference_data_file; a.reference_pop_desc_file = reference_pop_desc_file;
     if (annotation_file) a.annotation_file = annotation_file;
-    a.af1_cutoff = std::isnan(af1_cutoff) ? 0.01 : af1_cutoff;          // dist.cpp:53-57
-    const bool mix = (kind == GAUSS_KIND_COMPUTELD || kind == GAUSS_KIND_DISTMIX || kind == GAUSS_KIND_JEPEGMIX);
+    a.af1_cutoff = std::isnan(af1_cutoff) ? (kind == GAUSS_KIND_QCAT ? 0.05 : 0.01) : af1_cutoff;   // dist.cpp:53-57, qcat.cpp:53-57
+    const bool mix = (kind == GAUSS_KIND_COMPUTELD || kind == GAUSS_KIND_DISTMIX || kind == GAUSS_KIND_JEPEGMIX ||
+                      kind == GAUSS_KIND_QCATMIX);
     if (mix) {
         if (!pop_names || !pop_wgts || n_pop_wgt < 1) return herr("pop_wgt_df is empty");
         set_pop_wgt_map(a, pop_names, pop_wgts, n_pop_wgt);
@@ -830,12 +869,42 @@ const double* gauss_prepared_z1(const gauss_prepared* p) { return p ? p->z1.data
 const int32_t* gauss_prepared_gene_off(const gauss_prepared* p) { return (p && !p->gene_off.empty()) ? p->gene_off.data() : nullptr; }
 void gauss_prepared_free(gauss_prepared* p) { delete p; }
 
+int gauss_prepared_qcat_counts(const gauss_prepared* p, int* n_head, int* n_predm)
+{
+    if (!p) return herr("prepared is NULL");
+    if (n_head) *n_head = p->n_head;
+    if (n_predm) *n_predm = p->n_predm;
+    return 0;
+}
+
 int gauss_prepared_window_desc(gauss_prepared* p, gauss_window_desc* d)
 {
     if (!p || !d) return herr("bad arguments");
-    if (p->kind != GAUSS_KIND_DIST && p->kind != GAUSS_KIND_DISTMIX) return herr("not an imputation window");
+    const bool qcat = (p->kind == GAUSS_KIND_QCAT || p->kind == GAUSS_KIND_QCATMIX);
+    if (p->kind != GAUSS_KIND_DIST && p->kind != GAUSS_KIND_DISTMIX && !qcat) return herr("not an imputation or QCAT window");
     const Args& a = p->args;
     const int M = (int)p->measured.size(), U = (int)p->unmeasured.size();
+    if (qcat) {
+        // qcat.cpp:157-162 guards on the measured count only; qcatmix.cpp:168-174 on both (texts as in the reference)
+        if (p->kind == GAUSS_KIND_QCAT && M <= a.min_num_measured_snp)
+            return herr("Not enough number of SNPs loaded - QCAT not performed (measured %d, unmeasured %d)", M, U);
+        if (p->kind == GAUSS_KIND_QCATMIX && (M <= a.min_num_measured_snp || U <= a.min_num_unmeasured_snp))
+            return herr("Not enough number of SNPs loaded - QCAT performed (measured %d, unmeasured %d)", M, U);
+        p->out_r.assign((size_t)p->n_predm + U, 0.0);
+        p->num_eig = M;
+        memset(d, 0, sizeof(*d));
+        d->kind = GAUSS_WIN_QCAT;
+        d->mode = (p->kind == GAUSS_KIND_QCAT) ? GAUSS_MODE_POOLED : GAUSS_MODE_WEIGHTED;
+        d->n_pop = (int)p->pop_off.size() - 1;
+        d->pop_off = p->pop_off.data(); d->pop_wgt = p->pop_wgt.data();
+        d->n_measured = M; d->n_unmeasured = U;
+        d->geno_m = p->gm.data(); d->geno_u = p->gu.data(); d->ld = p->ld;
+        d->z1 = p->z1.data(); d->lambda = a.lambda; d->min_abs_eig = a.min_abs_eig;
+        d->n_head_measured = p->n_head; d->n_pred_measured = p->n_predm; d->eig_cutoff = a.eig_cutoff;
+        d->out_r = p->out_r.data(); d->out_num_eig = &p->num_eig; d->out_status = &p->status;
+        if (p->n_predm + U < 1) return herr("QCAT window has no SNP to test");
+        return 0;
+    }
     if (M <= a.min_num_measured_snp || U <= a.min_num_unmeasured_snp)      // dist.cpp:145-151
         return herr("Not enough number of SNPs loaded - %s not performed (measured %d, unmeasured %d)",
                     p->kind == GAUSS_KIND_DIST ? "DIST" : "DISTMIX", M, U);
@@ -854,6 +923,18 @@ int gauss_prepared_window_desc(gauss_prepared* p, gauss_window_desc* d)
 int gauss_prepared_finish(gauss_prepared* p, gauss_table** out)
 {
     if (!p || !out) return herr("bad arguments");
+    if (p->kind == GAUSS_KIND_QCAT || p->kind == GAUSS_KIND_QCATMIX) {
+        const int m = p->num_eig;
+        for (size_t t = 0; t < p->out_r.size(); t++) {                           // qcat.cpp:216-243
+            Snp* s = (t < (size_t)p->n_predm) ? p->measured[p->n_head + t] : p->unmeasured[t - p->n_predm];
+            const double r = p->out_r[t];
+            s->qcat_m = m;
+            s->qcat_t = std::sqrt((double)(m - 3)) * r;
+            s->qcat_chisq = (m - 3) * r * r;
+        }
+        *out = qcat_output(*p);
+        return 0;
+    }
     for (size_t i = 0; i < p->unmeasured.size() && i < p->out_z.size(); i++) {   // dist.cpp:200-202
         p->unmeasured[i]->z = p->out_z[i];
         p->unmeasured[i]->info = p->out_info[i];
@@ -890,6 +971,23 @@ int gauss_host_distmix(gauss_ctx* ctx, int chr, int64_t start_bp, int64_t end_bp
                        double af1_cutoff, gauss_table** out)
 {
     return run_impute(ctx, GAUSS_KIND_DISTMIX, chr, start_bp, end_bp, wing_size, nullptr, pop_names, pop_wgts, n_pop_wgt,
+                      input_file, reference_index_file, reference_data_file, reference_pop_desc_file, af1_cutoff, out);
+}
+
+int gauss_host_qcat(gauss_ctx* ctx, int chr, int64_t start_bp, int64_t end_bp, int64_t wing_size, const char* study_pop,
+                    const char* input_file, const char* reference_index_file, const char* reference_data_file,
+                    const char* reference_pop_desc_file, double af1_cutoff, gauss_table** out)
+{
+    return run_impute(ctx, GAUSS_KIND_QCAT, chr, start_bp, end_bp, wing_size, study_pop, nullptr, nullptr, 0, input_file,
+                      reference_index_file, reference_data_file, reference_pop_desc_file, af1_cutoff, out);
+}
+
+int gauss_host_qcatmix(gauss_ctx* ctx, int chr, int64_t start_bp, int64_t end_bp, int64_t wing_size,
+                       const char* const* pop_names, const double* pop_wgts, int n_pop_wgt, const char* input_file,
+                       const char* reference_index_file, const char* reference_data_file, const char* reference_pop_desc_file,
+                       double af1_cutoff, gauss_table** out)
+{
+    return run_impute(ctx, GAUSS_KIND_QCATMIX, chr, start_bp, end_bp, wing_size, nullptr, pop_names, pop_wgts, n_pop_wgt,
                       input_file, reference_index_file, reference_data_file, reference_pop_desc_file, af1_cutoff, out);
 }
 

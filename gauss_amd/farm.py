@@ -67,7 +67,7 @@ def impute_chromosome(kind, chr, start_bp, end_bp, wing_size, input_file, refere
                       window_size=1_000_000, compute=gpu_compute, group=None, threads=None, timings=None):
     """dist()/distmix() over every window of [start_bp, end_bp], sharded across the ranks of `group`.
 
-    kind: api.KIND_DIST or api.KIND_DISTMIX.  Returns on rank 0 (or the single process) a dict
+    kind: api.KIND_DIST / KIND_DISTMIX (imputation) or api.KIND_QCAT / KIND_QCATMIX (QC test).  Returns on rank 0 (or the single process) a dict
     {"table": DataFrame of all windows in window order, "skipped": [(window, reason), ...]};
     other ranks return None.  Windows that fail the reference's ">10 measured / >10 unmeasured"
     guard (dist.cpp:145-151) are reported in "skipped" instead of aborting the run.
@@ -118,7 +118,7 @@ def impute_chromosome(kind, chr, start_bp, end_bp, wing_size, input_file, refere
     for i, p, err in results:
         if err is not None:
             skipped.append((i, err))
-        elif p.M <= 10 or p.U <= 10:
+        elif p.M <= 10 or (p.U <= 10 and kind != api.KIND_QCAT):       # qcat.cpp:157 guards on measured SNPs only
             skipped.append((i, f"Not enough number of SNPs loaded (measured {p.M}, unmeasured {p.U})"))
             p.close()
         else:

@@ -1,5 +1,5 @@
 /*
- * gauss_host.h -- C ABI of libgauss_host.so: the host side of the hot path, i.e. the five
+ * gauss_host.h -- C ABI of libgauss_host.so: the host side of the hot path, i.e. the
  * reference entry points with their reference argument lists, in plain C.
  *
  *   reference (Rcpp, src/RcppExports.cpp:335-340)          here
@@ -11,6 +11,8 @@
  *   distmix(chr,start_bp,end_bp,wing_size,pop_wgt_df,...)   gauss_host_distmix   distmix.cpp:30-135
  *   jepeg(study_pop,input_file,annotation_file,...)         gauss_host_jepeg     jepeg.cpp:28-153
  *   jepegmix(pop_wgt_df,input_file,annotation_file,...)     gauss_host_jepegmix  jepegmix.cpp:26-161
+ *   qcat(chr,start_bp,end_bp,wing_size,study_pop,...)       gauss_host_qcat      qcat.cpp:30-132
+ *   qcatmix(chr,start_bp,end_bp,wing_size,pop_wgt_df,...)   gauss_host_qcatmix   qcatmix.cpp:30-140
  *
  * Same argument meaning, same defaults (af1_cutoff NaN = R's NULL -> 0.01, dist.cpp:53-57), same
  * row order (std::map order on (chr,bp,a1,a2), gauss.h:72-99), same column names and types as
@@ -46,6 +48,8 @@ typedef struct gauss_prepared gauss_prepared; /* one window/gene set after the h
 #define GAUSS_KIND_DISTMIX   2
 #define GAUSS_KIND_JEPEG     3
 #define GAUSS_KIND_JEPEGMIX  4
+#define GAUSS_KIND_QCAT      5
+#define GAUSS_KIND_QCATMIX   6
 
 const char* gauss_host_last_error(void);
 
@@ -85,6 +89,20 @@ int gauss_host_jepegmix(gauss_ctx* ctx, const char* const* pop_names, const doub
                         const char* reference_index_file, const char* reference_data_file,
                         const char* reference_pop_desc_file, double af1_cutoff, gauss_table** out);
 
+/* QCAT / QCATMIX: same feeder as dist / distmix, the window core is
+ * run_qcat (qcat.cpp:134-262) / run_qcatmix (qcatmix.cpp:144-297).  af1_cutoff NaN -> 0.05 for qcat
+ * (qcat.cpp:53-57), 0.01 for qcatmix (qcatmix.cpp:61-65).  Output columns: rsid chr bp a1 a2
+ * af1ref|af1mix z qcat_m qcat_t qcat_chisq qcat_pval type. */
+int gauss_host_qcat(gauss_ctx* ctx, int chr, int64_t start_bp, int64_t end_bp, int64_t wing_size,
+                    const char* study_pop, const char* input_file, const char* reference_index_file,
+                    const char* reference_data_file, const char* reference_pop_desc_file,
+                    double af1_cutoff, gauss_table** out);
+int gauss_host_qcatmix(gauss_ctx* ctx, int chr, int64_t start_bp, int64_t end_bp, int64_t wing_size,
+                       const char* const* pop_names, const double* pop_wgts, int n_pop_wgt,
+                       const char* input_file, const char* reference_index_file,
+                       const char* reference_data_file, const char* reference_pop_desc_file,
+                       double af1_cutoff, gauss_table** out);
+
 /* Re-block a BGZF text file line by line (reader + writer round trip); returns lines copied or -1. */
 int64_t gauss_host_bgzf_copy(const char* in_path, const char* out_path);
 
@@ -115,7 +133,9 @@ const int32_t* gauss_prepared_pop_off(const gauss_prepared* p);
 const double* gauss_prepared_pop_wgt(const gauss_prepared* p);
 const double* gauss_prepared_z1(const gauss_prepared* p);
 const int32_t* gauss_prepared_gene_off(const gauss_prepared* p);
-/* Fill a window descriptor for gauss_job_create from a prepared dist/distmix window; the outputs
+/* QCAT windows: number of measured SNPs left of the prediction window and inside it (qcat.cpp:147-150) */
+int gauss_prepared_qcat_counts(const gauss_prepared* p, int* n_head_measured, int* n_pred_measured);
+/* Fill a window descriptor for gauss_job_create from a prepared dist/distmix/qcat/qcatmix window; the outputs
  * point into the prepared object and are written back into its SNP list by gauss_prepared_finish. */
 int gauss_prepared_window_desc(gauss_prepared* p, gauss_window_desc* out);
 /* After the GPU results are in: build the reference's output DataFrame (dist.cpp:91-124). */

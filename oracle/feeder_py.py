@@ -279,6 +279,56 @@ def distmix(chr_, start_bp, end_bp, wing, pop_wgt, input_file, index, data, desc
     return _impute(True, chr_, start_bp, end_bp, wing, None, pop_wgt, (input_file, index, data, desc), af1_cutoff)
 
 
+def _qcat(kind_mix, chr_, start_bp, end_bp, wing, study_pop, pop_wgt, files, af1_cutoff):
+    """qcat.cpp:30-262 / qcatmix.cpp:30-297: the dist / distmix feeder, then run_qcat[mix]."""
+    import math
+    input_file, index, data, desc = files
+    cutoff = (0.01 if kind_mix else 0.05) if af1_cutoff is None else af1_cutoff     # qcatmix.cpp:61-65, qcat.cpp:53-57
+    pops = read_ref_desc(desc)
+    if kind_mix:
+        flags, w = pop_flags_wgt(pops, *pop_wgt)
+    else:
+        flags, w = pop_flags(pops, study_pop), None
+    lo, hi = start_bp - wing, end_bp + wing
+    m = read_input_z(input_file, chr_, lo, hi, False)
+    read_reference_index(m, index, chr_, lo, hi, False)
+    vec = make_snp_vec(m, data, flags, cutoff, w)
+    meas = [s for s in vec if s.type == 1]
+    unme = [s for s in vec if s.type == 0 and start_bp <= s.bp <= end_bp]
+    n_head = sum(1 for s in meas if s.bp < start_bp)
+    n_pred = sum(1 for s in meas if start_bp <= s.bp <= end_bp)
+    if len(meas) <= Args.min_measured or (kind_mix and len(unme) <= Args.min_unmeasured):
+        raise ValueError("Not enough number of SNPs loaded")        # qcat.cpp:157, qcatmix.cpp:168
+    off = _selected_off(pops, flags)
+    res = oc.run_qcat(1 if kind_mix else 0, _matrix(meas), _matrix(unme) if unme else None, off, w,
+                      [s.z for s in meas], n_head, n_pred, Args.lam, 0.01)
+    ne = res["num_eig"]
+    for s in vec:
+        s.qcat_m, s.qcat_t, s.qcat_chisq = 0, 0.0, 0.0              # snp.cpp:26-28
+    tested = meas[n_head:n_head + n_pred] + unme
+    for s, r in zip(tested, res["r"]):
+        s.qcat_m = ne
+        s.qcat_t = (math.sqrt(ne - 3) if ne >= 3 else float("nan")) * float(r)
+        s.qcat_chisq = (ne - 3) * float(r) * float(r)
+    rows = [s for s in vec if start_bp <= s.bp <= end_bp]
+    return dict(rsid=[s.rsid for s in rows], chr=[s.chr for s in rows], bp=[s.bp for s in rows],
+                a1=[s.a1 for s in rows], a2=[s.a2 for s in rows],
+                af=[(s.af1mix if kind_mix else s.af1ref) for s in rows], z=[s.z for s in rows],
+                qcat_m=[s.qcat_m for s in rows], qcat_t=[s.qcat_t for s in rows],
+                qcat_chisq=[s.qcat_chisq for s in rows],
+                qcat_pval=[oc.pchisq_upper(s.qcat_chisq, 1) for s in rows],
+                type=[s.type for s in rows], n_measured=len(meas), n_unmeasured=len(unme),
+                n_head=n_head, n_pred=n_pred, num_eig=ne)
+
+
+def qcat(chr_, start_bp, end_bp, wing, study_pop, input_file, index, data, desc, af1_cutoff=None):
+    return _qcat(False, chr_, start_bp, end_bp, wing, study_pop, None, (input_file, index, data, desc), af1_cutoff)
+
+
+def qcatmix(chr_, start_bp, end_bp, wing, pop_wgt, input_file, index, data, desc, af1_cutoff=None):
+    return _qcat(True, chr_, start_bp, end_bp, wing, None, pop_wgt, (input_file, index, data, desc), af1_cutoff)
+
+
 def computeLD(chr_, start_bp, end_bp, pop_wgt, input_file, index, data, desc, af1_cutoff=None):
     cutoff = 0.01 if af1_cutoff is None else af1_cutoff
     pops = read_ref_desc(desc)

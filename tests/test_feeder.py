@@ -120,6 +120,41 @@ def test_prepare_window_matches_python_feeder(study, mix):
     pr.close()
 
 
+def test_prepare_qcat_counts_head_and_prediction_snps(study):
+    # qcat.cpp:140-152: same partition as dist plus the counts of measured SNPs left of / inside the
+    # prediction window; qcat's default af1_cutoff is 0.05 (qcat.cpp:53-57), qcatmix's 0.01
+    inp, idx, dat, desc = _files(study)
+    chr_, lo, hi, wing = 22, 1_400_000, 2_000_000, 250_000
+    pops = fp.read_ref_desc(desc)
+    flags = fp.pop_flags(pops, "EUR")
+    m = fp.read_input_z(inp, chr_, lo - wing, hi + wing, False)
+    fp.read_reference_index(m, idx, chr_, lo - wing, hi + wing, False)
+    vec = fp.make_snp_vec(m, dat, flags, 0.05, None)
+    meas = [s for s in vec if s.type == 1]
+    unme = [s for s in vec if s.type == 0 and lo <= s.bp <= hi]
+    pr = api.Prepared(api.KIND_QCAT, chr=chr_, start_bp=lo, end_bp=hi, wing_size=wing, study_pop="EUR", input_file=inp,
+                      reference_index_file=idx, reference_data_file=dat, reference_pop_desc_file=desc)
+    _check_prepared(pr, vec, meas, unme, False)
+    assert pr.n_head == sum(1 for s in meas if s.bp < lo) > 0
+    assert pr.n_pred == sum(1 for s in meas if lo <= s.bp <= hi) > 0
+    d = pr.window_desc()
+    assert d.kind == 1 and d.n_head_measured == pr.n_head and d.n_pred_measured == pr.n_pred and d.eig_cutoff == 0.01
+    pr.close()
+    pr = api.Prepared(api.KIND_QCATMIX, chr=chr_, start_bp=lo, end_bp=hi, wing_size=wing, pop_wgt_df=WGT, input_file=inp,
+                      reference_index_file=idx, reference_data_file=dat, reference_pop_desc_file=desc)
+    flags, w = fp.pop_flags_wgt(pops, *WGT)
+    vec = fp.make_snp_vec(m2 := _reload(fp, inp, idx, chr_, lo - wing, hi + wing), dat, flags, 0.01, w)
+    assert pr.M == sum(1 for s in vec if s.type == 1)
+    assert pr.window_desc().mode == 1
+    pr.close()
+
+
+def _reload(fp, inp, idx, chr_, lo, hi):
+    m = fp.read_input_z(inp, chr_, lo, hi, False)
+    fp.read_reference_index(m, idx, chr_, lo, hi, False)
+    return m
+
+
 def test_prepare_jepeg_matches_python_feeder(study):
     inp, idx, dat, desc = _files(study)
     ann = study["paths"]["annot.txt"]

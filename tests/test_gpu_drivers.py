@@ -52,6 +52,35 @@ def test_distmix_end_to_end(ctx, study):
     _cmp_impute(df, fp.distmix(*args, af1_cutoff=0.02), "af1mix")
 
 
+def _cmp_qcat(df, want, afcol):
+    assert list(df.columns) == ["rsid", "chr", "bp", "a1", "a2", afcol, "z", "qcat_m", "qcat_t", "qcat_chisq",
+                                "qcat_pval", "type"]
+    assert list(df["rsid"]) == want["rsid"] and list(df["bp"]) == want["bp"] and list(df["type"]) == want["type"]
+    assert np.array_equal(df[afcol].to_numpy(), np.array(want["af"]))
+    assert np.array_equal(df["z"].to_numpy(), np.array(want["z"]))
+    assert list(df["qcat_m"]) == want["qcat_m"]
+    t, wt = df["qcat_t"].to_numpy(), np.array(want["qcat_t"])
+    assert np.max(np.abs(t - wt)) <= 1e-8
+    c, wc = df["qcat_chisq"].to_numpy(), np.array(want["qcat_chisq"])
+    assert np.max(np.abs(c - wc) / np.maximum(1.0, wc)) <= 1e-8
+    pv, wp = df["qcat_pval"].to_numpy(), np.array(want["qcat_pval"])
+    assert np.max(np.abs(pv - wp) / wp) <= 1e-6
+    # GWAS-only SNPs (type 2) are never tested and keep the constructor's zeros (snp.cpp:26-28)
+    t2 = df["type"].to_numpy() == 2
+    assert np.all(df["qcat_m"].to_numpy()[t2] == 0) and np.all(pv[t2] == 1.0)
+    assert want["n_pred"] > 0 and (df["qcat_m"].to_numpy() > 0).sum() == want["n_pred"] + want["n_unmeasured"]
+
+
+def test_qcat_end_to_end(ctx, study):
+    args = (22, 1_500_000, 2_000_000, 300_000, "EUR") + _files(study)
+    _cmp_qcat(api.qcat(*args, ctx=ctx), fp.qcat(*args), "af1ref")
+
+
+def test_qcatmix_end_to_end(ctx, study):
+    args = (22, 1_500_000, 2_000_000, 300_000, WGT) + _files(study)
+    _cmp_qcat(api.qcatmix(*args, af1_cutoff=0.02, ctx=ctx), fp.qcatmix(*args, af1_cutoff=0.02), "af1mix")
+
+
 def test_computeLD_end_to_end(ctx, study):
     args = (22, 1_200_000, 2_300_000, WGT) + _files(study)
     got = api.computeLD(*args, ctx=ctx)
