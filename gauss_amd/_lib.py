@@ -18,6 +18,8 @@ ST_CLAMPED = 1
 ST_NONFINITE = 2
 WIN_IMPUTE = 0
 WIN_QCAT = 1
+WIN_LD = 2
+CODE_ADDITIVE, CODE_DOMINANT, CODE_RECESSIVE = 1, 2, 4
 GRAM_F32 = 0
 GRAM_I8 = 1
 
@@ -34,7 +36,7 @@ class WindowDesc(C.Structure):
         ("lambda_", C.c_double), ("min_abs_eig", C.c_double),
         ("out_z", _dp), ("out_info", _dp), ("out_status", _ip), ("out_b11", _dp), ("out_b21", _dp),
         ("kind", C.c_int), ("n_head_measured", C.c_int), ("n_pred_measured", C.c_int), ("eig_cutoff", C.c_double),
-        ("out_r", _dp), ("out_num_eig", _ip),
+        ("out_r", _dp), ("out_num_eig", _ip), ("u_codings", C.c_int),
     ]
 
 

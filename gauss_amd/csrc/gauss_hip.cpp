@@ -73,6 +73,7 @@ struct Plan {
     double* out_r = nullptr;
     int32_t* out_num_eig = nullptr;
     double* out_ld_user = nullptr;           // ld_only / gene outputs
+    int U_user = 0;                          // geno_u rows as passed by the caller (before codings)
     size_t out_ld_count = 0;
     double* d_b11_copy = nullptr;
     size_t res_off = 0;                      // offset (in doubles) of this problem's z in the result block
@@ -124,6 +125,7 @@ struct WinSpec {
     const int32_t* gene_off;
     int n_gene;
     int kind = 0, n_head = 0, n_predm = 0;   // QCAT windows (qcat.cpp:134-262)
+    int u_codings = 0;                       // GAUSS_CODE_* mask for the geno_u rows (0 = additive)
     double eig_cutoff = 0.01;
 };
 
@@ -151,22 +153,32 @@ static int plan_problem(const WinSpec& w, Plan& pl, int seg_max, int group_targe
     const int N = w.pop_off[w.n_pop];
     if (N < 1) return fail(GAUSS_E_INVALID, "no samples");
     if (w.ld < N) return fail(GAUSS_E_INVALID, "ld (%lld) < n_samples (%d)", w.ld, N);
-    if (!w.ld_only && (w.U > 0 || w.kind == GAUSS_WIN_QCAT) && !w.z1) return fail(GAUSS_E_INVALID, "z1 is NULL");
-    if (w.kind != GAUSS_WIN_IMPUTE && w.kind != GAUSS_WIN_QCAT) return fail(GAUSS_E_INVALID, "bad window kind %d", w.kind);
+    if (w.kind != GAUSS_WIN_IMPUTE && w.kind != GAUSS_WIN_QCAT && w.kind != GAUSS_WIN_LD)
+        return fail(GAUSS_E_INVALID, "bad window kind %d", w.kind);
+    if (!w.ld_only && w.kind != GAUSS_WIN_LD && (w.U > 0 || w.kind == GAUSS_WIN_QCAT) && !w.z1) return fail(GAUSS_E_INVALID, "z1 is NULL");
+    if (w.u_codings & ~(GAUSS_CODE_ADDITIVE | GAUSS_CODE_DOMINANT | GAUSS_CODE_RECESSIVE))
+        return fail(GAUSS_E_INVALID, "bad u_codings mask %d", w.u_codings);
     if (w.kind == GAUSS_WIN_QCAT && (w.n_head < 0 || w.n_predm < 0 || w.n_head + w.n_predm > w.M))
         return fail(GAUSS_E_INVALID, "QCAT: n_head_measured + n_pred_measured exceeds n_measured");
 
     Prob& p = pl.p;
     memset(&p, 0, sizeof(p));
     p.mode = w.mode;
-    p.M = w.M; p.U = w.U; p.N = N;
+    p.M = w.M; p.N = N;
+    {
+        int nc = 0;
+        for (int c = 0; c < 3; c++) if (w.u_codings & (1 << c)) p.code_blk[nc++] = c;
+        if (nc == 0) { p.code_blk[0] = 0; nc = 1; }
+        p.U_raw = std::max(w.U, 1);
+        p.U = w.U * nc;                          // one block of U rows per coding
+    }
     p.lambda = w.lambda; p.diag = w.diag;
     p.ld_only = w.ld_only;
     p.kind = w.kind; p.n_head = w.n_head; p.n_predm = w.n_predm;
     // the shifted factorisation tests lambda_min against MakePosDef's floor (imputation, util.cpp:310)
     // or against CountPC's cutoff (QCAT, util.cpp:379)
     p.eps = (w.kind == GAUSS_WIN_QCAT) ? w.eig_cutoff : w.eps;
-    p.n_rhs = (w.kind == GAUSS_WIN_QCAT) ? w.n_predm + w.U : w.U;
+    p.n_rhs = (w.kind == GAUSS_WIN_QCAT) ? w.n_predm + p.U : p.U;
     if (w.mode == GAUSS_MODE_POOLED) {
         // CalCor pools every selected population (util.cpp:53-64): one pseudo-population
         p.P = 1;
@@ -219,7 +231,7 @@ static int plan_problem(const WinSpec& w, Plan& pl, int seg_max, int group_targe
     }
 
     p.Mp = (int)rup((size_t)w.M, TILE);
-    p.Up = (int)rup((size_t)w.U, TILE);
+    p.Up = (int)rup((size_t)p.U, TILE);
     p.Sp = p.Mp + p.Up;
     p.nT = p.Sp / TILE;
     const int mt = p.Mp / TILE;
@@ -256,7 +268,8 @@ static int plan_problem(const WinSpec& w, Plan& pl, int seg_max, int group_targe
     p.npair = (int)pl.pair_ti.size();
     p.Mld = (int)rup((size_t)w.M, NB);
     p.nblk = p.Mld / NB;
-    p.npanel = w.ld_only ? 0 : (p.n_rhs + NRU - 1) / NRU;
+    p.npanel = (w.ld_only || w.kind == GAUSS_WIN_LD) ? 0 : (p.n_rhs + NRU - 1) / NRU;
+    pl.U_user = w.U;
     if (w.z1) pl.z1.assign(w.z1, w.z1 + w.M);
     pl.h_geno_m = w.geno_m; pl.h_geno_u = w.geno_u; pl.user_ld = w.ld;
     return GAUSS_OK;
@@ -338,6 +351,26 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
     }
     // longest segments first: the tail of the launch is then made of short items
     std::stable_sort(items.begin(), items.end(), [](const ItemH& a, const ItemH& b) { return a.len > b.len; });
+    // XCD-aware launch order.  Workgroup b runs on XCD b % 8 (each XCD has its own 4 MiB L2).  Neighbours in
+    // the sorted list share operand tiles (same window, same K range, adjacent tile pairs), so the list is
+    // cut into super-blocks of xcd_block items and super-block j is queued on XCD j % 8: the items that are
+    // resident together on one XCD then read the same tiles at about the same K position.  Measured on the
+    // bench workload (rocprofv3 FETCH_SIZE): 22.0 GB -> 16.0 GB per launch at 36, same kernel time; larger
+    // blocks start to cost time (load balance).  GAUSS_XCD_BLOCK overrides (0 = plain order).
+    {
+        static const int xcd_block = [] { const char* e = getenv("GAUSS_XCD_BLOCK"); return e ? atoi(e) : 36; }();
+        if (xcd_block > 0 && items.size() > (size_t)8 * xcd_block) {
+            std::vector<std::vector<ItemH>> q(8);
+            for (size_t i = 0; i < items.size(); i++) q[(i / xcd_block) % 8].push_back(items[i]);
+            std::vector<ItemH> out;
+            out.reserve(items.size());
+            size_t pos[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            while (out.size() < items.size())
+                for (int x = 0; x < 8; x++)
+                    if (pos[x] < q[x].size()) out.push_back(q[x][pos[x]++]);
+            items.swap(out);
+        }
+    }
     const size_t o_items = ta.take(sizeof(Item) * std::max<size_t>(items.size(), 1));
     const size_t o_rowmap = put(blob, ta, rowmap);
     const size_t o_tilemap = put(blob, ta, tilemap);
@@ -361,7 +394,7 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
         if (!on_device) {
             w.ldraw = (long long)rup((size_t)p.N, 16);
             w.raw_m = wa.take((size_t)p.M * w.ldraw);
-            w.raw_u = wa.take((size_t)std::max(p.U, 1) * w.ldraw);
+            w.raw_u = wa.take((size_t)std::max(pl.U_user, 1) * w.ldraw);
         } else {
             w.ldraw = pl.user_ld;
         }
@@ -373,10 +406,14 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
         w.wm = wa.take((size_t)p.Sp * sizeof(double));
         w.mu = wa.take((size_t)p.Sp * p.P * sizeof(double));
         w.wmu = wa.take((size_t)p.Sp * p.P * sizeof(double));
-        if (p.npanel > 0) {
-            w.A = wa.take((size_t)4 * p.Mld * p.Mld * sizeof(double));
-            w.Linv = wa.take((size_t)2 * p.nblk * NB * NB * sizeof(double));
+        if (!p.ld_only) {
+            // the LD epilogue writes B11 (and its shifted twin) and B21 for every window that is not a plain
+            // gauss_ld / gene batch; the factor and solve scratch only exists when there is something to solve
+            w.A = wa.take((size_t)(p.npanel > 0 ? 4 : 2) * p.Mld * p.Mld * sizeof(double));
             w.B21 = wa.take((size_t)std::max(p.U, 1) * p.Mld * sizeof(double));
+        }
+        if (p.npanel > 0) {
+            w.Linv = wa.take((size_t)2 * p.nblk * NB * NB * sizeof(double));
             w.V = wa.take((size_t)p.npanel * p.Mld * NR * sizeof(double));
             w.b11c = wa.take((size_t)p.Mld * p.Mld * sizeof(double));
         }
@@ -429,9 +466,9 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
         p.rt_sd = (double*)(W + w.sd); p.rt_wm = (double*)(W + w.wm);
         p.rt_mu = (double*)(W + w.mu); p.rt_wmu = (double*)(W + w.wmu);
         p.z1 = (const double*)(T + to[i].z1);
+        if (!p.ld_only) { p.A = (double*)(W + w.A); p.B21 = (double*)(W + w.B21); }
         if (p.npanel > 0) {
-            p.A = (double*)(W + w.A); p.Linv = (double*)(W + w.Linv);
-            p.B21 = (double*)(W + w.B21); p.V = (double*)(W + w.V);
+            p.Linv = (double*)(W + w.Linv); p.V = (double*)(W + w.V);
             pl.d_b11_copy = (double*)(W + w.b11c);
         }
         p.out_z = job->d_results + pl.res_off;
@@ -444,9 +481,9 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
         if (!on_device) {
             HIPCHK(hipMemcpy2DAsync(W + w.raw_m, (size_t)w.ldraw, pl.h_geno_m, (size_t)pl.user_ld,
                                     (size_t)p.N, (size_t)p.M, hipMemcpyHostToDevice, st));
-            if (p.U > 0)
+            if (pl.U_user > 0)
                 HIPCHK(hipMemcpy2DAsync(W + w.raw_u, (size_t)w.ldraw, pl.h_geno_u, (size_t)pl.user_ld,
-                                        (size_t)p.N, (size_t)p.U, hipMemcpyHostToDevice, st));
+                                        (size_t)p.N, (size_t)pl.U_user, hipMemcpyHostToDevice, st));
         }
     }
     // device work items: every pointer is resolved here so the kernel starts loading operands at once
@@ -622,6 +659,17 @@ static int job_fetch(gauss_job* job)
         Plan& pl = job->plans[i];
         const Prob& p = pl.p;
         int bits = 0;
+        if (p.kind == GAUSS_WIN_LD) {
+            // raw LD export: B11 sits unfactored in A[0] (diagonal 1 + lambda), B21 in its buffer
+            if (pl.out_b11)
+                HIPCHK(hipMemcpy2D(pl.out_b11, sizeof(double) * p.M, p.A, sizeof(double) * p.Mld,
+                                   sizeof(double) * p.M, p.M, hipMemcpyDeviceToHost));
+            if (pl.out_b21 && p.U > 0)
+                HIPCHK(hipMemcpy2D(pl.out_b21, sizeof(double) * p.M, p.B21, sizeof(double) * p.Mld,
+                                   sizeof(double) * p.M, p.U, hipMemcpyDeviceToHost));
+            if (pl.out_status) *pl.out_status = 0;
+            continue;
+        }
         if (p.kind == GAUSS_WIN_QCAT) {
             // QCAT never repairs B11 (MakePosDef is commented out, qcat.cpp:206); CountPC only counts
             int num_eig = p.M;
@@ -686,6 +734,7 @@ static WinSpec spec_from_desc(const gauss_window_desc& d)
     w.z1 = d.z1; w.lambda = d.lambda; w.eps = d.min_abs_eig; w.diag = 1.0; w.ld_only = 0;
     w.gene_off = nullptr; w.n_gene = 0;
     w.kind = d.kind; w.n_head = d.n_head_measured; w.n_predm = d.n_pred_measured; w.eig_cutoff = d.eig_cutoff;
+    w.u_codings = d.u_codings;
     return w;
 }
 
@@ -733,7 +782,8 @@ int gauss_job_create(gauss_ctx* ctx, const gauss_window_desc* wins, int n_win, i
     if (!ctx || !wins || n_win < 1 || !out_job) return fail(GAUSS_E_INVALID, "bad arguments to gauss_job_create");
     std::vector<WinSpec> specs;
     for (int i = 0; i < n_win; i++) {
-        if (wins[i].n_unmeasured < 1 && !(wins[i].kind == GAUSS_WIN_QCAT && wins[i].n_pred_measured > 0))
+        if (wins[i].n_unmeasured < 1 && wins[i].kind != GAUSS_WIN_LD &&
+            !(wins[i].kind == GAUSS_WIN_QCAT && wins[i].n_pred_measured > 0))
             return fail(GAUSS_E_INVALID, "window %d has no unmeasured SNPs", i);
         specs.push_back(spec_from_desc(wins[i]));
     }

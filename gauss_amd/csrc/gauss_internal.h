@@ -12,6 +12,7 @@ constexpr int NB = 64;         // fp64 factor / solve block edge
 constexpr int NR = 64;         // right-hand sides per solve panel (63 SNPs + the z1 column)
 constexpr int NRU = 63;
 constexpr int WIN_QCAT = 1;          // gauss_window_desc.kind == GAUSS_WIN_QCAT
+constexpr int WIN_LD = 2;            // gauss_window_desc.kind == GAUSS_WIN_LD
 
 // Pointers stored inside a Prob are loaded from memory, so the compiler could not infer their
 // address space and would emit flat_* accesses.  Everything a Prob points to is device global
@@ -37,6 +38,8 @@ struct Prob {
     int kind;               // 0 imputation (z, info), 1 QCAT (correlation of whitened vectors)
     int n_head, n_predm;    // QCAT: measured rows before / inside the prediction window
     int n_rhs;              // right-hand sides of the solve: U (imputation) or n_predm + U (QCAT)
+    int U_raw;              // rows of raw_u; U = U_raw * (number of codings)
+    int code_blk[3];        // coding of B21 row block b: 0 additive, 1 dominant, 2 recessive (gauss.cpp:1196-1250)
     int gram_i8;            // 1: operands are raw codes and slabs hold int32 (i8 MFMA path); 0: e4m3 codes, f32 slabs
     double lambda, eps, diag;
     long long ld_raw;

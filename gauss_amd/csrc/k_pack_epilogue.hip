@@ -27,8 +27,16 @@ __global__ __launch_bounds__(256) void pack_stats_kernel(const Prob* __restrict_
     const int r = rm.y;
     const uint8_t* src;
     int prow;
-    if (r < pb.M) { src = pb.raw_m + (size_t)r * pb.ld_raw; prow = r; }
-    else { src = pb.raw_u + (size_t)(r - pb.M) * pb.ld_raw; prow = pb.Mp + (r - pb.M); }
+    src = pb.raw_m + (size_t)r * pb.ld_raw; prow = r;
+    int code = 0;
+    if (r >= pb.M) {
+        // row block b of the unmeasured rows re-reads raw row (r - M) % U_raw under coding code_blk[b]
+        const int ur = r - pb.M;
+        const int blk = ur / pb.U_raw;
+        src = pb.raw_u + (size_t)(ur - blk * pb.U_raw) * pb.ld_raw;
+        prow = pb.Mp + ur;
+        code = pb.code_blk[blk];
+    }
     uint4* dst = reinterpret_cast<uint4*>(pb.packed + (size_t)prow * pb.Kp);
 
     __shared__ int s_sx[64];
@@ -58,7 +66,15 @@ __global__ __launch_bounds__(256) void pack_stats_kernel(const Prob* __restrict_
         int sx = 0, sxx = 0;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const uint32_t x = v[q] & 0x0F0F0F0Fu;   // '0'..'9' and 0..15 both decode as byte & 0x0F
+            uint32_t x = v[q] & 0x0F0F0F0Fu;         // '0'..'9' and 0..15 both decode as byte & 0x0F
+            if (code) {
+                // ConvertGenotypesToDominant / ToRecessive (gauss.cpp:1196-1250): only codes 0..2 are mapped
+                const uint32_t ge4 = ((x >> 2) | (x >> 3)) & 0x01010101u;
+                const uint32_t is3 = x & (x >> 1) & 0x01010101u & ~ge4;
+                const uint32_t keep = (ge4 | is3) * 0xFFu;
+                const uint32_t rec = (code == 1) ? ((x | (x >> 1)) & 0x01010101u) : ((x >> 1) & 0x01010101u);
+                x = (x & keep) | (rec & ~keep);
+            }
             sx = __builtin_amdgcn_udot4(x, 0x01010101u, sx, false);
             sxx = __builtin_amdgcn_udot4(x, x, sxx, false);
             // operand encoding for the Gram kernel: the code as an OCP e4m3 byte (exact for 0..15)

@@ -109,7 +109,7 @@ class _Win:
     """Keeps the numpy buffers of one window alive next to its C descriptor."""
 
     def __init__(self, desc, mode, geno_m, geno_u, pop_off, pop_wgt, z1, lam, min_abs_eig,
-                 want_mats, dev_ptrs=None, qcat=None):
+                 want_mats, dev_ptrs=None, qcat=None, ld_codings=None):
         self.po, self.w = _pops(pop_off, pop_wgt)
         self.z1 = np.ascontiguousarray(z1, dtype=np.float64)
         if dev_ptrs is None:
@@ -122,6 +122,11 @@ class _Win:
         else:
             pm, pu, M, U, ld = dev_ptrs
         self.M, self.U = M, U
+        self.ld_codings = ld_codings
+        if ld_codings is not None:
+            ncode = max(1, bin(int(ld_codings)).count("1"))
+            want_mats = True
+            self.b21_ld = np.zeros((ncode * U, M))
         self.z = np.zeros(U)
         self.info = np.zeros(U)
         self.status = np.zeros(1, dtype=np.int32)
@@ -140,6 +145,12 @@ class _Win:
         desc.out_status = self.status.ctypes.data_as(_ip)
         desc.out_b11 = _lib.ptr(self.b11, _dp)
         desc.out_b21 = _lib.ptr(self.b21, _dp)
+        if ld_codings is not None:
+            desc.kind = _lib.WIN_LD
+            desc.u_codings = int(ld_codings)
+            desc.out_b21 = _lib.ptr(self.b21_ld, _dp)
+            desc.out_z = desc.out_info = None
+            desc.z1 = None
         self.qcat = qcat
         if qcat is not None:
             n_head, n_pred, eig_cutoff = qcat
@@ -153,6 +164,8 @@ class _Win:
             desc.out_z = desc.out_info = None
 
     def result(self):
+        if self.ld_codings is not None:
+            return dict(b11=self.b11, b21=self.b21_ld, status=int(self.status[0]))
         if self.qcat is not None:
             out = dict(r=self.r, num_eig=int(self.num_eig[0]), status=int(self.status[0]))
             if self.b11 is not None:
@@ -187,6 +200,18 @@ def qcat_window(mode, geno_m, geno_u, pop_off, pop_wgt, z1, n_head, n_pred, lam=
     return win.result()
 
 
+def ld_window(mode, geno_m, geno_u, pop_off, pop_wgt, lam=0.0, codings=_lib.CODE_ADDITIVE, ctx=None):
+    """Raw LD export (prep_qcat.cpp:104-132, prep_qcatmix.cpp:136-221): B11 among the measured rows
+    (diagonal 1 + lam) and B21 of the geno_u rows against them, one block of rows per coding in
+    `codings` (additive, dominant, recessive)."""
+    ctx = ctx or default_context()
+    desc = WindowDesc()
+    M = len(geno_m)
+    win = _Win(desc, mode, geno_m, geno_u, pop_off, pop_wgt, np.zeros(M), lam, 1e-5, True, ld_codings=codings)
+    check(ctx.lib.gauss_impute_window(ctx.handle, C.byref(desc)))
+    return win.result()
+
+
 class Job:
     """A batch of windows sharing every launch (gauss_job_*)."""
 
@@ -200,7 +225,7 @@ class Job:
         for i, w in enumerate(windows):
             self.wins.append(_Win(self.descs[i], w["mode"], w.get("geno_m"), w.get("geno_u"),
                                   w["pop_off"], w.get("pop_wgt"), w["z1"], w.get("lam", 0.1),
-                                  w.get("min_abs_eig", 1e-5), want_mats, w.get("dev"), w.get("qcat")))
+                                  w.get("min_abs_eig", 1e-5), want_mats, w.get("dev"), w.get("qcat"), w.get("ld_codings")))
         h = C.c_void_p()
         check(self.ctx.lib.gauss_job_create(self.ctx.handle, self.descs, n, 1 if on_device else 0,
                                             C.byref(h)))

@@ -82,16 +82,29 @@ typedef struct gauss_window_desc {
      * kind = GAUSS_WIN_QCAT tests, for the n_pred_measured measured SNPs of the prediction window
      * (rows n_head_measured .. of geno_m) and then the U unmeasured ones, the Pearson correlation
      * between L^-1 Z1 and L^-1 b (b = their row of B11 / B21; L = Cholesky factor of B11). */
-    int kind;                 /* GAUSS_WIN_IMPUTE (0, default) or GAUSS_WIN_QCAT                    */
+    int kind;                 /* GAUSS_WIN_IMPUTE (0, default), GAUSS_WIN_QCAT or GAUSS_WIN_LD        */
     int n_head_measured;      /* measured SNPs with bp < start_bp (qcat.cpp:146-147)               */
     int n_pred_measured;      /* measured SNPs inside the prediction window (qcat.cpp:148-149)     */
     double eig_cutoff;        /* CountPC cutoff: Arguments::eig_cutoff = 0.01 (gauss.cpp:22)       */
     double* out_r;            /* [n_pred_measured + U] correlations, measured first   host pointer */
     int32_t* out_num_eig;     /* [1] CountPC(B11, eig_cutoff)                          host pointer */
+    /* ---- raw LD export (prep_qcat prep_qcat.cpp:104-132, prep_recessive_impute prep_qcatmix.cpp:136-221) ----
+     * kind = GAUSS_WIN_LD stops after the LD step: out_b11 = B11 (diagonal 1 + lambda; pass lambda = 0 for
+     * the reference's 1.0) and out_b21 = the LD of the geno_u rows against the measured rows; no z1 needed.
+     * u_codings (any kind, 0 = additive only) makes the device derive several codings of every geno_u row
+     * (gauss.cpp:1196-1250): B21 then holds one block of n_unmeasured rows per selected coding, in the
+     * order additive, dominant (0/1/2 -> 0/1/1), recessive (0/1/2 -> 0/0/1); out_b21 is
+     * [n_codings * U x M].  Codes outside 0..2 are left unchanged, as in the reference. */
+    int u_codings;            /* bit mask of GAUSS_CODE_*                                          */
 } gauss_window_desc;
 
 #define GAUSS_WIN_IMPUTE 0
 #define GAUSS_WIN_QCAT   1
+#define GAUSS_WIN_LD     2
+
+#define GAUSS_CODE_ADDITIVE  1
+#define GAUSS_CODE_DOMINANT  2
+#define GAUSS_CODE_RECESSIVE 4
 
 /* ---- context ------------------------------------------------------------------------------- */
 int gauss_hip_init(int device, gauss_ctx** out_ctx);

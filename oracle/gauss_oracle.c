@@ -476,6 +476,46 @@ ORC_API int orc_run_impute(int mode, const char* geno_m, int M, const char* geno
 }
 
 /* ------------------------------------------------------------------------- */
+/* n2. raw LD export   src/prep_qcat.cpp:104-132 (mode 0, CalCor)              */
+/*                     src/prep_qcatmix.cpp:136-158, 187-197 (mode 1)          */
+/*   b11: M x M, diagonal `diag`; b21: U x M row-major, x = geno_u row (first  */
+/*   argument of CalCor / CalWgtCov), y = measured row.  Recoded (dominant /    */
+/*   recessive) rows are passed in already recoded (gauss.cpp:1196-1250).       */
+/* ------------------------------------------------------------------------- */
+ORC_API int orc_ld_blocks(int mode, const char* geno_m, int M, const char* geno_u, int U, long ld,
+                          const int* pop_off, int P, const double* pop_wgt, double diag,
+                          double* b11, double* b21)
+{
+    double* sd = (double*)calloc((size_t)(M + U) ? (size_t)(M + U) : 1, sizeof(double));
+    if (mode == 1) {
+        for (int i = 0; i < M; i++)
+            sd[i] = sqrt(orc_calwgtcov(geno_m + (size_t)i * ld, geno_m + (size_t)i * ld, pop_off, P, pop_wgt));
+        for (int i = 0; i < U; i++)
+            sd[M + i] = sqrt(orc_calwgtcov(geno_u + (size_t)i * ld, geno_u + (size_t)i * ld, pop_off, P, pop_wgt));
+    }
+    if (b11)
+        for (int i = 0; i < M; i++) {
+            b11[(size_t)i * M + i] = diag;
+            for (int j = i + 1; j < M; j++) {
+                double v;
+                if (mode == 0) v = orc_calcor(geno_m + (size_t)i * ld, geno_m + (size_t)j * ld, pop_off, P);
+                else v = orc_calwgtcov(geno_m + (size_t)i * ld, geno_m + (size_t)j * ld, pop_off, P, pop_wgt) / (sd[i] * sd[j]);
+                b11[(size_t)i * M + j] = v;
+                b11[(size_t)j * M + i] = v;
+            }
+        }
+    for (int i = 0; i < U; i++)
+        for (int j = 0; j < M; j++) {
+            double v;
+            if (mode == 0) v = orc_calcor(geno_u + (size_t)i * ld, geno_m + (size_t)j * ld, pop_off, P);
+            else v = orc_calwgtcov(geno_u + (size_t)i * ld, geno_m + (size_t)j * ld, pop_off, P, pop_wgt) / (sd[M + i] * sd[j]);
+            b21[(size_t)i * M + j] = v;
+        }
+    free(sd);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
 /* n1. run_qcat / run_qcatmix core          src/qcat.cpp:166-245 (mode 0)      */
 /*                                          src/qcatmix.cpp:179-277 (mode 1)   */
 /*   B11 (+lambda on the diagonal) and B21 as in DIST / DISTMIX; then          */

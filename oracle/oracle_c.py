@@ -152,6 +152,40 @@ def run_qcat(mode, geno_m, geno_u, pop_off, pop_wgt, z1, n_head, n_pred, lam=0.1
     return out
 
 
+def recode(geno, coding):
+    """ConvertGenotypesToDominant (coding 1) / ToRecessive (coding 2), gauss.cpp:1196-1250: only the
+    codes 0..2 are mapped, in the input's own alphabet (ASCII digits or small integers)."""
+    g = np.array(geno, dtype=np.uint8)
+    base = np.where(g >= 48, 48, 0).astype(np.uint8)
+    v = g - base
+    ok = v <= 2
+    new = (v >= 1) if coding == 1 else (v == 2)
+    return np.where(ok, new.astype(np.uint8) + base, g).astype(np.uint8) if coding else g
+
+
+def ld_blocks(mode, geno_m, geno_u, pop_off, pop_wgt, diag=1.0, codings=(0,)):
+    """B11 (diagonal `diag`) and the stacked B21 blocks, one per coding (0 additive, 1 dominant,
+    2 recessive) of the geno_u rows: prep_qcat.cpp:104-132, prep_qcatmix.cpp:136-221."""
+    lib = load()
+    gm = _geno(geno_m)
+    M, N = gm.shape
+    po = _off(pop_off)
+    P = len(po) - 1
+    w = np.ascontiguousarray(pop_wgt if pop_wgt is not None else np.ones(P), dtype=np.float64)
+    b11 = np.zeros((M, M))
+    blocks = []
+    for k, c in enumerate(codings):
+        gu = _geno(recode(geno_u, c)) if len(geno_u) else np.zeros((0, N), dtype=gm.dtype)
+        U = gu.shape[0]
+        b21 = np.zeros((max(U, 1), M))
+        lib.orc_ld_blocks(C.c_int(mode), gm.ctypes.data_as(C.c_char_p), C.c_int(M),
+                          gu.ctypes.data_as(C.c_char_p), C.c_int(U), C.c_long(N),
+                          _cp(po, _ip), C.c_int(P), _cp(w, _dp), C.c_double(diag),
+                          _cp(b11, _dp) if k == 0 else None, _cp(b21, _dp))
+        blocks.append(b21[:U])
+    return dict(b11=b11, b21=np.vstack(blocks))
+
+
 def count_pc(a, eig_cutoff=0.01):
     lib = load()
     a = np.array(a, dtype=np.float64, order="F")

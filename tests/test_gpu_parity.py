@@ -261,3 +261,38 @@ def test_qcat_and_impute_windows_share_a_job(ctx):
     assert relerr(res[0]["info"], a["info"]) <= Z_TOL
     assert np.max(np.abs(res[1]["r"] - b["r"])) <= R_TOL and res[1]["num_eig"] == b["num_eig"]
     assert np.max(np.abs(res[2]["r"] - c["r"])) <= R_TOL and res[2]["num_eig"] == c["num_eig"]
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("codings", [(0,), (0, 1, 2), (2,)])
+def test_ld_export_with_recoded_rows_matches_oracle(ctx, mode, codings):
+    """Raw LD export for prep_qcat (prep_qcat.cpp:104-132) and prep_recessive_impute
+    (prep_qcatmix.cpp:136-221): B11 with unit diagonal, B21 per coding of the prediction-window SNPs."""
+    p = small_panel(n_snp=330, scale=0.02, seed=51)
+    gm, gu = p["G"][:140], p["G"][100:300]                       # overlapping sets, as in prep_qcat (pred_all includes measured)
+    mask = sum(1 << c for c in codings)
+    got = hotpath.ld_window(mode, gm, gu, p["off"], p["w"], lam=0.0, codings=mask, ctx=ctx)
+    want = oracle.ld_blocks(mode, gm, gu, p["off"], p["w"], diag=1.0, codings=codings)
+    assert got["b21"].shape == want["b21"].shape == (len(codings) * 200, 140)
+    assert np.all(np.diag(got["b11"]) == 1.0)
+    assert np.max(np.abs(got["b11"] - want["b11"])) <= LD_TOL
+    # a rare SNP without homozygotes recodes to an all-zero recessive row: 0/0 = NaN in the reference too
+    nan = np.isnan(want["b21"])
+    assert np.array_equal(np.isnan(got["b21"]), nan)
+    assert np.max(np.abs(got["b21"][~nan] - want["b21"][~nan])) <= LD_TOL
+    assert np.mean(got["b21"][~nan] == want["b21"][~nan]) > 0.999
+
+
+def test_ld_export_recoding_leaves_codes_above_two_alone(ctx):
+    # gauss.cpp:1209-1215: characters outside '0'..'2' are copied through unchanged
+    p = small_panel(n_snp=60, scale=0.01, n_pops=4, seed=52)
+    gm = p["G"][:30]
+    gu = p["G"][30:50].copy()
+    rng = np.random.default_rng(3)
+    gu[rng.random(gu.shape) < 0.05] = 3
+    gu[rng.random(gu.shape) < 0.02] = 7
+    got = hotpath.ld_window(0, gm, gu, p["off"], None, codings=6, ctx=ctx)
+    want = oracle.ld_blocks(0, gm, gu, p["off"], None, codings=(1, 2))
+    nan = np.isnan(want["b21"])
+    assert np.array_equal(np.isnan(got["b21"]), nan) and not nan.all()
+    assert np.max(np.abs(got["b21"][~nan] - want["b21"][~nan])) <= LD_TOL

@@ -184,3 +184,24 @@ def test_gram_counts_match_numpy():
     p = small_panel(n_snp=25, scale=0.01, n_pops=4)
     G = p["G"].astype(np.int64)
     assert np.array_equal(oracle.gram_counts(p["G"]), G @ G.T)
+
+
+def test_recode_and_ld_blocks_against_numpy():
+    # dominant / recessive recoding (gauss.cpp:1196-1250) then CalCor against additive measured rows
+    p = small_panel(n_snp=70, scale=0.02, n_pops=5, seed=8)
+    gm, gu = p["G"][:30], p["G"][25:60]
+    dom, rec = oracle.recode(gu, 1), oracle.recode(gu, 2)
+    assert np.array_equal(dom, (gu >= 1).astype(np.uint8)) and np.array_equal(rec, (gu == 2).astype(np.uint8))
+    asc = gu + np.uint8(48)
+    assert np.array_equal(oracle.recode(asc, 1), dom + 48) and np.array_equal(oracle.recode(asc, 2), rec + 48)
+    got = oracle.ld_blocks(0, gm, gu, p["off"], None, codings=(0, 1, 2))
+    with np.errstate(invalid="ignore", divide="ignore"):
+        want = np.vstack([onp.pooled_cor(x, gm) for x in (gu, dom, rec)])
+    ok = np.isfinite(want)
+    assert np.array_equal(ok, np.isfinite(got["b21"]))
+    assert np.max(np.abs(got["b21"][ok] - want[ok])) <= 1e-12
+    gw = oracle.ld_blocks(1, gm, gu, p["off"], p["w"], codings=(1,))
+    with np.errstate(invalid="ignore", divide="ignore"):
+        ww = onp.weighted_cor(dom, gm, p["off"], p["w"])
+    ok = np.isfinite(ww)
+    assert np.max(np.abs(gw["b21"][ok] - ww[ok])) <= 1e-12
