@@ -24,13 +24,16 @@ from . import _lib, hotpath
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HOST_LIB_PATH = os.path.join(_HERE, "lib", "libgauss_host.so")
 
-KIND_COMPUTELD, KIND_DIST, KIND_DISTMIX, KIND_JEPEG, KIND_JEPEGMIX, KIND_QCAT, KIND_QCATMIX = range(7)
+KIND_COMPUTELD, KIND_DIST, KIND_DISTMIX, KIND_JEPEG, KIND_JEPEGMIX, KIND_QCAT, KIND_QCATMIX, \
+    KIND_PREP_QCAT, KIND_PREP_RECESSIVE = range(9)
 
 HOST_SYMBOLS = [
     "gauss_host_last_error", "gauss_table_nrow", "gauss_table_ncol", "gauss_table_colname",
     "gauss_table_coltype", "gauss_table_str", "gauss_table_int", "gauss_table_dbl", "gauss_table_matrix",
     "gauss_table_free", "gauss_host_computeLD", "gauss_host_dist", "gauss_host_distmix", "gauss_host_jepeg",
-    "gauss_host_jepegmix", "gauss_host_qcat", "gauss_host_qcatmix", "gauss_prepared_qcat_counts", "gauss_host_prepare", "gauss_prepared_snps", "gauss_prepared_counts",
+    "gauss_host_jepegmix", "gauss_host_qcat", "gauss_host_qcatmix", "gauss_prepared_qcat_counts",
+    "gauss_host_prep_qcat", "gauss_host_prep_recessive_impute", "gauss_table_n_named", "gauss_table_named_name",
+    "gauss_table_named", "gauss_host_prepare", "gauss_prepared_snps", "gauss_prepared_counts",
     "gauss_prepared_measured_rows", "gauss_prepared_unmeasured_rows", "gauss_prepared_geno_m",
     "gauss_prepared_geno_u", "gauss_prepared_pop_off", "gauss_prepared_pop_wgt", "gauss_prepared_z1",
     "gauss_prepared_gene_off", "gauss_prepared_window_desc", "gauss_prepared_finish", "gauss_prepared_free",
@@ -81,6 +84,13 @@ def load_host():
     h.gauss_host_distmix.argtypes = [_vp, C.c_int, _i64, _i64, _i64, _strs, _dp, C.c_int] + files4 + [_dbl, C.POINTER(_vp)]
     h.gauss_host_jepeg.argtypes = [_vp, _cp, _cp] + files4 + [_dbl, C.POINTER(_vp)]
     h.gauss_host_jepegmix.argtypes = [_vp, _strs, _dp, C.c_int, _cp] + files4 + [_dbl, C.POINTER(_vp)]
+    h.gauss_host_prep_qcat.argtypes = h.gauss_host_dist.argtypes
+    h.gauss_host_prep_recessive_impute.argtypes = h.gauss_host_distmix.argtypes
+    h.gauss_table_n_named.argtypes = [_vp]
+    h.gauss_table_named_name.restype = _cp
+    h.gauss_table_named_name.argtypes = [_vp, C.c_int]
+    h.gauss_table_named.restype = _dp
+    h.gauss_table_named.argtypes = [_vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     h.gauss_host_qcat.argtypes = h.gauss_host_dist.argtypes
     h.gauss_host_qcatmix.argtypes = h.gauss_host_distmix.argtypes
     h.gauss_prepared_qcat_counts.argtypes = [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -226,6 +236,46 @@ def qcatmix(chr, start_bp, end_bp, wing_size, pop_wgt_df, input_file, reference_
                                  w.ctypes.data_as(_dp), n, _enc(input_file), _enc(reference_index_file),
                                  _enc(reference_data_file), _enc(reference_pop_desc_file), _af(af1_cutoff), C.byref(out)))
     return _table(h, out)[0]
+
+
+def _named(h, t):
+    """Named numeric members of a result List (column-major in C, returned as (nrow, ncol) arrays)."""
+    out = {}
+    for k in range(h.gauss_table_n_named(t)):
+        nr, nc = C.c_int(), C.c_int()
+        p = h.gauss_table_named(t, k, C.byref(nr), C.byref(nc))
+        name = h.gauss_table_named_name(t, k).decode()
+        n = nr.value * nc.value
+        a = np.ctypeslib.as_array(p, shape=(n,)).copy() if n else np.zeros(0)
+        out[name] = a if nc.value == 1 else a.reshape(nc.value, nr.value).T
+    return out
+
+
+def prep_qcat(chr, start_bp, end_bp, wing_size, study_pop, input_file, reference_index_file, reference_data_file,
+              reference_pop_desc_file, af1_cutoff=None, ctx=None):
+    """prep_qcat() of the reference (prep_qcat.cpp:16-205): list(snplist, z_vec, cor_mat1, cor_mat2)."""
+    h = load_host()
+    out = _vp()
+    _hcheck(h.gauss_host_prep_qcat(_ctx(ctx), int(chr), int(start_bp), int(end_bp), int(wing_size), _enc(study_pop),
+                                   _enc(input_file), _enc(reference_index_file), _enc(reference_data_file),
+                                   _enc(reference_pop_desc_file), _af(af1_cutoff), C.byref(out)))
+    named = _named(h, out)
+    return dict(snplist=_table(h, out)[0], **named)
+
+
+def prep_recessive_impute(chr, start_bp, end_bp, wing_size, pop_wgt_df, input_file, reference_index_file,
+                          reference_data_file, reference_pop_desc_file, af1_cutoff=None, ctx=None):
+    """prep_recessive_impute() of the reference (prep_qcatmix.cpp:36-316): list(snplist, zvec, cormat,
+    cormat_add, cormat_dom, cormat_rec)."""
+    h = load_host()
+    names, w, n = _pop_wgt(pop_wgt_df)
+    out = _vp()
+    _hcheck(h.gauss_host_prep_recessive_impute(_ctx(ctx), int(chr), int(start_bp), int(end_bp), int(wing_size), names,
+                                               w.ctypes.data_as(_dp), n, _enc(input_file), _enc(reference_index_file),
+                                               _enc(reference_data_file), _enc(reference_pop_desc_file),
+                                               _af(af1_cutoff), C.byref(out)))
+    named = _named(h, out)
+    return dict(snplist=_table(h, out)[0], **named)
 
 
 def jepeg(study_pop, input_file, annotation_file, reference_index_file, reference_data_file, reference_pop_desc_file,

@@ -60,10 +60,17 @@ struct Column {
     std::vector<double> d;
 };
 
+struct NamedMat {
+    std::string name;
+    int nrow = 0, ncol = 0;
+    std::vector<double> d;        // column-major (R NumericMatrix layout)
+};
+
 struct gauss_table {
     std::vector<Column> cols;
     std::vector<double> matrix;
     int matrix_n = 0;
+    std::vector<NamedMat> named;
     int nrow() const
     {
         if (cols.empty()) return 0;
@@ -89,6 +96,7 @@ struct Snp {
     long long fpos = -1;
     std::string geneid = ".";
     std::map<int, double> categ;   // Snp::categ_map_
+    bool flip_geno = false;        // UpdateSnpToMinorAllele (gauss.cpp:1137-1184): genotype d -> 2 - d
     std::string line;              // cached panel data line (read once instead of twice)
     bool have_line = false;
     std::vector<std::pair<const char*, int>> geno;   // selected populations' genotype strings (into `line`)
@@ -416,7 +424,7 @@ struct gauss_prepared {
     std::vector<int32_t> pop_off;
     std::vector<double> pop_wgt, z1;
     std::vector<int32_t> gene_off;
-    std::vector<double> out_z, out_info, out_r;
+    std::vector<double> out_z, out_info, out_r, out_b11, out_b21;
     int n_head = 0, n_predm = 0;               // QCAT: measured SNPs left of / inside the prediction window
     int32_t num_eig = 0;
     int32_t status = 0;
@@ -429,7 +437,11 @@ static void fill_matrix(std::vector<uint8_t>& G, const std::vector<Snp*>& rows, 
     G.assign((size_t)std::max<size_t>(rows.size(), 1) * ld, (uint8_t)'0');
     for (size_t r = 0; r < rows.size(); r++) {
         uint8_t* dst = G.data() + r * ld;
+        uint8_t* const row0 = dst;
         for (auto& g : rows[r]->geno) { memcpy(dst, g.first, (size_t)g.second); dst += g.second; }
+        if (rows[r]->flip_geno)                                  // gauss.cpp:1165-1176: only '0'..'2' are flipped
+            for (uint8_t* c = row0; c < dst; c++)
+                if (*c >= '0' && *c <= '2') *c = (uint8_t)('0' + (2 - (*c - '0')));
     }
 }
 
@@ -438,7 +450,7 @@ static void build_snp_table(gauss_prepared& p)
     gauss_table& t = p.snps;
     t.cols.clear();
     const bool mix = (p.kind == GAUSS_KIND_COMPUTELD || p.kind == GAUSS_KIND_DISTMIX || p.kind == GAUSS_KIND_JEPEGMIX ||
-                      p.kind == GAUSS_KIND_QCATMIX);
+                      p.kind == GAUSS_KIND_QCATMIX || p.kind == GAUSS_KIND_PREP_RECESSIVE);
     Column& rsid = t.add("rsid", GAUSS_COL_STR);
     for (Snp* s : p.snp_vec) rsid.s.push_back(s->rsid);
     Column& chr = t.add("chr", GAUSS_COL_INT);
@@ -469,9 +481,10 @@ static int prepare(gauss_prepared& p)
     Args& a = p.args;
     const int kind = p.kind;
     const bool mix = (kind == GAUSS_KIND_COMPUTELD || kind == GAUSS_KIND_DISTMIX || kind == GAUSS_KIND_JEPEGMIX ||
-                      kind == GAUSS_KIND_QCATMIX);
+                      kind == GAUSS_KIND_QCATMIX || kind == GAUSS_KIND_PREP_RECESSIVE);
     const bool gene = (kind == GAUSS_KIND_JEPEG || kind == GAUSS_KIND_JEPEGMIX);
     const bool qcat = (kind == GAUSS_KIND_QCAT || kind == GAUSS_KIND_QCATMIX);
+    const bool prep = (kind == GAUSS_KIND_PREP_QCAT || kind == GAUSS_KIND_PREP_RECESSIVE);
     if (read_ref_desc(a)) return -1;
     if (mix) init_pop_flag_wgt_vec(a);
     else if (init_pop_flag_vec(a)) return -1;
@@ -490,7 +503,23 @@ static int prepare(gauss_prepared& p)
     if (mix) p.pop_wgt = a.pop_wgt_vec;
     else p.pop_wgt.assign(p.pop_off.size() - 1, 1.0);
 
-    if (kind == GAUSS_KIND_DIST || kind == GAUSS_KIND_DISTMIX || qcat) {
+    if (kind == GAUSS_KIND_PREP_RECESSIVE) {
+        for (Snp* s : p.snp_vec)                                // UpdateSnpToMinorAllele, gauss.cpp:1137-1184
+            if (s->af1mix > 0.5) {
+                s->af1mix = 1 - s->af1mix;
+                s->z = -s->z;
+                std::swap(s->a1, s->a2);
+                s->flip_geno = true;
+            }
+    }
+    if (prep) {
+        for (size_t r = 0; r < p.snp_vec.size(); r++) {        // prep_qcat.cpp:69-78, prep_qcatmix.cpp:104-117
+            Snp* s = p.snp_vec[r];
+            // "unmeasured" here = every panel SNP of the prediction window, measured ones included
+            if (s->type != 2 && (s->bp >= a.start_bp && s->bp <= a.end_bp)) { p.unmeasured.push_back(s); p.unmeasured_rows.push_back((int32_t)r); }
+            if (s->type == 1) { p.measured.push_back(s); p.measured_rows.push_back((int32_t)r); }
+        }
+    } else if (kind == GAUSS_KIND_DIST || kind == GAUSS_KIND_DISTMIX || qcat) {
         for (size_t r = 0; r < p.snp_vec.size(); r++) {        // dist.cpp:132-140, qcat.cpp:140-152
             Snp* s = p.snp_vec[r];
             if (s->type == 0 && (s->bp >= a.start_bp && s->bp <= a.end_bp)) { p.unmeasured.push_back(s); p.unmeasured_rows.push_back((int32_t)r); }
@@ -772,6 +801,46 @@ static gauss_table* qcat_output(gauss_prepared& p)     // qcat.cpp:94-131 / qcat
     return t;
 }
 
+static void add_named(gauss_table* t, const char* name, int nrow, int ncol, const double* row_major)
+{
+    NamedMat m;
+    m.name = name; m.nrow = nrow; m.ncol = ncol;
+    m.d.resize((size_t)nrow * ncol);
+    for (int r = 0; r < nrow; r++)
+        for (int c = 0; c < ncol; c++) m.d[(size_t)c * nrow + r] = row_major[(size_t)r * ncol + c];
+    t->named.push_back(std::move(m));
+}
+
+static gauss_table* prep_output(gauss_prepared& p)     // prep_qcat.cpp:135-204 / prep_qcatmix.cpp:262-315
+{
+    const bool rec = p.kind == GAUSS_KIND_PREP_RECESSIVE;
+    const int M = (int)p.measured.size(), U = (int)p.unmeasured.size();
+    gauss_table* t = new gauss_table();
+    Column rsid{"rsid", GAUSS_COL_STR, {}, {}, {}}, chr{"chr", GAUSS_COL_INT, {}, {}, {}}, bp{"bp", GAUSS_COL_INT, {}, {}, {}};
+    Column a1{"a1", GAUSS_COL_STR, {}, {}, {}}, a2{"a2", GAUSS_COL_STR, {}, {}, {}};
+    Column af{rec ? "af1mix" : "af1ref", GAUSS_COL_DBL, {}, {}, {}}, z{"z", GAUSS_COL_DBL, {}, {}, {}};
+    Column type{"type", GAUSS_COL_INT, {}, {}, {}};
+    // prep_qcat lists the whole extended window (prep_qcat.cpp:146-155), prep_recessive_impute only the
+    // prediction window (prep_qcatmix.cpp:267-276)
+    const std::vector<Snp*>& rows = rec ? p.unmeasured : p.snp_vec;
+    for (Snp* s : rows) {
+        rsid.s.push_back(s->rsid); chr.i.push_back(s->chr); bp.i.push_back((int)s->bp);
+        a1.s.push_back(s->a1); a2.s.push_back(s->a2);
+        af.d.push_back(rec ? s->af1mix : s->af1ref);
+        z.d.push_back(s->z); type.i.push_back(s->type);
+    }
+    t->cols = {rsid, chr, bp, a1, a2, af, z, type};
+    add_named(t, rec ? "zvec" : "z_vec", M, 1, p.z1.data());
+    add_named(t, rec ? "cormat" : "cor_mat1", M, M, p.out_b11.data());
+    if (!rec) add_named(t, "cor_mat2", U, M, p.out_b21.data());
+    else {
+        add_named(t, "cormat_add", U, M, p.out_b21.data());
+        add_named(t, "cormat_dom", U, M, p.out_b21.data() + (size_t)U * M);
+        add_named(t, "cormat_rec", U, M, p.out_b21.data() + (size_t)2 * U * M);
+    }
+    return t;
+}
+
 // ------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------
@@ -792,6 +861,15 @@ const int32_t* gauss_table_int(const gauss_table* t, int c) { return (t && c >= 
 const double* gauss_table_dbl(const gauss_table* t, int c) { return (t && c >= 0 && c < (int)t->cols.size() && t->cols[c].type == GAUSS_COL_DBL) ? t->cols[c].d.data() : nullptr; }
 const double* gauss_table_matrix(const gauss_table* t, int* n) { if (!t || t->matrix.empty()) { if (n) *n = 0; return nullptr; } if (n) *n = t->matrix_n; return t->matrix.data(); }
 void gauss_table_free(gauss_table* t) { delete t; }
+int gauss_table_n_named(const gauss_table* t) { return t ? (int)t->named.size() : 0; }
+const char* gauss_table_named_name(const gauss_table* t, int k) { return (t && k >= 0 && k < (int)t->named.size()) ? t->named[k].name.c_str() : nullptr; }
+const double* gauss_table_named(const gauss_table* t, int k, int* nrow, int* ncol)
+{
+    if (!t || k < 0 || k >= (int)t->named.size()) return nullptr;
+    if (nrow) *nrow = t->named[k].nrow;
+    if (ncol) *ncol = t->named[k].ncol;
+    return t->named[k].d.data();
+}
 
 // Re-block a BGZF text file line by line (exercises reader + writer; used by tests and by tools that
 // rewrite panels).  Returns the number of lines copied, or -1.
@@ -824,7 +902,7 @@ int gauss_host_prepare(int kind, int chr, int64_t start_bp, int64_t end_bp, int6
                        const char* reference_pop_desc_file, double af1_cutoff, gauss_prepared** out)
 {
     if (!out) return herr("out is NULL");
-    if (kind < 0 || kind > GAUSS_KIND_QCATMIX) return herr("bad kind %d", kind);
+    if (kind < 0 || kind > GAUSS_KIND_PREP_RECESSIVE) return herr("bad kind %d", kind);
     if (!input_file || !reference_index_file || !reference_data_file || !reference_pop_desc_file) return herr("file name is NULL");
     std::unique_ptr<gauss_prepared> p(new gauss_prepared());
     p->kind = kind;
@@ -837,7 +915,7 @@ int gauss_host_prepare(int kind, int chr, int64_t start_bp, int64_t end_bp, int6
     if (annotation_file) a.annotation_file = annotation_file;
     a.af1_cutoff = std::isnan(af1_cutoff) ? (kind == GAUSS_KIND_QCAT ? 0.05 : 0.01) : af1_cutoff;   // dist.cpp:53-57, qcat.cpp:53-57
     const bool mix = (kind == GAUSS_KIND_COMPUTELD || kind == GAUSS_KIND_DISTMIX || kind == GAUSS_KIND_JEPEGMIX ||
-                      kind == GAUSS_KIND_QCATMIX);
+                      kind == GAUSS_KIND_QCATMIX || kind == GAUSS_KIND_PREP_RECESSIVE);
     if (mix) {
         if (!pop_names || !pop_wgts || n_pop_wgt < 1) return herr("pop_wgt_df is empty");
         set_pop_wgt_map(a, pop_names, pop_wgts, n_pop_wgt);
@@ -881,9 +959,29 @@ int gauss_prepared_window_desc(gauss_prepared* p, gauss_window_desc* d)
 {
     if (!p || !d) return herr("bad arguments");
     const bool qcat = (p->kind == GAUSS_KIND_QCAT || p->kind == GAUSS_KIND_QCATMIX);
-    if (p->kind != GAUSS_KIND_DIST && p->kind != GAUSS_KIND_DISTMIX && !qcat) return herr("not an imputation or QCAT window");
+    const bool prep = (p->kind == GAUSS_KIND_PREP_QCAT || p->kind == GAUSS_KIND_PREP_RECESSIVE);
+    if (p->kind != GAUSS_KIND_DIST && p->kind != GAUSS_KIND_DISTMIX && !qcat && !prep) return herr("not a window kind");
     const Args& a = p->args;
     const int M = (int)p->measured.size(), U = (int)p->unmeasured.size();
+    if (prep) {
+        if (M <= a.min_num_measured_snp)                       // prep_qcat.cpp:86-91, prep_qcatmix.cpp:126-128
+            return herr("Not enough number of SNPs loaded - %s not performed (measured %d, prediction window %d)",
+                        p->kind == GAUSS_KIND_PREP_QCAT ? "QCAT" : "Recessive Imputation", M, U);
+        const int ncode = (p->kind == GAUSS_KIND_PREP_RECESSIVE) ? 3 : 1;
+        p->out_b11.assign((size_t)M * M, 0.0);
+        p->out_b21.assign((size_t)std::max(1, ncode * U) * M, 0.0);
+        memset(d, 0, sizeof(*d));
+        d->kind = GAUSS_WIN_LD;
+        d->mode = (p->kind == GAUSS_KIND_PREP_QCAT) ? GAUSS_MODE_POOLED : GAUSS_MODE_WEIGHTED;
+        d->n_pop = (int)p->pop_off.size() - 1;
+        d->pop_off = p->pop_off.data(); d->pop_wgt = p->pop_wgt.data();
+        d->n_measured = M; d->n_unmeasured = U;
+        d->geno_m = p->gm.data(); d->geno_u = p->gu.data(); d->ld = p->ld;
+        d->lambda = 0.0;                                       // B11(i,i) = 1.0 (prep_qcat.cpp:109)
+        d->u_codings = (ncode == 3) ? (GAUSS_CODE_ADDITIVE | GAUSS_CODE_DOMINANT | GAUSS_CODE_RECESSIVE) : GAUSS_CODE_ADDITIVE;
+        d->out_b11 = p->out_b11.data(); d->out_b21 = p->out_b21.data(); d->out_status = &p->status;
+        return 0;
+    }
     if (qcat) {
         // qcat.cpp:157-162 guards on the measured count only; qcatmix.cpp:168-174 on both (texts as in the reference)
         if (p->kind == GAUSS_KIND_QCAT && M <= a.min_num_measured_snp)
@@ -923,6 +1021,7 @@ int gauss_prepared_window_desc(gauss_prepared* p, gauss_window_desc* d)
 int gauss_prepared_finish(gauss_prepared* p, gauss_table** out)
 {
     if (!p || !out) return herr("bad arguments");
+    if (p->kind == GAUSS_KIND_PREP_QCAT || p->kind == GAUSS_KIND_PREP_RECESSIVE) { *out = prep_output(*p); return 0; }
     if (p->kind == GAUSS_KIND_QCAT || p->kind == GAUSS_KIND_QCATMIX) {
         const int m = p->num_eig;
         for (size_t t = 0; t < p->out_r.size(); t++) {                           // qcat.cpp:216-243
@@ -989,6 +1088,24 @@ int gauss_host_qcatmix(gauss_ctx* ctx, int chr, int64_t start_bp, int64_t end_bp
 {
     return run_impute(ctx, GAUSS_KIND_QCATMIX, chr, start_bp, end_bp, wing_size, nullptr, pop_names, pop_wgts, n_pop_wgt,
                       input_file, reference_index_file, reference_data_file, reference_pop_desc_file, af1_cutoff, out);
+}
+
+int gauss_host_prep_qcat(gauss_ctx* ctx, int chr, int64_t start_bp, int64_t end_bp, int64_t wing_size, const char* study_pop,
+                         const char* input_file, const char* reference_index_file, const char* reference_data_file,
+                         const char* reference_pop_desc_file, double af1_cutoff, gauss_table** out)
+{
+    return run_impute(ctx, GAUSS_KIND_PREP_QCAT, chr, start_bp, end_bp, wing_size, study_pop, nullptr, nullptr, 0, input_file,
+                      reference_index_file, reference_data_file, reference_pop_desc_file, af1_cutoff, out);
+}
+
+int gauss_host_prep_recessive_impute(gauss_ctx* ctx, int chr, int64_t start_bp, int64_t end_bp, int64_t wing_size,
+                                     const char* const* pop_names, const double* pop_wgts, int n_pop_wgt,
+                                     const char* input_file, const char* reference_index_file,
+                                     const char* reference_data_file, const char* reference_pop_desc_file,
+                                     double af1_cutoff, gauss_table** out)
+{
+    return run_impute(ctx, GAUSS_KIND_PREP_RECESSIVE, chr, start_bp, end_bp, wing_size, nullptr, pop_names, pop_wgts,
+                      n_pop_wgt, input_file, reference_index_file, reference_data_file, reference_pop_desc_file, af1_cutoff, out);
 }
 
 int gauss_host_computeLD(gauss_ctx* ctx, int chr, int64_t start_bp, int64_t end_bp, const char* const* pop_names,

@@ -13,6 +13,9 @@
  *   jepegmix(pop_wgt_df,input_file,annotation_file,...)     gauss_host_jepegmix  jepegmix.cpp:26-161
  *   qcat(chr,start_bp,end_bp,wing_size,study_pop,...)       gauss_host_qcat      qcat.cpp:30-132
  *   qcatmix(chr,start_bp,end_bp,wing_size,pop_wgt_df,...)   gauss_host_qcatmix   qcatmix.cpp:30-140
+ *   prep_qcat(chr,start_bp,end_bp,wing_size,study_pop,...)  gauss_host_prep_qcat prep_qcat.cpp:16-205
+ *   prep_recessive_impute(chr,...,pop_wgt_df,...)           gauss_host_prep_recessive_impute
+ *                                                           prep_qcatmix.cpp:36-316
  *
  * Same argument meaning, same defaults (af1_cutoff NaN = R's NULL -> 0.01, dist.cpp:53-57), same
  * row order (std::map order on (chr,bp,a1,a2), gauss.h:72-99), same column names and types as
@@ -50,6 +53,8 @@ typedef struct gauss_prepared gauss_prepared; /* one window/gene set after the h
 #define GAUSS_KIND_JEPEGMIX  4
 #define GAUSS_KIND_QCAT      5
 #define GAUSS_KIND_QCATMIX   6
+#define GAUSS_KIND_PREP_QCAT 7
+#define GAUSS_KIND_PREP_RECESSIVE 8
 
 const char* gauss_host_last_error(void);
 
@@ -61,6 +66,12 @@ int gauss_table_coltype(const gauss_table* t, int col);
 const char* gauss_table_str(const gauss_table* t, int col, int row);
 const int32_t* gauss_table_int(const gauss_table* t, int col);
 const double* gauss_table_dbl(const gauss_table* t, int col);
+/* Named numeric members of a result List (prep_qcat's z_vec / cor_mat1 / cor_mat2, prep_recessive_impute's
+ * zvec / cormat / cormat_add / cormat_dom / cormat_rec): nrow x ncol, COLUMN-major like an R NumericMatrix
+ * (vectors have ncol = 1). */
+int gauss_table_n_named(const gauss_table* t);
+const char* gauss_table_named_name(const gauss_table* t, int k);
+const double* gauss_table_named(const gauss_table* t, int k, int* nrow, int* ncol);
 /* computeLD's `cormat` (n x n, symmetric); NULL for the other tables */
 const double* gauss_table_matrix(const gauss_table* t, int* n);
 void gauss_table_free(gauss_table* t);
@@ -102,6 +113,24 @@ int gauss_host_qcatmix(gauss_ctx* ctx, int chr, int64_t start_bp, int64_t end_bp
                        const char* input_file, const char* reference_index_file,
                        const char* reference_data_file, const char* reference_pop_desc_file,
                        double af1_cutoff, gauss_table** out);
+
+/* Raw LD export.  prep_qcat (prep_qcat.cpp:16-205): snplist = every SNP of the
+ * extended window after the AF filter (rsid chr bp a1 a2 af1ref z type); z_vec [M]; cor_mat1 [M x M] pooled
+ * LD among the measured SNPs, unit diagonal; cor_mat2 [A x M] LD of ALL prediction-window SNPs (measured and
+ * unmeasured) against them.  prep_recessive_impute (prep_qcatmix.cpp:36-316): SNPs are first re-oriented to
+ * the minor allele (UpdateSnpToMinorAllele, gauss.cpp:1137-1184); snplist = the prediction-window SNPs
+ * (rsid chr bp a1 a2 af1mix z type); zvec [M]; cormat [M x M] weighted LD; cormat_add / cormat_dom /
+ * cormat_rec [A x M] with the prediction-window SNPs additive / dominant / recessive coded
+ * (gauss.cpp:1196-1250, recoded on the device). */
+int gauss_host_prep_qcat(gauss_ctx* ctx, int chr, int64_t start_bp, int64_t end_bp, int64_t wing_size,
+                         const char* study_pop, const char* input_file, const char* reference_index_file,
+                         const char* reference_data_file, const char* reference_pop_desc_file,
+                         double af1_cutoff, gauss_table** out);
+int gauss_host_prep_recessive_impute(gauss_ctx* ctx, int chr, int64_t start_bp, int64_t end_bp, int64_t wing_size,
+                                     const char* const* pop_names, const double* pop_wgts, int n_pop_wgt,
+                                     const char* input_file, const char* reference_index_file,
+                                     const char* reference_data_file, const char* reference_pop_desc_file,
+                                     double af1_cutoff, gauss_table** out);
 
 /* Re-block a BGZF text file line by line (reader + writer round trip); returns lines copied or -1. */
 int64_t gauss_host_bgzf_copy(const char* in_path, const char* out_path);

