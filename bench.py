@@ -255,7 +255,7 @@ def main():
     return out
 
 
-def pmc_traffic(kernel="gauss::gram_kernel"):
+def pmc_traffic(kernel="gauss::gram_kernel<float>"):
     """HBM-side bytes per launch of the Gram kernel from the committed rocprofv3 PMC passes
     (profiles/*_pmc_traffic.csv: separate FETCH_SIZE / WRITE_SIZE runs of this same command,
     gfx950 correction applied).  PMC counters cannot be collected from inside the timed run."""
@@ -264,7 +264,7 @@ def pmc_traffic(kernel="gauss::gram_kernel"):
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.csv"))):
         for r in csv.DictReader(open(f)):
-            if r["kernel"] == kernel:
+            if r["kernel"] == kernel or r["kernel"] == kernel.split("<")[0]:
                 best = float(r["hbm_bytes_per_launch_corrected"])
     return best
 
