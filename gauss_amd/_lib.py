@@ -19,6 +19,7 @@ ST_NONFINITE = 2
 WIN_IMPUTE = 0
 WIN_QCAT = 1
 WIN_LD = 2
+GENO_U8, GENO_2BIT = 0, 1
 CODE_ADDITIVE, CODE_DOMINANT, CODE_RECESSIVE = 1, 2, 4
 GRAM_F32 = 0
 GRAM_I8 = 1
@@ -37,6 +38,7 @@ class WindowDesc(C.Structure):
         ("out_z", _dp), ("out_info", _dp), ("out_status", _ip), ("out_b11", _dp), ("out_b21", _dp),
         ("kind", C.c_int), ("n_head_measured", C.c_int), ("n_pred_measured", C.c_int), ("eig_cutoff", C.c_double),
         ("out_r", _dp), ("out_num_eig", _ip), ("u_codings", C.c_int),
+        ("geno_format", C.c_int), ("rows_m", _ip), ("rows_u", _ip), ("pop_src_off", _ip),
     ]
 
 
@@ -48,7 +50,7 @@ _lib = None
 
 # every symbol include/gauss_hip.h declares
 SYMBOLS = [
-    "gauss_hip_init", "gauss_hip_destroy", "gauss_last_error", "gauss_hip_version", "gauss_hip_set_gram_dtype", "gauss_ld",
+    "gauss_hip_init", "gauss_hip_destroy", "gauss_last_error", "gauss_hip_version", "gauss_hip_set_gram_dtype", "gauss_store_upload", "gauss_store_free", "gauss_ld",
     "gauss_impute_window", "gauss_gene_ld_batch", "gauss_gram_counts", "gauss_job_create",
     "gauss_job_run", "gauss_job_fetch", "gauss_job_destroy", "gauss_job_profile",
     "gauss_job_profile_get", "gauss_job_work", "gauss_job_stats", "gauss_synth_device",
@@ -74,6 +76,8 @@ def load():
     lib.gauss_hip_destroy.argtypes = [C.c_void_p]
     lib.gauss_hip_destroy.restype = None
     lib.gauss_hip_set_gram_dtype.argtypes = [C.c_void_p, C.c_int]
+    lib.gauss_store_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]
+    lib.gauss_store_free.argtypes = [C.c_void_p, C.c_void_p]
     lib.gauss_ld.argtypes = [C.c_void_p, C.c_int, _u8p, C.c_int, C.c_int64, _ip, _dp, C.c_int,
                              C.c_double, _dp]
     lib.gauss_impute_window.argtypes = [C.c_void_p, C.POINTER(WindowDesc)]

@@ -12,6 +12,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <deque>
 #include <string>
 #include <vector>
 
@@ -57,7 +58,10 @@ struct Plan {
     std::vector<int> pop_raw_off, pop_pk_off, seg_pop, seg_k0, seg_k1, pop_seg0;
     std::vector<int> pair_ti, pair_tj, pair_lut;
     std::vector<double> pop_w, pop_wf, pop_md, z1;
-    std::vector<uint8_t> word_pop;
+    std::vector<uint8_t> word_pop, word_run;
+    std::vector<int> run_pk_off, run_src;
+    std::vector<int32_t> rows_m, rows_u;     // store rows; empty = contiguous
+    size_t row_bytes = 0;                    // bytes of a source row that the kernels read
     std::vector<int> gene_off;
     std::vector<long long> gene_out_off;
     std::vector<std::pair<int, int>> groups;   // runs of consecutive segments handled by one work item
@@ -126,6 +130,10 @@ struct WinSpec {
     int n_gene;
     int kind = 0, n_head = 0, n_predm = 0;   // QCAT windows (qcat.cpp:134-262)
     int u_codings = 0;                       // GAUSS_CODE_* mask for the geno_u rows (0 = additive)
+    int geno_fmt = 0;                        // GAUSS_GENO_*
+    const int32_t* rows_m = nullptr;         // store rows (host arrays) or NULL = contiguous matrices
+    const int32_t* rows_u = nullptr;
+    const int32_t* pop_src_off = nullptr;    // 2-bit: byte offset of each population block in a row
     double eig_cutoff = 0.01;
 };
 
@@ -152,7 +160,19 @@ static int plan_problem(const WinSpec& w, Plan& pl, int seg_max, int group_targe
     if (w.pop_off[0] != 0) return fail(GAUSS_E_INVALID, "pop_off[0] must be 0");
     const int N = w.pop_off[w.n_pop];
     if (N < 1) return fail(GAUSS_E_INVALID, "no samples");
-    if (w.ld < N) return fail(GAUSS_E_INVALID, "ld (%lld) < n_samples (%d)", w.ld, N);
+    if (w.geno_fmt != GAUSS_GENO_U8 && w.geno_fmt != GAUSS_GENO_2BIT) return fail(GAUSS_E_INVALID, "bad geno_format %d", w.geno_fmt);
+    if (w.geno_fmt == GAUSS_GENO_U8 && w.ld < N) return fail(GAUSS_E_INVALID, "ld (%lld) < n_samples (%d)", w.ld, N);
+    if (w.geno_fmt == GAUSS_GENO_2BIT) {
+        if (w.ld % 16) return fail(GAUSS_E_INVALID, "2-bit rows need a stride that is a multiple of 16 bytes (got %lld)", w.ld);
+        long long end = 0;
+        for (int q = 0; q < w.n_pop; q++) {
+            const long long blk = (long long)rup((size_t)(w.pop_off[q + 1] - w.pop_off[q]), 64) / 4;
+            const long long off = w.pop_src_off ? w.pop_src_off[q] : end;
+            if (off < 0 || off % 16) return fail(GAUSS_E_INVALID, "pop_src_off[%d] = %lld is not a multiple of 16", q, off);
+            if (off + blk > w.ld) return fail(GAUSS_E_INVALID, "population block %d ends past the row stride", q);
+            if (!w.pop_src_off) end = off + blk;
+        }
+    }
     if (w.kind != GAUSS_WIN_IMPUTE && w.kind != GAUSS_WIN_QCAT && w.kind != GAUSS_WIN_LD)
         return fail(GAUSS_E_INVALID, "bad window kind %d", w.kind);
     if (!w.ld_only && w.kind != GAUSS_WIN_LD && (w.U > 0 || w.kind == GAUSS_WIN_QCAT) && !w.z1) return fail(GAUSS_E_INVALID, "z1 is NULL");
@@ -201,6 +221,29 @@ static int plan_problem(const WinSpec& w, Plan& pl, int seg_max, int group_targe
         const int m = pl.pop_raw_off[q + 1] - pl.pop_raw_off[q];
         pl.pop_pk_off[q + 1] = pl.pop_pk_off[q] + (int)rup((size_t)m, KC);
     }
+    p.geno_fmt = w.geno_fmt;
+    pl.row_bytes = (size_t)N;
+    if (w.geno_fmt == GAUSS_GENO_2BIT) {
+        // every selected population is one source block ("run") padded to 64 samples, in the source row and in
+        // the packed operand row alike; pooled statistics still see one pseudo-population spanning all runs
+        pl.run_pk_off.assign(w.n_pop + 1, 0);
+        long long end = 0;
+        pl.row_bytes = 0;
+        for (int q = 0; q < w.n_pop; q++) {
+            const int blk = (int)rup((size_t)(w.pop_off[q + 1] - w.pop_off[q]), 64);
+            pl.run_pk_off[q + 1] = pl.run_pk_off[q] + blk;
+            const long long off = w.pop_src_off ? w.pop_src_off[q] : end;
+            pl.run_src.push_back((int)off);
+            if (!w.pop_src_off) end = off + blk / 4;
+            pl.row_bytes = std::max(pl.row_bytes, (size_t)(off + blk / 4));
+        }
+        if (P == 1) pl.pop_pk_off[1] = pl.run_pk_off[w.n_pop];
+        pl.word_run.assign(pl.run_pk_off[w.n_pop] / 16, 0);
+        for (int q = 0; q < w.n_pop; q++)
+            for (int b = pl.run_pk_off[q] / 16; b < pl.run_pk_off[q + 1] / 16; b++) pl.word_run[b] = (uint8_t)q;
+    }
+    if (w.rows_m) pl.rows_m.assign(w.rows_m, w.rows_m + w.M);
+    if (w.rows_u && w.U > 0) pl.rows_u.assign(w.rows_u, w.rows_u + w.U);
     p.Kp = pl.pop_pk_off[P];
     pl.word_pop.assign(p.Kp / 16, 0);
     pl.pop_seg0.assign(P + 1, 0);
@@ -309,7 +352,7 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
     // ---- table arena (host mirrored) ----
     Arena ta;
     std::vector<char>& blob = job->h_tab;
-    struct TabOff { size_t raw_off, pk_off, w, wf, md, seg_pop, k0, k1, seg0, ti, tj, lut, wp, z1, goff, gout; };
+    struct TabOff { size_t raw_off, pk_off, w, wf, md, seg_pop, k0, k1, seg0, ti, tj, lut, wp, z1, goff, gout, wr, rpk, rsrc, rm, ru; };
     std::vector<TabOff> to(job->n);
     for (int i = 0; i < job->n; i++) {
         Plan& pl = job->plans[i];
@@ -329,6 +372,11 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
         to[i].z1 = put(blob, ta, pl.z1);
         to[i].goff = put(blob, ta, pl.gene_off);
         to[i].gout = put(blob, ta, pl.gene_out_off);
+        to[i].wr = put(blob, ta, pl.word_run);
+        to[i].rpk = put(blob, ta, pl.run_pk_off);
+        to[i].rsrc = put(blob, ta, pl.run_src);
+        to[i].rm = put(blob, ta, pl.rows_m);
+        to[i].ru = put(blob, ta, pl.rows_u);
     }
     // work lists
     struct ItemH { int prob, pair, group, len; };
@@ -392,7 +440,7 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
         Prob& p = pl.p;
         WsOff& w = wo[i];
         if (!on_device) {
-            w.ldraw = (long long)rup((size_t)p.N, 16);
+            w.ldraw = (long long)rup(pl.row_bytes, 16);
             w.raw_m = wa.take((size_t)p.M * w.ldraw);
             w.raw_u = wa.take((size_t)std::max(pl.U_user, 1) * w.ldraw);
         } else {
@@ -438,6 +486,7 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
 
     job->d_status = (int*)(job->d_ws + o_status);
     job->d_results = (double*)(job->d_ws + o_results);
+    std::deque<std::vector<uint8_t>> stage;      // host gather buffers, alive until the copies have drained
     for (int i = 0; i < job->n; i++) {
         Plan& pl = job->plans[i];
         Prob& p = pl.p;
@@ -462,6 +511,12 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
         p.pair_tj = (const int*)(T + to[i].tj);
         p.pair_lut = (const int*)(T + to[i].lut);
         p.word_pop = (const uint8_t*)(T + to[i].wp);
+        p.word_run = (const uint8_t*)(T + to[i].wr);
+        // row lists are resolved on the device only for a resident store; host rows are gathered while staging
+        p.rows_m = (on_device && !pl.rows_m.empty()) ? (const int*)(T + to[i].rm) : nullptr;
+        p.rows_u = (on_device && !pl.rows_u.empty()) ? (const int*)(T + to[i].ru) : nullptr;
+        p.run_pk_off = (const int*)(T + to[i].rpk);
+        p.run_src = (const int*)(T + to[i].rsrc);
         p.slab = (float*)(W + w.slab);
         p.rt_sd = (double*)(W + w.sd); p.rt_wm = (double*)(W + w.wm);
         p.rt_mu = (double*)(W + w.mu); p.rt_wmu = (double*)(W + w.wmu);
@@ -479,11 +534,23 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
         p.gene_out_off = p.n_gene ? (long long*)(T + to[i].gout) : nullptr;
         memcpy(blob.data() + o_probs + sizeof(Prob) * i, &p, sizeof(Prob));
         if (!on_device) {
-            HIPCHK(hipMemcpy2DAsync(W + w.raw_m, (size_t)w.ldraw, pl.h_geno_m, (size_t)pl.user_ld,
-                                    (size_t)p.N, (size_t)p.M, hipMemcpyHostToDevice, st));
-            if (pl.U_user > 0)
-                HIPCHK(hipMemcpy2DAsync(W + w.raw_u, (size_t)w.ldraw, pl.h_geno_u, (size_t)pl.user_ld,
-                                        (size_t)p.N, (size_t)pl.U_user, hipMemcpyHostToDevice, st));
+            auto upload = [&](size_t dst_off, const uint8_t* src, const std::vector<int32_t>& rows, int nrows) -> int {
+                if (nrows <= 0) return GAUSS_OK;
+                if (rows.empty()) {
+                    HIPCHK(hipMemcpy2DAsync(W + dst_off, (size_t)w.ldraw, src, (size_t)pl.user_ld, pl.row_bytes,
+                                            (size_t)nrows, hipMemcpyHostToDevice, st));
+                    return GAUSS_OK;
+                }
+                stage.emplace_back((size_t)nrows * w.ldraw);               // gather the listed store rows
+                std::vector<uint8_t>& buf = stage.back();
+                for (int r = 0; r < nrows; r++)
+                    memcpy(buf.data() + (size_t)r * w.ldraw, src + (size_t)rows[r] * pl.user_ld, pl.row_bytes);
+                HIPCHK(hipMemcpyAsync(W + dst_off, buf.data(), buf.size(), hipMemcpyHostToDevice, st));
+                return GAUSS_OK;
+            };
+            int rc = upload(w.raw_m, pl.h_geno_m, pl.rows_m, p.M);
+            if (!rc) rc = upload(w.raw_u, pl.h_geno_u, pl.rows_u, pl.U_user);
+            if (rc) return rc;
         }
     }
     // device work items: every pointer is resolved here so the kernel starts loading operands at once
@@ -735,6 +802,7 @@ static WinSpec spec_from_desc(const gauss_window_desc& d)
     w.gene_off = nullptr; w.n_gene = 0;
     w.kind = d.kind; w.n_head = d.n_head_measured; w.n_predm = d.n_pred_measured; w.eig_cutoff = d.eig_cutoff;
     w.u_codings = d.u_codings;
+    w.geno_fmt = d.geno_format; w.rows_m = d.rows_m; w.rows_u = d.rows_u; w.pop_src_off = d.pop_src_off;
     return w;
 }
 
@@ -768,6 +836,27 @@ void gauss_hip_destroy(gauss_ctx* ctx)
     hipSetDevice(ctx->device);
     hipStreamDestroy(ctx->stream);
     delete ctx;
+}
+
+int gauss_store_upload(gauss_ctx* ctx, const void* host_rows, int64_t bytes, void** out_device_ptr)
+{
+    if (!ctx || !host_rows || bytes <= 0 || !out_device_ptr) return fail(GAUSS_E_INVALID, "bad arguments to gauss_store_upload");
+    HIPCHK(hipSetDevice(ctx->device));
+    void* d = nullptr;
+    hipError_t e = hipMalloc(&d, (size_t)bytes + 64);      // slack: a row's last dword load may end on the last byte
+    if (e != hipSuccess) return fail(GAUSS_E_NOMEM, "hipMalloc(%lld bytes row store) failed: %s", (long long)bytes, hipGetErrorString(e));
+    e = hipMemcpy(d, host_rows, (size_t)bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { hipFree(d); return fail(GAUSS_E_DEVICE, "row store upload failed: %s", hipGetErrorString(e)); }
+    *out_device_ptr = d;
+    return GAUSS_OK;
+}
+
+int gauss_store_free(gauss_ctx* ctx, void* device_ptr)
+{
+    if (!ctx) return fail(GAUSS_E_INVALID, "ctx is NULL");
+    HIPCHK(hipSetDevice(ctx->device));
+    if (device_ptr) HIPCHK(hipFree(device_ptr));
+    return GAUSS_OK;
 }
 
 int gauss_hip_set_gram_dtype(gauss_ctx* ctx, int dtype)

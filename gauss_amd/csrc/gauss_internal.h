@@ -40,6 +40,7 @@ struct Prob {
     int n_rhs;              // right-hand sides of the solve: U (imputation) or n_predm + U (QCAT)
     int U_raw;              // rows of raw_u; U = U_raw * (number of codings)
     int code_blk[3];        // coding of B21 row block b: 0 additive, 1 dominant, 2 recessive (gauss.cpp:1196-1250)
+    int geno_fmt;           // 0: one byte per genotype (ASCII digit or small integer); 1: 2-bit packed blocks
     int gram_i8;            // 1: operands are raw codes and slabs hold int32 (i8 MFMA path); 0: e4m3 codes, f32 slabs
     double lambda, eps, diag;
     long long ld_raw;
@@ -61,6 +62,11 @@ struct Prob {
     GP(const int) pair_tj;
     GP(const int) pair_lut;    // [nT x nT] -> pair index or -1
     GP(const uint8_t) word_pop;// [Kp/16] population of each packed 16-byte word
+    GP(const int) rows_m;      // store row of each measured / unmeasured matrix row, or null (contiguous)
+    GP(const int) rows_u;
+    GP(const uint8_t) word_run;// 2-bit sources: [Kp/16] source block ("run") of each packed word
+    GP(const int) run_pk_off;  // [n_run+1] packed column range of each run
+    GP(const int) run_src;     // [n_run] byte offset of each run inside a source row
     GP(float) slab;            // [npair*nseg][TILE*TILE] exact integer partial Grams
     GP(double) rt_sd;          // [Sp] weighted: sqrt(self cov); pooled: sqrt(n*Sxx - Sx^2)
     GP(double) rt_wm;          // [Sp] weighted: sum_p w_p mu_p ; pooled: Sx (as double)

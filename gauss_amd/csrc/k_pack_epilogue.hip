@@ -27,13 +27,17 @@ __global__ __launch_bounds__(256) void pack_stats_kernel(const Prob* __restrict_
     const int r = rm.y;
     const uint8_t* src;
     int prow;
-    src = pb.raw_m + (size_t)r * pb.ld_raw; prow = r;
     int code = 0;
-    if (r >= pb.M) {
+    if (r < pb.M) {
+        const long long srow = pb.rows_m ? pb.rows_m[r] : r;            // row lists gather from a resident store
+        src = pb.raw_m + (size_t)srow * pb.ld_raw; prow = r;
+    } else {
         // row block b of the unmeasured rows re-reads raw row (r - M) % U_raw under coding code_blk[b]
         const int ur = r - pb.M;
         const int blk = ur / pb.U_raw;
-        src = pb.raw_u + (size_t)(ur - blk * pb.U_raw) * pb.ld_raw;
+        const int rr = ur - blk * pb.U_raw;
+        const long long srow = pb.rows_u ? pb.rows_u[rr] : rr;
+        src = pb.raw_u + (size_t)srow * pb.ld_raw;
         prow = pb.Mp + ur;
         code = pb.code_blk[blk];
     }
@@ -57,7 +61,18 @@ __global__ __launch_bounds__(256) void pack_stats_kernel(const Prob* __restrict_
         if (!live) valid = 0;
         uint32_t v[4] = {0u, 0u, 0u, 0u};
         const uint8_t* s = src + pb.pop_raw_off[p] + o;
-        if (valid == 16) {
+        if (pb.geno_fmt) {
+            // 2-bit packed source: 16 samples = 4 bytes; blocks are 16-byte aligned and zero padded to 64
+            // samples, i.e. they have exactly the packed operand layout at a quarter of the bytes
+            const int run = pb.word_run[w];
+            const int ro = (w << 4) - pb.run_pk_off[run];
+            const uint32_t bits = live ? *reinterpret_cast<const uint32_t*>(src + pb.run_src[run] + (ro >> 2)) : 0u;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t b = (bits >> (8 * q)) & 0xFFu;
+                v[q] = (b & 3u) | (((b >> 2) & 3u) << 8) | (((b >> 4) & 3u) << 16) | (((b >> 6) & 3u) << 24);
+            }
+        } else if (valid == 16) {
 #pragma unroll
             for (int q = 0; q < 4; q++) v[q] = reinterpret_cast<const U32u*>(s + 4 * q)->v;
         } else {

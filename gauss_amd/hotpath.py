@@ -109,7 +109,7 @@ class _Win:
     """Keeps the numpy buffers of one window alive next to its C descriptor."""
 
     def __init__(self, desc, mode, geno_m, geno_u, pop_off, pop_wgt, z1, lam, min_abs_eig,
-                 want_mats, dev_ptrs=None, qcat=None, ld_codings=None):
+                 want_mats, dev_ptrs=None, qcat=None, ld_codings=None, packed=None):
         self.po, self.w = _pops(pop_off, pop_wgt)
         self.z1 = np.ascontiguousarray(z1, dtype=np.float64)
         if dev_ptrs is None:
@@ -121,6 +121,9 @@ class _Win:
                 raise ValueError("geno_m and geno_u must share a row stride")
         else:
             pm, pu, M, U, ld = dev_ptrs
+        if packed is not None and packed.get("rows_m") is not None:
+            M = len(packed["rows_m"])                       # matrices are row lists into a store
+            U = len(packed["rows_u"]) if packed.get("rows_u") is not None else 0
         self.M, self.U = M, U
         self.ld_codings = ld_codings
         if ld_codings is not None:
@@ -145,6 +148,17 @@ class _Win:
         desc.out_status = self.status.ctypes.data_as(_ip)
         desc.out_b11 = _lib.ptr(self.b11, _dp)
         desc.out_b21 = _lib.ptr(self.b21, _dp)
+        if packed is not None:
+            # packed=dict(fmt=GENO_*, rows_m=, rows_u=, pop_src_off=): rows taken from a row store (dev_ptrs or
+            # geno_m/geno_u give its base pointer and stride), optionally 2-bit packed (include/gauss_hip.h)
+            desc.geno_format = int(packed.get("fmt", _lib.GENO_U8))
+            self._rows = []
+            for key in ("rows_m", "rows_u", "pop_src_off"):
+                a = packed.get(key)
+                if a is not None:
+                    a = np.ascontiguousarray(a, dtype=np.int32)
+                    self._rows.append(a)
+                    setattr(desc, key, a.ctypes.data_as(_ip))
         if ld_codings is not None:
             desc.kind = _lib.WIN_LD
             desc.u_codings = int(ld_codings)
@@ -212,6 +226,30 @@ def ld_window(mode, geno_m, geno_u, pop_off, pop_wgt, lam=0.0, codings=_lib.CODE
     return win.result()
 
 
+class RowStore:
+    """Genotype rows resident in HBM (gauss_store_upload): a whole packed chromosome is uploaded once and
+    windows name their rows by index."""
+
+    def __init__(self, rows, ctx=None):
+        self.ctx = ctx or default_context()
+        rows = np.ascontiguousarray(rows, dtype=np.uint8)
+        self.n_rows, self.ld = rows.shape
+        p = C.c_void_p()
+        check(self.ctx.lib.gauss_store_upload(self.ctx.handle, rows.ctypes.data_as(C.c_void_p), rows.nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    def close(self):
+        if self.ptr:
+            self.ctx.lib.gauss_store_free(self.ctx.handle, C.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Job:
     """A batch of windows sharing every launch (gauss_job_*)."""
 
@@ -225,7 +263,7 @@ class Job:
         for i, w in enumerate(windows):
             self.wins.append(_Win(self.descs[i], w["mode"], w.get("geno_m"), w.get("geno_u"),
                                   w["pop_off"], w.get("pop_wgt"), w["z1"], w.get("lam", 0.1),
-                                  w.get("min_abs_eig", 1e-5), want_mats, w.get("dev"), w.get("qcat"), w.get("ld_codings")))
+                                  w.get("min_abs_eig", 1e-5), want_mats, w.get("dev"), w.get("qcat"), w.get("ld_codings"), w.get("packed")))
         h = C.c_void_p()
         check(self.ctx.lib.gauss_job_create(self.ctx.handle, self.descs, n, 1 if on_device else 0,
                                             C.byref(h)))

@@ -142,3 +142,47 @@ def make_synthetic_study(outdir, pops, n_snp=400, chr_=22, bp_lo=1_000_000, bp_h
                                   float(np.round(rng.uniform(0.2, 2.0), 3))))
         write_annotation(paths["annot.txt"], annot)
     return dict(paths=paths, bp=bp, rsid=rsid, a1=a1, a2=a2, G=G, af=af, pops=pops, measured=meas, annot=annot)
+
+
+# ------------------------------------------------------------------------------------------
+# 2-bit packed genotype rows (include/gauss_hip.h, GAUSS_GENO_2BIT): every population block starts on
+# a 16-byte boundary and is zero padded to a multiple of 64 samples; sample s of a block sits at bits
+# 2*(s % 4) of byte s // 4.
+# ------------------------------------------------------------------------------------------
+def pack2bit_layout(pop_sizes):
+    """Byte offset of every population block and the row stride (a multiple of 16)."""
+    off, o = [], 0
+    for m in pop_sizes:
+        off.append(o)
+        o += ((int(m) + 63) // 64) * 16
+    return np.array(off, dtype=np.int32), max(o, 16)
+
+
+def pack2bit(G, pop_off):
+    """G: (S, N) codes 0..2 (or ASCII digits); pop_off: (P+1,) column ranges.  Returns (rows, src_off):
+    rows (S, ld) uint8 in the 2-bit layout and the byte offset of each population block."""
+    G = np.asarray(G, dtype=np.uint8) & 0x0F
+    pop_off = np.asarray(pop_off)
+    sizes = np.diff(pop_off)
+    src_off, ld = pack2bit_layout(sizes)
+    rows = np.zeros((G.shape[0], ld), dtype=np.uint8)
+    for q, m in enumerate(sizes):
+        blk = np.zeros((G.shape[0], ((int(m) + 63) // 64) * 64), dtype=np.uint8)
+        blk[:, :m] = G[:, pop_off[q]:pop_off[q + 1]]
+        b4 = blk.reshape(G.shape[0], -1, 4)
+        rows[:, src_off[q]:src_off[q] + b4.shape[1]] = b4[:, :, 0] | (b4[:, :, 1] << 2) | (b4[:, :, 2] << 4) | (b4[:, :, 3] << 6)
+    return rows, src_off
+
+
+def unpack2bit(rows, pop_sizes, src_off=None):
+    """Inverse of pack2bit for the listed populations: (S, sum(pop_sizes)) codes."""
+    rows = np.asarray(rows, dtype=np.uint8)
+    if src_off is None:
+        src_off, _ = pack2bit_layout(pop_sizes)
+    out = []
+    for q, m in enumerate(pop_sizes):
+        nb = (int(m) + 3) // 4
+        b = rows[:, src_off[q]:src_off[q] + nb]
+        codes = np.stack([(b >> (2 * k)) & 3 for k in range(4)], axis=2).reshape(rows.shape[0], -1)
+        out.append(codes[:, :m])
+    return np.concatenate(out, axis=1) if out else np.zeros((rows.shape[0], 0), dtype=np.uint8)

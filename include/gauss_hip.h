@@ -96,7 +96,21 @@ typedef struct gauss_window_desc {
      * order additive, dominant (0/1/2 -> 0/1/1), recessive (0/1/2 -> 0/0/1); out_b21 is
      * [n_codings * U x M].  Codes outside 0..2 are left unchanged, as in the reference. */
     int u_codings;            /* bit mask of GAUSS_CODE_*                                          */
+    /* ---- packed panel rows -------------------------------------------------
+     * geno_format = GAUSS_GENO_2BIT: a genotype row is a 2-bit stream (sample s of a population block at bits
+     * 2*(s%4) of byte s/4, codes 0..2), each selected population's block starting on a 16-byte boundary and
+     * zero padded to a multiple of 64 samples.  pop_src_off[q] is the byte offset of selected population q
+     * inside a row (NULL: the blocks follow each other in pop_off order); ld is the row stride in bytes.
+     * rows_m / rows_u (either format): when non-NULL, geno_m / geno_u point at a row store (e.g. a whole
+     * chromosome resident in HBM, see gauss_store_upload) and matrix row r is store row rows_x[r]. */
+    int geno_format;          /* GAUSS_GENO_U8 (0, default) or GAUSS_GENO_2BIT                      */
+    const int32_t* rows_m;    /* [M] store row of each measured SNP, or NULL          host pointer */
+    const int32_t* rows_u;    /* [U] store row of each geno_u SNP, or NULL            host pointer */
+    const int32_t* pop_src_off; /* [P] 2-bit format: byte offset of each population block, or NULL */
 } gauss_window_desc;
+
+#define GAUSS_GENO_U8   0
+#define GAUSS_GENO_2BIT 1
 
 #define GAUSS_WIN_IMPUTE 0
 #define GAUSS_WIN_QCAT   1
@@ -105,6 +119,13 @@ typedef struct gauss_window_desc {
 #define GAUSS_CODE_ADDITIVE  1
 #define GAUSS_CODE_DOMINANT  2
 #define GAUSS_CODE_RECESSIVE 4
+
+/* ---- resident row store ---------------------------------------------------------------------
+ * Copies `bytes` of genotype rows to the context's GPU and returns the device pointer to use as
+ * geno_m / geno_u (with gauss_job_create's on_device = 1 and rows_m / rows_u).  288 GB of HBM hold a
+ * whole 2-bit panel (33 k samples x 10 M SNPs = 82 GB), so a panel is uploaded once, not per window. */
+int gauss_store_upload(gauss_ctx* ctx, const void* host_rows, int64_t bytes, void** out_device_ptr);
+int gauss_store_free(gauss_ctx* ctx, void* device_ptr);
 
 /* ---- context ------------------------------------------------------------------------------- */
 int gauss_hip_init(int device, gauss_ctx** out_ctx);

@@ -296,3 +296,97 @@ def test_ld_export_recoding_leaves_codes_above_two_alone(ctx):
     nan = np.isnan(want["b21"])
     assert np.array_equal(np.isnan(got["b21"]), nan) and not nan.all()
     assert np.max(np.abs(got["b21"][~nan] - want["b21"][~nan])) <= LD_TOL
+
+
+def _same(a, b, keys=("z", "info", "b11", "b21")):
+    return all(np.array_equal(a[k], b[k]) for k in keys)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_packed_2bit_rows_give_bit_identical_results(ctx, mode):
+    """GAUSS_GENO_2BIT sources (packed panel rows) feed the same exact Gram: LD, z and info must equal the
+    one-byte-per-genotype path bit for bit, and hence the oracle."""
+    from gauss_amd import panel
+    p = small_panel(n_snp=300, scale=0.03, seed=61)
+    G, off = p["G"], p["off"]
+    gm, gu = np.ascontiguousarray(G[:110]), np.ascontiguousarray(G[110:260])
+    z1 = np.random.default_rng(7).normal(size=110) * 2.0
+    base = hotpath.impute_window(mode, gm, gu, off, p["w"], z1, want_mats=True, ctx=ctx)
+    rows, src_off = panel.pack2bit(G[:260], off)
+    assert np.array_equal(panel.unpack2bit(rows, np.diff(off)), G[:260])
+    # (a) contiguous packed matrices from host memory
+    job = hotpath.Job([dict(mode=mode, geno_m=rows[:110], geno_u=rows[110:], pop_off=off, pop_wgt=p["w"], z1=z1,
+                            packed=dict(fmt=1))], ctx=ctx, want_mats=True)
+    job.run()
+    a = job.fetch()[0]
+    job.close()
+    assert _same(a, base)
+    # (b) row lists into a host row store (shuffled store order)
+    perm = np.random.default_rng(1).permutation(260)
+    store = np.ascontiguousarray(rows[perm])
+    inv = np.argsort(perm).astype(np.int32)
+    job = hotpath.Job([dict(mode=mode, geno_m=store, geno_u=store, pop_off=off, pop_wgt=p["w"], z1=z1,
+                            packed=dict(fmt=1, rows_m=inv[:110], rows_u=inv[110:]))], ctx=ctx, want_mats=True)
+    job.run()
+    b = job.fetch()[0]
+    job.close()
+    assert _same(b, base)
+    # (c) the same store resident in HBM, rows gathered by the pack kernel
+    rs = hotpath.RowStore(store, ctx=ctx)
+    job = hotpath.Job([dict(mode=mode, pop_off=off, pop_wgt=p["w"], z1=z1, dev=(rs.ptr, rs.ptr, 110, 150, rs.ld),
+                            packed=dict(fmt=1, rows_m=inv[:110], rows_u=inv[110:]))], ctx=ctx, on_device=True,
+                      want_mats=True)
+    job.run()
+    c = job.fetch()[0]
+    job.close()
+    rs.close()
+    assert _same(c, base)
+    want = oracle.run_impute(mode, gm, gu, off, p["w"], z1)
+    assert relerr(c["info"], want["info"]) <= Z_TOL
+
+
+def test_packed_store_with_population_subset(ctx):
+    # the store holds every population of the panel; a window selects some of them through pop_src_off
+    from gauss_amd import panel
+    p = small_panel(n_snp=200, scale=0.03, seed=62, n_pops=7)
+    G, off = p["G"], p["off"]
+    rows, src_off = panel.pack2bit(G, off)
+    sel = [1, 3, 4, 6]
+    cols = np.concatenate([np.arange(off[q], off[q + 1]) for q in sel])
+    Gs = np.ascontiguousarray(G[:, cols])
+    offs = np.concatenate([[0], np.cumsum([off[q + 1] - off[q] for q in sel])]).astype(np.int32)
+    w = p["w"][sel]
+    keep = np.flatnonzero(Gs.min(1) != Gs.max(1))[:160].astype(np.int32)
+    M = 70
+    z1 = np.random.default_rng(2).normal(size=M)
+    rs = hotpath.RowStore(rows, ctx=ctx)
+    for mode in (0, 1):
+        base = hotpath.impute_window(mode, Gs[keep[:M]], Gs[keep[M:]], offs, w, z1, want_mats=True, ctx=ctx)
+        job = hotpath.Job([dict(mode=mode, pop_off=offs, pop_wgt=w, z1=z1, dev=(rs.ptr, rs.ptr, M, len(keep) - M, rs.ld),
+                                packed=dict(fmt=1, rows_m=keep[:M], rows_u=keep[M:], pop_src_off=src_off[sel]))],
+                          ctx=ctx, on_device=True, want_mats=True)
+        job.run()
+        got = job.fetch()[0]
+        job.close()
+        assert _same(got, base)
+    rs.close()
+
+
+def test_u8_row_lists_from_a_resident_store(ctx):
+    p = small_panel(n_snp=150, scale=0.02, seed=63)
+    G, off = p["G"], p["off"]
+    S, N = G.shape
+    store = np.zeros((S, (N + 15) // 16 * 16), dtype=np.uint8)
+    store[:, :N] = G
+    idx = np.random.default_rng(4).permutation(S).astype(np.int32)
+    M = 60
+    z1 = np.random.default_rng(5).normal(size=M)
+    base = hotpath.impute_window(1, G[idx[:M]], G[idx[M:]], off, p["w"], z1, want_mats=True, ctx=ctx)
+    rs = hotpath.RowStore(store, ctx=ctx)
+    job = hotpath.Job([dict(mode=1, pop_off=off, pop_wgt=p["w"], z1=z1, dev=(rs.ptr, rs.ptr, M, S - M, rs.ld),
+                            packed=dict(fmt=0, rows_m=idx[:M], rows_u=idx[M:]))], ctx=ctx, on_device=True, want_mats=True)
+    job.run()
+    got = job.fetch()[0]
+    job.close()
+    rs.close()
+    assert _same(got, base)
