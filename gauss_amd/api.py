@@ -32,7 +32,7 @@ HOST_SYMBOLS = [
     "gauss_table_coltype", "gauss_table_str", "gauss_table_int", "gauss_table_dbl", "gauss_table_matrix",
     "gauss_table_free", "gauss_host_computeLD", "gauss_host_dist", "gauss_host_distmix", "gauss_host_jepeg",
     "gauss_host_jepegmix", "gauss_host_qcat", "gauss_host_qcatmix", "gauss_prepared_qcat_counts",
-    "gauss_host_prep_qcat", "gauss_host_prep_recessive_impute", "gauss_table_n_named", "gauss_table_named_name",
+    "gauss_host_prep_qcat", "gauss_host_prep_recessive_impute", "gauss_host_pack_panel", "gauss_prepared_packed_store", "gauss_table_n_named", "gauss_table_named_name",
     "gauss_table_named", "gauss_host_prepare", "gauss_prepared_snps", "gauss_prepared_counts",
     "gauss_prepared_measured_rows", "gauss_prepared_unmeasured_rows", "gauss_prepared_geno_m",
     "gauss_prepared_geno_u", "gauss_prepared_pop_off", "gauss_prepared_pop_wgt", "gauss_prepared_z1",
@@ -84,6 +84,9 @@ def load_host():
     h.gauss_host_distmix.argtypes = [_vp, C.c_int, _i64, _i64, _i64, _strs, _dp, C.c_int] + files4 + [_dbl, C.POINTER(_vp)]
     h.gauss_host_jepeg.argtypes = [_vp, _cp, _cp] + files4 + [_dbl, C.POINTER(_vp)]
     h.gauss_host_jepegmix.argtypes = [_vp, _strs, _dp, C.c_int, _cp] + files4 + [_dbl, C.POINTER(_vp)]
+    h.gauss_host_pack_panel.restype = _i64
+    h.gauss_host_pack_panel.argtypes = [_cp, _cp, _cp, _cp]
+    h.gauss_prepared_packed_store.argtypes = [_vp, C.POINTER(C.c_void_p), C.POINTER(_i64), C.POINTER(_i64)]
     h.gauss_host_prep_qcat.argtypes = h.gauss_host_dist.argtypes
     h.gauss_host_prep_recessive_impute.argtypes = h.gauss_host_distmix.argtypes
     h.gauss_table_n_named.argtypes = [_vp]
@@ -119,6 +122,16 @@ def load_host():
     h.gauss_host_bgzf_copy.argtypes = [_cp, _cp]
     _host = h
     return h
+
+
+def pack_panel(reference_index_file, reference_data_file, reference_pop_desc_file, out_file):
+    """BGZF text panel -> packed panel (gauss_host_pack_panel); returns the number of SNPs.  The packed file is
+    then passed as reference_data_file to any entry point."""
+    n = load_host().gauss_host_pack_panel(_enc(reference_index_file), _enc(reference_data_file),
+                                          _enc(reference_pop_desc_file), _enc(out_file))
+    if n < 0:
+        raise GaussError(load_host().gauss_host_last_error().decode())
+    return int(n)
 
 
 def set_host_threads(n):
@@ -359,6 +372,12 @@ class Prepared:
 
     def geno_u(self):
         return self._geno(self.h.gauss_prepared_geno_u, self.U)
+
+    def packed_store(self):
+        """(host pointer, bytes, row stride) of the packed panel's genotype section, or None for byte matrices."""
+        base, nb, rb = C.c_void_p(), _i64(), _i64()
+        _hcheck(self.h.gauss_prepared_packed_store(self.handle, C.byref(base), C.byref(nb), C.byref(rb)))
+        return (base.value, nb.value, rb.value) if base.value else None
 
     def window_desc(self):
         d = _lib.WindowDesc()

@@ -68,8 +68,8 @@ def build_host(force=False, verbose=False):
     os.makedirs(OBJDIR, exist_ok=True)
     hip_so = build_hip(force=False, verbose=verbose)
     hdir = os.path.join(CSRC, "host")
-    srcs = [os.path.join(hdir, f) for f in ("gauss_host.cpp", "bgzf_io.cpp")]
-    deps = srcs + [os.path.join(hdir, "bgzf_io.h"), os.path.join(HERE, "..", "include", "gauss_host.h"),
+    srcs = [os.path.join(hdir, f) for f in ("gauss_host.cpp", "bgzf_io.cpp", "packed_panel.cpp")]
+    deps = srcs + [os.path.join(hdir, "bgzf_io.h"), os.path.join(hdir, "packed_panel.h"), os.path.join(HERE, "..", "include", "gauss_host.h"),
                    os.path.join(HERE, "..", "include", "gauss_hip.h"), hip_so]
     so = os.path.join(LIBDIR, "libgauss_host.so")
     if force or _newer(so, deps):

@@ -32,8 +32,11 @@
 #include <vector>
 
 #include "bgzf_io.h"
+#include "packed_panel.h"
 
 using gauss_host::BgzfReader;
+using gauss_host::PackedPanel;
+using gauss_host::PkSnp;
 
 // ------------------------------------------------------------------------------------------
 static thread_local std::string g_err;
@@ -131,6 +134,7 @@ struct Args {                       // Arguments, gauss.h:18-69 with the default
     int num_pops = 0, num_samples = 0;
     double af1_cutoff = 0.01;
     int min_num_measured_snp = 10, min_num_unmeasured_snp = 10;
+    std::shared_ptr<PackedPanel> pk;   // set when reference_data_file is a packed panel (packed_panel.h)
     int total_num_categ = 6;
     double categ_cor_cutoff = 0.8;
     int denorm_norm_w = 3;
@@ -237,9 +241,55 @@ static int ReadInputZ(SnpMap& m, const Args& a, bool All)
     return 0;
 }
 
+// One index entry merged into the SNP map: the body of the loops of ReadReferenceIndex (gauss.cpp:340-390)
+// and ReadReferenceIndexAll (gauss.cpp:478-512).
+static int merge_index_entry(SnpMap& m, const Args& a, bool All, const std::string& rsid, int chr, long long bp,
+                             const std::string& a1, const std::string& a2, long long fpos)
+{
+    if (!All) {
+        if ((a.chr > 0) && (a.chr != chr)) return 0;
+        if ((a.start_bp - a.wing_size) > bp || (a.end_bp + a.wing_size) < bp) return 0;
+    }
+    auto it1 = m.find(MapKey{chr, bp, a1, a2});
+    auto it2 = m.find(MapKey{chr, bp, a2, a1});
+    if (it1 != m.end() && it2 == m.end()) {
+        it1->second->rsid = rsid; it1->second->type = 1; it1->second->fpos = fpos;
+    } else if (it1 == m.end() && it2 != m.end()) {
+        // GWAS alleles are swapped relative to the panel: adopt the panel's order, flip z
+        std::unique_ptr<Snp> s = std::move(it2->second);
+        m.erase(it2);
+        s->rsid = rsid; s->a1 = a1; s->a2 = a2; s->z = s->z * (-1); s->type = 1; s->fpos = fpos;
+        m[MapKey{chr, bp, a1, a2}] = std::move(s);
+    } else if (it1 == m.end() && it2 == m.end()) {
+        if (!All) {       // gauss.cpp:373-385; ReadReferenceIndexAll never adds unmeasured SNPs
+            std::unique_ptr<Snp> s(new Snp());
+            s->rsid = rsid; s->chr = chr; s->bp = bp; s->a1 = a1; s->a2 = a2; s->type = 0; s->fpos = fpos;
+            m[MapKey{chr, bp, a1, a2}] = std::move(s);
+        }
+    } else {
+        return herr("ERROR: input file contains duplicates");
+    }
+    return 0;
+}
+
 // ReadReferenceIndex (gauss.cpp:293-399) and ReadReferenceIndexAll (gauss.cpp:431-518)
 static int ReadReferenceIndex(SnpMap& m, const Args& a, bool All)
 {
+    if (a.pk) {
+        // packed panel: the SNP table is in memory; a sorted panel is entered by binary search instead of the
+        // reference's genome-wide scan.  fpos is the row number.
+        const PackedPanel& pk = *a.pk;
+        int64_t i0 = 0, i1 = pk.n_snp();
+        if (!All && a.chr > 0 && pk.header().sorted) {
+            i0 = pk.lower_bound(a.chr, a.start_bp - a.wing_size);
+            i1 = pk.lower_bound(a.chr, a.end_bp + a.wing_size + 1);
+        }
+        for (int64_t i = i0; i < i1; i++) {
+            const PkSnp& s = pk.snp(i);
+            if (merge_index_entry(m, a, All, pk.str(s.rsid), s.chr, s.bp, pk.str(s.a1), pk.str(s.a2), i)) return -1;
+        }
+        return 0;
+    }
     BgzfReader fp;
     if (!fp.open(a.reference_index_file)) return herr("ERROR: can't open reference index file '%s'", a.reference_index_file.c_str());
     std::string line, rsid, a1, a2;
@@ -250,29 +300,7 @@ static int ReadReferenceIndex(SnpMap& m, const Args& a, bool All)
         if (last == -1) break;
         Tok t(line);
         if (t.str(rsid) && t.i32(chr) && t.i64(bp) && t.str(a1) && t.str(a2) && t.dbl(af1ref)) t.i64(fpos);
-        if (!All) {
-            if ((a.chr > 0) && (a.chr != chr)) continue;
-            if ((a.start_bp - a.wing_size) > bp || (a.end_bp + a.wing_size) < bp) continue;
-        }
-        auto it1 = m.find(MapKey{chr, bp, a1, a2});
-        auto it2 = m.find(MapKey{chr, bp, a2, a1});
-        if (it1 != m.end() && it2 == m.end()) {
-            it1->second->rsid = rsid; it1->second->type = 1; it1->second->fpos = fpos;
-        } else if (it1 == m.end() && it2 != m.end()) {
-            // GWAS alleles are swapped relative to the panel: adopt the panel's order, flip z
-            std::unique_ptr<Snp> s = std::move(it2->second);
-            m.erase(it2);
-            s->rsid = rsid; s->a1 = a1; s->a2 = a2; s->z = s->z * (-1); s->type = 1; s->fpos = fpos;
-            m[MapKey{chr, bp, a1, a2}] = std::move(s);
-        } else if (it1 == m.end() && it2 == m.end()) {
-            if (!All) {       // gauss.cpp:373-385; ReadReferenceIndexAll never adds unmeasured SNPs
-                std::unique_ptr<Snp> s(new Snp());
-                s->rsid = rsid; s->chr = chr; s->bp = bp; s->a1 = a1; s->a2 = a2; s->type = 0; s->fpos = fpos;
-                m[MapKey{chr, bp, a1, a2}] = std::move(s);
-            }
-        } else {
-            return herr("ERROR: input file contains duplicates");
-        }
+        if (merge_index_entry(m, a, All, rsid, chr, bp, a1, a2, fpos)) return -1;
     }
     return 0;
 }
@@ -334,9 +362,39 @@ static int preload_lines(SnpMap& m, const Args& a, bool want_af, std::vector<std
     return 0;
 }
 
+// MakeSnpVec / MakeSnpVecMix on a packed panel: the per-population allele counts and allele frequencies
+// were tabulated when the panel was packed, so no genotype line is touched for the AF filter.
+static int MakeSnpVecPacked(std::vector<Snp*>& v, SnpMap& m, const Args& a, bool mix)
+{
+    const PackedPanel& pk = *a.pk;
+    for (auto& kv : m) {
+        Snp& s = *kv.second;
+        if (s.fpos < 0 || s.fpos >= pk.n_snp()) continue;      // GWAS-only SNP: the text path reads an empty line, AF = NaN / 0
+        if (!mix) {
+            double allele_counter = 0, num_subj = 0;           // gauss.cpp:574-591 (integer-valued sums)
+            const int32_t* c = pk.cnt(s.fpos);
+            for (int k = 0; k < a.num_pops; k++)
+                if (a.pop_flag_vec[k]) { allele_counter += (double)c[k]; num_subj += a.ref_pop_size_vec[k]; }
+            double af1ref = allele_counter / (2 * num_subj);
+            af1ref = std::ceil(af1ref * 100000.0) / 100000.0;
+            s.af1ref = af1ref;
+            if ((af1ref > a.af1_cutoff) && (af1ref < (1 - a.af1_cutoff))) v.push_back(&s);
+        } else {
+            double af1_mix = 0;                                // gauss.cpp:676-682
+            const double* f = pk.af(s.fpos);
+            int j = 0;
+            for (int k = 0; k < a.num_pops; k++)
+                if (a.pop_flag_vec[k]) af1_mix += f[k] * a.pop_wgt_vec[j++];
+            if ((af1_mix > a.af1_cutoff) && (af1_mix < (1 - a.af1_cutoff))) { s.af1mix = af1_mix; v.push_back(&s); }
+        }
+    }
+    return 0;
+}
+
 // MakeSnpVec (gauss.cpp:543-604)
 static int MakeSnpVec(std::vector<Snp*>& v, SnpMap& m, const Args& a)
 {
+    if (a.pk) return MakeSnpVecPacked(v, m, a, false);
     if (preload_lines(m, a, false, nullptr)) return -1;
     for (auto& kv : m) {
         Snp& s = *kv.second;
@@ -356,6 +414,7 @@ static int MakeSnpVec(std::vector<Snp*>& v, SnpMap& m, const Args& a)
 // MakeSnpVecMix (gauss.cpp:631-693)
 static int MakeSnpVecMix(std::vector<Snp*>& v, SnpMap& m, const Args& a)
 {
+    if (a.pk) return MakeSnpVecPacked(v, m, a, true);
     std::vector<std::vector<double>> afs;
     if (preload_lines(m, a, true, &afs)) return -1;
     size_t idx = 0;
@@ -426,6 +485,10 @@ struct gauss_prepared {
     std::vector<int32_t> gene_off;
     std::vector<double> out_z, out_info, out_r, out_b11, out_b21;
     int n_head = 0, n_predm = 0;               // QCAT: measured SNPs left of / inside the prediction window
+    // packed panel: rows stay in the mmap'd file and are named by index (zero-copy); gm / gu are only
+    // materialised (as ASCII) for the kinds that need bytes on the host
+    bool packed_rows = false;
+    std::vector<int32_t> store_rows_m, store_rows_u, pop_src_off;
     int32_t num_eig = 0;
     int32_t status = 0;
     gauss_table snps;
@@ -443,6 +506,35 @@ static void fill_matrix(std::vector<uint8_t>& G, const std::vector<Snp*>& rows, 
             for (uint8_t* c = row0; c < dst; c++)
                 if (*c >= '0' && *c <= '2') *c = (uint8_t)('0' + (2 - (*c - '0')));
     }
+}
+
+// ASCII genotype matrices out of the packed rows (selected populations, panel order), with the
+// minor-allele flip of UpdateSnpToMinorAllele applied where flagged.
+static void unpack_rows(const gauss_prepared& p, const std::vector<Snp*>& rows, std::vector<uint8_t>& G)
+{
+    const PackedPanel& pk = *p.args.pk;
+    G.assign((size_t)std::max<size_t>(rows.size(), 1) * p.ld, (uint8_t)'0');
+    for (size_t r = 0; r < rows.size(); r++) {
+        uint8_t* dst = G.data() + r * p.ld;
+        const uint8_t* src = pk.row(rows[r]->fpos);
+        const bool flip = rows[r]->flip_geno;
+        for (int k = 0; k < p.args.num_pops; k++) {
+            if (!p.args.pop_flag_vec[k]) continue;
+            const uint8_t* b = src + pk.pop(k).byte_off;
+            const int m = (int)pk.pop(k).size;
+            for (int i = 0; i < m; i++) {
+                int c = (b[i >> 2] >> (2 * (i & 3))) & 3;
+                if (flip && c <= 2) c = 2 - c;
+                *dst++ = (uint8_t)('0' + c);
+            }
+        }
+    }
+}
+
+static void materialise_from_packed(gauss_prepared& p)
+{
+    unpack_rows(p, p.measured, p.gm);
+    unpack_rows(p, p.unmeasured, p.gu);
 }
 
 static void build_snp_table(gauss_prepared& p)
@@ -486,6 +578,13 @@ static int prepare(gauss_prepared& p)
     const bool qcat = (kind == GAUSS_KIND_QCAT || kind == GAUSS_KIND_QCATMIX);
     const bool prep = (kind == GAUSS_KIND_PREP_QCAT || kind == GAUSS_KIND_PREP_RECESSIVE);
     if (read_ref_desc(a)) return -1;
+    if (a.pk) {
+        if (a.pk->n_pop() != a.num_pops) return herr("packed panel has %d populations, the description file %d", a.pk->n_pop(), a.num_pops);
+        for (int k = 0; k < a.num_pops; k++)
+            if (a.ref_pop_vec[k] != a.pk->pop(k).name || a.ref_pop_size_vec[k] != (int)a.pk->pop(k).size)
+                return herr("packed panel population %d is %s (%u samples), the description file says %s (%d)", k,
+                            a.pk->pop(k).name, a.pk->pop(k).size, a.ref_pop_vec[k].c_str(), a.ref_pop_size_vec[k]);
+    }
     if (mix) init_pop_flag_wgt_vec(a);
     else if (init_pop_flag_vec(a)) return -1;
     if (ReadInputZ(p.snp_map, a, gene)) return -1;
@@ -547,19 +646,31 @@ static int prepare(gauss_prepared& p)
             if (i == 0 || p.measured[i]->geneid != p.measured[i - 1]->geneid) p.gene_off.push_back((int32_t)i);
         p.gene_off.push_back((int32_t)p.measured.size());
     }
-    // every selected population string must have its panel length, otherwise the matrix is ragged
-    for (Snp* s : p.measured) {
-        int n = 0;
-        for (auto& g : s->geno) n += g.second;
-        if (n != p.N) return herr("ERROR: genotype line of %s has %d samples, population table says %d", s->rsid.c_str(), n, p.N);
+    if (a.pk) {
+        const PackedPanel& pk = *a.pk;
+        for (int k = 0; k < a.num_pops; k++)
+            if (a.pop_flag_vec[k]) p.pop_src_off.push_back((int32_t)pk.pop(k).byte_off);
+        for (Snp* s : p.measured) p.store_rows_m.push_back((int32_t)s->fpos);
+        for (Snp* s : p.unmeasured) p.store_rows_u.push_back((int32_t)s->fpos);
+        // windows whose numeric step accepts row lists leave the genotypes in the mmap'd panel; the LD-only
+        // entry points (gauss_ld, gauss_gene_ld_batch) and the minor-allele flip need bytes on the host
+        p.packed_rows = (kind == GAUSS_KIND_DIST || kind == GAUSS_KIND_DISTMIX || qcat || kind == GAUSS_KIND_PREP_QCAT);
+        if (!p.packed_rows) materialise_from_packed(p);
+    } else {
+        // every selected population string must have its panel length, otherwise the matrix is ragged
+        for (Snp* s : p.measured) {
+            int n = 0;
+            for (auto& g : s->geno) n += g.second;
+            if (n != p.N) return herr("ERROR: genotype line of %s has %d samples, population table says %d", s->rsid.c_str(), n, p.N);
+        }
+        for (Snp* s : p.unmeasured) {
+            int n = 0;
+            for (auto& g : s->geno) n += g.second;
+            if (n != p.N) return herr("ERROR: genotype line of %s has %d samples, population table says %d", s->rsid.c_str(), n, p.N);
+        }
+        fill_matrix(p.gm, p.measured, p.ld);                       // ReadGenotype, gauss.cpp:720-785
+        fill_matrix(p.gu, p.unmeasured, p.ld);
     }
-    for (Snp* s : p.unmeasured) {
-        int n = 0;
-        for (auto& g : s->geno) n += g.second;
-        if (n != p.N) return herr("ERROR: genotype line of %s has %d samples, population table says %d", s->rsid.c_str(), n, p.N);
-    }
-    fill_matrix(p.gm, p.measured, p.ld);                       // ReadGenotype, gauss.cpp:720-785
-    fill_matrix(p.gu, p.unmeasured, p.ld);
     p.z1.clear();
     for (Snp* s : p.measured) p.z1.push_back(s->z);
     build_snp_table(p);
@@ -894,6 +1005,15 @@ int64_t gauss_host_bgzf_copy(const char* in_path, const char* out_path)
     return n;
 }
 
+int64_t gauss_host_pack_panel(const char* index_file, const char* data_file, const char* desc_file, const char* out_file)
+{
+    if (!index_file || !data_file || !desc_file || !out_file) { herr("file name is NULL"); return -1; }
+    std::string err;
+    const int64_t n = gauss_host::pack_panel(index_file, data_file, desc_file, out_file, err);
+    if (n < 0) herr("%s", err.c_str());
+    return n;
+}
+
 void gauss_host_set_threads(int n) { g_host_threads = n < 1 ? 1 : (n > 64 ? 64 : n); }
 
 int gauss_host_prepare(int kind, int chr, int64_t start_bp, int64_t end_bp, int64_t wing_size, const char* study_pop,
@@ -913,6 +1033,12 @@ int gauss_host_prepare(int kind, int chr, int64_t start_bp, int64_t end_bp, int6
     a.input_file = input_file; a.reference_index_file = reference_index_file;
     a.reference_data_file = reference_data_file; a.reference_pop_desc_file = reference_pop_desc_file;
     if (annotation_file) a.annotation_file = annotation_file;
+    if (PackedPanel::is_packed(a.reference_data_file)) {
+        // a packed panel replaces both the index and the data file (reference_index_file is not opened)
+        a.pk = std::make_shared<PackedPanel>();
+        std::string err;
+        if (!a.pk->open(a.reference_data_file, err)) return herr("%s", err.c_str());
+    }
     a.af1_cutoff = std::isnan(af1_cutoff) ? (kind == GAUSS_KIND_QCAT ? 0.05 : 0.01) : af1_cutoff;   // dist.cpp:53-57, qcat.cpp:53-57
     const bool mix = (kind == GAUSS_KIND_COMPUTELD || kind == GAUSS_KIND_DISTMIX || kind == GAUSS_KIND_JEPEGMIX ||
                       kind == GAUSS_KIND_QCATMIX || kind == GAUSS_KIND_PREP_RECESSIVE);
@@ -939,8 +1065,23 @@ int gauss_prepared_counts(const gauss_prepared* p, int* m, int* u, int* n, int* 
 }
 const int32_t* gauss_prepared_measured_rows(const gauss_prepared* p) { return p ? p->measured_rows.data() : nullptr; }
 const int32_t* gauss_prepared_unmeasured_rows(const gauss_prepared* p) { return p ? p->unmeasured_rows.data() : nullptr; }
-const uint8_t* gauss_prepared_geno_m(const gauss_prepared* p, int64_t* ld) { if (!p) return nullptr; if (ld) *ld = p->ld; return p->gm.data(); }
-const uint8_t* gauss_prepared_geno_u(const gauss_prepared* p, int64_t* ld) { if (!p) return nullptr; if (ld) *ld = p->ld; return p->gu.data(); }
+static void ensure_bytes(const gauss_prepared* cp)
+{
+    gauss_prepared* p = const_cast<gauss_prepared*>(cp);     // lazily unpacked view of packed rows (tests, debugging)
+    if (p->packed_rows && p->gm.empty()) materialise_from_packed(*p);
+}
+const uint8_t* gauss_prepared_geno_m(const gauss_prepared* p, int64_t* ld) { if (!p) return nullptr; ensure_bytes(p); if (ld) *ld = p->ld; return p->gm.data(); }
+const uint8_t* gauss_prepared_geno_u(const gauss_prepared* p, int64_t* ld) { if (!p) return nullptr; ensure_bytes(p); if (ld) *ld = p->ld; return p->gu.data(); }
+int gauss_prepared_packed_store(const gauss_prepared* p, const uint8_t** base, int64_t* bytes, int64_t* row_bytes)
+{
+    if (!p) return herr("prepared is NULL");
+    if (!p->packed_rows) { if (base) *base = nullptr; if (bytes) *bytes = 0; if (row_bytes) *row_bytes = 0; return 0; }
+    const PackedPanel& pk = *p->args.pk;
+    if (base) *base = pk.geno();
+    if (bytes) *bytes = pk.n_snp() * pk.row_bytes();
+    if (row_bytes) *row_bytes = pk.row_bytes();
+    return 0;
+}
 const int32_t* gauss_prepared_pop_off(const gauss_prepared* p) { return p ? p->pop_off.data() : nullptr; }
 const double* gauss_prepared_pop_wgt(const gauss_prepared* p) { return p ? p->pop_wgt.data() : nullptr; }
 const double* gauss_prepared_z1(const gauss_prepared* p) { return p ? p->z1.data() : nullptr; }
@@ -953,6 +1094,19 @@ int gauss_prepared_qcat_counts(const gauss_prepared* p, int* n_head, int* n_pred
     if (n_head) *n_head = p->n_head;
     if (n_predm) *n_predm = p->n_predm;
     return 0;
+}
+
+// genotype source of a window: host byte matrices, or row lists into the mmap'd packed panel
+static void set_geno(gauss_prepared* p, gauss_window_desc* d)
+{
+    if (!p->packed_rows) { d->geno_m = p->gm.data(); d->geno_u = p->gu.data(); d->ld = p->ld; return; }
+    const PackedPanel& pk = *p->args.pk;
+    d->geno_format = GAUSS_GENO_2BIT;
+    d->geno_m = d->geno_u = pk.geno();
+    d->ld = pk.row_bytes();
+    d->rows_m = p->store_rows_m.data();
+    d->rows_u = p->store_rows_u.data();
+    d->pop_src_off = p->pop_src_off.data();
 }
 
 int gauss_prepared_window_desc(gauss_prepared* p, gauss_window_desc* d)
@@ -976,7 +1130,7 @@ int gauss_prepared_window_desc(gauss_prepared* p, gauss_window_desc* d)
         d->n_pop = (int)p->pop_off.size() - 1;
         d->pop_off = p->pop_off.data(); d->pop_wgt = p->pop_wgt.data();
         d->n_measured = M; d->n_unmeasured = U;
-        d->geno_m = p->gm.data(); d->geno_u = p->gu.data(); d->ld = p->ld;
+        set_geno(p, d);
         d->lambda = 0.0;                                       // B11(i,i) = 1.0 (prep_qcat.cpp:109)
         d->u_codings = (ncode == 3) ? (GAUSS_CODE_ADDITIVE | GAUSS_CODE_DOMINANT | GAUSS_CODE_RECESSIVE) : GAUSS_CODE_ADDITIVE;
         d->out_b11 = p->out_b11.data(); d->out_b21 = p->out_b21.data(); d->out_status = &p->status;
@@ -996,7 +1150,7 @@ int gauss_prepared_window_desc(gauss_prepared* p, gauss_window_desc* d)
         d->n_pop = (int)p->pop_off.size() - 1;
         d->pop_off = p->pop_off.data(); d->pop_wgt = p->pop_wgt.data();
         d->n_measured = M; d->n_unmeasured = U;
-        d->geno_m = p->gm.data(); d->geno_u = p->gu.data(); d->ld = p->ld;
+        set_geno(p, d);
         d->z1 = p->z1.data(); d->lambda = a.lambda; d->min_abs_eig = a.min_abs_eig;
         d->n_head_measured = p->n_head; d->n_pred_measured = p->n_predm; d->eig_cutoff = a.eig_cutoff;
         d->out_r = p->out_r.data(); d->out_num_eig = &p->num_eig; d->out_status = &p->status;
@@ -1012,7 +1166,7 @@ int gauss_prepared_window_desc(gauss_prepared* p, gauss_window_desc* d)
     d->n_pop = (int)p->pop_off.size() - 1;
     d->pop_off = p->pop_off.data(); d->pop_wgt = p->pop_wgt.data();
     d->n_measured = M; d->n_unmeasured = U;
-    d->geno_m = p->gm.data(); d->geno_u = p->gu.data(); d->ld = p->ld;
+    set_geno(p, d);
     d->z1 = p->z1.data(); d->lambda = a.lambda; d->min_abs_eig = a.min_abs_eig;
     d->out_z = p->out_z.data(); d->out_info = p->out_info.data(); d->out_status = &p->status;
     return 0;

@@ -41,8 +41,12 @@ def window_cost(n_samples, m, u):
     return float(n_samples) * (m * (m + 1) / 2.0 + float(u) * m)
 
 
-def gpu_compute(prepared_list, ctx=None):
-    """Run the prepared windows as ONE batched job on this rank's GPU; returns one table per window."""
+def gpu_compute(prepared_list, ctx=None, resident=True):
+    """Run the prepared windows as ONE batched job on this rank's GPU; returns one table per window.
+
+    Windows that read a packed panel name their genotype rows by index.  With `resident` the slice of the
+    panel that this rank's windows touch is uploaded once (gauss_store_upload) and the pack kernel gathers the
+    rows from HBM; overlapping windows (the 500 kb wings) then share one copy instead of uploading twice."""
     if not prepared_list:
         return []
     ctx = ctx or hotpath.default_context()
@@ -52,13 +56,37 @@ def gpu_compute(prepared_list, ctx=None):
     for i, p in enumerate(prepared_list):
         d = p.window_desc()
         C.memmove(C.byref(descs[i]), C.byref(d), C.sizeof(d))
+    stores = [p.packed_store() for p in prepared_list]
+    store, keep, on_device = None, [], 0
+    if resident and all(s is not None and s == stores[0] for s in stores):
+        base, nbytes, rb = stores[0]
+        rows = []
+        for d in descs:
+            rm = np.ctypeslib.as_array(d.rows_m, shape=(d.n_measured,))
+            ru = np.ctypeslib.as_array(d.rows_u, shape=(d.n_unmeasured,)) if d.n_unmeasured else np.zeros(0, np.int32)
+            rows.append((rm, ru))
+        lo = min(int(min(rm.min(), ru.min() if len(ru) else rm.min())) for rm, ru in rows)
+        hi = max(int(max(rm.max(), ru.max() if len(ru) else rm.max())) for rm, ru in rows) + 1
+        dev = C.c_void_p()
+        hotpath.check(lib.gauss_store_upload(ctx.handle, C.c_void_p(base + lo * rb), (hi - lo) * rb, C.byref(dev)))
+        store, on_device = dev, 1
+        for d, (rm, ru) in zip(descs, rows):
+            a, b = np.ascontiguousarray(rm - lo, dtype=np.int32), np.ascontiguousarray(ru - lo, dtype=np.int32)
+            keep += [a, b]
+            d.rows_m = a.ctypes.data_as(C.POINTER(C.c_int32))
+            d.rows_u = b.ctypes.data_as(C.POINTER(C.c_int32))
+            d.geno_m = d.geno_u = dev.value
     h = C.c_void_p()
-    hotpath.check(lib.gauss_job_create(ctx.handle, descs, len(prepared_list), 0, C.byref(h)))
     try:
-        hotpath.check(lib.gauss_job_run(h))
-        hotpath.check(lib.gauss_job_fetch(h))
+        hotpath.check(lib.gauss_job_create(ctx.handle, descs, len(prepared_list), on_device, C.byref(h)))
+        try:
+            hotpath.check(lib.gauss_job_run(h))
+            hotpath.check(lib.gauss_job_fetch(h))
+        finally:
+            lib.gauss_job_destroy(h)
     finally:
-        lib.gauss_job_destroy(h)
+        if store is not None:
+            lib.gauss_store_free(ctx.handle, store)
     return [p.finish() for p in prepared_list]
 
 

@@ -132,6 +132,20 @@ int gauss_host_prep_recessive_impute(gauss_ctx* ctx, int chr, int64_t start_bp, 
                                      const char* reference_data_file, const char* reference_pop_desc_file,
                                      double af1_cutoff, gauss_table** out);
 
+/* ---- packed panel -------------------------------------------------
+ * Converts the reference's BGZF text panel (index + data + population description) into one mmap-able
+ * file: SNP table, per-population allele frequencies and allele counts, and 2-bit genotype rows
+ * (gauss_amd/csrc/host/packed_panel.h).  Passing that file as reference_data_file to any entry point
+ * above selects the packed feeder (reference_index_file is then ignored): no inflate, no text parsing,
+ * windows entered by binary search, each SNP row read once -- results are identical to the text path.
+ * Returns the number of SNPs packed or -1. */
+int64_t gauss_host_pack_panel(const char* reference_index_file, const char* reference_data_file,
+                              const char* reference_pop_desc_file, const char* out_file);
+/* For a prepared window that reads a packed panel: the panel's genotype section (host pointer into the
+ * mmap), its size and row stride, so a harness can upload it once with gauss_store_upload and run its
+ * windows with on_device = 1.  base = NULL for byte-matrix windows. */
+int gauss_prepared_packed_store(const gauss_prepared* p, const uint8_t** base, int64_t* bytes, int64_t* row_bytes);
+
 /* Re-block a BGZF text file line by line (reader + writer round trip); returns lines copied or -1. */
 int64_t gauss_host_bgzf_copy(const char* in_path, const char* out_path);
 

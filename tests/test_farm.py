@@ -120,3 +120,23 @@ def test_gpu_farm_single_rank(ctx, tmp_path):
     assert list(a["rsid"]) == list(b["rsid"])
     assert np.max(np.abs(a["z"].to_numpy() - b["z"].to_numpy()) / np.maximum(1, np.abs(b["z"].to_numpy()))) <= 1e-8
     assert np.max(np.abs(a["info"].to_numpy() - b["info"].to_numpy())) <= 1e-8
+
+
+@pytest.mark.gpu
+def test_gpu_farm_packed_panel_resident_store(ctx, tmp_path):
+    """A packed panel is uploaded once per rank (the slice its windows touch) and the windows gather their
+    rows from HBM: same table as the BGZF text path, bit for bit; and the same again without residency."""
+    st = make_study(tmp_path)
+    p = st["paths"]
+    gpk = str(tmp_path / "panel.gpk")
+    assert api.pack_panel(p["index.gz"], p["data.gz"], p["desc.txt"], gpk) > 0
+    common = dict(input_file=p["gwas.txt"], reference_index_file=p["index.gz"], reference_pop_desc_file=p["desc.txt"])
+    run = lambda data, **kw: farm.impute_chromosome(
+        api.KIND_DISTMIX, 22, 1_000_001, 4_000_000, 200_000, pop_wgt_df=WGT, window_size=500_000,
+        compute=lambda pl: farm.gpu_compute(pl, ctx, **kw), reference_data_file=data, **common)["table"]
+    text = run(p["data.gz"])
+    for kw in (dict(resident=True), dict(resident=False)):
+        got = run(gpk, **kw)
+        assert list(got["rsid"]) == list(text["rsid"])
+        assert np.array_equal(got["z"].to_numpy(), text["z"].to_numpy())
+        assert np.array_equal(got["info"].to_numpy(), text["info"].to_numpy())

@@ -240,3 +240,78 @@ def test_host_header_symbols_exported():
     h = api.load_host()
     for s in declared:
         assert hasattr(h, s)
+
+
+# ---- packed panel ------------------------------------------------
+@pytest.fixture(scope="module")
+def packed(study):
+    out = os.path.join(os.path.dirname(study["paths"]["data.gz"]), "panel.gpk")
+    _, idx, dat, desc = _files(study)
+    n = api.pack_panel(idx, dat, desc, out)
+    assert n == len(study["panel_rsid"]) if "panel_rsid" in study else n > 0
+    return out
+
+
+def _same_prepared(a, b):
+    da, db = a.snps(), b.snps()
+    assert list(da.columns) == list(db.columns)
+    for c in da.columns:
+        if c == "fpos":
+            continue                                   # virtual file offset vs row number
+        if da[c].dtype.kind == "f":
+            assert np.array_equal(da[c].to_numpy(), db[c].to_numpy(), equal_nan=True), c
+        else:
+            assert list(da[c]) == list(db[c]), c
+    assert (a.M, a.U, a.N, a.P, a.n_gene) == (b.M, b.U, b.N, b.P, b.n_gene)
+    assert np.array_equal(a.measured_rows(), b.measured_rows()) and np.array_equal(a.unmeasured_rows(), b.unmeasured_rows())
+    assert np.array_equal(a.geno_m(), b.geno_m()) and np.array_equal(a.geno_u(), b.geno_u())
+    assert np.array_equal(a.z1(), b.z1()) and np.array_equal(a.pop_off(), b.pop_off())
+    assert np.array_equal(a.pop_wgt(), b.pop_wgt()) and np.array_equal(a.gene_off(), b.gene_off())
+
+
+@pytest.mark.parametrize("kind", ["DIST", "DISTMIX", "QCAT", "QCATMIX", "PREP_QCAT", "PREP_RECESSIVE", "COMPUTELD"])
+def test_packed_panel_feeder_equals_text_feeder(study, packed, kind):
+    """The packed feeder (binary-searched SNP table, tabulated AF / allele counts, 2-bit rows) must hand the
+    numeric step exactly what the BGZF text feeder does."""
+    inp, idx, dat, desc = _files(study)
+    k = getattr(api, "KIND_" + kind)
+    mix = kind in ("DISTMIX", "QCATMIX", "PREP_RECESSIVE", "COMPUTELD")
+    kw = dict(chr=22, start_bp=1_400_000, end_bp=2_000_000, wing_size=250_000, study_pop=None if mix else "EUR",
+              pop_wgt_df=WGT if mix else None, input_file=inp, reference_index_file=idx, reference_pop_desc_file=desc)
+    a = api.Prepared(k, reference_data_file=dat, **kw)
+    b = api.Prepared(k, reference_data_file=packed, **dict(kw, reference_index_file="(ignored)"))
+    _same_prepared(a, b)
+    if kind in ("DIST", "DISTMIX", "QCAT", "QCATMIX", "PREP_QCAT"):
+        d = b.window_desc()
+        assert d.geno_format == 1 and bool(d.rows_m) and bool(d.pop_src_off) and d.ld % 16 == 0
+        base, nbytes, rb = b.packed_store()
+        assert rb == d.ld and nbytes % rb == 0
+        # the rows the descriptor names unpack to the same genotypes
+        rows = np.ctypeslib.as_array(C.cast(base, C.POINTER(C.c_uint8)), shape=(nbytes // rb, rb))
+        rm = np.ctypeslib.as_array(d.rows_m, shape=(b.M,))
+        so = np.ctypeslib.as_array(d.pop_src_off, shape=(b.P,))
+        sizes = np.diff(b.pop_off())
+        assert np.array_equal(panel.unpack2bit(rows[rm], sizes, so) + 48, b.geno_m())
+    else:
+        assert b.packed_store() is None
+    a.close()
+    b.close()
+
+
+def test_packed_panel_jepeg_and_errors(study, packed, tmp_path):
+    inp, idx, dat, desc = _files(study)
+    ann = study["paths"]["annot.txt"]
+    kw = dict(study_pop="ASN", input_file=inp, annotation_file=ann, reference_index_file=idx, reference_pop_desc_file=desc)
+    a = api.Prepared(api.KIND_JEPEG, reference_data_file=dat, **kw)
+    b = api.Prepared(api.KIND_JEPEG, reference_data_file=packed, **kw)
+    _same_prepared(a, b)
+    a.close()
+    b.close()
+    # a description file that disagrees with the packed panel is refused
+    bad = tmp_path / "desc_bad.txt"
+    lines = open(desc).read().splitlines()
+    bad.write_text("\n".join(lines[:-1]) + "\n")
+    with pytest.raises(api.GaussError) as ei:
+        api.Prepared(api.KIND_DIST, chr=22, start_bp=1_400_000, end_bp=2_000_000, wing_size=250_000, study_pop="EUR",
+                     input_file=inp, reference_index_file=idx, reference_data_file=packed, reference_pop_desc_file=str(bad))
+    assert "populations" in str(ei.value)

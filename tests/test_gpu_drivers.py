@@ -160,3 +160,47 @@ def test_not_enough_snps_is_an_error(ctx, study):
         api.distmix(22, 1_000_000, 1_005_000, 0, WGT, *_files(study), ctx=ctx)
     with pytest.raises(api.GaussError, match="Not enough number of SNPs loaded - computeLD not performed"):
         api.computeLD(22, 1_000_000, 1_005_000, WGT, *_files(study), ctx=ctx)
+
+
+# ---- packed panel: same entry points, reference_data_file = packed file ------------------------------
+@pytest.fixture(scope="module")
+def packed(study):
+    import os
+    _, idx, dat, desc = _files(study)
+    out = os.path.join(os.path.dirname(dat), "panel.gpk")
+    assert api.pack_panel(idx, dat, desc, out) > 0
+    return out
+
+
+def _same_frame(a, b):
+    assert list(a.columns) == list(b.columns) and len(a) == len(b)
+    for c in a.columns:
+        if a[c].dtype.kind == "f":
+            assert np.array_equal(a[c].to_numpy(), b[c].to_numpy(), equal_nan=True), c
+        else:
+            assert list(a[c]) == list(b[c]), c
+
+
+def test_packed_panel_gives_identical_tables(ctx, study, packed):
+    """The packed feeder changes how bytes reach the GPU (2-bit rows gathered by index), not one output bit."""
+    inp, idx, dat, desc = _files(study)
+    win = (22, 1_500_000, 2_000_000, 300_000)
+    for fn, who in ((api.dist, "EUR"), (api.distmix, WGT), (api.qcat, "EUR"), (api.qcatmix, WGT)):
+        t = fn(*win, who, inp, idx, dat, desc, ctx=ctx)
+        p = fn(*win, who, inp, "(unused)", packed, desc, ctx=ctx)
+        _same_frame(t, p)
+    t = api.prep_qcat(*win, "EUR", inp, idx, dat, desc, ctx=ctx)
+    p = api.prep_qcat(*win, "EUR", inp, idx, packed, desc, ctx=ctx)
+    _same_frame(t["snplist"], p["snplist"])
+    for k in ("z_vec", "cor_mat1", "cor_mat2"):
+        assert np.array_equal(t[k], p[k], equal_nan=True), k
+    t = api.prep_recessive_impute(*win, WGT, inp, idx, dat, desc, ctx=ctx)
+    p = api.prep_recessive_impute(*win, WGT, inp, idx, packed, desc, ctx=ctx)
+    for k in ("zvec", "cormat", "cormat_add", "cormat_dom", "cormat_rec"):
+        assert np.array_equal(t[k], p[k], equal_nan=True), k
+    t = api.computeLD(22, 1_200_000, 2_300_000, WGT, inp, idx, dat, desc, ctx=ctx)
+    p = api.computeLD(22, 1_200_000, 2_300_000, WGT, inp, idx, packed, desc, ctx=ctx)
+    _same_frame(t["snplist"], p["snplist"])
+    assert np.array_equal(t["cormat"], p["cormat"])
+    ann = study["paths"]["annot.txt"]
+    _same_frame(api.jepeg("EUR", inp, ann, idx, dat, desc, ctx=ctx), api.jepeg("EUR", inp, ann, idx, packed, desc, ctx=ctx))
