@@ -31,6 +31,10 @@
 #include <thread>
 #include <vector>
 
+#include <sys/stat.h>
+
+#include <mutex>
+
 #include "bgzf_io.h"
 #include "packed_panel.h"
 
@@ -465,6 +469,27 @@ static int ReadAnnotation(SnpMap& m, const Args& a)
         }
     }
     return 0;
+}
+
+// One mapping per packed panel file and process: every window of a chromosome shares it (and so the farm
+// sees one store to make resident).  Keyed by path + size + mtime; dropped when the last window closes.
+static std::shared_ptr<PackedPanel> open_packed_shared(const std::string& path, std::string& err)
+{
+    static std::mutex mu;
+    static std::map<std::string, std::weak_ptr<PackedPanel>> cache;
+    struct stat st;
+    if (stat(path.c_str(), &st) != 0) { err = "ERROR: can't open reference data file '" + path + "'"; return nullptr; }
+    char key[64];
+    snprintf(key, sizeof(key), "|%lld|%lld.%ld", (long long)st.st_size, (long long)st.st_mtim.tv_sec, (long)st.st_mtim.tv_nsec);
+    const std::string k = path + key;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(k);
+    if (it != cache.end())
+        if (std::shared_ptr<PackedPanel> sp = it->second.lock()) return sp;
+    std::shared_ptr<PackedPanel> sp = std::make_shared<PackedPanel>();
+    if (!sp->open(path, err)) return nullptr;
+    cache[k] = sp;
+    return sp;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1035,9 +1060,9 @@ int gauss_host_prepare(int kind, int chr, int64_t start_bp, int64_t end_bp, int6
     if (annotation_file) a.annotation_file = annotation_file;
     if (PackedPanel::is_packed(a.reference_data_file)) {
         // a packed panel replaces both the index and the data file (reference_index_file is not opened)
-        a.pk = std::make_shared<PackedPanel>();
         std::string err;
-        if (!a.pk->open(a.reference_data_file, err)) return herr("%s", err.c_str());
+        a.pk = open_packed_shared(a.reference_data_file, err);
+        if (!a.pk) return herr("%s", err.c_str());
     }
     a.af1_cutoff = std::isnan(af1_cutoff) ? (kind == GAUSS_KIND_QCAT ? 0.05 : 0.01) : af1_cutoff;   // dist.cpp:53-57, qcat.cpp:53-57
     const bool mix = (kind == GAUSS_KIND_COMPUTELD || kind == GAUSS_KIND_DISTMIX || kind == GAUSS_KIND_JEPEGMIX ||

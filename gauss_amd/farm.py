@@ -41,7 +41,7 @@ def window_cost(n_samples, m, u):
     return float(n_samples) * (m * (m + 1) / 2.0 + float(u) * m)
 
 
-def gpu_compute(prepared_list, ctx=None, resident=True):
+def gpu_compute(prepared_list, ctx=None, resident=True, timings=None):
     """Run the prepared windows as ONE batched job on this rank's GPU; returns one table per window.
 
     Windows that read a packed panel name their genotype rows by index.  With `resident` the slice of the
@@ -56,6 +56,8 @@ def gpu_compute(prepared_list, ctx=None, resident=True):
     for i, p in enumerate(prepared_list):
         d = p.window_desc()
         C.memmove(C.byref(descs[i]), C.byref(d), C.sizeof(d))
+    import time
+    t0 = time.perf_counter()
     stores = [p.packed_store() for p in prepared_list]
     store, keep, on_device = None, [], 0
     if resident and all(s is not None and s == stores[0] for s in stores):
@@ -77,11 +79,15 @@ def gpu_compute(prepared_list, ctx=None, resident=True):
             d.rows_u = b.ctypes.data_as(C.POINTER(C.c_int32))
             d.geno_m = d.geno_u = dev.value
     h = C.c_void_p()
+    t1 = time.perf_counter()
     try:
         hotpath.check(lib.gauss_job_create(ctx.handle, descs, len(prepared_list), on_device, C.byref(h)))
+        t2 = time.perf_counter()
         try:
             hotpath.check(lib.gauss_job_run(h))
             hotpath.check(lib.gauss_job_fetch(h))
+            if timings is not None:
+                timings.update(store_upload_s=t1 - t0, job_create_s=t2 - t1, run_fetch_s=time.perf_counter() - t2)
         finally:
             lib.gauss_job_destroy(h)
     finally:

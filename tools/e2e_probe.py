@@ -27,8 +27,24 @@ out = {"n_snp": n_snp, "panel_bytes": os.path.getsize(p["data.gz"]), "generate_s
 for threads in (1, 3):
     tm = {}
     res = farm.impute_chromosome(api.KIND_DISTMIX, 22, 20_000_001, 23_000_000, 500_000, pop_wgt_df=wgt, threads=threads,
-                                 timings=tm, compute=lambda pl: farm.gpu_compute(pl, ctx), **files)
+                                 timings=tm, compute=lambda pl: farm.gpu_compute(pl, ctx, timings=tm), **files)
     tm["rows"] = len(res["table"])
     tm["imputed_per_s_end_to_end"] = tm["imputed"] / (tm["feeder_s"] + tm["compute_s"])
     out[f"threads_{threads}"] = tm
+# the same study through the packed panel: no inflate / text parse, rows resident in HBM
+gpk = os.path.join(d, "panel.gpk")
+t0 = time.perf_counter()
+api.pack_panel(p["index.gz"], p["data.gz"], p["desc.txt"], gpk)
+out["pack_panel_s"] = time.perf_counter() - t0
+out["packed_bytes"] = os.path.getsize(gpk)
+pfiles = dict(files, reference_data_file=gpk)
+for threads in (1, 3):
+    for resident in (False, True):
+        tm = {}
+        res2 = farm.impute_chromosome(api.KIND_DISTMIX, 22, 20_000_001, 23_000_000, 500_000, pop_wgt_df=wgt, threads=threads,
+                                      timings=tm, compute=lambda pl: farm.gpu_compute(pl, ctx, resident=resident, timings=tm), **pfiles)
+        tm["rows"] = len(res2["table"])
+        tm["identical_to_text_path"] = bool(np.array_equal(res2["table"]["z"].to_numpy(), res["table"]["z"].to_numpy()))
+        tm["imputed_per_s_end_to_end"] = tm["imputed"] / (tm["feeder_s"] + tm["compute_s"])
+        out[f"packed_threads_{threads}_{'resident' if resident else 'staged'}"] = tm
 print(json.dumps(out))
