@@ -32,7 +32,7 @@ HOST_SYMBOLS = [
     "gauss_table_coltype", "gauss_table_str", "gauss_table_int", "gauss_table_dbl", "gauss_table_matrix",
     "gauss_table_free", "gauss_host_computeLD", "gauss_host_dist", "gauss_host_distmix", "gauss_host_jepeg",
     "gauss_host_jepegmix", "gauss_host_qcat", "gauss_host_qcatmix", "gauss_prepared_qcat_counts",
-    "gauss_host_prep_qcat", "gauss_host_prep_recessive_impute", "gauss_host_pack_panel", "gauss_prepared_packed_store", "gauss_table_n_named", "gauss_table_named_name",
+    "gauss_host_prep_qcat", "gauss_host_prep_recessive_impute", "gauss_host_pack_panel", "gauss_prepared_packed_store", "gauss_host_prep_zmix5", "gauss_table_n_named", "gauss_table_named_name",
     "gauss_table_named", "gauss_host_prepare", "gauss_prepared_snps", "gauss_prepared_counts",
     "gauss_prepared_measured_rows", "gauss_prepared_unmeasured_rows", "gauss_prepared_geno_m",
     "gauss_prepared_geno_u", "gauss_prepared_pop_off", "gauss_prepared_pop_wgt", "gauss_prepared_z1",
@@ -84,6 +84,7 @@ def load_host():
     h.gauss_host_distmix.argtypes = [_vp, C.c_int, _i64, _i64, _i64, _strs, _dp, C.c_int] + files4 + [_dbl, C.POINTER(_vp)]
     h.gauss_host_jepeg.argtypes = [_vp, _cp, _cp] + files4 + [_dbl, C.POINTER(_vp)]
     h.gauss_host_jepegmix.argtypes = [_vp, _strs, _dp, C.c_int, _cp] + files4 + [_dbl, C.POINTER(_vp)]
+    h.gauss_host_prep_zmix5.argtypes = [_vp, _cp, _cp, _cp, _cp, _dbl, C.c_int, C.POINTER(_vp)]
     h.gauss_host_pack_panel.restype = _i64
     h.gauss_host_pack_panel.argtypes = [_cp, _cp, _cp, _cp]
     h.gauss_prepared_packed_store.argtypes = [_vp, C.POINTER(C.c_void_p), C.POINTER(_i64), C.POINTER(_i64)]
@@ -289,6 +290,19 @@ def prep_recessive_impute(chr, start_bp, end_bp, wing_size, pop_wgt_df, input_fi
                                                _af(af1_cutoff), C.byref(out)))
     named = _named(h, out)
     return dict(snplist=_table(h, out)[0], **named)
+
+
+def prep_zmix5(input_file, reference_index_file, reference_data_file, reference_pop_desc_file, percentile=None,
+               interval=None, ctx=None, with_snps=False):
+    """prep_zmix5() of the reference (zmix.cpp:44-190): matrix [n_pairs x (1 + n_pop)], column 0 = z_i*z_j,
+    column k+1 = genotype correlation of the pair inside population k."""
+    h = load_host()
+    out = _vp()
+    _hcheck(h.gauss_host_prep_zmix5(_ctx(ctx), _enc(input_file), _enc(reference_index_file), _enc(reference_data_file),
+                                    _enc(reference_pop_desc_file), _af(percentile), int(interval or 0), C.byref(out)))
+    named = _named(h, out)
+    df = _table(h, out)[0]
+    return (named["data_mat"], df) if with_snps else named["data_mat"]
 
 
 def jepeg(study_pop, input_file, annotation_file, reference_index_file, reference_data_file, reference_pop_desc_file,

@@ -1014,6 +1014,38 @@ int gauss_gene_ld_batch(gauss_ctx* ctx, int mode, const uint8_t* geno, int n_snp
     return ld_common(ctx, mode, geno, n_snp, ld, pop_off, pop_wgt, n_pop, diag, gene_off, n_gene, out_blocks, nullptr, 0);
 }
 
+int gauss_ld_per_pop(gauss_ctx* ctx, const uint8_t* geno, int n_snp, int64_t ld, const int32_t* pop_off, int n_pop,
+                     double* out)
+{
+    if (!ctx || !geno || !pop_off || !out) return fail(GAUSS_E_INVALID, "bad arguments to gauss_ld_per_pop");
+    if (n_snp < 2) return fail(GAUSS_E_INVALID, "need at least two SNPs");
+    // the weighted layout keeps one exact Gram partial per population: all that is needed here
+    std::vector<double> ones((size_t)std::max(n_pop, 1), 1.0);
+    WinSpec w;
+    w.mode = GAUSS_MODE_WEIGHTED; w.n_pop = n_pop; w.pop_off = pop_off; w.pop_wgt = ones.data();
+    w.M = n_snp; w.U = 0; w.geno_m = geno; w.geno_u = nullptr; w.ld = ld; w.z1 = nullptr;
+    w.lambda = 0; w.eps = 0; w.diag = 1.0; w.ld_only = 1; w.gene_off = nullptr; w.n_gene = 0;
+    gauss_job* job = nullptr;
+    std::vector<WinSpec> specs{w};
+    int rc = job_build(ctx, specs, 0, &job);
+    if (rc) return rc;
+    rc = job_run(job, false);
+    if (!rc) {
+        const size_t npairs = (size_t)n_snp * (n_snp - 1) / 2;
+        const size_t bytes = sizeof(double) * npairs * (size_t)n_pop;
+        double* d_out = nullptr;
+        hipError_t e = hipMalloc((void**)&d_out, bytes);
+        if (e != hipSuccess) { job_free(job); return fail(GAUSS_E_NOMEM, "hipMalloc(%zu bytes per-population LD) failed", bytes); }
+        launch_pop_cor(job->d_probs, 0, job->plans[0].p.npair, d_out, ctx->stream);
+        e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess) e = hipMemcpy(out, d_out, bytes, hipMemcpyDeviceToHost);
+        hipFree(d_out);
+        if (e != hipSuccess) { job_free(job); return fail(GAUSS_E_DEVICE, "per-population LD: %s", hipGetErrorString(e)); }
+    }
+    job_free(job);
+    return rc;
+}
+
 int gauss_gram_counts(gauss_ctx* ctx, const uint8_t* geno, int n_snp, int n_samples, int64_t ld, int64_t* out_counts)
 {
     if (!out_counts) return fail(GAUSS_E_INVALID, "out_counts is NULL");

@@ -1287,6 +1287,121 @@ int gauss_host_prep_recessive_impute(gauss_ctx* ctx, int chr, int64_t start_bp, 
                       n_pop_wgt, input_file, reference_index_file, reference_data_file, reference_pop_desc_file, af1_cutoff, out);
 }
 
+// stats::quantile(x, probs = p) of R, default type 7 (quantile.default): index = 1 + (n-1)p, lo = floor, hi = ceiling,
+// q = x[lo], and if index > lo and x[hi] != q:  q = (1-h) q + h x[hi]  with h = index - lo.  NaN input is an error in R.
+static int r_quantile7(std::vector<double> x, double p, double* q)
+{
+    const size_t n = x.size();
+    for (double v : x) if (std::isnan(v)) return herr("missing values and NaN's not allowed if 'na.rm' is FALSE");
+    if (n == 0) { *q = NAN; return 0; }
+    std::sort(x.begin(), x.end());
+    const double index = 1 + (double)(n - 1) * p;
+    const double lo = std::floor(index), hi = std::ceil(index);
+    double qs = x[(size_t)lo - 1];
+    const double xh = x[(size_t)hi - 1];
+    if (index > lo && xh != qs) { const double h = index - lo; qs = (1 - h) * qs + h * xh; }
+    *q = qs;
+    return 0;
+}
+
+int gauss_host_prep_zmix5(gauss_ctx* ctx, const char* input_file, const char* reference_index_file,
+                          const char* reference_data_file, const char* reference_pop_desc_file,
+                          double percentile, int interval, gauss_table** out)
+{
+    if (!ctx || !out) return herr("bad arguments");
+    if (!input_file || !reference_index_file || !reference_data_file || !reference_pop_desc_file) return herr("file name is NULL");
+    Args a;
+    a.input_file = input_file; a.reference_index_file = reference_index_file;
+    a.reference_data_file = reference_data_file; a.reference_pop_desc_file = reference_pop_desc_file;
+    const double pct = std::isnan(percentile) ? 0.99 : percentile;            // zmix.cpp:57-61
+    const int step = interval > 0 ? interval : 1;                             // zmix.cpp:63-67
+    if (PackedPanel::is_packed(a.reference_data_file)) {
+        std::string err;
+        a.pk = open_packed_shared(a.reference_data_file, err);
+        if (!a.pk) return herr("%s", err.c_str());
+    }
+    if (read_ref_desc(a)) return -1;
+    if (a.pk && a.pk->n_pop() != a.num_pops) return herr("packed panel has %d populations, the description file %d", a.pk->n_pop(), a.num_pops);
+    a.pop_flag_vec.assign(a.num_pops, 1);                                     // zmix.cpp:148-150: every population
+    SnpMap m;
+    if (ReadInputZ(m, a, true)) return -1;                                    // read_input_zmix, zmix.cpp:1078-1113 (no window)
+    if (ReadReferenceIndex(m, a, true)) return -1;                            // read_ref_index_zmix, zmix.cpp:1115-1181
+    std::vector<Snp*> measured, snp_vec;
+    for (auto& kv : m) if (kv.second->type == 1) measured.push_back(kv.second.get());   // zmix.cpp:88-92
+    for (size_t i = 0; i < measured.size(); i += (size_t)step) snp_vec.push_back(measured[i]);   // zmix.cpp:111-119
+
+    // cal_af_norm_var (zmix.cpp:1183-1214): variance of the panel AF columns, normalised by mean(1-mean)
+    std::vector<double> norm_var;
+    {
+        BgzfReader fp;
+        if (!a.pk && !fp.open(a.reference_data_file)) return herr("ERROR: can't open reference data file '%s'", a.reference_data_file.c_str());
+        std::vector<double> af;
+        for (Snp* s : snp_vec) {
+            if (a.pk) af.assign(a.pk->af(s->fpos), a.pk->af(s->fpos) + a.num_pops);
+            else load_line(fp, *s, a, &af);
+            const int n = (int)af.size();
+            double sum = 0.0, sq = 0.0;
+            for (double v : af) sum += v;
+            for (double v : af) sq += v * v;
+            const double mean = sum / n;
+            const double variance = sq / n - mean * mean;
+            norm_var.push_back(variance / (mean * (1 - mean)));
+        }
+    }
+    double cutoff = 0;
+    if (r_quantile7(norm_var, pct, &cutoff)) return -1;                       // zmix.cpp:126-130
+    std::vector<Snp*> sub;
+    std::vector<double> sub_nv;
+    for (size_t i = 0; i < snp_vec.size(); i++)
+        if (norm_var[i] > cutoff) { sub.push_back(snp_vec[i]); sub_nv.push_back(norm_var[i]); }   // zmix.cpp:135-139
+
+    const int S = (int)sub.size(), P = a.num_pops;
+    int N = 0;
+    for (int k = 0; k < P; k++) N += a.ref_pop_size_vec[k];
+    std::vector<int32_t> pop_off(1, 0);
+    for (int k = 0; k < P; k++) pop_off.push_back(pop_off.back() + a.ref_pop_size_vec[k]);
+    const size_t npairs = S > 1 ? (size_t)S * (S - 1) / 2 : 0;
+    gauss_table* t = new gauss_table();
+    std::unique_ptr<gauss_table> hold(t);
+    NamedMat dm;
+    dm.name = "data_mat"; dm.nrow = (int)npairs; dm.ncol = 1 + P;
+    dm.d.assign(npairs * (size_t)(1 + P), 0.0);
+    if (S > 1) {
+        // ReadGenotype for the selected SNPs, all populations (zmix.cpp:148-153), then the pair table
+        gauss_prepared tmp;
+        tmp.args = a; tmp.N = N; tmp.ld = ((int64_t)N + 15) / 16 * 16;
+        std::vector<uint8_t> G;
+        if (a.pk) unpack_rows(tmp, sub, G);
+        else {
+            BgzfReader fp;
+            if (!fp.open(a.reference_data_file)) return herr("ERROR: can't open reference data file '%s'", a.reference_data_file.c_str());
+            for (Snp* s : sub) {
+                load_line(fp, *s, a, nullptr);
+                int n = 0;
+                for (auto& g : s->geno) n += g.second;
+                if (n != N) return herr("ERROR: genotype line of %s has %d samples, population table says %d", s->rsid.c_str(), n, N);
+            }
+            fill_matrix(G, sub, tmp.ld);
+        }
+        size_t row = 0;
+        for (int i = 0; i < S; i++)
+            for (int j = i + 1; j < S; j++) dm.d[row++] = sub[i]->z * sub[j]->z;         // zmix.cpp:165
+        if (gauss_ld_per_pop(ctx, G.data(), S, tmp.ld, pop_off.data(), P, dm.d.data() + npairs) != 0)
+            return herr("%s", gauss_last_error());
+    }
+    Column rsid{"rsid", GAUSS_COL_STR, {}, {}, {}}, chr{"chr", GAUSS_COL_INT, {}, {}, {}}, bp{"bp", GAUSS_COL_INT, {}, {}, {}};
+    Column a1{"a1", GAUSS_COL_STR, {}, {}, {}}, a2{"a2", GAUSS_COL_STR, {}, {}, {}}, z{"z", GAUSS_COL_DBL, {}, {}, {}};
+    Column nv{"norm_var", GAUSS_COL_DBL, {}, {}, {}};
+    for (int i = 0; i < S; i++) {
+        rsid.s.push_back(sub[i]->rsid); chr.i.push_back(sub[i]->chr); bp.i.push_back((int)sub[i]->bp);
+        a1.s.push_back(sub[i]->a1); a2.s.push_back(sub[i]->a2); z.d.push_back(sub[i]->z); nv.d.push_back(sub_nv[i]);
+    }
+    t->cols = {rsid, chr, bp, a1, a2, z, nv};
+    t->named.push_back(std::move(dm));
+    *out = hold.release();
+    return 0;
+}
+
 int gauss_host_computeLD(gauss_ctx* ctx, int chr, int64_t start_bp, int64_t end_bp, const char* const* pop_names,
                          const double* pop_wgts, int n_pop_wgt, const char* input_file, const char* reference_index_file,
                          const char* reference_data_file, const char* reference_pop_desc_file, double af1_cutoff,

@@ -424,6 +424,44 @@ __global__ __launch_bounds__(256) void counts_kernel(const Prob* __restrict__ pr
     }
 }
 
+// Per-population Pearson correlation of every SNP pair i < j (prep_zmix5, zmix.cpp:158-176; CalCor on one
+// population's strings, util.cpp:153-169):  r_p = (m*Sxy_p - Sx_p*Sy_p) / (sqrt(m*Sxx_p - Sx_p^2) * sqrt(m*Syy_p - Sy_p^2)).
+// out is [P][S(S-1)/2]: population-major, pairs in the reference's row order (i ascending, then j).
+__global__ __launch_bounds__(256) void pop_cor_kernel(const Prob* __restrict__ probs, int prob, double* __restrict__ out)
+{
+    const Prob& pb = probs[prob];
+    const int pair = blockIdx.x;
+    const int ti = pb.pair_ti[pair], tj = pb.pair_tj[pair];
+    const int P = pb.P, S = pb.M;
+    const float* tile_slab = pb.slab + (size_t)pair * pb.nseg * TILE * TILE;
+    const long long npairs = (long long)S * (S - 1) / 2;
+    for (int e = threadIdx.x; e < TILE * TILE; e += 256) {
+        const int ri = ti * TILE + e / TILE, rj = tj * TILE + e % TILE;
+        if (ri >= S || rj >= S || ri >= rj) continue;       // i < j only; diagonal tiles hold the upper part
+        const long long row = (long long)ri * S - (long long)ri * (ri + 1) / 2 + (rj - ri - 1);
+        const int* sxi = pb.sx + (size_t)ri * P;
+        const int* sxj = pb.sx + (size_t)rj * P;
+        const int* sxxi = pb.sxx + (size_t)ri * P;
+        const int* sxxj = pb.sxx + (size_t)rj * P;
+        for (int p = 0; p < P; p++) {
+            double sumxy = 0;
+            for (int g = pb.pop_seg0[p]; g < pb.pop_seg0[p + 1]; g++)
+                sumxy += slab_val(tile_slab[(size_t)g * TILE * TILE + e], pb.gram_i8);
+            const int n = pb.pop_raw_off[p + 1] - pb.pop_raw_off[p];
+            const double sumx = (double)sxi[p], sumy = (double)sxj[p];
+            const double sumxsq = (double)sxxi[p], sumysq = (double)sxxj[p];
+            const double numer = n * sumxy - sumx * sumy;                                            // util.cpp:165
+            const double denor = sqrt((n) * sumxsq - sumx * sumx) * sqrt((n) * sumysq - sumy * sumy);  // util.cpp:166
+            out[(size_t)p * npairs + row] = numer / denor;
+        }
+    }
+}
+
+void launch_pop_cor(const Prob* d_probs, int prob, int npair, double* d_out, hipStream_t s)
+{
+    if (npair > 0) hipLaunchKernelGGL(pop_cor_kernel, dim3(npair), dim3(256), 0, s, d_probs, prob, d_out);
+}
+
 void launch_counts(const Prob* d_probs, int prob, int npair, long long* d_out, hipStream_t s)
 {
     if (npair > 0) hipLaunchKernelGGL(counts_kernel, dim3(npair), dim3(256), 0, s, d_probs, prob, d_out);

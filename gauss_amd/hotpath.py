@@ -85,6 +85,18 @@ def ld_matrix(geno, pop_off, pop_wgt=None, mode=MODE_WEIGHTED, diag=1.0, ctx=Non
     return out
 
 
+def ld_per_pop(geno, pop_off, ctx=None):
+    """Per-population Pearson r of every SNP pair i < j (prep_zmix5, zmix.cpp:158-176): (P, S(S-1)/2)."""
+    ctx = ctx or default_context()
+    g = _lib.as_u8(geno)
+    po, _ = _pops(pop_off, None)
+    S, P = g.shape[0], len(po) - 1
+    out = np.zeros((P, S * (S - 1) // 2))
+    check(ctx.lib.gauss_ld_per_pop(ctx.handle, g.ctypes.data, S, g.strides[0], po.ctypes.data_as(_ip), P,
+                                   out.ctypes.data_as(_dp)))
+    return out
+
+
 def gene_ld_batch(geno, pop_off, gene_off, pop_wgt=None, mode=MODE_POOLED, diag=1.1, ctx=None):
     """LD blocks of all genes in one launch; returns a list of (n_g, n_g) arrays."""
     ctx = ctx or default_context()

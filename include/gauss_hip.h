@@ -160,6 +160,14 @@ int gauss_gene_ld_batch(gauss_ctx* ctx, int mode, const uint8_t* geno, int n_snp
                         const int32_t* pop_off, const double* pop_wgt, int n_pop,
                         const int32_t* gene_off, int n_gene, double diag, double* out_blocks);
 
+/* Per-population Pearson correlations of every SNP pair (prep_zmix5, zmix.cpp:158-176: CalCor on each
+ * population's genotype strings, util.cpp:153-169).  out is [n_pop][n_snp*(n_snp-1)/2], population-major,
+ * pairs in the reference's row order (i ascending, then j > i): column k+1 of the reference's column-major
+ * NumericMatrix data_mat is out + k * npairs.  A population in which a SNP is monomorphic gives NaN there,
+ * as in the reference. */
+int gauss_ld_per_pop(gauss_ctx* ctx, const uint8_t* geno, int n_snp, int64_t ld,
+                     const int32_t* pop_off, int n_pop, double* out);
+
 /* Exact co-occurrence counts sum_n x_i[n] x_j[n] over all columns -- the integer the reference
  * accumulates as `sumxy` (util.cpp:62,114).  out: S x S int64, row-major.  Integer parity hook. */
 int gauss_gram_counts(gauss_ctx* ctx, const uint8_t* geno, int n_snp, int n_samples, int64_t ld,

@@ -16,6 +16,7 @@
  *   prep_qcat(chr,start_bp,end_bp,wing_size,study_pop,...)  gauss_host_prep_qcat prep_qcat.cpp:16-205
  *   prep_recessive_impute(chr,...,pop_wgt_df,...)           gauss_host_prep_recessive_impute
  *                                                           prep_qcatmix.cpp:36-316
+ *   prep_zmix5(input_file,...,percentile,interval)          gauss_host_prep_zmix5 zmix.cpp:44-190
  *
  * Same argument meaning, same defaults (af1_cutoff NaN = R's NULL -> 0.01, dist.cpp:53-57), same
  * row order (std::map order on (chr,bp,a1,a2), gauss.h:72-99), same column names and types as
@@ -131,6 +132,16 @@ int gauss_host_prep_recessive_impute(gauss_ctx* ctx, int chr, int64_t start_bp, 
                                      const char* input_file, const char* reference_index_file,
                                      const char* reference_data_file, const char* reference_pop_desc_file,
                                      double af1_cutoff, gauss_table** out);
+
+/* prep_zmix5 (zmix.cpp:44-190): every `interval`-th measured SNP, keep those whose
+ * across-population allele-frequency variance var(AF)/(mean(1-mean)) exceeds its `percentile` quantile
+ * (R stats::quantile type 7, restated), and tabulate for every pair of them z_i*z_j and the Pearson
+ * correlation of their genotypes inside each of the panel's populations (on the GPU).  Result: named
+ * matrix "data_mat", [n_pairs x (1 + n_pop)] column-major like the reference's NumericMatrix; the table
+ * lists the selected SNPs (rsid chr bp a1 a2 z norm_var).  percentile NaN -> 0.99, interval <= 0 -> 1. */
+int gauss_host_prep_zmix5(gauss_ctx* ctx, const char* input_file, const char* reference_index_file,
+                          const char* reference_data_file, const char* reference_pop_desc_file,
+                          double percentile, int interval, gauss_table** out);
 
 /* ---- packed panel -------------------------------------------------
  * Converts the reference's BGZF text panel (index + data + population description) into one mmap-able

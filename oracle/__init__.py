@@ -11,6 +11,6 @@ implementation in ``oracle_np.py``; the BGZF codec is pinned against the referen
 ``src/bgzf.c`` compiled into ``oracle/_ref/``.
 """
 from .oracle_c import (  # noqa: F401
-    load, calcor, calwgtcov, compute_ld, ld_pooled, run_impute, run_qcat, count_pc, ld_blocks, recode, make_pos_def, inv_mat,
+    load, calcor, calwgtcov, compute_ld, ld_pooled, run_impute, run_qcat, count_pc, ld_blocks, recode, ld_per_pop, make_pos_def, inv_mat,
     pnorm_upper, pchisq_upper, jepeg_gene_tail, gram_counts, build,
 )

@@ -376,6 +376,66 @@ def prep_recessive_impute(chr_, start_bp, end_bp, wing, pop_wgt, input_file, ind
                 cormat_dom=res["b21"][A:2 * A], cormat_rec=res["b21"][2 * A:])
 
 
+def r_quantile7(x, p):
+    """stats::quantile(x, p), type 7, as written in R's quantile.default."""
+    import math
+    x = sorted(float(v) for v in x)
+    n = len(x)
+    if n == 0:
+        return float("nan")
+    if any(math.isnan(v) for v in x):
+        raise ValueError("missing values and NaN's not allowed if 'na.rm' is FALSE")
+    index = 1 + (n - 1) * p
+    lo, hi = math.floor(index), math.ceil(index)
+    qs = x[lo - 1]
+    if index > lo and x[hi - 1] != qs:
+        h = index - lo
+        qs = (1 - h) * qs + h * x[hi - 1]
+    return qs
+
+
+def prep_zmix5(input_file, index, data, desc, percentile=None, interval=None):
+    """zmix.cpp:44-190 with stats::quantile(type 7) from numpy (same definition, 'linear')."""
+    pct = 0.99 if percentile is None else percentile
+    step = interval or 1
+    pops = read_ref_desc(desc)
+    flags = [1] * len(pops)
+    m = read_input_z(input_file, 0, 0, 0, True)
+    read_reference_index(m, index, 0, 0, 0, True)
+    measured = [s for _, s in sorted(m.items()) if s.type == 1]
+    vec = measured[::step]
+    bg = Bgzf(data)
+    nv = []
+    for s in vec:
+        toks = bg.line_at(s.fpos).split()
+        af = np.array([float(x) for x in toks[len(pops):2 * len(pops)]])
+        mean = 0.0
+        for v in af:
+            mean += v
+        mean /= len(af)
+        sq = 0.0
+        for v in af:
+            sq += v * v
+        nv.append((sq / len(af) - mean * mean) / (mean * (1 - mean)))
+        s.geno = toks[:len(pops)]
+    nv = np.array(nv)
+    cutoff = r_quantile7(nv, pct)
+    sub = [s for s, v in zip(vec, nv) if v > cutoff]
+    S = len(sub)
+    rows = S * (S - 1) // 2
+    out = np.zeros((rows, 1 + len(pops)))
+    if S > 1:
+        off = _selected_off(pops, flags)
+        r = oc.ld_per_pop(_matrix(sub), off)
+        out[:, 1:] = r.T
+        k = 0
+        for i in range(S):
+            for j in range(i + 1, S):
+                out[k, 0] = sub[i].z * sub[j].z
+                k += 1
+    return dict(data_mat=out, rsid=[s.rsid for s in sub], cutoff=cutoff, norm_var=[float(v) for s, v in zip(vec, nv) if v > cutoff])
+
+
 def computeLD(chr_, start_bp, end_bp, pop_wgt, input_file, index, data, desc, af1_cutoff=None):
     cutoff = 0.01 if af1_cutoff is None else af1_cutoff
     pops = read_ref_desc(desc)

@@ -476,6 +476,25 @@ ORC_API int orc_run_impute(int mode, const char* geno_m, int M, const char* geno
 }
 
 /* ------------------------------------------------------------------------- */
+/* n4. per-population LD of every SNP pair   src/zmix.cpp:158-176              */
+/*   data_mat(row, k+1) = CalCor(snpi_geno_vec[k], snpj_geno_vec[k])           */
+/*   (CalCor(std::string&, std::string&), util.cpp:153-169 == a1 on one pop).  */
+/*   out: [P][S(S-1)/2], population-major, rows in the reference's (i, j>i)    */
+/*   order.                                                                    */
+/* ------------------------------------------------------------------------- */
+ORC_API void orc_ld_per_pop(const char* geno, long ld, int S, const int* pop_off, int P, double* out)
+{
+    size_t npairs = (size_t)S * (S - 1) / 2;
+    size_t row = 0;
+    for (int i = 0; i < S; i++)
+        for (int j = i + 1; j < S; j++) {
+            for (int k = 0; k < P; k++)
+                out[(size_t)k * npairs + row] = orc_calcor(geno + (size_t)i * ld, geno + (size_t)j * ld, pop_off + k, 1);
+            row++;
+        }
+}
+
+/* ------------------------------------------------------------------------- */
 /* n2. raw LD export   src/prep_qcat.cpp:104-132 (mode 0, CalCor)              */
 /*                     src/prep_qcatmix.cpp:136-158, 187-197 (mode 1)          */
 /*   b11: M x M, diagonal `diag`; b21: U x M row-major, x = geno_u row (first  */

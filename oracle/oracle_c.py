@@ -186,6 +186,19 @@ def ld_blocks(mode, geno_m, geno_u, pop_off, pop_wgt, diag=1.0, codings=(0,)):
     return dict(b11=b11, b21=np.vstack(blocks))
 
 
+def ld_per_pop(geno, pop_off):
+    """(P, S(S-1)/2) per-population Pearson r of every pair i < j (zmix.cpp:158-176)."""
+    lib = load()
+    g = _geno(geno)
+    S, N = g.shape
+    po = _off(pop_off)
+    P = len(po) - 1
+    out = np.zeros((P, S * (S - 1) // 2))
+    lib.orc_ld_per_pop.restype = None
+    lib.orc_ld_per_pop(g.ctypes.data_as(C.c_char_p), C.c_long(N), C.c_int(S), _cp(po, _ip), C.c_int(P), _cp(out, _dp))
+    return out
+
+
 def count_pc(a, eig_cutoff=0.01):
     lib = load()
     a = np.array(a, dtype=np.float64, order="F")

@@ -204,3 +204,19 @@ def test_packed_panel_gives_identical_tables(ctx, study, packed):
     assert np.array_equal(t["cormat"], p["cormat"])
     ann = study["paths"]["annot.txt"]
     _same_frame(api.jepeg("EUR", inp, ann, idx, dat, desc, ctx=ctx), api.jepeg("EUR", inp, ann, idx, packed, desc, ctx=ctx))
+
+
+@pytest.mark.parametrize("use_packed", [False, True])
+def test_prep_zmix5_end_to_end(ctx, study, packed, use_packed):
+    """prep_zmix5 (zmix.cpp:44-190): ancestry-informative SNPs by AF variance, then per-population LD of all pairs."""
+    inp, idx, dat, desc = _files(study)
+    want = fp.prep_zmix5(inp, idx, dat, desc, percentile=0.8, interval=2)
+    got, snps = api.prep_zmix5(inp, idx, packed if use_packed else dat, desc, percentile=0.8, interval=2, ctx=ctx,
+                               with_snps=True)
+    assert list(snps["rsid"]) == want["rsid"] and len(want["rsid"]) > 10
+    assert np.array_equal(snps["norm_var"].to_numpy(), np.array(want["norm_var"]))
+    assert got.shape == want["data_mat"].shape == (len(want["rsid"]) * (len(want["rsid"]) - 1) // 2, 1 + len(POPS))
+    assert np.array_equal(got[:, 0], want["data_mat"][:, 0])
+    nan = np.isnan(want["data_mat"])
+    assert np.array_equal(np.isnan(got), nan)
+    assert np.max(np.abs(got[~nan] - want["data_mat"][~nan])) <= 1e-12

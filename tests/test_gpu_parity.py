@@ -390,3 +390,16 @@ def test_u8_row_lists_from_a_resident_store(ctx):
     job.close()
     rs.close()
     assert _same(got, base)
+
+
+def test_per_population_ld_matches_oracle(ctx):
+    """prep_zmix5's pair table (zmix.cpp:158-176): CalCor on each population's strings for every SNP pair."""
+    p = small_panel(n_snp=170, scale=0.03, seed=71, n_pops=9)
+    G, off = p["G"][:150], p["off"]
+    got = hotpath.ld_per_pop(G, off, ctx=ctx)
+    want = oracle.ld_per_pop(G, off)
+    assert got.shape == want.shape == (9, 150 * 149 // 2)
+    nan = np.isnan(want)                                   # SNP monomorphic in a small population: 0/0 in both
+    assert np.array_equal(np.isnan(got), nan) and nan.mean() < 0.5
+    assert np.max(np.abs(got[~nan] - want[~nan])) <= LD_TOL
+    assert np.mean(got[~nan] == want[~nan]) > 0.999

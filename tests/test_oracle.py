@@ -205,3 +205,24 @@ def test_recode_and_ld_blocks_against_numpy():
         ww = onp.weighted_cor(dom, gm, p["off"], p["w"])
     ok = np.isfinite(ww)
     assert np.max(np.abs(gw["b21"][ok] - ww[ok])) <= 1e-12
+
+
+def test_ld_per_pop_against_numpy():
+    p = small_panel(n_snp=40, scale=0.03, n_pops=4, seed=9)
+    G, off = p["G"][:25], p["off"]
+    got = oracle.ld_per_pop(G, off)
+    iu = np.triu_indices(25, 1)
+    for k in range(4):
+        with np.errstate(invalid="ignore", divide="ignore"):
+            r = np.corrcoef(G[:, off[k]:off[k + 1]].astype(float))[iu]
+        ok = np.isfinite(r) & np.isfinite(got[k])
+        assert ok.sum() > 50 and np.max(np.abs(got[k][ok] - r[ok])) <= 1e-12
+
+
+def test_r_quantile_type7_matches_numpy_linear():
+    from oracle import feeder_py as fp
+    rng = np.random.default_rng(12)
+    for n in (1, 2, 7, 100):
+        x = rng.random(n)
+        for q in (0.0, 0.3, 0.5, 0.99, 1.0):
+            assert abs(fp.r_quantile7(x, q) - np.quantile(x, q)) <= 1e-15
