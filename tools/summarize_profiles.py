@@ -13,8 +13,9 @@ from collections import defaultdict
 
 
 def find(d, pat):
-    hits = sorted(glob.glob(os.path.join(d, "**", pat), recursive=True))
-    return hits[0] if hits else None
+    """The largest match: a run leaves one file per traced process, the bench process has by far the most rows."""
+    hits = glob.glob(os.path.join(d, "**", pat), recursive=True)
+    return max(hits, key=os.path.getsize) if hits else None
 
 
 def short(name):
