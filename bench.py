@@ -88,6 +88,9 @@ def main():
     ap.add_argument("--gram-dtype", choices=["f32", "i8"], default="f32",
                     help="LD Gram arithmetic of the headline run (f32 MFMA = north star; i8 MFMA = exact fast variant)")
     ap.add_argument("--no-i8-variant", action="store_true", help="skip the extra timing of the exact int8 variant")
+    ap.add_argument("--panel-format", choices=["u8", "2bit"], default="2bit",
+                    help="how the chromosome sits in HBM: per-window byte matrices, or one 2-bit packed row store "
+                         "(the packed panel's resident form) that windows index by row")
     ap.add_argument("--streams", type=int, default=1, help="split the windows over this many jobs/streams")
     args = ap.parse_args()
 
@@ -127,12 +130,29 @@ def main():
                                       C.c_uint64(20260213 + rank)))
     wins = windows_of(ch, args)
     keep, descs = [], []
-    for mi, ui in wins:
-        gm = panel.index_select(0, torch.from_numpy(mi).cuda())
-        gu = panel.index_select(0, torch.from_numpy(ui).cuda())
-        keep.append((gm, gu))
-        descs.append(dict(mode=hotpath.MODE_WEIGHTED, pop_off=ch["off"], pop_wgt=ch["w"], z1=ch["z"][mi],
-                          dev=(gm.data_ptr(), gu.data_ptr(), len(mi), len(ui), ld)))
+    store = None
+    if args.panel_format == "2bit":
+        # the whole chromosome as ONE resident 2-bit row store (288 GB of HBM hold an entire panel); windows
+        # name their rows, the pack kernel gathers and unpacks them
+        sizes = np.diff(ch["off"])
+        ld2 = int(sum((int(m) + 63) // 64 * 16 for m in sizes))
+        store = torch.empty((args.snps, ld2), dtype=torch.uint8, device="cuda")
+        _lib.check(lib.gauss_pack2bit_device(ctx.handle, panel.data_ptr(), ld, store.data_ptr(), ld2, args.snps,
+                                             ch["off"].ctypes.data_as(C.POINTER(C.c_int32)), len(ch["pops"])))
+    for k, (mi, ui) in enumerate(wins):
+        if store is None or k == 0:
+            gm = panel.index_select(0, torch.from_numpy(mi).cuda())
+            gu = panel.index_select(0, torch.from_numpy(ui).cuda())
+            keep.append((gm, gu))                       # window 0 also feeds the CPU baseline sample
+        if store is None:
+            descs.append(dict(mode=hotpath.MODE_WEIGHTED, pop_off=ch["off"], pop_wgt=ch["w"], z1=ch["z"][mi],
+                              dev=(gm.data_ptr(), gu.data_ptr(), len(mi), len(ui), ld)))
+        else:
+            descs.append(dict(mode=hotpath.MODE_WEIGHTED, pop_off=ch["off"], pop_wgt=ch["w"], z1=ch["z"][mi],
+                              dev=(store.data_ptr(), store.data_ptr(), len(mi), len(ui), ld2),
+                              packed=dict(fmt=1, rows_m=mi.astype(np.int32), rows_u=ui.astype(np.int32))))
+    if store is not None:
+        del panel
     torch.cuda.synchronize()
     ctx.set_gram_dtype(args.gram_dtype)
     if args.streams > 1:
@@ -229,6 +249,8 @@ def main():
                 "mean_measured": float(np.mean([len(m) for m, _ in wins])),
                 "mean_unmeasured": float(np.mean([len(u) for _, u in wins])),
                 "windows_flagged": bad, "all_finite": bool(finite),
+                "panel_in_hbm": ("one 2-bit packed row store, windows index it by row" if args.panel_format == "2bit"
+                                 else "per-window one-byte genotype matrices"),
             },
             "roofline": {
                 "kernel": "gram_kernel (LD GEMM, v_mfma_f32_32x32x2_f32)",

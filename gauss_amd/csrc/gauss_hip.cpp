@@ -1053,6 +1053,25 @@ int gauss_gram_counts(gauss_ctx* ctx, const uint8_t* geno, int n_snp, int n_samp
                      out_counts, n_samples);
 }
 
+int gauss_pack2bit_device(gauss_ctx* ctx, const uint8_t* d_in, int64_t ld_in, uint8_t* d_out, int64_t ld_out,
+                          int n_snp, const int32_t* pop_off, int n_pop)
+{
+    if (!ctx || !d_in || !d_out || !pop_off || n_snp < 1 || n_pop < 1) return fail(GAUSS_E_INVALID, "bad arguments");
+    std::vector<int> blk(n_pop + 1, 0);
+    for (int q = 0; q < n_pop; q++) blk[q + 1] = blk[q] + (int)rup((size_t)(pop_off[q + 1] - pop_off[q]), 64) / 4;
+    if (ld_out % 16 || ld_out < blk[n_pop]) return fail(GAUSS_E_INVALID, "ld_out must be a multiple of 16 and >= %d", blk[n_pop]);
+    HIPCHK(hipSetDevice(ctx->device));
+    int* d_tab = nullptr;
+    HIPCHK(hipMalloc((void**)&d_tab, sizeof(int) * 2 * (n_pop + 1)));
+    HIPCHK(hipMemcpy(d_tab, pop_off, sizeof(int) * (n_pop + 1), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_tab + n_pop + 1, blk.data(), sizeof(int) * (n_pop + 1), hipMemcpyHostToDevice));
+    HIPCHK(hipMemsetAsync(d_out, 0, (size_t)n_snp * ld_out, ctx->stream));
+    launch_pack2bit(d_in, ld_in, d_out, ld_out, n_snp, d_tab, d_tab + n_pop + 1, n_pop, ctx->stream);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    hipFree(d_tab);
+    return GAUSS_OK;
+}
+
 int gauss_synth_device(gauss_ctx* ctx, uint8_t* d_out, int n_snp, int64_t ld, const int32_t* pop_off, int n_pop,
                        const float* thr, const float* rho, uint64_t seed)
 {

@@ -183,6 +183,35 @@ __global__ __launch_bounds__(256) void synth_kernel(uint8_t* __restrict__ out, i
     }
 }
 
+// One-byte genotype rows -> 2-bit packed rows (GAUSS_GENO_2BIT layout) on the device: the resident form of a
+// panel.  One thread per output byte (4 samples); population blocks are 16-byte aligned, zero padded.
+__global__ __launch_bounds__(256) void pack2bit_kernel(const uint8_t* __restrict__ in, long long ld_in,
+                                                       uint8_t* __restrict__ out, long long ld_out, int n_snp,
+                                                       const int* __restrict__ pop_off, const int* __restrict__ blk_off,
+                                                       int n_pop)
+{
+    const long long b = (long long)blockIdx.x * 256 + threadIdx.x;     // byte within the row
+    const int row = blockIdx.y;
+    if (b >= ld_out || row >= n_snp) return;
+    int q = 0;
+    while (q + 1 < n_pop && b >= blk_off[q + 1]) q++;
+    const int s0 = (int)(b - blk_off[q]) * 4;
+    const int m = pop_off[q + 1] - pop_off[q];
+    const uint8_t* src = in + (size_t)row * ld_in + pop_off[q];
+    uint32_t v = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        if (s0 + k < m) v |= (uint32_t)(src[s0 + k] & 3u) << (2 * k);
+    out[(size_t)row * ld_out + b] = (uint8_t)v;
+}
+
+void launch_pack2bit(const uint8_t* d_in, long long ld_in, uint8_t* d_out, long long ld_out, int n_snp,
+                     const int* d_pop_off, const int* d_blk_off, int n_pop, hipStream_t s)
+{
+    hipLaunchKernelGGL(pack2bit_kernel, dim3((unsigned)((ld_out + 255) / 256), n_snp), dim3(256), 0, s, d_in, ld_in, d_out,
+                       ld_out, n_snp, d_pop_off, d_blk_off, n_pop);
+}
+
 void launch_synth(uint8_t* d_out, int n_snp, long long ld, const int* d_pop_off, int n_pop, int n_samples,
                   const float* d_thr, const float* d_rho, uint64_t seed, hipStream_t s)
 {

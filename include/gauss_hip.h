@@ -202,6 +202,13 @@ int gauss_job_work(gauss_job* job, double* out_ld_flops, double* out_solve_flops
  * out[3] = device workspace bytes.  Diagnostic only. */
 int gauss_job_stats(gauss_job* job, double* out4);
 
+/* Device-side conversion of one-byte genotype rows [n_snp x ld_in] into GAUSS_GENO_2BIT rows [n_snp x ld_out]
+ * (population blocks consecutive, 16-byte aligned, zero padded to 64 samples; ld_out >= their total and a
+ * multiple of 16).  Both pointers are device pointers.  Used to build a resident row store from rows that are
+ * already in HBM (bench plumbing; a packed panel file is uploaded as it is). */
+int gauss_pack2bit_device(gauss_ctx* ctx, const uint8_t* d_in, int64_t ld_in, uint8_t* d_out, int64_t ld_out,
+                          int n_snp, const int32_t* pop_off, int n_pop);
+
 /* Synthetic genotype generator on the device (bench plumbing; mirrors gauss_amd/synth.py's
  * model with a counter-based RNG).  Writes n_snp rows of n_samples bytes {0,1,2} at d_out with
  * row stride ld.  thr is a host array [n_snp x n_pop] of per-population latent thresholds,
