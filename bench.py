@@ -310,9 +310,20 @@ def cpu_baseline(ch, wins, keep, work):
     pairs_sample = m * (m + 1) / 2 + u + u * m
     pairs_total = sum(len(a) * (len(a) + 1) / 2 + len(b) + len(a) * len(b) for a, b in wins)
     est = t * pairs_total / pairs_sample
+    # what an R user could do with one process per window: the same sample on several cores at once
+    # (threads here: the oracle is plain C behind ctypes, which releases the GIL)
+    from concurrent.futures import ThreadPoolExecutor
+    par = max(1, min(16, (os.cpu_count() or 1)))
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=par) as pool:
+        list(pool.map(lambda _: oracle.run_impute(1, gm_h, gu_h, ch["off"], ch["w"], z1), range(par)))
+    tp = time.perf_counter() - t0
+    est_par = tp / par * pairs_total / pairs_sample
     return {
         "value": work["imputed_snps"] / est, "unit": "imputed SNPs/s", "cores": 1, "kind": "port",
         "host_cores": os.cpu_count(),
+        "windows_in_parallel": {"value": work["imputed_snps"] / est_par, "unit": "imputed SNPs/s", "cores": par,
+                                "sample": f"{par} concurrent copies of the same sample in {tp:.2f} s"},
         "sample": f"oracle run_distmix on a sub-window of window 0 (M={m}, U={u}, N={N}): {t:.2f} s for "
                   f"{pairs_sample:.0f} SNP pairs; scaled by the workload's {pairs_total:.3g} pairs "
                   f"(estimated {est:.0f} s per chromosome, dense tail of the full-size windows not included)",

@@ -43,6 +43,17 @@ def main():
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "window_small.npz"), **out)
     print("wrote tests/golden/window_small.npz", {k: v.shape for k, v in out.items()})
 
+    # the widened rows: QCAT, raw LD export with recoded rows, per-population LD
+    ext = dict(n_head=np.int32(6), n_pred=np.int32(25))
+    for mode in (0, 1):
+        q = oracle.run_qcat(mode, gm, gu, off, w, z1, 6, 25)
+        ext[f"qcat_r{mode}"], ext[f"qcat_num_eig{mode}"] = q["r"], np.int32(q["num_eig"])
+        b = oracle.ld_blocks(mode, gm, gu, off, w, 1.0, (0, 1, 2))
+        ext[f"ldx_b11_{mode}"], ext[f"ldx_b21_{mode}"] = b["b11"], b["b21"]
+    ext["ld_per_pop"] = oracle.ld_per_pop(gm[:24], off)
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "window_small_ext.npz"), **ext)
+    print("wrote tests/golden/window_small_ext.npz", {k: np.shape(v) for k, v in ext.items()})
+
 
 if __name__ == "__main__":
     main()
