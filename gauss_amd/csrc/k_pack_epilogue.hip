@@ -279,66 +279,104 @@ __global__ __launch_bounds__(1024) void epilogue_kernel(const Prob* __restrict__
         __syncthreads();
     }
 
-    const int jj = tid & (TILE - 1), sub = tid >> 7;          // 8 row phases
-    const int rj = tj * TILE + jj;
-    const double sd_j = pb.rt_sd[rj], wm_j = pb.rt_wm[rj];
+    // Thread t owns the 4 consecutive columns 4 (t & 31) .. +3 and the 4 rows (t >> 5) + 32 q: every partial row
+    // is read with one 16-byte load per thread (a wave covers two 512-byte rows), 16 entries per thread.
+    const int c0 = (tid & 31) * 4, rg = tid >> 5;
+    int rows[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) rows[q] = rg + 32 * q;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    double cov[4][4];
+    double sd_j[4], wm_j[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) { sd_j[c] = pb.rt_sd[tj * TILE + c0 + c]; wm_j[c] = pb.rt_wm[tj * TILE + c0 + c]; }
     const int num_samples = pb.N;
 
-    for (int r4 = 0; r4 < TILE / 32; r4++) {
-        double cov[4];
-        int rows[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) rows[q] = sub + 8 * (4 * r4 + q);
-        if (!weighted) {
-            // CalCor tail (util.cpp:66-68): r = (n*sxy - sx*sy) / (sqrt(..x..) * sqrt(..y..))
-            double sumxy[4] = {0, 0, 0, 0};
-            for (int s = 0; s < nseg; s++)
-#pragma unroll
-                for (int q = 0; q < 4; q++) sumxy[q] += slab_val(tile_slab[s * seg_stride + rows[q] * TILE + jj], isint);
+    if (!weighted) {
+        // CalCor tail (util.cpp:66-68): r = (n*sxy - sx*sy) / (sqrt(..x..) * sqrt(..y..))
+        double sumxy[4][4] = {};
+        for (int s = 0; s < nseg; s++)
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                const int ri = ti * TILE + rows[q];
-                const double numer = num_samples * sumxy[q] - pb.rt_wm[ri] * wm_j;
-                const double denor = pb.rt_sd[ri] * sd_j;
-                cov[q] = numer / denor;
-            }
-        } else if (lds_tables) {
-            // CalWgtCov (util.cpp:103-124) in the reference's population order
-            double wsumcov[4] = {0, 0, 0, 0}, wmm[4] = {0, 0, 0, 0};
-            for (int p = 0; p < P; p++) {
-                double sumxy[4] = {0, 0, 0, 0};
-                for (int s = pb.pop_seg0[p]; s < pb.pop_seg0[p + 1]; s++)
+                const f32x4 v = *(GP(const f32x4))(tile_slab + s * seg_stride + rows[q] * TILE + c0);
 #pragma unroll
-                    for (int q = 0; q < 4; q++) sumxy[q] += slab_val(tile_slab[s * seg_stride + rows[q] * TILE + jj], isint);
-                const double md = pb.pop_md[p], wf = pb.pop_wf[p];
-                const double sumy = (double)s_sxj[p * TILE + jj];
-                const double mu_y = s_muj[p * TILE + jj];
+                for (int c = 0; c < 4; c++) sumxy[q][c] += slab_val(v[c], isint);
+            }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int ri = ti * TILE + rows[q];
+            const double wm_i = pb.rt_wm[ri], sd_i = pb.rt_sd[ri];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const double numer = num_samples * sumxy[q][c] - wm_i * wm_j[c];
+                const double denor = sd_i * sd_j[c];
+                cov[q][c] = numer / denor;
+            }
+        }
+    } else if (lds_tables) {
+        // CalWgtCov (util.cpp:103-124) in the reference's population order
+        double wsumcov[4][4] = {};
+        for (int p = 0; p < P; p++) {
+            double sumxy[4][4] = {};
+            for (int s = pb.pop_seg0[p]; s < pb.pop_seg0[p + 1]; s++)
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    const double sumx = (double)s_sxi[p * TILE + rows[q]];
-                    wsumcov[q] += wf * (md * sumxy[q] - sumx * sumy);          // util.cpp:118
-                    wmm[q] += s_wmui[p * TILE + rows[q]] * mu_y;               // util.cpp:119
+                    const f32x4 v = *(GP(const f32x4))(tile_slab + s * seg_stride + rows[q] * TILE + c0);
+#pragma unroll
+                    for (int c = 0; c < 4; c++) sumxy[q][c] += slab_val(v[c], isint);
                 }
-            }
+            const double md = pb.pop_md[p], wf = pb.pop_wf[p];
+            double sumy[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) sumy[c] = (double)s_sxj[p * TILE + c0 + c];
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                const int ri = ti * TILE + rows[q];
-                const double c = wsumcov[q] + wmm[q] - pb.rt_wm[ri] * wm_j;    // util.cpp:123
-                cov[q] = c / (pb.rt_sd[ri] * sd_j);                            // distmix.cpp:196
-            }
-        } else {
+                const double sumx = (double)s_sxi[p * TILE + rows[q]];
 #pragma unroll
-            for (int q = 0; q < 4; q++)
-                cov[q] = cor_entry(pb, (const float*)tile_slab, rows[q] * TILE + jj, ti * TILE + rows[q], rj);
+                for (int c = 0; c < 4; c++) wsumcov[q][c] += wf * (md * sumxy[q][c] - sumx * sumy[c]);      // util.cpp:118
+            }
+        }
+        double wmm[4][4] = {};
+        for (int p = 0; p < P; p++) {
+            double mu_y[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) mu_y[c] = s_muj[p * TILE + c0 + c];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const double wmu_x = s_wmui[p * TILE + rows[q]];
+#pragma unroll
+                for (int c = 0; c < 4; c++) wmm[q][c] += wmu_x * mu_y[c];                                    // util.cpp:119
+            }
         }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const int ri = ti * TILE + rows[q];
+            const double wm_i = pb.rt_wm[ri], sd_i = pb.rt_sd[ri];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const double cv = wsumcov[q][c] + wmm[q][c] - wm_i * wm_j[c];                                // util.cpp:123
+                cov[q][c] = cv / (sd_i * sd_j[c]);                                                           // distmix.cpp:196
+            }
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+                cov[q][c] = cor_entry(pb, (const float*)tile_slab, rows[q] * TILE + c0 + c, ti * TILE + rows[q], tj * TILE + c0 + c);
+    }
+
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int ri = ti * TILE + rows[q];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int rj = tj * TILE + c0 + c;
             if (sym) {
                 if (ri > rj) continue;                            // mirror handles the lower part
                 if (pb.ld_only) {
                     if (ri >= pb.M || rj >= pb.M) continue;
-                    const double v = (ri == rj) ? pb.diag : cov[q];
+                    const double v = (ri == rj) ? pb.diag : cov[q][c];
                     pb.out_ld[(size_t)ri * pb.M + rj] = v;
                     pb.out_ld[(size_t)rj * pb.M + ri] = v;
                     continue;
@@ -347,7 +385,7 @@ __global__ __launch_bounds__(1024) void epilogue_kernel(const Prob* __restrict__
                 double v0, v1;
                 if (ri >= pb.M || rj >= pb.M) { v0 = v1 = (ri == rj) ? 1.0 : 0.0; }
                 else if (ri == rj) { v0 = 1.0 + pb.lambda; v1 = v0 - pb.eps; }   // dist.cpp:172
-                else { v0 = v1 = cov[q]; }                                        // dist.cpp:174-177
+                else { v0 = v1 = cov[q][c]; }                                     // dist.cpp:174-177
                 const auto A0 = pb.A;
                 const auto A1 = pb.A + (size_t)Mld * Mld;
                 A0[(size_t)ri * Mld + rj] = v0; A0[(size_t)rj * Mld + ri] = v0;
@@ -355,7 +393,7 @@ __global__ __launch_bounds__(1024) void epilogue_kernel(const Prob* __restrict__
             } else {
                 const int u = ri - pb.Mp;                         // unmeasured row (x), measured col (y)
                 if (u >= pb.U || rj >= pb.M) continue;
-                pb.B21[(size_t)u * Mld + rj] = cov[q];            // dist.cpp:188-191
+                pb.B21[(size_t)u * Mld + rj] = cov[q][c];         // dist.cpp:188-191
             }
         }
     }
