@@ -160,6 +160,8 @@ static int plan_problem(const WinSpec& w, Plan& pl, int seg_max, int group_targe
     if (w.pop_off[0] != 0) return fail(GAUSS_E_INVALID, "pop_off[0] must be 0");
     const int N = w.pop_off[w.n_pop];
     if (N < 1) return fail(GAUSS_E_INVALID, "no samples");
+    // sums of code products are kept as exact integers: 15 * 15 * n must stay below 2^31
+    if ((long long)N * 225 >= (1LL << 31)) return fail(GAUSS_E_RANGE, "%d samples exceed the exact-integer range (9.5 M)", N);
     if (w.geno_fmt != GAUSS_GENO_U8 && w.geno_fmt != GAUSS_GENO_2BIT) return fail(GAUSS_E_INVALID, "bad geno_format %d", w.geno_fmt);
     if (w.geno_fmt == GAUSS_GENO_U8 && w.ld < N) return fail(GAUSS_E_INVALID, "ld (%lld) < n_samples (%d)", w.ld, N);
     if (w.geno_fmt == GAUSS_GENO_2BIT) {
@@ -630,7 +632,7 @@ static int job_run(gauss_job* job, bool solve)
     launch_gram(job->d_items, job->n_items, job->gram_i8, st);
     prof_end(job);
     prof_begin(job, 2);
-    launch_epilogue(job->d_probs, job->d_tilemap, job->n_tiles, job->max_pop, st);
+    launch_epilogue(job->d_probs, job->d_tilemap, job->n_tiles, job->max_pop, job->gram_i8, st);
     for (int i = 0; i < job->n; i++)
         if (job->plans[i].p.n_gene) launch_gene_epilogue(job->d_probs, i, job->plans[i].p.n_gene, st);
     prof_end(job);
@@ -665,7 +667,7 @@ static int job_clamp_window(gauss_job* job, int i, int* status_bits)
     int2* d_tm = nullptr;
     HIPCHK(hipMalloc((void**)&d_tm, sizeof(int2) * tm.size()));
     HIPCHK(hipMemcpyAsync(d_tm, tm.data(), sizeof(int2) * tm.size(), hipMemcpyHostToDevice, st));
-    launch_epilogue(job->d_probs, d_tm, (int)tm.size(), job->max_pop, st);
+    launch_epilogue(job->d_probs, d_tm, (int)tm.size(), job->max_pop, job->gram_i8, st);
     double* d_work = nullptr;
     const size_t n = (size_t)p.Mld;
     HIPCHK(hipMalloc((void**)&d_work, sizeof(double) * (2 * n * n + 4 * n)));

@@ -112,7 +112,7 @@ template <typename T> __device__ __forceinline__ gptr<T> G(gptr<T> p) { return p
 void launch_pack_stats(const Prob* d_probs, const int2* d_rowmap, int n_rows, hipStream_t s);
 void launch_row_stats(const Prob* d_probs, const int2* d_rowmap, int n_rows, hipStream_t s);
 void launch_gram(const Item* d_items, int n_items, int dtype_i8, hipStream_t s);
-void launch_epilogue(const Prob* d_probs, const int2* d_tilemap, int n_tiles, int max_pop, hipStream_t s);
+void launch_epilogue(const Prob* d_probs, const int2* d_tilemap, int n_tiles, int max_pop, int dtype_i8, hipStream_t s);
 void launch_pop_cor(const Prob* d_probs, int prob, int npair, double* d_out, hipStream_t s);
 void launch_gene_epilogue(const Prob* d_probs, int prob, int n_gene, hipStream_t s);
 void launch_factor_step(const Prob* d_probs, int n_prob, int step, int max_nblk, hipStream_t s);

@@ -245,6 +245,18 @@ constexpr int EPI_MAXP = 32;     // LDS table capacity (33KG has 29 populations)
 
 struct EpiOut { double v0, v1; };
 
+// Partial slabs hold exact integers: as f32 (f32 MFMA path) or as int32 bit patterns (i8 MFMA path).  The sum
+// of a population's partials is accumulated as int32 -- exact below 2^31, i.e. for populations of up to
+// 9.5 M samples even with the largest accepted codes (15 * 15 * m; the planner enforces the bound) -- and
+// widened to fp64 once per population.
+template <bool ISINT> struct SlabAcc {
+    int v;
+    __device__ __forceinline__ void zero() { v = 0; }
+    __device__ __forceinline__ void add(float x) { v += ISINT ? __float_as_int(x) : (int)x; }
+    __device__ __forceinline__ double get() const { return (double)v; }
+};
+
+template <bool ISINT>
 __global__ __launch_bounds__(1024) void epilogue_kernel(const Prob* __restrict__ probs,
                                                         const int2* __restrict__ tilemap, int lds_pop_cap)
 {
@@ -294,14 +306,31 @@ __global__ __launch_bounds__(1024) void epilogue_kernel(const Prob* __restrict__
 
     if (!weighted) {
         // CalCor tail (util.cpp:66-68): r = (n*sxy - sx*sy) / (sqrt(..x..) * sqrt(..y..))
-        double sumxy[4][4] = {};
-        for (int s = 0; s < nseg; s++)
+        SlabAcc<ISINT> acc[4][4];
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const f32x4 v = *(GP(const f32x4))(tile_slab + s * seg_stride + rows[q] * TILE + c0);
+        for (int q = 0; q < 4; q++)
 #pragma unroll
-                for (int c = 0; c < 4; c++) sumxy[q][c] += slab_val(v[c], isint);
-            }
+            for (int c = 0; c < 4; c++) acc[q][c].zero();
+        f32x4 nxt[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) nxt[q] = *(GP(const f32x4))(tile_slab + rows[q] * TILE + c0);
+        for (int s = 0; s < nseg; s++) {
+            f32x4 cur[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) cur[q] = nxt[q];
+            if (s + 1 < nseg)                                     // next partial flies while this one is added
+#pragma unroll
+                for (int q = 0; q < 4; q++) nxt[q] = *(GP(const f32x4))(tile_slab + (s + 1) * seg_stride + rows[q] * TILE + c0);
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+#pragma unroll
+                for (int c = 0; c < 4; c++) acc[q][c].add(cur[q][c]);
+        }
+        double sumxy[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) sumxy[q][c] = acc[q][c].get();
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const int ri = ti * TILE + rows[q];
@@ -316,15 +345,32 @@ __global__ __launch_bounds__(1024) void epilogue_kernel(const Prob* __restrict__
     } else if (lds_tables) {
         // CalWgtCov (util.cpp:103-124) in the reference's population order
         double wsumcov[4][4] = {};
+        f32x4 nxt[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) nxt[q] = *(GP(const f32x4))(tile_slab + rows[q] * TILE + c0);
         for (int p = 0; p < P; p++) {
-            double sumxy[4][4] = {};
-            for (int s = pb.pop_seg0[p]; s < pb.pop_seg0[p + 1]; s++)
+            SlabAcc<ISINT> acc[4][4];
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const f32x4 v = *(GP(const f32x4))(tile_slab + s * seg_stride + rows[q] * TILE + c0);
+            for (int q = 0; q < 4; q++)
 #pragma unroll
-                    for (int c = 0; c < 4; c++) sumxy[q][c] += slab_val(v[c], isint);
-                }
+                for (int c = 0; c < 4; c++) acc[q][c].zero();
+            for (int s = pb.pop_seg0[p]; s < pb.pop_seg0[p + 1]; s++) {
+                f32x4 cur[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) cur[q] = nxt[q];
+                if (s + 1 < nseg)                                 // segments are stored in population order: the next
+#pragma unroll                                                    // partial (same or next population) flies during the fp64 tail
+                    for (int q = 0; q < 4; q++) nxt[q] = *(GP(const f32x4))(tile_slab + (s + 1) * seg_stride + rows[q] * TILE + c0);
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+#pragma unroll
+                    for (int c = 0; c < 4; c++) acc[q][c].add(cur[q][c]);
+            }
+            double sumxy[4][4];
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+#pragma unroll
+                for (int c = 0; c < 4; c++) sumxy[q][c] = acc[q][c].get();
             const double md = pb.pop_md[p], wf = pb.pop_wf[p];
             double sumy[4];
 #pragma unroll
@@ -399,18 +445,20 @@ __global__ __launch_bounds__(1024) void epilogue_kernel(const Prob* __restrict__
     }
 }
 
-void launch_epilogue(const Prob* d_probs, const int2* d_tilemap, int n_tiles, int max_pop, hipStream_t s)
+void launch_epilogue(const Prob* d_probs, const int2* d_tilemap, int n_tiles, int max_pop, int dtype_i8, hipStream_t s)
 {
     if (n_tiles <= 0) return;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(epilogue_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)((size_t)EPI_MAXP * TILE * (2 * sizeof(double) + 2 * sizeof(int))));
+        const int maxb = (int)((size_t)EPI_MAXP * TILE * (2 * sizeof(double) + 2 * sizeof(int)));
+        hipFuncSetAttribute(reinterpret_cast<const void*>(epilogue_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, maxb);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(epilogue_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, maxb);
         attr_set = true;
     }
     const int cap = max_pop > EPI_MAXP ? EPI_MAXP : (max_pop < 1 ? 1 : max_pop);   // P > cap: tables stay in global memory
     const size_t smem = (size_t)cap * TILE * (2 * sizeof(double) + 2 * sizeof(int));
-    hipLaunchKernelGGL(epilogue_kernel, dim3(n_tiles), dim3(1024), smem, s, d_probs, d_tilemap, cap);
+    if (dtype_i8) hipLaunchKernelGGL(epilogue_kernel<true>, dim3(n_tiles), dim3(1024), smem, s, d_probs, d_tilemap, cap);
+    else hipLaunchKernelGGL(epilogue_kernel<false>, dim3(n_tiles), dim3(1024), smem, s, d_probs, d_tilemap, cap);
 }
 
 // Gene batches (gene.cpp:305-315, 571-586): block g is n_g x n_g with pb.diag on the diagonal.
