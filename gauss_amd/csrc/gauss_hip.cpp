@@ -240,6 +240,7 @@ static int plan_problem(const WinSpec& w, Plan& pl, int seg_max, int group_targe
             pl.row_bytes = std::max(pl.row_bytes, (size_t)(off + blk / 4));
         }
         if (P == 1) pl.pop_pk_off[1] = pl.run_pk_off[w.n_pop];
+        p.n_run = w.n_pop;
         pl.word_run.assign(pl.run_pk_off[w.n_pop] / 16, 0);
         for (int q = 0; q < w.n_pop; q++)
             for (int b = pl.run_pk_off[q] / 16; b < pl.run_pk_off[q + 1] / 16; b++) pl.word_run[b] = (uint8_t)q;

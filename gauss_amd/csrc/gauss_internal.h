@@ -40,6 +40,7 @@ struct Prob {
     int n_rhs;              // right-hand sides of the solve: U (imputation) or n_predm + U (QCAT)
     int U_raw;              // rows of raw_u; U = U_raw * (number of codings)
     int code_blk[3];        // coding of B21 row block b: 0 additive, 1 dominant, 2 recessive (gauss.cpp:1196-1250)
+    int n_run;              // 2-bit sources: number of source blocks (selected populations)
     int geno_fmt;           // 0: one byte per genotype (ASCII digit or small integer); 1: 2-bit packed blocks
     int gram_i8;            // 1: operands are raw codes and slabs hold int32 (i8 MFMA path); 0: e4m3 codes, f32 slabs
     double lambda, eps, diag;

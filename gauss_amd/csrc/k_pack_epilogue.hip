@@ -45,38 +45,57 @@ __global__ __launch_bounds__(256) void pack_stats_kernel(const Prob* __restrict_
 
     __shared__ int s_sx[64];
     __shared__ int s_sxx[64];
+    // word -> source block tables staged in LDS: looked up once per 16 samples, and a chain of dependent global
+    // loads (word table -> offsets -> data) would set the pace of the whole kernel
+    constexpr int PACK_LDS_WORDS = 8192;
+    __shared__ uint8_t s_word[PACK_LDS_WORDS];
+    __shared__ int s_pk[65], s_src[65], s_len[64];
     if (threadIdx.x < 64) { s_sx[threadIdx.x] = 0; s_sxx[threadIdx.x] = 0; }
+    const int nwords = pb.Kp >> 4;                 // a multiple of 4 (Kp is a multiple of 64)
+    const bool fmt2 = pb.geno_fmt != 0;
+    const int n_tab = fmt2 ? pb.n_run : pb.P;      // source blocks ("runs"): populations, or 2-bit blocks
+    const bool tab_lds = nwords <= PACK_LDS_WORDS;
+    {
+        const auto wt = fmt2 ? pb.word_run : pb.word_pop;
+        if (tab_lds)
+            for (int w = threadIdx.x; w < nwords; w += 256) s_word[w] = wt[w];
+        if (threadIdx.x < n_tab) {
+            const int r = threadIdx.x;
+            s_pk[r] = fmt2 ? pb.run_pk_off[r] : pb.pop_pk_off[r];
+            s_src[r] = fmt2 ? pb.run_src[r] : pb.pop_raw_off[r];
+            s_len[r] = fmt2 ? 0 : pb.pop_raw_off[r + 1] - pb.pop_raw_off[r];
+        }
+    }
     __syncthreads();
 
-    const int nwords = pb.Kp >> 4;                 // a multiple of 4 (Kp is a multiple of 64)
     const int nloop = (nwords + 255) & ~255;
     for (int w0 = threadIdx.x; w0 < nloop; w0 += 256) {
         const bool live = w0 < nwords;                // keep whole waves in the loop for the cross-lane sums
         const int w = live ? w0 : nwords - 1;
-        const int p = pb.word_pop[w];
-        const int o = (w << 4) - pb.pop_pk_off[p];
-        const int m = pb.pop_raw_off[p + 1] - pb.pop_raw_off[p];
-        int valid = m - o;
-        valid = valid < 0 ? 0 : (valid > 16 ? 16 : valid);
-        if (!live) valid = 0;
+        const int run = tab_lds ? s_word[w] : (fmt2 ? pb.word_run[w] : pb.word_pop[w]);
+        const int p = (pb.P == 1) ? 0 : run;          // pooled statistics see one pseudo-population
+        const int o = (w << 4) - s_pk[run];
         uint32_t v[4] = {0u, 0u, 0u, 0u};
-        const uint8_t* s = src + pb.pop_raw_off[p] + o;
-        if (pb.geno_fmt) {
+        if (fmt2) {
             // 2-bit packed source: 16 samples = 4 bytes; blocks are 16-byte aligned and zero padded to 64
             // samples, i.e. they have exactly the packed operand layout at a quarter of the bytes
-            const int run = pb.word_run[w];
-            const int ro = (w << 4) - pb.run_pk_off[run];
-            const uint32_t bits = live ? *reinterpret_cast<const uint32_t*>(src + pb.run_src[run] + (ro >> 2)) : 0u;
+            const uint32_t bits = live ? *reinterpret_cast<const uint32_t*>(src + s_src[run] + (o >> 2)) : 0u;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const uint32_t b = (bits >> (8 * q)) & 0xFFu;
                 v[q] = (b & 3u) | (((b >> 2) & 3u) << 8) | (((b >> 4) & 3u) << 16) | (((b >> 6) & 3u) << 24);
             }
-        } else if (valid == 16) {
-#pragma unroll
-            for (int q = 0; q < 4; q++) v[q] = reinterpret_cast<const U32u*>(s + 4 * q)->v;
         } else {
-            for (int b = 0; b < valid; b++) v[b >> 2] |= (uint32_t)s[b] << (8 * (b & 3));
+            int valid = s_len[run] - o;
+            valid = valid < 0 ? 0 : (valid > 16 ? 16 : valid);
+            if (!live) valid = 0;
+            const uint8_t* s = src + s_src[run] + o;
+            if (valid == 16) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) v[q] = reinterpret_cast<const U32u*>(s + 4 * q)->v;
+            } else {
+                for (int b = 0; b < valid; b++) v[b >> 2] |= (uint32_t)s[b] << (8 * (b & 3));
+            }
         }
         int sx = 0, sxx = 0;
 #pragma unroll
