@@ -460,7 +460,7 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
         if (!p.ld_only) {
             // the LD epilogue writes B11 (and its shifted twin) and B21 for every window that is not a plain
             // gauss_ld / gene batch; the factor and solve scratch only exists when there is something to solve
-            w.A = wa.take((size_t)(p.npanel > 0 ? 4 : 2) * p.Mld * p.Mld * sizeof(double));
+            w.A = wa.take((size_t)(p.npanel > 0 ? 5 : 2) * p.Mld * p.Mld * sizeof(double));   // A0 A1 [L0 L1 W0]
             w.B21 = wa.take((size_t)std::max(p.U, 1) * p.Mld * sizeof(double));
         }
         if (p.npanel > 0) {
@@ -681,6 +681,7 @@ static int job_clamp_window(gauss_job* job, int i, int* status_bits)
     HIPCHK(hipMalloc((void**)&d_pm, sizeof(int2) * pm.size()));
     HIPCHK(hipMemcpyAsync(d_pm, pm.data(), sizeof(int2) * pm.size(), hipMemcpyHostToDevice, st));
     if (pl.out_b11) HIPCHK(hipMemcpyAsync(pl.d_b11_copy, p.A, sizeof(double) * n * n, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(p.A + 4 * n * n, p.A, sizeof(double) * n * n, hipMemcpyDeviceToDevice, st));   // W0 = clamped B11
     for (int s = 0; s < p.nblk; s++) {
         // launch over all problems would redo the others; use a single-problem launch instead
         launch_factor_step(job->d_probs + i, 1, s, p.nblk, st);

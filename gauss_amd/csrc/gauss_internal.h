@@ -74,7 +74,7 @@ struct Prob {
     GP(double) rt_mu;          // [Sp x P] Sx_p / m_p
     GP(double) rt_wmu;         // [Sp x P] w_p * mu_p
     GP(const double) z1;       // [M]
-    GP(double) A;              // [4][Mld x Mld] row-major: B11, B11 - eps*I, and their factors L0, L1
+    GP(double) A;              // [5][Mld x Mld] row-major: B11, B11 - eps*I, their factors L0, L1, working copy W0 of B11
     GP(double) Linv;           // [2][nblk][NB x NB] inverses of the diagonal Cholesky blocks
     GP(double) B21;            // [Upad x Mld] row-major (Upad = npanel*NRU rounded)
     GP(double) V;              // [npanel][Mld][NR]

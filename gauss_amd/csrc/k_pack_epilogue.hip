@@ -455,6 +455,10 @@ __global__ __launch_bounds__(1024) void epilogue_kernel(const Prob* __restrict__
                 const auto A1 = pb.A + (size_t)Mld * Mld;
                 A0[(size_t)ri * Mld + rj] = v0; A0[(size_t)rj * Mld + ri] = v0;
                 A1[(size_t)ri * Mld + rj] = v1; A1[(size_t)rj * Mld + ri] = v1;
+                if (pb.npanel > 0) {                              // working copy of B11 for the in-place factorisation
+                    const auto W0 = pb.A + (size_t)4 * Mld * Mld;
+                    W0[(size_t)ri * Mld + rj] = v0; W0[(size_t)rj * Mld + ri] = v0;
+                }
             } else {
                 const int u = ri - pb.Mp;                         // unmeasured row (x), measured col (y)
                 if (u >= pb.U || rj >= pb.M) continue;

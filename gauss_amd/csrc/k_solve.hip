@@ -155,12 +155,28 @@ __device__ int tile_chol_inv(double* __restrict__ D, double* __restrict__ X, int
     return *s_flag;
 }
 
-// Layout of the factor workspace of one problem: pb.A = [A0 | A1 | L0 | L1], each Mld x Mld
+// Layout of the factor workspace of one problem: pb.A = [A0 | A1 | L0 | L1 | W0], each Mld x Mld
 // row-major; pb.Linv = [2][nblk][NB x NB] inverses of the diagonal blocks of L.
 
 // ------------------------------------------------------------------------------------------
-// K5a: factor the first diagonal block of both matrices of every problem.
+// K5: right-looking blocked Cholesky (block 64) of both matrices of every problem.
+// Working copies: matrix 0 is factored in W0 = pb.A + 4 ld^2 (the epilogue writes B11 there as well; A[0]
+// itself stays intact for QCAT right-hand sides, B11 export and the clamp path), matrix 1 = B11 - eps I is
+// factored in place in A[1] (nobody needs it afterwards).  L goes to A[2], A[3], the inverses of the diagonal
+// blocks to pb.Linv.  Per block column s:
+//   panel(s):   L[k][s] = W[k][s] * Linv_ss^T                      for k > s        (one product per workgroup)
+//   update(s):  W[k][j] -= L[k][s] * L[j][s]^T                      for s < j <= k   (one product per workgroup)
+//               and the workgroup of tile (s+1, s+1) -- dispatched first -- goes on to factor that tile and
+//               to invert the factor, so that panel(s+1) finds L_dd^-1 ready.
+// Every step is the same short dependency chain (one product, one product + 64x64 Cholesky) whatever s is;
+// the left-looking variant this replaces chained s products per workgroup.
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ GP(double) factor_work(const Prob& pb, int mat)
+{
+    const size_t ld2 = (size_t)pb.Mld * pb.Mld;
+    return mat == 0 ? pb.A + 4 * ld2 : pb.A + ld2;
+}
+
 __global__ __launch_bounds__(256) void factor_init_kernel(const Prob* __restrict__ probs)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -171,9 +187,9 @@ __global__ __launch_bounds__(256) void factor_init_kernel(const Prob* __restrict
     const int mat = blockIdx.x & 1;
     if (pb.ld_only || pb.npanel == 0) return;
     const int tid = threadIdx.x, ld = pb.Mld;
-    const auto A = pb.A + (size_t)mat * ld * ld;
+    const auto W = factor_work(pb, mat);
     const auto Lm = pb.A + (size_t)(2 + mat) * ld * ld;
-    tile_load(TD, A, ld, tid);
+    tile_load(TD, W, ld, tid);
     const int fail = tile_chol_inv(TD, TX, tid, &s_flag);
     tile_store(Lm, ld, TD, tid);
     const auto Li = pb.Linv + (size_t)mat * pb.nblk * NB * NB;
@@ -181,110 +197,109 @@ __global__ __launch_bounds__(256) void factor_init_kernel(const Prob* __restrict
     if (fail && tid == 0) pb.status[mat] = 1;
 }
 
-// ------------------------------------------------------------------------------------------
-// K5b: block column s of L (left-looking), for every problem and both matrices.
-//   workgroup bi (s < bi < nblk):
-//       C        = A[bi][s] - sum_{j<s} L[bi][j] L[s][j]^T
-//       L[bi][s] = C * Linv_ss^T
-//   the workgroup bi = s+1 then also finishes the next diagonal block, so that the next launch
-//   finds L[s+1][s+1] and its inverse ready and no workgroup ever waits on another one:
-//       D = A[s+1][s+1] - sum_{j<=s} L[s+1][j] L[s+1][j]^T ;  D = L_d L_d^T ;  Linv_{s+1} = L_d^-1
-// grid.x = max_nblk - 1 - s, grid.y = problem * 2 + matrix.
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void factor_col_kernel(const Prob* __restrict__ probs, int s)
+// panel(s): grid.x = max_nblk - 1 - s (block row k = s + 1 + x), grid.y = problem * 2 + matrix
+__global__ __launch_bounds__(256) void factor_panel_kernel(const Prob* __restrict__ probs, int s)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    double* TA = smem;                 // L[bi][j]           | C            | L_new  | X
-    double* TB = TA + NB * LDT;        // L[s][j]            | Linv_ss      | D
-    __shared__ int s_flag;
-
+    double* TA = smem;                 // W[k][s]
+    double* TB = TA + NB * LDT;        // Linv_ss
     const Prob& pb = probs[blockIdx.y >> 1];
     const int mat = blockIdx.y & 1;
     if (pb.ld_only || pb.npanel == 0) return;
     const int nb = pb.nblk;
-    const int bi = s + 1 + blockIdx.x;
-    if (bi >= nb) return;
-    const bool next_diag = (bi == s + 1);
-
+    const int k = s + 1 + blockIdx.x;
+    if (k >= nb) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ld = pb.Mld;
-    const auto A = pb.A + (size_t)mat * ld * ld;
+    const auto W = factor_work(pb, mat);
     const auto Lm = pb.A + (size_t)(2 + mat) * ld * ld;
-
-    f64x4 acc[4], accd[4];
-#pragma unroll
-    for (int n = 0; n < 4; n++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int row = acc_row(wave, lane, r), col = acc_col(lane, n);
-            acc[n][r] = A[(size_t)(bi * NB + row) * ld + s * NB + col];
-            accd[n][r] = next_diag ? A[(size_t)(bi * NB + row) * ld + bi * NB + col] : 0.0;
-        }
-    TileRegs ra, rb;
-    if (s > 0) {
-        tile_fetch(ra, Lm + (size_t)bi * NB * ld, ld, tid);
-        tile_fetch(rb, Lm + (size_t)s * NB * ld, ld, tid);
-    }
-    for (int j = 0; j < s; j++) {
-        __syncthreads();                              // previous tiles are no longer being read
-        tile_commit<LDT>(TA, ra, tid);
-        tile_commit<LDT>(TB, rb, tid);
-        __syncthreads();
-        if (j + 1 < s) {                              // next tiles fly during the products
-            tile_fetch(ra, Lm + (size_t)bi * NB * ld + (size_t)(j + 1) * NB, ld, tid);
-            tile_fetch(rb, Lm + (size_t)s * NB * ld + (size_t)(j + 1) * NB, ld, tid);
-        }
-        mfma_nt<4, true>(acc, TA, TB, wave, lane);
-        if (next_diag) mfma_nt<4, true>(accd, TA, TA, wave, lane);
-    }
-    __syncthreads();
-    // TA <- C, TB <- Linv_ss
-#pragma unroll
-    for (int n = 0; n < 4; n++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) TA[acc_row(wave, lane, r) * LDT + acc_col(lane, n)] = acc[n][r];
+    TileRegs ra;
+    tile_fetch(ra, W + (size_t)k * NB * ld + (size_t)s * NB, ld, tid);
     {
         const auto Li = pb.Linv + ((size_t)mat * nb + s) * NB * NB;
         for (int e = tid; e < NB * NB; e += 256) TB[(e >> 6) * LDT + (e & 63)] = Li[e];
     }
+    tile_commit<LDT>(TA, ra, tid);
     __syncthreads();
+    f64x4 acc[4];
 #pragma unroll
     for (int n = 0; n < 4; n++) acc[n] = f64x4{0.0, 0.0, 0.0, 0.0};
-    mfma_nt<4, false>(acc, TA, TB, wave, lane);              // L[bi][s] = C * Linv_ss^T
-    __syncthreads();
+    mfma_nt<4, false>(acc, TA, TB, wave, lane);              // L[k][s] = W[k][s] * Linv_ss^T
 #pragma unroll
     for (int n = 0; n < 4; n++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int row = acc_row(wave, lane, r), col = acc_col(lane, n);
-            Lm[(size_t)(bi * NB + row) * ld + s * NB + col] = acc[n][r];
-            TA[row * LDT + col] = acc[n][r];
-        }
-    if (!next_diag) return;
-    __syncthreads();
-    mfma_nt<4, true>(accd, TA, TA, wave, lane);              // D -= L[s+1][s] L[s+1][s]^T
+        for (int r = 0; r < 4; r++)
+            Lm[(size_t)(k * NB + acc_row(wave, lane, r)) * ld + s * NB + acc_col(lane, n)] = acc[n][r];
+}
+
+// update(s): grid.x = T (T + 1) / 2 with T = max_nblk - 1 - s; x = 0 is tile (s+1, s+1)
+__global__ __launch_bounds__(256) void factor_update_kernel(const Prob* __restrict__ probs, int s, int T)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* TA = smem;                 // L[k][s]            | D (next diagonal tile)
+    double* TB = TA + NB * LDT;        // L[j][s]            | its inverse
+    __shared__ int s_flag;
+    const Prob& pb = probs[blockIdx.y >> 1];
+    const int mat = blockIdx.y & 1;
+    if (pb.ld_only || pb.npanel == 0) return;
+    const int nb = pb.nblk;
+    // x -> (jj, kk), 0 <= jj <= kk < T, column-major over the lower triangle: x = 0 is (0, 0)
+    int jj = 0, rem = blockIdx.x;
+    while (rem >= T - jj) { rem -= T - jj; jj++; }
+    const int kk = jj + rem;
+    const int j = s + 1 + jj, k = s + 1 + kk;
+    if (k >= nb) return;
+    const bool next_diag = (jj == 0 && kk == 0);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ld = pb.Mld;
+    const auto W = factor_work(pb, mat);
+    const auto Lm = pb.A + (size_t)(2 + mat) * ld * ld;
+    TileRegs ra, rb;
+    tile_fetch(ra, Lm + (size_t)k * NB * ld + (size_t)s * NB, ld, tid);
+    if (k != j) tile_fetch(rb, Lm + (size_t)j * NB * ld + (size_t)s * NB, ld, tid);
+    f64x4 acc[4];
 #pragma unroll
     for (int n = 0; n < 4; n++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) TB[acc_row(wave, lane, r) * LDT + acc_col(lane, n)] = accd[n][r];
+        for (int r = 0; r < 4; r++)
+            acc[n][r] = W[(size_t)(k * NB + acc_row(wave, lane, r)) * ld + j * NB + acc_col(lane, n)];
+    tile_commit<LDT>(TA, ra, tid);
+    if (k != j) tile_commit<LDT>(TB, rb, tid);
     __syncthreads();
-    const int fail = tile_chol_inv(TB, TA, tid, &s_flag);    // TB = L_dd, TA = its inverse
-    tile_store(Lm + (size_t)bi * NB * ld + (size_t)bi * NB, ld, TB, tid);
-    const auto Li = pb.Linv + ((size_t)mat * nb + bi) * NB * NB;
-    for (int e = tid; e < NB * NB; e += 256) Li[e] = TA[(e >> 6) * LDT + (e & 63)];
+    mfma_nt<4, true>(acc, TA, (k != j) ? TB : TA, wave, lane);       // W[k][j] -= L[k][s] L[j][s]^T
+    if (!next_diag) {
+#pragma unroll
+        for (int n = 0; n < 4; n++)
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                W[(size_t)(k * NB + acc_row(wave, lane, r)) * ld + j * NB + acc_col(lane, n)] = acc[n][r];
+        return;
+    }
+    __syncthreads();                                                  // everyone is done reading TA
+#pragma unroll
+    for (int n = 0; n < 4; n++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) TA[acc_row(wave, lane, r) * LDT + acc_col(lane, n)] = acc[n][r];
+    __syncthreads();
+    const int fail = tile_chol_inv(TA, TB, tid, &s_flag);             // TA = L_dd, TB = its inverse
+    tile_store(Lm + (size_t)k * NB * ld + (size_t)k * NB, ld, TA, tid);
+    const auto Li = pb.Linv + ((size_t)mat * nb + k) * NB * NB;
+    for (int e = tid; e < NB * NB; e += 256) Li[e] = TB[(e >> 6) * LDT + (e & 63)];
     if (fail && tid == 0) pb.status[mat] = 1;
 }
 
 static const size_t FACTOR_SMEM = (size_t)2 * NB * LDT * sizeof(double);
 
-// step 0 factors the first diagonal block; step s >= 1 builds block column s-1
+// step 0 factors the first diagonal block; step s >= 1 builds block column s-1 and updates the trailing matrix
 void launch_factor_step(const Prob* d_probs, int n_prob, int step, int max_nblk, hipStream_t st)
 {
     if (n_prob <= 0 || step >= max_nblk) return;
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(factor_init_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FACTOR_SMEM);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(factor_col_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FACTOR_SMEM);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(factor_panel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FACTOR_SMEM);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(factor_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FACTOR_SMEM);
         attr_set = true;
     }
     if (step == 0) {
@@ -292,9 +307,10 @@ void launch_factor_step(const Prob* d_probs, int n_prob, int step, int max_nblk,
         return;
     }
     const int s = step - 1;
-    const int rows = max_nblk - 1 - s;
-    if (rows <= 0) return;
-    hipLaunchKernelGGL(factor_col_kernel, dim3(rows, n_prob * 2), dim3(256), FACTOR_SMEM, st, d_probs, s);
+    const int T = max_nblk - 1 - s;
+    if (T <= 0) return;
+    hipLaunchKernelGGL(factor_panel_kernel, dim3(T, n_prob * 2), dim3(256), FACTOR_SMEM, st, d_probs, s);
+    hipLaunchKernelGGL(factor_update_kernel, dim3(T * (T + 1) / 2, n_prob * 2), dim3(256), FACTOR_SMEM, st, d_probs, s, T);
 }
 
 // ------------------------------------------------------------------------------------------
