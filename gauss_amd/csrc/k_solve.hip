@@ -103,54 +103,71 @@ __device__ __forceinline__ void tile_commit(double* __restrict__ T, const TileRe
     }
 }
 
-// In-place Cholesky of the 64x64 LDS tile D (lower triangle result, upper zeroed), followed by
-// the inverse of the factor into X (both [row][col] with leading dimension LDT).  Returns
-// (block-uniform) 1 if a pivot was not positive.  A dependency chain of 64 columns: run by ONE
-// wave (lane = row) that needs no workgroup barriers -- the LDS operations of a wave complete in
-// order.  Left-looking:  s_i = a_ij - sum_{k<j} l_ik l_jk ;  l_jj = sqrt(s_j) ;  l_ij = s_i / l_jj
-// then X = L^-1 by forward substitution, lane = column of X.
+// In-place Cholesky of the 64x64 LDS tile D (lower triangle result, upper zeroed) together with the
+// inverse of the factor in X (both [row][col] with leading dimension LDT).  Returns (block-uniform) 1
+// if a pivot was not positive.  Right-looking, all four waves, two barriers per column j:
+//   phase 1 (wave 0, lane c):   d = sqrt(D[j][j]);  L[c][j] = D[c][j] / d  (c > j),  L[j][j] = d;
+//                               X[j][c] = T[j][c] / d  (c <= j)   -- row j of L^-1, T starts as I --
+//                               M[c] = L[c][j] for c > j,  X[j][c] for c <= j
+//   phase 2 (rows i > j dealt round-robin to the waves, lane = column c <= i):
+//                               c >  j:  D[i][c] -= L[i][j] * L[c][j]     (trailing update of the Cholesky)
+//                               c <= j:  X[i][c] -= L[i][j] * X[j][c]     (forward substitution of L X = I)
+// i.e. one fused rank-1 sweep per column; every LDS access of phase 2 is row-contiguous.  The single-wave
+// left-looking routine this replaces took 75 us per tile (a chain of ~8000 dependent LDS reads).
 __device__ int tile_chol_inv(double* __restrict__ D, double* __restrict__ X, int tid, int* s_flag)
 {
+    __shared__ double s_lc[NB];      // column j of L
+    __shared__ double s_m[NB];       // the row multiplier M of phase 2
+    const int lane = tid & 63, wave = tid >> 6;
     if (tid == 0) *s_flag = 0;
+    for (int e = tid; e < NB * NB; e += 256) X[(e >> 6) * LDT + (e & 63)] = ((e >> 6) == (e & 63)) ? 1.0 : 0.0;
     __syncthreads();
-    if (tid < NB) {
-        const int i = tid;
-        int bad = 0;
-        for (int j = 0; j < NB; j++) {
-            double s0 = D[i * LDT + j], s1 = 0.0, s2 = 0.0, s3 = 0.0;
-            int k = 0;
-            for (; k + 3 < j; k += 4) {
-                s0 = fma(-D[i * LDT + k], D[j * LDT + k], s0);
-                s1 = fma(-D[i * LDT + k + 1], D[j * LDT + k + 1], s1);
-                s2 = fma(-D[i * LDT + k + 2], D[j * LDT + k + 2], s2);
-                s3 = fma(-D[i * LDT + k + 3], D[j * LDT + k + 3], s3);
-            }
-            for (; k < j; k++) s0 = fma(-D[i * LDT + k], D[j * LDT + k], s0);
-            const double s = (s0 + s1) + (s2 + s3);
-            const double piv = __shfl(s, j);
+    int bad = 0;
+    for (int j = 0; j < NB; j++) {
+        if (wave == 0) {
+            const int c = lane;
+            const double piv = D[j * LDT + j];
             if (!(piv > 0.0)) bad = 1;
-            const double d = sqrt(piv);
-            const double l = (i == j) ? d : ((i > j) ? s / d : 0.0);
-            WAVE_LDS_SYNC();                       // every lane has finished reading column/row data
-            D[i * LDT + j] = l;
-            WAVE_LDS_SYNC();                       // column j visible to the whole wave
+            const double a = D[c * LDT + j];
+            const double t = X[j * LDT + c];
+            // 1/sqrt(piv) by v_rsq_f64 + two Newton steps (full double accuracy) instead of an fp64 sqrt and two
+            // fp64 divisions on the 64-step critical path; a non-positive pivot gives NaN and is flagged above
+            double r = __builtin_amdgcn_rsq(piv);
+            const double h = 0.5 * piv;
+            r = fma(r, fma(-h * r, r, 0.5), r);
+            r = fma(r, fma(-h * r, r, 0.5), r);
+            double d = piv * r;
+            d = fma(fma(-d, d, piv), 0.5 * r, d);
+            const double l = (c == j) ? d : ((c > j) ? a * r : 0.0);
+            const double x = (c <= j) ? t * r : 0.0;
+            D[c * LDT + j] = l;
+            X[j * LDT + c] = x;
+            s_lc[c] = l;
+            s_m[c] = (c > j) ? l : x;
         }
-        const int c = tid;                         // X = L^-1 : lane c owns column c
-        for (int r = 0; r < NB; r++) {
-            double s0 = (r == c) ? 1.0 : 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-            int k = 0;
-            for (; k + 3 < r; k += 4) {
-                s0 = fma(-D[r * LDT + k], X[k * LDT + c], s0);
-                s1 = fma(-D[r * LDT + k + 1], X[(k + 1) * LDT + c], s1);
-                s2 = fma(-D[r * LDT + k + 2], X[(k + 2) * LDT + c], s2);
-                s3 = fma(-D[r * LDT + k + 3], X[(k + 3) * LDT + c], s3);
+        __syncthreads();
+        {
+            const int c = lane;
+            const double m = s_m[c];
+            double* const base = (c > j) ? D : X;
+            // every row of this wave's share (at most 16) is read before the first dependent op
+            const int i0 = j + 1 + wave;
+            double li[16], v[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) {
+                const int i = (i0 + 4 * u < NB) ? i0 + 4 * u : NB - 1;
+                li[u] = s_lc[i];
+                v[u] = base[i * LDT + c];
             }
-            for (; k < r; k++) s0 = fma(-D[r * LDT + k], X[k * LDT + c], s0);
-            const double x = (r >= c) ? ((s0 + s1) + (s2 + s3)) / D[r * LDT + r] : 0.0;
-            X[r * LDT + c] = x;                    // only this lane ever reads column c of X
+#pragma unroll
+            for (int u = 0; u < 16; u++) {
+                const int i = i0 + 4 * u;
+                if (i < NB && c <= i) base[i * LDT + c] = fma(-li[u], m, v[u]);
+            }
         }
-        if (bad) *s_flag = 1;
+        __syncthreads();
     }
+    if (bad) *s_flag = 1;            // only wave 0 ever sets bad
     __syncthreads();
     return *s_flag;
 }
