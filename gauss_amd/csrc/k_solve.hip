@@ -26,7 +26,7 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 constexpr int LDT = NB + 2;    // LDS leading dimension of a 64 x 64 [row][k] tile: 66 doubles = 528 B;
                                // 528 mod 256 = 16 puts the 32 lanes of a ds_read_b64 group on distinct banks
-constexpr int LDV = 80;        // LDS leading dimension of a 64 x 64 [k][col] tile: 640 B, 640 mod 256 = 128
+constexpr int LDV = 66;        // LDS leading dimension of a 64 x 64 [k][col] tile; with LDT = 66 a solve workgroup needs 73.6 KB of LDS: two per CU
 
 #define WAVE_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
