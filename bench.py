@@ -195,7 +195,7 @@ def main():
     # the same job with the LD Gram on the int8 matrix cores (identical integers, identical outputs):
     # reported next to the headline, never as `value`
     i8_variant = None
-    if args.gram_dtype == "f32" and not args.no_i8_variant and args.streams == 1:
+    if args.gram_dtype == "f32" and not args.no_i8_variant and args.streams == 1 and world == 1:
         ctx.set_gram_dtype("i8")
         j8 = hotpath.Job(descs, ctx=ctx, on_device=True)
         ctx.set_gram_dtype("f32")
@@ -267,7 +267,7 @@ def main():
         }
         if i8_variant is not None:
             out["int8_exact_variant"] = i8_variant
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:        # the CPU baseline is timed at N = 1 only
             out["cpu_baseline"] = cpu_baseline(ch, wins, keep, work)
         print(json.dumps(out), flush=True)
     if dist is not None:
