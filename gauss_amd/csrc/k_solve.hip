@@ -150,19 +150,20 @@ __device__ int tile_chol_inv(double* __restrict__ D, double* __restrict__ X, int
             const int c = lane;
             const double m = s_m[c];
             double* const base = (c > j) ? D : X;
-            // every row of this wave's share (at most 16) is read before the first dependent op
-            const int i0 = j + 1 + wave;
-            double li[16], v[16];
+            // rows j+1+wave, +4, ... in batches of four: the LDS reads of a batch are issued before its first
+            // dependent op; the LDS pipe is the bottleneck of this routine, so no row beyond NB is touched
+            for (int i0 = j + 1 + wave; i0 < NB; i0 += 16) {
+                double li[4], v[4];
 #pragma unroll
-            for (int u = 0; u < 16; u++) {
-                const int i = (i0 + 4 * u < NB) ? i0 + 4 * u : NB - 1;
-                li[u] = s_lc[i];
-                v[u] = base[i * LDT + c];
-            }
+                for (int u = 0; u < 4; u++) {
+                    const int i = i0 + 4 * u;
+                    if (i < NB) { li[u] = s_lc[i]; v[u] = base[i * LDT + c]; }
+                }
 #pragma unroll
-            for (int u = 0; u < 16; u++) {
-                const int i = i0 + 4 * u;
-                if (i < NB && c <= i) base[i * LDT + c] = fma(-li[u], m, v[u]);
+                for (int u = 0; u < 4; u++) {
+                    const int i = i0 + 4 * u;
+                    if (i < NB && c <= i) base[i * LDT + c] = fma(-li[u], m, v[u]);
+                }
             }
         }
         __syncthreads();
