@@ -144,6 +144,35 @@ def make_synthetic_study(outdir, pops, n_snp=400, chr_=22, bp_lo=1_000_000, bp_h
     return dict(paths=paths, bp=bp, rsid=rsid, a1=a1, a2=a2, G=G, af=af, pops=pops, measured=meas, annot=annot)
 
 
+def make_panel_for_gwas(outdir, pops, gwas_file, n_extra=800, frac_swapped=0.1, seed=7, prefix="cfg"):
+    """Synthetic panel (BGZF text index + data, population description) around an EXISTING GWAS summary file:
+    every GWAS SNP is in the panel (a fraction with the two alleles the other way round), plus n_extra panel-only
+    SNPs at random positions of the same range.  Returns dict(paths=...) like make_synthetic_study."""
+    import os
+    from . import synth
+    rng = np.random.default_rng(seed)
+    rows = [l.split() for l in open(gwas_file).read().splitlines()[1:] if l.strip()]
+    g_rsid = np.array([r[0] for r in rows]); g_chr = np.array([int(r[1]) for r in rows])
+    g_bp = np.array([int(r[2]) for r in rows]); g_a1 = np.array([r[3] for r in rows]); g_a2 = np.array([r[4] for r in rows])
+    ebp = rng.choice(np.setdiff1d(np.arange(g_bp.min(), g_bp.max()), g_bp), size=n_extra, replace=False)
+    alle = np.array(list("ACGT"))
+    e_a1 = alle[rng.integers(0, 4, n_extra)]
+    e_a2 = alle[(np.searchsorted(alle, e_a1) + rng.integers(1, 4, n_extra)) % 4]
+    swap = rng.random(len(rows)) < frac_swapped
+    p_a1 = np.where(swap, g_a2, g_a1); p_a2 = np.where(swap, g_a1, g_a2)
+    bp = np.concatenate([g_bp, ebp]); order = np.argsort(bp, kind="stable")
+    rsid = np.concatenate([g_rsid, [f"rsE{i}" for i in range(n_extra)]])[order]
+    chrs = np.concatenate([g_chr, np.full(n_extra, g_chr[0])])[order]
+    a1 = np.concatenate([p_a1, e_a1])[order]; a2 = np.concatenate([p_a2, e_a2])[order]
+    bp = bp[order]
+    G, af = synth.synth_genotypes(bp, pops, seed=seed + 1)
+    paths = {k: os.path.join(outdir, f"{prefix}_{k}") for k in ("desc.txt", "index.gz", "data.gz")}
+    paths["gwas.txt"] = gwas_file
+    write_pop_desc(paths["desc.txt"], pops)
+    write_panel(paths["index.gz"], paths["data.gz"], rsid, chrs, bp, a1, a2, G, af, [p[1] for p in pops])
+    return dict(paths=paths, bp=bp, rsid=rsid, pops=pops, n_swapped=int(swap.sum()))
+
+
 # ------------------------------------------------------------------------------------------
 # 2-bit packed genotype rows (include/gauss_hip.h, GAUSS_GENO_2BIT): every population block starts on
 # a 16-byte boundary and is zero padded to a multiple of 64 samples; sample s of a block sits at bits
