@@ -9,8 +9,10 @@ constexpr int TILE = 128;      // Gram output tile edge per workgroup (4 waves x
 constexpr int KC = 64;         // packed K chunk in bytes (= samples); pops are padded to it
 constexpr int SEG_MAX = 2048;  // max samples per K segment (split-K granularity)
 constexpr int NB = 64;         // fp64 factor / solve block edge
-constexpr int NR = 64;         // right-hand sides per solve panel (63 SNPs + the z1 column)
-constexpr int NRU = 63;
+constexpr int NR = 64;         // right-hand sides per solve panel (63 SNPs + the z1 column); the solve kernel is
+                               // written for any multiple of 64 -- 128 was measured slower (2.23 vs 1.80 ms: half as
+                               // many workgroups, each more than twice as long)
+constexpr int NRU = NR - 1;
 constexpr int WIN_QCAT = 1;          // gauss_window_desc.kind == GAUSS_WIN_QCAT
 constexpr int WIN_LD = 2;            // gauss_window_desc.kind == GAUSS_WIN_LD
 

@@ -26,7 +26,7 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 constexpr int LDT = NB + 2;    // LDS leading dimension of a 64 x 64 [row][k] tile: 66 doubles = 528 B;
                                // 528 mod 256 = 16 puts the 32 lanes of a ds_read_b64 group on distinct banks
-constexpr int LDV = 66;        // LDS leading dimension of a 64 x 64 [k][col] tile; with LDT = 66 a solve workgroup needs 73.6 KB of LDS: two per CU
+constexpr int LDV = NR + 2;     // LDS leading dimension of the 64 x NR [k][col] tile of the solve
 
 #define WAVE_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
@@ -332,7 +332,7 @@ void launch_factor_step(const Prob* d_probs, int n_prob, int step, int max_nblk,
 }
 
 // ------------------------------------------------------------------------------------------
-// K6/K7: forward substitution for one panel of NR = 64 right-hand sides (63 unmeasured SNPs'
+// K6/K7: forward substitution for one panel of NR right-hand sides (NR - 1 unmeasured SNPs'
 // b21 rows + the z1 column), left-looking over the 64-blocks of L, then z / info.
 // One workgroup per panel; panels are independent (no inter-workgroup traffic).
 //   V_k = Linv_kk * (B_k - sum_{j<k} L_kj V_j)
@@ -345,6 +345,9 @@ __global__ __launch_bounds__(256) void solve_kernel(const Prob* __restrict__ pro
     double* TL = smem;                       // [64][LDT]   L_kj, then Linv_kk
     double* TV = TL + NB * LDT;              // [64][LDV]   V_j, then the rhs block X, then V_k
     double* red = TV + NB * LDV;             // [3][256]
+    constexpr int NT = NR / 16;              // accumulator tiles (16 columns each) per wave
+    constexpr int NG = 256 / NR;             // row groups of the z / info reduction
+    constexpr int RG = NB / NG;              // rows per group
 
     const int2 pm = panelmap[blockIdx.x];
     const Prob& pb = probs[pm.x];
@@ -361,31 +364,34 @@ __global__ __launch_bounds__(256) void solve_kernel(const Prob* __restrict__ pro
     // (rows n_head .. of the symmetric A[0], which the factorisation leaves intact), then the B21 rows
     const auto Brow = pb.A + (size_t)pb.n_head * ld;
 
-    const int cc = tid & 63, rg = tid >> 6;                   // reduction: column cc, rows 16 rg ..
+    const int cc = tid % NR, rg = tid / NR;                   // reduction: column cc, rows RG rg ..
     double zsum = 0.0, isum = 0.0, vsum = 0.0;
 
     for (int kb = 0; kb < nb; kb++) {
-        f64x4 acc[4];
+        f64x4 acc[NT];
 #pragma unroll
-        for (int n = 0; n < 4; n++) acc[n] = f64x4{0.0, 0.0, 0.0, 0.0};
-        TileRegs rl, rv;
+        for (int n = 0; n < NT; n++) acc[n] = f64x4{0.0, 0.0, 0.0, 0.0};
+        TileRegs rl, rv[NR / 64];
         if (kb > 0) {
             tile_fetch(rl, Lm + (size_t)kb * NB * ld, ld, tid);
-            tile_fetch(rv, V, NR, tid);
+#pragma unroll
+            for (int h = 0; h < NR / 64; h++) tile_fetch(rv[h], V + 64 * h, NR, tid);
         }
         for (int jb = 0; jb < kb; jb++) {
             __syncthreads();                                  // previous tiles are no longer being read
             tile_commit<LDT>(TL, rl, tid);
-            tile_commit<LDV>(TV, rv, tid);
+#pragma unroll
+            for (int h = 0; h < NR / 64; h++) tile_commit<LDV>(TV + 64 * h, rv[h], tid);
             __syncthreads();
             if (jb + 1 < kb) {                                // next tiles fly during the product
                 tile_fetch(rl, Lm + (size_t)kb * NB * ld + (size_t)(jb + 1) * NB, ld, tid);
-                tile_fetch(rv, V + (size_t)(jb + 1) * NB * NR, NR, tid);
+#pragma unroll
+                for (int h = 0; h < NR / 64; h++) tile_fetch(rv[h], V + (size_t)(jb + 1) * NB * NR + 64 * h, NR, tid);
             }
-            mfma_nn<4, true>(acc, TL, TV, wave, lane);        // acc = - sum_j L_kj V_j
+            mfma_nn<NT, true>(acc, TL, TV, wave, lane);       // acc = - sum_j L_kj V_j
         }
         __syncthreads();
-        // TV <- rhs block: column c < 63: B21[u0+c][kb*64 + r]; column 63: z1 (zero padded)
+        // TV <- rhs block: column c < NRU: B21[u0+c][kb*64 + r]; column NRU: z1 (zero padded)
         for (int e = tid; e < NB * NR; e += 256) {
             const int c = e >> 6, r = e & 63;                 // r fastest: coalesced along a B21 row
             const int k = kb * NB + r;
@@ -404,16 +410,16 @@ __global__ __launch_bounds__(256) void solve_kernel(const Prob* __restrict__ pro
         }
         __syncthreads();
 #pragma unroll
-        for (int n = 0; n < 4; n++)
+        for (int n = 0; n < NT; n++)
 #pragma unroll
             for (int r = 0; r < 4; r++) TV[acc_row(wave, lane, r) * LDV + acc_col(lane, n)] += acc[n][r];
         __syncthreads();
 #pragma unroll
-        for (int n = 0; n < 4; n++) acc[n] = f64x4{0.0, 0.0, 0.0, 0.0};
-        mfma_nn<4, false>(acc, TL, TV, wave, lane);           // V_k = Linv_kk * X
+        for (int n = 0; n < NT; n++) acc[n] = f64x4{0.0, 0.0, 0.0, 0.0};
+        mfma_nn<NT, false>(acc, TL, TV, wave, lane);          // V_k = Linv_kk * X
         __syncthreads();
 #pragma unroll
-        for (int n = 0; n < 4; n++)
+        for (int n = 0; n < NT; n++)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int row = acc_row(wave, lane, r), col = acc_col(lane, n);
@@ -421,11 +427,11 @@ __global__ __launch_bounds__(256) void solve_kernel(const Prob* __restrict__ pro
                 V[(size_t)(kb * NB + row) * NR + col] = acc[n][r];
             }
         __syncthreads();
-        // accumulate z and info for column cc over this block's rows 16 rg .. 16 rg + 15
+        // accumulate z and info for column cc over this block's rows RG rg .. RG rg + RG - 1
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const double x = TV[(rg * 16 + r) * LDV + cc];
-            const double y = TV[(rg * 16 + r) * LDV + NRU];
+        for (int r = 0; r < RG; r++) {
+            const double x = TV[(rg * RG + r) * LDV + cc];
+            const double y = TV[(rg * RG + r) * LDV + NRU];
             zsum = fma(x, y, zsum);
             isum = fma(x, x, isum);
             vsum += x;
@@ -438,15 +444,15 @@ __global__ __launch_bounds__(256) void solve_kernel(const Prob* __restrict__ pro
     __syncthreads();
     if (tid < NRU) {
         double z = 0.0, info = 0.0;
-        for (int g = 0; g < 4; g++) { z += red[g * 64 + tid]; info += red[256 + g * 64 + tid]; }
+        for (int g = 0; g < NG; g++) { z += red[g * NR + tid]; info += red[256 + g * NR + tid]; }
         const int u = u0 + tid;
         if (qcat) {
             // r = CalCor(Linv z1, Linv b)  (util.cpp:72-101; qcat.cpp:221,239), vectors of length M
             double sv = 0.0, sy = 0.0, syy = 0.0;
-            for (int g = 0; g < 4; g++) {
-                sv += red[512 + g * 64 + tid];
-                sy += red[512 + g * 64 + NRU];
-                syy += red[256 + g * 64 + NRU];
+            for (int g = 0; g < NG; g++) {
+                sv += red[512 + g * NR + tid];
+                sy += red[512 + g * NR + NRU];
+                syy += red[256 + g * NR + NRU];
             }
             if (u < pb.n_rhs) {
                 const double n = (double)pb.M;
