@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstring>
 #include <deque>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -48,6 +49,7 @@ struct gauss_ctx {
     int device;
     hipStream_t stream;
     int gram_i8 = 0;
+    std::map<const void*, size_t> stores;    // row stores made by gauss_store_upload: base pointer -> bytes
 };
 
 static inline size_t rup(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -349,6 +351,33 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
         int rc = plan_problem(specs[i], job->plans[i], seg_max_for(specs.size()), group_target_for(specs.size()));
         if (rc) { delete job; return rc; }
         job->plans[i].p.gram_i8 = job->gram_i8;
+    }
+    // Row lists are resolved by the pack kernel: an index beyond the store would be an out-of-bounds read on the
+    // GPU.  Host stores cannot be checked (only a pointer is known), stores made by gauss_store_upload can.
+    for (int i = 0; i < job->n; i++) {
+        const Plan& pl = job->plans[i];
+        for (int side = 0; side < 2; side++) {
+            const std::vector<int32_t>& rows = side ? pl.rows_u : pl.rows_m;
+            const uint8_t* base = side ? pl.h_geno_u : pl.h_geno_m;
+            if (rows.empty()) continue;
+            long long mx = -1;
+            for (int32_t r : rows) {
+                if (r < 0) { delete job; return fail(GAUSS_E_INVALID, "window %d: negative row index %d", i, (int)r); }
+                mx = std::max<long long>(mx, r);
+            }
+            if (!on_device) continue;
+            // the store that contains `base` (a window may point into the middle of an uploaded store)
+            auto it = ctx->stores.upper_bound(base);
+            if (it == ctx->stores.begin()) continue;                      // not one of ours: caller's responsibility
+            --it;
+            const uint8_t* s0 = (const uint8_t*)it->first;
+            if (base >= s0 + it->second) continue;
+            const size_t need = (size_t)(base - s0) + (size_t)mx * (size_t)pl.user_ld + pl.row_bytes;
+            if (need > it->second) {
+                delete job;
+                return fail(GAUSS_E_INVALID, "window %d: row index %lld reaches past the end of the row store (%zu bytes)", i, mx, it->second);
+            }
+        }
     }
     HIPCHK(hipSetDevice(ctx->device));
 
@@ -851,6 +880,7 @@ int gauss_store_upload(gauss_ctx* ctx, const void* host_rows, int64_t bytes, voi
     if (e != hipSuccess) return fail(GAUSS_E_NOMEM, "hipMalloc(%lld bytes row store) failed: %s", (long long)bytes, hipGetErrorString(e));
     e = hipMemcpy(d, host_rows, (size_t)bytes, hipMemcpyHostToDevice);
     if (e != hipSuccess) { hipFree(d); return fail(GAUSS_E_DEVICE, "row store upload failed: %s", hipGetErrorString(e)); }
+    ctx->stores[d] = (size_t)bytes;
     *out_device_ptr = d;
     return GAUSS_OK;
 }
@@ -859,7 +889,7 @@ int gauss_store_free(gauss_ctx* ctx, void* device_ptr)
 {
     if (!ctx) return fail(GAUSS_E_INVALID, "ctx is NULL");
     HIPCHK(hipSetDevice(ctx->device));
-    if (device_ptr) HIPCHK(hipFree(device_ptr));
+    if (device_ptr) { ctx->stores.erase(device_ptr); HIPCHK(hipFree(device_ptr)); }
     return GAUSS_OK;
 }
 

@@ -5,7 +5,7 @@ import pytest
 
 import oracle
 from gauss_amd import hotpath, synth
-from helpers import relerr
+from helpers import relerr, small_panel
 
 pytestmark = pytest.mark.gpu
 
@@ -235,3 +235,26 @@ def test_randomized_shapes_against_oracle(ctx):
             assert np.max(np.abs(got["b21"] - want["b21"])) <= 1e-12
             assert relerr(got["info"], want["info"]) <= 1e-7
             assert np.max(np.abs(got["z"] - want["z"]) / np.maximum(1.0, np.abs(want["z"]))) <= 1e-7
+
+
+def test_row_index_past_a_resident_store_is_refused(ctx):
+    """Row lists are resolved on the GPU; an index beyond a store made by gauss_store_upload must be caught on the
+    host (an out-of-bounds read there could fault the device), and so must a negative one."""
+    from gauss_amd import panel
+    p = small_panel(n_snp=60, scale=0.02, seed=81)
+    rows, _ = panel.pack2bit(p["G"], p["off"])
+    rs = hotpath.RowStore(rows, ctx=ctx)
+    z1 = np.zeros(20)
+    good = np.arange(20, dtype=np.int32)
+    for bad_u in (np.array([25, 26, len(rows)], dtype=np.int32), np.array([25, -1, 27], dtype=np.int32)):
+        with pytest.raises(Exception) as ei:
+            hotpath.Job([dict(mode=0, pop_off=p["off"], pop_wgt=None, z1=z1, dev=(rs.ptr, rs.ptr, 20, 3, rs.ld),
+                              packed=dict(fmt=1, rows_m=good, rows_u=bad_u))], ctx=ctx, on_device=True)
+        assert "row" in str(ei.value)
+    job = hotpath.Job([dict(mode=0, pop_off=p["off"], pop_wgt=None, z1=z1, dev=(rs.ptr, rs.ptr, 20, 3, rs.ld),
+                            packed=dict(fmt=1, rows_m=good, rows_u=np.array([25, 26, len(rows) - 1], dtype=np.int32)))],
+                      ctx=ctx, on_device=True)
+    job.run()
+    assert job.fetch()[0]["status"] == 0
+    job.close()
+    rs.close()
