@@ -30,7 +30,7 @@ KIND_COMPUTELD, KIND_DIST, KIND_DISTMIX, KIND_JEPEG, KIND_JEPEGMIX, KIND_QCAT, K
 HOST_SYMBOLS = [
     "gauss_host_last_error", "gauss_table_nrow", "gauss_table_ncol", "gauss_table_colname",
     "gauss_table_coltype", "gauss_table_str", "gauss_table_int", "gauss_table_dbl", "gauss_table_matrix",
-    "gauss_table_free", "gauss_host_computeLD", "gauss_host_dist", "gauss_host_distmix", "gauss_host_jepeg",
+    "gauss_table_free", "gauss_table_strcol", "gauss_host_computeLD", "gauss_host_dist", "gauss_host_distmix", "gauss_host_jepeg",
     "gauss_host_jepegmix", "gauss_host_qcat", "gauss_host_qcatmix", "gauss_prepared_qcat_counts",
     "gauss_host_prep_qcat", "gauss_host_prep_recessive_impute", "gauss_host_pack_panel", "gauss_prepared_packed_store", "gauss_host_prep_zmix5", "gauss_table_n_named", "gauss_table_named_name",
     "gauss_table_named", "gauss_host_prepare", "gauss_prepared_snps", "gauss_prepared_counts",
@@ -67,6 +67,8 @@ def load_host():
     h.gauss_table_colname.argtypes = [_vp, C.c_int]
     h.gauss_table_str.restype = _cp
     h.gauss_table_str.argtypes = [_vp, C.c_int, C.c_int]
+    h.gauss_table_strcol.restype = C.c_void_p
+    h.gauss_table_strcol.argtypes = [_vp, C.c_int, C.POINTER(_i64)]
     h.gauss_table_int.restype = C.POINTER(C.c_int32)
     h.gauss_table_int.argtypes = [_vp, C.c_int]
     h.gauss_table_dbl.restype = _dp
@@ -170,7 +172,9 @@ def _table(h, t, free=True):
         name = h.gauss_table_colname(t, c).decode()
         ty = h.gauss_table_coltype(t, c)
         if ty == 0:
-            cols[name] = [h.gauss_table_str(t, c, r).decode() for r in range(n)]
+            nb = _i64()
+            buf = h.gauss_table_strcol(t, c, C.byref(nb))       # one call per column, not one per cell
+            cols[name] = C.string_at(buf, nb.value).decode().split("\0")[:n] if (n and buf) else []
         elif ty == 1:
             cols[name] = np.ctypeslib.as_array(h.gauss_table_int(t, c), shape=(n,)).copy() if n else np.zeros(0, np.int32)
         else:

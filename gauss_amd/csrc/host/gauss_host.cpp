@@ -63,6 +63,7 @@ struct Column {
     std::string name;
     int type;
     std::vector<std::string> s;
+    mutable std::string joined;      // lazily built NUL-separated image of s (gauss_table_strcol)
     std::vector<int32_t> i;
     std::vector<double> d;
 };
@@ -996,6 +997,19 @@ const char* gauss_table_str(const gauss_table* t, int c, int r)
 const int32_t* gauss_table_int(const gauss_table* t, int c) { return (t && c >= 0 && c < (int)t->cols.size() && t->cols[c].type == GAUSS_COL_INT) ? t->cols[c].i.data() : nullptr; }
 const double* gauss_table_dbl(const gauss_table* t, int c) { return (t && c >= 0 && c < (int)t->cols.size() && t->cols[c].type == GAUSS_COL_DBL) ? t->cols[c].d.data() : nullptr; }
 const double* gauss_table_matrix(const gauss_table* t, int* n) { if (!t || t->matrix.empty()) { if (n) *n = 0; return nullptr; } if (n) *n = t->matrix_n; return t->matrix.data(); }
+const char* gauss_table_strcol(const gauss_table* t, int c, int64_t* bytes)
+{
+    if (!t || c < 0 || c >= (int)t->cols.size() || t->cols[c].type != GAUSS_COL_STR) return nullptr;
+    const Column& col = t->cols[c];
+    if (col.joined.empty() && !col.s.empty()) {
+        size_t n = 0;
+        for (const std::string& v : col.s) n += v.size() + 1;
+        col.joined.reserve(n);
+        for (const std::string& v : col.s) { col.joined += v; col.joined.push_back('\0'); }
+    }
+    if (bytes) *bytes = (int64_t)col.joined.size();
+    return col.joined.data();
+}
 void gauss_table_free(gauss_table* t) { delete t; }
 int gauss_table_n_named(const gauss_table* t) { return t ? (int)t->named.size() : 0; }
 const char* gauss_table_named_name(const gauss_table* t, int k) { return (t && k >= 0 && k < (int)t->named.size()) ? t->named[k].name.c_str() : nullptr; }

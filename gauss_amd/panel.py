@@ -215,3 +215,51 @@ def unpack2bit(rows, pop_sizes, src_off=None):
         codes = np.stack([(b >> (2 * k)) & 3 for k in range(4)], axis=2).reshape(rows.shape[0], -1)
         out.append(codes[:, :m])
     return np.concatenate(out, axis=1) if out else np.zeros((rows.shape[0], 0), dtype=np.uint8)
+
+
+def write_packed_panel(path, pops, rsid, chr_, bp, a1, a2, rows2bit, af, cnt, sorted_flag=None):
+    """Write a packed panel file (GAUSSPK1, gauss_amd/csrc/host/packed_panel.h) directly from arrays:
+    pops [(name, size, super)], per-SNP strings / positions, rows2bit (S, row_bytes) uint8 in the 2-bit
+    layout of pack2bit(), af (S, P) float64 and cnt (S, P) int32.  The C++ converter
+    (api.pack_panel) produces the same file from a BGZF text panel."""
+    import struct
+    S, P = len(rsid), len(pops)
+    rows2bit = np.ascontiguousarray(rows2bit, dtype=np.uint8)
+    row_bytes = rows2bit.shape[1]
+    src_off, ld = pack2bit_layout([q[1] for q in pops])
+    assert row_bytes == ld and row_bytes % 16 == 0 and rows2bit.shape[0] == S
+    if sorted_flag is None:
+        key = np.asarray(chr_, dtype=np.int64) * (1 << 40) + np.asarray(bp, dtype=np.int64)
+        sorted_flag = bool(np.all(np.diff(key) >= 0))
+    strings = bytearray()
+    def add(sv):
+        o = len(strings)
+        strings.extend(str(sv).encode() + b"\0")
+        return o
+    snp = np.zeros(S, dtype=[("chr", "<i4"), ("rsid", "<u4"), ("a1", "<u4"), ("a2", "<u4"), ("bp", "<i8")])
+    for i in range(S):
+        snp[i] = (int(chr_[i]), add(rsid[i]), add(a1[i]), add(a2[i]), int(bp[i]))
+    popb = b"".join(struct.pack("<24s24sII", q[0].encode(), q[2].encode(), int(q[1]), int(src_off[k])) for k, q in enumerate(pops))
+    al = lambda v, a: (v + a - 1) // a * a
+    off = 128
+    off_pops = off; off = al(off + len(popb), 64)
+    off_snps = off; off = al(off + snp.nbytes, 64)
+    off_str = off; off = al(off + len(strings), 64)
+    off_af = off; off = al(off + S * P * 8, 64)
+    off_cnt = off; off = al(off + S * P * 4, 4096)
+    off_geno = off; total = off + S * row_bytes
+    hdr = struct.pack("<8sIIQQQQQQQQQI36x", b"GAUSSPK1", 1, P, S, row_bytes, off_pops, off_snps, off_str, off_af, off_cnt,
+                      off_geno, total, 1 if sorted_flag else 0)
+    assert len(hdr) == 128
+    with open(path, "wb") as f:
+        f.write(hdr)
+        for o, b in ((off_pops, popb), (off_snps, snp.tobytes()), (off_str, bytes(strings)),
+                     (off_af, np.ascontiguousarray(af, dtype="<f8").tobytes()),
+                     (off_cnt, np.ascontiguousarray(cnt, dtype="<i4").tobytes())):
+            f.seek(o)
+            f.write(b)
+        f.seek(off_geno)
+        rows2bit.tofile(f)
+        if f.tell() < total:
+            f.truncate(total)
+    return total

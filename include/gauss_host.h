@@ -67,6 +67,8 @@ int gauss_table_coltype(const gauss_table* t, int col);
 const char* gauss_table_str(const gauss_table* t, int col, int row);
 const int32_t* gauss_table_int(const gauss_table* t, int col);
 const double* gauss_table_dbl(const gauss_table* t, int col);
+/* A whole string column at once: NUL-separated values in one buffer (n values, *bytes long in total). */
+const char* gauss_table_strcol(const gauss_table* t, int c, int64_t* bytes);
 /* Named numeric members of a result List (prep_qcat's z_vec / cor_mat1 / cor_mat2, prep_recessive_impute's
  * zvec / cormat / cormat_add / cormat_dom / cormat_rec): nrow x ncol, COLUMN-major like an R NumericMatrix
  * (vectors have ncol = 1). */

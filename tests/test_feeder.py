@@ -315,3 +315,17 @@ def test_packed_panel_jepeg_and_errors(study, packed, tmp_path):
         api.Prepared(api.KIND_DIST, chr=22, start_bp=1_400_000, end_bp=2_000_000, wing_size=250_000, study_pop="EUR",
                      input_file=inp, reference_index_file=idx, reference_data_file=packed, reference_pop_desc_file=str(bad))
     assert "populations" in str(ei.value)
+
+
+def test_python_packed_writer_is_byte_identical_to_the_converter(study, packed, tmp_path):
+    """panel.write_packed_panel (arrays -> GAUSSPK1) and api.pack_panel (BGZF text -> GAUSSPK1) must agree byte
+    for byte: two independent writers of the same format."""
+    sizes = [q[1] for q in POPS]
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    G = study["G"]
+    rows, _ = panel.pack2bit(G, off)
+    cnt = np.stack([G[:, off[k]:off[k + 1]].sum(1) for k in range(len(POPS))], axis=1)
+    out = str(tmp_path / "py.gpk")
+    panel.write_packed_panel(out, POPS, study["rsid"], np.full(len(G), 22), study["bp"], study["a1"], study["a2"], rows,
+                             study["af"], cnt)
+    assert open(out, "rb").read() == open(packed, "rb").read()
