@@ -42,3 +42,21 @@ def test_product_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in text and "from oracle" not in text, f
                 assert "liboracle" not in text, f
+
+
+def test_integration_snippets_compile_against_the_headers():
+    """The driver-side code of INTEGRATION.md (with a mock of the few reference types it touches) must compile
+    against include/gauss_hip.h: keeps the documented Rcpp bindings in step with the C ABI."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gxx = shutil.which("g++")
+    if gxx is None:
+        pytest.skip("g++ not available")
+    subprocess.check_call([gxx, "-std=c++17", "-fsyntax-only", "-Wall", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "tests", "abi", "integration_snippets.cpp")])
+    # and a plain C compiler must accept both headers (the boundary is a C ABI)
+    gcc = shutil.which("gcc")
+    src = os.path.join(root, "tests", "abi", "c_abi.c")
+    if gcc and os.path.exists(src):
+        subprocess.check_call([gcc, "-std=c99", "-fsyntax-only", "-Wall", "-I" + os.path.join(root, "include"), src])
