@@ -143,10 +143,21 @@ struct WinSpec {
 // a batch of windows has plenty of items already, and longer segments mean fewer partial slabs
 // for the epilogue to read back.  Either way a partial sum stays an exact f32 integer
 // (15 * 15 * 8192 < 2^24).
-static int seg_max_for(size_t n_windows) { return n_windows >= 4 ? 8192 : SEG_MAX; }
+static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+static int seg_max_for(size_t n_windows)
+{
+    static const int ov = env_int("GAUSS_SEG_MAX", 0);          // experiment override (multiple of 64)
+    if (ov > 0) return ov / KC * KC;
+    return n_windows >= 4 ? 8192 : SEG_MAX;
+}
 // Consecutive segments are chained into one work item until the run reaches this many samples
 // (a fresh item costs a pipeline fill: descriptor, first operand tiles, barrier).  0 = no chaining.
-static int group_target_for(size_t n_windows) { return n_windows >= 4 ? 4096 : 0; }
+static int group_target_for(size_t n_windows)
+{
+    static const int ov = env_int("GAUSS_GROUP_TARGET", -1);    // experiment override
+    if (ov >= 0) return ov;
+    return n_windows >= 4 ? 4096 : 0;
+}
 
 static int plan_problem(const WinSpec& w, Plan& pl, int seg_max, int group_target)
 {
