@@ -10,14 +10,14 @@
 // accumulation (bitwise a k-ordered fmaf chain) is exact in any summation order.  The k order
 // inside a chunk is therefore permuted freely to make the LDS reads wide.
 //
-// Work item = (tile pair, K segment).  Workgroup = 256 threads = 4 waves, each wave owns a
-// 64 x 64 sub-tile = 2 x 2 MFMA tiles of 32 x 32 (four independent accumulators keep the
-// 64-cycle MFMA pipe issuing back to back).  K is walked in chunks of KC = 64 bytes staged
-// through LDS with register prefetch (global -> VGPR -> LDS, write after the barrier).
+// Work item = (tile pair, run of K segments).  Workgroup = 256 threads = 4 waves, each wave owns a
+// 64 x 64 sub-tile = 2 x 2 MFMA tiles of 32 x 32 (four independent accumulators keep the MFMA pipe
+// issuing back to back).  K is walked in chunks of KC = 64 bytes staged by LDS-DMA
+// (global_load_lds_dwordx4) into a ring of NS chunk images (NS = 2: one chunk in flight while the previous
+// one is multiplied; the ring depth is a template parameter, deeper rings brought nothing).
 //
-// LDS image: [128 rows][80 bytes] per operand (64 data + 16 pad).  A ds_read_b128 is served in
-// groups of 16 lanes that hold 16 different rows; with an 80-byte (= 16 x 5) row stride those
-// 16 sixteen-byte slots are distinct modulo the 256-byte bank row: conflict-free.
+// LDS image: [128 rows][64 bytes] per operand, unpadded; the bank conflicts of the ds_read_b128 fragment
+// reads are avoided by an XOR swizzle applied to the DMA source address and to the read address.
 #include "gauss_internal.h"
 #include <cstdlib>
 
@@ -116,7 +116,24 @@ __device__ __forceinline__ float slab_bits(int v) { return __int_as_float(v); }
 // One work item for a wave with NA x NB live 32-row halves (NA = 0: staging and barriers only).
 // The K loop runs over the whole run of segments without draining the prefetch pipeline; at each
 // segment end the accumulators are flushed to that segment's slab and cleared.
-template <int NA, int NB, typename ACC>
+// s_waitcnt vmcnt(N) + workgroup barrier.  Vector memory operations complete in issue order, so "at most N
+// outstanding" means every DMA group but the newest N / 4 has landed in LDS (stores issued later, e.g. a slab
+// flush, only make the wait longer, never shorter).  lgkmcnt(0): this wave's LDS reads of the image about to be
+// overwritten are done.  The "memory" clobber keeps the compiler from moving LDS traffic across it.
+template <int N>
+__device__ __forceinline__ void wait_dma_barrier()
+{
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+template <int NS>
+__device__ __forceinline__ void wait_dma_barrier_dyn(int groups_newer)
+{
+    if (NS <= 2 || groups_newer <= 0) wait_dma_barrier<0>();
+    else if (groups_newer == 1) wait_dma_barrier<4>();
+    else wait_dma_barrier<8>();
+}
+
+template <int NA, int NB, typename ACC, int NS>
 __device__ __forceinline__ void run_item(const Item& it, uint8_t* lds, int wr, int wc)
 {
     const int Kp = it.Kp;
@@ -156,9 +173,15 @@ __device__ __forceinline__ void run_item(const Item& it, uint8_t* lds, int wr, i
             __builtin_amdgcn_global_load_lds((glb_ptr)Bg + gsrc[j] + (KOFF), (lds_ptr)(lds + (BUF) * 2 * LTILE + LTILE + t * 1024), 16, 0, 0);  \
         }                                                                                                        \
     }
+    // ring of NS chunk images: up to NS - 1 chunks are in flight beyond the one being multiplied
     int cur = 0;
-    GAUSS_STAGE(0, k0)
-    __syncthreads();                                              // waits for the DMA (vmcnt) and the other waves
+    int kpre = k0;                                                // next chunk to request
+    int ahead = 0;                                                // chunks requested and not yet consumed
+#pragma unroll
+    for (int d = 0; d < NS - 1; d++)
+        if (kpre < klast) { GAUSS_STAGE(d, kpre) kpre += KC; ahead++; }
+    wait_dma_barrier_dyn<NS>(ahead - 1);                          // the first chunk has landed (all waves)
+    ahead--;
 
     // fragment read offsets: logical piece 2g + lh of rows wr*64 + li (+32 has the same swizzle)
     const int sw = (li >> 2) & 3;
@@ -173,13 +196,21 @@ __device__ __forceinline__ void run_item(const Item& it, uint8_t* lds, int wr, i
     for (int seg = 0; seg < nseg; seg++) {
         const int kend = it.seg_k1[seg];
         for (; k < kend; k += KC) {
-            const bool more = (k + KC) < klast;          // the prefetch runs across segment ends
-            if (more) GAUSS_STAGE(cur ^ 1, k + KC)
+            // the image consumed in the previous iteration is free: request the chunk NS - 1 ahead into it
+            // (the prefetch runs across segment ends)
+            if (kpre < klast) {
+                int nb_ = cur + NS - 1;
+                if (nb_ >= NS) nb_ -= NS;
+                GAUSS_STAGE(nb_, kpre)
+                kpre += KC;
+                ahead++;
+            }
             const uint8_t* la = lds + cur * 2 * LTILE;
             const uint8_t* lb = la + LTILE;
             if (NA > 0) chunk_mfma<NA, NB>(la, lb, aoff, boff, acc00, acc01, acc10, acc11);
-            __syncthreads();                             // DMA of the next chunk landed; everyone is done reading
-            cur ^= 1;
+            wait_dma_barrier_dyn<NS>(ahead - 1);         // next chunk landed; everyone is done reading this one
+            if (ahead > 0) ahead--;
+            cur = (cur + 1 == NS) ? 0 : cur + 1;
         }
 #undef GAUSS_STAGE
         // end of a segment: flush its exact partial sums, start the next segment from zero.
@@ -202,10 +233,10 @@ __device__ __forceinline__ void run_item(const Item& it, uint8_t* lds, int wr, i
     }
 }
 
-template <typename ACC>
-__global__ __launch_bounds__(256, 4) void gram_kernel(const Item* __restrict__ items)
+template <typename ACC, int NS, int OCC>
+__global__ __launch_bounds__(256, OCC) void gram_kernel(const Item* __restrict__ items)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[2 * 2 * LTILE];
+    __shared__ __attribute__((aligned(16))) uint8_t lds[NS * 2 * LTILE];
 
     const Item& it = items[blockIdx.x];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -218,18 +249,25 @@ __global__ __launch_bounds__(256, 4) void gram_kernel(const Item* __restrict__ i
     nb = nb < 0 ? 0 : (nb > 2 ? 2 : nb);
     // diagonal tile: the lower-left 64 x 64 quadrant mirrors the upper-right one and is never read
     if (it.diag && wr == 1 && wc == 0) na = 0;
-    if (na == 0 || nb == 0) run_item<0, 0, ACC>(it, lds, wr, wc);
-    else if (na == 2 && nb == 2) run_item<2, 2, ACC>(it, lds, wr, wc);
-    else if (na == 2) run_item<2, 1, ACC>(it, lds, wr, wc);
-    else if (nb == 2) run_item<1, 2, ACC>(it, lds, wr, wc);
-    else run_item<1, 1, ACC>(it, lds, wr, wc);
+    if (na == 0 || nb == 0) run_item<0, 0, ACC, NS>(it, lds, wr, wc);
+    else if (na == 2 && nb == 2) run_item<2, 2, ACC, NS>(it, lds, wr, wc);
+    else if (na == 2) run_item<2, 1, ACC, NS>(it, lds, wr, wc);
+    else if (nb == 2) run_item<1, 2, ACC, NS>(it, lds, wr, wc);
+    else run_item<1, 1, ACC, NS>(it, lds, wr, wc);
 }
 
 void launch_gram(const Item* d_items, int n_items, int dtype_i8, hipStream_t s)
 {
     if (n_items <= 0) return;
-    if (dtype_i8) hipLaunchKernelGGL(gram_kernel<i32x16>, dim3(n_items), dim3(256), 0, s, d_items);
-    else hipLaunchKernelGGL(gram_kernel<f32x16>, dim3(n_items), dim3(256), 0, s, d_items);
+    // two chunk images (32 KB), four workgroups per CU for both paths.  Deeper rings were measured for the int8
+    // kernel (NS 3 / 4 with 3 / 2 workgroups per CU: 5.28 / 5.38 ms against 5.16 ms): it is not waiting for its
+    // loads but for LDS bandwidth (1 KB of fragment reads per MFMA with 64 x 64 wave tiles)
+#ifndef GAUSS_I8_NS
+#define GAUSS_I8_NS 2
+#define GAUSS_I8_OCC 4
+#endif
+    if (dtype_i8) hipLaunchKernelGGL((gram_kernel<i32x16, GAUSS_I8_NS, GAUSS_I8_OCC>), dim3(n_items), dim3(256), 0, s, d_items);
+    else hipLaunchKernelGGL((gram_kernel<f32x16, 2, 4>), dim3(n_items), dim3(256), 0, s, d_items);
 }
 
 }  // namespace gauss
