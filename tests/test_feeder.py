@@ -329,3 +329,73 @@ def test_python_packed_writer_is_byte_identical_to_the_converter(study, packed, 
     panel.write_packed_panel(out, POPS, study["rsid"], np.full(len(G), 22), study["bp"], study["a1"], study["a2"], rows,
                              study["af"], cnt)
     assert open(out, "rb").read() == open(packed, "rb").read()
+
+
+# ---- feeder edge cases the reference's drivers hit (no GPU involved) --------------------------------------
+def _prep(kind, inp, idx, dat, desc, **kw):
+    base = dict(chr=22, start_bp=1_400_000, end_bp=2_000_000, wing_size=250_000, study_pop="EUR", input_file=inp,
+                reference_index_file=idx, reference_data_file=dat, reference_pop_desc_file=desc)
+    base.update(kw)
+    return api.Prepared(kind, **base)
+
+
+def test_duplicate_gwas_alleles_are_an_error(study, packed, tmp_path):
+    """A GWAS file that lists a panel SNP under both allele orders trips the reference's duplicate check
+    (gauss.cpp:386-392) -- through the text index and through the packed SNP table alike."""
+    inp, idx, dat, desc = _files(study)
+    lines = open(inp).read().splitlines()
+    # find a GWAS SNP that the panel has, and add its allele-swapped twin
+    panel_keys = {(int(b), a, c) for b, a, c in zip(study["bp"], study["a1"], study["a2"])}
+    for l in lines[1:]:
+        t = l.split()
+        if (int(t[2]), t[3], t[4]) in panel_keys or (int(t[2]), t[4], t[3]) in panel_keys:
+            twin = " ".join([t[0] + "_dup", t[1], t[2], t[4], t[3], t[5]])
+            break
+    bad = tmp_path / "dup.txt"
+    bad.write_text("\n".join(lines + [twin]) + "\n")
+    for data in (dat, packed):
+        with pytest.raises(api.GaussError, match="input file contains duplicates"):
+            _prep(api.KIND_DIST, str(bad), idx, data, desc, start_bp=1_000_000, end_bp=2_600_000, wing_size=0)
+
+
+def test_af_cutoffs_are_strict_and_other_chromosomes_are_ignored(study, packed):
+    inp, idx, dat, desc = _files(study)
+    a = _prep(api.KIND_DIST, inp, idx, dat, desc, af1_cutoff=0.01)
+    af = a.snps()["af1ref"].to_numpy()
+    assert np.all((af > 0.01) & (af < 0.99))                    # strict on both sides (gauss.cpp:593)
+    # a cutoff exactly equal to some SNP's (ceil-rounded) frequency excludes that SNP
+    cut = float(np.sort(af)[3])
+    b = _prep(api.KIND_DIST, inp, idx, dat, desc, af1_cutoff=cut)
+    afb = b.snps()["af1ref"].to_numpy()
+    assert cut not in afb and np.all(afb > cut) and len(afb) < len(af)
+    a.close()
+    b.close()
+    # chr filter: nothing of chr 22 is in a chr-21 window; the driver then refuses the window
+    for data in (dat, packed):
+        c = _prep(api.KIND_DIST, inp, idx, data, desc, chr=21)
+        assert c.M == 0 and c.U == 0
+        with pytest.raises(api.GaussError, match="Not enough number of SNPs loaded"):
+            c.window_desc()
+        c.close()
+
+
+def test_more_than_ten_guard_is_exact(study):
+    """dist.cpp:145-151: measured <= 10 or unmeasured <= 10 stops; 11 of each passes."""
+    inp, idx, dat, desc = _files(study)
+    # grow the window from its left edge until it holds 11 measured and 11 unmeasured SNPs
+    lo = 1_000_000
+    last = None
+    for hi in range(1_020_000, 2_600_000, 10_000):
+        p = _prep(api.KIND_DIST, inp, idx, dat, desc, start_bp=lo, end_bp=hi, wing_size=0)
+        ok = p.M > 10 and p.U > 10
+        if ok:
+            p.window_desc()                                      # accepted
+            assert last is not None and (last[0] <= 10 or last[1] <= 10)
+            p.close()
+            break
+        with pytest.raises(api.GaussError, match="DIST not performed"):
+            p.window_desc()
+        last = (p.M, p.U)
+        p.close()
+    else:
+        pytest.fail("window never reached 11 + 11 SNPs")
