@@ -258,3 +258,62 @@ def test_row_index_past_a_resident_store_is_refused(ctx):
     assert job.fetch()[0]["status"] == 0
     job.close()
     rs.close()
+
+
+def test_full_size_properties_of_the_widened_rows(ctx):
+    """QCAT, LD export with recoded rows, per-population LD and the 2-bit source at the BASELINE shape
+    (N = 32 147, 21 populations): properties that need no oracle at full size + numpy spot checks."""
+    from gauss_amd import panel
+    pops = [p for p in synth.POPS_33KG if p[0] in synth.PGC2_WEIGHTS]
+    off = synth.pop_offsets([p[1] for p in pops])
+    w = np.array([synth.PGC2_WEIGHTS[p[0]] for p in pops])
+    N = int(off[-1])
+    rng = np.random.default_rng(78)
+    M, U = 700, 900
+    base = rand_geno(rng, 120, N)
+    G = base[rng.integers(0, 120, size=M + U)].copy()
+    noise = rng.random(G.shape) < 0.4
+    G[noise] = rand_geno(rng, 1, N)[0][np.nonzero(noise)[1]]
+    gm, gu = np.ascontiguousarray(G[:M]), np.ascontiguousarray(G[M:])
+    z1 = rng.standard_normal(M) * 2
+    # QCAT: |r| <= 1, num_eig = M (ridge 0.1 keeps every eigenvalue above the 0.01 cutoff), and r equals the
+    # numpy statement on the GPU's own B11 / B21
+    n_head, n_pred = 150, 400
+    q = hotpath.qcat_window(1, gm, gu, off, w, z1, n_head, n_pred, want_mats=True, ctx=ctx)
+    assert q["status"] == 0 and q["num_eig"] == M and q["r"].shape == (n_pred + U,)
+    assert np.all(np.abs(q["r"]) <= 1 + 1e-12)
+    L = np.linalg.cholesky(q["b11"])
+    rhs = np.vstack([q["b11"][n_head:n_head + n_pred], q["b21"]]).T
+    wz = np.linalg.solve(L, z1); wb = np.linalg.solve(L, rhs)
+    wz = wz - wz.mean(); wb = wb - wb.mean(0)
+    want = (wz @ wb) / np.sqrt((wz @ wz) * np.einsum("ij,ij->j", wb, wb))
+    assert np.max(np.abs(q["r"] - want)) <= 1e-9
+    # the same window from 2-bit rows in a resident store, rows in scrambled order: bit-identical
+    rows, src_off = panel.pack2bit(G, off)
+    perm = rng.permutation(M + U)
+    store = hotpath.RowStore(np.ascontiguousarray(rows[perm]), ctx=ctx)
+    inv = np.argsort(perm).astype(np.int32)
+    job = hotpath.Job([dict(mode=1, pop_off=off, pop_wgt=w, z1=z1, dev=(store.ptr, store.ptr, M, U, store.ld),
+                            qcat=(n_head, n_pred, 0.01), packed=dict(fmt=1, rows_m=inv[:M], rows_u=inv[M:]))],
+                      ctx=ctx, on_device=True)
+    job.run()
+    q2 = job.fetch()[0]
+    job.close()
+    store.close()
+    assert np.array_equal(q2["r"], q["r"]) and q2["num_eig"] == M
+    # LD export with recoded prediction rows: the dominant / recessive blocks equal the additive LD of the
+    # recoded genotypes; unit diagonal
+    ld = hotpath.ld_window(1, gm[:300], gu[:200], off, w, lam=0.0, codings=7, ctx=ctx)
+    dom = hotpath.ld_window(1, gm[:300], (gu[:200] >= 1).astype(np.uint8), off, w, lam=0.0, codings=1, ctx=ctx)
+    rec = hotpath.ld_window(1, gm[:300], (gu[:200] == 2).astype(np.uint8), off, w, lam=0.0, codings=1, ctx=ctx)
+    assert np.all(np.diag(ld["b11"]) == 1.0)
+    assert np.array_equal(ld["b21"][200:400], dom["b21"], equal_nan=True)
+    assert np.array_equal(ld["b21"][400:600], rec["b21"], equal_nan=True)
+    # per-population LD: population k's column equals numpy's corrcoef on that population's samples
+    pp = hotpath.ld_per_pop(gm[:120], off, ctx=ctx)
+    iu = np.triu_indices(120, 1)
+    for k in (0, 7, 20):
+        with np.errstate(invalid="ignore", divide="ignore"):
+            r = np.corrcoef(gm[:120, off[k]:off[k + 1]].astype(float))[iu]
+        ok = np.isfinite(r)
+        assert np.array_equal(np.isfinite(pp[k]), ok) and np.max(np.abs(pp[k][ok] - r[ok])) <= 1e-12
