@@ -50,7 +50,7 @@ _lib = None
 
 # every symbol include/gauss_hip.h declares
 SYMBOLS = [
-    "gauss_hip_init", "gauss_hip_destroy", "gauss_last_error", "gauss_hip_version", "gauss_hip_set_gram_dtype", "gauss_store_upload", "gauss_store_free", "gauss_pack2bit_device", "gauss_ld", "gauss_ld_per_pop",
+    "gauss_hip_init", "gauss_hip_destroy", "gauss_last_error", "gauss_hip_version", "gauss_hip_set_gram_dtype", "gauss_pinned_alloc", "gauss_pinned_free", "gauss_store_upload", "gauss_store_free", "gauss_pack2bit_device", "gauss_ld", "gauss_ld_per_pop",
     "gauss_impute_window", "gauss_gene_ld_batch", "gauss_gram_counts", "gauss_job_create",
     "gauss_job_run", "gauss_job_fetch", "gauss_job_destroy", "gauss_job_profile",
     "gauss_job_profile_get", "gauss_job_work", "gauss_job_stats", "gauss_synth_device",
@@ -76,6 +76,8 @@ def load():
     lib.gauss_hip_destroy.argtypes = [C.c_void_p]
     lib.gauss_hip_destroy.restype = None
     lib.gauss_hip_set_gram_dtype.argtypes = [C.c_void_p, C.c_int]
+    lib.gauss_pinned_alloc.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]
+    lib.gauss_pinned_free.argtypes = [C.c_void_p, C.c_void_p]
     lib.gauss_store_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]
     lib.gauss_store_free.argtypes = [C.c_void_p, C.c_void_p]
     lib.gauss_ld.argtypes = [C.c_void_p, C.c_int, _u8p, C.c_int, C.c_int64, _ip, _dp, C.c_int,

@@ -238,6 +238,30 @@ def ld_window(mode, geno_m, geno_u, pop_off, pop_wgt, lam=0.0, codings=_lib.CODE
     return win.result()
 
 
+class PinnedArray:
+    """A numpy uint8 matrix in page-locked host memory (gauss_pinned_alloc): uploads from it run at PCIe speed."""
+
+    def __init__(self, shape, ctx=None):
+        self.ctx = ctx or default_context()
+        n = int(np.prod(shape))
+        p = C.c_void_p()
+        check(self.ctx.lib.gauss_pinned_alloc(self.ctx.handle, max(n, 1), C.byref(p)))
+        self.ptr = p.value
+        self.array = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(max(n, 1),))[:n].reshape(shape)
+
+    def close(self):
+        if self.ptr:
+            self.array = None
+            self.ctx.lib.gauss_pinned_free(self.ctx.handle, C.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class RowStore:
     """Genotype rows resident in HBM (gauss_store_upload): a whole packed chromosome is uploaded once and
     windows name their rows by index."""

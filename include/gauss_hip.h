@@ -120,6 +120,13 @@ typedef struct gauss_window_desc {
 #define GAUSS_CODE_DOMINANT  2
 #define GAUSS_CODE_RECESSIVE 4
 
+/* ---- pinned host buffers ---------------------------------------------------------------------
+ * Page-locked host memory for the genotype matrices a driver marshals (pack_genotypes): the
+ * upload of a window is then one DMA at PCIe speed instead of a staged copy of pageable memory (a full-size
+ * window is 101 MB of genotype bytes).  Plain pointers; any host pointer remains valid input. */
+int gauss_pinned_alloc(gauss_ctx* ctx, int64_t bytes, void** out_host_ptr);
+int gauss_pinned_free(gauss_ctx* ctx, void* host_ptr);
+
 /* ---- resident row store ---------------------------------------------------------------------
  * Copies `bytes` of genotype rows to the context's GPU and returns the device pointer to use as
  * geno_m / geno_u (with gauss_job_create's on_device = 1 and rows_m / rows_u).  288 GB of HBM hold a
