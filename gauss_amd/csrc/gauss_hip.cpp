@@ -745,6 +745,18 @@ static int job_clamp_window(gauss_job* job, int i, int* status_bits)
     return GAUSS_OK;
 }
 
+// Device matrix [rows x pitch] -> host [rows x width] doubles.  One linear copy into a staging buffer and a
+// row-wise compaction on the host: a pitched device-to-host copy of a few thousand rows is many times slower.
+static int fetch_matrix(double* dst, const double* d_src, int rows, int width, int pitch)
+{
+    if (rows <= 0 || width <= 0) return GAUSS_OK;
+    if (pitch == width) { HIPCHK(hipMemcpy(dst, d_src, sizeof(double) * (size_t)rows * width, hipMemcpyDeviceToHost)); return GAUSS_OK; }
+    std::vector<double> tmp((size_t)(rows - 1) * pitch + width);
+    HIPCHK(hipMemcpy(tmp.data(), d_src, sizeof(double) * tmp.size(), hipMemcpyDeviceToHost));
+    for (int r = 0; r < rows; r++) memcpy(dst + (size_t)r * width, tmp.data() + (size_t)r * pitch, sizeof(double) * width);
+    return GAUSS_OK;
+}
+
 // CountPC (util.cpp:355-388) when the smallest eigenvalue of B11 is below the cutoff: eigenvalues by the
 // device Jacobi sweep, counted on the host (the matrix itself is left alone).
 static int job_count_small_eigs(gauss_job* job, int i, int* num_eig)
@@ -782,11 +794,9 @@ static int job_fetch(gauss_job* job)
         if (p.kind == GAUSS_WIN_LD) {
             // raw LD export: B11 sits unfactored in A[0] (diagonal 1 + lambda), B21 in its buffer
             if (pl.out_b11)
-                HIPCHK(hipMemcpy2D(pl.out_b11, sizeof(double) * p.M, p.A, sizeof(double) * p.Mld,
-                                   sizeof(double) * p.M, p.M, hipMemcpyDeviceToHost));
+                { int rc2 = fetch_matrix(pl.out_b11, p.A, p.M, p.M, p.Mld); if (rc2) return rc2; }
             if (pl.out_b21 && p.U > 0)
-                HIPCHK(hipMemcpy2D(pl.out_b21, sizeof(double) * p.M, p.B21, sizeof(double) * p.Mld,
-                                   sizeof(double) * p.M, p.U, hipMemcpyDeviceToHost));
+                { int rc2 = fetch_matrix(pl.out_b21, p.B21, p.U, p.M, p.Mld); if (rc2) return rc2; }
             if (pl.out_status) *pl.out_status = 0;
             continue;
         }
@@ -801,11 +811,9 @@ static int job_fetch(gauss_job* job)
             if (pl.out_num_eig) *pl.out_num_eig = num_eig;
             if (pl.out_status) *pl.out_status = bits;
             if (pl.out_b11)
-                HIPCHK(hipMemcpy2D(pl.out_b11, sizeof(double) * p.M, pl.d_b11_copy, sizeof(double) * p.Mld,
-                                   sizeof(double) * p.M, p.M, hipMemcpyDeviceToHost));
+                { int rc2 = fetch_matrix(pl.out_b11, pl.d_b11_copy, p.M, p.M, p.Mld); if (rc2) return rc2; }
             if (pl.out_b21 && p.U > 0)
-                HIPCHK(hipMemcpy2D(pl.out_b21, sizeof(double) * p.M, p.B21, sizeof(double) * p.Mld,
-                                   sizeof(double) * p.M, p.U, hipMemcpyDeviceToHost));
+                { int rc2 = fetch_matrix(pl.out_b21, p.B21, p.U, p.M, p.Mld); if (rc2) return rc2; }
             continue;
         }
         if (p.npanel > 0 && (job->h_status[4 * i + 0] || job->h_status[4 * i + 1])) {
@@ -820,11 +828,9 @@ static int job_fetch(gauss_job* job)
             if (pl.out_z) memcpy(pl.out_z, job->h_results + pl.res_off, sizeof(double) * p.U);
             if (pl.out_info) memcpy(pl.out_info, job->h_results + pl.res_off + p.U, sizeof(double) * p.U);
             if (pl.out_b11)
-                HIPCHK(hipMemcpy2D(pl.out_b11, sizeof(double) * p.M, pl.d_b11_copy, sizeof(double) * p.Mld,
-                                   sizeof(double) * p.M, p.M, hipMemcpyDeviceToHost));
+                { int rc2 = fetch_matrix(pl.out_b11, pl.d_b11_copy, p.M, p.M, p.Mld); if (rc2) return rc2; }
             if (pl.out_b21 && p.U > 0)
-                HIPCHK(hipMemcpy2D(pl.out_b21, sizeof(double) * p.M, p.B21, sizeof(double) * p.Mld,
-                                   sizeof(double) * p.M, p.U, hipMemcpyDeviceToHost));
+                { int rc2 = fetch_matrix(pl.out_b21, p.B21, p.U, p.M, p.Mld); if (rc2) return rc2; }
         }
         if (pl.out_status) *pl.out_status = bits;
         if (pl.out_ld_user && pl.out_ld_count)

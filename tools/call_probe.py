@@ -14,3 +14,8 @@ for _ in range(3):
     t1 = time.perf_counter(); job.run(); r = job.fetch()
     t2 = time.perf_counter(); job.close(); t3 = time.perf_counter()
     print("create %.2f ms  run+fetch %.2f ms  destroy %.2f ms" % ((t1-t0)*1e3, (t2-t1)*1e3, (t3-t2)*1e3))
+# raw LD export (prep_qcat-style): B11 + B21 fetched to the host
+for _ in range(3):
+    t0 = time.perf_counter()
+    r = hotpath.ld_window(1, gm, gu, off, w, lam=0.0, codings=1, ctx=ctx)
+    print("ld_window (B11 %dx%d + B21 %dx%d to host) %.2f ms" % (M, M, U, M, (time.perf_counter() - t0) * 1e3))
