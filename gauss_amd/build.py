@@ -74,7 +74,7 @@ def build_host(force=False, verbose=False):
     so = os.path.join(LIBDIR, "libgauss_host.so")
     if force or _newer(so, deps):
         cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", so] + srcs + [
-            "-L" + LIBDIR, "-lgauss_hip", "-Wl,-rpath,$ORIGIN", "-lz", "-lpthread"]
+            "-L" + LIBDIR, "-lgauss_hip", "-Wl,-rpath,$ORIGIN", "-lz", "-lpthread", "-ldl"]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)

@@ -41,6 +41,7 @@ private:
     int64_t next_address_ = 0;
     bool loaded_ = false;
     std::vector<unsigned char> comp_, data_;
+    void* fast_ = nullptr;      // libdeflate decompressor, when that library is present at run time
 };
 
 class BgzfWriter {

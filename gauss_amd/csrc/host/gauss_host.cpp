@@ -149,12 +149,31 @@ struct Args {                       // Arguments, gauss.h:18-69 with the default
 struct Tok {
     const char* p; const char* e;
     explicit Tok(const std::string& s) : p(s.data()), e(s.data() + s.size()) {}
+    // whitespace as std::isspace in the "C" locale (what operator>> skips), from a table: panel lines are ~33 kB
+    // of genotype digits and this scan runs over every byte of them
+    static const bool* ws_table()
+    {
+        static const struct T { bool t[256]; T() { for (int c = 0; c < 256; c++) t[c] = (c == ' ' || (c >= 9 && c <= 13)); } } tab;
+        return tab.t;
+    }
     bool next(const char*& b, int& n)
     {
-        while (p < e && isspace((unsigned char)*p)) p++;
+        const bool* ws = ws_table();
+        while (p < e && ws[(unsigned char)*p]) p++;
         if (p >= e) return false;
         b = p;
-        while (p < e && !isspace((unsigned char)*p)) p++;
+        // long tokens (a population's genotype string) end at a blank in practice: let memchr find it, then
+        // make sure no other white-space character came first
+        const char* q = (const char*)memchr(p, ' ', (size_t)(e - p));
+        const char* lim = q ? q : e;
+        const char* r = p;
+        while (r < lim && !ws[(unsigned char)*r]) {
+            // skip ahead in blocks of 8 digits while there is room
+            if (lim - r >= 8 && !(ws[(unsigned char)r[0]] | ws[(unsigned char)r[1]] | ws[(unsigned char)r[2]] | ws[(unsigned char)r[3]] |
+                                  ws[(unsigned char)r[4]] | ws[(unsigned char)r[5]] | ws[(unsigned char)r[6]] | ws[(unsigned char)r[7]])) r += 8;
+            else r++;
+        }
+        p = r;
         n = (int)(p - b);
         return true;
     }
