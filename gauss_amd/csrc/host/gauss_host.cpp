@@ -265,6 +265,59 @@ static int ReadInputZ(SnpMap& m, const Args& a, bool All)
     return 0;
 }
 
+// Parsed image of a BGZF text index file (rsid chr bp a1 a2 af1ref fpos per line), kept per process and
+// shared by every call that names the same file (path + size + mtime).  Entries are in file order and carry the
+// reference's parsing state semantics: a field that fails to parse keeps the value of the previous line, as the
+// reference's variables do (they are declared outside its loop, gauss.cpp:317-321).
+struct IndexCache {
+    struct Entry { int32_t chr; uint32_t rsid, a1, a2; long long bp, fpos; };
+    std::vector<Entry> e;
+    std::vector<char> pool;
+    bool sorted = true;
+    size_t lower_bound(int chr, long long bp) const
+    {
+        size_t lo = 0, hi = e.size();
+        while (lo < hi) {
+            const size_t mid = lo + (hi - lo) / 2;
+            if (e[mid].chr < chr || (e[mid].chr == chr && e[mid].bp < bp)) lo = mid + 1; else hi = mid;
+        }
+        return lo;
+    }
+};
+
+static std::shared_ptr<const IndexCache> load_index_cached(const std::string& path, std::string& err)
+{
+    static std::mutex mu;
+    static std::map<std::string, std::shared_ptr<const IndexCache>> cache;      // a handful of panels per process
+    struct stat st;
+    if (stat(path.c_str(), &st) != 0) { err = "ERROR: can't open reference index file '" + path + "'"; return nullptr; }
+    char key[64];
+    snprintf(key, sizeof(key), "|%lld|%lld.%ld", (long long)st.st_size, (long long)st.st_mtim.tv_sec, (long)st.st_mtim.tv_nsec);
+    const std::string k = path + key;
+    std::lock_guard<std::mutex> lock(mu);             // concurrent windows of a farm: the first one parses
+    auto it = cache.find(k);
+    if (it != cache.end()) return it->second;
+    BgzfReader fp;
+    if (!fp.open(path)) { err = "ERROR: can't open reference index file '" + path + "'"; return nullptr; }
+    std::shared_ptr<IndexCache> ic = std::make_shared<IndexCache>();
+    std::string line, rsid, a1, a2;
+    int chr = 0; double af1ref = 0; long long bp = 0, fpos = 0;
+    auto add = [&](const std::string& v) { const uint32_t o = (uint32_t)ic->pool.size(); ic->pool.insert(ic->pool.end(), v.begin(), v.end()); ic->pool.push_back(0); return o; };
+    for (;;) {
+        const int last = fp.getline(line);
+        if (last == -2) { err = "Error: can't read reference index file '" + path + "'"; return nullptr; }
+        if (last == -1) break;
+        Tok t(line);
+        if (t.str(rsid) && t.i32(chr) && t.i64(bp) && t.str(a1) && t.str(a2) && t.dbl(af1ref)) t.i64(fpos);
+        IndexCache::Entry en{chr, add(rsid), add(a1), add(a2), bp, fpos};
+        if (!ic->e.empty() && (chr < ic->e.back().chr || (chr == ic->e.back().chr && bp < ic->e.back().bp))) ic->sorted = false;
+        ic->e.push_back(en);
+    }
+    if (cache.size() >= 4) cache.clear();              // bound the memory of a long-lived process
+    cache[k] = ic;
+    return ic;
+}
+
 // One index entry merged into the SNP map: the body of the loops of ReadReferenceIndex (gauss.cpp:340-390)
 // and ReadReferenceIndexAll (gauss.cpp:478-512).
 static int merge_index_entry(SnpMap& m, const Args& a, bool All, const std::string& rsid, int chr, long long bp,
@@ -314,17 +367,21 @@ static int ReadReferenceIndex(SnpMap& m, const Args& a, bool All)
         }
         return 0;
     }
-    BgzfReader fp;
-    if (!fp.open(a.reference_index_file)) return herr("ERROR: can't open reference index file '%s'", a.reference_index_file.c_str());
-    std::string line, rsid, a1, a2;
-    int chr = 0; double af1ref = 0; long long bp = 0, fpos = 0;
-    for (;;) {
-        const int last = fp.getline(line);
-        if (last == -2) return herr("Error: can't read reference index file '%s'", a.reference_index_file.c_str());
-        if (last == -1) break;
-        Tok t(line);
-        if (t.str(rsid) && t.i32(chr) && t.i64(bp) && t.str(a1) && t.str(a2) && t.dbl(af1ref)) t.i64(fpos);
-        if (merge_index_entry(m, a, All, rsid, chr, bp, a1, a2, fpos)) return -1;
+    // text index: parsed once per file and process (read-once index) -- the
+    // reference inflates and parses the whole genome-wide index on every call (gauss.cpp:322-392)
+    std::string err;
+    std::shared_ptr<const IndexCache> ic = load_index_cached(a.reference_index_file, err);
+    if (!ic) return herr("%s", err.c_str());
+    size_t i0 = 0, i1 = ic->e.size();
+    if (!All && a.chr > 0 && ic->sorted) {
+        i0 = ic->lower_bound(a.chr, a.start_bp - a.wing_size);
+        i1 = ic->lower_bound(a.chr, a.end_bp + a.wing_size + 1);
+    }
+    std::string rsid, a1, a2;
+    for (size_t i = i0; i < i1; i++) {
+        const IndexCache::Entry& e = ic->e[i];
+        rsid = ic->pool.data() + e.rsid; a1 = ic->pool.data() + e.a1; a2 = ic->pool.data() + e.a2;
+        if (merge_index_entry(m, a, All, rsid, e.chr, e.bp, a1, a2, e.fpos)) return -1;
     }
     return 0;
 }
