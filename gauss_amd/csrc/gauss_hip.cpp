@@ -14,6 +14,7 @@
 #include <cstring>
 #include <deque>
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -352,9 +353,13 @@ static size_t put(std::vector<char>& blob, Arena& a, const std::vector<T>& v)
     return o;
 }
 
+static void job_free(gauss_job* job);
+
 static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_device, gauss_job** out)
 {
     gauss_job* job = new gauss_job();
+    // every early return below (bad arguments, a failed HIP call) releases the job and what it owns
+    std::unique_ptr<gauss_job, void (*)(gauss_job*)> guard(job, job_free);
     job->ctx = ctx;
     job->n = (int)specs.size();
     job->on_device = on_device;
@@ -362,7 +367,7 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
     job->plans.resize(job->n);
     for (int i = 0; i < job->n; i++) {
         int rc = plan_problem(specs[i], job->plans[i], seg_max_for(specs.size()), group_target_for(specs.size()));
-        if (rc) { delete job; return rc; }
+        if (rc) return rc;
         job->plans[i].p.gram_i8 = job->gram_i8;
     }
     // Row lists are resolved by the pack kernel: an index beyond the store would be an out-of-bounds read on the
@@ -375,7 +380,7 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
             if (rows.empty()) continue;
             long long mx = -1;
             for (int32_t r : rows) {
-                if (r < 0) { delete job; return fail(GAUSS_E_INVALID, "window %d: negative row index %d", i, (int)r); }
+                if (r < 0) { return fail(GAUSS_E_INVALID, "window %d: negative row index %d", i, (int)r); }
                 mx = std::max<long long>(mx, r);
             }
             if (!on_device) continue;
@@ -387,7 +392,6 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
             if (base >= s0 + it->second) continue;
             const size_t need = (size_t)(base - s0) + (size_t)mx * (size_t)pl.user_ld + pl.row_bytes;
             if (need > it->second) {
-                delete job;
                 return fail(GAUSS_E_INVALID, "window %d: row index %lld reaches past the end of the row store (%zu bytes)", i, mx, it->second);
             }
         }
@@ -524,9 +528,9 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
     job->tab_bytes = blob.size();
 
     hipError_t e = hipMalloc((void**)&job->d_ws, job->ws_bytes);
-    if (e != hipSuccess) { delete job; return fail(GAUSS_E_NOMEM, "hipMalloc(%zu bytes workspace) failed: %s", wa.off, hipGetErrorString(e)); }
+    if (e != hipSuccess) { return fail(GAUSS_E_NOMEM, "hipMalloc(%zu bytes workspace) failed: %s", wa.off, hipGetErrorString(e)); }
     e = hipMalloc((void**)&job->d_tab, job->tab_bytes);
-    if (e != hipSuccess) { hipFree(job->d_ws); delete job; return fail(GAUSS_E_NOMEM, "hipMalloc(%zu bytes tables) failed", blob.size()); }
+    if (e != hipSuccess) { job->d_tab = nullptr; return fail(GAUSS_E_NOMEM, "hipMalloc(%zu bytes tables) failed", blob.size()); }
 
     hipStream_t st = ctx->stream;
     // zero once: operand padding, B21 padding and the solve matrices rely on it
@@ -632,7 +636,7 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
     HIPCHK(hipHostMalloc((void**)&job->h_results, sizeof(double) * std::max<size_t>(res, 1), hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void**)&job->h_status, sizeof(int) * 4 * job->n, hipHostMallocDefault));
     HIPCHK(hipStreamSynchronize(st));   // uploads from pageable user memory are complete
-    *out = job;
+    *out = guard.release();
     return GAUSS_OK;
 }
 
