@@ -37,7 +37,7 @@ __device__ __forceinline__ void mfma_nt(f64x4 (&acc)[NT], const double* __restri
 {
     const double* ap = A + (16 * wave + (lane & 15)) * LDT + (lane >> 4);
     const double* bp = B + (lane & 15) * LDT + (lane >> 4);
-#pragma unroll 4
+#pragma unroll 8
     for (int k0 = 0; k0 < NB; k0 += 4) {
         double a = ap[k0];
         if (NEG) a = -a;
@@ -53,7 +53,7 @@ __device__ __forceinline__ void mfma_nn(f64x4 (&acc)[NT], const double* __restri
 {
     const double* ap = A + (16 * wave + (lane & 15)) * LDT + (lane >> 4);
     const double* vp = V + (lane >> 4) * LDV + (lane & 15);
-#pragma unroll 4
+#pragma unroll 8
     for (int k0 = 0; k0 < NB; k0 += 4) {
         double a = ap[k0];
         if (NEG) a = -a;
