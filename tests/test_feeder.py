@@ -399,3 +399,46 @@ def test_more_than_ten_guard_is_exact(study):
         p.close()
     else:
         pytest.fail("window never reached 11 + 11 SNPs")
+
+
+@pytest.mark.parametrize("seed", [101, 102, 103, 104])
+def test_feeder_fuzz_against_python_feeder(tmp_path, seed):
+    """Random small studies (population tables, SNP densities, allele swaps, GWAS-only SNPs, window placement,
+    cutoffs): the C++ host layer -- text and packed -- must hand over exactly what the Python restatement of the
+    reference feeder produces."""
+    rng = np.random.default_rng(seed)
+    npop = int(rng.integers(2, 7))
+    sups = ["EUR", "ASN", "AFR"]
+    pops = [(f"P{k:02d}", int(rng.integers(25, 90)), sups[int(rng.integers(0, 3))]) for k in range(npop)]
+    pops[0] = (pops[0][0], pops[0][1], "EUR")
+    st = panel.make_synthetic_study(str(tmp_path), pops, n_snp=int(rng.integers(120, 260)), bp_lo=500_000, bp_hi=1_500_000,
+                                    frac_measured=float(rng.uniform(0.2, 0.6)), frac_swapped=float(rng.uniform(0, 0.4)),
+                                    frac_not_in_panel=float(rng.uniform(0, 0.1)), seed=seed)
+    p = st["paths"]
+    inp, idx, dat, desc = p["gwas.txt"], p["index.gz"], p["data.gz"], p["desc.txt"]
+    gpk = str(tmp_path / "f.gpk")
+    api.pack_panel(idx, dat, desc, gpk)
+    lo = int(rng.integers(500_000, 1_000_000))
+    hi = lo + int(rng.integers(150_000, 450_000))
+    wing = int(rng.integers(0, 200_000))
+    mix = bool(rng.integers(0, 2))
+    cutoff = float(rng.choice([0.01, 0.05, 0.1]))
+    ref_pops = fp.read_ref_desc(desc)
+    if mix:
+        names = [q[0].lower() for q in pops if rng.random() < 0.7] or [pops[0][0]]
+        wgt = (names, [float(x) for x in rng.uniform(0.05, 0.6, len(names))])
+        flags, w = fp.pop_flags_wgt(ref_pops, *wgt)
+    else:
+        flags, w, wgt = fp.pop_flags(ref_pops, "EUR"), None, None
+    m = fp.read_input_z(inp, 22, lo - wing, hi + wing, False)
+    fp.read_reference_index(m, idx, 22, lo - wing, hi + wing, False)
+    vec = fp.make_snp_vec(m, dat, flags, cutoff, w)
+    meas = [s for s in vec if s.type == 1]
+    unme = [s for s in vec if s.type == 0 and lo <= s.bp <= hi]
+    for data in (dat, gpk):
+        pr = api.Prepared(api.KIND_DISTMIX if mix else api.KIND_DIST, chr=22, start_bp=lo, end_bp=hi, wing_size=wing,
+                          study_pop=None if mix else "EUR", pop_wgt_df=wgt, input_file=inp, reference_index_file=idx,
+                          reference_data_file=data, reference_pop_desc_file=desc, af1_cutoff=cutoff)
+        _check_prepared(pr, vec, meas, unme, mix)
+        assert np.array_equal(pr.pop_off(), fp._selected_off(ref_pops, flags))
+        pr.close()
