@@ -317,3 +317,70 @@ def test_full_size_properties_of_the_widened_rows(ctx):
             r = np.corrcoef(gm[:120, off[k]:off[k + 1]].astype(float))[iu]
         ok = np.isfinite(r)
         assert np.array_equal(np.isfinite(pp[k]), ok) and np.max(np.abs(pp[k][ok] - r[ok])) <= 1e-12
+
+
+def test_randomized_kinds_and_sources_against_oracle(ctx):
+    """Fuzz over the widened rows: each job mixes imputation, QCAT and LD-export windows; genotype sources are
+    byte matrices, 2-bit matrices or row lists into a resident 2-bit store, at random."""
+    from gauss_amd import panel
+    rng = np.random.default_rng(2027)
+    for trial in range(5):
+        P = int(rng.integers(1, 8))
+        sizes = rng.integers(20, 300, size=P)
+        off = synth.pop_offsets(sizes)
+        N = int(off[-1])
+        w = rng.uniform(0.05, 1.0, P)
+        w /= w.sum()
+        S = int(rng.integers(150, 420))
+        G = rand_geno(rng, S, N, 0.15, 0.85)
+        rows2, _ = panel.pack2bit(G, off)
+        store = hotpath.RowStore(rows2, ctx=ctx)
+        wins, checks = [], []
+        on_device = bool(rng.integers(0, 2))
+        for k in range(int(rng.integers(2, 6))):
+            M, U = int(rng.integers(12, 120)), int(rng.integers(1, 130))
+            idx = rng.permutation(S)[: M + U].astype(np.int32)
+            mi, ui = np.sort(idx[:M]), np.sort(idx[M:])
+            gm, gu = np.ascontiguousarray(G[mi]), np.ascontiguousarray(G[ui])
+            mode = int(rng.integers(0, 2))
+            z1 = rng.standard_normal(M)
+            d = dict(mode=mode, pop_off=off, pop_wgt=w, z1=z1)
+            if on_device:
+                d.update(dev=(store.ptr, store.ptr, M, U, store.ld), packed=dict(fmt=1, rows_m=mi, rows_u=ui))
+            elif rng.random() < 0.5:
+                d.update(geno_m=np.ascontiguousarray(rows2[mi]), geno_u=np.ascontiguousarray(rows2[ui]), packed=dict(fmt=1))
+            else:
+                d.update(geno_m=gm, geno_u=gu)
+            kind = int(rng.integers(0, 3))
+            if kind == 1:
+                n_head = int(rng.integers(0, M // 2)); n_pred = int(rng.integers(1, M - n_head + 1))
+                d["qcat"] = (n_head, n_pred, 0.01)
+                checks.append(("qcat", oracle.run_qcat(mode, gm, gu, off, w, z1, n_head, n_pred)))
+            elif kind == 2:
+                codes = [c for c in (0, 1, 2) if rng.random() < 0.6] or [0]
+                d["ld_codings"] = sum(1 << c for c in codes)
+                d["lam"] = 0.0
+                checks.append(("ld", oracle.ld_blocks(mode, gm, gu, off, w, 1.0, tuple(codes))))
+            else:
+                checks.append(("imp", oracle.run_impute(mode, gm, gu, off, w, z1)))
+            wins.append(d)
+        job = hotpath.Job(wins, ctx=ctx, on_device=on_device)
+        job.run()
+        res = job.fetch()
+        job.close()
+        store.close()
+        for got, (kind, want) in zip(res, checks):
+            if kind == "imp":
+                if want["mpd"] != 0 or not np.all(np.isfinite(want["z"])):
+                    continue
+                assert relerr(got["info"], want["info"]) <= 1e-7
+                assert np.max(np.abs(got["z"] - want["z"]) / np.maximum(1.0, np.abs(want["z"]))) <= 1e-7
+            elif kind == "qcat":
+                if not np.all(np.isfinite(want["r"])):
+                    continue
+                assert got["num_eig"] == want["num_eig"] and np.max(np.abs(got["r"] - want["r"])) <= 1e-8
+            else:
+                nan = np.isnan(want["b21"])
+                assert np.array_equal(np.isnan(got["b21"]), nan)
+                assert np.max(np.abs(got["b11"] - want["b11"])) <= 1e-12
+                assert nan.all() or np.max(np.abs(got["b21"][~nan] - want["b21"][~nan])) <= 1e-12
