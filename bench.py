@@ -238,7 +238,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 MFMA (exact integer Gram) + f64 epilogue/solve",
+            "dtype": "f32" if args.gram_dtype == "f32" else "i8",
+            "dtype_detail": ("LD GEMM on the %s matrix cores with exact integer partial sums; correlation tails, Cholesky and "
+                             "solve in f64" % ("fp32" if args.gram_dtype == "f32" else "int8")),
             "data": "synthetic",
             "config": {
                 "workload": "distmix() synthetic chr22-scale (BASELINE.json configs[3]): "
