@@ -232,7 +232,7 @@ def main():
         avg_gram_s = gram_ms / max(1, gram_n) * 1e-3
         achieved = work["ld_flops"] / avg_gram_s / 1e12 if avg_gram_s > 0 else 0.0
         out = {
-            "metric": "imputed SNPs/sec (whole node); LD-GEMM MFMA TFLOP/s vs peak",
+            "metric": "imputed SNPs/sec (whole node) at 1/2/4/8 GPUs; LD-GEMM MFMA TFLOP/s vs peak",
             "value": snps / (tmax / args.steps),
             "unit": "imputed SNPs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
