@@ -31,10 +31,13 @@ def make_chromosome(args, seed):
     from scipy.stats import norm
     from gauss_amd import synth
     rng = np.random.default_rng(seed)
-    pops = [p for p in synth.POPS_33KG if p[0] in synth.PGC2_WEIGHTS]      # 21 populations, N = 32 147
+    if getattr(args, "mode", "distmix") == "dist":
+        pops = [p for p in synth.POPS_33KG if p[2] == "EUR"]                   # dist(study_pop="EUR"): N = 20 281
+    else:
+        pops = [p for p in synth.POPS_33KG if p[0] in synth.PGC2_WEIGHTS]      # 21 populations, N = 32 147
     if args.sample_scale != 1.0:
         pops = [(a, max(30, int(n * args.sample_scale)), s) for a, n, s in pops]
-    w = np.array([synth.PGC2_WEIGHTS[p[0]] for p in pops])
+    w = np.array([synth.PGC2_WEIGHTS.get(p[0], 1.0) for p in pops])
     off = synth.pop_offsets([p[1] for p in pops])
     lo, hi = 16_050_000, 51_210_000                                        # chr22 span of the PGC2 file
     bp = np.sort(rng.choice(np.arange(lo, hi), size=args.snps, replace=False))
@@ -88,6 +91,8 @@ def main():
     ap.add_argument("--gram-dtype", choices=["f32", "i8"], default="f32",
                     help="LD Gram arithmetic of the headline run (f32 MFMA = north star; i8 MFMA = exact fast variant)")
     ap.add_argument("--no-i8-variant", action="store_true", help="skip the extra timing of the exact int8 variant")
+    ap.add_argument("--mode", choices=["distmix", "dist"], default="distmix",
+                    help="distmix (BASELINE configs[3], the headline) or dist on the EUR super-population (configs[2])")
     ap.add_argument("--panel-format", choices=["u8", "2bit"], default="2bit",
                     help="how the chromosome sits in HBM: per-window byte matrices, or one 2-bit packed row store "
                          "(the packed panel's resident form) that windows index by row")
@@ -129,6 +134,7 @@ def main():
                                       ch["rho"].ctypes.data_as(C.POINTER(C.c_float)),
                                       C.c_uint64(20260213 + rank)))
     wins = windows_of(ch, args)
+    win_mode = hotpath.MODE_POOLED if args.mode == "dist" else hotpath.MODE_WEIGHTED
     keep, descs = [], []
     store = None
     if args.panel_format == "2bit":
@@ -145,10 +151,10 @@ def main():
             gu = panel.index_select(0, torch.from_numpy(ui).cuda())
             keep.append((gm, gu))                       # window 0 also feeds the CPU baseline sample
         if store is None:
-            descs.append(dict(mode=hotpath.MODE_WEIGHTED, pop_off=ch["off"], pop_wgt=ch["w"], z1=ch["z"][mi],
+            descs.append(dict(mode=win_mode, pop_off=ch["off"], pop_wgt=ch["w"], z1=ch["z"][mi],
                               dev=(gm.data_ptr(), gu.data_ptr(), len(mi), len(ui), ld)))
         else:
-            descs.append(dict(mode=hotpath.MODE_WEIGHTED, pop_off=ch["off"], pop_wgt=ch["w"], z1=ch["z"][mi],
+            descs.append(dict(mode=win_mode, pop_off=ch["off"], pop_wgt=ch["w"], z1=ch["z"][mi],
                               dev=(store.data_ptr(), store.data_ptr(), len(mi), len(ui), ld2),
                               packed=dict(fmt=1, rows_m=mi.astype(np.int32), rows_u=ui.astype(np.int32))))
     if store is not None:
@@ -243,8 +249,9 @@ def main():
                              "solve in f64" % ("fp32" if args.gram_dtype == "f32" else "int8")),
             "data": "synthetic",
             "config": {
-                "workload": "distmix() synthetic chr22-scale (BASELINE.json configs[3]): "
-                            f"{args.snps} SNPs x {N} samples (21 PGC2 populations), {len(wins)} windows of 1 Mb, "
+                "workload": ("distmix() synthetic chr22-scale (BASELINE.json configs[3]): " if args.mode == "distmix"
+                             else "dist(study_pop=EUR) synthetic chr22-scale (BASELINE.json configs[2]): ") +
+                            f"{args.snps} SNPs x {N} samples ({len(ch['pops'])} populations), {len(wins)} windows of 1 Mb, "
                             f"{args.wing // 1000} kb wings, one chromosome per GPU",
                 "windows_per_gpu": len(wins), "snps": args.snps, "samples": N,
                 "imputed_snps_per_gpu": int(work["imputed_snps"]),
@@ -270,7 +277,7 @@ def main():
         if i8_variant is not None:
             out["int8_exact_variant"] = i8_variant
         if not args.no_cpu_baseline and world == 1:        # the CPU baseline is timed at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(ch, wins, keep, work)
+            out["cpu_baseline"] = cpu_baseline(ch, wins, keep, work, 0 if args.mode == "dist" else 1)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
@@ -293,7 +300,7 @@ def pmc_traffic(kernel="gauss::gram_kernel<float>"):
     return best
 
 
-def cpu_baseline(ch, wins, keep, work):
+def cpu_baseline(ch, wins, keep, work, mode=1):
     """The loop-literal CPU oracle (1 thread, like the reference) on a bounded sample, scaled to
     the workload by its pair count: the reference's cost is N inner iterations per SNP pair
     (util.cpp:103-124), M(M+1)/2 + U + U*M pairs per window (distmix.cpp:180-217)."""
@@ -306,7 +313,7 @@ def cpu_baseline(ch, wins, keep, work):
     gu_h = np.ascontiguousarray(gu[:us_, :N].cpu().numpy())
     z1 = ch["z"][mi][:ms_]
     t0 = time.perf_counter()
-    oracle.run_impute(1, gm_h, gu_h, ch["off"], ch["w"], z1)
+    oracle.run_impute(mode, gm_h, gu_h, ch["off"], ch["w"], z1)
     t = time.perf_counter() - t0
     m, u = gm_h.shape[0], gu_h.shape[0]
     pairs_sample = m * (m + 1) / 2 + u + u * m
@@ -318,7 +325,7 @@ def cpu_baseline(ch, wins, keep, work):
     par = max(1, min(16, (os.cpu_count() or 1)))
     t0 = time.perf_counter()
     with ThreadPoolExecutor(max_workers=par) as pool:
-        list(pool.map(lambda _: oracle.run_impute(1, gm_h, gu_h, ch["off"], ch["w"], z1), range(par)))
+        list(pool.map(lambda _: oracle.run_impute(mode, gm_h, gu_h, ch["off"], ch["w"], z1), range(par)))
     tp = time.perf_counter() - t0
     est_par = tp / par * pairs_total / pairs_sample
     return {
@@ -326,7 +333,7 @@ def cpu_baseline(ch, wins, keep, work):
         "host_cores": os.cpu_count(),
         "windows_in_parallel": {"value": work["imputed_snps"] / est_par, "unit": "imputed SNPs/s", "cores": par,
                                 "sample": f"{par} concurrent copies of the same sample in {tp:.2f} s"},
-        "sample": f"oracle run_distmix on a sub-window of window 0 (M={m}, U={u}, N={N}): {t:.2f} s for "
+        "sample": f"oracle run_{'distmix' if mode else 'dist'} on a sub-window of window 0 (M={m}, U={u}, N={N}): {t:.2f} s for "
                   f"{pairs_sample:.0f} SNP pairs; scaled by the workload's {pairs_total:.3g} pairs "
                   f"(estimated {est:.0f} s per chromosome, dense tail of the full-size windows not included)",
     }
