@@ -1,19 +1,32 @@
 #!/usr/bin/env python3
-"""bench.py -- imputed SNPs/sec of the DISTMIX hot path on synthetic chr22-scale input.
+"""bench.py -- imputed SNPs/sec of the DISTMIX hot path on the chr22 study (BASELINE.json configs[3]).
 
-One "step" = one full pass of the hot path (pack/stats -> fp32-MFMA LD Gram -> fp64 LD epilogue
--> Cholesky -> solve) over every 1 Mb window of one synthetic chromosome that is already
-resident in HBM (BASELINE.json configs[3]: distmix, PGC2 weights, ~100k SNPs x 32 147 samples,
-500 kb wings).  With N GPUs every rank owns one such chromosome (independent windows, no
-data-path collective): weak scaling, value = all ranks' imputed SNPs / max-over-ranks time.
+One "step" = one full pass of the hot path (pack/stats -> fp32-MFMA LD Gram -> fp64 LD epilogue ->
+Cholesky -> solve) over every 1 Mb window of ONE chromosome whose panel is already resident in HBM.
+Measured SNPs (positions, z) are the reference's own chr22 study file; unmeasured SNPs and genotypes
+are synthetic (gauss_amd/workload.py).
 
-Prints ONE JSON line (rank 0).  Extra keys: "roofline" for the LD GEMM kernel (HIP events
-recorded by the library on its own stream around every launch) and "cpu_baseline" (the CPU
-oracle timed on a bounded sample and scaled to the workload's pair count).
+Multi-GPU (`--gpus N`, one process per GPU, no data-path collective):
+  --scaling strong (default)  the windows of the ONE chromosome are sharded over the ranks by LPT on
+                              their LD flops (farm.assign_windows); every rank keeps only the panel rows
+                              its windows touch; value = the chromosome's imputed SNPs / max-over-ranks
+                              time.  This is configs[3]: "windows sharded across 8xMI355X".
+  --scaling weak              every rank imputes its own whole chromosome (round-1 behaviour).
+With N > 1 the strong line carries a "weak_scaling" block measured in the same launch.
+`python bench.py --gpus N` without a torchrun environment starts the N ranks itself (child process,
+before anything touches the GPU).
+
+Other modes (never the headline): --mode dist (configs[2]), --mode computeLD (configs[1]),
+--mode jepegmix (configs[4]), --mode e2e (packed panel file + GWAS file on disk -> result table).
+
+Prints ONE JSON line (rank 0).  "roofline" describes the LD GEMM kernel from HIP events recorded by
+the library on its own stream around every launch; "cpu_baseline" is the CPU oracle timed on a
+bounded sample (N = 1 only).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -24,65 +37,17 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+FP64_MFMA_PEAK_TFLOPS = 78.6    # v_mfma_f64_16x16x4_f64: 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz
+HBM_PEAK_GBS = 8000.0
+METRIC = "imputed SNPs/sec (whole node) at 1/2/4/8 GPUs; LD-GEMM MFMA TFLOP/s vs peak"
+STAGES = ["gram", "pack_stats", "ld_epilogue", "factor", "solve"]
 
 
-def make_chromosome(args, seed):
-    """Positions, measured mask, thresholds: host-side description of one synthetic chromosome."""
-    from scipy.stats import norm
-    from gauss_amd import synth
-    rng = np.random.default_rng(seed)
-    if getattr(args, "mode", "distmix") == "dist":
-        pops = [p for p in synth.POPS_33KG if p[2] == "EUR"]                   # dist(study_pop="EUR"): N = 20 281
-    else:
-        pops = [p for p in synth.POPS_33KG if p[0] in synth.PGC2_WEIGHTS]      # 21 populations, N = 32 147
-    if args.sample_scale != 1.0:
-        pops = [(a, max(30, int(n * args.sample_scale)), s) for a, n, s in pops]
-    w = np.array([synth.PGC2_WEIGHTS.get(p[0], 1.0) for p in pops])
-    off = synth.pop_offsets([p[1] for p in pops])
-    lo, hi = 16_050_000, 51_210_000                                        # chr22 span of the PGC2 file
-    bp = np.sort(rng.choice(np.arange(lo, hi), size=args.snps, replace=False))
-    measured = np.zeros(args.snps, dtype=bool)
-    measured[rng.choice(args.snps, size=int(round(args.snps * 0.13362)), replace=False)] = True
-    # Balding-Nichols frequencies (as gauss_amd/synth.py), kept inside (0.02, 0.98)
-    p0 = rng.uniform(0.03, 0.5, args.snps)
-    p0 = np.where(rng.random(args.snps) < 0.5, 1 - p0, p0)
-    sups = sorted(set(p[2] for p in pops))
-
-    def bn(p, f):
-        return np.clip(rng.beta(p * (1 - f) / f, (1 - p) * (1 - f) / f), 0.02, 0.98)
-    psup = {s: bn(p0, 0.15) for s in sups}
-    ppop = np.stack([bn(psup[p[2]], 0.05) for p in pops], axis=1)
-    thr = norm.ppf(ppop).astype(np.float32)
-    rho = np.ones(args.snps, dtype=np.float32)
-    rho[1:] = np.exp(-np.diff(bp) / 50e3)
-    z = rng.standard_normal(args.snps) * 1.5
-    return dict(pops=pops, w=w, off=off, bp=bp, measured=measured, thr=thr, rho=rho, z=z)
-
-
-def windows_of(ch, args):
-    """1 Mb prediction windows with 500 kb wings (dist.cpp:135-139 membership rules)."""
-    bp, meas = ch["bp"], ch["measured"]
-    out = []
-    start = (int(bp[0]) // 1_000_000) * 1_000_000 + 1
-    while start <= bp[-1]:
-        end = start + 1_000_000 - 1
-        ext = (bp >= start - args.wing) & (bp <= end + args.wing)
-        pred = (bp >= start) & (bp <= end)
-        mi = np.nonzero(ext & meas)[0]
-        ui = np.nonzero(pred & ~meas)[0]
-        if len(mi) > 10 and len(ui) > 10:                                  # dist.cpp:145-146
-            out.append((mi, ui))
-        start += 1_000_000
-    if args.windows:
-        out = out[: args.windows]
-    return out
-
-
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--snps", type=int, default=100_000)
     ap.add_argument("--windows", type=int, default=0, help="limit the number of windows (0 = all)")
     ap.add_argument("--wing", type=int, default=500_000)
@@ -91,233 +56,394 @@ def main():
     ap.add_argument("--gram-dtype", choices=["f32", "i8"], default="f32",
                     help="LD Gram arithmetic of the headline run (f32 MFMA = north star; i8 MFMA = exact fast variant)")
     ap.add_argument("--no-i8-variant", action="store_true", help="skip the extra timing of the exact int8 variant")
-    ap.add_argument("--mode", choices=["distmix", "dist"], default="distmix",
-                    help="distmix (BASELINE configs[3], the headline) or dist on the EUR super-population (configs[2])")
-    ap.add_argument("--panel-format", choices=["u8", "2bit"], default="2bit",
-                    help="how the chromosome sits in HBM: per-window byte matrices, or one 2-bit packed row store "
-                         "(the packed panel's resident form) that windows index by row")
-    ap.add_argument("--streams", type=int, default=1, help="split the windows over this many jobs/streams")
-    args = ap.parse_args()
+    ap.add_argument("--mode", choices=["distmix", "dist", "computeLD", "jepegmix", "e2e"], default="distmix",
+                    help="distmix = BASELINE configs[3], the headline; the others are the remaining configs / the file-to-table run")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
+    ap.add_argument("--no-weak-line", action="store_true", help="N > 1, strong: skip the extra weak-scaling pass")
+    ap.add_argument("--verify-shards", action="store_true",
+                    help="N > 1, strong: rank 0 also runs every window itself and checks the ranks' z / info bit for bit")
+    ap.add_argument("--streams", type=int, default=1, help="split a rank's windows over this many jobs/streams")
+    return ap.parse_args(argv)
 
-    import torch
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the HIP hot path has no CPU fallback")
-    # rehearsal hook: several ranks on ONE card (gloo instead of RCCL, which refuses duplicate devices)
-    rehearsal = os.environ.get("GAUSS_BENCH_SHARED_DEVICE") == "1"
-    if rehearsal:
-        local = 0
-    torch.cuda.set_device(local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        # RCCL ("nccl" on ROCm); used for the timing barriers and two scalar reductions only
-        dist.init_process_group("gloo" if rehearsal else "nccl", rank=rank, world_size=world)
-    red_dev = "cpu" if rehearsal else "cuda"
 
-    from gauss_amd import _lib, hotpath
-    ctx = hotpath.Context(local)
-    lib = ctx.lib
+def launch_ranks(args):
+    """`python bench.py --gpus N` outside torchrun: start the N ranks as a child (torch.distributed.run),
+    relay its output and exit code.  Nothing in this process has touched the GPU."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
 
-    # ---- synthetic chromosome, generated straight into HBM --------------------------------
-    ch = make_chromosome(args, seed=20260213 + 3 + rank)
+
+class Rig:
+    """Process-level plumbing: rank, device, torch.distributed (timing barriers + scalar reductions only)."""
+
+    def __init__(self, args):
+        import torch
+        self.torch = torch
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if self.world != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={self.world}")
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the HIP hot path has no CPU fallback")
+        from gauss_amd import hotpath
+        # rehearsal hook: several ranks on ONE card (gloo instead of RCCL, which refuses duplicate devices)
+        self.rehearsal = os.environ.get("GAUSS_BENCH_SHARED_DEVICE") == "1"
+        self.local = hotpath.rank_device()
+        torch.cuda.set_device(self.local)
+        self.dist = None
+        if self.world > 1:
+            import torch.distributed as dist
+            # RCCL ("nccl" on ROCm); used for the timing barriers and a few scalar reductions only
+            dist.init_process_group("gloo" if self.rehearsal else "nccl", rank=self.rank, world_size=self.world)
+            self.dist = dist
+        self.red_dev = "cpu" if (self.rehearsal or self.world == 1) else "cuda"
+        self.ctx = hotpath.Context(self.local)
+
+    def barrier(self):
+        self.torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def reduce(self, x, op):
+        if self.dist is None:
+            return float(x)
+        t = self.torch.tensor([float(x)], dtype=self.torch.float64, device=self.red_dev)
+        self.dist.all_reduce(t, op={"max": self.dist.ReduceOp.MAX, "sum": self.dist.ReduceOp.SUM}[op])
+        return float(t.item())
+
+    def gather(self, obj):
+        if self.dist is None:
+            return [obj]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def synth_panel(rig, ch, seed):
+    """The chromosome's genotypes, generated in HBM: (u8 panel tensor, row stride)."""
+    import ctypes as C
+    from gauss_amd import _lib
+    torch, ctx = rig.torch, rig.ctx
     N = int(ch["off"][-1])
     ld = (N + 63) // 64 * 64
-    panel = torch.empty((args.snps, ld), dtype=torch.uint8, device="cuda")
+    S = len(ch["bp"])
+    panel = torch.empty((S, ld), dtype=torch.uint8, device="cuda")
     thr = np.ascontiguousarray(ch["thr"])
+    _lib.check(ctx.lib.gauss_synth_device(ctx.handle, panel.data_ptr(), S, ld,
+                                          ch["off"].ctypes.data_as(C.POINTER(C.c_int32)), len(ch["pops"]),
+                                          thr.ctypes.data_as(C.POINTER(C.c_float)),
+                                          ch["rho"].ctypes.data_as(C.POINTER(C.c_float)), C.c_uint64(seed)))
+    return panel, ld
+
+
+def pack_store(rig, ch, panel, ld):
+    """The whole chromosome as ONE 2-bit row store (the packed panel's resident form)."""
     import ctypes as C
-    _lib.check(lib.gauss_synth_device(ctx.handle, panel.data_ptr(), args.snps, ld,
-                                      ch["off"].ctypes.data_as(C.POINTER(C.c_int32)), len(ch["pops"]),
-                                      thr.ctypes.data_as(C.POINTER(C.c_float)),
-                                      ch["rho"].ctypes.data_as(C.POINTER(C.c_float)),
-                                      C.c_uint64(20260213 + rank)))
-    wins = windows_of(ch, args)
-    win_mode = hotpath.MODE_POOLED if args.mode == "dist" else hotpath.MODE_WEIGHTED
-    keep, descs = [], []
-    store = None
-    if args.panel_format == "2bit":
-        # the whole chromosome as ONE resident 2-bit row store (288 GB of HBM hold an entire panel); windows
-        # name their rows, the pack kernel gathers and unpacks them
-        sizes = np.diff(ch["off"])
-        ld2 = int(sum((int(m) + 63) // 64 * 16 for m in sizes))
-        store = torch.empty((args.snps, ld2), dtype=torch.uint8, device="cuda")
-        _lib.check(lib.gauss_pack2bit_device(ctx.handle, panel.data_ptr(), ld, store.data_ptr(), ld2, args.snps,
+    from gauss_amd import _lib
+    torch, ctx = rig.torch, rig.ctx
+    sizes = np.diff(ch["off"])
+    ld2 = int(sum((int(m) + 63) // 64 * 16 for m in sizes))
+    store = torch.empty((panel.shape[0], ld2), dtype=torch.uint8, device="cuda")
+    _lib.check(ctx.lib.gauss_pack2bit_device(ctx.handle, panel.data_ptr(), ld, store.data_ptr(), ld2, panel.shape[0],
                                              ch["off"].ctypes.data_as(C.POINTER(C.c_int32)), len(ch["pops"])))
-    for k, (mi, ui) in enumerate(wins):
-        if store is None or k == 0:
-            gm = panel.index_select(0, torch.from_numpy(mi).cuda())
-            gu = panel.index_select(0, torch.from_numpy(ui).cuda())
-            keep.append((gm, gu))                       # window 0 also feeds the CPU baseline sample
-        if store is None:
-            descs.append(dict(mode=win_mode, pop_off=ch["off"], pop_wgt=ch["w"], z1=ch["z"][mi],
-                              dev=(gm.data_ptr(), gu.data_ptr(), len(mi), len(ui), ld)))
-        else:
-            descs.append(dict(mode=win_mode, pop_off=ch["off"], pop_wgt=ch["w"], z1=ch["z"][mi],
-                              dev=(store.data_ptr(), store.data_ptr(), len(mi), len(ui), ld2),
-                              packed=dict(fmt=1, rows_m=mi.astype(np.int32), rows_u=ui.astype(np.int32))))
-    if store is not None:
-        del panel
-    torch.cuda.synchronize()
-    ctx.set_gram_dtype(args.gram_dtype)
-    if args.streams > 1:
-        jobs = [hotpath.Job(descs[i::args.streams], ctx=(ctx if i == 0 else hotpath.Context(local)), on_device=True)
-                for i in range(args.streams)]
-    else:
-        jobs = [hotpath.Job(descs, ctx=ctx, on_device=True)]
-    job = jobs[0]
-    work = {k: sum(j.work()[k] for j in jobs) for k in job.work()}
-    stats = {k: sum(j.stats()[k] for j in jobs) for k in job.stats()}
+    return store, ld2
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
 
-    def step():
-        for j in jobs:
+def window_descs(ch, wins, store, ld2, mode, rows_of=None):
+    """Window descriptors naming their rows in a resident 2-bit store (rows_of maps chromosome rows to store rows)."""
+    from gauss_amd import hotpath
+    win_mode = hotpath.MODE_POOLED if mode == "dist" else hotpath.MODE_WEIGHTED
+    descs = []
+    for _, mi, ui in wins:
+        rm = mi if rows_of is None else np.searchsorted(rows_of, mi)
+        ru = ui if rows_of is None else np.searchsorted(rows_of, ui)
+        descs.append(dict(mode=win_mode, pop_off=ch["off"], pop_wgt=ch["w"], z1=ch["z"][mi],
+                          dev=(store.data_ptr(), store.data_ptr(), len(mi), len(ui), ld2),
+                          packed=dict(fmt=1, rows_m=rm.astype(np.int32), rows_u=ru.astype(np.int32))))
+    return descs
+
+
+class Runner:
+    """A rank's windows as one job per stream; step() = run + fetch of all of them."""
+
+    def __init__(self, rig, descs, streams=1):
+        from gauss_amd import hotpath
+        self.rig = rig
+        self.ctxs = [rig.ctx] + [hotpath.Context(rig.local) for _ in range(max(1, streams) - 1)]
+        self.jobs, self.order = [], []
+        if descs:
+            n = min(len(self.ctxs), len(descs))
+            self.jobs = [hotpath.Job(descs[i::n], ctx=self.ctxs[i], on_device=True) for i in range(n)]
+            self.order = [k for i in range(n) for k in range(i, len(descs), n)]
+        self.work = {k: sum(j.work()[k] for j in self.jobs) for k in ("ld_flops", "solve_flops", "bytes", "imputed_snps")}
+        self.stats = {k: sum(j.stats()[k] for j in self.jobs) for k in ("items", "executed_flops", "slab_bytes", "workspace_bytes")}
+
+    def step(self):
+        for j in self.jobs:
             j.run()
         out = []
-        for j in jobs:
+        for j in self.jobs:
             out += j.fetch()
         return out
 
-    for _ in range(args.warmup):
-        step()
-    job.profile(True)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    gram_ms, gram_n = job.profile_get(0)
-    stage_ms = {k: job.profile_get(i)[0] / max(1, args.steps) for i, k in
-                enumerate(["gram", "pack_stats", "ld_epilogue", "factor", "solve"])}
-    job.profile(False)
+    def results_in_order(self, res):
+        out = [None] * len(res)
+        for k, r in zip(self.order, res):
+            out[k] = r
+        return out
+
+    def profile(self, on):
+        for j in self.jobs:
+            j.profile(on)
+
+    def stage_ms(self):
+        """(ms, launches) per stage summed over this rank's jobs since profiling was enabled."""
+        tot = {}
+        for i, k in enumerate(STAGES):
+            ms = n = 0
+            for j in self.jobs:
+                a, b = j.profile_get(i)
+                ms += a
+                n += b
+            tot[k] = (ms, n)
+        return tot
+
+    def timed(self, steps, warmup):
+        res = []
+        for _ in range(warmup):
+            res = self.step()
+        self.profile(True)
+        self.rig.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            res = self.step()
+        self.rig.barrier()
+        dt = time.perf_counter() - t0
+        st = self.stage_ms()
+        self.profile(False)
+        return dt, st, res
+
+    def close(self):
+        for j in self.jobs:
+            j.close()
+        for c in self.ctxs[1:]:
+            c.close()
+        self.jobs = []
+
+
+def result_digest(res):
+    """Order-independent check values of a list of window results (exact: sums of the raw bit patterns)."""
+    z = np.concatenate([r["z"] for r in res]) if res else np.zeros(0)
+    info = np.concatenate([r["info"] for r in res]) if res else np.zeros(0)
+    return [int(z.view(np.uint64).astype(object).sum() % (1 << 61)), int(info.view(np.uint64).astype(object).sum() % (1 << 61)),
+            int(sum(int(r["status"] != 0) for r in res)), bool(np.all(np.isfinite(z)) and np.all(np.isfinite(info)))]
+
+
+def run_impute(args, rig):
+    """--mode distmix / dist: the headline."""
+    from gauss_amd import workload
+    torch = rig.torch
+    strong = args.scaling == "strong"
+    seed = 20260216 + (0 if strong else rig.rank)
+    ch = workload.make_chromosome(args.snps, args.mode, seed=seed, sample_scale=args.sample_scale)
+    N = int(ch["off"][-1])
+    wins = workload.windows_of(ch, args.wing, args.windows)
+    owner, load = workload.shard(wins, N, rig.world if strong else 1)
+    mine = [k for k in range(len(wins)) if (owner[k] == rank_of(rig) if strong else True)]
+
+    panel, ld = synth_panel(rig, ch, seed)
+    store, ld2 = pack_store(rig, ch, panel, ld)
+    keep0 = None
+    if rig.rank == 0 and not args.no_cpu_baseline and rig.world == 1:
+        _, mi, ui = wins[0]                                   # window 0 also feeds the CPU baseline sample
+        keep0 = (panel.index_select(0, torch.from_numpy(mi[:600]).cuda()).cpu().numpy(),
+                 panel.index_select(0, torch.from_numpy(ui[:600]).cuda()).cpu().numpy())
+    del panel
+    full_store = store
+    rows_of = None
+    if strong and rig.world > 1:
+        # this rank keeps only the panel rows its windows touch (the slice a farm rank uploads)
+        rows_of = np.unique(np.concatenate([np.concatenate([wins[k][1], wins[k][2]]) for k in mine])) if mine else np.zeros(0, np.int64)
+        store = full_store.index_select(0, torch.from_numpy(rows_of).cuda()) if len(rows_of) else full_store[:1]
+    torch.cuda.synchronize()
+    rig.ctx.set_gram_dtype(args.gram_dtype)
+    runner = Runner(rig, window_descs(ch, [wins[k] for k in mine], store, ld2, args.mode, rows_of), args.streams)
+    work, stats = runner.work, runner.stats
+
+    dt, st, res = runner.timed(args.steps, args.warmup)
+    res = runner.results_in_order(res) if runner.jobs else []
+    gram_ms, gram_n = st["gram"]
+    tmax = rig.reduce(dt, "max")
+    snps = rig.reduce(work["imputed_snps"], "sum")
+    digests = rig.gather(dict(rank=rig.rank, windows=mine, digest=result_digest(res), dt=dt,
+                              resident_rows=int(store.shape[0]), imputed=int(work["imputed_snps"])))
+
+    shard_check = None
+    if args.verify_shards and strong and rig.world > 1:
+        # every rank hands its windows' z / info to rank 0, which imputes the whole chromosome itself
+        parts = rig.gather({k: (r["z"], r["info"]) for k, r in zip(mine, res)})
+        if rig.rank == 0:
+            allr = Runner(rig, window_descs(ch, wins, full_store, ld2, args.mode), 1)
+            ref = allr.step()
+            allr.close()
+            got = {}
+            for p in parts:
+                got.update(p)
+            shard_check = bool(len(got) == len(wins) and all(
+                np.array_equal(got[k][0], ref[k]["z"]) and np.array_equal(got[k][1], ref[k]["info"]) for k in range(len(wins))))
 
     # the same job with the LD Gram on the int8 matrix cores (identical integers, identical outputs):
     # reported next to the headline, never as `value`
     i8_variant = None
-    if args.gram_dtype == "f32" and not args.no_i8_variant and args.streams == 1 and world == 1:
-        ctx.set_gram_dtype("i8")
-        j8 = hotpath.Job(descs, ctx=ctx, on_device=True)
-        ctx.set_gram_dtype("f32")
-        for _ in range(max(1, args.warmup)):
-            j8.run(); r8 = j8.fetch()
-        j8.profile(True)
-        barrier()
-        t8 = time.perf_counter()
-        for _ in range(args.steps):
-            j8.run(); r8 = j8.fetch()
-        torch.cuda.synchronize()
-        dt8 = time.perf_counter() - t8
-        g8, n8 = j8.profile_get(0)
-        same = all(np.array_equal(a["z"], b["z"]) and np.array_equal(a["info"], b["info"]) for a, b in zip(res, r8))
+    if args.gram_dtype == "f32" and not args.no_i8_variant and args.streams == 1 and rig.world == 1:
+        rig.ctx.set_gram_dtype("i8")
+        r8 = Runner(rig, window_descs(ch, wins, store, ld2, args.mode), 1)
+        rig.ctx.set_gram_dtype("f32")
+        dt8, st8, res8 = r8.timed(args.steps, max(1, args.warmup))
+        same = all(np.array_equal(a["z"], b["z"]) and np.array_equal(a["info"], b["info"]) for a, b in zip(res, res8))
+        g8, n8 = st8["gram"]
         i8_variant = {"ms_per_step": dt8 / args.steps * 1e3, "imputed_snps_per_s_this_rank": work["imputed_snps"] / (dt8 / args.steps),
                       "gram_ms": g8 / max(1, n8), "gram_tops_algorithmic": work["ld_flops"] / (g8 / max(1, n8) * 1e-3) / 1e12,
                       "kernel": "gram_kernel<i32x16> (v_mfma_i32_32x32x32_i8)", "bit_identical_to_f32_path": bool(same)}
-        j8.close()
+        r8.close()
 
-    bad = sum(int(r["status"] != 0) for r in res)
-    finite = all(np.all(np.isfinite(r["z"])) and np.all(np.isfinite(r["info"])) for r in res)
-
-    tmax, snps = dt, float(work["imputed_snps"])
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        s = torch.tensor([snps], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(s, op=dist.ReduceOp.SUM)
-        tmax, snps = float(t.item()), float(s.item())
+    weak = None
+    if strong and rig.world > 1 and not args.no_weak_line:
+        # second line: every rank imputes the WHOLE chromosome (per-GPU work fixed as N grows)
+        runner.close()
+        wr = Runner(rig, window_descs(ch, wins, full_store, ld2, args.mode), 1)
+        wdt, _, _ = wr.timed(args.steps, max(1, args.warmup))
+        wt = rig.reduce(wdt, "max")
+        ws = rig.reduce(wr.work["imputed_snps"], "sum")
+        weak = {"scaling": "weak", "value": ws / (wt / args.steps), "unit": "imputed SNPs/s", "ms_per_step": wt / args.steps * 1e3,
+                "workload": "the whole chromosome on every rank"}
+        wr.close()
 
     out = None
-    if rank == 0:
-        ms_per_step = tmax / args.steps * 1e3
+    if rig.rank == 0:
+        nsteps = max(1, args.steps)
         avg_gram_s = gram_ms / max(1, gram_n) * 1e-3
         achieved = work["ld_flops"] / avg_gram_s / 1e12 if avg_gram_s > 0 else 0.0
+        per_step = {k: v[0] / nsteps for k, v in st.items()}
+        tail_s = (per_step["factor"] + per_step["solve"]) * 1e-3
+        solve_ach = work["solve_flops"] / tail_s / 1e12 if tail_s > 0 else 0.0
+        bad = sum(d["digest"][2] for d in digests)
+        finite = all(d["digest"][3] for d in digests)
+        m_all = [len(mi) for _, mi, _ in wins]
+        u_all = [len(ui) for _, _, ui in wins]
         out = {
-            "metric": "imputed SNPs/sec (whole node) at 1/2/4/8 GPUs; LD-GEMM MFMA TFLOP/s vs peak",
+            "metric": METRIC,
             "value": snps / (tmax / args.steps),
             "unit": "imputed SNPs/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "n_gpus": rig.world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": tmax / args.steps * 1e3,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32" if args.gram_dtype == "f32" else "i8",
             "dtype_detail": ("LD GEMM on the %s matrix cores with exact integer partial sums; correlation tails, Cholesky and "
                              "solve in f64" % ("fp32" if args.gram_dtype == "f32" else "int8")),
             "data": "synthetic",
             "config": {
-                "workload": ("distmix() synthetic chr22-scale (BASELINE.json configs[3]): " if args.mode == "distmix"
-                             else "dist(study_pop=EUR) synthetic chr22-scale (BASELINE.json configs[2]): ") +
-                            f"{args.snps} SNPs x {N} samples ({len(ch['pops'])} populations), {len(wins)} windows of 1 Mb, "
-                            f"{args.wing // 1000} kb wings, one chromosome per GPU",
-                "windows_per_gpu": len(wins), "snps": args.snps, "samples": N,
-                "imputed_snps_per_gpu": int(work["imputed_snps"]),
-                "mean_measured": float(np.mean([len(m) for m, _ in wins])),
-                "mean_unmeasured": float(np.mean([len(u) for _, u in wins])),
+                "workload": (("distmix() chr22 (BASELINE.json configs[3]): " if args.mode == "distmix"
+                              else "dist(study_pop=EUR) chr22 (BASELINE.json configs[2]): ") +
+                             f"measured SNPs (positions, z) from {ch['study']}, synthetic unmeasured SNPs and genotypes; "
+                             f"{len(ch['bp'])} SNPs x {N} samples ({len(ch['pops'])} populations), {len(wins)} windows of 1 Mb, "
+                             f"{args.wing // 1000} kb wings; " +
+                             ("the windows of ONE chromosome sharded over the ranks (LPT on LD flops)" if strong
+                              else "one whole chromosome per rank")),
+                "windows": len(wins), "snps": int(len(ch["bp"])), "samples": N,
+                "imputed_snps_per_step": int(snps),
+                "measured_per_window": {"min": int(min(m_all)), "mean": float(np.mean(m_all)), "max": int(max(m_all))},
+                "unmeasured_per_window": {"min": int(min(u_all)), "mean": float(np.mean(u_all)), "max": int(max(u_all))},
+                "windows_per_rank": [len(d["windows"]) for d in digests],
+                "resident_panel_rows_per_rank": [d["resident_rows"] for d in digests],
+                "lpt_load_imbalance": (max(load) / (sum(load) / len(load))) if strong else 1.0,
+                "rank_seconds": [d["dt"] for d in digests],
                 "windows_flagged": bad, "all_finite": bool(finite),
-                "panel_in_hbm": ("one 2-bit packed row store, windows index it by row" if args.panel_format == "2bit"
-                                 else "per-window one-byte genotype matrices"),
+                "panel_in_hbm": "one 2-bit packed row store per rank, windows index it by row",
             },
             "roofline": {
-                "kernel": "gram_kernel (LD GEMM, v_mfma_f32_32x32x2_f32)",
+                "kernel": "gram_kernel (LD GEMM, v_mfma_f32_32x32x2_f32)" + (" on rank 0" if rig.world > 1 else ""),
                 "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
-                "traffic": pmc_traffic() if (len(wins) == 36 and args.snps == 100_000) else None,
                 "algorithmic_flops_per_launch": work["ld_flops"],
                 "avg_launch_ms": gram_ms / max(1, gram_n), "launches": int(gram_n),
                 "issued_flops_per_launch": stats["executed_flops"],
                 "issued_tflops": stats["executed_flops"] / avg_gram_s / 1e12 if avg_gram_s > 0 else 0.0,
                 "work_items": stats["items"], "partial_slab_bytes": stats["slab_bytes"],
             },
-            "stage_ms_per_step": stage_ms,
+            "roofline_solve": {
+                "kernel": "factor_*_kernel + solve_kernel (v_mfma_f64_16x16x4_f64)", "bound": "mfma",
+                "achieved": solve_ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": solve_ach / FP64_MFMA_PEAK_TFLOPS,
+                "algorithmic_flops_per_step": work["solve_flops"], "ms_per_step": tail_s * 1e3,
+                "definition": "sum over windows of M^3/3 + 2 U M^2 + 4 U M (SURVEY.md 8d) / (factor + solve time)",
+            },
+            "stage_ms_per_step": per_step,
         }
+        out["roofline"].update(pmc_traffic(len(wins) == 36 and len(ch["bp"]) == 100_000 and rig.world == 1))
+        if shard_check is not None:
+            out["config"]["shards_bit_identical_to_one_rank"] = shard_check
+        if weak is not None:
+            out["weak_scaling"] = weak
         if i8_variant is not None:
             out["int8_exact_variant"] = i8_variant
-        if not args.no_cpu_baseline and world == 1:        # the CPU baseline is timed at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(ch, wins, keep, work, 0 if args.mode == "dist" else 1)
+        if keep0 is not None:
+            out["cpu_baseline"] = cpu_baseline(ch, wins, keep0, work, 0 if args.mode == "dist" else 1)
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
-    job.close()
+    runner.close()
     return out
 
 
-def pmc_traffic(kernel="gauss::gram_kernel<float>"):
+def rank_of(rig):
+    return rig.rank
+
+
+def pmc_traffic(applicable, kernel="gauss::gram_kernel<float>"):
     """HBM-side bytes per launch of the Gram kernel from the committed rocprofv3 PMC passes
-    (profiles/*_pmc_traffic.csv: separate FETCH_SIZE / WRITE_SIZE runs of this same command,
-    gfx950 correction applied).  PMC counters cannot be collected from inside the timed run."""
+    (profiles/*_pmc_traffic.csv: separate FETCH_SIZE / WRITE_SIZE runs of this same command, gfx950
+    correction applied).  PMC counters cannot be collected from inside the timed run, so the source file is
+    named next to the number; null when the run is not the profiled workload."""
     import csv
     import glob
-    best = None
+    if not applicable:
+        return {"traffic": None, "traffic_source": None}
+    best, src = None, None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.csv"))):
         for r in csv.DictReader(open(f)):
             if r["kernel"] == kernel or r["kernel"] == kernel.split("<")[0]:
-                best = float(r["hbm_bytes_per_launch_corrected"])
-    return best
+                best, src = float(r["hbm_bytes_per_launch_corrected"]), os.path.relpath(f, ROOT)
+    return {"traffic": best, "traffic_source": src}
 
 
-def cpu_baseline(ch, wins, keep, work, mode=1):
+def cpu_baseline(ch, wins, keep0, work, mode=1):
     """The loop-literal CPU oracle (1 thread, like the reference) on a bounded sample, scaled to
     the workload by its pair count: the reference's cost is N inner iterations per SNP pair
     (util.cpp:103-124), M(M+1)/2 + U + U*M pairs per window (distmix.cpp:180-217)."""
     import oracle
-    ms_, us_ = 600, 600
-    gm, gu = keep[0]
-    mi, ui = wins[0]
+    gm, gu = keep0
+    _, mi, ui = wins[0]
     N = int(ch["off"][-1])
-    gm_h = np.ascontiguousarray(gm[:ms_, :N].cpu().numpy())
-    gu_h = np.ascontiguousarray(gu[:us_, :N].cpu().numpy())
+    ms_ = min(600, gm.shape[0], 150 if N < 5000 else 600)
+    gm_h = np.ascontiguousarray(gm[:ms_, :N])
+    gu_h = np.ascontiguousarray(gu[:600, :N])
     z1 = ch["z"][mi][:ms_]
     t0 = time.perf_counter()
     oracle.run_impute(mode, gm_h, gu_h, ch["off"], ch["w"], z1)
     t = time.perf_counter() - t0
     m, u = gm_h.shape[0], gu_h.shape[0]
     pairs_sample = m * (m + 1) / 2 + u + u * m
-    pairs_total = sum(len(a) * (len(a) + 1) / 2 + len(b) + len(a) * len(b) for a, b in wins)
+    pairs_total = sum(len(a) * (len(a) + 1) / 2 + len(b) + len(a) * len(b) for _, a, b in wins)
     est = t * pairs_total / pairs_sample
     # what an R user could do with one process per window: the same sample on several cores at once
     # (threads here: the oracle is plain C behind ctypes, which releases the GIL)
@@ -337,6 +463,20 @@ def cpu_baseline(ch, wins, keep, work, mode=1):
                   f"{pairs_sample:.0f} SNP pairs; scaled by the workload's {pairs_total:.3g} pairs "
                   f"(estimated {est:.0f} s per chromosome, dense tail of the full-size windows not included)",
     }
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
+    rig = Rig(args)
+    if args.mode in ("distmix", "dist"):
+        out = run_impute(args, rig)
+    else:
+        from gauss_amd import benchmodes
+        out = {"computeLD": benchmodes.run_computeld, "jepegmix": benchmodes.run_jepegmix, "e2e": benchmodes.run_e2e}[args.mode](args, rig)
+    rig.close()           # not in a `finally`: a rank that failed must not wait in a barrier for the others
+    return out
 
 
 if __name__ == "__main__":

@@ -50,7 +50,7 @@ _lib = None
 
 # every symbol include/gauss_hip.h declares
 SYMBOLS = [
-    "gauss_hip_init", "gauss_hip_destroy", "gauss_last_error", "gauss_hip_version", "gauss_hip_set_gram_dtype", "gauss_pinned_alloc", "gauss_pinned_free", "gauss_store_upload", "gauss_store_free", "gauss_pack2bit_device", "gauss_ld", "gauss_ld_per_pop",
+    "gauss_hip_init", "gauss_hip_device_count", "gauss_hip_device_of", "gauss_hip_destroy", "gauss_last_error", "gauss_hip_version", "gauss_hip_set_gram_dtype", "gauss_pinned_alloc", "gauss_pinned_free", "gauss_store_upload", "gauss_store_free", "gauss_pack2bit_device", "gauss_ld", "gauss_ld_per_pop",
     "gauss_impute_window", "gauss_gene_ld_batch", "gauss_gram_counts", "gauss_job_create",
     "gauss_job_run", "gauss_job_fetch", "gauss_job_destroy", "gauss_job_profile",
     "gauss_job_profile_get", "gauss_job_work", "gauss_job_stats", "gauss_synth_device",
@@ -73,6 +73,8 @@ def load():
     lib.gauss_last_error.restype = C.c_char_p
     lib.gauss_hip_version.restype = C.c_char_p
     lib.gauss_hip_init.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    lib.gauss_hip_device_count.argtypes = [C.POINTER(C.c_int)]
+    lib.gauss_hip_device_of.argtypes = [C.c_void_p]
     lib.gauss_hip_destroy.argtypes = [C.c_void_p]
     lib.gauss_hip_destroy.restype = None
     lib.gauss_hip_set_gram_dtype.argtypes = [C.c_void_p, C.c_int]

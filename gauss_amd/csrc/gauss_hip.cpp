@@ -55,6 +55,17 @@ struct gauss_ctx {
 
 static inline size_t rup(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// Device scratch released on every exit path (an early HIPCHK return included).
+struct DevBuf {
+    void* p = nullptr;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+    template <typename T> T* as() const { return (T*)p; }
+};
+
 // Host-side plan of one problem
 struct Plan {
     Prob p;                                  // device descriptor (pointers filled at layout time)
@@ -718,33 +729,33 @@ static int job_clamp_window(gauss_job* job, int i, int* status_bits)
     // Re-run the epilogue for this problem only to restore A[0] (the factorisation overwrote it)
     std::vector<int2> tm;
     for (int pr = 0; pr < p.npair; pr++) tm.push_back(make_int2(i, pr));
-    int2* d_tm = nullptr;
-    HIPCHK(hipMalloc((void**)&d_tm, sizeof(int2) * tm.size()));
-    HIPCHK(hipMemcpyAsync(d_tm, tm.data(), sizeof(int2) * tm.size(), hipMemcpyHostToDevice, st));
-    launch_epilogue(job->d_probs, d_tm, (int)tm.size(), job->max_pop, job->gram_i8, st);
-    double* d_work = nullptr;
+    DevBuf d_tm, d_work, d_pm;
+    HIPCHK(d_tm.alloc(sizeof(int2) * tm.size()));
+    HIPCHK(hipMemcpyAsync(d_tm.p, tm.data(), sizeof(int2) * tm.size(), hipMemcpyHostToDevice, st));
+    launch_epilogue(job->d_probs, d_tm.as<int2>(), (int)tm.size(), job->max_pop, job->gram_i8, st);
+    HIPCHK(hipGetLastError());
     const size_t n = (size_t)p.Mld;
-    HIPCHK(hipMalloc((void**)&d_work, sizeof(double) * (2 * n * n + 4 * n)));
+    HIPCHK(d_work.alloc(sizeof(double) * (2 * n * n + 4 * n)));
     HIPCHK(hipMemsetAsync(p.status, 0, sizeof(int) * 4, st));
-    launch_jacobi_clamp(job->d_probs, i, p, d_work, true, st);
+    launch_jacobi_clamp(job->d_probs, i, p, d_work.as<double>(), true, st);
+    HIPCHK(hipGetLastError());
     // refactor (both matrices are factored again; only matrix 0 is used) and solve this window
     std::vector<int2> pm;
     for (int pn = 0; pn < p.npanel; pn++) pm.push_back(make_int2(i, pn));
-    int2* d_pm = nullptr;
-    HIPCHK(hipMalloc((void**)&d_pm, sizeof(int2) * pm.size()));
-    HIPCHK(hipMemcpyAsync(d_pm, pm.data(), sizeof(int2) * pm.size(), hipMemcpyHostToDevice, st));
+    HIPCHK(d_pm.alloc(sizeof(int2) * pm.size()));
+    HIPCHK(hipMemcpyAsync(d_pm.p, pm.data(), sizeof(int2) * pm.size(), hipMemcpyHostToDevice, st));
     if (pl.out_b11) HIPCHK(hipMemcpyAsync(pl.d_b11_copy, p.A, sizeof(double) * n * n, hipMemcpyDeviceToDevice, st));
     HIPCHK(hipMemcpyAsync(p.A + 4 * n * n, p.A, sizeof(double) * n * n, hipMemcpyDeviceToDevice, st));   // W0 = clamped B11
     for (int s = 0; s < p.nblk; s++) {
         // launch over all problems would redo the others; use a single-problem launch instead
         launch_factor_step(job->d_probs + i, 1, s, p.nblk, st);
     }
-    launch_solve(job->d_probs, d_pm, (int)pm.size(), st);
+    launch_solve(job->d_probs, d_pm.as<int2>(), (int)pm.size(), st);
+    HIPCHK(hipGetLastError());
     int h_status[4];
     HIPCHK(hipMemcpyAsync(h_status, p.status, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(job->h_results + pl.res_off, job->d_results + pl.res_off, sizeof(double) * 2 * p.n_rhs, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    hipFree(d_tm); hipFree(d_pm); hipFree(d_work);
     *status_bits = (h_status[2] || h_status[0]) ? GAUSS_ST_NONFINITE : GAUSS_ST_CLAMPED;
     return GAUSS_OK;
 }
@@ -769,13 +780,13 @@ static int job_count_small_eigs(gauss_job* job, int i, int* num_eig)
     Plan& pl = job->plans[i];
     Prob& p = pl.p;
     const size_t n = (size_t)p.Mld;
-    double* d_work = nullptr;
-    HIPCHK(hipMalloc((void**)&d_work, sizeof(double) * (2 * n * n + 4 * n)));
-    launch_jacobi_clamp(job->d_probs, i, p, d_work, false, st);
+    DevBuf d_work;
+    HIPCHK(d_work.alloc(sizeof(double) * (2 * n * n + 4 * n)));
+    launch_jacobi_clamp(job->d_probs, i, p, d_work.as<double>(), false, st);
+    HIPCHK(hipGetLastError());
     std::vector<double> delta(n);
-    HIPCHK(hipMemcpyAsync(delta.data(), d_work + 2 * n * n, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(delta.data(), d_work.as<double>() + 2 * n * n, sizeof(double) * n, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    hipFree(d_work);
     int small = 0;
     for (size_t k = 0; k < n; k++) if (delta[k] > 0.0) small++;
     *num_eig = p.M - small;
@@ -892,6 +903,19 @@ int gauss_hip_init(int device, gauss_ctx** out_ctx)
     *out_ctx = c;
     return GAUSS_OK;
 }
+
+int gauss_hip_device_count(int* out_n)
+{
+    if (!out_n) return fail(GAUSS_E_INVALID, "out_n is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e == hipErrorNoDevice) { n = 0; e = hipSuccess; (void)hipGetLastError(); }
+    if (e != hipSuccess) return fail(GAUSS_E_DEVICE, "hipGetDeviceCount failed: %s", hipGetErrorString(e));
+    *out_n = n;
+    return GAUSS_OK;
+}
+
+int gauss_hip_device_of(const gauss_ctx* ctx) { return ctx ? ctx->device : fail(GAUSS_E_INVALID, "ctx is NULL"); }
 
 void gauss_hip_destroy(gauss_ctx* ctx)
 {
@@ -1065,22 +1089,20 @@ static int ld_common(gauss_ctx* ctx, int mode, const uint8_t* geno, int n_snp, i
     std::vector<WinSpec> specs{w};
     int rc = job_build(ctx, specs, 0, &job);
     if (rc) return rc;
+    std::unique_ptr<gauss_job, void (*)(gauss_job*)> guard(job, job_free);
     if (!out_counts) job->plans[0].out_ld_user = out;
     rc = job_run(job, false);
-    if (!rc && out_counts) {
-        long long* d_cnt = nullptr;
+    if (rc) return rc;
+    if (out_counts) {
+        DevBuf d_cnt;
         const size_t bytes = sizeof(long long) * (size_t)n_snp * n_snp;
-        hipError_t e = hipMalloc((void**)&d_cnt, bytes);
-        if (e != hipSuccess) { job_free(job); return fail(GAUSS_E_NOMEM, "hipMalloc counts failed"); }
-        launch_counts(job->d_probs, 0, job->plans[0].p.npair, d_cnt, ctx->stream);
-        e = hipStreamSynchronize(ctx->stream);
-        if (e == hipSuccess) e = hipMemcpy(out_counts, d_cnt, bytes, hipMemcpyDeviceToHost);
-        hipFree(d_cnt);
-        if (e != hipSuccess) { job_free(job); return fail(GAUSS_E_DEVICE, "counts: %s", hipGetErrorString(e)); }
+        if (d_cnt.alloc(bytes) != hipSuccess) return fail(GAUSS_E_NOMEM, "hipMalloc(%zu bytes of counts) failed", bytes);
+        launch_counts(job->d_probs, 0, job->plans[0].p.npair, d_cnt.as<long long>(), ctx->stream);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        HIPCHK(hipMemcpy(out_counts, d_cnt.p, bytes, hipMemcpyDeviceToHost));
     }
-    if (!rc) rc = job_fetch(job);
-    job_free(job);
-    return rc;
+    return job_fetch(job);
 }
 
 int gauss_ld(gauss_ctx* ctx, int mode, const uint8_t* geno, int n_snp, int64_t ld, const int32_t* pop_off,
@@ -1112,21 +1134,18 @@ int gauss_ld_per_pop(gauss_ctx* ctx, const uint8_t* geno, int n_snp, int64_t ld,
     std::vector<WinSpec> specs{w};
     int rc = job_build(ctx, specs, 0, &job);
     if (rc) return rc;
+    std::unique_ptr<gauss_job, void (*)(gauss_job*)> guard(job, job_free);
     rc = job_run(job, false);
-    if (!rc) {
-        const size_t npairs = (size_t)n_snp * (n_snp - 1) / 2;
-        const size_t bytes = sizeof(double) * npairs * (size_t)n_pop;
-        double* d_out = nullptr;
-        hipError_t e = hipMalloc((void**)&d_out, bytes);
-        if (e != hipSuccess) { job_free(job); return fail(GAUSS_E_NOMEM, "hipMalloc(%zu bytes per-population LD) failed", bytes); }
-        launch_pop_cor(job->d_probs, 0, job->plans[0].p.npair, d_out, ctx->stream);
-        e = hipStreamSynchronize(ctx->stream);
-        if (e == hipSuccess) e = hipMemcpy(out, d_out, bytes, hipMemcpyDeviceToHost);
-        hipFree(d_out);
-        if (e != hipSuccess) { job_free(job); return fail(GAUSS_E_DEVICE, "per-population LD: %s", hipGetErrorString(e)); }
-    }
-    job_free(job);
-    return rc;
+    if (rc) return rc;
+    const size_t npairs = (size_t)n_snp * (n_snp - 1) / 2;
+    const size_t bytes = sizeof(double) * npairs * (size_t)n_pop;
+    DevBuf d_out;
+    if (d_out.alloc(bytes) != hipSuccess) return fail(GAUSS_E_NOMEM, "hipMalloc(%zu bytes per-population LD) failed", bytes);
+    launch_pop_cor(job->d_probs, 0, job->plans[0].p.npair, d_out.as<double>(), ctx->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipMemcpy(out, d_out.p, bytes, hipMemcpyDeviceToHost));
+    return GAUSS_OK;
 }
 
 int gauss_gram_counts(gauss_ctx* ctx, const uint8_t* geno, int n_snp, int n_samples, int64_t ld, int64_t* out_counts)
@@ -1144,14 +1163,15 @@ int gauss_pack2bit_device(gauss_ctx* ctx, const uint8_t* d_in, int64_t ld_in, ui
     for (int q = 0; q < n_pop; q++) blk[q + 1] = blk[q] + (int)rup((size_t)(pop_off[q + 1] - pop_off[q]), 64) / 4;
     if (ld_out % 16 || ld_out < blk[n_pop]) return fail(GAUSS_E_INVALID, "ld_out must be a multiple of 16 and >= %d", blk[n_pop]);
     HIPCHK(hipSetDevice(ctx->device));
-    int* d_tab = nullptr;
-    HIPCHK(hipMalloc((void**)&d_tab, sizeof(int) * 2 * (n_pop + 1)));
+    DevBuf tab;
+    HIPCHK(tab.alloc(sizeof(int) * 2 * (n_pop + 1)));
+    int* d_tab = tab.as<int>();
     HIPCHK(hipMemcpy(d_tab, pop_off, sizeof(int) * (n_pop + 1), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_tab + n_pop + 1, blk.data(), sizeof(int) * (n_pop + 1), hipMemcpyHostToDevice));
     HIPCHK(hipMemsetAsync(d_out, 0, (size_t)n_snp * ld_out, ctx->stream));
     launch_pack2bit(d_in, ld_in, d_out, ld_out, n_snp, d_tab, d_tab + n_pop + 1, n_pop, ctx->stream);
+    HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    hipFree(d_tab);
     return GAUSS_OK;
 }
 
@@ -1161,16 +1181,16 @@ int gauss_synth_device(gauss_ctx* ctx, uint8_t* d_out, int n_snp, int64_t ld, co
     if (!ctx || !d_out || !pop_off || !thr || !rho || n_snp < 1 || n_pop < 1) return fail(GAUSS_E_INVALID, "bad arguments");
     HIPCHK(hipSetDevice(ctx->device));
     const int N = pop_off[n_pop];
-    int* d_off = nullptr; float* d_thr = nullptr; float* d_rho = nullptr;
-    HIPCHK(hipMalloc((void**)&d_off, sizeof(int) * (n_pop + 1)));
-    HIPCHK(hipMalloc((void**)&d_thr, sizeof(float) * (size_t)n_snp * n_pop));
-    HIPCHK(hipMalloc((void**)&d_rho, sizeof(float) * n_snp));
-    HIPCHK(hipMemcpy(d_off, pop_off, sizeof(int) * (n_pop + 1), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d_thr, thr, sizeof(float) * (size_t)n_snp * n_pop, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d_rho, rho, sizeof(float) * n_snp, hipMemcpyHostToDevice));
-    launch_synth(d_out, n_snp, ld, d_off, n_pop, N, d_thr, d_rho, seed, ctx->stream);
+    DevBuf b_off, b_thr, b_rho;
+    HIPCHK(b_off.alloc(sizeof(int) * (n_pop + 1)));
+    HIPCHK(b_thr.alloc(sizeof(float) * (size_t)n_snp * n_pop));
+    HIPCHK(b_rho.alloc(sizeof(float) * n_snp));
+    HIPCHK(hipMemcpy(b_off.p, pop_off, sizeof(int) * (n_pop + 1), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(b_thr.p, thr, sizeof(float) * (size_t)n_snp * n_pop, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(b_rho.p, rho, sizeof(float) * n_snp, hipMemcpyHostToDevice));
+    launch_synth(d_out, n_snp, ld, b_off.as<int>(), n_pop, N, b_thr.as<float>(), b_rho.as<float>(), seed, ctx->stream);
+    HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    hipFree(d_off); hipFree(d_thr); hipFree(d_rho);
     return GAUSS_OK;
 }
 

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 namespace gauss {
 
@@ -110,6 +111,16 @@ struct Item {
 template <typename T> using gptr = T __attribute__((address_space(1)))*;
 template <typename T> __device__ __forceinline__ gptr<T> G(T* p) { return (gptr<T>)p; }
 template <typename T> __device__ __forceinline__ gptr<T> G(gptr<T> p) { return p; }
+
+// hipFuncSetAttribute is per device: true the first time the calling thread's current device is seen for `mask`
+// (one static mask per launcher), so a process that drives several GPUs sets the attribute on each of them.
+inline bool first_use_on_device(std::atomic<unsigned long long>& mask)
+{
+    int d = 0;
+    (void)hipGetDevice(&d);
+    const unsigned long long bit = 1ull << (d & 63);
+    return (mask.fetch_or(bit) & bit) == 0;
+}
 
 // ---- launchers (host functions defined in the .hip files) ----
 void launch_pack_stats(const Prob* d_probs, const int2* d_rowmap, int n_rows, hipStream_t s);

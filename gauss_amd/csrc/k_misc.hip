@@ -190,8 +190,8 @@ __global__ __launch_bounds__(256) void pack2bit_kernel(const uint8_t* __restrict
                                                        const int* __restrict__ pop_off, const int* __restrict__ blk_off,
                                                        int n_pop)
 {
-    const long long b = (long long)blockIdx.x * 256 + threadIdx.x;     // byte within the row
-    const int row = blockIdx.y;
+    const long long b = (long long)blockIdx.y * 256 + threadIdx.x;     // byte within the row
+    const int row = blockIdx.x;                                        // rows in grid.x: grid.y stops at 65 535
     if (b >= ld_out || row >= n_snp) return;
     int q = 0;
     while (q + 1 < n_pop && b >= blk_off[q + 1]) q++;
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void pack2bit_kernel(const uint8_t* __restrict
 void launch_pack2bit(const uint8_t* d_in, long long ld_in, uint8_t* d_out, long long ld_out, int n_snp,
                      const int* d_pop_off, const int* d_blk_off, int n_pop, hipStream_t s)
 {
-    hipLaunchKernelGGL(pack2bit_kernel, dim3((unsigned)((ld_out + 255) / 256), n_snp), dim3(256), 0, s, d_in, ld_in, d_out,
+    hipLaunchKernelGGL(pack2bit_kernel, dim3(n_snp, (unsigned)((ld_out + 255) / 256)), dim3(256), 0, s, d_in, ld_in, d_out,
                        ld_out, n_snp, d_pop_off, d_blk_off, n_pop);
 }
 

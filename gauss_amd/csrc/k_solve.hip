@@ -313,12 +313,11 @@ static const size_t FACTOR_SMEM = (size_t)2 * NB * LDT * sizeof(double);
 void launch_factor_step(const Prob* d_probs, int n_prob, int step, int max_nblk, hipStream_t st)
 {
     if (n_prob <= 0 || step >= max_nblk) return;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<unsigned long long> attr_set{0};
+    if (first_use_on_device(attr_set)) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(factor_init_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FACTOR_SMEM);
         hipFuncSetAttribute(reinterpret_cast<const void*>(factor_panel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FACTOR_SMEM);
         hipFuncSetAttribute(reinterpret_cast<const void*>(factor_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FACTOR_SMEM);
-        attr_set = true;
     }
     if (step == 0) {
         hipLaunchKernelGGL(factor_init_kernel, dim3(n_prob * 2), dim3(256), FACTOR_SMEM, st, d_probs);
@@ -475,11 +474,9 @@ void launch_solve(const Prob* d_probs, const int2* d_panelmap, int n_panels, hip
 {
     if (n_panels <= 0) return;
     const size_t sh = ((size_t)NB * LDT + (size_t)NB * LDV + 768) * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<unsigned long long> attr_set{0};
+    if (first_use_on_device(attr_set))
         hipFuncSetAttribute(reinterpret_cast<const void*>(solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-        attr_set = true;
-    }
     hipLaunchKernelGGL(solve_kernel, dim3(n_panels), dim3(256), sh, s, d_probs, d_panelmap);
 }
 

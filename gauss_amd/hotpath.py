@@ -44,10 +44,33 @@ class Context:
 _default_ctx = None
 
 
+def device_count():
+    """HIP devices visible to this process (gauss_hip_device_count; does not create a context)."""
+    n = C.c_int()
+    check(_lib.load().gauss_hip_device_count(C.byref(n)))
+    return n.value
+
+
+def rank_device(local_rank=None, n_devices=None):
+    """The device a rank of a one-process-per-GPU job owns: LOCAL_RANK modulo the visible devices.
+    GAUSS_SHARED_DEVICE=1 (a rehearsal of several ranks on one card) maps every rank to device 0."""
+    import os
+    if os.environ.get("GAUSS_SHARED_DEVICE") == "1" or os.environ.get("GAUSS_BENCH_SHARED_DEVICE") == "1":
+        return 0
+    if local_rank is None:
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if n_devices is None:
+        n_devices = device_count()
+    if n_devices < 1:
+        raise _lib.GaussHipError("no HIP device is visible: the hot path has no CPU fallback")
+    return int(local_rank) % int(n_devices)
+
+
 def default_context():
+    """One context per process, on the device this rank owns (LOCAL_RANK under torchrun, else 0)."""
     global _default_ctx
     if _default_ctx is None:
-        _default_ctx = Context(0)
+        _default_ctx = Context(rank_device())
     return _default_ctx
 
 

@@ -136,6 +136,10 @@ int gauss_store_free(gauss_ctx* ctx, void* device_ptr);
 
 /* ---- context ------------------------------------------------------------------------------- */
 int gauss_hip_init(int device, gauss_ctx** out_ctx);
+/* Number of HIP devices visible to the process (no context is created; a farm rank picks
+ * LOCAL_RANK modulo this), and the device index a context was created on. */
+int gauss_hip_device_count(int* out_n);
+int gauss_hip_device_of(const gauss_ctx* ctx);
 void gauss_hip_destroy(gauss_ctx* ctx);
 const char* gauss_last_error(void);
 const char* gauss_hip_version(void);

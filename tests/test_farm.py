@@ -140,3 +140,50 @@ def test_gpu_farm_packed_panel_resident_store(ctx, tmp_path):
         assert list(got["rsid"]) == list(text["rsid"])
         assert np.array_equal(got["z"].to_numpy(), text["z"].to_numpy())
         assert np.array_equal(got["info"].to_numpy(), text["info"].to_numpy())
+
+
+class _StubLib:
+    """Stands in for libgauss_hip.so: records the device gauss_hip_init is asked for (no GPU needed)."""
+
+    def __init__(self, n_devices):
+        self.n_devices = n_devices
+        self.init_devices = []
+
+    def gauss_hip_device_count(self, out):
+        out._obj.value = self.n_devices
+        return 0
+
+    def gauss_hip_init(self, device, out):
+        self.init_devices.append(device)
+        out._obj.value = 0xBEEF
+        return 0
+
+    def gauss_hip_destroy(self, handle):
+        pass
+
+
+@pytest.mark.parametrize("local_rank,n_dev,want", [(0, 8, 0), (3, 8, 3), (7, 8, 7), (9, 8, 1), (2, 1, 0)])
+def test_farm_rank_binds_its_own_device(monkeypatch, local_rank, n_dev, want):
+    """One process per GPU: the default context of rank r is created on device LOCAL_RANK % n_devices
+    (round 1 bound every rank to device 0)."""
+    from gauss_amd import _lib, hotpath
+    stub = _StubLib(n_dev)
+    monkeypatch.setattr(_lib, "load", lambda: stub)
+    monkeypatch.setattr(hotpath, "_default_ctx", None)
+    monkeypatch.setenv("LOCAL_RANK", str(local_rank))
+    monkeypatch.delenv("GAUSS_SHARED_DEVICE", raising=False)
+    monkeypatch.delenv("GAUSS_BENCH_SHARED_DEVICE", raising=False)
+    ctx = hotpath.default_context()
+    assert stub.init_devices == [want] and ctx.device == want
+    monkeypatch.setattr(hotpath, "_default_ctx", None)
+    monkeypatch.setenv("GAUSS_SHARED_DEVICE", "1")          # rehearsal: several ranks on one card
+    assert hotpath.default_context().device == 0
+    monkeypatch.setattr(hotpath, "_default_ctx", None)
+
+
+@pytest.mark.gpu
+def test_gpu_context_reports_its_device(ctx):
+    from gauss_amd import hotpath
+    assert ctx.lib.gauss_hip_device_of(ctx.handle) == ctx.device
+    assert hotpath.device_count() >= 1
+    assert hotpath.rank_device(local_rank=hotpath.device_count() + 2) == 2 % hotpath.device_count()

@@ -39,6 +39,50 @@ def pmc(dirname, counter):
     return per
 
 
+def pmc_all(dirname):
+    """kernel -> counter -> (sum over dispatches, dispatches)"""
+    f = find(dirname, "*counter_collection.csv")
+    acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+    if f:
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                a = acc[short(row["Kernel_Name"])][row["Counter_Name"]]
+                a[0] += float(row["Counter_Value"])
+                a[1] += 1
+    return acc
+
+
+def sq_mfma(tag, d, out):
+    """Wave-state fractions and matrix-core utilisation per kernel (MI355X_MICROARCH.md, rocprofv3 PMC slots):
+    parked = SQ_WAIT_ANY, issue stall = SQ_WAIT_INST_ANY, issuing = SQ_ACTIVE_INST_ANY, each / SQ_WAVE_CYCLES
+    (all three in quad-cycles); mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES (cycles, summed over the chip's SIMD pipes as
+    reported) / (4 * SQ_BUSY_CYCLES) -- the share of the kernel's busy time its matrix pipes were executing."""
+    a = pmc_all(os.path.join(d, "pmc_sq"))
+    b = pmc_all(os.path.join(d, "pmc_sq2"))
+    if not a:
+        return
+    cols = ["SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY",
+            "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_F32", "SQ_INSTS_VALU_MFMA_MOPS_F64"]
+    cols2 = ["GRBM_GUI_ACTIVE", "SQ_INSTS_MFMA", "SQ_INSTS_VALU", "SQ_WAIT_INST_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE",
+             "SQ_VALU_MFMA_COEXEC_CYCLES"]
+    with open(os.path.join(out, f"{tag}_sq_mfma.csv"), "w") as fh:
+        fh.write("kernel,launches,parked_frac,issue_stall_frac,issuing_frac,mfma_busy_over_4x_sq_busy," +
+                 ",".join(c + "_per_launch" for c in cols + cols2) + "\n")
+        for k in sorted(a):
+            if "gauss" not in k:
+                continue
+            v = a[k]
+            n = max(1, v["SQ_WAVE_CYCLES"][1])
+            w = v["SQ_WAVE_CYCLES"][0] or 1.0
+            busy = v["SQ_BUSY_CYCLES"][0] or 1.0
+            row = [k, str(n), "%.3f" % (v["SQ_WAIT_ANY"][0] / w), "%.3f" % (v["SQ_WAIT_INST_ANY"][0] / w),
+                   "%.3f" % (v["SQ_ACTIVE_INST_ANY"][0] / w), "%.3f" % (v["SQ_VALU_MFMA_BUSY_CYCLES"][0] / (4.0 * busy))]
+            row += ["%.0f" % (v[c][0] / n) for c in cols]
+            vb = b.get(k, {})
+            row += ["%.0f" % (vb[c][0] / max(1, vb[c][1])) if c in vb else "" for c in cols2]
+            fh.write(",".join(row) + "\n")
+
+
 def main():
     tag, d = sys.argv[1], sys.argv[2]
     out = os.path.join(d, "summary")
@@ -61,6 +105,7 @@ def main():
             wa = sum(write[k]) / max(1, len(write[k]))
             # gfx950: FETCH_SIZE under-counts wide coalesced reads by 2x (MI355X_MICROARCH.md, HBM section)
             fh.write(f"{k},{max(len(fetch[k]), len(write[k]))},{fa:.1f},{wa:.1f},{int((2 * fa + wa) * 1024)}\n")
+    sq_mfma(tag, d, out)
     print("summaries in", out, os.listdir(out))
 
 
