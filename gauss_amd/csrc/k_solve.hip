@@ -19,6 +19,7 @@
 // rows (lane>>4) + 4*reg, column lane&15).  A workgroup is 4 waves; wave w owns rows 16w..16w+15
 // of a 64-row block.
 #include "gauss_internal.h"
+#include <cstdlib>
 
 namespace gauss {
 
@@ -173,6 +174,170 @@ __device__ int tile_chol_inv(double* __restrict__ D, double* __restrict__ X, int
     return *s_flag;
 }
 
+// ------------------------------------------------------------------------------------------
+// MFMA-blocked form of the same routine (block columns of 16), the one the factor kernels use.
+//   for K = 0..3:   wave 0 holds block column K in registers, lane = tile row r (rows >= 16K matter), and runs
+//                   the 16 pivot steps of that column on the whole 64-row panel at once: pivot by v_readlane,
+//                   1/sqrt by v_rsq_f64 + Newton, column scale, and the rank-1 update of the panel's remaining
+//                   columns with the multipliers L[16K+c][j] fetched by v_readlane (no LDS round trip, no
+//                   workgroup barrier inside a block column; the rows below the diagonal block come out as the
+//                   finished panel, so no triangular solve / inverse is needed on this critical path);
+//                   then all four waves apply the rank-16 update of the trailing blocks on the fp64 matrix cores.
+//   X = L^-1:       the four diagonal 16x16 blocks are inverted in parallel (wave w: block w, lane = column of X,
+//                   forward substitution with wave-uniform L entries), the off-diagonal blocks follow by distance
+//                   from the diagonal:  X_ij = -X_ii * sum_{m=j}^{i-1} L_im X_mj   (two small MFMA products).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// wave 0: the 16 pivot steps of block column K on the 64-row panel (lane = row).  `bad` is wave-uniform.
+template <int K>
+__device__ __forceinline__ void chol_block_column(double* __restrict__ D, double* __restrict__ s_rinv, int lane, int& bad)
+{
+    double a[16];
+#pragma unroll
+    for (int c = 0; c < 16; c += 2) {
+        const f64x2 v = *reinterpret_cast<const f64x2*>(D + lane * LDT + 16 * K + c);
+        a[c] = v[0]; a[c + 1] = v[1];
+    }
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const int jj = 16 * K + j;
+        const double piv = readlane_f64(a[j], jj);
+        if (!(piv > 0.0)) bad = 1;
+        double r = __builtin_amdgcn_rsq(piv);
+        const double h = 0.5 * piv;
+        r = fma(r, fma(-h * r, r, 0.5), r);
+        r = fma(r, fma(-h * r, r, 0.5), r);
+        double d = piv * r;
+        d = fma(fma(-d, d, piv), 0.5 * r, d);
+        const double l = (lane == jj) ? d : a[j] * r;        // rows above jj hold junk that is never stored
+        a[j] = l;
+        if (lane == jj) s_rinv[jj] = r;                      // 1 / L[jj][jj]
+#pragma unroll
+        for (int c = j + 1; c < 16; c++) {
+            const double lc = readlane_f64(l, 16 * K + c);   // L[16K + c][jj], wave-uniform
+            a[c] = fma(-l, lc, a[c]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 16; c += 2) {
+        f64x2 v;
+        v[0] = (lane >= 16 * K + c) ? a[c] : 0.0;
+        v[1] = (lane >= 16 * K + c + 1) ? a[c + 1] : 0.0;
+        *reinterpret_cast<f64x2*>(D + lane * LDT + 16 * K + c) = v;
+    }
+}
+
+// D_ij -= L_iK L_jK^T for one 16 x 16 block (i >= j > K), one wave
+template <int K>
+__device__ __forceinline__ void chol_trailing_block(double* __restrict__ D, int i, int j, int lane)
+{
+    const int lr = lane & 15, lk = lane >> 4;
+    f64x4 acc;
+#pragma unroll
+    for (int r = 0; r < 4; r++) acc[r] = D[(16 * i + lk + 4 * r) * LDT + 16 * j + lr];
+#pragma unroll
+    for (int k0 = 0; k0 < 16; k0 += 4)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-D[(16 * i + lr) * LDT + 16 * K + k0 + lk],
+                                                   D[(16 * j + lr) * LDT + 16 * K + k0 + lk], acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; r++) D[(16 * i + lk + 4 * r) * LDT + 16 * j + lr] = acc[r];
+}
+
+template <int K>
+__device__ __forceinline__ void chol_trailing(double* __restrict__ D, int wave, int lane)
+{
+    int t = 0;
+#pragma unroll
+    for (int j = K + 1; j < 4; j++)
+#pragma unroll
+        for (int i = j; i < 4; i++) {
+            if ((t & 3) == wave) chol_trailing_block<K>(D, i, j, lane);
+            t++;
+        }
+}
+
+__device__ int tile_chol_inv_blk(double* __restrict__ D, double* __restrict__ X, int tid, int* s_flag)
+{
+    __shared__ double s_rinv[NB];
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid == 0) *s_flag = 0;
+    for (int e = tid; e < NB * NB; e += 256) X[(e >> 6) * LDT + (e & 63)] = 0.0;
+    __syncthreads();
+    int bad = 0;
+    if (wave == 0) chol_block_column<0>(D, s_rinv, lane, bad);
+    __syncthreads();
+    chol_trailing<0>(D, wave, lane);
+    __syncthreads();
+    if (wave == 0) chol_block_column<1>(D, s_rinv, lane, bad);
+    __syncthreads();
+    chol_trailing<1>(D, wave, lane);
+    __syncthreads();
+    if (wave == 0) chol_block_column<2>(D, s_rinv, lane, bad);
+    __syncthreads();
+    chol_trailing<2>(D, wave, lane);
+    __syncthreads();
+    if (wave == 0) { chol_block_column<3>(D, s_rinv, lane, bad); if (bad && lane == 0) *s_flag = 1; }
+    __syncthreads();
+    // the strict upper blocks of D were never touched by the factorisation: clear them (L is lower triangular)
+    for (int e = tid; e < NB * NB; e += 256) {
+        const int r = e >> 6, c = e & 63;
+        if ((c >> 4) > (r >> 4)) D[r * LDT + c] = 0.0;
+    }
+    // ---- X_ww = L_ww^-1: lane c (< 16) solves L_ww x = e_c by forward substitution; the L entries are wave-uniform
+    {
+        const int c = lane & 15, b = 16 * wave;
+        double sacc[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) sacc[i] = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const double xj = sacc[j] * s_rinv[b + j];
+            sacc[j] = xj;
+#pragma unroll
+            for (int i = j + 1; i < 16; i++) sacc[i] = fma(-D[(b + i) * LDT + b + j], xj, sacc[i]);
+        }
+        if (lane < 16) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) X[(b + i) * LDT + b + c] = sacc[i];     // exact zeros above the diagonal
+        }
+    }
+    __syncthreads();
+    // ---- off-diagonal blocks by distance from the diagonal
+    const int lr = lane & 15, lk = lane >> 4;
+#pragma unroll
+    for (int dist = 1; dist < 4; dist++) {
+        const int i = dist + wave, j = wave;                    // block (i, j): one per wave, 4 - dist of them
+        if (i < 4) {
+            f64x4 s = f64x4{0.0, 0.0, 0.0, 0.0};
+            for (int m = j; m < i; m++)
+#pragma unroll
+                for (int k0 = 0; k0 < 16; k0 += 4)
+                    s = __builtin_amdgcn_mfma_f64_16x16x4f64(D[(16 * i + lr) * LDT + 16 * m + k0 + lk],
+                                                             X[(16 * m + k0 + lk) * LDT + 16 * j + lr], s, 0, 0, 0);
+            // park S in the (still empty) X_ij block, then X_ij = -X_ii S
+#pragma unroll
+            for (int r = 0; r < 4; r++) X[(16 * i + lk + 4 * r) * LDT + 16 * j + lr] = s[r];
+            WAVE_LDS_SYNC();
+            f64x4 o = f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int k0 = 0; k0 < 16; k0 += 4)
+                o = __builtin_amdgcn_mfma_f64_16x16x4f64(-X[(16 * i + lr) * LDT + 16 * i + k0 + lk],
+                                                         X[(16 * i + k0 + lk) * LDT + 16 * j + lr], o, 0, 0, 0);
+            WAVE_LDS_SYNC();
+#pragma unroll
+            for (int r = 0; r < 4; r++) X[(16 * i + lk + 4 * r) * LDT + 16 * j + lr] = o[r];
+        }
+        __syncthreads();
+    }
+    return *s_flag;
+}
+
 // Layout of the factor workspace of one problem: pb.A = [A0 | A1 | L0 | L1 | W0], each Mld x Mld
 // row-major; pb.Linv = [2][nblk][NB x NB] inverses of the diagonal blocks of L.
 
@@ -195,6 +360,64 @@ __device__ __forceinline__ GP(double) factor_work(const Prob& pb, int mat)
     return mat == 0 ? pb.A + 4 * ld2 : pb.A + ld2;
 }
 
+// ------------------------------------------------------------------------------------------
+// Certificate that the shifted factorisation is not needed.  MakePosDef (util.cpp:302-318) / CountPC
+// (util.cpp:355-388) act only if lambda_min(B11) < eps, and B11 = R + lambda I with R the LD matrix in exact
+// arithmetic plus rounding noise E, |E|_2 <= M * 1e-15.  For the pooled estimator R is a Gram matrix of
+// standardised rows: PSD.  For the weighted estimator (util.cpp:103-124), in covariance scale
+//     C = sum_p wf_p m_p (centred Gram of population p)  +  [ sum_p w_p mu_p mu_p^T - mubar mubar^T ],
+// the first term is PSD for w_p >= 0, and by Cauchy-Schwarz the bracket is >= -(W - 1)_+ sum_p w_p mu_p mu_p^T
+// with W = sum_p w_p (the PGC2 weights are un-normalised, W = 1.061).  In correlation scale therefore
+//     lambda_min(B11) >= lambda - (W - 1)_+ * sum_p w_p sum_i (mu_p(i) / sd_i)^2 - M * 1e-10.
+// If that bound exceeds eps the predicate is decided (status[3] = 1) and matrix 1 = B11 - eps I is never
+// factored; otherwise (negative weights, degenerate rows, tiny lambda) the exact test runs as before.
+// The m^2 scaling of the reference's covariance (quirk Q1) makes the correction term ~1e-3 on real panels.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void shift_cert_kernel(const Prob* __restrict__ probs)
+{
+    __shared__ double red[256];
+    __shared__ int s_ok;
+    const Prob& pb = probs[blockIdx.x];
+    if (pb.ld_only || pb.npanel == 0) return;
+    const int tid = threadIdx.x;
+    const int P = pb.P;
+    if (tid == 0) s_ok = 1;
+    __syncthreads();
+    double wtot = 0.0;
+    int ok = 1;
+    if (pb.mode != 0)
+        for (int p = 0; p < P; p++) {
+            const double w = pb.pop_w[p];
+            if (!(w >= 0.0) || !(pb.pop_md[p] >= 2.0)) ok = 0;
+            wtot += w;
+        }
+    else wtot = 1.0;
+    double acc = 0.0;
+    for (int i = tid; i < pb.M; i += 256) {
+        const double sd = pb.rt_sd[i];
+        if (!(sd > 0.0) || !(sd < 1e300)) ok = 0;
+        if (pb.mode != 0) {
+            const double inv = 1.0 / (sd * sd);
+            for (int p = 0; p < P; p++) {
+                const double mu = pb.rt_mu[(size_t)i * P + p];
+                acc = fma(pb.pop_w[p] * mu, mu * inv, acc);
+            }
+        }
+    }
+    if (!ok) s_ok = 0;
+    red[tid] = acc;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if (tid < h) red[tid] += red[tid + h];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double excess = wtot > 1.0 ? wtot - 1.0 : 0.0;
+        const double bound = pb.lambda - excess * red[0] - 1e-10 * (double)pb.M;
+        pb.status[3] = (s_ok && bound > pb.eps) ? 1 : 0;       // NaN compares false
+    }
+}
+
 __global__ __launch_bounds__(256) void factor_init_kernel(const Prob* __restrict__ probs)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -204,11 +427,12 @@ __global__ __launch_bounds__(256) void factor_init_kernel(const Prob* __restrict
     const Prob& pb = probs[blockIdx.x >> 1];
     const int mat = blockIdx.x & 1;
     if (pb.ld_only || pb.npanel == 0) return;
+    if (mat == 1 && pb.status[3]) return;              // certified: lambda_min(B11) > eps
     const int tid = threadIdx.x, ld = pb.Mld;
     const auto W = factor_work(pb, mat);
     const auto Lm = pb.A + (size_t)(2 + mat) * ld * ld;
     tile_load(TD, W, ld, tid);
-    const int fail = tile_chol_inv(TD, TX, tid, &s_flag);
+    const int fail = tile_chol_inv_blk(TD, TX, tid, &s_flag);
     tile_store(Lm, ld, TD, tid);
     const auto Li = pb.Linv + (size_t)mat * pb.nblk * NB * NB;
     for (int e = tid; e < NB * NB; e += 256) Li[e] = TX[(e >> 6) * LDT + (e & 63)];
@@ -224,6 +448,7 @@ __global__ __launch_bounds__(256) void factor_panel_kernel(const Prob* __restric
     const Prob& pb = probs[blockIdx.y >> 1];
     const int mat = blockIdx.y & 1;
     if (pb.ld_only || pb.npanel == 0) return;
+    if (mat == 1 && pb.status[3]) return;              // certified: lambda_min(B11) > eps
     const int nb = pb.nblk;
     const int k = s + 1 + blockIdx.x;
     if (k >= nb) return;
@@ -260,6 +485,7 @@ __global__ __launch_bounds__(256) void factor_update_kernel(const Prob* __restri
     const Prob& pb = probs[blockIdx.y >> 1];
     const int mat = blockIdx.y & 1;
     if (pb.ld_only || pb.npanel == 0) return;
+    if (mat == 1 && pb.status[3]) return;              // certified: lambda_min(B11) > eps
     const int nb = pb.nblk;
     // x -> (jj, kk), 0 <= jj <= kk < T, column-major over the lower triangle: x = 0 is (0, 0)
     int jj = 0, rem = blockIdx.x;
@@ -300,7 +526,7 @@ __global__ __launch_bounds__(256) void factor_update_kernel(const Prob* __restri
 #pragma unroll
         for (int r = 0; r < 4; r++) TA[acc_row(wave, lane, r) * LDT + acc_col(lane, n)] = acc[n][r];
     __syncthreads();
-    const int fail = tile_chol_inv(TA, TB, tid, &s_flag);             // TA = L_dd, TB = its inverse
+    const int fail = tile_chol_inv_blk(TA, TB, tid, &s_flag);         // TA = L_dd, TB = its inverse
     tile_store(Lm + (size_t)k * NB * ld + (size_t)k * NB, ld, TA, tid);
     const auto Li = pb.Linv + ((size_t)mat * nb + k) * NB * NB;
     for (int e = tid; e < NB * NB; e += 256) Li[e] = TB[(e >> 6) * LDT + (e & 63)];
@@ -320,6 +546,8 @@ void launch_factor_step(const Prob* d_probs, int n_prob, int step, int max_nblk,
         hipFuncSetAttribute(reinterpret_cast<const void*>(factor_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FACTOR_SMEM);
     }
     if (step == 0) {
+        static const bool no_cert = getenv("GAUSS_NO_SHIFT_CERT") != nullptr;     // experiment: always run the exact test
+        if (!no_cert) hipLaunchKernelGGL(shift_cert_kernel, dim3(n_prob), dim3(256), 0, st, d_probs);
         hipLaunchKernelGGL(factor_init_kernel, dim3(n_prob * 2), dim3(256), FACTOR_SMEM, st, d_probs);
         return;
     }

@@ -403,3 +403,23 @@ def test_per_population_ld_matches_oracle(ctx):
     assert np.array_equal(np.isnan(got), nan) and nan.mean() < 0.5
     assert np.max(np.abs(got[~nan] - want[~nan])) <= LD_TOL
     assert np.mean(got[~nan] == want[~nan]) > 0.999
+
+
+@pytest.mark.parametrize("wscale,lam", [(1.0, 0.1), (3.0, 0.1), (3.0, 2e-5), (8.0, 1e-3), (40.0, 1e-3), (1.0, 0.0)])
+def test_shift_certificate_never_changes_the_answer(ctx, wscale, lam):
+    """The factorisation of B11 - eps I is skipped when lambda - (sum w - 1)+ * sum_p w_p |mu_p / sd|^2 certifies
+    lambda_min(B11) > eps (k_solve.hip:shift_cert_kernel).  Whatever the certificate decides -- weights far above
+    1, lambda next to eps, lambda = 0 -- z, info and the MakePosDef decision must equal the oracle's, which runs
+    the reference's eigen-decomposition test (util.cpp:302-318)."""
+    p = small_panel(n_snp=90, scale=0.02, n_pops=7, seed=31)
+    gm, gu, z1 = split_window(p, 40)
+    w = p["w"] * wscale
+    got = hotpath.impute_window(1, gm, gu, p["off"], w, z1, lam=lam, ctx=ctx)
+    want = oracle.run_impute(1, gm, gu, p["off"], w, z1, lam=lam, want_mats=True)
+    if want["mpd"] < 0:       # weights far above 1 can turn a self-covariance negative: NaN everywhere, like the reference
+        assert got["status"] & 2 and np.all(np.isnan(got["z"])) and np.all(np.isnan(want["z"]))
+        return
+    assert bool(got["status"] & 1) == bool(want["mpd"])
+    tol = 1e-5 if want["mpd"] else 1e-8
+    assert relerr(got["info"], want["info"]) <= tol
+    assert np.max(np.abs(got["z"] - want["z"]) / np.maximum(1.0, np.abs(want["z"]))) <= tol

@@ -213,6 +213,29 @@ __global__ __launch_bounds__(256) void probe_regs(const double* A, double* L, do
     if (tid == 0) cycles[0] = best;
 }
 
+template <bool BLK>
+__global__ __launch_bounds__(256) void probe_kernel_t(const double* A, double* L, double* Xo, long long* cycles, int reps)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* TD = smem;
+    double* TX = TD + NB * LDT;
+    __shared__ int s_flag;
+    const int tid = threadIdx.x;
+    long long best = 1LL << 60;
+    for (int r = 0; r < reps; r++) {
+        for (int e = tid; e < NB * NB; e += 256) TD[(e >> 6) * LDT + (e & 63)] = A[e];
+        __syncthreads();
+        const long long t0 = wall_clock64();
+        const int fail = BLK ? tile_chol_inv_blk(TD, TX, tid, &s_flag) : tile_chol_inv(TD, TX, tid, &s_flag);
+        const long long t1 = wall_clock64();
+        if (t1 - t0 < best) best = t1 - t0;
+        if (fail && tid == 0) cycles[1] = 1;
+        __syncthreads();
+    }
+    for (int e = tid; e < NB * NB; e += 256) { L[e] = TD[(e >> 6) * LDT + (e & 63)]; Xo[e] = TX[(e >> 6) * LDT + (e & 63)]; }
+    if (tid == 0) cycles[0] = best;
+}
+
 __global__ __launch_bounds__(256) void probe_kernel(const double* A, double* L, double* Xo, long long* cycles, int reps)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -265,6 +288,28 @@ int main()
     hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, 0);
     printf("tile_chol_inv: %lld wall-clock ticks at %d kHz = %.2f us (min of 20), fail=%lld, |LL^T-A|=%.2e |XL-I|=%.2e\n",
            c[0], khz, khz ? c[0] * 1e3 / khz : 0.0, c[1], e1, e2);
+    for (int blk = 0; blk < 2; blk++) {
+        auto kern = blk ? probe_kernel_t<true> : probe_kernel_t<false>;
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        hipMemset(dc, 0, 16);
+        hipLaunchKernelGGL(kern, dim3(1), dim3(256), sh, 0, dA, dL, dX, dc, 20);
+        hipDeviceSynchronize();
+        hipMemcpy(c, dc, 16, hipMemcpyDeviceToHost);
+        hipMemcpy(L.data(), dL, sizeof(double) * n * n, hipMemcpyDeviceToHost);
+        hipMemcpy(X.data(), dX, sizeof(double) * n * n, hipMemcpyDeviceToHost);
+        double f1 = 0, f2 = 0, up = 0;
+        for (int i = 0; i < n; i++)
+            for (int j = 0; j < n; j++) {
+                double s2 = 0, t2 = 0;
+                for (int k = 0; k < n; k++) { s2 += L[i * n + k] * L[j * n + k]; t2 += X[i * n + k] * L[k * n + j]; }
+                f1 = std::fmax(f1, std::fabs(s2 - A[i * n + j]));
+                f2 = std::fmax(f2, std::fabs(t2 - (i == j ? 1.0 : 0.0)));
+                if (j > i) up = std::fmax(up, std::fmax(std::fabs(L[i * n + j]), std::fabs(X[i * n + j])));
+            }
+        printf("%s  %.2f us  fail=%lld |LL^T-A|=%.2e |XL-I|=%.2e upper=%.1e\n",
+               blk ? "tile_chol_inv_blk (MFMA-blocked, product)" : "tile_chol_inv (rank-1 sweep, round 1)    ",
+               khz ? c[0] * 1e3 / khz : 0.0, c[1], f1, f2, up);
+    }
     auto run = [&](auto kern, const char* what) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
         hipMemset(dc, 0, 16);
