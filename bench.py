@@ -62,6 +62,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-weak-line", action="store_true", help="N > 1, strong: skip the extra weak-scaling pass")
     ap.add_argument("--verify-shards", action="store_true",
                     help="N > 1, strong: rank 0 also runs every window itself and checks the ranks' z / info bit for bit")
+    ap.add_argument("--no-e2e", action="store_true", help="N = 1: skip the end_to_end block (files on disk -> result table)")
     ap.add_argument("--streams", type=int, default=1, help="split a rank's windows over this many jobs/streams")
     return ap.parse_args(argv)
 
@@ -267,8 +268,9 @@ def run_impute(args, rig):
     store, ld2 = pack_store(rig, ch, panel, ld)
     keep0 = None
     if rig.rank == 0 and not args.no_cpu_baseline and rig.world == 1:
-        _, mi, ui = wins[0]                                   # window 0 also feeds the CPU baseline sample
-        keep0 = (panel.index_select(0, torch.from_numpy(mi[:600]).cuda()).cpu().numpy(),
+        k0 = next((k for k, w in enumerate(wins) if len(w[1]) >= 600 and len(w[2]) >= 600), 0)
+        _, mi, ui = wins[k0]                                  # this window also feeds the CPU baseline sample
+        keep0 = (k0, panel.index_select(0, torch.from_numpy(mi[:600]).cuda()).cpu().numpy(),
                  panel.index_select(0, torch.from_numpy(ui[:600]).cuda()).cpu().numpy())
     del panel
     full_store = store
@@ -330,6 +332,14 @@ def run_impute(args, rig):
         weak = {"scaling": "weak", "value": ws / (wt / args.steps), "unit": "imputed SNPs/s", "ms_per_step": wt / args.steps * 1e3,
                 "workload": "the whole chromosome on every rank"}
         wr.close()
+
+    e2e = None
+    if rig.world == 1 and args.mode == "distmix" and not args.no_e2e and not args.windows and args.streams == 1:
+        runner.close()
+        del store, full_store
+        torch.cuda.empty_cache()
+        from gauss_amd import benchmodes
+        e2e = benchmodes.e2e_block(args, rig, ch, steps=5)
 
     out = None
     if rig.rank == 0:
@@ -398,6 +408,8 @@ def run_impute(args, rig):
             out["weak_scaling"] = weak
         if i8_variant is not None:
             out["int8_exact_variant"] = i8_variant
+        if e2e is not None:
+            out["end_to_end"] = e2e
         if keep0 is not None:
             out["cpu_baseline"] = cpu_baseline(ch, wins, keep0, work, 0 if args.mode == "dist" else 1)
         print(json.dumps(out), flush=True)
@@ -431,8 +443,8 @@ def cpu_baseline(ch, wins, keep0, work, mode=1):
     the workload by its pair count: the reference's cost is N inner iterations per SNP pair
     (util.cpp:103-124), M(M+1)/2 + U + U*M pairs per window (distmix.cpp:180-217)."""
     import oracle
-    gm, gu = keep0
-    _, mi, ui = wins[0]
+    k0, gm, gu = keep0
+    _, mi, ui = wins[k0]
     N = int(ch["off"][-1])
     ms_ = min(600, gm.shape[0], 150 if N < 5000 else 600)
     gm_h = np.ascontiguousarray(gm[:ms_, :N])
@@ -459,7 +471,7 @@ def cpu_baseline(ch, wins, keep0, work, mode=1):
         "host_cores": os.cpu_count(),
         "windows_in_parallel": {"value": work["imputed_snps"] / est_par, "unit": "imputed SNPs/s", "cores": par,
                                 "sample": f"{par} concurrent copies of the same sample in {tp:.2f} s"},
-        "sample": f"oracle run_{'distmix' if mode else 'dist'} on a sub-window of window 0 (M={m}, U={u}, N={N}): {t:.2f} s for "
+        "sample": f"oracle run_{'distmix' if mode else 'dist'} on a sub-window of window {k0} (M={m}, U={u}, N={N}): {t:.2f} s for "
                   f"{pairs_sample:.0f} SNP pairs; scaled by the workload's {pairs_total:.3g} pairs "
                   f"(estimated {est:.0f} s per chromosome, dense tail of the full-size windows not included)",
     }

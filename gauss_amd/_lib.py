@@ -52,7 +52,7 @@ _lib = None
 SYMBOLS = [
     "gauss_hip_init", "gauss_hip_device_count", "gauss_hip_device_of", "gauss_hip_destroy", "gauss_last_error", "gauss_hip_version", "gauss_hip_set_gram_dtype", "gauss_pinned_alloc", "gauss_pinned_free", "gauss_store_upload", "gauss_store_free", "gauss_pack2bit_device", "gauss_ld", "gauss_ld_per_pop",
     "gauss_impute_window", "gauss_gene_ld_batch", "gauss_gram_counts", "gauss_job_create",
-    "gauss_job_run", "gauss_job_fetch", "gauss_job_destroy", "gauss_job_profile",
+    "gauss_job_run", "gauss_job_fetch", "gauss_job_destroy", "gauss_job_span_ms", "gauss_job_profile",
     "gauss_job_profile_get", "gauss_job_work", "gauss_job_stats", "gauss_synth_device",
 ]
 
@@ -97,6 +97,7 @@ def load():
     lib.gauss_job_fetch.argtypes = [C.c_void_p]
     lib.gauss_job_destroy.argtypes = [C.c_void_p]
     lib.gauss_job_destroy.restype = None
+    lib.gauss_job_span_ms.argtypes = [C.c_void_p, C.c_void_p, _dp]
     lib.gauss_job_profile.argtypes = [C.c_void_p, C.c_int]
     lib.gauss_job_profile_get.argtypes = [C.c_void_p, C.c_int, _dp, C.POINTER(C.c_int64)]
     lib.gauss_job_work.argtypes = [C.c_void_p, _dp, _dp, _dp, C.POINTER(C.c_int64)]

@@ -38,7 +38,17 @@ HOST_SYMBOLS = [
     "gauss_prepared_geno_u", "gauss_prepared_pop_off", "gauss_prepared_pop_wgt", "gauss_prepared_z1",
     "gauss_prepared_gene_off", "gauss_prepared_window_desc", "gauss_prepared_finish", "gauss_prepared_free",
     "gauss_host_bgzf_copy", "gauss_host_set_threads",
+    "gauss_host_panel_resident", "gauss_host_panel_evict", "gauss_host_impute_chromosome", "gauss_table_n_messages",
+    "gauss_table_message", "gauss_table_strcol_fixed",
 ]
+
+
+class ChromStats(C.Structure):
+    """gauss_chrom_stats (include/gauss_host.h)"""
+    _fields_ = [("n_windows", C.c_int32), ("n_windows_mine", C.c_int32), ("n_skipped", C.c_int32), ("n_failed", C.c_int32),
+                ("n_batches", C.c_int32), ("pad_", C.c_int32), ("imputed", C.c_int64), ("panel_bytes_uploaded", C.c_int64),
+                ("t_total", C.c_double), ("t_plan", C.c_double), ("t_panel_upload", C.c_double), ("t_feeder_wait", C.c_double),
+                ("t_job_create", C.c_double), ("t_gpu_wait", C.c_double), ("t_tables", C.c_double), ("gpu_span_ms", C.c_double)]
 
 
 class GaussError(RuntimeError):
@@ -123,6 +133,15 @@ def load_host():
     h.gauss_host_set_threads.restype = None
     h.gauss_host_bgzf_copy.restype = _i64
     h.gauss_host_bgzf_copy.argtypes = [_cp, _cp]
+    h.gauss_host_panel_resident.argtypes = [_vp, _cp, C.POINTER(_i64)]
+    h.gauss_host_panel_evict.argtypes = [_vp, _cp]
+    h.gauss_host_impute_chromosome.argtypes = [_vp, C.c_int, C.c_int, _i64, _i64, _i64, _i64, _cp, _strs, _dp, C.c_int, _cp, _cp, _cp,
+                                               _dbl, C.c_int, C.c_int, C.c_int, C.POINTER(_vp), C.POINTER(ChromStats)]
+    h.gauss_table_n_messages.argtypes = [_vp]
+    h.gauss_table_message.restype = _cp
+    h.gauss_table_message.argtypes = [_vp, C.c_int]
+    h.gauss_table_strcol_fixed.restype = C.c_void_p
+    h.gauss_table_strcol_fixed.argtypes = [_vp, C.c_int, C.POINTER(C.c_int)]
     _host = h
     return h
 
@@ -328,6 +347,93 @@ def jepegmix(pop_wgt_df, input_file, annotation_file, reference_index_file, refe
                                   _enc(reference_index_file), _enc(reference_data_file), _enc(reference_pop_desc_file),
                                   _af(af1_cutoff), C.byref(out)))
     return _table(h, out)[0]
+
+
+def _columns(h, t):
+    """gauss_table -> {name: numpy array}; string columns come across as ONE fixed-width bytes array each
+    (dtype "S<w>"), not as Python strings: a chromosome's table has ~10^5 rows."""
+    cols = {}
+    n = h.gauss_table_nrow(t)
+    for c in range(h.gauss_table_ncol(t)):
+        name = h.gauss_table_colname(t, c).decode()
+        ty = h.gauss_table_coltype(t, c)
+        if ty == 0:
+            w = C.c_int()
+            buf = h.gauss_table_strcol_fixed(t, c, C.byref(w))
+            cols[name] = (np.frombuffer(C.string_at(buf, n * w.value), dtype=f"S{w.value}").copy() if (n and buf)
+                          else np.zeros(0, dtype="S1"))
+        elif ty == 1:
+            cols[name] = np.ctypeslib.as_array(h.gauss_table_int(t, c), shape=(n,)).copy() if n else np.zeros(0, np.int32)
+        else:
+            cols[name] = np.ctypeslib.as_array(h.gauss_table_dbl(t, c), shape=(n,)).copy() if n else np.zeros(0)
+    return cols
+
+
+class ChromResult:
+    """What gauss_host_impute_chromosome hands back for one rank: `columns` (the reference's output columns as numpy
+    arrays plus "window"), `windows` [n_windows x 6: start_bp end_bp owner status measured unmeasured], `stats`
+    (dict of gauss_chrom_stats) and `messages` (one text per failed window)."""
+
+    def __init__(self, columns, windows, stats, messages):
+        self.columns, self.windows, self.stats, self.messages = columns, windows, stats, messages
+
+    def frame(self):
+        """pandas DataFrame with the reference's column names and types (strings decoded)."""
+        import pandas as pd
+        return pd.DataFrame({k: (v.astype(str) if v.dtype.kind == "S" else v) for k, v in self.columns.items() if k != "window"})
+
+    @staticmethod
+    def merge(parts):
+        """Tables of several ranks -> one, in window order (prediction windows are disjoint: no de-duplication)."""
+        parts = [p for p in parts if p is not None]
+        names = list(parts[0].columns)
+        cat = {}
+        for k in names:
+            arrs = [p.columns[k] for p in parts]
+            if arrs[0].dtype.kind == "S":
+                w = max(a.dtype.itemsize for a in arrs)
+                arrs = [a.astype(f"S{w}") for a in arrs]
+            cat[k] = np.concatenate(arrs)
+        order = np.argsort(cat["window"], kind="stable")
+        cat = {k: v[order] for k, v in cat.items()}
+        windows = parts[0].windows.copy()
+        for p in parts[1:]:
+            mine = p.windows[:, 3] >= 0
+            windows[mine] = p.windows[mine]
+        stats = {k: ([p.stats[k] for p in parts]) for k in parts[0].stats}
+        return ChromResult(cat, windows, stats, [m for p in parts for m in p.messages])
+
+
+def panel_resident(packed_file, ctx=None):
+    """Upload a packed panel's genotype rows to the GPU once (gauss_host_panel_resident); returns the bytes moved now."""
+    n = _i64()
+    _hcheck(load_host().gauss_host_panel_resident(_ctx(ctx), _enc(packed_file), C.byref(n)))
+    return n.value
+
+
+def panel_evict(packed_file=None, ctx=None):
+    _hcheck(load_host().gauss_host_panel_evict(_ctx(ctx), _enc(packed_file)))
+
+
+def impute_chromosome(kind, chr, start_bp, end_bp, wing_size, input_file, reference_data_file, reference_pop_desc_file,
+                      study_pop=None, pop_wgt_df=None, af1_cutoff=None, window_size=1_000_000, rank=0, world=1, n_batches=0,
+                      ctx=None):
+    """dist / distmix / qcat / qcatmix over every window of [start_bp, end_bp] as ONE native call
+    (gauss_host_impute_chromosome): windows sharded over `world` ranks, this rank's windows pipelined through the
+    GPU in batches against the resident packed panel.  Returns a ChromResult."""
+    h = load_host()
+    names, w, n = (None, None, 0) if pop_wgt_df is None else _pop_wgt(pop_wgt_df)
+    out, st = _vp(), ChromStats()
+    _hcheck(h.gauss_host_impute_chromosome(_ctx(ctx), int(kind), int(chr), int(start_bp), int(end_bp), int(wing_size),
+                                           int(window_size), _enc(study_pop), names, None if w is None else w.ctypes.data_as(_dp), n,
+                                           _enc(input_file), _enc(reference_data_file), _enc(reference_pop_desc_file),
+                                           _af(af1_cutoff), int(rank), int(world), int(n_batches), C.byref(out), C.byref(st)))
+    cols = _columns(h, out)
+    windows = _named(h, out)["windows"]
+    msgs = [h.gauss_table_message(out, k).decode() for k in range(h.gauss_table_n_messages(out))]
+    h.gauss_table_free(out)
+    stats = {k: getattr(st, k) for k, _ in ChromStats._fields_ if k != "pad_"}
+    return ChromResult(cols, windows, stats, msgs)
 
 
 class Prepared:

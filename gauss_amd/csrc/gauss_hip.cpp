@@ -15,6 +15,8 @@
 #include <deque>
 #include <map>
 #include <memory>
+#include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -46,12 +48,78 @@ static int fail(int code, const char* fmt, ...)
                         __FILE__, __LINE__);                                                  \
     } while (0)
 
+// Freed job workspaces (device) and staging blocks (pinned host) are kept per context and handed to the next job
+// that fits: hipFree / hipHostFree wait for the device to go idle, which would stall a pipeline that retires job
+// k while job k+1 is running, and a 15 GB hipMalloc per chromosome is not free either.
+struct BlockCache {
+    std::multimap<size_t, void*> free_blocks;
+    size_t held = 0;
+    void* take(size_t bytes)
+    {
+        auto it = free_blocks.lower_bound(bytes);
+        if (it == free_blocks.end() || it->first > bytes + bytes / 2 + (1u << 20)) return nullptr;
+        void* p = it->second;
+        held -= it->first;
+        free_blocks.erase(it);
+        return p;
+    }
+};
+
 struct gauss_ctx {
     int device;
     hipStream_t stream;
     int gram_i8 = 0;
     std::map<const void*, size_t> stores;    // row stores made by gauss_store_upload: base pointer -> bytes
+    std::mutex mu;
+    BlockCache dev_cache, pin_cache;
+    std::map<void*, size_t> block_size;      // every live block handed out by ctx_dev_alloc / ctx_pin_alloc
 };
+
+static const size_t DEV_CACHE_LIMIT = (size_t)96 << 30;      // of 288 GB
+static const size_t PIN_CACHE_LIMIT = (size_t)1 << 30;
+
+static hipError_t ctx_dev_alloc(gauss_ctx* c, size_t bytes, void** out)
+{
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (void* p = c->dev_cache.take(bytes)) { *out = p; return hipSuccess; }
+    hipError_t e = hipMalloc(out, bytes);
+    if (e != hipSuccess && !c->dev_cache.free_blocks.empty()) {       // make room and retry once
+        for (auto& kv : c->dev_cache.free_blocks) { (void)hipFree(kv.second); c->block_size.erase(kv.second); }
+        c->dev_cache.free_blocks.clear(); c->dev_cache.held = 0;
+        (void)hipGetLastError();
+        e = hipMalloc(out, bytes);
+    }
+    if (e == hipSuccess) c->block_size[*out] = bytes;
+    return e;
+}
+static void ctx_dev_release(gauss_ctx* c, void* p)
+{
+    if (!p) return;
+    std::lock_guard<std::mutex> lock(c->mu);
+    auto it = c->block_size.find(p);
+    const size_t bytes = it == c->block_size.end() ? 0 : it->second;
+    if (bytes && c->dev_cache.held + bytes <= DEV_CACHE_LIMIT) { c->dev_cache.free_blocks.emplace(bytes, p); c->dev_cache.held += bytes; return; }
+    if (it != c->block_size.end()) c->block_size.erase(it);
+    (void)hipFree(p);
+}
+static hipError_t ctx_pin_alloc(gauss_ctx* c, size_t bytes, void** out)
+{
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (void* p = c->pin_cache.take(bytes)) { *out = p; return hipSuccess; }
+    hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
+    if (e == hipSuccess) c->block_size[*out] = bytes;
+    return e;
+}
+static void ctx_pin_release(gauss_ctx* c, void* p)
+{
+    if (!p) return;
+    std::lock_guard<std::mutex> lock(c->mu);
+    auto it = c->block_size.find(p);
+    const size_t bytes = it == c->block_size.end() ? 0 : it->second;
+    if (bytes && c->pin_cache.held + bytes <= PIN_CACHE_LIMIT) { c->pin_cache.free_blocks.emplace(bytes, p); c->pin_cache.held += bytes; return; }
+    if (it != c->block_size.end()) c->block_size.erase(it);
+    (void)hipHostFree(p);
+}
 
 static inline size_t rup(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -106,7 +174,10 @@ struct gauss_job {
     std::vector<Plan> plans;
     char* d_tab = nullptr;      size_t tab_bytes = 0;     // tables (host mirrored)
     char* d_ws = nullptr;       size_t ws_bytes = 0;      // workspace
-    std::vector<char> h_tab;
+    std::vector<char> h_tab;                               // host image of the tables while they are being built
+    char* h_pin = nullptr;                                 // pinned block: [table image | results | status]
+    hipEvent_t begin = nullptr;                            // recorded when gauss_job_run starts queuing
+    hipEvent_t done = nullptr;                             // recorded after the result copies of gauss_job_run
     Prob* d_probs = nullptr;
     Item* d_items = nullptr;    int n_items = 0;
     int2* d_rowmap = nullptr;   int n_rows = 0;
@@ -117,8 +188,8 @@ struct gauss_job {
     int gram_i8 = 0;
     int* d_status = nullptr;                               // [n][4]
     double* d_results = nullptr; size_t n_results = 0;     // z then info per problem
-    double* h_results = nullptr;                           // pinned
-    int* h_status = nullptr;                               // pinned
+    double* h_results = nullptr;                           // inside h_pin
+    int* h_status = nullptr;                               // inside h_pin
     bool prof = false;
     std::vector<ProfSlot> slots;
     double prof_ms[5] = {0, 0, 0, 0, 0};
@@ -538,10 +609,19 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
     job->ws_bytes = wa.off;
     job->tab_bytes = blob.size();
 
-    hipError_t e = hipMalloc((void**)&job->d_ws, job->ws_bytes);
-    if (e != hipSuccess) { return fail(GAUSS_E_NOMEM, "hipMalloc(%zu bytes workspace) failed: %s", wa.off, hipGetErrorString(e)); }
-    e = hipMalloc((void**)&job->d_tab, job->tab_bytes);
+    hipError_t e = ctx_dev_alloc(ctx, job->ws_bytes, (void**)&job->d_ws);
+    if (e != hipSuccess) { job->d_ws = nullptr; return fail(GAUSS_E_NOMEM, "hipMalloc(%zu bytes workspace) failed: %s", wa.off, hipGetErrorString(e)); }
+    e = ctx_dev_alloc(ctx, job->tab_bytes, (void**)&job->d_tab);
     if (e != hipSuccess) { job->d_tab = nullptr; return fail(GAUSS_E_NOMEM, "hipMalloc(%zu bytes tables) failed", blob.size()); }
+    // one pinned block for the table image and the result mirrors: the table upload is then a true asynchronous
+    // DMA and a job over resident rows is created without waiting for the stream (another job may be running on it)
+    const size_t pin_tab = rup(job->tab_bytes, 256), pin_res = rup(sizeof(double) * std::max<size_t>(res, 1), 256);
+    e = ctx_pin_alloc(ctx, pin_tab + pin_res + sizeof(int) * 4 * job->n, (void**)&job->h_pin);
+    if (e != hipSuccess) { job->h_pin = nullptr; return fail(GAUSS_E_NOMEM, "hipHostMalloc(%zu bytes) failed", pin_tab + pin_res); }
+    job->h_results = (double*)(job->h_pin + pin_tab);
+    job->h_status = (int*)(job->h_pin + pin_tab + pin_res);
+    HIPCHK(hipEventCreate(&job->begin));
+    HIPCHK(hipEventCreate(&job->done));
 
     hipStream_t st = ctx->stream;
     // zero once: operand padding, B21 padding and the solve matrices rely on it
@@ -638,15 +718,15 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
         it.rows_a = rows(ti); it.rows_b = rows(tj); it.diag = (ti == tj); it.len = h.len; it.pad = 0;
         memcpy(blob.data() + o_items + sizeof(Item) * n, &it, sizeof(Item));
     }
-    HIPCHK(hipMemcpyAsync(job->d_tab, blob.data(), blob.size(), hipMemcpyHostToDevice, st));
+    memcpy(job->h_pin, blob.data(), blob.size());
+    HIPCHK(hipMemcpyAsync(job->d_tab, job->h_pin, blob.size(), hipMemcpyHostToDevice, st));
     job->d_probs = (Prob*)(job->d_tab + o_probs);
     job->d_items = (Item*)(job->d_tab + o_items);
     job->d_rowmap = (int2*)(job->d_tab + o_rowmap);
     job->d_tilemap = (int2*)(job->d_tab + o_tilemap);
     job->d_panelmap = (int2*)(job->d_tab + o_panelmap);
-    HIPCHK(hipHostMalloc((void**)&job->h_results, sizeof(double) * std::max<size_t>(res, 1), hipHostMallocDefault));
-    HIPCHK(hipHostMalloc((void**)&job->h_status, sizeof(int) * 4 * job->n, hipHostMallocDefault));
-    HIPCHK(hipStreamSynchronize(st));   // uploads from pageable user memory are complete
+    if (!on_device) HIPCHK(hipStreamSynchronize(st));   // uploads from pageable user memory are complete
+    std::vector<char>().swap(job->h_tab);
     *out = guard.release();
     return GAUSS_OK;
 }
@@ -688,6 +768,7 @@ static int job_run(gauss_job* job, bool solve)
 {
     hipStream_t st = job->ctx->stream;
     HIPCHK(hipSetDevice(job->ctx->device));
+    HIPCHK(hipEventRecord(job->begin, st));
     HIPCHK(hipMemsetAsync(job->d_status, 0, sizeof(int) * 4 * job->n, st));
     prof_begin(job, 1);
     launch_pack_stats(job->d_probs, job->d_rowmap, job->n_rows, st);
@@ -715,6 +796,12 @@ static int job_run(gauss_job* job, bool solve)
         prof_end(job);
     }
     HIPCHK(hipGetLastError());
+    // the result mirrors travel with the run, so that gauss_job_fetch waits for THIS job only (an event), not for
+    // whatever else has been queued on the stream since (the next job of a pipeline)
+    if (job->n_results)
+        HIPCHK(hipMemcpyAsync(job->h_results, job->d_results, sizeof(double) * job->n_results, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(job->h_status, job->d_status, sizeof(int) * 4 * job->n, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipEventRecord(job->done, st));
     job->ran = true;
     return GAUSS_OK;
 }
@@ -798,10 +885,7 @@ static int job_fetch(gauss_job* job)
     if (!job->ran) return fail(GAUSS_E_INVALID, "gauss_job_fetch before gauss_job_run");
     hipStream_t st = job->ctx->stream;
     HIPCHK(hipSetDevice(job->ctx->device));
-    if (job->n_results)
-        HIPCHK(hipMemcpyAsync(job->h_results, job->d_results, sizeof(double) * job->n_results, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(job->h_status, job->d_status, sizeof(int) * 4 * job->n, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipEventSynchronize(job->done));
     for (int i = 0; i < job->n; i++) {
         Plan& pl = job->plans[i];
         const Prob& p = pl.p;
@@ -860,10 +944,13 @@ static void job_free(gauss_job* job)
     if (!job) return;
     if (job->ctx) hipSetDevice(job->ctx->device);
     for (ProfSlot& s : job->slots) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
-    if (job->d_ws) hipFree(job->d_ws);
-    if (job->d_tab) hipFree(job->d_tab);
-    if (job->h_results) hipHostFree(job->h_results);
-    if (job->h_status) hipHostFree(job->h_status);
+    if (job->ctx) {
+        ctx_dev_release(job->ctx, job->d_ws);
+        ctx_dev_release(job->ctx, job->d_tab);
+        ctx_pin_release(job->ctx, job->h_pin);
+    }
+    if (job->begin) hipEventDestroy(job->begin);
+    if (job->done) hipEventDestroy(job->done);
     delete job;
 }
 
@@ -921,6 +1008,9 @@ void gauss_hip_destroy(gauss_ctx* ctx)
 {
     if (!ctx) return;
     hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    for (auto& kv : ctx->dev_cache.free_blocks) (void)hipFree(kv.second);
+    for (auto& kv : ctx->pin_cache.free_blocks) (void)hipHostFree(kv.second);
     hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -944,6 +1034,51 @@ int gauss_pinned_free(gauss_ctx* ctx, void* host_ptr)
     return GAUSS_OK;
 }
 
+// Host rows -> HBM.  Large stores (a packed panel's genotype section is ~0.8 GB per chromosome) go through two
+// pinned staging buffers: host threads copy chunk k+1 out of the caller's (pageable, typically mmap'd) memory while
+// chunk k travels by hipMemcpyAsync -- the staged copy the runtime would do by itself for pageable memory, made
+// parallel and overlapped with the DMA.  Small stores take one plain copy.
+static int upload_rows(gauss_ctx* ctx, void* d, const void* host_rows, size_t bytes)
+{
+    const size_t CH = (size_t)32 << 20;
+    if (bytes < 2 * CH) { HIPCHK(hipMemcpy(d, host_rows, bytes, hipMemcpyHostToDevice)); return GAUSS_OK; }
+    void* pin[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    int rc = GAUSS_OK;
+    auto cleanup = [&]() {
+        for (int b = 0; b < 2; b++) { if (ev[b]) hipEventDestroy(ev[b]); ctx_pin_release(ctx, pin[b]); }
+    };
+    for (int b = 0; b < 2; b++) {
+        if (ctx_pin_alloc(ctx, CH, &pin[b]) != hipSuccess || hipEventCreateWithFlags(&ev[b], hipEventDisableTiming) != hipSuccess) {
+            cleanup();
+            return fail(GAUSS_E_NOMEM, "pinned staging buffers for the row store upload could not be allocated");
+        }
+    }
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int nt = (int)std::max(1u, std::min(8u, hw ? hw / 2 : 2u));
+    const uint8_t* src = (const uint8_t*)host_rows;
+    size_t k = 0;
+    for (size_t off = 0; off < bytes && rc == GAUSS_OK; off += CH, k++) {
+        const int b = (int)(k & 1);
+        const size_t len = std::min(CH, bytes - off);
+        if (k >= 2 && hipEventSynchronize(ev[b]) != hipSuccess) { rc = fail(GAUSS_E_DEVICE, "row store upload: event wait failed"); break; }
+        std::vector<std::thread> th;
+        const size_t per = (len + nt - 1) / nt;
+        for (int t = 1; t < nt; t++) {
+            const size_t o = per * t;
+            if (o < len) th.emplace_back([=]() { memcpy((uint8_t*)pin[b] + o, src + off + o, std::min(per, len - o)); });
+        }
+        memcpy(pin[b], src + off, std::min(per, len));
+        for (std::thread& x : th) x.join();
+        if (hipMemcpyAsync((uint8_t*)d + off, pin[b], len, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+            hipEventRecord(ev[b], ctx->stream) != hipSuccess)
+            rc = fail(GAUSS_E_DEVICE, "row store upload: hipMemcpyAsync failed");
+    }
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess && rc == GAUSS_OK) rc = fail(GAUSS_E_DEVICE, "row store upload failed");
+    cleanup();
+    return rc;
+}
+
 int gauss_store_upload(gauss_ctx* ctx, const void* host_rows, int64_t bytes, void** out_device_ptr)
 {
     if (!ctx || !host_rows || bytes <= 0 || !out_device_ptr) return fail(GAUSS_E_INVALID, "bad arguments to gauss_store_upload");
@@ -951,8 +1086,8 @@ int gauss_store_upload(gauss_ctx* ctx, const void* host_rows, int64_t bytes, voi
     void* d = nullptr;
     hipError_t e = hipMalloc(&d, (size_t)bytes + 64);      // slack: a row's last dword load may end on the last byte
     if (e != hipSuccess) return fail(GAUSS_E_NOMEM, "hipMalloc(%lld bytes row store) failed: %s", (long long)bytes, hipGetErrorString(e));
-    e = hipMemcpy(d, host_rows, (size_t)bytes, hipMemcpyHostToDevice);
-    if (e != hipSuccess) { hipFree(d); return fail(GAUSS_E_DEVICE, "row store upload failed: %s", hipGetErrorString(e)); }
+    const int rc = upload_rows(ctx, d, host_rows, (size_t)bytes);
+    if (rc) { hipFree(d); return rc; }
     ctx->stores[d] = (size_t)bytes;
     *out_device_ptr = d;
     return GAUSS_OK;
@@ -999,6 +1134,16 @@ int gauss_job_create(gauss_ctx* ctx, const gauss_window_desc* wins, int n_win, i
 int gauss_job_run(gauss_job* job) { return job ? job_run(job, true) : fail(GAUSS_E_INVALID, "job is NULL"); }
 int gauss_job_fetch(gauss_job* job) { return job ? job_fetch(job) : fail(GAUSS_E_INVALID, "job is NULL"); }
 void gauss_job_destroy(gauss_job* job) { job_free(job); }
+
+int gauss_job_span_ms(gauss_job* first, gauss_job* last, double* out_ms)
+{
+    if (!first || !last || !out_ms || !first->ran || !last->ran) return fail(GAUSS_E_INVALID, "gauss_job_span_ms: both jobs must have run");
+    HIPCHK(hipEventSynchronize(last->done));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, first->begin, last->done));
+    *out_ms = (double)ms;
+    return GAUSS_OK;
+}
 
 int gauss_job_profile(gauss_job* job, int enable)
 {

@@ -27,6 +27,8 @@
 #include <memory>
 #include <sstream>
 #include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <string>
 #include <thread>
 #include <vector>
@@ -64,6 +66,8 @@ struct Column {
     int type;
     std::vector<std::string> s;
     mutable std::string joined;      // lazily built NUL-separated image of s (gauss_table_strcol)
+    mutable std::vector<char> fixed; // lazily built fixed-width image of s (gauss_table_strcol_fixed)
+    mutable int fixed_w = 0;
     std::vector<int32_t> i;
     std::vector<double> d;
 };
@@ -79,13 +83,14 @@ struct gauss_table {
     std::vector<double> matrix;
     int matrix_n = 0;
     std::vector<NamedMat> named;
+    std::vector<std::string> messages;   // per-window failure texts of a chromosome run
     int nrow() const
     {
         if (cols.empty()) return 0;
         const Column& c = cols[0];
         return (int)(c.type == GAUSS_COL_STR ? c.s.size() : c.type == GAUSS_COL_INT ? c.i.size() : c.d.size());
     }
-    Column& add(const char* name, int type) { cols.push_back(Column{name, type, {}, {}, {}}); return cols.back(); }
+    Column& add(const char* name, int type) { Column c; c.name = name; c.type = type; cols.push_back(std::move(c)); return cols.back(); }
 };
 
 // ------------------------------------------------------------------------------------------
@@ -241,26 +246,57 @@ static void set_pop_wgt_map(Args& a, const char* const* names, const double* w, 
     }
 }
 
-// ReadInputZ (gauss.cpp:121-190)
-static int ReadInputZ(SnpMap& m, const Args& a, bool All)
+// Parsed image of a GWAS summary file (rsid chr bp a1 a2 z), kept per process and shared by every window of a
+// chromosome run that names the same file (path + size + mtime): the reference re-reads the text once per call
+// (gauss.cpp:146-152).  Rows are in file order and carry the reference's parsing-state semantics: a field that
+// fails to parse keeps the value of the previous line (the variables live outside the loop there too).
+struct GwasRow { std::string rsid, a1, a2; int chr; long long bp; double z; };
+struct GwasCache { std::vector<GwasRow> rows; };
+
+static std::shared_ptr<const GwasCache> load_gwas_cached(const std::string& path, std::string& err)
 {
-    std::ifstream in(a.input_file.c_str());
-    if (!in) return herr("ERROR: can't open input file '%s'", a.input_file.c_str());
+    static std::mutex mu;
+    static std::map<std::string, std::shared_ptr<const GwasCache>> cache;
+    struct stat st;
+    if (stat(path.c_str(), &st) != 0) { err = "ERROR: can't open input file '" + path + "'"; return nullptr; }
+    char key[64];
+    snprintf(key, sizeof(key), "|%lld|%lld.%ld", (long long)st.st_size, (long long)st.st_mtim.tv_sec, (long)st.st_mtim.tv_nsec);
+    const std::string k = path + key;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(k);
+    if (it != cache.end()) return it->second;
+    std::ifstream in(path.c_str());
+    if (!in) { err = "ERROR: can't open input file '" + path + "'"; return nullptr; }
+    std::shared_ptr<GwasCache> c = std::make_shared<GwasCache>();
     std::string line, rsid, a1, a2;
     int chr = 0; long long bp = 0; double z = 0;
     std::getline(in, line);   // header
     while (std::getline(in, line)) {
         Tok t(line);
         if (t.str(rsid) && t.i32(chr) && t.i64(bp) && t.str(a1) && t.str(a2)) t.dbl(z);
+        c->rows.push_back(GwasRow{rsid, a1, a2, chr, bp, z});
+    }
+    if (cache.size() >= 8) cache.clear();          // a handful of studies per process at most
+    cache[k] = c;
+    return c;
+}
+
+// ReadInputZ (gauss.cpp:121-190)
+static int ReadInputZ(SnpMap& m, const Args& a, bool All)
+{
+    std::string err;
+    std::shared_ptr<const GwasCache> gw = load_gwas_cached(a.input_file, err);
+    if (!gw) return herr("%s", err.c_str());
+    for (const GwasRow& r : gw->rows) {
         if (!All) {
-            if ((a.chr > 0) && (a.chr != chr)) continue;
-            if ((a.start_bp - a.wing_size) > bp || (a.end_bp + a.wing_size) < bp) continue;
+            if ((a.chr > 0) && (a.chr != r.chr)) continue;
+            if ((a.start_bp - a.wing_size) > r.bp || (a.end_bp + a.wing_size) < r.bp) continue;
         }
         std::unique_ptr<Snp> s(new Snp());
-        s->rsid = rsid; s->chr = chr; s->bp = bp; s->a1 = a1; s->a2 = a2; s->z = z;
+        s->rsid = r.rsid; s->chr = r.chr; s->bp = r.bp; s->a1 = r.a1; s->a2 = r.a2; s->z = r.z;
         s->info = 1.0;     // gauss.cpp:142
         s->type = 2;       // gauss.cpp:176
-        m[MapKey{chr, bp, a1, a2}] = std::move(s);
+        m[MapKey{r.chr, r.bp, r.a1, r.a2}] = std::move(s);
     }
     return 0;
 }
@@ -1575,6 +1611,390 @@ int gauss_host_jepegmix(gauss_ctx* ctx, const char* const* pop_names, const doub
 {
     return run_jepeg(ctx, GAUSS_KIND_JEPEGMIX, nullptr, pop_names, pop_wgts, n_pop_wgt, input_file, annotation_file,
                      reference_index_file, reference_data_file, reference_pop_desc_file, af1_cutoff, out);
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------
+// Resident panels: the genotype section of a packed panel file, uploaded once per (context, file) and kept in HBM
+// (288 GB hold the whole 33KG panel, 82 GB as 2-bit rows).  Windows then name their rows by index.
+// ------------------------------------------------------------------------------------------
+struct ResidentPanel {
+    std::shared_ptr<PackedPanel> pk;       // keeps the mapping (and so the file identity) alive
+    void* dev = nullptr;
+    int64_t bytes = 0;
+};
+static std::mutex g_res_mu;
+static std::map<std::pair<gauss_ctx*, std::string>, ResidentPanel> g_resident;
+
+static std::string file_key(const std::string& path)
+{
+    struct stat st;
+    if (stat(path.c_str(), &st) != 0) return path;
+    char key[64];
+    snprintf(key, sizeof(key), "|%lld|%lld.%ld", (long long)st.st_size, (long long)st.st_mtim.tv_sec, (long)st.st_mtim.tv_nsec);
+    return path + key;
+}
+
+// returns the device pointer of the panel's row 0 (uploading the section on first use); *uploaded = bytes moved now
+static int panel_make_resident(gauss_ctx* ctx, const std::string& path, void** dev, int64_t* uploaded)
+{
+    if (uploaded) *uploaded = 0;
+    const std::pair<gauss_ctx*, std::string> key(ctx, file_key(path));
+    std::lock_guard<std::mutex> lock(g_res_mu);
+    auto it = g_resident.find(key);
+    if (it != g_resident.end()) { *dev = it->second.dev; return 0; }
+    std::string err;
+    ResidentPanel rp;
+    rp.pk = open_packed_shared(path, err);
+    if (!rp.pk) return herr("%s", err.c_str());
+    rp.bytes = rp.pk->n_snp() * rp.pk->row_bytes();
+    if (rp.bytes <= 0) return herr("packed panel '%s' holds no SNPs", path.c_str());
+    if (gauss_store_upload(ctx, rp.pk->geno(), rp.bytes, &rp.dev) != 0) return herr("%s", gauss_last_error());
+    if (uploaded) *uploaded = rp.bytes;
+    *dev = rp.dev;
+    g_resident[key] = rp;
+    return 0;
+}
+
+// minimal fork-join helper: fn(i) for i in [0, n) on up to nt threads
+template <typename F>
+static void parallel_for(int n, int nt, F fn)
+{
+    if (n <= 0) return;
+    nt = std::max(1, std::min(nt, n));
+    if (nt == 1) { for (int i = 0; i < n; i++) fn(i); return; }
+    std::atomic<int> next{0};
+    std::vector<std::thread> th;
+    auto body = [&]() { for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i); };
+    for (int t = 1; t < nt; t++) th.emplace_back(body);
+    body();
+    for (std::thread& x : th) x.join();
+}
+
+static double now_s()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+extern "C" {
+
+int gauss_host_panel_resident(gauss_ctx* ctx, const char* packed_file, int64_t* bytes_uploaded)
+{
+    if (!ctx || !packed_file) return herr("bad arguments");
+    if (!PackedPanel::is_packed(packed_file)) return herr("'%s' is not a packed panel", packed_file);
+    void* dev = nullptr;
+    return panel_make_resident(ctx, packed_file, &dev, bytes_uploaded);
+}
+
+int gauss_host_panel_evict(gauss_ctx* ctx, const char* packed_file)
+{
+    if (!ctx) return herr("ctx is NULL");
+    std::lock_guard<std::mutex> lock(g_res_mu);
+    for (auto it = g_resident.begin(); it != g_resident.end();) {
+        if (it->first.first == ctx && (!packed_file || it->first.second.compare(0, strlen(packed_file), packed_file) == 0)) {
+            gauss_store_free(ctx, it->second.dev);
+            it = g_resident.erase(it);
+        } else ++it;
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// A whole chromosome: the caller-level loop over windows that the reference leaves to the R user
+// (docs/articles/dist_example.md:144-153 calls one window), as ONE native call per rank.
+//
+//   windows   [start + k*window_size, ...] over [start_bp, end_bp]; sharded over `world` ranks by LPT on their LD
+//             flops (measured count from the GWAS file, panel count from the packed index; the same list on every
+//             rank, no communication)
+//   pipeline  this rank's windows are cut into batches; host threads run the data layer of batch b+1 (window
+//             membership, allele matching, AF filter: gauss_host_prepare) and build the tables of batch b-1 while
+//             the GPU works on batch b: jobs are created and queued without waiting for the stream, results come
+//             back through a per-job event.  The panel's rows are resident in HBM (uploaded once per context and
+//             file through pinned double buffers), so a window carries only row indices to the device.
+//   failures  a window that fails its guards (dist.cpp:145-151) or its data layer is reported in the "windows"
+//             matrix and skipped; a batch whose job fails is retried window by window, so one bad window never
+//             takes the rank's other windows with it.
+// Result: the reference's output table for every window of this rank, concatenated in window order, plus an int
+// column "window"; named matrix "windows" [n_windows x 6]: start_bp end_bp owner status measured unmeasured
+// (status 0 done, 1 skipped by the ">10" guards, 2 failed, -1 another rank's).
+// ------------------------------------------------------------------------------------------
+int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t start_bp, int64_t end_bp, int64_t wing_size,
+                                 int64_t window_size, const char* study_pop, const char* const* pop_names,
+                                 const double* pop_wgts, int n_pop_wgt, const char* input_file,
+                                 const char* reference_data_file, const char* reference_pop_desc_file, double af1_cutoff,
+                                 int rank, int world, int n_batches, gauss_table** out, gauss_chrom_stats* stats)
+{
+    if (!ctx || !out || !input_file || !reference_data_file || !reference_pop_desc_file) return herr("bad arguments");
+    if (kind != GAUSS_KIND_DIST && kind != GAUSS_KIND_DISTMIX && kind != GAUSS_KIND_QCAT && kind != GAUSS_KIND_QCATMIX)
+        return herr("gauss_host_impute_chromosome: kind must be dist, distmix, qcat or qcatmix");
+    if (window_size < 1 || end_bp < start_bp || world < 1 || rank < 0 || rank >= world) return herr("bad window / rank arguments");
+    if (!PackedPanel::is_packed(reference_data_file)) return herr("gauss_host_impute_chromosome needs a packed panel (gauss_host_pack_panel)");
+    const double t_begin = now_s();
+    gauss_chrom_stats st;
+    memset(&st, 0, sizeof(st));
+
+    // ---- plan: windows, costs, owners (identical on every rank) ----
+    std::string err;
+    std::shared_ptr<PackedPanel> pk = open_packed_shared(reference_data_file, err);
+    if (!pk) return herr("%s", err.c_str());
+    std::shared_ptr<const GwasCache> gw = load_gwas_cached(input_file, err);
+    if (!gw) return herr("%s", err.c_str());
+    std::vector<long long> gbp;
+    for (const GwasRow& r : gw->rows)
+        if (chr <= 0 || r.chr == chr) gbp.push_back(r.bp);
+    std::sort(gbp.begin(), gbp.end());
+    struct Win { int64_t s, e; double cost; int owner, status, M, U; std::string why; };
+    std::vector<Win> wins;
+    for (int64_t s0 = start_bp; s0 <= end_bp; s0 += window_size) {
+        Win w;
+        w.s = s0; w.e = std::min(end_bp, s0 + window_size - 1);
+        const double m = (double)(std::upper_bound(gbp.begin(), gbp.end(), (long long)(w.e + wing_size)) -
+                                  std::lower_bound(gbp.begin(), gbp.end(), (long long)(w.s - wing_size)));
+        double u = 0;
+        if (pk->header().sorted && chr > 0) {
+            const double in_panel = (double)(pk->lower_bound(chr, w.e + 1) - pk->lower_bound(chr, w.s));
+            const double m_pred = (double)(std::upper_bound(gbp.begin(), gbp.end(), (long long)w.e) -
+                                           std::lower_bound(gbp.begin(), gbp.end(), (long long)w.s));
+            u = std::max(0.0, in_panel - m_pred);
+        }
+        w.cost = m * (m + 1.0 + 2.0 * u) + 1.0;        // LD flops / N
+        w.owner = 0; w.status = -1; w.M = (int)m; w.U = (int)u;
+        wins.push_back(w);
+    }
+    {   // longest processing time first, ties by index: farm.assign_windows
+        std::vector<int> order(wins.size());
+        for (size_t i = 0; i < order.size(); i++) order[i] = (int)i;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return wins[a].cost > wins[b].cost; });
+        std::vector<double> load((size_t)world, 0.0);
+        for (int i : order) {
+            int r = 0;
+            for (int k = 1; k < world; k++) if (load[k] < load[r]) r = k;
+            wins[i].owner = r; load[r] += wins[i].cost;
+        }
+    }
+    std::vector<int> mine;
+    for (size_t i = 0; i < wins.size(); i++) if (wins[i].owner == rank) mine.push_back((int)i);
+    st.n_windows = (int)wins.size();
+    st.n_windows_mine = (int)mine.size();
+    if (n_batches < 1) n_batches = mine.size() >= 16 ? 4 : (mine.size() >= 9 ? 3 : (mine.size() >= 4 ? 2 : 1));
+    n_batches = std::max(1, std::min<int>(n_batches, std::max<size_t>(mine.size(), 1)));
+    // contiguous batches by cost.  The first batch is the one nothing overlaps with on the way in (its data layer)
+    // and the last one on the way out (its tables), so with four or more batches those two get half a share.
+    std::vector<std::vector<int>> batches((size_t)n_batches);
+    {
+        std::vector<double> share((size_t)n_batches, 1.0);
+        if (n_batches >= 4) { share.front() = 0.5; share.back() = 0.5; }
+        double ssum = 0;
+        for (double v : share) ssum += v;
+        double total = 0;
+        for (int i : mine) total += wins[i].cost;
+        double acc = 0, edge = share[0] / ssum;
+        int b = 0;
+        for (int i : mine) {
+            while (b + 1 < n_batches && total > 0 && acc / total >= edge - 1e-12 && !batches[b].empty()) { b++; edge += share[b] / ssum; }
+            batches[b].push_back(i);
+            acc += wins[i].cost;
+        }
+    }
+    st.n_batches = n_batches;
+    st.t_plan = now_s() - t_begin;
+
+    // ---- the panel's rows in HBM ----
+    double t0 = now_s();
+    void* d_rows = nullptr;
+    if (!mine.empty() && panel_make_resident(ctx, reference_data_file, &d_rows, &st.panel_bytes_uploaded)) return -1;
+    st.t_panel_upload = now_s() - t0;
+
+    // ---- feeder thread: the data layer, batch by batch ----
+    struct Slot { std::unique_ptr<gauss_prepared> p; gauss_window_desc d; bool ok = false; gauss_table* tab = nullptr; };
+    std::vector<std::vector<Slot>> slots((size_t)n_batches);
+    for (int b = 0; b < n_batches; b++) slots[b].resize(batches[b].size());
+    std::mutex mu;
+    std::condition_variable cv;
+    int ready = 0;                                                // batches whose data layer is done
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int nthreads = (int)std::max(1u, std::min(16u, (hw ? hw : 4u) / (unsigned)std::max(1, std::min(world, 8))));
+    std::thread feeder([&]() {
+        for (int b = 0; b < n_batches; b++) {
+            parallel_for((int)batches[b].size(), nthreads, [&](int k) {
+                Win& w = wins[batches[b][k]];
+                Slot& sl = slots[b][k];
+                gauss_prepared* p = nullptr;
+                if (gauss_host_prepare(kind, chr, w.s, w.e, wing_size, study_pop, pop_names, pop_wgts, n_pop_wgt, input_file, nullptr,
+                                       "(packed)", reference_data_file, reference_pop_desc_file, af1_cutoff, &p)) {
+                    w.status = 2; w.why = gauss_host_last_error();
+                    return;
+                }
+                sl.p.reset(p);
+                w.M = (int)p->measured.size(); w.U = (int)p->unmeasured.size();
+                if (gauss_prepared_window_desc(p, &sl.d)) {       // the ">10" guards (dist.cpp:145-151)
+                    w.status = 1; w.why = gauss_host_last_error();
+                    sl.p.reset();
+                    return;
+                }
+                sl.d.geno_m = sl.d.geno_u = (const uint8_t*)d_rows;   // rows_m / rows_u are panel row indices already
+                sl.ok = true;
+            });
+            { std::lock_guard<std::mutex> lock(mu); ready = b + 1; }
+            cv.notify_all();
+        }
+    });
+
+    // ---- GPU pipeline ----
+    std::vector<gauss_job*> jobs((size_t)n_batches, nullptr);
+    std::vector<std::vector<int>> live((size_t)n_batches);       // slots of batch b that are in its job
+    int rc_fatal = 0;
+    auto retire = [&](int b) {
+        // results of batch b -> SNP objects -> per-window tables (host threads; the GPU is on batch b+1 meanwhile)
+        double tw = now_s();
+        int rc = jobs[b] ? gauss_job_fetch(jobs[b]) : 0;
+        st.t_gpu_wait += now_s() - tw;
+        if (rc != 0 && jobs[b]) {
+            // the batch failed as a whole: run its windows one by one so that only the culprit is lost
+            const std::string why = gauss_last_error();
+            for (int k : live[b]) {
+                Slot& sl = slots[b][k];
+                gauss_job* one = nullptr;
+                if (gauss_job_create(ctx, &sl.d, 1, 1, &one) != 0 || gauss_job_run(one) != 0 || gauss_job_fetch(one) != 0) {
+                    Win& w = wins[batches[b][k]];
+                    w.status = 2; w.why = std::string(gauss_last_error()) + " (batch error: " + why + ")";
+                    sl.ok = false;
+                }
+                if (one) gauss_job_destroy(one);
+            }
+        }
+        double tt = now_s();
+        parallel_for((int)slots[b].size(), nthreads, [&](int k) {
+            Slot& sl = slots[b][k];
+            if (!sl.ok) return;
+            gauss_table* t = nullptr;
+            if (gauss_prepared_finish(sl.p.get(), &t) == 0) { sl.tab = t; wins[batches[b][k]].status = 0; }
+            else { wins[batches[b][k]].status = 2; wins[batches[b][k]].why = gauss_host_last_error(); }
+            sl.p.reset();
+        });
+        st.t_tables += now_s() - tt;
+    };
+    for (int b = 0; b < n_batches && !rc_fatal; b++) {
+        double tw = now_s();
+        { std::unique_lock<std::mutex> lock(mu); cv.wait(lock, [&]() { return ready > b; }); }
+        st.t_feeder_wait += now_s() - tw;
+        std::vector<gauss_window_desc> descs;
+        for (size_t k = 0; k < slots[b].size(); k++)
+            if (slots[b][k].ok) { descs.push_back(slots[b][k].d); live[b].push_back((int)k); }
+        if (!descs.empty()) {
+            double tc = now_s();
+            if (gauss_job_create(ctx, descs.data(), (int)descs.size(), 1, &jobs[b]) != 0 || gauss_job_run(jobs[b]) != 0) {
+                // could not even queue the batch: fall back to single windows at retire time
+                if (jobs[b]) { gauss_job_destroy(jobs[b]); jobs[b] = nullptr; }
+                for (int k : live[b]) {
+                    Slot& sl = slots[b][k];
+                    gauss_job* one = nullptr;
+                    if (gauss_job_create(ctx, &sl.d, 1, 1, &one) != 0 || gauss_job_run(one) != 0 || gauss_job_fetch(one) != 0) {
+                        Win& w = wins[batches[b][k]];
+                        w.status = 2; w.why = gauss_last_error();
+                        sl.ok = false;
+                    }
+                    if (one) gauss_job_destroy(one);
+                }
+            }
+            st.t_job_create += now_s() - tc;
+        }
+        if (b > 0) retire(b - 1);
+    }
+    if (!rc_fatal && n_batches > 0) retire(n_batches - 1);
+    feeder.join();
+    {
+        gauss_job *jf = nullptr, *jl = nullptr;
+        for (gauss_job* j : jobs) if (j) { if (!jf) jf = j; jl = j; }
+        if (jf && gauss_job_span_ms(jf, jl, &st.gpu_span_ms) != 0) st.gpu_span_ms = 0.0;
+    }
+    for (gauss_job* j : jobs) if (j) gauss_job_destroy(j);
+
+    // ---- one table, window order ----
+    double tt = now_s();
+    std::unique_ptr<gauss_table> all(new gauss_table());
+    Column win_col{"window", GAUSS_COL_INT, {}, {}, {}};
+    bool first = true;
+    size_t total_rows = 0;
+    for (int b = 0; b < n_batches; b++)
+        for (Slot& sl : slots[b]) if (sl.tab) total_rows += (size_t)sl.tab->nrow();
+    for (int b = 0; b < n_batches; b++)
+        for (size_t k = 0; k < slots[b].size(); k++) {
+            Slot& sl = slots[b][k];
+            if (!sl.tab) continue;
+            const int nr = sl.tab->nrow();
+            if (first) {
+                for (const Column& c : sl.tab->cols) {
+                    Column& nc = all->add(c.name.c_str(), c.type);
+                    if (c.type == GAUSS_COL_STR) nc.s.reserve(total_rows);
+                    else if (c.type == GAUSS_COL_INT) nc.i.reserve(total_rows);
+                    else nc.d.reserve(total_rows);
+                }
+                win_col.i.reserve(total_rows);
+                first = false;
+            }
+            for (size_t c = 0; c < sl.tab->cols.size(); c++) {
+                Column& src = sl.tab->cols[c];
+                Column& dst = all->cols[c];
+                if (src.type == GAUSS_COL_STR) for (std::string& v : src.s) dst.s.push_back(std::move(v));
+                else if (src.type == GAUSS_COL_INT) dst.i.insert(dst.i.end(), src.i.begin(), src.i.end());
+                else dst.d.insert(dst.d.end(), src.d.begin(), src.d.end());
+            }
+            win_col.i.insert(win_col.i.end(), (size_t)nr, (int32_t)batches[b][k]);
+            if (wins[batches[b][k]].status == 0) st.imputed += wins[batches[b][k]].U;
+            delete sl.tab;
+            sl.tab = nullptr;
+        }
+    if (first) {       // no window produced rows: still hand back the reference's column set
+        const bool mix = (kind == GAUSS_KIND_DISTMIX || kind == GAUSS_KIND_QCATMIX);
+        const bool qc = (kind == GAUSS_KIND_QCAT || kind == GAUSS_KIND_QCATMIX);
+        all->add("rsid", GAUSS_COL_STR); all->add("chr", GAUSS_COL_INT); all->add("bp", GAUSS_COL_INT);
+        all->add("a1", GAUSS_COL_STR); all->add("a2", GAUSS_COL_STR); all->add(mix ? "af1mix" : "af1ref", GAUSS_COL_DBL);
+        all->add("z", GAUSS_COL_DBL);
+        if (qc) { all->add("qcat_m", GAUSS_COL_INT); all->add("qcat_t", GAUSS_COL_DBL); all->add("qcat_chisq", GAUSS_COL_DBL); all->add("qcat_pval", GAUSS_COL_DBL); }
+        else { all->add("pval", GAUSS_COL_DBL); all->add("info", GAUSS_COL_DBL); }
+        all->add("type", GAUSS_COL_INT);
+    }
+    all->cols.push_back(win_col);
+    {
+        NamedMat nm;
+        nm.name = "windows"; nm.nrow = (int)wins.size(); nm.ncol = 6;
+        nm.d.assign((size_t)nm.nrow * 6, 0.0);
+        for (int i = 0; i < nm.nrow; i++) {
+            const Win& w = wins[i];
+            const double v[6] = {(double)w.s, (double)w.e, (double)w.owner, (double)w.status, (double)w.M, (double)w.U};
+            for (int c = 0; c < 6; c++) nm.d[(size_t)c * nm.nrow + i] = v[c];
+            if (w.status == 1) st.n_skipped++;
+            if (w.status == 2) { st.n_failed++; if (all->messages.size() < 64) all->messages.push_back("window " + std::to_string(i) + ": " + w.why); }
+        }
+        all->named.push_back(nm);
+    }
+    st.t_tables += now_s() - tt;
+    st.t_total = now_s() - t_begin;
+    if (stats) *stats = st;
+    *out = all.release();
+    return 0;
+}
+
+int gauss_table_n_messages(const gauss_table* t) { return t ? (int)t->messages.size() : 0; }
+const char* gauss_table_message(const gauss_table* t, int k) { return (t && k >= 0 && k < (int)t->messages.size()) ? t->messages[k].c_str() : nullptr; }
+
+// A whole string column as one fixed-width, NUL-padded byte matrix [nrow x *width] (numpy dtype "S<width>"):
+// 90 000 rows come across the boundary as one buffer instead of 90 000 Python strings.
+const char* gauss_table_strcol_fixed(const gauss_table* t, int c, int* width)
+{
+    if (!t || c < 0 || c >= (int)t->cols.size() || t->cols[c].type != GAUSS_COL_STR) return nullptr;
+    const Column& col = t->cols[c];
+    size_t w = 1;
+    for (const std::string& v : col.s) w = std::max(w, v.size());
+    if (col.fixed.size() != w * col.s.size() || col.fixed_w != (int)w) {
+        col.fixed.assign(w * col.s.size(), '\0');
+        for (size_t r = 0; r < col.s.size(); r++) memcpy(&col.fixed[r * w], col.s[r].data(), col.s[r].size());
+        col.fixed_w = (int)w;
+    }
+    if (width) *width = (int)w;
+    return col.fixed.data();
 }
 
 }  // extern "C"

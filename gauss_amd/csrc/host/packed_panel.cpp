@@ -6,6 +6,7 @@
 #include <unistd.h>
 
 #include <cctype>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -49,13 +50,39 @@ bool PackedPanel::open(const std::string& path, std::string& err)
     base_ = (const uint8_t*)p;
     hdr_ = (const PkHeader*)base_;
     const PkHeader& h = *hdr_;
-    const bool ok = memcmp(h.magic, kMagic, 8) == 0 && h.version == 1 && h.file_bytes == bytes_ && h.row_bytes % 16 == 0 &&
-                    h.off_pops + (uint64_t)h.n_pop * sizeof(PkPop) <= bytes_ &&
-                    h.off_snps + h.n_snp * sizeof(PkSnp) <= bytes_ && h.off_strings <= bytes_ &&
-                    h.off_af + h.n_snp * h.n_pop * sizeof(double) <= bytes_ &&
-                    h.off_cnt + h.n_snp * h.n_pop * sizeof(int32_t) <= bytes_ &&
-                    h.off_geno + h.n_snp * h.row_bytes <= bytes_;
+    // the header is untrusted input: every section range is checked with overflow-safe arithmetic, then the
+    // records that carry offsets (population blocks, SNP strings) are checked against what they point into
+    auto section = [&](uint64_t off, uint64_t count, uint64_t elem, uint64_t align) {
+        uint64_t sz = 0;
+        if (__builtin_mul_overflow(count, elem, &sz)) return false;
+        return off % align == 0 && off <= (uint64_t)bytes_ && sz <= (uint64_t)bytes_ - off;
+    };
+    uint64_t n_cells = 0;
+    bool ok = memcmp(h.magic, kMagic, 8) == 0 && h.version == 1 && h.file_bytes == bytes_ && h.row_bytes % 16 == 0 &&
+              h.row_bytes > 0 && h.n_pop >= 1 && h.n_pop <= 4096 && h.n_snp <= (uint64_t)INT32_MAX &&
+              !__builtin_mul_overflow(h.n_snp, (uint64_t)h.n_pop, &n_cells) &&
+              section(h.off_pops, h.n_pop, sizeof(PkPop), 8) && section(h.off_snps, h.n_snp, sizeof(PkSnp), 8) &&
+              section(h.off_strings, 0, 1, 1) && h.off_strings <= h.off_af &&
+              section(h.off_af, n_cells, sizeof(double), 8) && section(h.off_cnt, n_cells, sizeof(int32_t), 4) &&
+              section(h.off_geno, h.n_snp, h.row_bytes, 16);
     if (!ok) { err = "packed panel '" + path + "' has a bad header"; close(); return false; }
+    {
+        const PkPop* pp = (const PkPop*)(base_ + h.off_pops);
+        for (uint32_t k = 0; k < h.n_pop && ok; k++) {
+            const uint64_t blk = ((uint64_t)pp[k].size + 63) / 64 * 16;
+            ok = pp[k].byte_off % 16 == 0 && (uint64_t)pp[k].byte_off + blk <= h.row_bytes &&
+                 memchr(pp[k].name, 0, sizeof(pp[k].name)) != nullptr && memchr(pp[k].super, 0, sizeof(pp[k].super)) != nullptr;
+        }
+        if (!ok) { err = "packed panel '" + path + "': a population block lies outside the genotype row"; close(); return false; }
+        // strings live in [off_strings, off_af); the last byte of that range must be NUL so that every offset
+        // below its length names a terminated string
+        const uint64_t str_bytes = h.off_af - h.off_strings;
+        const PkSnp* sp = (const PkSnp*)(base_ + h.off_snps);
+        ok = h.n_snp == 0 || (str_bytes > 0 && base_[h.off_af - 1] == 0);
+        for (uint64_t i = 0; i < h.n_snp && ok; i++)
+            ok = sp[i].rsid < str_bytes && sp[i].a1 < str_bytes && sp[i].a2 < str_bytes;
+        if (!ok) { err = "packed panel '" + path + "': a SNP record points outside the string table"; close(); return false; }
+    }
     pops_ = (const PkPop*)(base_ + h.off_pops);
     snps_ = (const PkSnp*)(base_ + h.off_snps);
     strings_ = (const char*)(base_ + h.off_strings);

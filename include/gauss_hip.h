@@ -197,6 +197,10 @@ int gauss_job_run(gauss_job* job);
  * of each window descriptor. */
 int gauss_job_fetch(gauss_job* job);
 void gauss_job_destroy(gauss_job* job);
+/* Device time from the moment `first` started to run until `last` had delivered its results (HIP events on the
+ * context's stream; both jobs must have run, on the same context).  With a pipeline of jobs this is the span the
+ * GPU was busy with them, whatever the host did meanwhile. */
+int gauss_job_span_ms(gauss_job* first, gauss_job* last, double* out_ms);
 
 /* Profiling hooks for bench.py: HIP events are recorded around every launch of the Gram kernel
  * on the job's own stream while enabled. */

@@ -159,6 +159,45 @@ int64_t gauss_host_pack_panel(const char* reference_index_file, const char* refe
  * windows with on_device = 1.  base = NULL for byte-matrix windows. */
 int gauss_prepared_packed_store(const gauss_prepared* p, const uint8_t** base, int64_t* bytes, int64_t* row_bytes);
 
+/* ---- resident panels and whole-chromosome runs (the farm's native side) --------------------------------
+ * gauss_host_panel_resident uploads the genotype section of a packed panel to the context's GPU once (pinned
+ * double-buffered hipMemcpyAsync; later calls for the same file and context are no-ops) -- 288 GB of HBM hold
+ * the whole 33KG panel.  gauss_host_panel_evict frees it (packed_file NULL: every panel of the context). */
+int gauss_host_panel_resident(gauss_ctx* ctx, const char* packed_file, int64_t* bytes_uploaded);
+int gauss_host_panel_evict(gauss_ctx* ctx, const char* packed_file);
+
+typedef struct gauss_chrom_stats {
+    int32_t n_windows, n_windows_mine, n_skipped, n_failed, n_batches, pad_;
+    int64_t imputed;               /* unmeasured SNPs imputed by this rank                                  */
+    int64_t panel_bytes_uploaded;  /* 0 when the panel was already resident                                 */
+    double t_total, t_plan, t_panel_upload;
+    double t_feeder_wait;          /* main thread waiting for the data layer of the next batch              */
+    double t_job_create;           /* planning + queuing the batches (the GPU keeps running meanwhile)      */
+    double t_gpu_wait;             /* main thread waiting for a batch's results                             */
+    double t_tables;               /* building and concatenating the result tables                          */
+    double gpu_span_ms;            /* device time from the first batch's start to the last batch's results  */
+} gauss_chrom_stats;
+
+/* dist / distmix / qcat / qcatmix over every window [start_bp + k*window_size, ...] of [start_bp, end_bp] -- the
+ * caller-level loop the reference leaves to the R user (one R call = one window, dist.cpp:30-126) -- as one native
+ * call per rank.  Windows are sharded over `world` ranks by LPT on their LD flops (the same plan on every rank,
+ * no communication); this rank's windows run as a pipeline of n_batches jobs (<= 0: chosen here): host threads
+ * prepare batch b+1 and build the tables of batch b-1 while the GPU works on batch b.  reference_data_file must
+ * be a packed panel; it is made resident on first use.  The result holds the reference's output table of every
+ * window of this rank in window order, an extra int column "window", a named matrix "windows"
+ * [n_windows x 6: start_bp end_bp owner status measured unmeasured; status 0 done, 1 skipped by the ">10" guards
+ * (dist.cpp:145-151), 2 failed, -1 another rank's] and one message per failed window (gauss_table_message):
+ * a window that fails never takes the others with it. */
+int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t start_bp, int64_t end_bp, int64_t wing_size,
+                                 int64_t window_size, const char* study_pop, const char* const* pop_names,
+                                 const double* pop_wgts, int n_pop_wgt, const char* input_file,
+                                 const char* reference_data_file, const char* reference_pop_desc_file, double af1_cutoff,
+                                 int rank, int world, int n_batches, gauss_table** out, gauss_chrom_stats* stats);
+int gauss_table_n_messages(const gauss_table* t);
+const char* gauss_table_message(const gauss_table* t, int k);
+/* A whole string column as one fixed-width, NUL-padded byte matrix [nrow x *width]. */
+const char* gauss_table_strcol_fixed(const gauss_table* t, int c, int* width);
+
 /* Re-block a BGZF text file line by line (reader + writer round trip); returns lines copied or -1. */
 int64_t gauss_host_bgzf_copy(const char* in_path, const char* out_path);
 

@@ -187,3 +187,71 @@ def test_gpu_context_reports_its_device(ctx):
     assert ctx.lib.gauss_hip_device_of(ctx.handle) == ctx.device
     assert hotpath.device_count() >= 1
     assert hotpath.rank_device(local_rank=hotpath.device_count() + 2) == 2 % hotpath.device_count()
+
+
+@pytest.mark.gpu
+def test_gpu_native_chromosome_run_equals_the_python_farm(ctx, tmp_path):
+    """gauss_host_impute_chromosome (native windows loop: LPT shard, batched pipeline against the resident panel,
+    per-job events) must hand back, bit for bit, what the Python farm assembles window by window -- for one rank,
+    for two ranks merged, for every batch count -- and report guarded windows instead of failing."""
+    st = make_study(tmp_path)
+    p = st["paths"]
+    gpk = str(tmp_path / "panel.gpk")
+    assert api.pack_panel(p["index.gz"], p["data.gz"], p["desc.txt"], gpk) > 0
+    span = dict(chr=22, start_bp=1_000_001, end_bp=4_000_000, wing_size=200_000)
+    want = farm.impute_chromosome(api.KIND_DISTMIX, pop_wgt_df=WGT, window_size=250_000, input_file=p["gwas.txt"],
+                                  reference_index_file=p["index.gz"], reference_data_file=gpk, reference_pop_desc_file=p["desc.txt"],
+                                  compute=lambda pl: farm.gpu_compute(pl, ctx), **span)
+    wt = want["table"]
+    kw = dict(kind=api.KIND_DISTMIX, pop_wgt_df=WGT, window_size=250_000, input_file=p["gwas.txt"], reference_data_file=gpk,
+              reference_pop_desc_file=p["desc.txt"], ctx=ctx, **span)
+
+    def same(res):
+        f = res.frame()
+        assert list(f.columns) == list(wt.columns)
+        assert list(f["rsid"]) == list(wt["rsid"]) and list(f["bp"]) == list(wt["bp"])
+        for c in ("z", "info", "pval", "af1mix"):
+            assert np.array_equal(f[c].to_numpy(), wt[c].to_numpy()), c
+        assert list(f["type"]) == list(wt["type"])
+
+    for nb in (1, 2, 5):
+        one = api.impute_chromosome(n_batches=nb, **kw)
+        same(one)
+        assert one.stats["n_windows"] == 12 and one.stats["n_failed"] == 0
+        assert one.stats["n_skipped"] == len(want["skipped"])
+        assert sorted(np.nonzero(one.windows[:, 3] == 1)[0]) == sorted(want["windows"].index(w) for w, _ in want["skipped"])
+    assert one.stats["panel_bytes_uploaded"] == 0                     # resident since the first call
+    parts = [api.impute_chromosome(rank=r, world=2, **kw) for r in range(2)]
+    assert all(q.stats["n_windows_mine"] > 0 for q in parts)
+    assert not (set(parts[0].columns["window"]) & set(parts[1].columns["window"]))
+    same(api.ChromResult.merge(parts))
+    api.panel_evict(ctx=ctx)
+    again = api.impute_chromosome(**kw)
+    assert again.stats["panel_bytes_uploaded"] > 0
+    same(again)
+    api.panel_evict(ctx=ctx)
+
+
+@pytest.mark.gpu
+def test_gpu_native_chromosome_isolates_a_failing_window(ctx, tmp_path):
+    """A window whose data layer fails (here: the GWAS file lists one SNP with both allele orders inside that
+    window, the reference's "duplicates" error, gauss.cpp:388-391) is reported, the other windows still come back."""
+    st = make_study(tmp_path)
+    p = st["paths"]
+    gpk = str(tmp_path / "panel.gpk")
+    api.pack_panel(p["index.gz"], p["data.gz"], p["desc.txt"], gpk)
+    lines = open(p["gwas.txt"]).read().splitlines()
+    rows = [l.split() for l in lines[1:]]
+    victim = next(r for r in rows if 1_600_000 < int(r[2]) < 1_900_000)
+    bad = tmp_path / "gwas_dup.txt"
+    bad.write_text("\n".join(lines + [" ".join([victim[0], victim[1], victim[2], victim[4], victim[3], victim[5]])]) + "\n")
+    kw = dict(kind=api.KIND_DISTMIX, pop_wgt_df=WGT, window_size=500_000, chr=22, start_bp=1_000_001, end_bp=4_000_000,
+              wing_size=100_000, reference_data_file=gpk, reference_pop_desc_file=p["desc.txt"], ctx=ctx)
+    good = api.impute_chromosome(input_file=p["gwas.txt"], **kw)
+    res = api.impute_chromosome(input_file=str(bad), **kw)
+    assert res.stats["n_failed"] >= 1 and any("duplicate" in m for m in res.messages)
+    failed = set(np.nonzero(res.windows[:, 3] == 2)[0])
+    keep = ~np.isin(good.columns["window"], list(failed))
+    assert np.array_equal(res.columns["z"], good.columns["z"][keep])
+    assert np.array_equal(res.columns["rsid"], good.columns["rsid"][keep])
+    api.panel_evict(ctx=ctx)

@@ -442,3 +442,43 @@ def test_feeder_fuzz_against_python_feeder(tmp_path, seed):
         _check_prepared(pr, vec, meas, unme, mix)
         assert np.array_equal(pr.pop_off(), fp._selected_off(ref_pops, flags))
         pr.close()
+
+
+def test_corrupt_packed_panels_are_refused_not_read(study, packed, tmp_path):
+    """A packed panel is untrusted input (it is mmap'd and its offsets end up on the GPU): truncated files, counts
+    that overflow, string offsets outside the string table and population blocks outside the row must all be
+    reported as errors at open time."""
+    import struct
+    inp, idx, dat, desc = _files(study)
+    good = open(packed, "rb").read()
+    hdr = struct.unpack("<8sIIQQQQQQQQQI36x", good[:128])
+    (magic, ver, n_pop, n_snp, row_bytes, off_pops, off_snps, off_str, off_af, off_cnt, off_geno, total, srt) = hdr
+
+    def repack(**kw):
+        f = dict(magic=magic, ver=ver, n_pop=n_pop, n_snp=n_snp, row_bytes=row_bytes, off_pops=off_pops, off_snps=off_snps,
+                 off_str=off_str, off_af=off_af, off_cnt=off_cnt, off_geno=off_geno, total=total, srt=srt)
+        f.update(kw)
+        return struct.pack("<8sIIQQQQQQQQQI36x", f["magic"], f["ver"], f["n_pop"], f["n_snp"], f["row_bytes"], f["off_pops"],
+                           f["off_snps"], f["off_str"], f["off_af"], f["off_cnt"], f["off_geno"], f["total"], f["srt"])
+
+    cases = {}
+    cases["truncated"] = good[: len(good) // 2]
+    cases["n_snp_overflow"] = repack(n_snp=(1 << 62) + 5) + good[128:]
+    cases["n_snp_too_many"] = repack(n_snp=n_snp + 1000) + good[128:]
+    cases["row_bytes_unaligned"] = repack(row_bytes=row_bytes + 4) + good[128:]
+    cases["geno_offset_past_end"] = repack(off_geno=total - 16) + good[128:]
+    b = bytearray(good)                                   # first SNP's rsid offset -> far outside the string table
+    struct.pack_into("<I", b, off_snps + 4, 0x7FFFFFF0)
+    cases["string_offset"] = bytes(b)
+    b = bytearray(good)                                   # last population block pushed past the end of a row
+    struct.pack_into("<I", b, off_pops + 56 * (n_pop - 1) + 52, (row_bytes + 64) // 16 * 16)
+    cases["pop_block"] = bytes(b)
+    b = bytearray(good)
+    struct.pack_into("<I", b, off_pops + 52, 8)           # population block not 16-byte aligned
+    cases["pop_alignment"] = bytes(b)
+    for name, blob in cases.items():
+        path = tmp_path / f"{name}.gpk"
+        path.write_bytes(blob)
+        with pytest.raises(api.GaussError):
+            api.Prepared(api.KIND_DIST, chr=22, start_bp=1_400_000, end_bp=2_000_000, wing_size=250_000, study_pop="EUR",
+                         input_file=inp, reference_index_file=idx, reference_data_file=str(path), reference_pop_desc_file=desc)
