@@ -11,14 +11,14 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 cd "$ROOT"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 bench.py --steps 20 --warmup 5 > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.log"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 bench.py --steps 20 --warmup 5 --no-e2e > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.log"
 echo "stats done" && tail -1 "$OUT/bench_under_rocprof.json" | head -c 600 && echo
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-i8-variant > "$OUT/pmc_fetch.json" 2> "$OUT/pmc_fetch.log"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-i8-variant --no-e2e > "$OUT/pmc_fetch.json" 2> "$OUT/pmc_fetch.log"
 echo "fetch done"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-i8-variant > "$OUT/pmc_write.json" 2> "$OUT/pmc_write.log"
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-i8-variant --no-e2e > "$OUT/pmc_write.json" 2> "$OUT/pmc_write.log"
 echo "write done"
 # 3. SQ wave-state + MFMA-utilisation counters (8 SQ slots per pass, own pass, no trace domains)
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_F64 --output-format csv -d "$OUT/pmc_sq" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-i8-variant > "$OUT/pmc_sq.json" 2> "$OUT/pmc_sq.log"
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_F64 --output-format csv -d "$OUT/pmc_sq" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-i8-variant --no-e2e > "$OUT/pmc_sq.json" 2> "$OUT/pmc_sq.log"
 echo "sq done"
-rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_COEXEC_CYCLES --output-format csv -d "$OUT/pmc_sq2" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-i8-variant > "$OUT/pmc_sq2.json" 2> "$OUT/pmc_sq2.log" || echo "sq2 pass failed (optional counters)"
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_COEXEC_CYCLES --output-format csv -d "$OUT/pmc_sq2" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-i8-variant --no-e2e > "$OUT/pmc_sq2.json" 2> "$OUT/pmc_sq2.log" || echo "sq2 pass failed (optional counters)"
 python3 tools/summarize_profiles.py "$TAG" "$OUT"

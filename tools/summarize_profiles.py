@@ -55,8 +55,11 @@ def pmc_all(dirname):
 def sq_mfma(tag, d, out):
     """Wave-state fractions and matrix-core utilisation per kernel (MI355X_MICROARCH.md, rocprofv3 PMC slots):
     parked = SQ_WAIT_ANY, issue stall = SQ_WAIT_INST_ANY, issuing = SQ_ACTIVE_INST_ANY, each / SQ_WAVE_CYCLES
-    (all three in quad-cycles); mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES (cycles, summed over the chip's SIMD pipes as
-    reported) / (4 * SQ_BUSY_CYCLES) -- the share of the kernel's busy time its matrix pipes were executing."""
+    (all three in quad-cycles).  mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (32 * SQ_BUSY_CYCLES): the busy cycles of the
+    1024 matrix pipes (256 CUs x 4 SIMDs, summed) over 1024 x the kernel's duration in cycles; SQ_BUSY_CYCLES is
+    reported summed over the 32 shader engines, so duration = SQ_BUSY_CYCLES / 32 (cross-check on this chip:
+    GRBM_GUI_ACTIVE, summed over the 8 XCDs, / 8 gives the same duration within 3 %).  For the f32 Gram kernel the
+    figure equals issued MFMA flops / peak (one v_mfma_f32_32x32x2_f32 holds a pipe for 64 cycles)."""
     a = pmc_all(os.path.join(d, "pmc_sq"))
     b = pmc_all(os.path.join(d, "pmc_sq2"))
     if not a:
@@ -66,7 +69,7 @@ def sq_mfma(tag, d, out):
     cols2 = ["GRBM_GUI_ACTIVE", "SQ_INSTS_MFMA", "SQ_INSTS_VALU", "SQ_WAIT_INST_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE",
              "SQ_VALU_MFMA_COEXEC_CYCLES"]
     with open(os.path.join(out, f"{tag}_sq_mfma.csv"), "w") as fh:
-        fh.write("kernel,launches,parked_frac,issue_stall_frac,issuing_frac,mfma_busy_over_4x_sq_busy," +
+        fh.write("kernel,launches,parked_frac,issue_stall_frac,issuing_frac,mfma_util," +
                  ",".join(c + "_per_launch" for c in cols + cols2) + "\n")
         for k in sorted(a):
             if "gauss" not in k:
@@ -76,7 +79,7 @@ def sq_mfma(tag, d, out):
             w = v["SQ_WAVE_CYCLES"][0] or 1.0
             busy = v["SQ_BUSY_CYCLES"][0] or 1.0
             row = [k, str(n), "%.3f" % (v["SQ_WAIT_ANY"][0] / w), "%.3f" % (v["SQ_WAIT_INST_ANY"][0] / w),
-                   "%.3f" % (v["SQ_ACTIVE_INST_ANY"][0] / w), "%.3f" % (v["SQ_VALU_MFMA_BUSY_CYCLES"][0] / (4.0 * busy))]
+                   "%.3f" % (v["SQ_ACTIVE_INST_ANY"][0] / w), "%.3f" % (v["SQ_VALU_MFMA_BUSY_CYCLES"][0] / (32.0 * busy))]
             row += ["%.0f" % (v[c][0] / n) for c in cols]
             vb = b.get(k, {})
             row += ["%.0f" % (vb[c][0] / max(1, vb[c][1])) if c in vb else "" for c in cols2]
