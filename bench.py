@@ -477,6 +477,21 @@ def cpu_baseline(ch, wins, keep0, work, mode=1):
     }
 
 
+def cpu_baseline_computeld(sample):
+    """computeLD's pair loops (computeLD.cpp:95-116) in the CPU oracle on a bounded sample of the window's rows,
+    scaled by the pair count M (M + 1) / 2 + M to the whole window: LD matrices per second on one core."""
+    import oracle
+    g = np.ascontiguousarray(sample["geno"])
+    t0 = time.perf_counter()
+    oracle.compute_ld(g, sample["off"], sample["w"])
+    t = time.perf_counter() - t0
+    m, M = g.shape[0], sample["M"]
+    est = t * (M * (M + 1) / 2 + M) / (m * (m + 1) / 2 + m)
+    return {"value": 1.0 / est, "unit": "LD matrices/s", "cores": 1, "kind": "port", "host_cores": os.cpu_count(),
+            "sample": f"oracle compute_ld on {m} of the window's {M} SNPs (N={sample['N']}): {t:.2f} s, scaled by pair count to "
+                      f"{est:.1f} s per window"}
+
+
 def main(argv=None):
     args = parse_args(argv)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -486,7 +501,16 @@ def main(argv=None):
         out = run_impute(args, rig)
     else:
         from gauss_amd import benchmodes
-        out = {"computeLD": benchmodes.run_computeld, "jepegmix": benchmodes.run_jepegmix, "e2e": benchmodes.run_e2e}[args.mode](args, rig)
+        if args.gpus > 1 and args.mode != "e2e":
+            raise SystemExit(f"--mode {args.mode} is a single-GPU measurement")
+        if args.mode == "e2e":
+            out = benchmodes.run_e2e(args, rig)
+        else:
+            out, sample = {"computeLD": benchmodes.run_computeld, "jepegmix": benchmodes.run_jepegmix}[args.mode](args, rig)
+            if out is not None and sample is not None and not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline_computeld(sample)
+            if out is not None:
+                print(json.dumps(out), flush=True)
     rig.close()           # not in a `finally`: a rank that failed must not wait in a barrier for the others
     return out
 

@@ -39,7 +39,8 @@ HOST_SYMBOLS = [
     "gauss_prepared_gene_off", "gauss_prepared_window_desc", "gauss_prepared_finish", "gauss_prepared_free",
     "gauss_host_bgzf_copy", "gauss_host_set_threads",
     "gauss_host_panel_resident", "gauss_host_panel_evict", "gauss_host_impute_chromosome", "gauss_table_n_messages",
-    "gauss_table_message", "gauss_table_strcol_fixed",
+    "gauss_table_message", "gauss_table_strcol_fixed", "gauss_host_panel_device_rows", "gauss_prepared_store_rows",
+    "gauss_host_jepeg_gene_tail",
 ]
 
 
@@ -135,6 +136,9 @@ def load_host():
     h.gauss_host_bgzf_copy.argtypes = [_cp, _cp]
     h.gauss_host_panel_resident.argtypes = [_vp, _cp, C.POINTER(_i64)]
     h.gauss_host_panel_evict.argtypes = [_vp, _cp]
+    h.gauss_host_panel_device_rows.argtypes = [_vp, _cp, C.POINTER(C.c_void_p)]
+    ipp = C.POINTER(C.POINTER(C.c_int32))
+    h.gauss_prepared_store_rows.argtypes = [_vp, ipp, ipp, ipp, C.POINTER(C.c_int)]
     h.gauss_host_impute_chromosome.argtypes = [_vp, C.c_int, C.c_int, _i64, _i64, _i64, _i64, _cp, _strs, _dp, C.c_int, _cp, _cp, _cp,
                                                _dbl, C.c_int, C.c_int, C.c_int, C.POINTER(_vp), C.POINTER(ChromStats)]
     h.gauss_table_n_messages.argtypes = [_vp]
@@ -404,6 +408,25 @@ class ChromResult:
         return ChromResult(cat, windows, stats, [m for p in parts for m in p.messages])
 
 
+def jepeg_gene_tail(corg, z, info, has, wgt):
+    """gauss_host_jepeg_gene_tail: the host k x k tail of jepeg()/jepegmix() for one gene (no GPU involved)."""
+    h = load_host()
+    corg = np.ascontiguousarray(corg, dtype=np.float64)
+    n = corg.shape[0]
+    z, info = np.ascontiguousarray(z, dtype=np.float64), np.ascontiguousarray(info, dtype=np.float64)
+    has = np.ascontiguousarray(has, dtype=np.int32).reshape(n, 6)
+    wgt = np.ascontiguousarray(wgt, dtype=np.float64).reshape(n, 6)
+    chisq, jp, tcp, tsp = C.c_double(), C.c_double(), C.c_double(), C.c_double()
+    df, tc, ts = C.c_int32(), C.c_int32(), C.c_int32()
+    ip = C.POINTER(C.c_int32)
+    h.gauss_host_jepeg_gene_tail.argtypes = [C.c_int, _dp, _dp, _dp, ip, _dp, _dp, ip, _dp, ip, _dp, ip, _dp]
+    _hcheck(h.gauss_host_jepeg_gene_tail(n, corg.ctypes.data_as(_dp), z.ctypes.data_as(_dp), info.ctypes.data_as(_dp),
+                                         has.ctypes.data_as(ip), wgt.ctypes.data_as(_dp), C.byref(chisq), C.byref(df), C.byref(jp),
+                                         C.byref(tc), C.byref(tcp), C.byref(ts), C.byref(tsp)))
+    return dict(chisq=chisq.value, df=df.value, jepeg_pval=jp.value, top_categ=tc.value, top_categ_pval=tcp.value,
+                top_snp=ts.value, top_snp_pval=tsp.value, num_snp=n)
+
+
 def panel_resident(packed_file, ctx=None):
     """Upload a packed panel's genotype rows to the GPU once (gauss_host_panel_resident); returns the bytes moved now."""
     n = _i64()
@@ -502,6 +525,20 @@ class Prepared:
         base, nb, rb = C.c_void_p(), _i64(), _i64()
         _hcheck(self.h.gauss_prepared_packed_store(self.handle, C.byref(base), C.byref(nb), C.byref(rb)))
         return (base.value, nb.value, rb.value) if base.value else None
+
+    def window_rows(self, packed_file=None, ctx=None):
+        """For a packed-panel object: dict(rows_m, rows_u, pop_src_off, ld[, store]) -- the panel rows of its SNPs and,
+        when `packed_file` is resident on `ctx`, the device pointer of the panel's row 0."""
+        rm, ru, so = (C.POINTER(C.c_int32)() for _ in range(3))
+        n = C.c_int()
+        _hcheck(self.h.gauss_prepared_store_rows(self.handle, C.byref(rm), C.byref(ru), C.byref(so), C.byref(n)))
+        arr = lambda p, k: (np.ctypeslib.as_array(p, shape=(k,)).astype(np.int32).copy() if k else np.zeros(0, np.int32))
+        out = dict(rows_m=arr(rm, self.M), rows_u=arr(ru, self.U), pop_src_off=arr(so, n.value), ld=self.packed_store()[2])
+        if packed_file is not None:
+            dev = C.c_void_p()
+            _hcheck(self.h.gauss_host_panel_device_rows(_ctx(ctx), _enc(packed_file), C.byref(dev)))
+            out["store"] = dev.value
+        return out
 
     def window_desc(self):
         d = _lib.WindowDesc()

@@ -175,9 +175,198 @@ def run_e2e(args, rig):
     return out
 
 
+def _time_job(rig, job, steps, warmup):
+    for _ in range(max(1, warmup)):
+        job.run(); res = job.fetch()
+    job.profile(True)
+    rig.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        job.run(); res = job.fetch()
+    rig.barrier()
+    dt = (time.perf_counter() - t0) / steps
+    stage = {k: job.profile_get(i) for i, k in enumerate(("gram", "pack_stats", "ld_epilogue", "factor", "solve"))}
+    job.profile(False)
+    return dt, stage, res
+
+
 def run_computeld(args, rig):
-    raise SystemExit("--mode computeLD: not built yet")
+    """--mode computeLD (BASELINE.json configs[1]): the LD matrix of the chr10 104-107 Mb window of the reference's
+    3 Mb study file (tests/golden/PGC2_3Mb.txt: 529 of its 721 SNPs) against a 33KG-shaped panel, PGC2 weights,
+    N = 32 147.  Three figures: the blocking gauss_ld call on host bytes (what the Rcpp driver binds; PCIe inclusive),
+    one window over resident 2-bit rows, and 32 such windows batched into one job (the form that fills the chip).
+    value = LD-GEMM TFLOP/s of the batched form (algorithmic N M (M+1) per window / Gram kernel time)."""
+    torch, ctx = rig.torch, rig.ctx
+    study = os.path.join(workload.ROOT, "tests", "golden", "PGC2_3Mb.txt")
+    _, bp, _, _, _ = workload.read_study(study)
+    ch = workload.make_chromosome(100_000, "distmix", seed=20260214, sample_scale=args.sample_scale, study=study)
+    # only the study's SNPs matter for computeLD (measured SNPs of the window, computeLD.cpp:80-86)
+    keep = np.nonzero(ch["measured"])[0]
+    sub = dict(ch, bp=ch["bp"][keep], thr=np.ascontiguousarray(ch["thr"][keep]), z=ch["z"][keep],
+               measured=ch["measured"][keep])
+    rho = np.ones(len(keep), dtype=np.float32)
+    rho[1:] = np.exp(-np.diff(sub["bp"]) / 50e3)
+    sub["rho"] = rho
+    import bench
+    panel_u8, ld = bench.synth_panel(rig, sub, 20260214)
+    store, ld2 = bench.pack_store(rig, sub, panel_u8, ld)
+    N = int(ch["off"][-1])
+    rows = np.nonzero((sub["bp"] >= 104_000_001) & (sub["bp"] <= 107_000_000))[0].astype(np.int32)
+    M = len(rows)
+    host = np.ascontiguousarray(panel_u8.index_select(0, torch.from_numpy(rows.astype(np.int64)).cuda())[:, :N].cpu().numpy())
+    del panel_u8
+
+    def desc():
+        return dict(mode=hotpath.MODE_WEIGHTED, pop_off=ch["off"], pop_wgt=ch["w"], z1=np.zeros(M), lam=0.0,
+                    dev=(store.data_ptr(), store.data_ptr(), M, 0, ld2), ld_codings=_lib.CODE_ADDITIVE,
+                    packed=dict(fmt=1, rows_m=rows, rows_u=np.zeros(0, np.int32)))
+    flops = float(N) * M * (M + 1)
+    steps = min(args.steps, 50)
+    # (a) blocking host-pointer call
+    hotpath.ld_matrix(host, ch["off"], ch["w"], ctx=ctx)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        ref = hotpath.ld_matrix(host, ch["off"], ch["w"], ctx=ctx)
+    t_block = (time.perf_counter() - t0) / 5
+    # (b) one resident window, (c) 32 resident windows in one job
+    one = hotpath.Job([desc()], ctx=ctx, on_device=True)
+    dt1, st1, r1 = _time_job(rig, one, steps, args.warmup)
+    B = 32
+    many = hotpath.Job([desc() for _ in range(B)], ctx=ctx, on_device=True)
+    dtb, stb, rb = _time_job(rig, many, steps, args.warmup)
+    ok = bool(np.array_equal(r1[0]["b11"], ref) and all(np.array_equal(x["b11"], ref) for x in rb) and
+              np.allclose(np.diag(ref), 1.0) and np.array_equal(ref, ref.T))
+    g1 = st1["gram"][0] / max(1, st1["gram"][1]) * 1e-3
+    gb = stb["gram"][0] / max(1, stb["gram"][1]) * 1e-3
+    out = None
+    if rig.rank == 0:
+        ach = B * flops / gb / 1e12
+        out = {
+            "metric": "computeLD() LD-GEMM MFMA TFLOP/s vs peak (BASELINE.json configs[1])",
+            "value": ach, "unit": "TFLOP/s", "n_gpus": 1, "steps": steps, "warmup": args.warmup, "ms_per_step": dtb * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"computeLD() chr10:104-107 Mb, {M} of the 721 SNPs of tests/golden/PGC2_3Mb.txt x {N} samples "
+                                   f"(21 populations, PGC2 weights), weighted LD (computeLD.cpp:95-116); batched form = {B} such windows in one job",
+                       "M": M, "samples": N, "batch": B, "results_identical_across_forms": ok},
+            "roofline": {"kernel": "gram_kernel (LD GEMM, v_mfma_f32_32x32x2_f32), batched form", "bound": "mfma", "achieved": ach,
+                         "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "algorithmic_flops_per_launch": B * flops, "avg_launch_ms": gb * 1e3},
+            "forms": {
+                "blocking_gauss_ld_host_bytes": {"ms_per_call": t_block * 1e3, "ld_matrices_per_s": 1.0 / t_block,
+                                                 "note": f"{host.nbytes / 1e6:.1f} MB of genotype bytes over PCIe per call, {M * M * 8 / 1e6:.1f} MB back"},
+                "one_resident_window": {"ms_per_step": dt1 * 1e3, "gram_ms": g1 * 1e3, "gram_tflops": flops / g1 / 1e12,
+                                        "stage_ms": {k: v[0] / steps for k, v in st1.items()}},
+                "batched_resident_windows": {"windows": B, "ms_per_step": dtb * 1e3, "gram_ms": gb * 1e3, "gram_tflops": ach,
+                                             "ld_matrices_per_s": B / dtb, "stage_ms": {k: v[0] / steps for k, v in stb.items()}},
+            },
+        }
+    one.close(); many.close()
+    sample = dict(kind="computeLD", geno=host[:160], off=ch["off"], w=ch["w"], M=M, N=N, batch=B)
+    return out, sample
+
+
+def make_annotation(ch, files, outdir, n_genes=350, seed=9):
+    """A JEPEG annotation in the documented 8-column format (gauss.cpp:1308,1319-1330): n_genes genes, 1-20 measured SNPs
+    each (consecutive measured SNPs around a random locus), 1-2 of the 6 functional categories per SNP, random weights
+    -- the stand-in for the missing JEPEG_SNP_Annotation.v1.0.txt."""
+    rng = np.random.default_rng(seed)
+    m = np.nonzero(ch["measured"])[0]
+    rows = []
+    starts = np.sort(rng.choice(len(m) - 20, size=n_genes, replace=False))
+    n_snp = 0
+    for g, s0 in enumerate(starts):
+        k = int(rng.integers(1, 21))
+        for s in m[s0:s0 + k]:
+            for c in rng.choice(6, size=int(rng.integers(1, 3)), replace=False):
+                rows.append((files["rsid"][s], 22, int(ch["bp"][s]), files["a1"][s], files["a2"][s], f"GENE{g:04d}", panel.CATEGS[c],
+                             float(np.round(rng.uniform(0.2, 2.0), 3))))
+        n_snp += k
+    path = os.path.join(outdir, "annot.txt")
+    panel.write_annotation(path, rows)
+    return path, n_genes, n_snp
 
 
 def run_jepegmix(args, rig):
-    raise SystemExit("--mode jepegmix: not built yet")
+    """--mode jepegmix (BASELINE.json configs[4]): jepegmix() over ~350 synthetic genes (1-20 SNPs each) of the chr22
+    study, PGC2 weights, N = 32 147, from files: packed panel + GWAS + annotation -> gene table.  The GPU part is the
+    batched gene LD (pack -> Gram on the tile pairs genes touch -> gene epilogue); the k x k tail (k <= 6) runs on the
+    host.  value = genes/s of the whole call (host bound, as SURVEY.md section 8d expects); the roofline entry is the
+    gene epilogue's byte roofline with the algorithmic bytes sum n_g N (2-bit: / 4) in + sum n_g^2 8 out."""
+    ch = workload.make_chromosome(args.snps, "distmix", seed=20260216, sample_scale=args.sample_scale)
+    tmp = tempfile.mkdtemp(prefix="gauss_jepeg_")
+    out = None
+    try:
+        files = write_study_files(rig, ch, tmp)
+        annot, n_genes, _ = make_annotation(ch, files, tmp)
+        wgt = (list(synth.PGC2_WEIGHTS.keys()), list(synth.PGC2_WEIGHTS.values()))
+        kw = dict(pop_wgt_df=wgt, input_file=files["gwas"], annotation_file=annot, reference_index_file="(packed)",
+                  reference_data_file=files["panel"], reference_pop_desc_file=files["desc"], ctx=rig.ctx)
+        api.panel_evict(ctx=rig.ctx)
+        t0 = time.perf_counter()
+        tab = api.jepegmix(**kw)
+        cold = time.perf_counter() - t0
+        steps = min(args.steps, 10)
+        ts = []
+        for _ in range(steps):
+            t0 = time.perf_counter()
+            tab = api.jepegmix(**kw)
+            ts.append(time.perf_counter() - t0)
+        warm = float(np.median(ts))
+        # the host data layer alone (no GPU call): what bounds the run
+        t0 = time.perf_counter()
+        pr = api.Prepared(api.KIND_JEPEGMIX, **{k: v for k, v in kw.items() if k != "ctx"})
+        t_host = time.perf_counter() - t0
+        go = pr.gene_off()
+        sizes = np.diff(go).astype(np.int64)
+        S, N = pr.M, pr.N
+        # the GPU part alone, resident rows, through the C ABI entry point the driver uses
+        gpu = gene_batch_gpu_time(rig, files, pr, ch, steps)
+        pr.close()
+        if rig.rank == 0:
+            bytes_in = float(sizes.sum()) * N / 4.0
+            bytes_out = float((sizes * sizes).sum()) * 8.0
+            out = {
+                "metric": "jepegmix() genes/sec from files (BASELINE.json configs[4])",
+                "value": len(tab) / warm, "unit": "genes/s", "n_gpus": 1, "steps": steps, "warmup": 1, "ms_per_step": warm * 1e3,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": f"jepegmix() chr22: {n_genes} synthetic genes (1-20 SNPs, {int(sizes.sum())} gene SNPs after the AF filter) from "
+                                       f"{ch['study']}, PGC2 weights, N = {N}; packed panel ({files['panel_bytes'] / 1e6:.0f} MB) + GWAS + annotation files -> gene table",
+                           "genes_in_table": int(len(tab)), "gene_snps": int(sizes.sum()), "samples": N,
+                           "all_finite_pvals": bool(np.all(np.isfinite(tab["jepeg_pval"].to_numpy()[tab["df"].to_numpy() > 0])))},
+                "breakdown": {"cold_call_s": cold, "warm_call_s_median": warm, "host_data_layer_s": t_host,
+                              "gpu_gene_ld_batch_ms": gpu["ms_per_call"], "note": "host bound: GWAS + annotation parsing and the SNP map dominate; "
+                              "the GPU batch is a few ms of pack + Gram on the tile pairs that genes touch"},
+                "roofline": {"kernel": "gauss_gene_ld_batch_rows (pack_stats + gram on gene tile pairs + gene_epilogue_kernel)", "bound": "hbm",
+                             "achieved": (bytes_in + bytes_out) / (gpu["ms_per_call"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": (bytes_in + bytes_out) / (gpu["ms_per_call"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                             "algorithmic_bytes": bytes_in + bytes_out,
+                             "note": "algorithmic bytes = sum n_g N / 4 (2-bit rows) in + sum n_g^2 8 out; the call is latency bound "
+                                     "(a handful of tile pairs), not bandwidth bound"},
+            }
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return out, None
+
+
+def gene_batch_gpu_time(rig, files, pr, ch, steps):
+    """gauss_gene_ld_batch_rows alone on the resident panel (what run_jepeg calls between the data layer and the tail)."""
+    ctx = rig.ctx
+    api.panel_resident(files["panel"], ctx=ctx)
+    d = pr.window_rows(files["panel"], ctx)
+    go = np.ascontiguousarray(pr.gene_off(), dtype=np.int32)
+    sizes = np.diff(go).astype(np.int64)
+    outb = np.zeros(int((sizes * sizes).sum()))
+    ip = C.POINTER(C.c_int32)
+    dp = C.POINTER(C.c_double)
+    po, w = np.ascontiguousarray(pr.pop_off(), np.int32), np.ascontiguousarray(pr.pop_wgt(), np.float64)
+
+    def call():
+        _lib.check(ctx.lib.gauss_gene_ld_batch_rows(ctx.handle, hotpath.MODE_WEIGHTED, d["store"], d["ld"], _lib.GENO_2BIT,
+                                                    d["rows_m"].ctypes.data_as(ip), pr.M, po.ctypes.data_as(ip),
+                                                    d["pop_src_off"].ctypes.data_as(ip), w.ctypes.data_as(dp), len(w),
+                                                    go.ctypes.data_as(ip), len(go) - 1, 1.1, 1, outb.ctypes.data_as(dp)))
+    call()
+    t0 = time.perf_counter()
+    for _ in range(max(1, steps)):
+        call()
+    return {"ms_per_call": (time.perf_counter() - t0) / max(1, steps) * 1e3}

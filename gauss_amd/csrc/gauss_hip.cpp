@@ -1220,9 +1220,17 @@ int gauss_impute_window(gauss_ctx* ctx, const gauss_window_desc* win)
     return rc;
 }
 
+struct RowSource {                 // where the rows of an LD-only call come from (default: a contiguous host byte matrix)
+    int geno_fmt = GAUSS_GENO_U8;
+    const int32_t* rows = nullptr;
+    const int32_t* pop_src_off = nullptr;
+    int on_device = 0;
+};
+
 static int ld_common(gauss_ctx* ctx, int mode, const uint8_t* geno, int n_snp, int64_t ld,
                      const int32_t* pop_off, const double* pop_wgt, int n_pop, double diag,
-                     const int32_t* gene_off, int n_gene, double* out, int64_t* out_counts, int n_samples)
+                     const int32_t* gene_off, int n_gene, double* out, int64_t* out_counts, int n_samples,
+                     const RowSource& src = RowSource())
 {
     if (!ctx || !geno || (!out && !out_counts)) return fail(GAUSS_E_INVALID, "bad arguments");
     WinSpec w;
@@ -1230,9 +1238,10 @@ static int ld_common(gauss_ctx* ctx, int mode, const uint8_t* geno, int n_snp, i
     w.mode = mode; w.n_pop = out_counts ? 1 : n_pop; w.pop_off = out_counts ? off1 : pop_off; w.pop_wgt = pop_wgt;
     w.M = n_snp; w.U = 0; w.geno_m = geno; w.geno_u = nullptr; w.ld = ld; w.z1 = nullptr;
     w.lambda = 0; w.eps = 0; w.diag = diag; w.ld_only = 1; w.gene_off = gene_off; w.n_gene = n_gene;
+    w.geno_fmt = src.geno_fmt; w.rows_m = src.rows; w.pop_src_off = src.pop_src_off;
     gauss_job* job = nullptr;
     std::vector<WinSpec> specs{w};
-    int rc = job_build(ctx, specs, 0, &job);
+    int rc = job_build(ctx, specs, src.on_device, &job);
     if (rc) return rc;
     std::unique_ptr<gauss_job, void (*)(gauss_job*)> guard(job, job_free);
     if (!out_counts) job->plans[0].out_ld_user = out;
@@ -1262,6 +1271,25 @@ int gauss_gene_ld_batch(gauss_ctx* ctx, int mode, const uint8_t* geno, int n_snp
 {
     if (!gene_off || n_gene < 1) return fail(GAUSS_E_INVALID, "gene_off is NULL or n_gene < 1");
     return ld_common(ctx, mode, geno, n_snp, ld, pop_off, pop_wgt, n_pop, diag, gene_off, n_gene, out_blocks, nullptr, 0);
+}
+
+int gauss_ld_rows(gauss_ctx* ctx, int mode, const uint8_t* store, int64_t ld, int geno_format, const int32_t* rows, int n_snp,
+                  const int32_t* pop_off, const int32_t* pop_src_off, const double* pop_wgt, int n_pop, double diag,
+                  int on_device, double* out_cor)
+{
+    RowSource src;
+    src.geno_fmt = geno_format; src.rows = rows; src.pop_src_off = pop_src_off; src.on_device = on_device;
+    return ld_common(ctx, mode, store, n_snp, ld, pop_off, pop_wgt, n_pop, diag, nullptr, 0, out_cor, nullptr, 0, src);
+}
+
+int gauss_gene_ld_batch_rows(gauss_ctx* ctx, int mode, const uint8_t* store, int64_t ld, int geno_format, const int32_t* rows,
+                             int n_snp, const int32_t* pop_off, const int32_t* pop_src_off, const double* pop_wgt, int n_pop,
+                             const int32_t* gene_off, int n_gene, double diag, int on_device, double* out_blocks)
+{
+    if (!gene_off || n_gene < 1) return fail(GAUSS_E_INVALID, "gene_off is NULL or n_gene < 1");
+    RowSource src;
+    src.geno_fmt = geno_format; src.rows = rows; src.pop_src_off = pop_src_off; src.on_device = on_device;
+    return ld_common(ctx, mode, store, n_snp, ld, pop_off, pop_wgt, n_pop, diag, gene_off, n_gene, out_blocks, nullptr, 0, src);
 }
 
 int gauss_ld_per_pop(gauss_ctx* ctx, const uint8_t* geno, int n_snp, int64_t ld, const int32_t* pop_off, int n_pop,

@@ -605,6 +605,9 @@ static std::shared_ptr<PackedPanel> open_packed_shared(const std::string& path, 
     return sp;
 }
 
+static int panel_make_resident(gauss_ctx* ctx, const std::string& path, void** dev, int64_t* uploaded);
+static bool panel_is_resident(gauss_ctx* ctx, const std::string& path, void** dev);
+
 // ------------------------------------------------------------------------------------------
 // prepared window / gene set
 // ------------------------------------------------------------------------------------------
@@ -790,9 +793,10 @@ static int prepare(gauss_prepared& p)
             if (a.pop_flag_vec[k]) p.pop_src_off.push_back((int32_t)pk.pop(k).byte_off);
         for (Snp* s : p.measured) p.store_rows_m.push_back((int32_t)s->fpos);
         for (Snp* s : p.unmeasured) p.store_rows_u.push_back((int32_t)s->fpos);
-        // windows whose numeric step accepts row lists leave the genotypes in the mmap'd panel; the LD-only
-        // entry points (gauss_ld, gauss_gene_ld_batch) and the minor-allele flip need bytes on the host
-        p.packed_rows = (kind == GAUSS_KIND_DIST || kind == GAUSS_KIND_DISTMIX || qcat || kind == GAUSS_KIND_PREP_QCAT);
+        // every numeric entry point accepts row lists (windows: gauss_window_desc.rows_m/rows_u; LD-only calls:
+        // gauss_ld_rows, gauss_gene_ld_batch_rows), so the genotypes stay in the mmap'd panel / in HBM; only the
+        // minor-allele flip of prep_recessive_impute needs bytes on the host
+        p.packed_rows = (kind != GAUSS_KIND_PREP_RECESSIVE);
         if (!p.packed_rows) materialise_from_packed(p);
     } else {
         // every selected population string must have its panel length, otherwise the matrix is ragged
@@ -994,6 +998,22 @@ static GeneResult jepeg_tail(const std::vector<Snp*>& gs, const double* CorG, co
     r.top_snp_pval = 2 * pnorm_upper(fabs(gs[ts]->z));
     r.geneid = gs[0]->geneid;                                           // gene.cpp:524 (only when df > 0)
     return r;
+}
+
+// Row store of an LD-only call on a packed panel: the resident copy in HBM when there is one (or the panel is small
+// enough to make resident on the spot: a chromosome is < 1 GB), else the mmap'd rows, gathered while staging.
+static int packed_row_source(gauss_ctx* ctx, const gauss_prepared& p, const uint8_t** store, int* on_device)
+{
+    const PackedPanel& pk = *p.args.pk;
+    void* dev = nullptr;
+    const int64_t bytes = pk.n_snp() * pk.row_bytes();
+    if (panel_is_resident(ctx, p.args.reference_data_file, &dev) ||
+        (bytes <= ((int64_t)4 << 30) && panel_make_resident(ctx, p.args.reference_data_file, &dev, nullptr) == 0)) {
+        *store = (const uint8_t*)dev; *on_device = 1;
+        return 0;
+    }
+    *store = pk.geno(); *on_device = 0;
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1544,8 +1564,15 @@ int gauss_host_computeLD(gauss_ctx* ctx, int chr, int64_t start_bp, int64_t end_
     std::unique_ptr<gauss_table> t(new gauss_table());
     t->matrix.assign((size_t)M * M, 0.0);
     t->matrix_n = M;
-    if (gauss_ld(ctx, GAUSS_MODE_WEIGHTED, p->gm.data(), M, p->ld, p->pop_off.data(), p->pop_wgt.data(),
-                 (int)p->pop_off.size() - 1, 1.0, t->matrix.data()) != 0) return herr("%s", gauss_last_error());
+    if (p->packed_rows) {
+        const uint8_t* store = nullptr;
+        int on_device = 0;
+        if (packed_row_source(ctx, *p, &store, &on_device)) return -1;
+        if (gauss_ld_rows(ctx, GAUSS_MODE_WEIGHTED, store, p->args.pk->row_bytes(), GAUSS_GENO_2BIT, p->store_rows_m.data(), M,
+                          p->pop_off.data(), p->pop_src_off.data(), p->pop_wgt.data(), (int)p->pop_off.size() - 1, 1.0, on_device,
+                          t->matrix.data()) != 0) return herr("%s", gauss_last_error());
+    } else if (gauss_ld(ctx, GAUSS_MODE_WEIGHTED, p->gm.data(), M, p->ld, p->pop_off.data(), p->pop_wgt.data(),
+                        (int)p->pop_off.size() - 1, 1.0, t->matrix.data()) != 0) return herr("%s", gauss_last_error());
     Column rsid{"rsid", GAUSS_COL_STR, {}, {}, {}}, chrc{"chr", GAUSS_COL_INT, {}, {}, {}}, bp{"bp", GAUSS_COL_INT, {}, {}, {}};
     Column a1{"a1", GAUSS_COL_STR, {}, {}, {}}, a2{"a2", GAUSS_COL_STR, {}, {}, {}}, af{"af1mix", GAUSS_COL_DBL, {}, {}, {}};
     for (Snp* s : p->measured) {                                        // computeLD.cpp:134-149
@@ -1576,8 +1603,16 @@ static int run_jepeg(gauss_ctx* ctx, int kind, const char* study_pop, const char
     if (S > 0 && ng > 0) {
         // CorG of every gene in one launch, diagonal 1 + lambda (gene.cpp:306-315 / 576-586)
         const int mode = (kind == GAUSS_KIND_JEPEG) ? GAUSS_MODE_POOLED : GAUSS_MODE_WEIGHTED;
-        if (gauss_gene_ld_batch(ctx, mode, p->gm.data(), S, p->ld, p->pop_off.data(), p->pop_wgt.data(),
-                                (int)p->pop_off.size() - 1, p->gene_off.data(), ng, 1.0 + a.lambda, blocks.data()) != 0)
+        if (p->packed_rows) {
+            const uint8_t* store = nullptr;
+            int on_device = 0;
+            if (packed_row_source(ctx, *p, &store, &on_device)) return -1;
+            if (gauss_gene_ld_batch_rows(ctx, mode, store, a.pk->row_bytes(), GAUSS_GENO_2BIT, p->store_rows_m.data(), S,
+                                         p->pop_off.data(), p->pop_src_off.data(), p->pop_wgt.data(), (int)p->pop_off.size() - 1,
+                                         p->gene_off.data(), ng, 1.0 + a.lambda, on_device, blocks.data()) != 0)
+                return herr("%s", gauss_last_error());
+        } else if (gauss_gene_ld_batch(ctx, mode, p->gm.data(), S, p->ld, p->pop_off.data(), p->pop_wgt.data(),
+                                       (int)p->pop_off.size() - 1, p->gene_off.data(), ng, 1.0 + a.lambda, blocks.data()) != 0)
             return herr("%s", gauss_last_error());
     }
     std::unique_ptr<gauss_table> t(new gauss_table());
@@ -1657,6 +1692,16 @@ static int panel_make_resident(gauss_ctx* ctx, const std::string& path, void** d
     return 0;
 }
 
+static bool panel_is_resident(gauss_ctx* ctx, const std::string& path, void** dev)
+{
+    const std::pair<gauss_ctx*, std::string> key(ctx, file_key(path));
+    std::lock_guard<std::mutex> lock(g_res_mu);
+    auto it = g_resident.find(key);
+    if (it == g_resident.end()) return false;
+    *dev = it->second.dev;
+    return true;
+}
+
 // minimal fork-join helper: fn(i) for i in [0, n) on up to nt threads
 template <typename F>
 static void parallel_for(int n, int nt, F fn)
@@ -1685,6 +1730,27 @@ int gauss_host_panel_resident(gauss_ctx* ctx, const char* packed_file, int64_t* 
     if (!PackedPanel::is_packed(packed_file)) return herr("'%s' is not a packed panel", packed_file);
     void* dev = nullptr;
     return panel_make_resident(ctx, packed_file, &dev, bytes_uploaded);
+}
+
+int gauss_host_panel_device_rows(gauss_ctx* ctx, const char* packed_file, const void** out_device_ptr)
+{
+    if (!ctx || !packed_file || !out_device_ptr) return herr("bad arguments");
+    void* dev = nullptr;
+    if (!panel_is_resident(ctx, packed_file, &dev)) return herr("packed panel '%s' is not resident on this context", packed_file);
+    *out_device_ptr = dev;
+    return 0;
+}
+
+int gauss_prepared_store_rows(const gauss_prepared* p, const int32_t** rows_m, const int32_t** rows_u,
+                              const int32_t** pop_src_off, int* n_pop_selected)
+{
+    if (!p) return herr("bad arguments");
+    if (!p->args.pk) return herr("not a packed-panel window");
+    if (rows_m) *rows_m = p->store_rows_m.data();
+    if (rows_u) *rows_u = p->store_rows_u.data();
+    if (pop_src_off) *pop_src_off = p->pop_src_off.data();
+    if (n_pop_selected) *n_pop_selected = (int)p->pop_src_off.size();
+    return 0;
 }
 
 int gauss_host_panel_evict(gauss_ctx* ctx, const char* packed_file)
@@ -1974,6 +2040,34 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
     st.t_total = now_s() - t_begin;
     if (stats) *stats = st;
     *out = all.release();
+    return 0;
+}
+
+// The JEPEG k x k tail of one gene on the host, as run_jepeg calls it after the GPU has produced CorG: exposed so that
+// it can be checked on its own (no GPU involved).  corg is n x n (symmetric), has / wgt are n x 6 row-major.
+int gauss_host_jepeg_gene_tail(int n, const double* corg, const double* z, const double* info, const int32_t* has,
+                               const double* wgt, double* chisq, int32_t* df, double* jepeg_pval, int32_t* top_categ,
+                               double* top_categ_pval, int32_t* top_snp, double* top_snp_pval)
+{
+    if (n < 0 || (n > 0 && (!corg || !z || !info || !has || !wgt))) return herr("bad arguments");
+    Args a;
+    std::vector<std::unique_ptr<Snp>> own;
+    std::vector<Snp*> gs;
+    for (int s = 0; s < n; s++) {
+        own.emplace_back(new Snp());
+        Snp& sn = *own.back();
+        sn.rsid = std::to_string(s); sn.z = z[s]; sn.info = info[s]; sn.geneid = "G";
+        for (int c = 0; c < 6; c++) if (has[(size_t)s * 6 + c]) sn.categ[c] = wgt[(size_t)s * 6 + c];
+        gs.push_back(&sn);
+    }
+    const GeneResult r = jepeg_tail(gs, corg, a);
+    if (chisq) *chisq = r.chisq;
+    if (df) *df = r.df;
+    if (jepeg_pval) *jepeg_pval = r.jepeg_pval;
+    if (top_categ) { *top_categ = -1; for (int c = 0; c < 6; c++) if (r.top_categ == categ_name(c)) *top_categ = c; }
+    if (top_categ_pval) *top_categ_pval = r.top_categ_pval;
+    if (top_snp) *top_snp = (r.top_snp == ".") ? -1 : atoi(r.top_snp.c_str());
+    if (top_snp_pval) *top_snp_pval = r.top_snp_pval;
     return 0;
 }
 

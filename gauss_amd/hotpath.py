@@ -140,6 +140,51 @@ def gene_ld_batch(geno, pop_off, gene_off, pop_wgt=None, mode=MODE_POOLED, diag=
     return blocks
 
 
+def _row_args(store, rows, pop_src_off):
+    """(pointer, int32 row array or None, int32 offsets or None) of a row-store call; `store` is a numpy matrix
+    (host rows), a RowStore (resident rows) or a raw device pointer."""
+    r = None if rows is None else np.ascontiguousarray(rows, dtype=np.int32)
+    so = None if pop_src_off is None else np.ascontiguousarray(pop_src_off, dtype=np.int32)
+    if isinstance(store, RowStore):
+        return store.ptr, store.ld, 1, r, so
+    if isinstance(store, np.ndarray):
+        return store.ctypes.data, store.strides[0], 0, r, so
+    ptr, ld = store
+    return ptr, ld, 1, r, so
+
+
+def ld_matrix_rows(store, rows, pop_off, pop_wgt=None, mode=MODE_WEIGHTED, diag=1.0, fmt=_lib.GENO_2BIT, pop_src_off=None,
+                   ctx=None):
+    """gauss_ld_rows: the LD matrix of the store rows `rows` (computeLD on a packed / resident panel)."""
+    ctx = ctx or default_context()
+    ptr, ld, on_dev, r, so = _row_args(store, rows, pop_src_off)
+    po, w = _pops(pop_off, pop_wgt)
+    S = len(r)
+    out = np.zeros((S, S))
+    check(ctx.lib.gauss_ld_rows(ctx.handle, int(mode), ptr, ld, int(fmt), _lib.ptr(r, _ip), S, po.ctypes.data_as(_ip),
+                                _lib.ptr(so, _ip), _lib.ptr(w, _dp), len(po) - 1, float(diag), on_dev, out.ctypes.data_as(_dp)))
+    return out
+
+
+def gene_ld_batch_rows(store, rows, pop_off, gene_off, pop_wgt=None, mode=MODE_POOLED, diag=1.1, fmt=_lib.GENO_2BIT,
+                       pop_src_off=None, ctx=None):
+    """gauss_gene_ld_batch_rows: LD blocks of all genes whose SNPs are the store rows `rows`."""
+    ctx = ctx or default_context()
+    ptr, ld, on_dev, r, so = _row_args(store, rows, pop_src_off)
+    po, w = _pops(pop_off, pop_wgt)
+    go = np.ascontiguousarray(gene_off, dtype=np.int32)
+    sizes = np.diff(go).astype(np.int64)
+    out = np.zeros(int((sizes * sizes).sum()))
+    check(ctx.lib.gauss_gene_ld_batch_rows(ctx.handle, int(mode), ptr, ld, int(fmt), _lib.ptr(r, _ip), len(r), po.ctypes.data_as(_ip),
+                                           _lib.ptr(so, _ip), _lib.ptr(w, _dp), len(po) - 1, go.ctypes.data_as(_ip), len(go) - 1,
+                                           float(diag), on_dev, out.ctypes.data_as(_dp)))
+    blocks, o = [], 0
+    for n in sizes:
+        blocks.append(out[o:o + n * n].reshape(n, n))
+        o += n * n
+    return blocks
+
+
 class _Win:
     """Keeps the numpy buffers of one window alive next to its C descriptor."""
 

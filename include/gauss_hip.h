@@ -171,6 +171,17 @@ int gauss_gene_ld_batch(gauss_ctx* ctx, int mode, const uint8_t* geno, int n_snp
                         const int32_t* pop_off, const double* pop_wgt, int n_pop,
                         const int32_t* gene_off, int n_gene, double diag, double* out_blocks);
 
+/* gauss_ld / gauss_gene_ld_batch over rows of a row store instead of a contiguous byte matrix: `store` holds rows of
+ * `ld` bytes in geno_format (GAUSS_GENO_U8 or GAUSS_GENO_2BIT, with pop_src_off as in gauss_window_desc), SNP s is store
+ * row rows[s] (rows NULL: row s).  on_device != 0: `store` is a device pointer, e.g. a packed panel made resident
+ * with gauss_store_upload -- nothing but the row indices travels to the GPU and only the LD blocks come back. */
+int gauss_ld_rows(gauss_ctx* ctx, int mode, const uint8_t* store, int64_t ld, int geno_format, const int32_t* rows, int n_snp,
+                  const int32_t* pop_off, const int32_t* pop_src_off, const double* pop_wgt, int n_pop, double diag,
+                  int on_device, double* out_cor);
+int gauss_gene_ld_batch_rows(gauss_ctx* ctx, int mode, const uint8_t* store, int64_t ld, int geno_format, const int32_t* rows,
+                             int n_snp, const int32_t* pop_off, const int32_t* pop_src_off, const double* pop_wgt, int n_pop,
+                             const int32_t* gene_off, int n_gene, double diag, int on_device, double* out_blocks);
+
 /* Per-population Pearson correlations of every SNP pair (prep_zmix5, zmix.cpp:158-176: CalCor on each
  * population's genotype strings, util.cpp:153-169).  out is [n_pop][n_snp*(n_snp-1)/2], population-major,
  * pairs in the reference's row order (i ascending, then j > i): column k+1 of the reference's column-major

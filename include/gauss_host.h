@@ -165,6 +165,12 @@ int gauss_prepared_packed_store(const gauss_prepared* p, const uint8_t** base, i
  * the whole 33KG panel.  gauss_host_panel_evict frees it (packed_file NULL: every panel of the context). */
 int gauss_host_panel_resident(gauss_ctx* ctx, const char* packed_file, int64_t* bytes_uploaded);
 int gauss_host_panel_evict(gauss_ctx* ctx, const char* packed_file);
+/* Device pointer of row 0 of a resident panel (error if it is not resident on this context), and, for a prepared
+ * object that reads a packed panel, the panel rows of its measured / unmeasured SNPs and the byte offset of each
+ * selected population block inside a row: what gauss_ld_rows / gauss_gene_ld_batch_rows / a window descriptor take. */
+int gauss_host_panel_device_rows(gauss_ctx* ctx, const char* packed_file, const void** out_device_ptr);
+int gauss_prepared_store_rows(const gauss_prepared* p, const int32_t** rows_m, const int32_t** rows_u,
+                              const int32_t** pop_src_off, int* n_pop_selected);
 
 typedef struct gauss_chrom_stats {
     int32_t n_windows, n_windows_mine, n_skipped, n_failed, n_batches, pad_;
@@ -193,6 +199,12 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
                                  const double* pop_wgts, int n_pop_wgt, const char* input_file,
                                  const char* reference_data_file, const char* reference_pop_desc_file, double af1_cutoff,
                                  int rank, int world, int n_batches, gauss_table** out, gauss_chrom_stats* stats);
+/* The host part of jepeg()/jepegmix() for ONE gene, given the CorG block the GPU produced (diagonal 1 + lambda):
+ * Gene::RunJepeg bookkeeping + CalJepegPval from W on (gene.cpp:88-185, 317-550).  corg [n x n], has / wgt [n x 6]
+ * row-major (category present, category weight).  top_categ / top_snp are indices (-1 when df = 0).  No GPU needed. */
+int gauss_host_jepeg_gene_tail(int n, const double* corg, const double* z, const double* info, const int32_t* has,
+                               const double* wgt, double* chisq, int32_t* df, double* jepeg_pval, int32_t* top_categ,
+                               double* top_categ_pval, int32_t* top_snp, double* top_snp_pval);
 int gauss_table_n_messages(const gauss_table* t);
 const char* gauss_table_message(const gauss_table* t, int k);
 /* A whole string column as one fixed-width, NUL-padded byte matrix [nrow x *width]. */

@@ -112,6 +112,74 @@ def run_qcat(mode, gm, gu, pop_off, w, z1, n_head, n_pred, lam=0.1, eig_cutoff=0
     return dict(r=r, num_eig=num_eig, b11=b11, b21=b21)
 
 
+def count_pc(b11, eig_cutoff=0.01):
+    """CountPC (util.cpp:355-388): M minus the number of eigenvalues below the cutoff, counted only when the
+    smallest one is below it (LAPACK eigvalsh instead of the C oracle's Jacobi sweep)."""
+    vals = np.linalg.eigvalsh(np.asarray(b11, dtype=np.float64))
+    return len(vals) - (int(np.sum(vals < eig_cutoff)) if vals[0] < eig_cutoff else 0)
+
+
+def jepeg_gene_tail(corg, z, info, has, wgt, min_abs_eig=1e-5, categ_cor_cutoff=0.8, denorm_norm_w=3):
+    """The k x k tail of one gene, stated from the reference alone (Gene::RunJepeg gene.cpp:88-185 for the category
+    bookkeeping, CalJepegPval gene.cpp:317-550, GetW :859-877, GetTopCateg :880-891, GetTopSNP :894-904,
+    CnvrtCovToCor util.cpp:284-296), in matrix form with LAPACK / scipy -- written without consulting
+    gauss_oracle.c or the product's host tail, so that a shared misreading cannot pass silently.
+
+    corg [n x n] is CorG including the 1 + lambda diagonal; has / wgt [n x 6] say which of the six functional
+    categories a SNP carries (Snp::categ_map_) and with what weight.  Returns the fields of the reference's output
+    row; for df = 0 the reference leaves chisq / p-values at their constructor value -1 and never sets the names.
+    """
+    corg = np.asarray(corg, dtype=np.float64)
+    z = np.asarray(z, dtype=np.float64)
+    info = np.asarray(info, dtype=np.float64)
+    has = np.asarray(has).astype(bool)
+    wgt = np.asarray(wgt, dtype=np.float64)
+    n = len(z)
+    # categories present in the gene, in category-number order (categ_count_vec_, categ_vec_: gene.cpp:152-166)
+    cats = [c for c in range(6) if has[:, c].any()]
+    k = len(cats)
+    out = dict(num_snp=n, df=0, chisq=-1.0, jepeg_pval=-1.0, top_categ=-1, top_categ_pval=-1.0, top_snp=-1, top_snp_pval=-1.0)
+    if k == 0 or n == 0:
+        return out
+    # W[c][s] = GetCategWgt(s, c) * sqrt(info_s); a SNP without the category contributes 0 (snp.cpp:37-43)
+    W = np.where(has[:, cats], wgt[:, cats], 0.0).T * np.sqrt(info)[None, :]
+    WWt = W @ W.T
+    CovU = W @ corg @ W.T
+    sd = np.sqrt(np.diag(CovU))
+    with np.errstate(invalid="ignore", divide="ignore"):
+        CorU = CovU / (sd[:, None] * sd[None, :])
+        U = W @ z
+        pv = 2.0 * stats.norm.sf(np.abs(U / sd))
+    rmv = np.zeros(k, dtype=bool)
+    for j in range(k - 1, 0, -1):                      # from the last category down to the second (gene.cpp:391-399)
+        if np.any(np.abs(CorU[:j, j]) > categ_cor_cutoff):
+            rmv[j] = True
+    rmv |= np.diag(CovU) < np.diag(WWt) / denorm_norm_w  # low variance (gene.cpp:408-414)
+    df = int(k - rmv.sum())
+    out["df"] = df
+    if df == 0:
+        return out
+    keep = ~rmv
+    X = U[keep]
+    CovX = CovU[np.ix_(keep, keep)]
+    vals, vecs = np.linalg.eigh(CovX)                   # MakePosDef (util.cpp:302-318)
+    if vals.min() < min_abs_eig:
+        CovX = (vecs * np.maximum(vals, min_abs_eig)) @ vecs.T
+    out["chisq"] = float(X @ np.linalg.inv(CovX) @ X)
+    out["jepeg_pval"] = float(stats.chi2.sf(out["chisq"], df))
+    top = 0                                             # GetTopCateg starts at index 0 even if that category was removed
+    for i in range(k):
+        if (pv[top] > pv[i]) and not rmv[i]:
+            top = i
+    out["top_categ"], out["top_categ_pval"] = cats[top], float(pv[top])
+    ts = 0                                              # GetTopSNP: first SNP with the largest |z|
+    for i in range(n):
+        if abs(z[ts]) < abs(z[i]):
+            ts = i
+    out["top_snp"], out["top_snp_pval"] = ts, float(2.0 * stats.norm.sf(abs(z[ts])))
+    return out
+
+
 def pnorm_upper(x):
     return stats.norm.sf(x)
 

@@ -384,3 +384,56 @@ def test_randomized_kinds_and_sources_against_oracle(ctx):
                 assert np.array_equal(np.isnan(got["b21"]), nan)
                 assert np.max(np.abs(got["b11"] - want["b11"])) <= 1e-12
                 assert nan.all() or np.max(np.abs(got["b21"][~nan] - want["b21"][~nan])) <= 1e-12
+
+
+@pytest.mark.parametrize("mode,pop_names", [(1, None), (0, ["GBR"])])
+def test_full_size_gene_ld_batch(ctx, mode, pop_names):
+    """BASELINE.json configs[4] at its real size: ~350 genes with 1-20 SNPs each (3 700 gene SNPs), jepegmix on the 21
+    PGC2 populations (N = 32 147, weighted LD) and jepeg on GBR (N = 2 020, pooled Pearson): gene blocks against the
+    whole-matrix LD of the same rows (bit for bit), structural properties, and oracle spot checks of single entries."""
+    if pop_names is None:
+        pops = [p for p in synth.POPS_33KG if p[0] in synth.PGC2_WEIGHTS]
+        w = np.array([synth.PGC2_WEIGHTS[p[0]] for p in pops])
+    else:
+        pops = [p for p in synth.POPS_33KG if p[0] in pop_names]
+        w = None
+    off = synth.pop_offsets([p[1] for p in pops])
+    N = int(off[-1])
+    assert N == (32147 if mode else 2020)
+    rng = np.random.default_rng(5 + mode)
+    sizes = rng.integers(1, 21, size=350)
+    S = int(sizes.sum())
+    gene_off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    base = rand_geno(rng, 200, N)
+    G = base[rng.integers(0, 200, size=S)].copy()
+    noise = rng.random(G.shape) < 0.3
+    G[noise] = rand_geno(rng, 1, N)[0][np.nonzero(noise)[1]]
+    G = np.ascontiguousarray(G)
+    diag = 1.1
+    blocks = hotpath.gene_ld_batch(G, off, gene_off, pop_wgt=w, mode=mode, diag=diag, ctx=ctx)
+    assert len(blocks) == 350
+    for g, b in enumerate(blocks):
+        n = sizes[g]
+        assert b.shape == (n, n) and np.array_equal(b, b.T) and np.all(np.diag(b) == diag)
+        assert np.all(np.isfinite(b)) and np.all(np.abs(b - np.diag(np.diag(b))) <= 1 + 1e-12)
+    # the same entries as the full LD matrix of a stretch of rows (one launch, all tile pairs)
+    r0, r1 = int(gene_off[40]), int(gene_off[75])
+    full = hotpath.ld_matrix(G[r0:r1], off, w, mode=mode, diag=diag, ctx=ctx)
+    for g in range(40, 75):
+        a, b = int(gene_off[g]) - r0, int(gene_off[g + 1]) - r0
+        assert np.array_equal(blocks[g], full[a:b, a:b])
+    # oracle spot checks (loop-literal pair functions)
+    def entry(i, j):
+        if mode == 0:
+            return oracle.calcor(G[i], G[j], off)
+        sd = lambda r: np.sqrt(oracle.calwgtcov(r, r, off, w))
+        return oracle.calwgtcov(G[i], G[j], off, w) / (sd(G[i]) * sd(G[j]))
+    checked = 0
+    for g in rng.choice(350, size=12, replace=False):
+        n = sizes[g]
+        if n < 2:
+            continue
+        i, j = sorted(rng.choice(n, size=2, replace=False))
+        assert abs(blocks[g][i, j] - entry(gene_off[g] + i, gene_off[g] + j)) <= 1e-13
+        checked += 1
+    assert checked >= 6

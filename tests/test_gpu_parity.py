@@ -423,3 +423,31 @@ def test_shift_certificate_never_changes_the_answer(ctx, wscale, lam):
     tol = 1e-5 if want["mpd"] else 1e-8
     assert relerr(got["info"], want["info"]) <= tol
     assert np.max(np.abs(got["z"] - want["z"]) / np.maximum(1.0, np.abs(want["z"]))) <= tol
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_ld_and_gene_batches_over_row_stores_equal_the_byte_calls(ctx, mode):
+    """gauss_ld_rows / gauss_gene_ld_batch_rows (what computeLD / jepeg use on a packed panel: rows named in a host
+    or resident store, 2-bit or one byte per genotype) must return the bits of gauss_ld / gauss_gene_ld_batch."""
+    from gauss_amd import panel
+    p = small_panel(n_snp=260, scale=0.03, seed=77)
+    G, off, w = p["G"], p["off"], p["w"]
+    S = G.shape[0]
+    rng = np.random.default_rng(3)
+    pick = np.sort(rng.choice(S, size=150, replace=False)).astype(np.int32)
+    cuts = np.concatenate([[0], np.sort(rng.choice(np.arange(1, 150), size=30, replace=False)), [150]]).astype(np.int32)
+    diag = 1.1 if mode == 0 else 1.0
+    want_ld = hotpath.ld_matrix(np.ascontiguousarray(G[pick]), off, w, mode=mode, diag=diag, ctx=ctx)
+    want_blocks = hotpath.gene_ld_batch(np.ascontiguousarray(G[pick]), off, cuts, pop_wgt=w, mode=mode, diag=diag, ctx=ctx)
+    rows2, src_off = panel.pack2bit(G, off)
+    stores = [("2-bit host", np.ascontiguousarray(rows2), 1, src_off), ("u8 host", np.ascontiguousarray(G), 0, None)]
+    res = hotpath.RowStore(rows2, ctx=ctx)
+    stores.append(("2-bit resident", res, 1, src_off))
+    for name, st, fmt, so in stores:
+        got = hotpath.ld_matrix_rows(st, pick, off, w, mode=mode, diag=diag, fmt=fmt, pop_src_off=so, ctx=ctx)
+        assert np.array_equal(got, want_ld), name
+        blocks = hotpath.gene_ld_batch_rows(st, pick, off, cuts, pop_wgt=w, mode=mode, diag=diag, fmt=fmt, pop_src_off=so, ctx=ctx)
+        assert len(blocks) == len(want_blocks) and all(np.array_equal(a, b) for a, b in zip(blocks, want_blocks)), name
+    res.close()
+    want = oracle.compute_ld(G[pick], off, w) if mode == 1 else oracle.ld_pooled(G[pick], off, diag)
+    assert np.max(np.abs(want_ld - want)) <= 1e-12

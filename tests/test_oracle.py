@@ -124,60 +124,70 @@ def test_tails_match_scipy():
     assert abs(oracle.pchisq_upper(38.41841, 1) / stats.chi2.sf(38.41841, 1) - 1) <= 1e-10
 
 
-def _jepeg_tail_np(corg, z, info, has, wgt, min_abs_eig=1e-5, cutoff=0.8, denorm=3):
-    """Independent numpy restatement of gene.cpp:317-550 for the cross-check."""
-    cats = [c for c in range(6) if has[:, c].any()]
-    k = len(cats)
-    W = (wgt[:, cats] * np.sqrt(info)[:, None]).T
-    WWt = W @ W.T
-    CovU = W @ corg @ W.T
-    d = np.sqrt(np.diag(CovU))
-    CorU = CovU / np.outer(d, d)
-    U = W @ z
-    pvals = 2 * stats.norm.sf(np.abs(U / d))
-    rmv = np.zeros(k, dtype=bool)
-    for j in range(k - 1, 0, -1):
-        if np.any(np.abs(CorU[:j, j]) > cutoff):
-            rmv[j] = True
-    rmv |= np.diag(CovU) < np.diag(WWt) / denorm
-    df = int(k - rmv.sum())
-    out = dict(df=df, chisq=-1.0, jepeg_pval=-1.0)
-    if df:
-        X = U[~rmv]
-        CovX, _ = onp.make_pos_def(CovU[np.ix_(~rmv, ~rmv)], min_abs_eig)
-        out["chisq"] = float(X @ np.linalg.inv(CovX) @ X)
-        out["jepeg_pval"] = float(stats.chi2.sf(out["chisq"], df))
-        top = 0
-        for i in range(k):
-            if pvals[top] > pvals[i] and not rmv[i]:
-                top = i
-        out["top_categ"] = cats[top]
-        out["top_categ_pval"] = float(pvals[top])
-        out["top_snp"] = int(np.argmax(np.abs(z)))
-    return out
+def _random_gene(rng, p, n):
+    rows = p["G"][rng.choice(p["G"].shape[0], n, replace=False)]
+    corg = oracle.ld_pooled(rows, p["off"], 1.1)
+    z = rng.standard_normal(n) * 2
+    info = np.where(rng.random(n) < 0.3, rng.uniform(0.3, 1.0, n), 1.0)     # imputed SNPs carry info < 1 (gene.cpp:871)
+    has = (rng.random((n, 6)) < 0.35).astype(np.int32)
+    has[rng.integers(0, n), rng.integers(0, 6)] = 1
+    wgt = np.where(has, rng.uniform(0.1, 2.0, (n, 6)), 0.0)
+    return corg, z, info, has, wgt
 
 
-def test_jepeg_gene_tail_c_vs_numpy():
+def _same_tail(a, b):
+    assert a["df"] == b["df"] and a["num_snp"] == b["num_snp"]
+    if b["df"]:
+        assert abs(a["chisq"] - b["chisq"]) <= 1e-9 * max(1.0, abs(b["chisq"]))
+        assert abs(a["jepeg_pval"] - b["jepeg_pval"]) <= 1e-9 * b["jepeg_pval"] + 1e-300
+        assert a["top_categ"] == b["top_categ"] and a["top_snp"] == b["top_snp"]
+        assert abs(a["top_categ_pval"] - b["top_categ_pval"]) <= 1e-9 * b["top_categ_pval"] + 1e-300
+        assert abs(a["top_snp_pval"] - b["top_snp_pval"]) <= 1e-9 * b["top_snp_pval"] + 1e-300
+    else:
+        assert a["chisq"] == -1.0 and a["jepeg_pval"] == -1.0 and a["top_categ"] == -1 and a["top_snp"] == -1
+
+
+def test_jepeg_gene_tail_c_oracle_and_product_host_tail_vs_independent_numpy():
+    """Three statements of gene.cpp:317-550 must agree: the C oracle (loop-literal), the product's host tail
+    (gauss_host.cpp:jepeg_tail, reached through gauss_host_jepeg_gene_tail, no GPU) and the independent numpy /
+    LAPACK / scipy statement in oracle_np.py that was written from the reference alone.  Cases include collinear
+    categories (|r| > 0.8 pruning from the last category down), low-variance categories, imputed SNPs (info < 1),
+    genes whose every category is pruned (df = 0) and single-SNP genes."""
+    from gauss_amd import api
     rng = np.random.default_rng(3)
     p = small_panel(n_snp=40, scale=0.02, n_pops=5)
-    for trial in range(20):
-        n = int(rng.integers(1, 12))
-        rows = p["G"][rng.choice(p["G"].shape[0], n, replace=False)]
-        corg = oracle.ld_pooled(rows, p["off"], 1.1)
-        z = rng.standard_normal(n) * 2
-        info = np.ones(n)
-        has = (rng.random((n, 6)) < 0.35).astype(np.int32)
-        has[rng.integers(0, n), rng.integers(0, 6)] = 1
-        wgt = np.where(has, rng.uniform(0.1, 2.0, (n, 6)), 0.0)
-        a = oracle.jepeg_gene_tail(corg, z, info, has, wgt)
-        b = _jepeg_tail_np(corg, z, info, has, wgt)
-        assert a["df"] == b["df"] and a["num_snp"] == n
-        if b["df"]:
-            assert abs(a["chisq"] - b["chisq"]) <= 1e-9 * max(1.0, abs(b["chisq"]))
-            assert abs(a["jepeg_pval"] - b["jepeg_pval"]) <= 1e-9 * b["jepeg_pval"] + 1e-300
-            assert a["top_categ"] == b["top_categ"] and a["top_snp"] == b["top_snp"]
-        else:
-            assert a["chisq"] == -1.0 and a["jepeg_pval"] == -1.0 and a["top_categ"] == -1
+    seen_df0 = seen_pruned = 0
+    for trial in range(60):
+        n = int(rng.integers(1, 14))
+        corg, z, info, has, wgt = _random_gene(rng, p, n)
+        if trial % 5 == 1 and n >= 2:          # make two categories collinear: identical membership and weights
+            has[:, 3], wgt[:, 3] = has[:, 1], wgt[:, 1]
+            if not has[:, 1].any():
+                has[0, 1] = has[0, 3] = 1
+                wgt[0, 1] = wgt[0, 3] = 0.7
+        if trial % 7 == 2:                      # a category carried by one weakly informative SNP: low variance
+            has[:, 5] = 0
+            has[0, 5] = 1
+            wgt[:, 5] = 0.0
+            wgt[0, 5] = 1.0
+            info[0] = 0.05
+        want = onp.jepeg_gene_tail(corg, z, info, has, wgt)
+        _same_tail(oracle.jepeg_gene_tail(corg, z, info, has, wgt), want)
+        _same_tail(api.jepeg_gene_tail(corg, z, info, has, wgt), want)
+        k = int(has.any(0).sum())
+        seen_df0 += want["df"] == 0
+        seen_pruned += 0 < want["df"] < k
+    assert seen_pruned >= 5                     # the pruning branches were really exercised
+
+
+def test_count_pc_c_vs_numpy():
+    p = small_panel(n_snp=50, scale=0.02, n_pops=4, seed=12)
+    gm = np.vstack([p["G"][:30], p["G"][:6]])                 # duplicated SNPs: eigenvalues at lambda exactly
+    for lam in (0.0, 0.005, 0.1):
+        b11 = onp.pooled_cor(gm)
+        np.fill_diagonal(b11, 1.0 + lam)
+        assert oracle.count_pc(b11) == onp.count_pc(b11)
+    assert onp.count_pc(b11) == len(gm)
 
 
 def test_gram_counts_match_numpy():
