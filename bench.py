@@ -103,6 +103,8 @@ class Rig:
             # RCCL ("nccl" on ROCm); used for the timing barriers and a few scalar reductions only
             dist.init_process_group("gloo" if self.rehearsal else "nccl", rank=self.rank, world_size=self.world)
             self.dist = dist
+            # python objects (window lists, digests, result tables) travel over a gloo group: host data, host transport
+            self.obj_group = None if self.rehearsal else dist.new_group(backend="gloo")
         self.red_dev = "cpu" if (self.rehearsal or self.world == 1) else "cuda"
         self.ctx = hotpath.Context(self.local)
 
@@ -123,7 +125,7 @@ class Rig:
         if self.dist is None:
             return [obj]
         out = [None] * self.world
-        self.dist.all_gather_object(out, obj)
+        self.dist.all_gather_object(out, obj, group=self.obj_group)
         return out
 
     def close(self):

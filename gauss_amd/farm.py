@@ -96,6 +96,32 @@ def gpu_compute(prepared_list, ctx=None, resident=True, timings=None):
     return [p.finish() for p in prepared_list]
 
 
+def impute_chromosome_native(kind, chr, start_bp, end_bp, wing_size, input_file, reference_data_file, reference_pop_desc_file,
+                             study_pop=None, pop_wgt_df=None, af1_cutoff=None, window_size=1_000_000, group=None, ctx=None,
+                             n_batches=0):
+    """The farm on a PACKED panel, natively: every rank makes ONE call into libgauss_host
+    (gauss_host_impute_chromosome: the same LPT plan on every rank, this rank's windows pipelined through its GPU in
+    batches against the resident panel), then the ranks' column arrays are gathered on rank 0 and merged in window
+    order.  Returns an api.ChromResult on rank 0 (or the single process), None elsewhere."""
+    dist, rank, world = None, 0, 1
+    try:
+        import torch.distributed as dist_mod
+        if dist_mod.is_available() and dist_mod.is_initialized():
+            dist = dist_mod
+            rank, world = dist.get_rank(group), dist.get_world_size(group)
+    except ImportError:     # pragma: no cover
+        pass
+    ctx = ctx or hotpath.default_context()          # this rank's own device (LOCAL_RANK)
+    res = api.impute_chromosome(kind, chr, start_bp, end_bp, wing_size, input_file, reference_data_file, reference_pop_desc_file,
+                                study_pop=study_pop, pop_wgt_df=pop_wgt_df, af1_cutoff=af1_cutoff, window_size=window_size,
+                                rank=rank, world=world, n_batches=n_batches, ctx=ctx)
+    if dist is None or world == 1:
+        return res
+    parts = [None] * world if rank == 0 else None
+    dist.gather_object(res, parts, dst=0, group=group)
+    return api.ChromResult.merge(parts) if rank == 0 else None
+
+
 def impute_chromosome(kind, chr, start_bp, end_bp, wing_size, input_file, reference_index_file, reference_data_file,
                       reference_pop_desc_file, study_pop=None, pop_wgt_df=None, af1_cutoff=None,
                       window_size=1_000_000, compute=gpu_compute, group=None, threads=None, timings=None):
