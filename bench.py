@@ -63,6 +63,9 @@ def parse_args(argv=None):
     ap.add_argument("--verify-shards", action="store_true",
                     help="N > 1, strong: rank 0 also runs every window itself and checks the ranks' z / info bit for bit")
     ap.add_argument("--no-e2e", action="store_true", help="N = 1: skip the end_to_end block (files on disk -> result table)")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="single GPU: time every rank's LPT share of an N-rank strong-scaling run one after the other "
+                         "(what one rank of N would do per step); printed as `emulated_strong_scaling`, never as `value`")
     ap.add_argument("--streams", type=int, default=1, help="split a rank's windows over this many jobs/streams")
     return ap.parse_args(argv)
 
@@ -335,6 +338,27 @@ def run_impute(args, rig):
                 "workload": "the whole chromosome on every rank"}
         wr.close()
 
+    emu = None
+    if rig.world == 1 and args.emulate_world > 1:
+        own_e, load_e = workload.shard(wins, N, args.emulate_world)
+        per_rank = []
+        for r in range(args.emulate_world):
+            wr = [wins[k] for k in range(len(wins)) if own_e[k] == r]
+            rr = Runner(rig, window_descs(ch, wr, store, ld2, args.mode), 1)
+            dtr, str_, _ = rr.timed(args.steps, max(1, args.warmup))
+            per_rank.append({"rank": r, "windows": len(wr), "ms_per_step": dtr / args.steps * 1e3,
+                             "stage_ms": {k: v[0] / args.steps for k, v in str_.items()},
+                             "gram_frac_of_peak": (rr.work["ld_flops"] / (str_["gram"][0] / max(1, str_["gram"][1]) * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS)
+                             if str_["gram"][0] > 0 else 0.0})
+            rr.close()
+        slow = max(q["ms_per_step"] for q in per_rank)
+        emu = {"world": args.emulate_world, "per_rank": per_rank, "slowest_rank_ms": slow,
+               "one_gpu_ms": dt / args.steps * 1e3, "predicted_speedup": dt / args.steps * 1e3 / slow,
+               "predicted_efficiency": dt / args.steps * 1e3 / slow / args.emulate_world,
+               "lpt_load_imbalance": max(load_e) / (sum(load_e) / len(load_e)),
+               "note": "each rank's share timed alone on ONE GPU, one after the other: an emulation of the per-rank step time, "
+                       "not a multi-GPU measurement (no 8-GPU node is available to the builder)"}
+
     e2e = None
     if rig.world == 1 and args.mode == "distmix" and not args.no_e2e and not args.windows and args.streams == 1:
         runner.close()
@@ -410,6 +434,8 @@ def run_impute(args, rig):
             out["weak_scaling"] = weak
         if i8_variant is not None:
             out["int8_exact_variant"] = i8_variant
+        if emu is not None:
+            out["emulated_strong_scaling"] = emu
         if e2e is not None:
             out["end_to_end"] = e2e
         if keep0 is not None:

@@ -184,6 +184,7 @@ struct gauss_job {
     int2* d_tilemap = nullptr;  int n_tiles = 0;
     int2* d_panelmap = nullptr; int n_panels = 0;
     int max_nblk = 0;
+    int max_npanel = 0;                                    // most solve panels of any one window
     int max_pop = 1;
     int gram_i8 = 0;
     int* d_status = nullptr;                               // [n][4]
@@ -525,7 +526,7 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
         if (!p.n_gene)
             for (int pr = 0; pr < p.npair; pr++) tilemap.push_back(make_int2(i, pr));
         for (int pn = 0; pn < p.npanel; pn++) panelmap.push_back(make_int2(i, pn));
-        if (p.npanel > 0) job->max_nblk = std::max(job->max_nblk, p.nblk);
+        if (p.npanel > 0) { job->max_nblk = std::max(job->max_nblk, p.nblk); job->max_npanel = std::max(job->max_npanel, p.npanel); }
         if (p.mode != 0) job->max_pop = std::max(job->max_pop, p.P);
     }
     // longest segments first: the tail of the launch is then made of short items
@@ -563,7 +564,7 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
 
     // ---- workspace arena ----
     Arena wa;
-    struct WsOff { size_t raw_m, raw_u, packed, sx, sxx, slab, sd, wm, mu, wmu, A, Linv, B21, V, ld, b11c; long long ldraw; };
+    struct WsOff { size_t raw_m, raw_u, packed, sx, sxx, slab, sd, wm, mu, wmu, A, Linv, B21, V, ld, b11c, sacc; long long ldraw; };
     std::vector<WsOff> wo(job->n);
     size_t res = 0;
     for (int i = 0; i < job->n; i++) {
@@ -597,6 +598,7 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
         if (p.npanel > 0) {
             w.Linv = wa.take((size_t)2 * p.nblk * NB * NB * sizeof(double));
             w.V = wa.take((size_t)p.npanel * p.Mld * NR * sizeof(double));
+            w.sacc = wa.take((size_t)p.npanel * 768 * sizeof(double));
             w.b11c = wa.take((size_t)p.Mld * p.Mld * sizeof(double));
         }
         w.ld = wa.take(std::max<size_t>(pl.out_ld_count, 1) * sizeof(double));
@@ -666,7 +668,7 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
         p.z1 = (const double*)(T + to[i].z1);
         if (!p.ld_only) { p.A = (double*)(W + w.A); p.B21 = (double*)(W + w.B21); }
         if (p.npanel > 0) {
-            p.Linv = (double*)(W + w.Linv); p.V = (double*)(W + w.V);
+            p.Linv = (double*)(W + w.Linv); p.V = (double*)(W + w.V); p.Sacc = (double*)(W + w.sacc);
             pl.d_b11_copy = (double*)(W + w.b11c);
         }
         p.out_z = job->d_results + pl.res_off;
@@ -788,11 +790,16 @@ static int job_run(gauss_job* job, bool solve)
             if (pl.out_b11 && pl.p.npanel > 0)
                 HIPCHK(hipMemcpyAsync(pl.d_b11_copy, pl.p.A, sizeof(double) * pl.p.Mld * pl.p.Mld, hipMemcpyDeviceToDevice, st));
         }
+        // fused (default): the solve's block rows ride in the factorisation's update launches (k_solve.hip); the stage
+        // timers then read "factor" = factorisation + all solve rows but the last, "solve" = the closing launch
+        static const bool fused = !(getenv("GAUSS_FUSED_SOLVE") && atoi(getenv("GAUSS_FUSED_SOLVE")) == 0);
         prof_begin(job, 3);
-        for (int s = 0; s < job->max_nblk; s++) launch_factor_step(job->d_probs, job->n, s, job->max_nblk, st);
+        for (int s = 0; s < job->max_nblk; s++)
+            launch_factor_step(job->d_probs, job->n, s, job->max_nblk, fused ? job->max_npanel : 0, st);
         prof_end(job);
         prof_begin(job, 4);
-        launch_solve(job->d_probs, job->d_panelmap, job->n_panels, st);
+        if (fused) launch_solve_last(job->d_probs, job->d_panelmap, job->n_panels, job->max_nblk, st);
+        else launch_solve(job->d_probs, job->d_panelmap, job->n_panels, st);
         prof_end(job);
     }
     HIPCHK(hipGetLastError());
@@ -835,7 +842,7 @@ static int job_clamp_window(gauss_job* job, int i, int* status_bits)
     HIPCHK(hipMemcpyAsync(p.A + 4 * n * n, p.A, sizeof(double) * n * n, hipMemcpyDeviceToDevice, st));   // W0 = clamped B11
     for (int s = 0; s < p.nblk; s++) {
         // launch over all problems would redo the others; use a single-problem launch instead
-        launch_factor_step(job->d_probs + i, 1, s, p.nblk, st);
+        launch_factor_step(job->d_probs + i, 1, s, p.nblk, 0, st);
     }
     launch_solve(job->d_probs, d_pm.as<int2>(), (int)pm.size(), st);
     HIPCHK(hipGetLastError());

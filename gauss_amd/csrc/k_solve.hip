@@ -19,6 +19,7 @@
 // rows (lane>>4) + 4*reg, column lane&15).  A workgroup is 4 waves; wave w owns rows 16w..16w+15
 // of a 64-row block.
 #include "gauss_internal.h"
+#include <algorithm>
 #include <cstdlib>
 
 namespace gauss {
@@ -361,6 +362,170 @@ __device__ __forceinline__ GP(double) factor_work(const Prob& pb, int mat)
 }
 
 // ------------------------------------------------------------------------------------------
+// K6/K7: forward substitution for one panel of NR right-hand sides (NR - 1 unmeasured SNPs'
+// b21 rows + the z1 column), left-looking over the 64-blocks of L, then z / info.
+//   V_k = Linv_kk * (B_k - sum_{j<k} L_kj V_j)
+// V blocks live in the problem's V scratch ([panel][Mld][NR]) for reuse by later block rows.
+//
+// Two drivers run the same row routine (identical arithmetic, identical results):
+//   * fused (default): block row k of every panel rides in the factorisation's update(k) launch -- it needs
+//     L[k][0..k-1] (finished by panel(k-1)), Linv_kk (finished by update(k-1)) and V[0..k-1] (earlier launches), all
+//     of which are complete when update(k) starts.  The solve's chain of k products per row then hides behind the
+//     tile Cholesky on the factorisation's critical path instead of following it; the per-thread partial sums of
+//     z / info cross the launches through a small scratch (pb.Sacc).  solve_last_kernel finishes the windows whose
+//     last row has no update launch (nblk == max_nblk).
+//   * solve_kernel: all rows of a panel in one workgroup (single-window redo of the clamp path, GAUSS_FUSED_SOLVE=0).
+// ------------------------------------------------------------------------------------------
+constexpr int SOLVE_NT = NR / 16;              // accumulator tiles (16 columns each) per wave
+constexpr int SOLVE_NG = 256 / NR;             // row groups of the z / info reduction
+constexpr int SOLVE_RG = NB / SOLVE_NG;        // rows per group
+static const size_t SOLVE_SMEM = ((size_t)NB * LDT + (size_t)NB * LDV + 768) * sizeof(double);
+
+struct SolveSums { double z, info, v; };       // per-thread partial sums: column tid % NR, rows of group tid / NR
+
+// block row kb of one panel; TL / TV are the workgroup's LDS tiles
+__device__ __forceinline__ void solve_row(const Prob& pb, int panel, int kb, double* __restrict__ TL, double* __restrict__ TV,
+                                          SolveSums& sums, int tid)
+{
+    constexpr int NT = SOLVE_NT;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int ld = pb.Mld;
+    const auto Lm = pb.A + (size_t)2 * ld * ld;               // factor of A[0]
+    const auto Linv = pb.Linv;                                // matrix 0
+    const auto V = pb.V + (size_t)panel * ld * NR;
+    const int u0 = panel * NRU;
+    const bool qcat = pb.kind == WIN_QCAT;
+    const int n_predm = pb.n_predm;
+    // QCAT right-hand sides (qcat.cpp:216-243): first the B11 columns of the tested measured SNPs
+    // (rows n_head .. of the symmetric A[0], which the factorisation leaves intact), then the B21 rows
+    const auto Brow = pb.A + (size_t)pb.n_head * ld;
+    const int cc = tid % NR, rg = tid / NR;
+
+    f64x4 acc[NT];
+#pragma unroll
+    for (int n = 0; n < NT; n++) acc[n] = f64x4{0.0, 0.0, 0.0, 0.0};
+    TileRegs rl, rv[NR / 64];
+    if (kb > 0) {
+        tile_fetch(rl, Lm + (size_t)kb * NB * ld, ld, tid);
+#pragma unroll
+        for (int h = 0; h < NR / 64; h++) tile_fetch(rv[h], V + 64 * h, NR, tid);
+    }
+    for (int jb = 0; jb < kb; jb++) {
+        __syncthreads();                                  // previous tiles are no longer being read
+        tile_commit<LDT>(TL, rl, tid);
+#pragma unroll
+        for (int h = 0; h < NR / 64; h++) tile_commit<LDV>(TV + 64 * h, rv[h], tid);
+        __syncthreads();
+        if (jb + 1 < kb) {                                // next tiles fly during the product
+            tile_fetch(rl, Lm + (size_t)kb * NB * ld + (size_t)(jb + 1) * NB, ld, tid);
+#pragma unroll
+            for (int h = 0; h < NR / 64; h++) tile_fetch(rv[h], V + (size_t)(jb + 1) * NB * NR + 64 * h, NR, tid);
+        }
+        mfma_nn<NT, true>(acc, TL, TV, wave, lane);       // acc = - sum_j L_kj V_j
+    }
+    __syncthreads();
+    // TV <- rhs block: column c < NRU: B21[u0+c][kb*64 + r]; column NRU: z1 (zero padded)
+    for (int e = tid; e < NB * NR; e += 256) {
+        const int c = e >> 6, r = e & 63;                 // r fastest: coalesced along a B21 row
+        const int k = kb * NB + r;
+        double v = 0.0;
+        if (c < NRU) {
+            const int u = u0 + c;
+            if (qcat && u < n_predm) v = Brow[(size_t)u * ld + k];
+            else if (u - (qcat ? n_predm : 0) < pb.U) v = pb.B21[(size_t)(u - (qcat ? n_predm : 0)) * ld + k];
+        }
+        else if (k < pb.M) v = pb.z1[k];
+        TV[r * LDV + c] = v;
+    }
+    {
+        const auto Li = Linv + (size_t)kb * NB * NB;
+        for (int e = tid; e < NB * NB; e += 256) TL[(e >> 6) * LDT + (e & 63)] = Li[e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < NT; n++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) TV[acc_row(wave, lane, r) * LDV + acc_col(lane, n)] += acc[n][r];
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < NT; n++) acc[n] = f64x4{0.0, 0.0, 0.0, 0.0};
+    mfma_nn<NT, false>(acc, TL, TV, wave, lane);          // V_k = Linv_kk * X
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < NT; n++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = acc_row(wave, lane, r), col = acc_col(lane, n);
+            TV[row * LDV + col] = acc[n][r];
+            V[(size_t)(kb * NB + row) * NR + col] = acc[n][r];
+        }
+    __syncthreads();
+    // accumulate z and info for column cc over this block's rows RG rg .. RG rg + RG - 1
+#pragma unroll
+    for (int r = 0; r < SOLVE_RG; r++) {
+        const double x = TV[(rg * SOLVE_RG + r) * LDV + cc];
+        const double y = TV[(rg * SOLVE_RG + r) * LDV + NRU];
+        sums.z = fma(x, y, sums.z);
+        sums.info = fma(x, x, sums.info);
+        sums.v += x;
+    }
+}
+
+// after the last block row: combine the per-thread sums and write z / info (or the QCAT correlation)
+__device__ __forceinline__ void solve_finish(const Prob& pb, int panel, double* __restrict__ red, const SolveSums& sums, int tid)
+{
+    constexpr int NG = SOLVE_NG;
+    const int u0 = panel * NRU;
+    const bool qcat = pb.kind == WIN_QCAT;
+    __syncthreads();
+    red[tid] = sums.z;
+    red[256 + tid] = sums.info;
+    red[512 + tid] = sums.v;
+    __syncthreads();
+    if (tid < NRU) {
+        double z = 0.0, info = 0.0;
+        for (int g = 0; g < NG; g++) { z += red[g * NR + tid]; info += red[256 + g * NR + tid]; }
+        const int u = u0 + tid;
+        if (qcat) {
+            // r = CalCor(Linv z1, Linv b)  (util.cpp:72-101; qcat.cpp:221,239), vectors of length M
+            double sv = 0.0, sy = 0.0, syy = 0.0;
+            for (int g = 0; g < NG; g++) {
+                sv += red[512 + g * NR + tid];
+                sy += red[512 + g * NR + NRU];
+                syy += red[256 + g * NR + NRU];
+            }
+            if (u < pb.n_rhs) {
+                const double n = (double)pb.M;
+                const double mx = sy / n, mv = sv / n;
+                const double cxx = syy - n * mx * mx;
+                const double cvv = info - n * mv * mv;
+                const double cxv = z - n * mx * mv;
+                pb.out_z[u] = cxv / sqrt(cxx * cvv);
+                pb.out_info[u] = cvv;
+            }
+        } else if (u < pb.U) {
+            info = fabs(info);                         // dist.cpp:198
+            pb.out_z[u] = z / sqrt(info);              // dist.cpp:200
+            pb.out_info[u] = info;                     // dist.cpp:202
+        }
+    }
+}
+
+// one block row of one panel inside a multi-launch solve: the partial sums travel through pb.Sacc [panel][3][256]
+__device__ __forceinline__ void solve_row_fused(const Prob& pb, int panel, int kb, double* __restrict__ smem, int tid)
+{
+    double* TL = smem;
+    double* TV = TL + NB * LDT;
+    double* red = TV + NB * LDV;
+    const auto S = pb.Sacc + (size_t)panel * 768;
+    SolveSums sums{0.0, 0.0, 0.0};
+    if (kb > 0) { sums.z = S[tid]; sums.info = S[256 + tid]; sums.v = S[512 + tid]; }
+    solve_row(pb, panel, kb, TL, TV, sums, tid);
+    if (kb == pb.nblk - 1) solve_finish(pb, panel, red, sums, tid);
+    else { S[tid] = sums.z; S[256 + tid] = sums.info; S[512 + tid] = sums.v; }
+}
+
+// ------------------------------------------------------------------------------------------
 // Certificate that the shifted factorisation is not needed.  MakePosDef (util.cpp:302-318) / CountPC
 // (util.cpp:355-388) act only if lambda_min(B11) < eps, and B11 = R + lambda I with R the LD matrix in exact
 // arithmetic plus rounding noise E, |E|_2 <= M * 1e-15.  For the pooled estimator R is a Gram matrix of
@@ -476,7 +641,7 @@ __global__ __launch_bounds__(256) void factor_panel_kernel(const Prob* __restric
 }
 
 // update(s): grid.x = T (T + 1) / 2 with T = max_nblk - 1 - s; x = 0 is tile (s+1, s+1)
-__global__ __launch_bounds__(256) void factor_update_kernel(const Prob* __restrict__ probs, int s, int T)
+__global__ __launch_bounds__(256) void factor_update_kernel(const Prob* __restrict__ probs, int s, int T, int n_tri)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* TA = smem;                 // L[k][s]            | D (next diagonal tile)
@@ -485,6 +650,12 @@ __global__ __launch_bounds__(256) void factor_update_kernel(const Prob* __restri
     const Prob& pb = probs[blockIdx.y >> 1];
     const int mat = blockIdx.y & 1;
     if (pb.ld_only || pb.npanel == 0) return;
+    if ((int)blockIdx.x >= n_tri) {
+        // block row s of the forward solve, one workgroup per right-hand-side panel, riding in this launch
+        const int panel = (int)blockIdx.x - n_tri;
+        if (mat == 0 && panel < pb.npanel && s < pb.nblk) solve_row_fused(pb, panel, s, smem, threadIdx.x);
+        return;
+    }
     if (mat == 1 && pb.status[3]) return;              // certified: lambda_min(B11) > eps
     const int nb = pb.nblk;
     // x -> (jj, kk), 0 <= jj <= kk < T, column-major over the lower triangle: x = 0 is (0, 0)
@@ -535,15 +706,18 @@ __global__ __launch_bounds__(256) void factor_update_kernel(const Prob* __restri
 
 static const size_t FACTOR_SMEM = (size_t)2 * NB * LDT * sizeof(double);
 
-// step 0 factors the first diagonal block; step s >= 1 builds block column s-1 and updates the trailing matrix
-void launch_factor_step(const Prob* d_probs, int n_prob, int step, int max_nblk, hipStream_t st)
+// step 0 factors the first diagonal block; step s >= 1 builds block column s-1 and updates the trailing matrix.
+// max_npanel > 0: the update launch of block column c also carries block row c of the forward solve for every
+// right-hand-side panel (see the K6/K7 notes above); 0: factorisation only.
+void launch_factor_step(const Prob* d_probs, int n_prob, int step, int max_nblk, int max_npanel, hipStream_t st)
 {
     if (n_prob <= 0 || step >= max_nblk) return;
+    const size_t upd_smem = std::max(FACTOR_SMEM, SOLVE_SMEM);
     static std::atomic<unsigned long long> attr_set{0};
     if (first_use_on_device(attr_set)) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(factor_init_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FACTOR_SMEM);
         hipFuncSetAttribute(reinterpret_cast<const void*>(factor_panel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FACTOR_SMEM);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(factor_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FACTOR_SMEM);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(factor_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)upd_smem);
     }
     if (step == 0) {
         static const bool no_cert = getenv("GAUSS_NO_SHIFT_CERT") != nullptr;     // experiment: always run the exact test
@@ -554,17 +728,12 @@ void launch_factor_step(const Prob* d_probs, int n_prob, int step, int max_nblk,
     const int s = step - 1;
     const int T = max_nblk - 1 - s;
     if (T <= 0) return;
+    const int n_tri = T * (T + 1) / 2;
     hipLaunchKernelGGL(factor_panel_kernel, dim3(T, n_prob * 2), dim3(256), FACTOR_SMEM, st, d_probs, s);
-    hipLaunchKernelGGL(factor_update_kernel, dim3(T * (T + 1) / 2, n_prob * 2), dim3(256), FACTOR_SMEM, st, d_probs, s, T);
+    hipLaunchKernelGGL(factor_update_kernel, dim3(n_tri + (max_npanel > 0 ? max_npanel : 0), n_prob * 2), dim3(256), upd_smem, st,
+                       d_probs, s, T, n_tri);
 }
 
-// ------------------------------------------------------------------------------------------
-// K6/K7: forward substitution for one panel of NR right-hand sides (NR - 1 unmeasured SNPs'
-// b21 rows + the z1 column), left-looking over the 64-blocks of L, then z / info.
-// One workgroup per panel; panels are independent (no inter-workgroup traffic).
-//   V_k = Linv_kk * (B_k - sum_{j<k} L_kj V_j)
-// V blocks live in the problem's V scratch ([panel][Mld][NR]) for reuse by later blocks.
-// ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void solve_kernel(const Prob* __restrict__ probs,
                                                     const int2* __restrict__ panelmap)
 {
@@ -572,140 +741,41 @@ __global__ __launch_bounds__(256) void solve_kernel(const Prob* __restrict__ pro
     double* TL = smem;                       // [64][LDT]   L_kj, then Linv_kk
     double* TV = TL + NB * LDT;              // [64][LDV]   V_j, then the rhs block X, then V_k
     double* red = TV + NB * LDV;             // [3][256]
-    constexpr int NT = NR / 16;              // accumulator tiles (16 columns each) per wave
-    constexpr int NG = 256 / NR;             // row groups of the z / info reduction
-    constexpr int RG = NB / NG;              // rows per group
-
     const int2 pm = panelmap[blockIdx.x];
     const Prob& pb = probs[pm.x];
-    const int panel = pm.y;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ld = pb.Mld, nb = pb.nblk;
-    const auto Lm = pb.A + (size_t)2 * ld * ld;               // factor of A[0]
-    const auto Linv = pb.Linv;                                // matrix 0
-    const auto V = pb.V + (size_t)panel * ld * NR;
-    const int u0 = panel * NRU;
-    const bool qcat = pb.kind == WIN_QCAT;
-    const int n_predm = pb.n_predm;
-    // QCAT right-hand sides (qcat.cpp:216-243): first the B11 columns of the tested measured SNPs
-    // (rows n_head .. of the symmetric A[0], which the factorisation leaves intact), then the B21 rows
-    const auto Brow = pb.A + (size_t)pb.n_head * ld;
+    const int tid = threadIdx.x;
+    SolveSums sums{0.0, 0.0, 0.0};
+    for (int kb = 0; kb < pb.nblk; kb++) solve_row(pb, pm.y, kb, TL, TV, sums, tid);
+    solve_finish(pb, pm.y, red, sums, tid);
+}
 
-    const int cc = tid % NR, rg = tid / NR;                   // reduction: column cc, rows RG rg ..
-    double zsum = 0.0, isum = 0.0, vsum = 0.0;
-
-    for (int kb = 0; kb < nb; kb++) {
-        f64x4 acc[NT];
-#pragma unroll
-        for (int n = 0; n < NT; n++) acc[n] = f64x4{0.0, 0.0, 0.0, 0.0};
-        TileRegs rl, rv[NR / 64];
-        if (kb > 0) {
-            tile_fetch(rl, Lm + (size_t)kb * NB * ld, ld, tid);
-#pragma unroll
-            for (int h = 0; h < NR / 64; h++) tile_fetch(rv[h], V + 64 * h, NR, tid);
-        }
-        for (int jb = 0; jb < kb; jb++) {
-            __syncthreads();                                  // previous tiles are no longer being read
-            tile_commit<LDT>(TL, rl, tid);
-#pragma unroll
-            for (int h = 0; h < NR / 64; h++) tile_commit<LDV>(TV + 64 * h, rv[h], tid);
-            __syncthreads();
-            if (jb + 1 < kb) {                                // next tiles fly during the product
-                tile_fetch(rl, Lm + (size_t)kb * NB * ld + (size_t)(jb + 1) * NB, ld, tid);
-#pragma unroll
-                for (int h = 0; h < NR / 64; h++) tile_fetch(rv[h], V + (size_t)(jb + 1) * NB * NR + 64 * h, NR, tid);
-            }
-            mfma_nn<NT, true>(acc, TL, TV, wave, lane);       // acc = - sum_j L_kj V_j
-        }
-        __syncthreads();
-        // TV <- rhs block: column c < NRU: B21[u0+c][kb*64 + r]; column NRU: z1 (zero padded)
-        for (int e = tid; e < NB * NR; e += 256) {
-            const int c = e >> 6, r = e & 63;                 // r fastest: coalesced along a B21 row
-            const int k = kb * NB + r;
-            double v = 0.0;
-            if (c < NRU) {
-                const int u = u0 + c;
-                if (qcat && u < n_predm) v = Brow[(size_t)u * ld + k];
-                else if (u - (qcat ? n_predm : 0) < pb.U) v = pb.B21[(size_t)(u - (qcat ? n_predm : 0)) * ld + k];
-            }
-            else if (k < pb.M) v = pb.z1[k];
-            TV[r * LDV + c] = v;
-        }
-        {
-            const auto Li = Linv + (size_t)kb * NB * NB;
-            for (int e = tid; e < NB * NB; e += 256) TL[(e >> 6) * LDT + (e & 63)] = Li[e];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int n = 0; n < NT; n++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) TV[acc_row(wave, lane, r) * LDV + acc_col(lane, n)] += acc[n][r];
-        __syncthreads();
-#pragma unroll
-        for (int n = 0; n < NT; n++) acc[n] = f64x4{0.0, 0.0, 0.0, 0.0};
-        mfma_nn<NT, false>(acc, TL, TV, wave, lane);          // V_k = Linv_kk * X
-        __syncthreads();
-#pragma unroll
-        for (int n = 0; n < NT; n++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int row = acc_row(wave, lane, r), col = acc_col(lane, n);
-                TV[row * LDV + col] = acc[n][r];
-                V[(size_t)(kb * NB + row) * NR + col] = acc[n][r];
-            }
-        __syncthreads();
-        // accumulate z and info for column cc over this block's rows RG rg .. RG rg + RG - 1
-#pragma unroll
-        for (int r = 0; r < RG; r++) {
-            const double x = TV[(rg * RG + r) * LDV + cc];
-            const double y = TV[(rg * RG + r) * LDV + NRU];
-            zsum = fma(x, y, zsum);
-            isum = fma(x, x, isum);
-            vsum += x;
-        }
-    }
-    __syncthreads();
-    red[tid] = zsum;
-    red[256 + tid] = isum;
-    red[512 + tid] = vsum;
-    __syncthreads();
-    if (tid < NRU) {
-        double z = 0.0, info = 0.0;
-        for (int g = 0; g < NG; g++) { z += red[g * NR + tid]; info += red[256 + g * NR + tid]; }
-        const int u = u0 + tid;
-        if (qcat) {
-            // r = CalCor(Linv z1, Linv b)  (util.cpp:72-101; qcat.cpp:221,239), vectors of length M
-            double sv = 0.0, sy = 0.0, syy = 0.0;
-            for (int g = 0; g < NG; g++) {
-                sv += red[512 + g * NR + tid];
-                sy += red[512 + g * NR + NRU];
-                syy += red[256 + g * NR + NRU];
-            }
-            if (u < pb.n_rhs) {
-                const double n = (double)pb.M;
-                const double mx = sy / n, mv = sv / n;
-                const double cxx = syy - n * mx * mx;
-                const double cvv = info - n * mv * mv;
-                const double cxv = z - n * mx * mv;
-                pb.out_z[u] = cxv / sqrt(cxx * cvv);
-                pb.out_info[u] = cvv;
-            }
-        } else if (u < pb.U) {
-            info = fabs(info);                         // dist.cpp:198
-            pb.out_z[u] = z / sqrt(info);              // dist.cpp:200
-            pb.out_info[u] = info;                     // dist.cpp:202
-        }
-    }
+// last block row of the windows that are as tall as the batch's tallest one (no update launch carries it)
+__global__ __launch_bounds__(256) void solve_last_kernel(const Prob* __restrict__ probs, const int2* __restrict__ panelmap,
+                                                         int s_last)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int2 pm = panelmap[blockIdx.x];
+    const Prob& pb = probs[pm.x];
+    if (pb.nblk - 1 != s_last) return;
+    solve_row_fused(pb, pm.y, s_last, smem, threadIdx.x);
 }
 
 void launch_solve(const Prob* d_probs, const int2* d_panelmap, int n_panels, hipStream_t s)
 {
     if (n_panels <= 0) return;
-    const size_t sh = ((size_t)NB * LDT + (size_t)NB * LDV + 768) * sizeof(double);
     static std::atomic<unsigned long long> attr_set{0};
     if (first_use_on_device(attr_set))
-        hipFuncSetAttribute(reinterpret_cast<const void*>(solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-    hipLaunchKernelGGL(solve_kernel, dim3(n_panels), dim3(256), sh, s, d_probs, d_panelmap);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SOLVE_SMEM);
+    hipLaunchKernelGGL(solve_kernel, dim3(n_panels), dim3(256), SOLVE_SMEM, s, d_probs, d_panelmap);
+}
+
+void launch_solve_last(const Prob* d_probs, const int2* d_panelmap, int n_panels, int max_nblk, hipStream_t s)
+{
+    if (n_panels <= 0 || max_nblk < 1) return;
+    static std::atomic<unsigned long long> attr_set{0};
+    if (first_use_on_device(attr_set))
+        hipFuncSetAttribute(reinterpret_cast<const void*>(solve_last_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SOLVE_SMEM);
+    hipLaunchKernelGGL(solve_last_kernel, dim3(n_panels), dim3(256), SOLVE_SMEM, s, d_probs, d_panelmap, max_nblk - 1);
 }
 
 }  // namespace gauss
