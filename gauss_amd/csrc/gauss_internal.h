@@ -8,7 +8,8 @@ namespace gauss {
 
 constexpr int TILE = 128;      // Gram output tile edge per workgroup (4 waves x 64x64)
 constexpr int KC = 64;         // packed K chunk in bytes (= samples); pops are padded to it
-constexpr int SEG_MAX = 2048;  // max samples per K segment (split-K granularity)
+constexpr int SEG_MAX = 2048;  // K segment cap for small jobs (< 4 windows); larger jobs use 8192 (seg_max_for); both keep
+                               // a partial sum below 2^24 (15 * 15 * 8192), the exactness bound of the f32 accumulators
 constexpr int NB = 64;         // fp64 factor / solve block edge
 constexpr int NR = 64;         // right-hand sides per solve panel (63 SNPs + the z1 column); the solve kernel is
                                // written for any multiple of 64 -- 128 was measured slower (2.23 vs 1.80 ms: half as

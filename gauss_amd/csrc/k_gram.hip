@@ -5,10 +5,12 @@
 // the reference re-runs for every SNP pair (dist.cpp:174,189; distmix.cpp:195,213;
 // computeLD.cpp:111; gene.cpp:309,581).  Here all pairs of a 128 x 128 tile are formed at once.
 //
-// Exactness: operands are genotype codes (0..15 admitted, 0..2 in practice); a segment spans at
-// most SEG_MAX = 2048 samples, so every partial sum is an integer < 2^24 and the f32 MFMA
-// accumulation (bitwise a k-ordered fmaf chain) is exact in any summation order.  The k order
-// inside a chunk is therefore permuted freely to make the LDS reads wide.
+// Exactness: operands are genotype codes (0..15 admitted, 0..2 in practice); a segment (the run of samples whose
+// products one accumulator sums before it is flushed) never spans more than 8192 samples of ONE population -- the
+// planner cuts longer populations, at SEG_MAX = 2048 for jobs of fewer than four windows (more work items) and at
+// 8192 otherwise (gauss_hip.cpp:seg_max_for) -- so every partial sum is an integer <= 15 * 15 * 8192 < 2^24 and the
+// f32 MFMA accumulation (bitwise a k-ordered fmaf chain) is exact in any summation order.  The k order inside a
+// chunk is therefore permuted freely to make the LDS reads wide.
 //
 // Work item = (tile pair, run of K segments).  Workgroup = 256 threads = 4 waves, each wave owns a
 // 64 x 64 sub-tile = 2 x 2 MFMA tiles of 32 x 32 (four independent accumulators keep the MFMA pipe
