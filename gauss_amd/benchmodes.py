@@ -91,6 +91,7 @@ def e2e_measure(rig, ch, files, steps, wing, n_batches=0):
     its LPT share of the windows and rank 0 merges the tables in window order."""
     sa = study_args(ch, files)
     lo, hi = chromosome_span(ch)
+    n_batches = n_batches or int(os.environ.get("GAUSS_E2E_BATCHES", "0"))     # experiment override
     kw = dict(chr=22, start_bp=lo, end_bp=hi, wing_size=wing, input_file=files["gwas"], reference_data_file=files["panel"],
               reference_pop_desc_file=files["desc"], rank=rig.rank, world=rig.world, n_batches=n_batches, ctx=rig.ctx, **sa)
 

@@ -363,6 +363,18 @@ static int merge_index_entry(SnpMap& m, const Args& a, bool All, const std::stri
         if ((a.chr > 0) && (a.chr != chr)) return 0;
         if ((a.start_bp - a.wing_size) > bp || (a.end_bp + a.wing_size) < bp) return 0;
     }
+    // Most panel SNPs share their position with no GWAS SNP: one ordered lookup at (chr, bp) settles that neither
+    // allele order is present and doubles as the insertion hint (same outcome as the two finds below, which only run
+    // when something already sits at this position).
+    auto pos = m.lower_bound(MapKey{chr, bp, std::string(), std::string()});
+    if (pos == m.end() || pos->first.chr != chr || pos->first.bp != bp) {
+        if (!All) {       // gauss.cpp:373-385; ReadReferenceIndexAll never adds unmeasured SNPs
+            std::unique_ptr<Snp> s(new Snp());
+            s->rsid = rsid; s->chr = chr; s->bp = bp; s->a1 = a1; s->a2 = a2; s->type = 0; s->fpos = fpos;
+            m.emplace_hint(pos, MapKey{chr, bp, a1, a2}, std::move(s));
+        }
+        return 0;
+    }
     auto it1 = m.find(MapKey{chr, bp, a1, a2});
     auto it2 = m.find(MapKey{chr, bp, a2, a1});
     if (it1 != m.end() && it2 == m.end()) {
@@ -718,6 +730,10 @@ static int prepare(gauss_prepared& p)
     const bool gene = (kind == GAUSS_KIND_JEPEG || kind == GAUSS_KIND_JEPEGMIX);
     const bool qcat = (kind == GAUSS_KIND_QCAT || kind == GAUSS_KIND_QCATMIX);
     const bool prep = (kind == GAUSS_KIND_PREP_QCAT || kind == GAUSS_KIND_PREP_RECESSIVE);
+    static const bool trace = getenv("GAUSS_PREP_TRACE") != nullptr;
+    auto tnow = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tt[8] = {0};
+    tt[0] = tnow();
     if (read_ref_desc(a)) return -1;
     if (a.pk) {
         if (a.pk->n_pop() != a.num_pops) return herr("packed panel has %d populations, the description file %d", a.pk->n_pop(), a.num_pops);
@@ -728,11 +744,15 @@ static int prepare(gauss_prepared& p)
     }
     if (mix) init_pop_flag_wgt_vec(a);
     else if (init_pop_flag_vec(a)) return -1;
+    tt[1] = tnow();
     if (ReadInputZ(p.snp_map, a, gene)) return -1;
+    tt[2] = tnow();
     if (ReadReferenceIndex(p.snp_map, a, gene)) return -1;
+    tt[3] = tnow();
     if (gene && ReadAnnotation(p.snp_map, a)) return -1;
     if (mix) { if (MakeSnpVecMix(p.snp_vec, p.snp_map, a)) return -1; }
     else if (MakeSnpVec(p.snp_vec, p.snp_map, a)) return -1;
+    tt[4] = tnow();
 
     // populations selected, in panel order; N = sum of their sizes as found in the panel lines
     p.pop_off.assign(1, 0);
@@ -815,7 +835,11 @@ static int prepare(gauss_prepared& p)
     }
     p.z1.clear();
     for (Snp* s : p.measured) p.z1.push_back(s->z);
-    build_snp_table(p);
+    tt[5] = tnow();
+    tt[6] = tnow();       // the SNP-list table (gauss_prepared_snps) is built on first request
+    if (trace)
+        fprintf(stderr, "[prepare] desc %.2f  gwas %.2f  index %.2f  af-filter %.2f  partition %.2f  snp-table %.2f ms (map %zu, kept %zu)\n",
+                tt[1] - tt[0], tt[2] - tt[1], tt[3] - tt[2], tt[4] - tt[3], tt[5] - tt[4], tt[6] - tt[5], p.snp_map.size(), p.snp_vec.size());
     return 0;
 }
 
@@ -1223,7 +1247,12 @@ int gauss_host_prepare(int kind, int chr, int64_t start_bp, int64_t end_bp, int6
     return 0;
 }
 
-const gauss_table* gauss_prepared_snps(const gauss_prepared* p) { return p ? &p->snps : nullptr; }
+const gauss_table* gauss_prepared_snps(const gauss_prepared* p)
+{
+    if (!p) return nullptr;
+    if (!p->snps_built) build_snp_table(*const_cast<gauss_prepared*>(p));      // a debugging / test view: built on demand
+    return &p->snps;
+}
 int gauss_prepared_counts(const gauss_prepared* p, int* m, int* u, int* n, int* np, int* ng)
 {
     if (!p) return herr("prepared is NULL");
@@ -1851,6 +1880,11 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
     {
         std::vector<double> share((size_t)n_batches, 1.0);
         if (n_batches >= 4) { share.front() = 0.5; share.back() = 0.5; }
+        if (const char* e = getenv("GAUSS_CHROM_SHARES")) {          // experiment: "0.2,1,1,0.5"
+            std::vector<double> v;
+            for (const char* q = e; *q;) { char* end = nullptr; const double x = strtod(q, &end); if (end == q) break; v.push_back(x); q = (*end == ',') ? end + 1 : end; }
+            if ((int)v.size() == n_batches) share = v;
+        }
         double ssum = 0;
         for (double v : share) ssum += v;
         double total = 0;
@@ -1878,39 +1912,81 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
     for (int b = 0; b < n_batches; b++) slots[b].resize(batches[b].size());
     std::mutex mu;
     std::condition_variable cv;
-    int ready = 0;                                                // batches whose data layer is done
     const unsigned hw = std::thread::hardware_concurrency();
-    const int nthreads = (int)std::max(1u, std::min(16u, (hw ? hw : 4u) / (unsigned)std::max(1, std::min(world, 8))));
+    int nthreads = (int)std::max(1u, std::min(16u, (hw ? hw : 4u) / (unsigned)std::max(1, std::min(world, 8))));
+    if (const char* e = getenv("GAUSS_CHROM_THREADS")) nthreads = std::max(1, atoi(e));
+    // One pool over ALL windows in batch order (not one fork-join per batch: a batch of five windows would leave
+    // eleven of sixteen threads idle); a batch is ready when its last window is.
+    std::vector<std::pair<int, int>> order;                       // (batch, slot)
+    for (int b = 0; b < n_batches; b++)
+        for (int k = 0; k < (int)batches[b].size(); k++) order.push_back(std::make_pair(b, k));
+    std::vector<int> left((size_t)n_batches);                     // windows of batch b still in the data layer (under mu)
+    for (int b = 0; b < n_batches; b++) left[b] = (int)batches[b].size();
+    auto batch_ready = [&](int b) { return left[b] == 0; };
     std::thread feeder([&]() {
-        for (int b = 0; b < n_batches; b++) {
-            parallel_for((int)batches[b].size(), nthreads, [&](int k) {
-                Win& w = wins[batches[b][k]];
-                Slot& sl = slots[b][k];
-                gauss_prepared* p = nullptr;
-                if (gauss_host_prepare(kind, chr, w.s, w.e, wing_size, study_pop, pop_names, pop_wgts, n_pop_wgt, input_file, nullptr,
-                                       "(packed)", reference_data_file, reference_pop_desc_file, af1_cutoff, &p)) {
-                    w.status = 2; w.why = gauss_host_last_error();
-                    return;
-                }
+        parallel_for((int)order.size(), nthreads, [&](int q) {
+            const int b = order[q].first, k = order[q].second;
+            Win& w = wins[batches[b][k]];
+            Slot& sl = slots[b][k];
+            gauss_prepared* p = nullptr;
+            if (gauss_host_prepare(kind, chr, w.s, w.e, wing_size, study_pop, pop_names, pop_wgts, n_pop_wgt, input_file, nullptr,
+                                   "(packed)", reference_data_file, reference_pop_desc_file, af1_cutoff, &p)) {
+                w.status = 2; w.why = gauss_host_last_error();
+            } else {
                 sl.p.reset(p);
                 w.M = (int)p->measured.size(); w.U = (int)p->unmeasured.size();
                 if (gauss_prepared_window_desc(p, &sl.d)) {       // the ">10" guards (dist.cpp:145-151)
                     w.status = 1; w.why = gauss_host_last_error();
                     sl.p.reset();
-                    return;
+                } else {
+                    sl.d.geno_m = sl.d.geno_u = (const uint8_t*)d_rows;   // rows_m / rows_u are panel row indices already
+                    sl.ok = true;
                 }
-                sl.d.geno_m = sl.d.geno_u = (const uint8_t*)d_rows;   // rows_m / rows_u are panel row indices already
-                sl.ok = true;
-            });
-            { std::lock_guard<std::mutex> lock(mu); ready = b + 1; }
-            cv.notify_all();
-        }
+            }
+            bool last;
+            { std::lock_guard<std::mutex> lock(mu); last = (--left[b] == 0); }
+            if (last) cv.notify_all();
+        });
     });
 
     // ---- GPU pipeline ----
     std::vector<gauss_job*> jobs((size_t)n_batches, nullptr);
     std::vector<std::vector<int>> live((size_t)n_batches);       // slots of batch b that are in its job
     int rc_fatal = 0;
+    // the result table grows batch by batch (batches are contiguous in window order), so that only the last batch's
+    // rows are appended after the GPU has finished
+    std::unique_ptr<gauss_table> all(new gauss_table());
+    Column win_col{"window", GAUSS_COL_INT, {}, {}, {}};
+    bool first = true;
+    auto append_batch = [&](int b) {
+        for (size_t k = 0; k < slots[b].size(); k++) {
+            Slot& sl = slots[b][k];
+            if (!sl.tab) continue;
+            const int nr = sl.tab->nrow();
+            if (first) {
+                const size_t guess = (size_t)nr * (mine.size() + 1);
+                for (const Column& c : sl.tab->cols) {
+                    Column& nc = all->add(c.name.c_str(), c.type);
+                    if (c.type == GAUSS_COL_STR) nc.s.reserve(guess);
+                    else if (c.type == GAUSS_COL_INT) nc.i.reserve(guess);
+                    else nc.d.reserve(guess);
+                }
+                win_col.i.reserve(guess);
+                first = false;
+            }
+            for (size_t c = 0; c < sl.tab->cols.size(); c++) {
+                Column& src = sl.tab->cols[c];
+                Column& dst = all->cols[c];
+                if (src.type == GAUSS_COL_STR) for (std::string& v : src.s) dst.s.push_back(std::move(v));
+                else if (src.type == GAUSS_COL_INT) dst.i.insert(dst.i.end(), src.i.begin(), src.i.end());
+                else dst.d.insert(dst.d.end(), src.d.begin(), src.d.end());
+            }
+            win_col.i.insert(win_col.i.end(), (size_t)nr, (int32_t)batches[b][k]);
+            if (wins[batches[b][k]].status == 0) st.imputed += wins[batches[b][k]].U;
+            delete sl.tab;
+            sl.tab = nullptr;
+        }
+    };
     auto retire = [&](int b) {
         // results of batch b -> SNP objects -> per-window tables (host threads; the GPU is on batch b+1 meanwhile)
         double tw = now_s();
@@ -1939,11 +2015,12 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
             else { wins[batches[b][k]].status = 2; wins[batches[b][k]].why = gauss_host_last_error(); }
             sl.p.reset();
         });
+        append_batch(b);
         st.t_tables += now_s() - tt;
     };
     for (int b = 0; b < n_batches && !rc_fatal; b++) {
         double tw = now_s();
-        { std::unique_lock<std::mutex> lock(mu); cv.wait(lock, [&]() { return ready > b; }); }
+        { std::unique_lock<std::mutex> lock(mu); cv.wait(lock, [&]() { return batch_ready(b); }); }
         st.t_feeder_wait += now_s() - tw;
         std::vector<gauss_window_desc> descs;
         for (size_t k = 0; k < slots[b].size(); k++)
@@ -1977,41 +2054,8 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
     }
     for (gauss_job* j : jobs) if (j) gauss_job_destroy(j);
 
-    // ---- one table, window order ----
+    // ---- one table, window order (batches were appended as they retired) ----
     double tt = now_s();
-    std::unique_ptr<gauss_table> all(new gauss_table());
-    Column win_col{"window", GAUSS_COL_INT, {}, {}, {}};
-    bool first = true;
-    size_t total_rows = 0;
-    for (int b = 0; b < n_batches; b++)
-        for (Slot& sl : slots[b]) if (sl.tab) total_rows += (size_t)sl.tab->nrow();
-    for (int b = 0; b < n_batches; b++)
-        for (size_t k = 0; k < slots[b].size(); k++) {
-            Slot& sl = slots[b][k];
-            if (!sl.tab) continue;
-            const int nr = sl.tab->nrow();
-            if (first) {
-                for (const Column& c : sl.tab->cols) {
-                    Column& nc = all->add(c.name.c_str(), c.type);
-                    if (c.type == GAUSS_COL_STR) nc.s.reserve(total_rows);
-                    else if (c.type == GAUSS_COL_INT) nc.i.reserve(total_rows);
-                    else nc.d.reserve(total_rows);
-                }
-                win_col.i.reserve(total_rows);
-                first = false;
-            }
-            for (size_t c = 0; c < sl.tab->cols.size(); c++) {
-                Column& src = sl.tab->cols[c];
-                Column& dst = all->cols[c];
-                if (src.type == GAUSS_COL_STR) for (std::string& v : src.s) dst.s.push_back(std::move(v));
-                else if (src.type == GAUSS_COL_INT) dst.i.insert(dst.i.end(), src.i.begin(), src.i.end());
-                else dst.d.insert(dst.d.end(), src.d.begin(), src.d.end());
-            }
-            win_col.i.insert(win_col.i.end(), (size_t)nr, (int32_t)batches[b][k]);
-            if (wins[batches[b][k]].status == 0) st.imputed += wins[batches[b][k]].U;
-            delete sl.tab;
-            sl.tab = nullptr;
-        }
     if (first) {       // no window produced rows: still hand back the reference's column set
         const bool mix = (kind == GAUSS_KIND_DISTMIX || kind == GAUSS_KIND_QCATMIX);
         const bool qc = (kind == GAUSS_KIND_QCAT || kind == GAUSS_KIND_QCATMIX);

@@ -437,3 +437,45 @@ def test_full_size_gene_ld_batch(ctx, mode, pop_names):
         assert abs(blocks[g][i, j] - entry(gene_off[g] + i, gene_off[g] + j)) <= 1e-13
         checked += 1
     assert checked >= 6
+
+
+def test_full_size_dist_window_at_the_largest_real_window(ctx):
+    """BASELINE.json configs[2] at its real size: dist(study_pop = "EUR"), N = 20 281 (6 populations pooled), with the
+    shape of the LARGEST window of the chr22 study (M = 1 213 measured = 19 factor blocks, U = 2 583): properties that
+    need no oracle at full size, oracle spot checks of single LD entries (loop-literal CalCor), and the solve against
+    numpy on the GPU's own B11 / B21."""
+    pops = [p for p in synth.POPS_33KG if p[2] == "EUR"]
+    off = synth.pop_offsets([p[1] for p in pops])
+    N = int(off[-1])
+    assert N == 20281
+    rng = np.random.default_rng(99)
+    M, U = 1213, 2583
+    base = rand_geno(rng, 220, N)
+    G = base[rng.integers(0, 220, size=M + U)].copy()
+    noise = rng.random(G.shape) < 0.4
+    G[noise] = rand_geno(rng, 1, N)[0][np.nonzero(noise)[1]]
+    gm, gu = np.ascontiguousarray(G[:M]), np.ascontiguousarray(G[M:])
+    z1 = rng.standard_normal(M) * 2
+    r = hotpath.impute_window(0, gm, gu, off, None, z1, want_mats=True, ctx=ctx)
+    assert r["status"] == 0
+    b11, b21 = r["b11"], r["b21"]
+    assert np.array_equal(b11, b11.T) and np.all(np.diag(b11) == 1.1)
+    assert np.all(np.abs(b21) <= 1 + 1e-9) and np.all(np.isfinite(r["z"]))
+    assert np.all(r["info"] > 0) and np.all(r["info"] < 1 + 1e-9)
+    assert np.linalg.eigvalsh(b11).min() > 0.09
+    for (i, j) in [(0, 1), (5, 1200), (640, 641), (1212, 3)]:
+        assert abs(b11[i, j] - oracle.calcor(gm[i], gm[j], off)) <= 1e-13
+    for (u, j) in [(0, 0), (2582, 1212), (1300, 17)]:
+        assert abs(b21[u, j] - oracle.calcor(gu[u], gm[j], off)) <= 1e-13
+    y = b21 @ np.linalg.inv(b11)
+    info = np.abs(np.einsum("ij,ij->i", y, b21))
+    assert relerr(r["info"], info) <= 1e-9
+    assert np.max(np.abs(r["z"] - (y @ z1) / np.sqrt(info))) <= 1e-8
+    # the same window inside a batch of others (shared launches, fused solve rows) gives the same bits
+    small = dict(mode=0, geno_m=gm[:200], geno_u=gu[:300], pop_off=off, pop_wgt=None, z1=z1[:200])
+    job = hotpath.Job([small, dict(mode=0, geno_m=gm, geno_u=gu, pop_off=off, pop_wgt=None, z1=z1), small], ctx=ctx)
+    job.run()
+    res = job.fetch()
+    job.close()
+    assert np.array_equal(res[1]["z"], r["z"]) and np.array_equal(res[1]["info"], r["info"])
+    assert np.array_equal(res[0]["z"], res[2]["z"])
