@@ -1,5 +1,10 @@
 #include "bgzf_io.h"
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <zlib.h>
 
 #include <cstdlib>
@@ -41,8 +46,20 @@ BgzfReader::~BgzfReader() { close(); }
 bool BgzfReader::open(const std::string& path)
 {
     close();
-    fp_ = fopen(path.c_str(), "rb");
-    if (!fp_) return false;
+    {
+        const int fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) return false;
+        struct stat st;
+        if (fstat(fd, &st) == 0 && st.st_size > 0 && !getenv("GAUSS_BGZF_NO_MMAP")) {
+            void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m != MAP_FAILED) { map_ = (const unsigned char*)m; map_size_ = (size_t)st.st_size; }
+        }
+        ::close(fd);
+    }
+    if (!map_) {
+        fp_ = fopen(path.c_str(), "rb");
+        if (!fp_) return false;
+    }
     comp_.resize(kMaxBlock);
     data_.resize(kMaxBlock);
     block_address_ = 0; block_offset_ = 0; block_length_ = 0; next_address_ = 0; loaded_ = false;
@@ -53,6 +70,8 @@ void BgzfReader::close()
 {
     if (fp_) fclose(fp_);
     fp_ = nullptr;
+    if (map_) munmap(const_cast<unsigned char*>(map_), map_size_);
+    map_ = nullptr; map_size_ = 0;
     if (fast_) { fast_inflate().release(fast_); fast_ = nullptr; }
 }
 
@@ -71,27 +90,49 @@ int BgzfReader::read_block()
 {
     block_length_ = 0;
     next_address_ = block_address_;
-    if (fseeko(fp_, (off_t)block_address_, SEEK_SET) != 0) return 0;   // unreachable offset reads as EOF
-    unsigned char hdr[12];
-    size_t n = fread(hdr, 1, 12, fp_);
-    if (n == 0) return 0;               // EOF
-    if (n != 12 || hdr[0] != 31 || hdr[1] != 139 || hdr[2] != 8 || !(hdr[3] & 4)) return -1;
-    const int xlen = hdr[10] | (hdr[11] << 8);
-    if (xlen < 6 || xlen > 4096) return -1;
-    unsigned char extra[4096];
-    if (fread(extra, 1, xlen, fp_) != (size_t)xlen) return -1;
-    int bsize = -1;
-    for (int p = 0; p + 4 <= xlen;) {
-        const int slen = extra[p + 2] | (extra[p + 3] << 8);
-        if (extra[p] == 'B' && extra[p + 1] == 'C' && slen == 2 && p + 6 <= xlen) bsize = extra[p + 4] | (extra[p + 5] << 8);
-        p += 4 + slen;
+    const unsigned char* cdata = nullptr;      // the compressed payload followed by the 8-byte trailer
+    int xlen = 0, total = 0, clen = 0;
+    auto parse_extra = [&](const unsigned char* extra) {
+        int bsize = -1;
+        for (int p = 0; p + 4 <= xlen;) {
+            const int slen = extra[p + 2] | (extra[p + 3] << 8);
+            if (extra[p] == 'B' && extra[p + 1] == 'C' && slen == 2 && p + 6 <= xlen) bsize = extra[p + 4] | (extra[p + 5] << 8);
+            p += 4 + slen;
+        }
+        return bsize;
+    };
+    if (map_) {
+        if (block_address_ < 0 || (uint64_t)block_address_ >= map_size_) return 0;    // unreachable offset reads as EOF
+        const unsigned char* hdr = map_ + block_address_;
+        const size_t left = map_size_ - (size_t)block_address_;
+        if (left < 12 || hdr[0] != 31 || hdr[1] != 139 || hdr[2] != 8 || !(hdr[3] & 4)) return -1;
+        xlen = hdr[10] | (hdr[11] << 8);
+        if (xlen < 6 || xlen > 4096 || left < (size_t)12 + xlen) return -1;
+        const int bsize = parse_extra(hdr + 12);
+        if (bsize < 0) return -1;
+        total = bsize + 1;
+        clen = total - 12 - xlen - 8;
+        if (clen < 0 || clen > kMaxBlock || left < (size_t)total) return -1;
+        cdata = hdr + 12 + xlen;
+    } else {
+        if (fseeko(fp_, (off_t)block_address_, SEEK_SET) != 0) return 0;   // unreachable offset reads as EOF
+        unsigned char hdr[12];
+        size_t n = fread(hdr, 1, 12, fp_);
+        if (n == 0) return 0;               // EOF
+        if (n != 12 || hdr[0] != 31 || hdr[1] != 139 || hdr[2] != 8 || !(hdr[3] & 4)) return -1;
+        xlen = hdr[10] | (hdr[11] << 8);
+        if (xlen < 6 || xlen > 4096) return -1;
+        unsigned char extra[4096];
+        if (fread(extra, 1, xlen, fp_) != (size_t)xlen) return -1;
+        const int bsize = parse_extra(extra);
+        if (bsize < 0) return -1;
+        total = bsize + 1;
+        clen = total - 12 - xlen - 8;
+        if (clen < 0 || clen > kMaxBlock) return -1;
+        if (fread(comp_.data(), 1, (size_t)clen + 8, fp_) != (size_t)clen + 8) return -1;
+        cdata = comp_.data();
     }
-    if (bsize < 0) return -1;
-    const int total = bsize + 1;
-    const int clen = total - 12 - xlen - 8;
-    if (clen < 0 || clen > kMaxBlock) return -1;
-    if (fread(comp_.data(), 1, (size_t)clen + 8, fp_) != (size_t)clen + 8) return -1;
-    const unsigned char* ft = comp_.data() + clen;
+    const unsigned char* ft = cdata + clen;
     const uint32_t crc = ft[0] | (ft[1] << 8) | (ft[2] << 16) | ((uint32_t)ft[3] << 24);
     const uint32_t isize = ft[4] | (ft[5] << 8) | (ft[6] << 16) | ((uint32_t)ft[7] << 24);
     // Raw deflate payload.  libdeflate (whole-buffer decoder, ~2-3x zlib) when its runtime library is present --
@@ -101,7 +142,7 @@ int BgzfReader::read_block()
     if (fi.decompress && isize <= (uint32_t)kMaxBlock) {
         if (!fast_) fast_ = fi.alloc();
         size_t got = 0;
-        if (fast_ && fi.decompress(fast_, comp_.data(), (size_t)clen, data_.data(), (size_t)kMaxBlock, &got) == 0 && got == isize) {
+        if (fast_ && fi.decompress(fast_, cdata, (size_t)clen, data_.data(), (size_t)kMaxBlock, &got) == 0 && got == isize) {
             block_length_ = (int)got;
             done = true;
         }
@@ -109,7 +150,7 @@ int BgzfReader::read_block()
     if (!done) {
         z_stream zs;
         memset(&zs, 0, sizeof(zs));
-        zs.next_in = comp_.data();
+        zs.next_in = const_cast<unsigned char*>(cdata);
         zs.avail_in = (uInt)clen;
         zs.next_out = data_.data();
         zs.avail_out = kMaxBlock;
@@ -127,7 +168,7 @@ int BgzfReader::read_block()
 int BgzfReader::getline(std::string& line)
 {
     line.clear();
-    if (!fp_) return -2;
+    if (!fp_ && !map_) return -2;
     for (;;) {
         if (!loaded_) {
             if (read_block() != 0) return -2;

@@ -23,7 +23,7 @@ public:
 
     bool open(const std::string& path);
     void close();
-    bool is_open() const { return fp_ != nullptr; }
+    bool is_open() const { return fp_ != nullptr || map_ != nullptr; }
     // Position at a virtual offset.  Offsets that land beyond the file read as EOF (the reference
     // relies on this for SNPs whose fpos is -1, gauss.cpp:561-597).
     void seek(int64_t voffset);
@@ -35,6 +35,10 @@ public:
 private:
     int read_block();   // 0 ok (block_length_ may be 0 at EOF), -1 error
     FILE* fp_ = nullptr;
+    // the file is mapped when possible: a block is then parsed straight out of the page cache (no lseek / read
+    // system calls per block -- they dominate, and serialise threads, in sandboxed containers); fp_ is the fallback
+    const unsigned char* map_ = nullptr;
+    size_t map_size_ = 0;
     int64_t block_address_ = 0;
     int block_offset_ = 0;
     int block_length_ = 0;

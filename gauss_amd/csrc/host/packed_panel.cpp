@@ -10,7 +10,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <atomic>
 #include <fstream>
+#include <mutex>
+#include <thread>
 
 #include "bgzf_io.h"
 
@@ -149,9 +153,9 @@ int64_t pack_panel(const std::string& index_path, const std::string& data_path, 
     const int P = (int)pops.size();
     const uint64_t row_bytes = std::max<uint64_t>(16, pops.back().byte_off + (pops.back().size + 63) / 64 * 16);
 
-    BgzfReader idx, dat;
+    BgzfReader idx;
     if (!idx.open(index_path)) { err = "ERROR: can't open reference index file '" + index_path + "'"; return -1; }
-    if (!dat.open(data_path)) { err = "ERROR: can't open reference data file '" + data_path + "'"; return -1; }
+    { BgzfReader probe; if (!probe.open(data_path)) { err = "ERROR: can't open reference data file '" + data_path + "'"; return -1; } }
 
     std::vector<PkSnp> snps;
     std::vector<char> strings;
@@ -161,59 +165,105 @@ int64_t pack_panel(const std::string& index_path, const std::string& data_path, 
     FILE* gf = fopen(geno_tmp.c_str(), "wb");
     if (!gf) { err = "can't write '" + geno_tmp + "'"; return -1; }
     auto add_str = [&](const char* b, int n) { const uint32_t o = (uint32_t)strings.size(); strings.insert(strings.end(), b, b + n); strings.push_back(0); return o; };
-    std::string line, dline;
-    std::vector<uint8_t> row(row_bytes);
     bool sorted = true;
-    for (;;) {
-        const int last = idx.getline(line);
-        if (last == -2) { err = "Error: can't read reference index file '" + index_path + "'"; fclose(gf); remove(geno_tmp.c_str()); return -1; }
-        if (last == -1 && line.empty()) break;
-        Fields t{line.data(), line.data() + line.size()};
-        const char *b_rs, *b_chr, *b_bp, *b_a1, *b_a2, *b_af, *b_fp;
-        int n_rs, n_chr, n_bp, n_a1, n_a2, n_af, n_fp;
-        if (!(t.next(b_rs, n_rs) && t.next(b_chr, n_chr) && t.next(b_bp, n_bp) && t.next(b_a1, n_a1) && t.next(b_a2, n_a2) &&
-              t.next(b_af, n_af) && t.next(b_fp, n_fp))) {
-            if (last == -1) break;
+
+    // The index is read sequentially in blocks of BLK lines; the data lines of a block (one ~33 kB text line per SNP,
+    // found by its BGZF virtual offset) are inflated, parsed and 2-bit packed by a pool of threads, each with its own
+    // reader, straight into the block's slots -- the conversion is a one-off per panel, but a genome-wide 33KG panel has
+    // millions of lines (0.29 ms per line on one thread).
+    const int BLK = 16384;
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int nt = (int)std::max(1u, std::min(16u, hw ? hw : 4u));
+    std::vector<BgzfReader> readers((size_t)nt);
+    for (BgzfReader& r : readers)
+        if (!r.open(data_path)) { err = "ERROR: can't open reference data file '" + data_path + "'"; fclose(gf); remove(geno_tmp.c_str()); return -1; }
+    struct Pending { long long fpos; std::string rsid; };
+    std::vector<Pending> pend;
+    std::vector<uint8_t> rows;
+    std::vector<double> baf;
+    std::vector<int32_t> bcnt;
+    std::string line;
+    bool eof = false;
+    while (!eof) {
+        pend.clear();
+        while ((int)pend.size() < BLK) {
+            const int last = idx.getline(line);
+            if (last == -2) { err = "Error: can't read reference index file '" + index_path + "'"; fclose(gf); remove(geno_tmp.c_str()); return -1; }
+            if (last == -1 && line.empty()) { eof = true; break; }
+            Fields t{line.data(), line.data() + line.size()};
+            const char *b_rs, *b_chr, *b_bp, *b_a1, *b_a2, *b_af, *b_fp;
+            int n_rs, n_chr, n_bp, n_a1, n_a2, n_af, n_fp;
+            if (t.next(b_rs, n_rs) && t.next(b_chr, n_chr) && t.next(b_bp, n_bp) && t.next(b_a1, n_a1) && t.next(b_a2, n_a2) &&
+                t.next(b_af, n_af) && t.next(b_fp, n_fp)) {
+                PkSnp sn;
+                sn.chr = (int32_t)strtol(std::string(b_chr, n_chr).c_str(), nullptr, 10);
+                sn.bp = strtoll(std::string(b_bp, n_bp).c_str(), nullptr, 10);
+                sn.rsid = add_str(b_rs, n_rs); sn.a1 = add_str(b_a1, n_a1); sn.a2 = add_str(b_a2, n_a2);
+                if (!snps.empty() && (sn.chr < snps.back().chr || (sn.chr == snps.back().chr && sn.bp < snps.back().bp))) sorted = false;
+                snps.push_back(sn);
+                pend.push_back(Pending{strtoll(std::string(b_fp, n_fp).c_str(), nullptr, 10), std::string(b_rs, n_rs)});
+            }
             line.clear();
-            continue;
+            if (last == -1) { eof = true; break; }
         }
-        PkSnp s;
-        s.chr = (int32_t)strtol(std::string(b_chr, n_chr).c_str(), nullptr, 10);
-        s.bp = strtoll(std::string(b_bp, n_bp).c_str(), nullptr, 10);
-        s.rsid = add_str(b_rs, n_rs); s.a1 = add_str(b_a1, n_a1); s.a2 = add_str(b_a2, n_a2);
-        const long long fpos = strtoll(std::string(b_fp, n_fp).c_str(), nullptr, 10);
-        if (!snps.empty() && (s.chr < snps.back().chr || (s.chr == snps.back().chr && s.bp < snps.back().bp))) sorted = false;
-        dat.seek(fpos);
-        dline.clear();
-        dat.getline(dline);
-        Fields d{dline.data(), dline.data() + dline.size()};
-        std::fill(row.begin(), row.end(), 0);
-        for (int k = 0; k < P; k++) {
-            const char* g; int n;
-            if (!d.next(g, n) || n != (int)pops[k].size) {
-                err = "panel line of " + std::string(b_rs, n_rs) + ": population " + pops[k].name + " does not have " + std::to_string(pops[k].size) + " genotypes";
-                fclose(gf); remove(geno_tmp.c_str()); return -1;
+        const int nb = (int)pend.size();
+        if (nb == 0) break;
+        rows.assign((size_t)nb * row_bytes, 0);
+        baf.assign((size_t)nb * P, 0.0);
+        bcnt.assign((size_t)nb * P, 0);
+        std::atomic<int> next{0};
+        std::mutex emu;
+        std::string first_err;
+        auto work = [&](int tid) {
+            BgzfReader& dat = readers[tid];
+            std::string dline;
+            // runs of consecutive SNPs per grab: neighbouring lines share BGZF blocks (a 33 kB line is half a block),
+            // interleaving single lines over the threads would make every thread inflate every block
+            const int RUN = 128;
+            for (int c0 = next.fetch_add(RUN); c0 < nb; c0 = next.fetch_add(RUN))
+            for (int i = c0; i < std::min(nb, c0 + RUN); i++) {
+                dat.seek(pend[i].fpos);
+                dline.clear();
+                dat.getline(dline);
+                Fields d{dline.data(), dline.data() + dline.size()};
+                uint8_t* row = rows.data() + (size_t)i * row_bytes;
+                for (int k = 0; k < P; k++) {
+                    const char* g; int n;
+                    if (!d.next(g, n) || n != (int)pops[k].size) {
+                        std::lock_guard<std::mutex> lock(emu);
+                        if (first_err.empty()) first_err = "panel line of " + pend[i].rsid + ": population " + pops[k].name + " does not have " + std::to_string(pops[k].size) + " genotypes";
+                        return;
+                    }
+                    int32_t c = 0;
+                    uint8_t* dst = row + pops[k].byte_off;
+                    for (int q = 0; q < n; q++) {
+                        const unsigned code = (unsigned)(g[q] - '0');
+                        if (code > 3) {
+                            std::lock_guard<std::mutex> lock(emu);
+                            if (first_err.empty()) first_err = "panel line of " + pend[i].rsid + " has a genotype outside 0..3";
+                            return;
+                        }
+                        c += (int32_t)code;
+                        dst[q >> 2] |= (uint8_t)(code << (2 * (q & 3)));
+                    }
+                    bcnt[(size_t)i * P + k] = c;
+                }
+                for (int k = 0; k < P; k++) {
+                    const char* g; int n;
+                    double v = 0.0;                           // a missing column reads as 0, like the text feeder
+                    if (d.next(g, n)) v = strtod(std::string(g, n).c_str(), nullptr);
+                    baf[(size_t)i * P + k] = v;
+                }
             }
-            int32_t c = 0;
-            uint8_t* dst = row.data() + pops[k].byte_off;
-            for (int i = 0; i < n; i++) {
-                const unsigned code = (unsigned)(g[i] - '0');
-                if (code > 3) { err = "panel line of " + std::string(b_rs, n_rs) + " has a genotype outside 0..3"; fclose(gf); remove(geno_tmp.c_str()); return -1; }
-                c += (int32_t)code;
-                dst[i >> 2] |= (uint8_t)(code << (2 * (i & 3)));
-            }
-            cnt.push_back(c);
-        }
-        for (int k = 0; k < P; k++) {
-            const char* g; int n;
-            double v = 0.0;                           // a missing column reads as 0, like the text feeder
-            if (d.next(g, n)) v = strtod(std::string(g, n).c_str(), nullptr);
-            af.push_back(v);
-        }
-        if (fwrite(row.data(), 1, row_bytes, gf) != row_bytes) { err = "short write to '" + geno_tmp + "'"; fclose(gf); remove(geno_tmp.c_str()); return -1; }
-        snps.push_back(s);
-        line.clear();
-        if (last == -1) break;
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < std::min(nt, nb); t++) th.emplace_back(work, t);
+        work(0);
+        for (std::thread& x : th) x.join();
+        if (!first_err.empty()) { err = first_err; fclose(gf); remove(geno_tmp.c_str()); return -1; }
+        af.insert(af.end(), baf.begin(), baf.end());
+        cnt.insert(cnt.end(), bcnt.begin(), bcnt.end());
+        if (fwrite(rows.data(), 1, rows.size(), gf) != rows.size()) { err = "short write to '" + geno_tmp + "'"; fclose(gf); remove(geno_tmp.c_str()); return -1; }
     }
     fclose(gf);
 
