@@ -185,6 +185,7 @@ struct gauss_job {
     int2* d_panelmap = nullptr; int n_panels = 0;
     int max_nblk = 0;
     int max_npanel = 0;                                    // most solve panels of any one window
+    int solve_split = 0;                                   // 1: small job, solve rows are cut in partial sums + combine (k_solve.hip)
     int max_pop = 1;
     int gram_i8 = 0;
     int* d_status = nullptr;                               // [n][4]
@@ -564,9 +565,17 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
 
     // ---- workspace arena ----
     Arena wa;
-    struct WsOff { size_t raw_m, raw_u, packed, sx, sxx, slab, sd, wm, mu, wmu, A, Linv, B21, V, ld, b11c, sacc; long long ldraw; };
+    struct WsOff { size_t raw_m, raw_u, packed, sx, sxx, slab, sd, wm, mu, wmu, A, Linv, B21, V, ld, b11c, sacc, part; long long ldraw; };
     std::vector<WsOff> wo(job->n);
     size_t res = 0;
+    {
+        // few panels in the whole job: the launches are latency bound and the solve's rows are split so that they hide
+        // behind the tile Cholesky (k_solve.hip); many panels: throughput bound, one workgroup per row.  The cut-off
+        // sits between the 4-5 windows an 8-rank share of a chromosome holds and a whole chromosome.
+        const char* e = getenv("GAUSS_SOLVE_SPLIT_MAX_PANELS");
+        const int cut = e ? atoi(e) : 400;
+        job->solve_split = (job->n_panels > 0 && job->n_panels <= cut) ? 1 : 0;
+    }
     for (int i = 0; i < job->n; i++) {
         Plan& pl = job->plans[i];
         Prob& p = pl.p;
@@ -599,6 +608,7 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
             w.Linv = wa.take((size_t)2 * p.nblk * NB * NB * sizeof(double));
             w.V = wa.take((size_t)p.npanel * p.Mld * NR * sizeof(double));
             w.sacc = wa.take((size_t)p.npanel * 768 * sizeof(double));
+            w.part = job->solve_split ? wa.take((size_t)p.npanel * 4 * NB * NR * sizeof(double)) : 0;
             w.b11c = wa.take((size_t)p.Mld * p.Mld * sizeof(double));
         }
         w.ld = wa.take(std::max<size_t>(pl.out_ld_count, 1) * sizeof(double));
@@ -669,6 +679,7 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
         if (!p.ld_only) { p.A = (double*)(W + w.A); p.B21 = (double*)(W + w.B21); }
         if (p.npanel > 0) {
             p.Linv = (double*)(W + w.Linv); p.V = (double*)(W + w.V); p.Sacc = (double*)(W + w.sacc);
+            p.Part = job->solve_split ? (double*)(W + w.part) : nullptr;
             pl.d_b11_copy = (double*)(W + w.b11c);
         }
         p.out_z = job->d_results + pl.res_off;
@@ -795,10 +806,10 @@ static int job_run(gauss_job* job, bool solve)
         static const bool fused = !(getenv("GAUSS_FUSED_SOLVE") && atoi(getenv("GAUSS_FUSED_SOLVE")) == 0);
         prof_begin(job, 3);
         for (int s = 0; s < job->max_nblk; s++)
-            launch_factor_step(job->d_probs, job->n, s, job->max_nblk, fused ? job->max_npanel : 0, st);
+            launch_factor_step(job->d_probs, job->n, s, job->max_nblk, fused ? job->max_npanel : 0, job->solve_split, st);
         prof_end(job);
         prof_begin(job, 4);
-        if (fused) launch_solve_last(job->d_probs, job->d_panelmap, job->n_panels, job->max_nblk, st);
+        if (fused) launch_solve_last(job->d_probs, job->d_panelmap, job->n_panels, job->max_nblk, job->solve_split, st);
         else launch_solve(job->d_probs, job->d_panelmap, job->n_panels, st);
         prof_end(job);
     }
@@ -842,7 +853,7 @@ static int job_clamp_window(gauss_job* job, int i, int* status_bits)
     HIPCHK(hipMemcpyAsync(p.A + 4 * n * n, p.A, sizeof(double) * n * n, hipMemcpyDeviceToDevice, st));   // W0 = clamped B11
     for (int s = 0; s < p.nblk; s++) {
         // launch over all problems would redo the others; use a single-problem launch instead
-        launch_factor_step(job->d_probs + i, 1, s, p.nblk, 0, st);
+        launch_factor_step(job->d_probs + i, 1, s, p.nblk, 0, 0, st);
     }
     launch_solve(job->d_probs, d_pm.as<int2>(), (int)pm.size(), st);
     HIPCHK(hipGetLastError());

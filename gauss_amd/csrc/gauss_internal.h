@@ -82,6 +82,7 @@ struct Prob {
     GP(double) Linv;           // [2][nblk][NB x NB] inverses of the diagonal Cholesky blocks
     GP(double) B21;            // [Upad x Mld] row-major (Upad = npanel*NRU rounded)
     GP(double) V;              // [npanel][Mld][NR]
+    GP(double) Part;           // [npanel][SOLVE_SPLIT][NB x NR] partial sums of a split solve row (small jobs only), else null
     GP(double) Sacc;           // [npanel][3][256] per-thread partial sums of z / info / v between the launches of a fused solve
     GP(double) out_z;          // [U]
     GP(double) out_info;       // [U]
@@ -131,9 +132,9 @@ void launch_gram(const Item* d_items, int n_items, int dtype_i8, hipStream_t s);
 void launch_epilogue(const Prob* d_probs, const int2* d_tilemap, int n_tiles, int max_pop, int dtype_i8, hipStream_t s);
 void launch_pop_cor(const Prob* d_probs, int prob, int npair, double* d_out, hipStream_t s);
 void launch_gene_epilogue(const Prob* d_probs, int prob, int n_gene, hipStream_t s);
-void launch_factor_step(const Prob* d_probs, int n_prob, int step, int max_nblk, int max_npanel, hipStream_t s);
+void launch_factor_step(const Prob* d_probs, int n_prob, int step, int max_nblk, int max_npanel, int split, hipStream_t s);
 void launch_solve(const Prob* d_probs, const int2* d_panelmap, int n_panels, hipStream_t s);
-void launch_solve_last(const Prob* d_probs, const int2* d_panelmap, int n_panels, int max_nblk, hipStream_t s);
+void launch_solve_last(const Prob* d_probs, const int2* d_panelmap, int n_panels, int max_nblk, int split, hipStream_t s);
 void launch_counts(const Prob* d_probs, int prob, int npair, long long* d_out, hipStream_t s);
 void launch_pack2bit(const uint8_t* d_in, long long ld_in, uint8_t* d_out, long long ld_out, int n_snp,
                      const int* d_pop_off, const int* d_blk_off, int n_pop, hipStream_t s);

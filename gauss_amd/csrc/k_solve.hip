@@ -383,14 +383,43 @@ static const size_t SOLVE_SMEM = ((size_t)NB * LDT + (size_t)NB * LDV + 768) * s
 
 struct SolveSums { double z, info, v; };       // per-thread partial sums: column tid % NR, rows of group tid / NR
 
-// block row kb of one panel; TL / TV are the workgroup's LDS tiles
-__device__ __forceinline__ void solve_row(const Prob& pb, int panel, int kb, double* __restrict__ TL, double* __restrict__ TV,
-                                          SolveSums& sums, int tid)
+// acc -= sum_{j = j0, j0 + jstep, ... < kb} L[kb][j] V[j]   (the products of block row kb; TL / TV: the workgroup's LDS tiles)
+__device__ __forceinline__ void solve_products(const Prob& pb, int panel, int kb, int j0, int jstep, f64x4 (&acc)[SOLVE_NT],
+                                               double* __restrict__ TL, double* __restrict__ TV, int tid)
 {
     constexpr int NT = SOLVE_NT;
     const int lane = tid & 63, wave = tid >> 6;
     const int ld = pb.Mld;
     const auto Lm = pb.A + (size_t)2 * ld * ld;               // factor of A[0]
+    const auto V = pb.V + (size_t)panel * ld * NR;
+    TileRegs rl, rv[NR / 64];
+    if (j0 < kb) {
+        tile_fetch(rl, Lm + (size_t)kb * NB * ld + (size_t)j0 * NB, ld, tid);
+#pragma unroll
+        for (int h = 0; h < NR / 64; h++) tile_fetch(rv[h], V + (size_t)j0 * NB * NR + 64 * h, NR, tid);
+    }
+    for (int jb = j0; jb < kb; jb += jstep) {
+        __syncthreads();                                  // previous tiles are no longer being read
+        tile_commit<LDT>(TL, rl, tid);
+#pragma unroll
+        for (int h = 0; h < NR / 64; h++) tile_commit<LDV>(TV + 64 * h, rv[h], tid);
+        __syncthreads();
+        if (jb + jstep < kb) {                            // next tiles fly during the product
+            tile_fetch(rl, Lm + (size_t)kb * NB * ld + (size_t)(jb + jstep) * NB, ld, tid);
+#pragma unroll
+            for (int h = 0; h < NR / 64; h++) tile_fetch(rv[h], V + (size_t)(jb + jstep) * NB * NR + 64 * h, NR, tid);
+        }
+        mfma_nn<NT, true>(acc, TL, TV, wave, lane);       // acc = - sum_j L_kj V_j
+    }
+}
+
+// X = B_kb + acc;  V_kb = Linv_kk X  (stored);  z / info sums of the block's rows
+__device__ __forceinline__ void solve_tail(const Prob& pb, int panel, int kb, f64x4 (&acc)[SOLVE_NT], double* __restrict__ TL,
+                                           double* __restrict__ TV, SolveSums& sums, int tid)
+{
+    constexpr int NT = SOLVE_NT;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int ld = pb.Mld;
     const auto Linv = pb.Linv;                                // matrix 0
     const auto V = pb.V + (size_t)panel * ld * NR;
     const int u0 = panel * NRU;
@@ -400,29 +429,6 @@ __device__ __forceinline__ void solve_row(const Prob& pb, int panel, int kb, dou
     // (rows n_head .. of the symmetric A[0], which the factorisation leaves intact), then the B21 rows
     const auto Brow = pb.A + (size_t)pb.n_head * ld;
     const int cc = tid % NR, rg = tid / NR;
-
-    f64x4 acc[NT];
-#pragma unroll
-    for (int n = 0; n < NT; n++) acc[n] = f64x4{0.0, 0.0, 0.0, 0.0};
-    TileRegs rl, rv[NR / 64];
-    if (kb > 0) {
-        tile_fetch(rl, Lm + (size_t)kb * NB * ld, ld, tid);
-#pragma unroll
-        for (int h = 0; h < NR / 64; h++) tile_fetch(rv[h], V + 64 * h, NR, tid);
-    }
-    for (int jb = 0; jb < kb; jb++) {
-        __syncthreads();                                  // previous tiles are no longer being read
-        tile_commit<LDT>(TL, rl, tid);
-#pragma unroll
-        for (int h = 0; h < NR / 64; h++) tile_commit<LDV>(TV + 64 * h, rv[h], tid);
-        __syncthreads();
-        if (jb + 1 < kb) {                                // next tiles fly during the product
-            tile_fetch(rl, Lm + (size_t)kb * NB * ld + (size_t)(jb + 1) * NB, ld, tid);
-#pragma unroll
-            for (int h = 0; h < NR / 64; h++) tile_fetch(rv[h], V + (size_t)(jb + 1) * NB * NR + 64 * h, NR, tid);
-        }
-        mfma_nn<NT, true>(acc, TL, TV, wave, lane);       // acc = - sum_j L_kj V_j
-    }
     __syncthreads();
     // TV <- rhs block: column c < NRU: B21[u0+c][kb*64 + r]; column NRU: z1 (zero padded)
     for (int e = tid; e < NB * NR; e += 256) {
@@ -469,6 +475,17 @@ __device__ __forceinline__ void solve_row(const Prob& pb, int panel, int kb, dou
         sums.info = fma(x, x, sums.info);
         sums.v += x;
     }
+}
+
+// block row kb of one panel, all of it in this workgroup
+__device__ __forceinline__ void solve_row(const Prob& pb, int panel, int kb, double* __restrict__ TL, double* __restrict__ TV,
+                                          SolveSums& sums, int tid)
+{
+    f64x4 acc[SOLVE_NT];
+#pragma unroll
+    for (int n = 0; n < SOLVE_NT; n++) acc[n] = f64x4{0.0, 0.0, 0.0, 0.0};
+    solve_products(pb, panel, kb, 0, 1, acc, TL, TV, tid);
+    solve_tail(pb, panel, kb, acc, TL, TV, sums, tid);
 }
 
 // after the last block row: combine the per-thread sums and write z / info (or the QCAT correlation)
@@ -521,6 +538,60 @@ __device__ __forceinline__ void solve_row_fused(const Prob& pb, int panel, int k
     SolveSums sums{0.0, 0.0, 0.0};
     if (kb > 0) { sums.z = S[tid]; sums.info = S[256 + tid]; sums.v = S[512 + tid]; }
     solve_row(pb, panel, kb, TL, TV, sums, tid);
+    if (kb == pb.nblk - 1) solve_finish(pb, panel, red, sums, tid);
+    else { S[tid] = sums.z; S[256 + tid] = sums.info; S[512 + tid] = sums.v; }
+}
+
+// ---- split form of a fused block row (small batches) ------------------------------------------------------------
+// With few windows per job the launches are latency bound and a row's kb dependent products (kb up to 18) outlast the
+// tile Cholesky they are meant to hide behind.  The row is then cut in two launches: SOLVE_SPLIT workgroups form the
+// partial sums of every SOLVE_SPLIT-th product in update(kb) (at most 5 products each) and park them in pb.Part;
+// one workgroup per panel adds them up (fixed order), applies Linv_kk and does the row's bookkeeping in the next
+// launch, panel(kb + 1), or in solve_last_kernel for the last two rows of the batch.  Large batches are throughput
+// bound and keep the one-workgroup row (the partial tiles would add two thirds to its traffic).
+constexpr int SOLVE_SPLIT = 4;
+
+__device__ __forceinline__ void solve_partial(const Prob& pb, int panel, int kb, int g, double* __restrict__ smem, int tid)
+{
+    double* TL = smem;
+    double* TV = TL + NB * LDT;
+    f64x4 acc[SOLVE_NT];
+#pragma unroll
+    for (int n = 0; n < SOLVE_NT; n++) acc[n] = f64x4{0.0, 0.0, 0.0, 0.0};
+    solve_products(pb, panel, kb, g, SOLVE_SPLIT, acc, TL, TV, tid);
+    const auto P = pb.Part + ((size_t)panel * SOLVE_SPLIT + g) * (NB * NR);
+#pragma unroll
+    for (int n = 0; n < SOLVE_NT; n++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) P[(size_t)(n * 4 + r) * 256 + tid] = acc[n][r];      // register layout, coalesced
+}
+
+// second half of a split row: sums may be carried in registers by the caller (carry = true) or through pb.Sacc
+__device__ __forceinline__ void solve_combine(const Prob& pb, int panel, int kb, double* __restrict__ smem, SolveSums& sums, int tid)
+{
+    double* TL = smem;
+    double* TV = TL + NB * LDT;
+    f64x4 acc[SOLVE_NT];
+#pragma unroll
+    for (int n = 0; n < SOLVE_NT; n++) acc[n] = f64x4{0.0, 0.0, 0.0, 0.0};
+    const int np = kb < SOLVE_SPLIT ? kb : SOLVE_SPLIT;           // partial sums that exist for this row
+    for (int g = 0; g < np; g++) {
+        const auto P = pb.Part + ((size_t)panel * SOLVE_SPLIT + g) * (NB * NR);
+#pragma unroll
+        for (int n = 0; n < SOLVE_NT; n++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) acc[n][r] += P[(size_t)(n * 4 + r) * 256 + tid];
+    }
+    solve_tail(pb, panel, kb, acc, TL, TV, sums, tid);
+}
+
+__device__ __forceinline__ void solve_combine_fused(const Prob& pb, int panel, int kb, double* __restrict__ smem, int tid)
+{
+    double* red = smem + NB * LDT + NB * LDV;
+    const auto S = pb.Sacc + (size_t)panel * 768;
+    SolveSums sums{0.0, 0.0, 0.0};
+    if (kb > 0) { sums.z = S[tid]; sums.info = S[256 + tid]; sums.v = S[512 + tid]; }
+    solve_combine(pb, panel, kb, smem, sums, tid);
     if (kb == pb.nblk - 1) solve_finish(pb, panel, red, sums, tid);
     else { S[tid] = sums.z; S[256 + tid] = sums.info; S[512 + tid] = sums.v; }
 }
@@ -605,7 +676,7 @@ __global__ __launch_bounds__(256) void factor_init_kernel(const Prob* __restrict
 }
 
 // panel(s): grid.x = max_nblk - 1 - s (block row k = s + 1 + x), grid.y = problem * 2 + matrix
-__global__ __launch_bounds__(256) void factor_panel_kernel(const Prob* __restrict__ probs, int s)
+__global__ __launch_bounds__(256) void factor_panel_kernel(const Prob* __restrict__ probs, int s, int T)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* TA = smem;                 // W[k][s]
@@ -613,6 +684,12 @@ __global__ __launch_bounds__(256) void factor_panel_kernel(const Prob* __restric
     const Prob& pb = probs[blockIdx.y >> 1];
     const int mat = blockIdx.y & 1;
     if (pb.ld_only || pb.npanel == 0) return;
+    if ((int)blockIdx.x >= T) {
+        // split solve: second half of block row s - 1 (its partial sums were formed in update(s - 1))
+        const int panel = (int)blockIdx.x - T;
+        if (mat == 0 && s >= 1 && panel < pb.npanel && s - 1 < pb.nblk) solve_combine_fused(pb, panel, s - 1, smem, threadIdx.x);
+        return;
+    }
     if (mat == 1 && pb.status[3]) return;              // certified: lambda_min(B11) > eps
     const int nb = pb.nblk;
     const int k = s + 1 + blockIdx.x;
@@ -641,7 +718,7 @@ __global__ __launch_bounds__(256) void factor_panel_kernel(const Prob* __restric
 }
 
 // update(s): grid.x = T (T + 1) / 2 with T = max_nblk - 1 - s; x = 0 is tile (s+1, s+1)
-__global__ __launch_bounds__(256) void factor_update_kernel(const Prob* __restrict__ probs, int s, int T, int n_tri)
+__global__ __launch_bounds__(256) void factor_update_kernel(const Prob* __restrict__ probs, int s, int T, int n_tri, int split)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* TA = smem;                 // L[k][s]            | D (next diagonal tile)
@@ -651,9 +728,15 @@ __global__ __launch_bounds__(256) void factor_update_kernel(const Prob* __restri
     const int mat = blockIdx.y & 1;
     if (pb.ld_only || pb.npanel == 0) return;
     if ((int)blockIdx.x >= n_tri) {
-        // block row s of the forward solve, one workgroup per right-hand-side panel, riding in this launch
-        const int panel = (int)blockIdx.x - n_tri;
-        if (mat == 0 && panel < pb.npanel && s < pb.nblk) solve_row_fused(pb, panel, s, smem, threadIdx.x);
+        // block row s of the forward solve riding in this launch: one workgroup per right-hand-side panel, or (split
+        // form) SOLVE_SPLIT workgroups per panel that only form partial sums
+        const int idx = (int)blockIdx.x - n_tri;
+        if (!split) {
+            if (mat == 0 && idx < pb.npanel && s < pb.nblk) solve_row_fused(pb, idx, s, smem, threadIdx.x);
+        } else {
+            const int panel = idx / SOLVE_SPLIT, g = idx % SOLVE_SPLIT;
+            if (mat == 0 && panel < pb.npanel && s < pb.nblk && g < s) solve_partial(pb, panel, s, g, smem, threadIdx.x);
+        }
         return;
     }
     if (mat == 1 && pb.status[3]) return;              // certified: lambda_min(B11) > eps
@@ -709,14 +792,14 @@ static const size_t FACTOR_SMEM = (size_t)2 * NB * LDT * sizeof(double);
 // step 0 factors the first diagonal block; step s >= 1 builds block column s-1 and updates the trailing matrix.
 // max_npanel > 0: the update launch of block column c also carries block row c of the forward solve for every
 // right-hand-side panel (see the K6/K7 notes above); 0: factorisation only.
-void launch_factor_step(const Prob* d_probs, int n_prob, int step, int max_nblk, int max_npanel, hipStream_t st)
+void launch_factor_step(const Prob* d_probs, int n_prob, int step, int max_nblk, int max_npanel, int split, hipStream_t st)
 {
     if (n_prob <= 0 || step >= max_nblk) return;
     const size_t upd_smem = std::max(FACTOR_SMEM, SOLVE_SMEM);
     static std::atomic<unsigned long long> attr_set{0};
     if (first_use_on_device(attr_set)) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(factor_init_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FACTOR_SMEM);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(factor_panel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FACTOR_SMEM);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(factor_panel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)upd_smem);
         hipFuncSetAttribute(reinterpret_cast<const void*>(factor_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)upd_smem);
     }
     if (step == 0) {
@@ -729,9 +812,12 @@ void launch_factor_step(const Prob* d_probs, int n_prob, int step, int max_nblk,
     const int T = max_nblk - 1 - s;
     if (T <= 0) return;
     const int n_tri = T * (T + 1) / 2;
-    hipLaunchKernelGGL(factor_panel_kernel, dim3(T, n_prob * 2), dim3(256), FACTOR_SMEM, st, d_probs, s);
-    hipLaunchKernelGGL(factor_update_kernel, dim3(n_tri + (max_npanel > 0 ? max_npanel : 0), n_prob * 2), dim3(256), upd_smem, st,
-                       d_probs, s, T, n_tri);
+    const bool fuse = max_npanel > 0;
+    const bool sp = fuse && split;
+    hipLaunchKernelGGL(factor_panel_kernel, dim3(T + (sp ? max_npanel : 0), n_prob * 2), dim3(256), sp ? upd_smem : FACTOR_SMEM, st,
+                       d_probs, s, T);
+    hipLaunchKernelGGL(factor_update_kernel, dim3(n_tri + (fuse ? max_npanel * (sp ? SOLVE_SPLIT : 1) : 0), n_prob * 2), dim3(256),
+                       upd_smem, st, d_probs, s, T, n_tri, sp ? 1 : 0);
 }
 
 __global__ __launch_bounds__(256) void solve_kernel(const Prob* __restrict__ probs,
@@ -749,15 +835,33 @@ __global__ __launch_bounds__(256) void solve_kernel(const Prob* __restrict__ pro
     solve_finish(pb, pm.y, red, sums, tid);
 }
 
-// last block row of the windows that are as tall as the batch's tallest one (no update launch carries it)
+// What the update launches could not carry: the last block row of the windows that are as tall as the batch's tallest
+// one and, in the split form, the second half of the row before it.
 __global__ __launch_bounds__(256) void solve_last_kernel(const Prob* __restrict__ probs, const int2* __restrict__ panelmap,
-                                                         int s_last)
+                                                         int s_last, int split)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int2 pm = panelmap[blockIdx.x];
     const Prob& pb = probs[pm.x];
-    if (pb.nblk - 1 != s_last) return;
-    solve_row_fused(pb, pm.y, s_last, smem, threadIdx.x);
+    const int last = pb.nblk - 1, tid = threadIdx.x, panel = pm.y;
+    if (!split) {
+        if (last == s_last) solve_row_fused(pb, panel, s_last, smem, tid);
+        return;
+    }
+    if (last < s_last - 1) return;                          // this window finished in an earlier launch
+    double* TL = smem;
+    double* TV = TL + NB * LDT;
+    double* red = TV + NB * LDV;
+    const auto S = pb.Sacc + (size_t)panel * 768;
+    SolveSums sums{0.0, 0.0, 0.0};
+    if (s_last >= 1) {
+        const int r = s_last - 1;                           // partial sums from update(r), the batch's last update launch
+        if (r > 0) { sums.z = S[tid]; sums.info = S[256 + tid]; sums.v = S[512 + tid]; }
+        solve_combine(pb, panel, r, smem, sums, tid);
+        if (r == last) { solve_finish(pb, panel, red, sums, tid); return; }
+    }
+    solve_row(pb, panel, s_last, TL, TV, sums, tid);        // last == s_last
+    solve_finish(pb, panel, red, sums, tid);
 }
 
 void launch_solve(const Prob* d_probs, const int2* d_panelmap, int n_panels, hipStream_t s)
@@ -769,13 +873,13 @@ void launch_solve(const Prob* d_probs, const int2* d_panelmap, int n_panels, hip
     hipLaunchKernelGGL(solve_kernel, dim3(n_panels), dim3(256), SOLVE_SMEM, s, d_probs, d_panelmap);
 }
 
-void launch_solve_last(const Prob* d_probs, const int2* d_panelmap, int n_panels, int max_nblk, hipStream_t s)
+void launch_solve_last(const Prob* d_probs, const int2* d_panelmap, int n_panels, int max_nblk, int split, hipStream_t s)
 {
     if (n_panels <= 0 || max_nblk < 1) return;
     static std::atomic<unsigned long long> attr_set{0};
     if (first_use_on_device(attr_set))
         hipFuncSetAttribute(reinterpret_cast<const void*>(solve_last_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SOLVE_SMEM);
-    hipLaunchKernelGGL(solve_last_kernel, dim3(n_panels), dim3(256), SOLVE_SMEM, s, d_probs, d_panelmap, max_nblk - 1);
+    hipLaunchKernelGGL(solve_last_kernel, dim3(n_panels), dim3(256), SOLVE_SMEM, s, d_probs, d_panelmap, max_nblk - 1, split);
 }
 
 }  // namespace gauss

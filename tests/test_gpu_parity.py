@@ -451,3 +451,34 @@ def test_ld_and_gene_batches_over_row_stores_equal_the_byte_calls(ctx, mode):
     res.close()
     want = oracle.compute_ld(G[pick], off, w) if mode == 1 else oracle.ld_pooled(G[pick], off, diag)
     assert np.max(np.abs(want_ld - want)) <= 1e-12
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_solve_forms_agree(ctx, mode, monkeypatch):
+    """The forward solve has three drivers for the same block-row routine (k_solve.hip): rows riding whole in the
+    factorisation's update launches (large jobs), rows split into partial sums + combine (small jobs, the default
+    for anything a test builds) and the stand-alone kernel.  Same windows through all three: each within 1e-8 of
+    the oracle, and within 1e-11 of each other (the split form adds its partial sums in a different order)."""
+    p = small_panel(n_snp=420, scale=0.03, seed=5)
+    G, off = p["G"], p["off"]
+    rng = np.random.default_rng(2)
+    wins = []
+    for (m, u) in [(300, 100), (130, 200), (65, 70), (64, 10)]:          # 5, 3, 2 and 1 factor blocks
+        idx = rng.permutation(G.shape[0])
+        gm, gu = np.ascontiguousarray(G[np.sort(idx[:m])]), np.ascontiguousarray(G[np.sort(idx[m:m + u])])
+        wins.append(dict(mode=mode, geno_m=gm, geno_u=gu, pop_off=off, pop_wgt=p["w"], z1=rng.standard_normal(m) * 2))
+    out = {}
+    for name, env in (("split", {"GAUSS_SOLVE_SPLIT_MAX_PANELS": "100000"}), ("rows", {"GAUSS_SOLVE_SPLIT_MAX_PANELS": "0"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        job = hotpath.Job(wins, ctx=ctx)
+        job.run()
+        out[name] = job.fetch()
+        job.close()
+    for w, a, b in zip(wins, out["split"], out["rows"]):
+        want = oracle.run_impute(mode, w["geno_m"], w["geno_u"], off, p["w"], w["z1"])
+        for r in (a, b):
+            assert r["status"] == 0
+            assert relerr(r["info"], want["info"]) <= Z_TOL
+            assert np.max(np.abs(r["z"] - want["z"]) / np.maximum(1.0, np.abs(want["z"]))) <= Z_TOL
+        assert relerr(a["info"], b["info"]) <= 1e-11 and np.max(np.abs(a["z"] - b["z"])) <= 1e-10
