@@ -379,6 +379,7 @@ __device__ __forceinline__ GP(double) factor_work(const Prob& pb, int mat)
 constexpr int SOLVE_NT = NR / 16;              // accumulator tiles (16 columns each) per wave
 constexpr int SOLVE_NG = 256 / NR;             // row groups of the z / info reduction
 constexpr int SOLVE_RG = NB / SOLVE_NG;        // rows per group
+constexpr int SOLVE_SPLIT = 4;                 // interleaved classes of a row's products (see solve_row / the split form)
 static const size_t SOLVE_SMEM = ((size_t)NB * LDT + (size_t)NB * LDV + 768) * sizeof(double);
 
 struct SolveSums { double z, info, v; };       // per-thread partial sums: column tid % NR, rows of group tid / NR
@@ -477,14 +478,25 @@ __device__ __forceinline__ void solve_tail(const Prob& pb, int panel, int kb, f6
     }
 }
 
-// block row kb of one panel, all of it in this workgroup
+// block row kb of one panel, all of it in this workgroup.  The products are summed in SOLVE_SPLIT interleaved classes
+// (j = g, g + SOLVE_SPLIT, ...) that are then added in class order -- the association the split form (below) needs for
+// its partial sums -- so that every driver of the solve returns the same bits.
 __device__ __forceinline__ void solve_row(const Prob& pb, int panel, int kb, double* __restrict__ TL, double* __restrict__ TV,
                                           SolveSums& sums, int tid)
 {
     f64x4 acc[SOLVE_NT];
 #pragma unroll
     for (int n = 0; n < SOLVE_NT; n++) acc[n] = f64x4{0.0, 0.0, 0.0, 0.0};
-    solve_products(pb, panel, kb, 0, 1, acc, TL, TV, tid);
+    for (int g = 0; g < SOLVE_SPLIT && g < kb; g++) {
+        f64x4 part[SOLVE_NT];
+#pragma unroll
+        for (int n = 0; n < SOLVE_NT; n++) part[n] = f64x4{0.0, 0.0, 0.0, 0.0};
+        solve_products(pb, panel, kb, g, SOLVE_SPLIT, part, TL, TV, tid);
+#pragma unroll
+        for (int n = 0; n < SOLVE_NT; n++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) acc[n][r] += part[n][r];
+    }
     solve_tail(pb, panel, kb, acc, TL, TV, sums, tid);
 }
 
@@ -549,8 +561,6 @@ __device__ __forceinline__ void solve_row_fused(const Prob& pb, int panel, int k
 // one workgroup per panel adds them up (fixed order), applies Linv_kk and does the row's bookkeeping in the next
 // launch, panel(kb + 1), or in solve_last_kernel for the last two rows of the batch.  Large batches are throughput
 // bound and keep the one-workgroup row (the partial tiles would add two thirds to its traffic).
-constexpr int SOLVE_SPLIT = 4;
-
 __device__ __forceinline__ void solve_partial(const Prob& pb, int panel, int kb, int g, double* __restrict__ smem, int tid)
 {
     double* TL = smem;
