@@ -169,3 +169,32 @@ void packed_window_body(gauss_ctx* ctx, const uint8_t* mapped_rows, int64_t row_
   gauss_job_destroy(job);
   gauss_store_free(ctx, dev);
 }
+
+// ---- section 5e: a whole chromosome per call (include/gauss_host.h) ----
+#include "gauss_host.h"
+struct ChromTable { std::vector<std::string> rsid; std::vector<int> bp, window; std::vector<double> z, info; };
+ChromTable distmix_chromosome_body(int chr, long long start_bp, long long end_bp, long long wing_size, long long window_size,
+                                   const std::vector<std::string>& names, const std::vector<double>& wgts,
+                                   const std::string& input_file, const std::string& packed_panel, const std::string& desc) {
+  std::vector<const char*> np;
+  for (auto& s : names) np.push_back(s.c_str());
+  gauss_table* t = nullptr;
+  gauss_chrom_stats st;
+  if (gauss_host_impute_chromosome(gauss_hip_ctx(), GAUSS_KIND_DISTMIX, chr, start_bp, end_bp, wing_size, window_size, NULL,
+                                   np.data(), wgts.data(), (int)np.size(), input_file.c_str(), packed_panel.c_str(), desc.c_str(),
+                                   NAN, /*rank*/0, /*world*/1, /*n_batches*/0, &t, &st) != 0)
+    Rcpp::stop(gauss_host_last_error());
+  ChromTable out;
+  const int n = gauss_table_nrow(t);
+  for (int c = 0; c < gauss_table_ncol(t); c++) {
+    const std::string name = gauss_table_colname(t, c);
+    if (name == "rsid") for (int r = 0; r < n; r++) out.rsid.push_back(gauss_table_str(t, c, r));
+    else if (name == "bp") out.bp.assign(gauss_table_int(t, c), gauss_table_int(t, c) + n);
+    else if (name == "window") out.window.assign(gauss_table_int(t, c), gauss_table_int(t, c) + n);
+    else if (name == "z") out.z.assign(gauss_table_dbl(t, c), gauss_table_dbl(t, c) + n);
+    else if (name == "info") out.info.assign(gauss_table_dbl(t, c), gauss_table_dbl(t, c) + n);
+  }
+  for (int k = 0; k < gauss_table_n_messages(t); k++) (void)gauss_table_message(t, k);     // one text per failed window
+  gauss_table_free(t);
+  return out;
+}
