@@ -1216,7 +1216,9 @@ int gauss_job_stats(gauss_job* job, double* out4)
             for (int wr = 0; wr < 2; wr++)
                 for (int wc = 0; wc < 2; wc++) {
                     if (ti == tj && wr == 1 && wc == 0) continue;
-                    tiles32 += halves(rows(ti), wr) * halves(rows(tj), wc);
+                    double t32 = halves(rows(ti), wr) * halves(rows(tj), wc);
+                    if (ti == tj && wr == wc && t32 == 4) t32 = 3;      // mirrored 32 x 32 sub-block of a diagonal quadrant
+                    tiles32 += t32;
                 }
             flops += tiles32 * 32.0 * 32.0 * 2.0 * p.Kp;
         }

@@ -40,7 +40,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // pack_stats_kernel): v_cvt_pk_f32_fp8 expands TWO of them per VALU instruction, exactly.  VALU
 // issue is not free next to the fp32 MFMA (each VALU op costs about 6 cycles of matrix-pipe time on
 // gfx950, measured), so halving the converts is worth ~5 % of the kernel.
-template <int NA, int NB>
+// SK10: the wave sits on the diagonal of a diagonal tile (its 64 x 64 block is symmetric): the lower-left 32 x 32
+// sub-block mirrors the upper-right one, no reader of the slab looks at it, its MFMAs are not issued.
+template <int NA, int NB, bool SK10>
 __device__ __forceinline__ void chunk_mfma(const uint8_t* __restrict__ la, const uint8_t* __restrict__ lb,
                                            const int (&aoff)[2], const int (&boff)[2], f32x16& acc00, f32x16& acc01,
                                            f32x16& acc10, f32x16& acc11)
@@ -56,7 +58,7 @@ __device__ __forceinline__ void chunk_mfma(const uint8_t* __restrict__ la, const
             acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[e], fb0[e], acc00, 0, 0, 0);              \
             if (NB > 1) acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[e], fb1[e], acc01, 0, 0, 0);  \
             if (NA > 1) {                                                                              \
-                acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[e], fb0[e], acc10, 0, 0, 0);          \
+                if (!SK10) acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[e], fb0[e], acc10, 0, 0, 0); \
                 if (NB > 1) acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[e], fb1[e], acc11, 0, 0, 0); \
             }                                                                                          \
         }                                                                                              \
@@ -87,7 +89,7 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 // The same chunk on the int8 matrix cores (v_mfma_i32_32x32x32_i8): operands are the raw genotype
 // codes, 16 bytes per lane and MFMA, sums are exact int32.  The 16 bytes a lane reads for A and for B
 // cover the same k positions, so the products line up whatever the instruction's internal k order is.
-template <int NA, int NB>
+template <int NA, int NB, bool SK10>
 __device__ __forceinline__ void chunk_mfma(const uint8_t* __restrict__ la, const uint8_t* __restrict__ lb,
                                            const int (&aoff)[2], const int (&boff)[2], i32x16& acc00, i32x16& acc01,
                                            i32x16& acc10, i32x16& acc11)
@@ -102,7 +104,7 @@ __device__ __forceinline__ void chunk_mfma(const uint8_t* __restrict__ la, const
             acc01 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b1, acc01, 0, 0, 0);
             if (NA > 1) {
                 const i32x4 a1 = *reinterpret_cast<const i32x4*>(la + aoff[g] + 32 * LROW);
-                acc10 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b0, acc10, 0, 0, 0);
+                if (!SK10) acc10 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b0, acc10, 0, 0, 0);
                 acc11 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b1, acc11, 0, 0, 0);
             }
         } else if (NA > 1) {
@@ -135,7 +137,7 @@ __device__ __forceinline__ void wait_dma_barrier_dyn(int groups_newer)
     else wait_dma_barrier<8>();
 }
 
-template <int NA, int NB, typename ACC, int NS>
+template <int NA, int NB, typename ACC, int NS, bool SK10 = false>
 __device__ __forceinline__ void run_item(const Item& it, uint8_t* lds, int wr, int wc)
 {
     const int Kp = it.Kp;
@@ -209,7 +211,7 @@ __device__ __forceinline__ void run_item(const Item& it, uint8_t* lds, int wr, i
             }
             const uint8_t* la = lds + cur * 2 * LTILE;
             const uint8_t* lb = la + LTILE;
-            if (NA > 0) chunk_mfma<NA, NB>(la, lb, aoff, boff, acc00, acc01, acc10, acc11);
+            if (NA > 0) chunk_mfma<NA, NB, SK10>(la, lb, aoff, boff, acc00, acc01, acc10, acc11);
             wait_dma_barrier_dyn<NS>(ahead - 1);         // next chunk landed; everyone is done reading this one
             if (ahead > 0) ahead--;
             cur = (cur + 1 == NS) ? 0 : cur + 1;
@@ -224,7 +226,7 @@ __device__ __forceinline__ void run_item(const Item& it, uint8_t* lds, int wr, i
                 out[o] = slab_bits(acc00[r]);
                 if (NB > 1) out[o + 32] = slab_bits(acc01[r]);
                 if (NA > 1) {
-                    out[o + 32 * TILE] = slab_bits(acc10[r]);
+                    if (!SK10) out[o + 32 * TILE] = slab_bits(acc10[r]);
                     if (NB > 1) out[o + 32 * TILE + 32] = slab_bits(acc11[r]);
                 }
             }
@@ -252,6 +254,7 @@ __global__ __launch_bounds__(256, OCC) void gram_kernel(const Item* __restrict__
     // diagonal tile: the lower-left 64 x 64 quadrant mirrors the upper-right one and is never read
     if (it.diag && wr == 1 && wc == 0) na = 0;
     if (na == 0 || nb == 0) run_item<0, 0, ACC, NS>(it, lds, wr, wc);
+    else if (na == 2 && nb == 2 && it.diag && wr == wc) run_item<2, 2, ACC, NS, true>(it, lds, wr, wc);
     else if (na == 2 && nb == 2) run_item<2, 2, ACC, NS>(it, lds, wr, wc);
     else if (na == 2) run_item<2, 1, ACC, NS>(it, lds, wr, wc);
     else if (nb == 2) run_item<1, 2, ACC, NS>(it, lds, wr, wc);
