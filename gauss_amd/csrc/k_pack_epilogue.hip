@@ -68,35 +68,8 @@ __global__ __launch_bounds__(256) void pack_stats_kernel(const Prob* __restrict_
     }
     __syncthreads();
 
-    const int nloop = (nwords + 255) & ~255;
-    for (int w0 = threadIdx.x; w0 < nloop; w0 += 256) {
-        const bool live = w0 < nwords;                // keep whole waves in the loop for the cross-lane sums
-        const int w = live ? w0 : nwords - 1;
-        const int run = tab_lds ? s_word[w] : (fmt2 ? pb.word_run[w] : pb.word_pop[w]);
-        const int p = (pb.P == 1) ? 0 : run;          // pooled statistics see one pseudo-population
-        const int o = (w << 4) - s_pk[run];
-        uint32_t v[4] = {0u, 0u, 0u, 0u};
-        if (fmt2) {
-            // 2-bit packed source: 16 samples = 4 bytes; blocks are 16-byte aligned and zero padded to 64
-            // samples, i.e. they have exactly the packed operand layout at a quarter of the bytes
-            const uint32_t bits = live ? *reinterpret_cast<const uint32_t*>(src + s_src[run] + (o >> 2)) : 0u;
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const uint32_t b = (bits >> (8 * q)) & 0xFFu;
-                v[q] = (b & 3u) | (((b >> 2) & 3u) << 8) | (((b >> 4) & 3u) << 16) | (((b >> 6) & 3u) << 24);
-            }
-        } else {
-            int valid = s_len[run] - o;
-            valid = valid < 0 ? 0 : (valid > 16 ? 16 : valid);
-            if (!live) valid = 0;
-            const uint8_t* s = src + s_src[run] + o;
-            if (valid == 16) {
-#pragma unroll
-                for (int q = 0; q < 4; q++) v[q] = reinterpret_cast<const U32u*>(s + 4 * q)->v;
-            } else {
-                for (int b = 0; b < valid; b++) v[b >> 2] |= (uint32_t)s[b] << (8 * (b & 3));
-            }
-        }
+    // one packed word (16 samples) of the row: recode, per-population sums, operand encoding, store
+    auto finish_word = [&](int w, bool live, int p, uint32_t (&v)[4]) {
         int sx = 0, sxx = 0;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -140,6 +113,73 @@ __global__ __launch_bounds__(256) void pack_stats_kernel(const Prob* __restrict_
             if ((threadIdx.x & 63) == 0 && sx) { atomicAdd(&s_sx[p0], sx); atomicAdd(&s_sxx[p0], sxx); }
         } else if (sx) {
             atomicAdd(&s_sx[p], sx); atomicAdd(&s_sxx[p], sxx);
+        }
+    };
+
+    const int nloop = (nwords + 255) & ~255;
+    if (fmt2 && tab_lds) {
+        // 2-bit packed source: 16 samples = 4 bytes; blocks are 16-byte aligned and zero padded to 64 samples, i.e. they
+        // have exactly the packed operand layout at a quarter of the bytes.  A lane's load is only 4 bytes, so several
+        // words per lane are requested before the first is used (the row is 8 KB: bytes in flight, not bandwidth,
+        // set the pace of a one-load-at-a-time loop).
+#ifndef GAUSS_PACK_BATCH
+#define GAUSS_PACK_BATCH 4
+#endif
+        constexpr int PB = GAUSS_PACK_BATCH;
+        for (int w0 = threadIdx.x; w0 < nloop; w0 += PB * 256) {
+            uint32_t bits[PB];
+            int ww[PB], pp[PB];
+            bool lv[PB];
+#pragma unroll
+            for (int j = 0; j < PB; j++) {
+                const int wj = w0 + 256 * j;
+                lv[j] = wj < nwords;
+                ww[j] = lv[j] ? wj : nwords - 1;
+                const int run = s_word[ww[j]];
+                pp[j] = (pb.P == 1) ? 0 : run;
+                const int o = (ww[j] << 4) - s_pk[run];
+                bits[j] = lv[j] ? *reinterpret_cast<const uint32_t*>(src + s_src[run] + (o >> 2)) : 0u;
+            }
+#pragma unroll
+            for (int j = 0; j < PB; j++) {
+                if (w0 + 256 * j >= nloop) break;              // whole waves stay together: nloop is a multiple of 256
+                uint32_t v[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t b = (bits[j] >> (8 * q)) & 0xFFu;
+                    v[q] = (b & 3u) | (((b >> 2) & 3u) << 8) | (((b >> 4) & 3u) << 16) | (((b >> 6) & 3u) << 24);
+                }
+                finish_word(ww[j], lv[j], pp[j], v);
+            }
+        }
+    } else {
+        for (int w0 = threadIdx.x; w0 < nloop; w0 += 256) {
+            const bool live = w0 < nwords;                // keep whole waves in the loop for the cross-lane sums
+            const int w = live ? w0 : nwords - 1;
+            const int run = tab_lds ? s_word[w] : (fmt2 ? pb.word_run[w] : pb.word_pop[w]);
+            const int p = (pb.P == 1) ? 0 : run;          // pooled statistics see one pseudo-population
+            const int o = (w << 4) - s_pk[run];
+            uint32_t v[4] = {0u, 0u, 0u, 0u};
+            if (fmt2) {
+                const uint32_t bits = live ? *reinterpret_cast<const uint32_t*>(src + s_src[run] + (o >> 2)) : 0u;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t b = (bits >> (8 * q)) & 0xFFu;
+                    v[q] = (b & 3u) | (((b >> 2) & 3u) << 8) | (((b >> 4) & 3u) << 16) | (((b >> 6) & 3u) << 24);
+                }
+            } else {
+                int valid = s_len[run] - o;
+                valid = valid < 0 ? 0 : (valid > 16 ? 16 : valid);
+                if (!live) valid = 0;
+                const uint8_t* s = src + s_src[run] + o;
+                if (valid == 16) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) v[q] = reinterpret_cast<const U32u*>(s + 4 * q)->v;
+                } else {
+                    for (int b = 0; b < valid; b++) v[b >> 2] |= (uint32_t)s[b] << (8 * (b & 3));
+                }
+            }
+            finish_word(w, live, p, v);
         }
     }
     __syncthreads();
