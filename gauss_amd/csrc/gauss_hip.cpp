@@ -348,6 +348,12 @@ static int plan_problem(const WinSpec& w, Plan& pl, int seg_max, int group_targe
     if (w.rows_m) pl.rows_m.assign(w.rows_m, w.rows_m + w.M);
     if (w.rows_u && w.U > 0) pl.rows_u.assign(w.rows_u, w.rows_u + w.U);
     p.Kp = pl.pop_pk_off[P];
+    // 16-bit partial slabs: 2-bit sources carry codes 0..3 (recoding only lowers them), so a segment of at most 7168
+    // samples sums to <= 9 * 7168 < 2^16; the fast epilogue reads them (windows with LDS-resident population tables);
+    // LD-only calls and gene batches keep f32 / int32 slabs
+    static const bool no16 = getenv("GAUSS_NO_SLAB16") != nullptr;
+    p.slab16 = (!no16 && w.geno_fmt == GAUSS_GENO_2BIT && !w.ld_only && !w.gene_off && P <= 32) ? 1 : 0;
+    if (p.slab16) seg_max = std::min(seg_max, 7168);
     pl.word_pop.assign(p.Kp / 16, 0);
     pl.pop_seg0.assign(P + 1, 0);
     for (int q = 0; q < P; q++) {
@@ -593,7 +599,7 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
         w.packed = wa.take((size_t)p.Sp * p.Kp);
         w.sx = wa.take((size_t)p.Sp * p.P * sizeof(int));
         w.sxx = wa.take((size_t)p.Sp * p.P * sizeof(int));
-        w.slab = wa.take((size_t)p.npair * p.nseg * TILE * TILE * sizeof(float));
+        w.slab = wa.take((size_t)p.npair * p.nseg * TILE * TILE * (p.slab16 ? sizeof(uint16_t) : sizeof(float)));
         w.sd = wa.take((size_t)p.Sp * sizeof(double));
         w.wm = wa.take((size_t)p.Sp * sizeof(double));
         w.mu = wa.take((size_t)p.Sp * p.P * sizeof(double));
@@ -725,10 +731,10 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
         Item it;
         it.a = p.packed + (size_t)ti * TILE * p.Kp;
         it.b = p.packed + (size_t)tj * TILE * p.Kp;
-        it.slab = p.slab + ((size_t)h.pair * p.nseg + gr.first) * (TILE * TILE);
+        it.slab = p.slab + ((size_t)h.pair * p.nseg + gr.first) * (p.slab16 ? TILE * TILE / 2 : TILE * TILE);
         it.seg_k1 = p.seg_k1 + gr.first;
         it.Kp = p.Kp; it.k0 = pl.seg_k0[gr.first]; it.nseg = gr.second - gr.first;
-        it.rows_a = rows(ti); it.rows_b = rows(tj); it.diag = (ti == tj); it.len = h.len; it.pad = 0;
+        it.rows_a = rows(ti); it.rows_b = rows(tj); it.diag = (ti == tj); it.len = h.len; it.slab16 = p.slab16;
         memcpy(blob.data() + o_items + sizeof(Item) * n, &it, sizeof(Item));
     }
     memcpy(job->h_pin, blob.data(), blob.size());
@@ -1222,7 +1228,7 @@ int gauss_job_stats(gauss_job* job, double* out4)
                 }
             flops += tiles32 * 32.0 * 32.0 * 2.0 * p.Kp;
         }
-        slab += (double)p.npair * p.nseg * TILE * TILE * sizeof(float);
+        slab += (double)p.npair * p.nseg * TILE * TILE * (p.slab16 ? sizeof(uint16_t) : sizeof(float));
     }
     out4[0] = job->n_items; out4[1] = flops; out4[2] = slab; out4[3] = (double)job->ws_bytes;
     return GAUSS_OK;

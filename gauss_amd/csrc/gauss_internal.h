@@ -47,6 +47,8 @@ struct Prob {
     int n_run;              // 2-bit sources: number of source blocks (selected populations)
     int geno_fmt;           // 0: one byte per genotype (ASCII digit or small integer); 1: 2-bit packed blocks
     int gram_i8;            // 1: operands are raw codes and slabs hold int32 (i8 MFMA path); 0: e4m3 codes, f32 slabs
+    int slab16;             // 1: partial slabs hold exact uint16 sums, two rows per dword (2-bit sources: codes <= 3 and
+                            // segments <= 7168 samples keep a partial below 2^16); halves the slab traffic
     double lambda, eps, diag;
     long long ld_raw;
     GP(const uint8_t) raw_m;   // [M x ld_raw]
@@ -108,7 +110,7 @@ struct Item {
     int rows_a, rows_b;      // live rows of the two tiles (the rest is zero padding)
     int diag;                // ti == tj
     int len;                 // columns in the run (sort key)
-    int pad;
+    int slab16;              // slabs are uint16 pairs (Prob::slab16): `slab` then counts dwords of that layout
 };
 
 template <typename T> using gptr = T __attribute__((address_space(1)))*;

@@ -116,6 +116,10 @@ __device__ __forceinline__ void chunk_mfma(const uint8_t* __restrict__ la, const
 
 __device__ __forceinline__ float slab_bits(float v) { return v; }
 __device__ __forceinline__ float slab_bits(int v) { return __int_as_float(v); }
+// 16-bit slabs: the exact sum as an unsigned integer; rows 2k and 2k + 1 of a column share one dword
+__device__ __forceinline__ uint32_t slab_u(float v) { return (uint32_t)v; }
+__device__ __forceinline__ uint32_t slab_u(int v) { return (uint32_t)v; }
+__device__ __forceinline__ float slab_pair(uint32_t lo, uint32_t hi) { return __uint_as_float((lo & 0xFFFFu) | (hi << 16)); }
 
 // One work item for a wave with NA x NB live 32-row halves (NA = 0: staging and barriers only).
 // The K loop runs over the whole run of segments without draining the prefetch pipeline; at each
@@ -168,6 +172,7 @@ __device__ __forceinline__ void run_item(const Item& it, uint8_t* lds, int wr, i
     const int klast = it.seg_k1[nseg - 1];
     auto out = it.slab;
     const int obase = (wr * 64 + 4 * lh) * TILE + wc * 64 + li;
+    const int obase16 = (wr * 32 + 2 * lh) * TILE + wc * 64 + li;         // row pair (wr * 64 + 4 lh) / 2
 
 #define GAUSS_STAGE(BUF, KOFF)                                                                                   \
     {                                                                                                            \
@@ -220,20 +225,34 @@ __device__ __forceinline__ void run_item(const Item& it, uint8_t* lds, int wr, i
         // end of a segment: flush its exact partial sums, start the next segment from zero.
         // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
         if (NA > 0) {
+            if (it.slab16) {
+                // accumulator registers r and r + 1 (r even) are rows 2k and 2k + 1 of the same column: one dword
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int o = obase + ((r & 3) + 8 * (r >> 2)) * TILE;
-                out[o] = slab_bits(acc00[r]);
-                if (NB > 1) out[o + 32] = slab_bits(acc01[r]);
-                if (NA > 1) {
-                    if (!SK10) out[o + 32 * TILE] = slab_bits(acc10[r]);
-                    if (NB > 1) out[o + 32 * TILE + 32] = slab_bits(acc11[r]);
+                for (int r = 0; r < 16; r += 2) {
+                    const int o = obase16 + (((r & 3) + 8 * (r >> 2)) >> 1) * TILE;
+                    out[o] = slab_pair(slab_u(acc00[r]), slab_u(acc00[r + 1]));
+                    if (NB > 1) out[o + 32] = slab_pair(slab_u(acc01[r]), slab_u(acc01[r + 1]));
+                    if (NA > 1) {
+                        if (!SK10) out[o + 16 * TILE] = slab_pair(slab_u(acc10[r]), slab_u(acc10[r + 1]));
+                        if (NB > 1) out[o + 16 * TILE + 32] = slab_pair(slab_u(acc11[r]), slab_u(acc11[r + 1]));
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int o = obase + ((r & 3) + 8 * (r >> 2)) * TILE;
+                    out[o] = slab_bits(acc00[r]);
+                    if (NB > 1) out[o + 32] = slab_bits(acc01[r]);
+                    if (NA > 1) {
+                        if (!SK10) out[o + 32 * TILE] = slab_bits(acc10[r]);
+                        if (NB > 1) out[o + 32 * TILE + 32] = slab_bits(acc11[r]);
+                    }
                 }
             }
 #pragma unroll
             for (int r = 0; r < 16; r++) { acc00[r] = 0; acc01[r] = 0; acc10[r] = 0; acc11[r] = 0; }
         }
-        out += TILE * TILE;
+        out += it.slab16 ? TILE * TILE / 2 : TILE * TILE;
     }
 }
 

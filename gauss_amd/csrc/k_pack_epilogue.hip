@@ -315,24 +315,43 @@ template <bool ISINT> struct SlabAcc {
     __device__ __forceinline__ double get() const { return (double)v; }
 };
 
-template <bool ISINT>
-__global__ __launch_bounds__(1024) void epilogue_kernel(const Prob* __restrict__ probs,
-                                                        const int2* __restrict__ tilemap, int lds_pop_cap)
+// The 4 x 4 block of one partial slab that a thread owns, in flight as raw dwords: four 16-byte loads for f32 / int32
+// slabs (rows rg + 32 q), two for 16-bit slabs (rows 2 rg, 2 rg + 1, 64 + 2 rg, 65 + 2 rg: a dword carries a row pair).
+typedef uint32_t u32x4e __attribute__((ext_vector_type(4)));
+template <bool ISINT, bool S16> struct SlabBlock {
+    u32x4e raw[S16 ? 2 : 4];
+    template <typename PT>
+    __device__ __forceinline__ void load(PT tile_slab, int s, const int (&rows)[4], int c0)
+    {
+        if (S16) {
+            const auto base = (GP(const uint32_t))tile_slab + (size_t)s * (TILE * TILE / 2);
+            raw[0] = *(GP(const u32x4e))(base + (rows[0] >> 1) * TILE + c0);
+            raw[1] = *(GP(const u32x4e))(base + (rows[2] >> 1) * TILE + c0);
+        } else {
+            const auto base = (GP(const uint32_t))tile_slab + (size_t)s * (TILE * TILE);
+#pragma unroll
+            for (int q = 0; q < 4; q++) raw[q] = *(GP(const u32x4e))(base + rows[q] * TILE + c0);
+        }
+    }
+    __device__ __forceinline__ int get(int q, int c) const
+    {
+        if (S16) { const uint32_t d = raw[q >> 1][c]; return (int)((q & 1) ? (d >> 16) : (d & 0xFFFFu)); }
+        return ISINT ? (int)raw[q][c] : (int)__uint_as_float(raw[q][c]);
+    }
+};
+
+template <bool ISINT, bool S16>
+__device__ __forceinline__ void epilogue_tile(const Prob& pb, int pair, int lds_pop_cap, char* esm)
 {
-    extern __shared__ __attribute__((aligned(16))) char esm[];
-    const int2 tm = tilemap[blockIdx.x];
-    const Prob& pb = probs[tm.x];
-    const int pair = tm.y;
     const int ti = pb.pair_ti[pair], tj = pb.pair_tj[pair];
     const int P = pb.P, nseg = pb.nseg;
-    const auto tile_slab = pb.slab + (size_t)pair * nseg * TILE * TILE;
-    const size_t seg_stride = (size_t)TILE * TILE;
+    // the pair's slabs; 16-bit slabs take half the floats (the planner only selects them when P fits the LDS tables)
+    const auto tile_slab = pb.slab + (size_t)pair * nseg * (S16 ? TILE * TILE / 2 : TILE * TILE);
     const int mt = pb.Mp / TILE;        // number of measured row tiles
     const bool sym = (ti < mt);         // measured x measured tile (ti <= tj < mt)
     const int Mld = pb.Mld;
     const int tid = threadIdx.x;
     const bool weighted = pb.mode != 0;
-    const int isint = pb.gram_i8;
     const bool lds_tables = weighted && P <= lds_pop_cap;
 
     double* s_wmui = reinterpret_cast<double*>(esm);          // [P][128]  w_p * mu_p(row i)
@@ -355,8 +374,7 @@ __global__ __launch_bounds__(1024) void epilogue_kernel(const Prob* __restrict__
     const int c0 = (tid & 31) * 4, rg = tid >> 5;
     int rows[4];
 #pragma unroll
-    for (int q = 0; q < 4; q++) rows[q] = rg + 32 * q;
-    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    for (int q = 0; q < 4; q++) rows[q] = S16 ? (2 * rg + (q & 1) + 64 * (q >> 1)) : (rg + 32 * q);
     double cov[4][4];
     double sd_j[4], wm_j[4];
 #pragma unroll
@@ -370,20 +388,15 @@ __global__ __launch_bounds__(1024) void epilogue_kernel(const Prob* __restrict__
         for (int q = 0; q < 4; q++)
 #pragma unroll
             for (int c = 0; c < 4; c++) acc[q][c].zero();
-        f32x4 nxt[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) nxt[q] = *(GP(const f32x4))(tile_slab + rows[q] * TILE + c0);
+        SlabBlock<ISINT, S16> nxt;
+        nxt.load(tile_slab, 0, rows, c0);
         for (int s = 0; s < nseg; s++) {
-            f32x4 cur[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) cur[q] = nxt[q];
-            if (s + 1 < nseg)                                     // next partial flies while this one is added
-#pragma unroll
-                for (int q = 0; q < 4; q++) nxt[q] = *(GP(const f32x4))(tile_slab + (s + 1) * seg_stride + rows[q] * TILE + c0);
+            const SlabBlock<ISINT, S16> cur = nxt;
+            if (s + 1 < nseg) nxt.load(tile_slab, s + 1, rows, c0);          // next partial flies while this one is added
 #pragma unroll
             for (int q = 0; q < 4; q++)
 #pragma unroll
-                for (int c = 0; c < 4; c++) acc[q][c].add(cur[q][c]);
+                for (int c = 0; c < 4; c++) acc[q][c].v += cur.get(q, c);
         }
         double sumxy[4][4];
 #pragma unroll
@@ -404,9 +417,8 @@ __global__ __launch_bounds__(1024) void epilogue_kernel(const Prob* __restrict__
     } else if (lds_tables) {
         // CalWgtCov (util.cpp:103-124) in the reference's population order
         double wsumcov[4][4] = {};
-        f32x4 nxt[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) nxt[q] = *(GP(const f32x4))(tile_slab + rows[q] * TILE + c0);
+        SlabBlock<ISINT, S16> nxt;
+        nxt.load(tile_slab, 0, rows, c0);
         for (int p = 0; p < P; p++) {
             SlabAcc<ISINT> acc[4][4];
 #pragma unroll
@@ -414,16 +426,14 @@ __global__ __launch_bounds__(1024) void epilogue_kernel(const Prob* __restrict__
 #pragma unroll
                 for (int c = 0; c < 4; c++) acc[q][c].zero();
             for (int s = pb.pop_seg0[p]; s < pb.pop_seg0[p + 1]; s++) {
-                f32x4 cur[4];
-#pragma unroll
-                for (int q = 0; q < 4; q++) cur[q] = nxt[q];
-                if (s + 1 < nseg)                                 // segments are stored in population order: the next
-#pragma unroll                                                    // partial (same or next population) flies during the fp64 tail
-                    for (int q = 0; q < 4; q++) nxt[q] = *(GP(const f32x4))(tile_slab + (s + 1) * seg_stride + rows[q] * TILE + c0);
+                const SlabBlock<ISINT, S16> cur = nxt;
+                // segments are stored in population order: the next partial (same or next population) flies during
+                // the fp64 tail
+                if (s + 1 < nseg) nxt.load(tile_slab, s + 1, rows, c0);
 #pragma unroll
                 for (int q = 0; q < 4; q++)
 #pragma unroll
-                    for (int c = 0; c < 4; c++) acc[q][c].add(cur[q][c]);
+                    for (int c = 0; c < 4; c++) acc[q][c].v += cur.get(q, c);
             }
             double sumxy[4][4];
 #pragma unroll
@@ -506,6 +516,17 @@ __global__ __launch_bounds__(1024) void epilogue_kernel(const Prob* __restrict__
             }
         }
     }
+}
+
+template <bool ISINT>
+__global__ __launch_bounds__(1024) void epilogue_kernel(const Prob* __restrict__ probs,
+                                                        const int2* __restrict__ tilemap, int lds_pop_cap)
+{
+    extern __shared__ __attribute__((aligned(16))) char esm[];
+    const int2 tm = tilemap[blockIdx.x];
+    const Prob& pb = probs[tm.x];
+    if (pb.slab16) epilogue_tile<ISINT, true>(pb, tm.y, lds_pop_cap, esm);
+    else epilogue_tile<ISINT, false>(pb, tm.y, lds_pop_cap, esm);
 }
 
 void launch_epilogue(const Prob* d_probs, const int2* d_tilemap, int n_tiles, int max_pop, int dtype_i8, hipStream_t s)
