@@ -570,7 +570,8 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
     job->n_panels = (int)panelmap.size();
 
     // ---- workspace arena ----
-    Arena wa;
+    Arena wa;         // zeroed once per job: operand padding, B21 padding and the solve matrices rely on it
+    Arena wslab;      // partial slabs: every entry a reader keeps is written by the Gram kernel first, so no zeroing
     struct WsOff { size_t raw_m, raw_u, packed, sx, sxx, slab, sd, wm, mu, wmu, A, Linv, B21, V, ld, b11c, sacc, part; long long ldraw; };
     std::vector<WsOff> wo(job->n);
     size_t res = 0;
@@ -599,7 +600,7 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
         w.packed = wa.take((size_t)p.Sp * p.Kp);
         w.sx = wa.take((size_t)p.Sp * p.P * sizeof(int));
         w.sxx = wa.take((size_t)p.Sp * p.P * sizeof(int));
-        w.slab = wa.take((size_t)p.npair * p.nseg * TILE * TILE * (p.slab16 ? sizeof(uint16_t) : sizeof(float)));
+        w.slab = wslab.take((size_t)p.npair * p.nseg * TILE * TILE * (p.slab16 ? sizeof(uint16_t) : sizeof(float)));
         w.sd = wa.take((size_t)p.Sp * sizeof(double));
         w.wm = wa.take((size_t)p.Sp * sizeof(double));
         w.mu = wa.take((size_t)p.Sp * p.P * sizeof(double));
@@ -624,7 +625,9 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
     const size_t o_status = wa.take(sizeof(int) * 4 * job->n);
     const size_t o_results = wa.take(sizeof(double) * std::max<size_t>(res, 1));
     job->n_results = res;
-    job->ws_bytes = wa.off;
+    const size_t slab_base = rup(wa.off, 4096);
+    for (WsOff& w : wo) w.slab += slab_base;
+    job->ws_bytes = slab_base + wslab.off;
     job->tab_bytes = blob.size();
 
     hipError_t e = ctx_dev_alloc(ctx, job->ws_bytes, (void**)&job->d_ws);
@@ -643,7 +646,7 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
 
     hipStream_t st = ctx->stream;
     // zero once: operand padding, B21 padding and the solve matrices rely on it
-    HIPCHK(hipMemsetAsync(job->d_ws, 0, job->ws_bytes, st));
+    HIPCHK(hipMemsetAsync(job->d_ws, 0, slab_base, st));
 
     job->d_status = (int*)(job->d_ws + o_status);
     job->d_results = (double*)(job->d_ws + o_results);
