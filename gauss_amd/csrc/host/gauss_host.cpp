@@ -1787,7 +1787,9 @@ int gauss_host_panel_evict(gauss_ctx* ctx, const char* packed_file)
     if (!ctx) return herr("ctx is NULL");
     std::lock_guard<std::mutex> lock(g_res_mu);
     for (auto it = g_resident.begin(); it != g_resident.end();) {
-        if (it->first.first == ctx && (!packed_file || it->first.second.compare(0, strlen(packed_file), packed_file) == 0)) {
+        const size_t pl = packed_file ? strlen(packed_file) : 0;      // keys are "<path>|<size>|<mtime>"
+        if (it->first.first == ctx && (!packed_file || (it->first.second.compare(0, pl, packed_file) == 0 &&
+                                                         (it->first.second.size() == pl || it->first.second[pl] == '|')))) {
             gauss_store_free(ctx, it->second.dev);
             it = g_resident.erase(it);
         } else ++it;
