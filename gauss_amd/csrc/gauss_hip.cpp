@@ -795,6 +795,7 @@ static int job_run(gauss_job* job, bool solve)
     prof_begin(job, 1);
     launch_pack_stats(job->d_probs, job->d_rowmap, job->n_rows, st);
     launch_row_stats(job->d_probs, job->d_rowmap, job->n_rows, st);
+    if (solve && job->n_panels > 0) launch_shift_cert(job->d_probs, job->n, st);      // needs the row tables only
     prof_end(job);
     prof_begin(job, 0);
     launch_gram(job->d_items, job->n_items, job->gram_i8, st);

@@ -135,6 +135,7 @@ void launch_epilogue(const Prob* d_probs, const int2* d_tilemap, int n_tiles, in
 void launch_pop_cor(const Prob* d_probs, int prob, int npair, double* d_out, hipStream_t s);
 void launch_gene_epilogue(const Prob* d_probs, int prob, int n_gene, hipStream_t s);
 void launch_factor_step(const Prob* d_probs, int n_prob, int step, int max_nblk, int max_npanel, int split, hipStream_t s);
+void launch_shift_cert(const Prob* d_probs, int n_prob, hipStream_t s);
 void launch_solve(const Prob* d_probs, const int2* d_panelmap, int n_panels, hipStream_t s);
 void launch_solve_last(const Prob* d_probs, const int2* d_panelmap, int n_panels, int max_nblk, int split, hipStream_t s);
 void launch_counts(const Prob* d_probs, int prob, int npair, long long* d_out, hipStream_t s);

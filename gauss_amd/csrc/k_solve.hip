@@ -414,25 +414,23 @@ __device__ __forceinline__ void solve_products(const Prob& pb, int panel, int kb
     }
 }
 
-// X = B_kb + acc;  V_kb = Linv_kk X  (stored);  z / info sums of the block's rows
-__device__ __forceinline__ void solve_tail(const Prob& pb, int panel, int kb, f64x4 (&acc)[SOLVE_NT], double* __restrict__ TL,
-                                           double* __restrict__ TV, SolveSums& sums, int tid)
+// The right-hand-side block and Linv_kk of block row kb, requested into registers (16 + 16 doubles per thread) so that a
+// caller can overlap them with other loads; solve_tail commits them to LDS.
+struct SolveRhs { double b[(NB * NR) / 256]; TileRegs li; };
+
+__device__ __forceinline__ void solve_rhs_fetch(const Prob& pb, int panel, int kb, SolveRhs& q, int tid)
 {
-    constexpr int NT = SOLVE_NT;
-    const int lane = tid & 63, wave = tid >> 6;
     const int ld = pb.Mld;
-    const auto Linv = pb.Linv;                                // matrix 0
-    const auto V = pb.V + (size_t)panel * ld * NR;
     const int u0 = panel * NRU;
     const bool qcat = pb.kind == WIN_QCAT;
     const int n_predm = pb.n_predm;
     // QCAT right-hand sides (qcat.cpp:216-243): first the B11 columns of the tested measured SNPs
     // (rows n_head .. of the symmetric A[0], which the factorisation leaves intact), then the B21 rows
     const auto Brow = pb.A + (size_t)pb.n_head * ld;
-    const int cc = tid % NR, rg = tid / NR;
-    __syncthreads();
-    // TV <- rhs block: column c < NRU: B21[u0+c][kb*64 + r]; column NRU: z1 (zero padded)
-    for (int e = tid; e < NB * NR; e += 256) {
+    // column c < NRU: B21[u0+c][kb*64 + r]; column NRU: z1 (zero padded)
+#pragma unroll
+    for (int i = 0; i < (NB * NR) / 256; i++) {
+        const int e = tid + 256 * i;
         const int c = e >> 6, r = e & 63;                 // r fastest: coalesced along a B21 row
         const int k = kb * NB + r;
         double v = 0.0;
@@ -442,12 +440,27 @@ __device__ __forceinline__ void solve_tail(const Prob& pb, int panel, int kb, f6
             else if (u - (qcat ? n_predm : 0) < pb.U) v = pb.B21[(size_t)(u - (qcat ? n_predm : 0)) * ld + k];
         }
         else if (k < pb.M) v = pb.z1[k];
-        TV[r * LDV + c] = v;
+        q.b[i] = v;
     }
-    {
-        const auto Li = Linv + (size_t)kb * NB * NB;
-        for (int e = tid; e < NB * NB; e += 256) TL[(e >> 6) * LDT + (e & 63)] = Li[e];
+    tile_fetch(q.li, pb.Linv + (size_t)kb * NB * NB, NB, tid);
+}
+
+// X = B_kb + acc;  V_kb = Linv_kk X  (stored);  z / info sums of the block's rows
+__device__ __forceinline__ void solve_tail(const Prob& pb, int panel, int kb, f64x4 (&acc)[SOLVE_NT], const SolveRhs& q,
+                                           double* __restrict__ TL, double* __restrict__ TV, SolveSums& sums, int tid)
+{
+    constexpr int NT = SOLVE_NT;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int ld = pb.Mld;
+    const auto V = pb.V + (size_t)panel * ld * NR;
+    const int cc = tid % NR, rg = tid / NR;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < (NB * NR) / 256; i++) {
+        const int e = tid + 256 * i;
+        TV[(e & 63) * LDV + (e >> 6)] = q.b[i];
     }
+    tile_commit<LDT>(TL, q.li, tid);
     __syncthreads();
 #pragma unroll
     for (int n = 0; n < NT; n++)
@@ -497,7 +510,9 @@ __device__ __forceinline__ void solve_row(const Prob& pb, int panel, int kb, dou
 #pragma unroll
             for (int r = 0; r < 4; r++) acc[n][r] += part[n][r];
     }
-    solve_tail(pb, panel, kb, acc, TL, TV, sums, tid);
+    SolveRhs q;
+    solve_rhs_fetch(pb, panel, kb, q, tid);
+    solve_tail(pb, panel, kb, acc, q, TL, TV, sums, tid);
 }
 
 // after the last block row: combine the per-thread sums and write z / info (or the QCAT correlation)
@@ -584,15 +599,32 @@ __device__ __forceinline__ void solve_combine(const Prob& pb, int panel, int kb,
     f64x4 acc[SOLVE_NT];
 #pragma unroll
     for (int n = 0; n < SOLVE_NT; n++) acc[n] = f64x4{0.0, 0.0, 0.0, 0.0};
+    SolveRhs q;
+    solve_rhs_fetch(pb, panel, kb, q, tid);                       // in flight together with the partial sums
     const int np = kb < SOLVE_SPLIT ? kb : SOLVE_SPLIT;           // partial sums that exist for this row
-    for (int g = 0; g < np; g++) {
-        const auto P = pb.Part + ((size_t)panel * SOLVE_SPLIT + g) * (NB * NR);
+    // every partial tile is requested before the first is added (four dependent round trips to tiles that other CUs
+    // have just written cost ~4 us each); the additions keep the class order
+    f64x4 part[SOLVE_SPLIT][SOLVE_NT];
 #pragma unroll
-        for (int n = 0; n < SOLVE_NT; n++)
+    for (int g = 0; g < SOLVE_SPLIT; g++) {
+        if (g < np) {
+            const auto P = pb.Part + ((size_t)panel * SOLVE_SPLIT + g) * (NB * NR);
 #pragma unroll
-            for (int r = 0; r < 4; r++) acc[n][r] += P[(size_t)(n * 4 + r) * 256 + tid];
+            for (int n = 0; n < SOLVE_NT; n++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) part[g][n][r] = P[(size_t)(n * 4 + r) * 256 + tid];
+        }
     }
-    solve_tail(pb, panel, kb, acc, TL, TV, sums, tid);
+#pragma unroll
+    for (int g = 0; g < SOLVE_SPLIT; g++) {
+        if (g < np) {
+#pragma unroll
+            for (int n = 0; n < SOLVE_NT; n++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) acc[n][r] += part[g][n][r];
+        }
+    }
+    solve_tail(pb, panel, kb, acc, q, TL, TV, sums, tid);
 }
 
 __device__ __forceinline__ void solve_combine_fused(const Prob& pb, int panel, int kb, double* __restrict__ smem, int tid)
@@ -813,8 +845,6 @@ void launch_factor_step(const Prob* d_probs, int n_prob, int step, int max_nblk,
         hipFuncSetAttribute(reinterpret_cast<const void*>(factor_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)upd_smem);
     }
     if (step == 0) {
-        static const bool no_cert = getenv("GAUSS_NO_SHIFT_CERT") != nullptr;     // experiment: always run the exact test
-        if (!no_cert) hipLaunchKernelGGL(shift_cert_kernel, dim3(n_prob), dim3(256), 0, st, d_probs);
         hipLaunchKernelGGL(factor_init_kernel, dim3(n_prob * 2), dim3(256), FACTOR_SMEM, st, d_probs);
         return;
     }
@@ -872,6 +902,14 @@ __global__ __launch_bounds__(256) void solve_last_kernel(const Prob* __restrict_
     }
     solve_row(pb, panel, s_last, TL, TV, sums, tid);        // last == s_last
     solve_finish(pb, panel, red, sums, tid);
+}
+
+// The certificate only needs the row tables: it is launched right after row_stats, ahead of the Gram kernel, so that
+// its ~30 us never sit on the latency-bound factorisation chain.  status[3] must not be cleared afterwards.
+void launch_shift_cert(const Prob* d_probs, int n_prob, hipStream_t st)
+{
+    static const bool no_cert = getenv("GAUSS_NO_SHIFT_CERT") != nullptr;         // experiment: always run the exact test
+    if (n_prob > 0 && !no_cert) hipLaunchKernelGGL(shift_cert_kernel, dim3(n_prob), dim3(256), 0, st, d_probs);
 }
 
 void launch_solve(const Prob* d_probs, const int2* d_panelmap, int n_panels, hipStream_t s)
