@@ -255,3 +255,37 @@ def test_gpu_native_chromosome_isolates_a_failing_window(ctx, tmp_path):
     assert np.array_equal(res.columns["z"], good.columns["z"][keep])
     assert np.array_equal(res.columns["rsid"], good.columns["rsid"][keep])
     api.panel_evict(ctx=ctx)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind_name", ["DIST", "QCAT", "QCATMIX"])
+def test_gpu_native_chromosome_run_other_kinds_equal_per_window_calls(ctx, tmp_path, kind_name):
+    """dist / qcat / qcatmix through the native chromosome driver against the reference-style entry point called window
+    by window on the same packed panel: same rows, same bits."""
+    st = make_study(tmp_path)
+    p = st["paths"]
+    gpk = str(tmp_path / "panel.gpk")
+    api.pack_panel(p["index.gz"], p["data.gz"], p["desc.txt"], gpk)
+    kind = getattr(api, "KIND_" + kind_name)
+    mix = kind_name.endswith("MIX")
+    sel = dict(pop_wgt_df=WGT) if mix else dict(study_pop="EUR")
+    res = api.impute_chromosome(kind, 22, 1_000_001, 4_000_000, 200_000, input_file=p["gwas.txt"], reference_data_file=gpk,
+                                reference_pop_desc_file=p["desc.txt"], window_size=750_000, n_batches=2, ctx=ctx, **sel)
+    assert res.stats["n_failed"] == 0 and res.stats["n_windows"] == 4
+    fn = {"DIST": api.dist, "QCAT": api.qcat, "QCATMIX": api.qcatmix}[kind_name]
+    frames = []
+    for k, (s, e, owner, status, m, u) in enumerate(res.windows):
+        if status != 0:
+            continue
+        a = (22, int(s), int(e), 200_000, WGT if mix else "EUR", p["gwas.txt"], p["index.gz"], gpk, p["desc.txt"])
+        frames.append(fn(*a, ctx=ctx))
+    import pandas as pd
+    want = pd.concat(frames, ignore_index=True)
+    got = res.frame()
+    assert list(got.columns) == list(want.columns) and len(got) == len(want)
+    for c in want.columns:
+        if want[c].dtype.kind == "f":
+            assert np.array_equal(got[c].to_numpy(), want[c].to_numpy(), equal_nan=True), c
+        else:
+            assert list(got[c]) == list(want[c]), c
+    api.panel_evict(ctx=ctx)
