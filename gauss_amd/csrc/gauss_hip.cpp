@@ -140,7 +140,7 @@ struct Plan {
     std::vector<int> pop_raw_off, pop_pk_off, seg_pop, seg_k0, seg_k1, pop_seg0;
     std::vector<int> pair_ti, pair_tj, pair_lut;
     std::vector<double> pop_w, pop_wf, pop_md, z1;
-    std::vector<uint8_t> word_pop, word_run;
+    std::vector<uint8_t> word_pop, word_run, chunk_half;
     std::vector<int> run_pk_off, run_src;
     std::vector<int32_t> rows_m, rows_u;     // store rows; empty = contiguous
     size_t row_bytes = 0;                    // bytes of a source row that the kernels read
@@ -355,6 +355,20 @@ static int plan_problem(const WinSpec& w, Plan& pl, int seg_max, int group_targe
     p.slab16 = (!no16 && w.geno_fmt == GAUSS_GENO_2BIT && !w.ld_only && !w.gene_off && P <= 32) ? 1 : 0;
     if (p.slab16) seg_max = std::min(seg_max, 7168);
     pl.word_pop.assign(p.Kp / 16, 0);
+    // K chunks whose upper 32 samples are padding: the last chunk of every zero-padded block (a population, or a 2-bit
+    // source block) whose size leaves a remainder of 1..32 samples
+    pl.chunk_half.assign(p.Kp / KC, 0);
+    if (w.geno_fmt == GAUSS_GENO_2BIT) {
+        for (int q = 0; q < w.n_pop; q++) {
+            const int m = w.pop_off[q + 1] - w.pop_off[q], rem = m % KC;
+            if (m > 0 && rem >= 1 && rem <= 32) pl.chunk_half[pl.run_pk_off[q + 1] / KC - 1] = 1;
+        }
+    } else {
+        for (int q = 0; q < P; q++) {
+            const int m = pl.pop_raw_off[q + 1] - pl.pop_raw_off[q], rem = m % KC;
+            if (m > 0 && rem >= 1 && rem <= 32) pl.chunk_half[pl.pop_pk_off[q + 1] / KC - 1] = 1;
+        }
+    }
     pl.pop_seg0.assign(P + 1, 0);
     for (int q = 0; q < P; q++) {
         for (int b = pl.pop_pk_off[q] / 16; b < pl.pop_pk_off[q + 1] / 16; b++) pl.word_pop[b] = (uint8_t)q;
@@ -491,7 +505,7 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
     // ---- table arena (host mirrored) ----
     Arena ta;
     std::vector<char>& blob = job->h_tab;
-    struct TabOff { size_t raw_off, pk_off, w, wf, md, seg_pop, k0, k1, seg0, ti, tj, lut, wp, z1, goff, gout, wr, rpk, rsrc, rm, ru; };
+    struct TabOff { size_t raw_off, pk_off, w, wf, md, seg_pop, k0, k1, seg0, ti, tj, lut, wp, z1, goff, gout, wr, rpk, rsrc, rm, ru, ch; };
     std::vector<TabOff> to(job->n);
     for (int i = 0; i < job->n; i++) {
         Plan& pl = job->plans[i];
@@ -516,6 +530,7 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
         to[i].rsrc = put(blob, ta, pl.run_src);
         to[i].rm = put(blob, ta, pl.rows_m);
         to[i].ru = put(blob, ta, pl.rows_u);
+        to[i].ch = put(blob, ta, pl.chunk_half);
     }
     // work lists
     struct ItemH { int prob, pair, group, len; };
@@ -736,8 +751,9 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
         it.b = p.packed + (size_t)tj * TILE * p.Kp;
         it.slab = p.slab + ((size_t)h.pair * p.nseg + gr.first) * (p.slab16 ? TILE * TILE / 2 : TILE * TILE);
         it.seg_k1 = p.seg_k1 + gr.first;
+        it.chunk_half = (const uint8_t*)(job->d_tab + to[h.prob].ch);
         it.Kp = p.Kp; it.k0 = pl.seg_k0[gr.first]; it.nseg = gr.second - gr.first;
-        it.rows_a = rows(ti); it.rows_b = rows(tj); it.diag = (ti == tj); it.len = h.len; it.slab16 = p.slab16;
+        it.rows_a = rows(ti); it.rows_b = rows(tj); it.flags = (ti == tj ? 1 : 0) | (p.slab16 ? 2 : 0);
         memcpy(blob.data() + o_items + sizeof(Item) * n, &it, sizeof(Item));
     }
     memcpy(job->h_pin, blob.data(), blob.size());

@@ -104,14 +104,15 @@ struct Item {
     GP(const uint8_t) b;     // packed rows of tile tj
     GP(float) slab;          // slab of (pair, first segment of the run); later segments follow
     GP(const int) seg_k1;    // end column of each segment of the run
+    GP(const uint8_t) chunk_half;  // [Kp / KC] 1: only the first 32 samples of that K chunk are live (the rest is the zero
+                             // padding that ends a population block): half of the chunk's MFMAs are not issued
     int Kp;                  // packed row stride
     int k0;                  // first column of the run
     int nseg;                // segments in the run
     int rows_a, rows_b;      // live rows of the two tiles (the rest is zero padding)
-    int diag;                // ti == tj
-    int len;                 // columns in the run (sort key)
-    int slab16;              // slabs are uint16 pairs (Prob::slab16): `slab` then counts dwords of that layout
+    int flags;               // bit 0: ti == tj (diagonal tile); bit 1: slabs are uint16 pairs (Prob::slab16)
 };
+static_assert(sizeof(Item) == 64, "work items are fetched as one 64-byte descriptor");
 
 template <typename T> using gptr = T __attribute__((address_space(1)))*;
 template <typename T> __device__ __forceinline__ gptr<T> G(T* p) { return (gptr<T>)p; }

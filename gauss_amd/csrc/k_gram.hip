@@ -45,7 +45,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int NA, int NB, bool SK10>
 __device__ __forceinline__ void chunk_mfma(const uint8_t* __restrict__ la, const uint8_t* __restrict__ lb,
                                            const int (&aoff)[2], const int (&boff)[2], f32x16& acc00, f32x16& acc01,
-                                           f32x16& acc10, f32x16& acc11)
+                                           f32x16& acc10, f32x16& acc11, bool half)
 {
 #define GAUSS_MFMA_PAIR(AW0, AW1, BW0, BW1, HI)                                                       \
     {                                                                                                  \
@@ -65,6 +65,7 @@ __device__ __forceinline__ void chunk_mfma(const uint8_t* __restrict__ la, const
     }
 #pragma unroll
     for (int g = 0; g < 2; g++) {
+        if (g == 1 && half) break;         // samples 32..63 of the chunk are padding zeros (wave-uniform)
         const u32x4 a0 = *reinterpret_cast<const u32x4*>(la + aoff[g]);
         const u32x4 b0 = *reinterpret_cast<const u32x4*>(lb + boff[g]);
         u32x4 a1 = a0, b1 = b0;
@@ -92,10 +93,11 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 template <int NA, int NB, bool SK10>
 __device__ __forceinline__ void chunk_mfma(const uint8_t* __restrict__ la, const uint8_t* __restrict__ lb,
                                            const int (&aoff)[2], const int (&boff)[2], i32x16& acc00, i32x16& acc01,
-                                           i32x16& acc10, i32x16& acc11)
+                                           i32x16& acc10, i32x16& acc11, bool half)
 {
 #pragma unroll
     for (int g = 0; g < 2; g++) {
+        if (g == 1 && half) break;
         const i32x4 a0 = *reinterpret_cast<const i32x4*>(la + aoff[g]);
         const i32x4 b0 = *reinterpret_cast<const i32x4*>(lb + boff[g]);
         acc00 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b0, acc00, 0, 0, 0);
@@ -202,6 +204,7 @@ __device__ __forceinline__ void run_item(const Item& it, uint8_t* lds, int wr, i
     }
 
     int k = k0;
+    bool half_next = it.chunk_half[k0 >> 6] != 0;
     for (int seg = 0; seg < nseg; seg++) {
         const int kend = it.seg_k1[seg];
         for (; k < kend; k += KC) {
@@ -216,7 +219,9 @@ __device__ __forceinline__ void run_item(const Item& it, uint8_t* lds, int wr, i
             }
             const uint8_t* la = lds + cur * 2 * LTILE;
             const uint8_t* lb = la + LTILE;
-            if (NA > 0) chunk_mfma<NA, NB, SK10>(la, lb, aoff, boff, acc00, acc01, acc10, acc11);
+            const bool half = half_next;
+            if (k + KC < klast) half_next = it.chunk_half[(k + KC) >> 6] != 0;     // scalar load, one chunk ahead of its use
+            if (NA > 0) chunk_mfma<NA, NB, SK10>(la, lb, aoff, boff, acc00, acc01, acc10, acc11, half);
             wait_dma_barrier_dyn<NS>(ahead - 1);         // next chunk landed; everyone is done reading this one
             if (ahead > 0) ahead--;
             cur = (cur + 1 == NS) ? 0 : cur + 1;
@@ -225,7 +230,7 @@ __device__ __forceinline__ void run_item(const Item& it, uint8_t* lds, int wr, i
         // end of a segment: flush its exact partial sums, start the next segment from zero.
         // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
         if (NA > 0) {
-            if (it.slab16) {
+            if ((it.flags & 2)) {
                 // accumulator registers r and r + 1 (r even) are rows 2k and 2k + 1 of the same column: one dword
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
@@ -252,7 +257,7 @@ __device__ __forceinline__ void run_item(const Item& it, uint8_t* lds, int wr, i
 #pragma unroll
             for (int r = 0; r < 16; r++) { acc00[r] = 0; acc01[r] = 0; acc10[r] = 0; acc11[r] = 0; }
         }
-        out += it.slab16 ? TILE * TILE / 2 : TILE * TILE;
+        out += (it.flags & 2) ? TILE * TILE / 2 : TILE * TILE;
     }
 }
 
@@ -271,9 +276,10 @@ __global__ __launch_bounds__(256, OCC) void gram_kernel(const Item* __restrict__
     na = na < 0 ? 0 : (na > 2 ? 2 : na);
     nb = nb < 0 ? 0 : (nb > 2 ? 2 : nb);
     // diagonal tile: the lower-left 64 x 64 quadrant mirrors the upper-right one and is never read
-    if (it.diag && wr == 1 && wc == 0) na = 0;
+    const bool diag = (it.flags & 1) != 0;
+    if (diag && wr == 1 && wc == 0) na = 0;
     if (na == 0 || nb == 0) run_item<0, 0, ACC, NS>(it, lds, wr, wc);
-    else if (na == 2 && nb == 2 && it.diag && wr == wc) run_item<2, 2, ACC, NS, true>(it, lds, wr, wc);
+    else if (na == 2 && nb == 2 && diag && wr == wc) run_item<2, 2, ACC, NS, true>(it, lds, wr, wc);
     else if (na == 2 && nb == 2) run_item<2, 2, ACC, NS>(it, lds, wr, wc);
     else if (na == 2) run_item<2, 1, ACC, NS>(it, lds, wr, wc);
     else if (nb == 2) run_item<1, 2, ACC, NS>(it, lds, wr, wc);
