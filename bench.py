@@ -7,9 +7,10 @@ Measured SNPs (positions, z) are the reference's own chr22 study file; unmeasure
 are synthetic (gauss_amd/workload.py).
 
 Multi-GPU (`--gpus N`, one process per GPU, no data-path collective):
-  --scaling strong (default)  the windows of the ONE chromosome are sharded over the ranks by LPT on
-                              their LD flops (farm.assign_windows); every rank keeps only the panel rows
-                              its windows touch; value = the chromosome's imputed SNPs / max-over-ranks
+  --scaling strong (default)  the windows of the ONE chromosome are sharded over the ranks: whole windows by
+                              LPT on their cost, then levelled by cutting a few windows' unmeasured SNPs
+                              between two ranks (farm.level_windows; --shard lpt = whole windows only);
+                              every rank keeps only the panel rows its windows touch; value = the chromosome's imputed SNPs / max-over-ranks
                               time.  This is configs[3]: "windows sharded across 8xMI355X".
   --scaling weak              every rank imputes its own whole chromosome (round-1 behaviour).
 With N > 1 the strong line carries a "weak_scaling" block measured in the same launch.
@@ -59,6 +60,10 @@ def parse_args(argv=None):
     ap.add_argument("--mode", choices=["distmix", "dist", "computeLD", "jepegmix", "e2e"], default="distmix",
                     help="distmix = BASELINE configs[3], the headline; the others are the remaining configs / the file-to-table run")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
+    ap.add_argument("--shard", choices=["leveled", "contiguous", "lpt"], default="leveled",
+                    help="strong scaling: lpt = whole windows, longest first (farm.assign_windows); leveled = LPT, then the most "
+                         "loaded ranks hand slices of a window's unmeasured SNPs to the least loaded ones (farm.level_windows); "
+                         "contiguous = equal-cost stretches of the chromosome, boundary windows cut (farm.balance_windows)")
     ap.add_argument("--no-weak-line", action="store_true", help="N > 1, strong: skip the extra weak-scaling pass")
     ap.add_argument("--verify-shards", action="store_true",
                     help="N > 1, strong: rank 0 also runs every window itself and checks the ranks' z / info bit for bit")
@@ -66,7 +71,11 @@ def parse_args(argv=None):
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="single GPU: time every rank's LPT share of an N-rank strong-scaling run one after the other "
                          "(what one rank of N would do per step); printed as `emulated_strong_scaling`, never as `value`")
-    ap.add_argument("--streams", type=int, default=1, help="split a rank's windows over this many jobs/streams")
+    ap.add_argument("--streams", type=int, default=1, help="split a rank's windows over this many contexts (one stream pair each)")
+    ap.add_argument("--jobs", type=int, default=1,
+                    help="split a rank's windows over this many jobs of ONE context, queued back to back: the factorisation and "
+                         "solve of job k (the context's tail stream) then run under the Gram kernel of job k+1, and a step's "
+                         "results are collected while the next step is already queued")
     return ap.parse_args(argv)
 
 
@@ -182,27 +191,41 @@ def window_descs(ch, wins, store, ld2, mode, rows_of=None):
 
 
 class Runner:
-    """A rank's windows as one job per stream; step() = run + fetch of all of them."""
+    """A rank's windows as `jobs` jobs per context; step() queues every job once and collects what the previous
+    step left (so the GPU always has the next job's Gram queued behind the tails it is finishing); drain() collects
+    the rest.  Every step's results are fetched exactly once, inside the timed region."""
 
-    def __init__(self, rig, descs, streams=1):
+    def __init__(self, rig, descs, streams=1, jobs=1):
         from gauss_amd import hotpath
         self.rig = rig
         self.ctxs = [rig.ctx] + [hotpath.Context(rig.local) for _ in range(max(1, streams) - 1)]
         self.jobs, self.order = [], []
         if descs:
-            n = min(len(self.ctxs), len(descs))
-            self.jobs = [hotpath.Job(descs[i::n], ctx=self.ctxs[i], on_device=True) for i in range(n)]
+            n = min(len(self.ctxs) * max(1, jobs), len(descs))
+            self.jobs = [hotpath.Job(descs[i::n], ctx=self.ctxs[i % len(self.ctxs)], on_device=True) for i in range(n)]
             self.order = [k for i in range(n) for k in range(i, len(descs), n)]
+        self.pending = [False] * len(self.jobs)
+        self.last = [[] for _ in self.jobs]
         self.work = {k: sum(j.work()[k] for j in self.jobs) for k in ("ld_flops", "solve_flops", "bytes", "imputed_snps")}
         self.stats = {k: sum(j.stats()[k] for j in self.jobs) for k in ("items", "executed_flops", "slab_bytes", "workspace_bytes")}
 
     def step(self):
-        for j in self.jobs:
+        if len(self.jobs) == 1:                      # one job: run + fetch, nothing to overlap with
+            self.jobs[0].run()
+            self.last[0] = self.jobs[0].fetch()
+            return
+        for i, j in enumerate(self.jobs):
+            if self.pending[i]:
+                self.last[i] = j.fetch()
             j.run()
-        out = []
-        for j in self.jobs:
-            out += j.fetch()
-        return out
+            self.pending[i] = True
+
+    def drain(self):
+        for i, j in enumerate(self.jobs):
+            if self.pending[i]:
+                self.last[i] = j.fetch()
+                self.pending[i] = False
+        return [r for part in self.last for r in part]
 
     def results_in_order(self, res):
         out = [None] * len(res)
@@ -227,14 +250,15 @@ class Runner:
         return tot
 
     def timed(self, steps, warmup):
-        res = []
         for _ in range(warmup):
-            res = self.step()
+            self.step()
+        self.drain()
         self.profile(True)
         self.rig.barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
-            res = self.step()
+            self.step()
+        res = self.drain()
         self.rig.barrier()
         dt = time.perf_counter() - t0
         st = self.stage_ms()
@@ -266,8 +290,9 @@ def run_impute(args, rig):
     ch = workload.make_chromosome(args.snps, args.mode, seed=seed, sample_scale=args.sample_scale)
     N = int(ch["off"][-1])
     wins = workload.windows_of(ch, args.wing, args.windows)
-    owner, load = workload.shard(wins, N, rig.world if strong else 1)
-    mine = [k for k in range(len(wins)) if (owner[k] == rank_of(rig) if strong else True)]
+    shares, load = shares_of(args, wins, N, rig.world if strong else 1)
+    mine = shares[rank_of(rig) if strong else 0]              # [(window, u0, u1)]: a cut window appears on two ranks
+    my_wins = workload.pieces_of(wins, mine)
 
     panel, ld = synth_panel(rig, ch, seed)
     store, ld2 = pack_store(rig, ch, panel, ld)
@@ -282,11 +307,11 @@ def run_impute(args, rig):
     rows_of = None
     if strong and rig.world > 1:
         # this rank keeps only the panel rows its windows touch (the slice a farm rank uploads)
-        rows_of = np.unique(np.concatenate([np.concatenate([wins[k][1], wins[k][2]]) for k in mine])) if mine else np.zeros(0, np.int64)
+        rows_of = np.unique(np.concatenate([np.concatenate([w[1], w[2]]) for w in my_wins])) if my_wins else np.zeros(0, np.int64)
         store = full_store.index_select(0, torch.from_numpy(rows_of).cuda()) if len(rows_of) else full_store[:1]
     torch.cuda.synchronize()
     rig.ctx.set_gram_dtype(args.gram_dtype)
-    runner = Runner(rig, window_descs(ch, [wins[k] for k in mine], store, ld2, args.mode, rows_of), args.streams)
+    runner = Runner(rig, window_descs(ch, my_wins, store, ld2, args.mode, rows_of), args.streams, args.jobs)
     work, stats = runner.work, runner.stats
 
     dt, st, res = runner.timed(args.steps, args.warmup)
@@ -300,16 +325,13 @@ def run_impute(args, rig):
     shard_check = None
     if args.verify_shards and strong and rig.world > 1:
         # every rank hands its windows' z / info to rank 0, which imputes the whole chromosome itself
-        parts = rig.gather({k: (r["z"], r["info"]) for k, r in zip(mine, res)})
+        parts = rig.gather({piece: (r["z"], r["info"]) for piece, r in zip(mine, res)})
         if rig.rank == 0:
             allr = Runner(rig, window_descs(ch, wins, full_store, ld2, args.mode), 1)
-            ref = allr.step()
+            allr.step()
+            ref = allr.drain()
             allr.close()
-            got = {}
-            for p in parts:
-                got.update(p)
-            shard_check = bool(len(got) == len(wins) and all(
-                np.array_equal(got[k][0], ref[k]["z"]) and np.array_equal(got[k][1], ref[k]["info"]) for k in range(len(wins))))
+            shard_check = pieces_equal_whole(parts, ref, wins)
 
     # the same job with the LD Gram on the int8 matrix cores (identical integers, identical outputs):
     # reported next to the headline, never as `value`
@@ -340,12 +362,13 @@ def run_impute(args, rig):
 
     emu = None
     if rig.world == 1 and args.emulate_world > 1:
-        own_e, load_e = workload.shard(wins, N, args.emulate_world)
-        per_rank = []
+        shares_e, load_e = shares_of(args, wins, N, args.emulate_world)
+        per_rank, parts_e = [], []
         for r in range(args.emulate_world):
-            wr = [wins[k] for k in range(len(wins)) if own_e[k] == r]
-            rr = Runner(rig, window_descs(ch, wr, store, ld2, args.mode), 1)
-            dtr, str_, _ = rr.timed(args.steps, max(1, args.warmup))
+            wr = workload.pieces_of(wins, shares_e[r])
+            rr = Runner(rig, window_descs(ch, wr, store, ld2, args.mode), 1, args.jobs)
+            dtr, str_, res_r = rr.timed(args.steps, max(1, args.warmup))
+            parts_e.append({piece: (q["z"], q["info"]) for piece, q in zip(shares_e[r], rr.results_in_order(res_r))})
             per_rank.append({"rank": r, "windows": len(wr), "ms_per_step": dtr / args.steps * 1e3,
                              "stage_ms": {k: v[0] / args.steps for k, v in str_.items()},
                              "gram_frac_of_peak": (rr.work["ld_flops"] / (str_["gram"][0] / max(1, str_["gram"][1]) * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS)
@@ -355,7 +378,9 @@ def run_impute(args, rig):
         emu = {"world": args.emulate_world, "per_rank": per_rank, "slowest_rank_ms": slow,
                "one_gpu_ms": dt / args.steps * 1e3, "predicted_speedup": dt / args.steps * 1e3 / slow,
                "predicted_efficiency": dt / args.steps * 1e3 / slow / args.emulate_world,
-               "lpt_load_imbalance": max(load_e) / (sum(load_e) / len(load_e)),
+               "load_imbalance": max(load_e) / (sum(load_e) / len(load_e)), "shard": args.shard,
+               "cut_windows": sum(1 for sh in shares_e for _, u0, _ in sh if u0 > 0),
+               "pieces_bit_identical_to_one_job": pieces_equal_whole(parts_e, res, wins),
                "note": "each rank's share timed alone on ONE GPU, one after the other: an emulation of the per-rank step time, "
                        "not a multi-GPU measurement (no 8-GPU node is available to the builder)"}
 
@@ -396,7 +421,11 @@ def run_impute(args, rig):
                              f"measured SNPs (positions, z) from {ch['study']}, synthetic unmeasured SNPs and genotypes; "
                              f"{len(ch['bp'])} SNPs x {N} samples ({len(ch['pops'])} populations), {len(wins)} windows of 1 Mb, "
                              f"{args.wing // 1000} kb wings; " +
-                             ("the windows of ONE chromosome sharded over the ranks (LPT on LD flops)" if strong
+                             (("the windows of ONE chromosome sharded over the ranks " +
+                               {"leveled": "(LPT on modelled cost, then levelled: a few windows are cut between two ranks, which both "
+                                           "factor the window's B11)",
+                                "contiguous": "(contiguous shares of equal cost; a window on a boundary is cut between two ranks)",
+                                "lpt": "(whole windows, LPT on modelled cost)"}[args.shard]) if strong
                               else "one whole chromosome per rank")),
                 "windows": len(wins), "snps": int(len(ch["bp"])), "samples": N,
                 "imputed_snps_per_step": int(snps),
@@ -404,7 +433,9 @@ def run_impute(args, rig):
                 "unmeasured_per_window": {"min": int(min(u_all)), "mean": float(np.mean(u_all)), "max": int(max(u_all))},
                 "windows_per_rank": [len(d["windows"]) for d in digests],
                 "resident_panel_rows_per_rank": [d["resident_rows"] for d in digests],
-                "lpt_load_imbalance": (max(load) / (sum(load) / len(load))) if strong else 1.0,
+                "shard": args.shard if strong else None,
+                "cut_windows": sum(1 for d in digests for _, u0, _ in d["windows"] if u0 > 0),
+                "load_imbalance": (max(load) / (sum(load) / len(load))) if strong else 1.0,
                 "rank_seconds": [d["dt"] for d in digests],
                 "windows_flagged": bad, "all_finite": bool(finite),
                 "panel_in_hbm": "one 2-bit packed row store per rank, windows index it by row",
@@ -447,6 +478,32 @@ def run_impute(args, rig):
 
 def rank_of(rig):
     return rig.rank
+
+
+def shares_of(args, wins, n_samples, world):
+    """Per-rank shares [(window, u0, u1)] and per-rank modelled cost."""
+    from gauss_amd import workload
+    if args.shard != "lpt":
+        return workload.shard_balanced(wins, n_samples, world, contiguous=args.shard == "contiguous")
+    owner, load = workload.shard(wins, n_samples, world)
+    return [[(k, 0, len(wins[k][2])) for k in range(len(wins)) if owner[k] == r] for r in range(world)], load
+
+
+def pieces_equal_whole(parts, ref, wins):
+    """Every window's z / info, put together from the ranks' pieces, equal bit for bit what ONE job over the whole
+    chromosome computed (parts: one {(window, u0, u1): (z, info)} per rank; ref: that job's results)."""
+    got = {}
+    for p in parts:
+        got.update(p)
+    for k in range(len(wins)):
+        pieces = sorted(q for q in got if q[0] == k)
+        if not pieces or pieces[0][1] != 0 or pieces[-1][2] != len(wins[k][2]) or any(a[2] != b[1] for a, b in zip(pieces, pieces[1:])):
+            return False
+        z = np.concatenate([got[q][0] for q in pieces])
+        info = np.concatenate([got[q][1] for q in pieces])
+        if not (np.array_equal(z, ref[k]["z"]) and np.array_equal(info, ref[k]["info"])):
+            return False
+    return True
 
 
 def pmc_traffic(applicable, kernel="gauss::gram_kernel<float>"):

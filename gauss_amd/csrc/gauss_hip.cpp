@@ -68,6 +68,10 @@ struct BlockCache {
 struct gauss_ctx {
     int device;
     hipStream_t stream;
+    // The factorisation and solve of a job (few, dependent, latency-bound launches) are queued here behind an event,
+    // so that they run under the NEXT job's Gram kernel, which the main stream starts at once (GAUSS_TAIL_STREAM=0:
+    // everything on `stream`).
+    hipStream_t tail = nullptr;
     int gram_i8 = 0;
     std::map<const void*, size_t> stores;    // row stores made by gauss_store_upload: base pointer -> bytes
     std::mutex mu;
@@ -178,6 +182,7 @@ struct gauss_job {
     char* h_pin = nullptr;                                 // pinned block: [table image | results | status]
     hipEvent_t begin = nullptr;                            // recorded when gauss_job_run starts queuing
     hipEvent_t done = nullptr;                             // recorded after the result copies of gauss_job_run
+    hipEvent_t mid = nullptr;                              // LD matrices written (main stream) -> tails may start (tail stream)
     Prob* d_probs = nullptr;
     Item* d_items = nullptr;    int n_items = 0;
     int2* d_rowmap = nullptr;   int n_rows = 0;
@@ -560,7 +565,11 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
     // bench workload (rocprofv3 FETCH_SIZE): 22.0 GB -> 16.0 GB per launch at 36, same kernel time; larger
     // blocks start to cost time (load balance).  GAUSS_XCD_BLOCK overrides (0 = plain order).
     {
-        static const int xcd_block = [] { const char* e = getenv("GAUSS_XCD_BLOCK"); return e ? atoi(e) : 36; }();
+        // Small jobs (the 4-5 windows an 8-rank run leaves per GPU, ~7 000 items) take blocks of 8: a block of 36 is
+        // 4 % of an XCD's share there, and the XCD that gets one more than the others finishes last (Gram kernel of
+        // the 8-rank shares 5.10 -> 5.03 ms; 36 windows: 38.5 ms either way, but 36 reads 27 % less from the fabric).
+        static const int xcd_env = [] { const char* e = getenv("GAUSS_XCD_BLOCK"); return e ? atoi(e) : -1; }();
+        const int xcd_block = xcd_env >= 0 ? xcd_env : (items.size() >= 20000 ? 36 : 8);
         if (xcd_block > 0 && items.size() > (size_t)8 * xcd_block) {
             std::vector<std::vector<ItemH>> q(8);
             for (size_t i = 0; i < items.size(); i++) q[(i / xcd_block) % 8].push_back(items[i]);
@@ -658,6 +667,7 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
     job->h_status = (int*)(job->h_pin + pin_tab + pin_res);
     HIPCHK(hipEventCreate(&job->begin));
     HIPCHK(hipEventCreate(&job->done));
+    HIPCHK(hipEventCreateWithFlags(&job->mid, hipEventDisableTiming));
 
     hipStream_t st = ctx->stream;
     // zero once: operand padding, B21 padding and the solve matrices rely on it
@@ -772,20 +782,20 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
 // ------------------------------------------------------------------------------------------
 // profiling helpers
 // ------------------------------------------------------------------------------------------
-static void prof_begin(gauss_job* job, int kernel)
+static void prof_begin(gauss_job* job, int kernel, hipStream_t st)
 {
     if (!job->prof) return;
     ProfSlot s;
     s.kernel = kernel;
     hipEventCreate(&s.a);
     hipEventCreate(&s.b);
-    hipEventRecord(s.a, job->ctx->stream);
+    hipEventRecord(s.a, st);
     job->slots.push_back(s);
 }
-static void prof_end(gauss_job* job)
+static void prof_end(gauss_job* job, hipStream_t st)
 {
     if (!job->prof) return;
-    hipEventRecord(job->slots.back().b, job->ctx->stream);
+    hipEventRecord(job->slots.back().b, st);
 }
 static void prof_collect(gauss_job* job)
 {
@@ -806,38 +816,45 @@ static int job_run(gauss_job* job, bool solve)
 {
     hipStream_t st = job->ctx->stream;
     HIPCHK(hipSetDevice(job->ctx->device));
+    // a job run again: its LD matrices and result block are still being read by the previous run's tails
+    if (job->ran && job->ctx->tail) HIPCHK(hipStreamWaitEvent(st, job->done, 0));
     HIPCHK(hipEventRecord(job->begin, st));
     HIPCHK(hipMemsetAsync(job->d_status, 0, sizeof(int) * 4 * job->n, st));
-    prof_begin(job, 1);
+    prof_begin(job, 1, st);
     launch_pack_stats(job->d_probs, job->d_rowmap, job->n_rows, st);
     launch_row_stats(job->d_probs, job->d_rowmap, job->n_rows, st);
     if (solve && job->n_panels > 0) launch_shift_cert(job->d_probs, job->n, st);      // needs the row tables only
-    prof_end(job);
-    prof_begin(job, 0);
+    prof_end(job, st);
+    prof_begin(job, 0, st);
     launch_gram(job->d_items, job->n_items, job->gram_i8, st);
-    prof_end(job);
-    prof_begin(job, 2);
+    prof_end(job, st);
+    prof_begin(job, 2, st);
     launch_epilogue(job->d_probs, job->d_tilemap, job->n_tiles, job->max_pop, job->gram_i8, st);
     for (int i = 0; i < job->n; i++)
         if (job->plans[i].p.n_gene) launch_gene_epilogue(job->d_probs, i, job->plans[i].p.n_gene, st);
-    prof_end(job);
+    prof_end(job, st);
     if (solve && job->n_panels > 0) {
         for (int i = 0; i < job->n; i++) {
             Plan& pl = job->plans[i];
             if (pl.out_b11 && pl.p.npanel > 0)
                 HIPCHK(hipMemcpyAsync(pl.d_b11_copy, pl.p.A, sizeof(double) * pl.p.Mld * pl.p.Mld, hipMemcpyDeviceToDevice, st));
         }
+        if (job->ctx->tail) {
+            HIPCHK(hipEventRecord(job->mid, st));
+            st = job->ctx->tail;
+            HIPCHK(hipStreamWaitEvent(st, job->mid, 0));
+        }
         // fused (default): the solve's block rows ride in the factorisation's update launches (k_solve.hip); the stage
         // timers then read "factor" = factorisation + all solve rows but the last, "solve" = the closing launch
         static const bool fused = !(getenv("GAUSS_FUSED_SOLVE") && atoi(getenv("GAUSS_FUSED_SOLVE")) == 0);
-        prof_begin(job, 3);
+        prof_begin(job, 3, st);
         for (int s = 0; s < job->max_nblk; s++)
             launch_factor_step(job->d_probs, job->n, s, job->max_nblk, fused ? job->max_npanel : 0, job->solve_split, st);
-        prof_end(job);
-        prof_begin(job, 4);
+        prof_end(job, st);
+        prof_begin(job, 4, st);
         if (fused) launch_solve_last(job->d_probs, job->d_panelmap, job->n_panels, job->max_nblk, job->solve_split, st);
         else launch_solve(job->d_probs, job->d_panelmap, job->n_panels, st);
-        prof_end(job);
+        prof_end(job, st);
     }
     HIPCHK(hipGetLastError());
     // the result mirrors travel with the run, so that gauss_job_fetch waits for THIS job only (an event), not for
@@ -987,6 +1004,9 @@ static void job_free(gauss_job* job)
 {
     if (!job) return;
     if (job->ctx) hipSetDevice(job->ctx->device);
+    // the workspace goes back to the context's cache: nothing of this job may still be queued (its tails run on
+    // their own stream, so the next owner's first write is not ordered behind them)
+    if (job->ran && job->done) (void)hipEventSynchronize(job->done);
     for (ProfSlot& s : job->slots) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
     if (job->ctx) {
         ctx_dev_release(job->ctx, job->d_ws);
@@ -995,6 +1015,7 @@ static void job_free(gauss_job* job)
     }
     if (job->begin) hipEventDestroy(job->begin);
     if (job->done) hipEventDestroy(job->done);
+    if (job->mid) hipEventDestroy(job->mid);
     delete job;
 }
 
@@ -1031,6 +1052,15 @@ int gauss_hip_init(int device, gauss_ctx** out_ctx)
     const char* e = getenv("GAUSS_GRAM_DTYPE");
     c->gram_i8 = (e && (strcmp(e, "i8") == 0 || strcmp(e, "int8") == 0)) ? 1 : 0;
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    const char* ts = getenv("GAUSS_TAIL_STREAM");
+    if (!(ts && atoi(ts) == 0)) {
+        // highest priority: the tails' few workgroups must get the slots the Gram kernel's workgroups free, or every
+        // dependent launch of the chain waits behind the Gram kernel's own backlog
+        int lo = 0, hi = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        const char* tp = getenv("GAUSS_TAIL_PRIORITY");
+        HIPCHK(hipStreamCreateWithPriority(&c->tail, hipStreamNonBlocking, (tp && atoi(tp) == 0) ? lo : hi));
+    }
     *out_ctx = c;
     return GAUSS_OK;
 }
@@ -1053,6 +1083,7 @@ void gauss_hip_destroy(gauss_ctx* ctx)
     if (!ctx) return;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
+    if (ctx->tail) { hipStreamSynchronize(ctx->tail); hipStreamDestroy(ctx->tail); }
     for (auto& kv : ctx->dev_cache.free_blocks) (void)hipFree(kv.second);
     for (auto& kv : ctx->pin_cache.free_blocks) (void)hipHostFree(kv.second);
     hipStreamDestroy(ctx->stream);
@@ -1202,6 +1233,7 @@ int gauss_job_profile_get(gauss_job* job, int kernel, double* out_ms, int64_t* o
 {
     if (!job || kernel < 0 || kernel > 4) return fail(GAUSS_E_INVALID, "bad arguments");
     hipStreamSynchronize(job->ctx->stream);
+    if (job->ctx->tail) hipStreamSynchronize(job->ctx->tail);
     prof_collect(job);
     if (out_ms) *out_ms = job->prof_ms[kernel];
     if (out_launches) *out_launches = job->prof_n[kernel];

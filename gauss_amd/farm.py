@@ -36,6 +36,136 @@ def assign_windows(costs, world_size):
     return owner
 
 
+def piece_cost(n_samples, m, u):
+    """Cost of imputing `u` unmeasured SNPs of a window with `m` measured ones, in fp32-matrix-flop units:
+    (setup, per unmeasured SNP).  The setup -- B11's Gram and its Cholesky factor -- is paid by every rank that
+    holds a piece of the window; fp64 matrix flops are priced at four fp32 ones (78.6 vs 157.3 TFLOP/s peak, and
+    the factor/solve kernels run at about half the Gram kernel's fraction of it)."""
+    setup = float(n_samples) * m * (m + 1.0) + 4.0 * m ** 3 / 3.0
+    per_u = 2.0 * n_samples * m + 8.0 * float(m) * m
+    return setup, per_u
+
+
+def balance_windows(mu, n_samples, world_size, granule=64):
+    """Contiguous, balanced shares of a chromosome's windows with window SPLITTING.
+
+    A window's imputed SNPs are independent given its measured set (dist.cpp:181-198: one row of B21, one solve,
+    per unmeasured SNP), so a window may be cut into pieces that share the measured SNPs and divide the unmeasured
+    ones; each piece repeats the B11 work.  Walking the windows in chromosome order, every rank is filled up to a
+    common load T and the window that straddles the boundary is cut (at a multiple of `granule` unmeasured SNPs);
+    the smallest feasible T is found by bisection.  At most world_size - 1 windows are cut, the ranks' loads agree
+    to within one granule, and every rank's windows cover one contiguous stretch of the chromosome (so its slice of
+    the panel is about 1 / world_size of it, plus the wings).
+
+    mu = [(M, U)] per window.  Returns (shares, loads): shares[r] = [(window, u0, u1)], deterministic on every rank."""
+    costs = [piece_cost(n_samples, m, u) for m, u in mu]
+    total = sum(b + u * r for (b, r), (_, u) in zip(costs, mu))
+    if world_size <= 1 or not mu:
+        return [[(k, 0, u) for k, (_, u) in enumerate(mu)]] + [[] for _ in range(world_size - 1)], [total] + [0.0] * (world_size - 1)
+
+    def fill(T):
+        shares, loads, cap = [[]], [0.0], T
+        for k, (_, U) in enumerate(mu):
+            b, r = costs[k]
+            u0 = 0
+            while u0 < U:
+                need = b + (U - u0) * r
+                if need <= cap:
+                    shares[-1].append((k, u0, U)); loads[-1] += need; cap -= need; u0 = U
+                    continue
+                room = int(max(0.0, cap - b) // r) // granule * granule
+                if room >= granule and U - u0 - room >= granule:
+                    shares[-1].append((k, u0, u0 + room)); loads[-1] += b + room * r; u0 += room
+                elif not shares[-1]:
+                    return None                      # T does not even hold this piece on an empty rank
+                if len(shares) == world_size:
+                    return None
+                shares.append([]); loads.append(0.0); cap = T
+        while len(shares) < world_size:
+            shares.append([]); loads.append(0.0)
+        return shares, loads
+
+    lo, hi = total / world_size, total + 1.0
+    best = fill(hi)
+    for _ in range(60):
+        mid = 0.5 * (lo + hi)
+        got = fill(mid)
+        if got is None:
+            lo = mid
+        else:
+            best, hi = got, mid
+    return best
+
+
+# One block step (64 measured SNPs) of a job's factorisation chain in piece_cost units: the chain is as long as the
+# job's tallest window and latency-bound on small jobs (measured on MI355X: 19 us per step against 8.06 ms per 1e12
+# cost units, bench.py --emulate-world fits)
+CHAIN_STEP_COST = 2.4e9
+
+
+def level_windows(mu, n_samples, world_size, granule=64):
+    """Whole windows by LPT, a local search, then LEVELLING with window cuts.
+
+    A rank's load is the cost of its pieces plus the factorisation chain of its tallest window (CHAIN_STEP_COST per
+    64 measured SNPs).  (1) LPT on the windows' costs; (2) while it lowers the largest load, one window of the most
+    loaded rank moves to, or trades places with a window of, another rank -- tall windows end up sharing ranks, the
+    other ranks' chains get short; (3) while it lowers the largest load, the most loaded rank hands a slice of one
+    window's unmeasured SNPs to the least loaded rank, which factors that window's B11 itself (piece_cost's setup):
+    in practice a window with few measured SNPs, whose B11 is cheap to repeat.  On the chr22 study at 8 ranks the
+    largest modelled load goes 1.07 -> 1.01 of the mean for < 1 % of repeated work; contiguous shares
+    (balance_windows) repeat 3.2 %.
+
+    mu = [(M, U)] per window.  Returns (shares, loads): shares[r] = [(window, u0, u1)], deterministic on every rank."""
+    costs = [piece_cost(n_samples, m, u) for m, u in mu]
+    nblk = [(m + 63) // 64 for m, _ in mu]
+
+    def load_of(pieces):
+        return (sum(costs[k][0] + (u1 - u0) * costs[k][1] for k, u0, u1 in pieces)
+                + CHAIN_STEP_COST * max((nblk[k] for k, _, _ in pieces), default=0))
+
+    owner = assign_windows([b + u * r for (b, r), (_, u) in zip(costs, mu)], world_size)
+    shares = [[(k, 0, mu[k][1]) for k in range(len(mu)) if owner[k] == r] for r in range(world_size)]
+    if world_size > 1:
+        for _ in range(4 * len(mu)):                                     # (2) moves and swaps of whole windows
+            loads = [load_of(sh) for sh in shares]
+            hi = max(range(world_size), key=lambda r: (loads[r], -r))
+            best = None
+            for a in shares[hi]:
+                rest = [p for p in shares[hi] if p != a]
+                for r in range(world_size):
+                    if r == hi:
+                        continue
+                    for b in [None] + shares[r]:
+                        g_hi = rest + ([b] if b else [])
+                        g_r = [p for p in shares[r] if p != b] + [a]
+                        m = max(load_of(g_hi), load_of(g_r))
+                        if m < loads[hi] * (1 - 1e-9) and (best is None or m < best[0]):
+                            best = (m, r, g_hi, g_r)
+            if best is None:
+                break
+            _, r, shares[hi], shares[r] = best
+        for _ in range(2 * world_size):                                  # (3) cuts
+            loads = [load_of(sh) for sh in shares]
+            hi = max(range(world_size), key=lambda r: (loads[r], -r))
+            lo = min(range(world_size), key=lambda r: (loads[r], r))
+            best = None
+            for idx, (k, u0, u1) in enumerate(shares[hi]):
+                b, r = costs[k]
+                extra = load_of(shares[lo] + [(k, 0, 0)]) - loads[lo]     # B11 again, and maybe a longer chain
+                d = min(int((loads[hi] - loads[lo] - extra) / (2.0 * r)) // granule * granule, (u1 - u0) - granule)
+                if d >= granule:
+                    g_hi = shares[hi][:idx] + [(k, u0, u1 - d)] + shares[hi][idx + 1:]
+                    g_lo = shares[lo] + [(k, u1 - d, u1)]
+                    m = max(load_of(g_hi), load_of(g_lo))
+                    if m < loads[hi] * (1 - 1e-9) and (best is None or m < best[0]):
+                        best = (m, g_hi, g_lo)
+            if best is None:
+                break
+            _, shares[hi], shares[lo] = best
+    shares = [sorted(sh) for sh in shares]
+    return shares, [load_of(sh) for sh in shares]
+
+
 def window_cost(n_samples, m, u):
     """Pair-loop cost of one window: N * (M(M+1)/2 + U*M)."""
     return float(n_samples) * (m * (m + 1) / 2.0 + float(u) * m)

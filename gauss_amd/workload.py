@@ -115,3 +115,17 @@ def shard(wins, n_samples, world):
     for c, r in zip(costs, owner):
         load[r] += c
     return owner, load
+
+
+def shard_balanced(wins, n_samples, world, granule=64, contiguous=False):
+    """Shares with window cutting: LPT + levelling (farm.level_windows) or contiguous equal-cost stretches
+    (farm.balance_windows).  Returns (shares[r] = [(window, u0, u1)], per-rank cost list)."""
+    from . import farm
+    mu = [(len(mi), len(ui)) for _, mi, ui in wins]
+    return (farm.balance_windows if contiguous else farm.level_windows)(mu, n_samples, world, granule)
+
+
+def pieces_of(wins, share):
+    """The window tuples of one rank's share: a cut window keeps its measured rows and a slice of the unmeasured ones."""
+    return [(wins[k][0], wins[k][1], wins[k][2][u0:u1]) for k, u0, u1 in share]
+
