@@ -72,10 +72,6 @@ def parse_args(argv=None):
                     help="single GPU: time every rank's LPT share of an N-rank strong-scaling run one after the other "
                          "(what one rank of N would do per step); printed as `emulated_strong_scaling`, never as `value`")
     ap.add_argument("--streams", type=int, default=1, help="split a rank's windows over this many contexts (one stream pair each)")
-    ap.add_argument("--jobs", type=int, default=1,
-                    help="split a rank's windows over this many jobs of ONE context, queued back to back: the factorisation and "
-                         "solve of job k (the context's tail stream) then run under the Gram kernel of job k+1, and a step's "
-                         "results are collected while the next step is already queued")
     return ap.parse_args(argv)
 
 
@@ -191,41 +187,27 @@ def window_descs(ch, wins, store, ld2, mode, rows_of=None):
 
 
 class Runner:
-    """A rank's windows as `jobs` jobs per context; step() queues every job once and collects what the previous
-    step left (so the GPU always has the next job's Gram queued behind the tails it is finishing); drain() collects
-    the rest.  Every step's results are fetched exactly once, inside the timed region."""
+    """A rank's windows as one job per context (stream); step() = run + fetch of all of them."""
 
-    def __init__(self, rig, descs, streams=1, jobs=1):
+    def __init__(self, rig, descs, streams=1):
         from gauss_amd import hotpath
         self.rig = rig
         self.ctxs = [rig.ctx] + [hotpath.Context(rig.local) for _ in range(max(1, streams) - 1)]
         self.jobs, self.order = [], []
         if descs:
-            n = min(len(self.ctxs) * max(1, jobs), len(descs))
-            self.jobs = [hotpath.Job(descs[i::n], ctx=self.ctxs[i % len(self.ctxs)], on_device=True) for i in range(n)]
+            n = min(len(self.ctxs), len(descs))
+            self.jobs = [hotpath.Job(descs[i::n], ctx=self.ctxs[i], on_device=True) for i in range(n)]
             self.order = [k for i in range(n) for k in range(i, len(descs), n)]
-        self.pending = [False] * len(self.jobs)
-        self.last = [[] for _ in self.jobs]
         self.work = {k: sum(j.work()[k] for j in self.jobs) for k in ("ld_flops", "solve_flops", "bytes", "imputed_snps")}
         self.stats = {k: sum(j.stats()[k] for j in self.jobs) for k in ("items", "executed_flops", "slab_bytes", "workspace_bytes")}
 
     def step(self):
-        if len(self.jobs) == 1:                      # one job: run + fetch, nothing to overlap with
-            self.jobs[0].run()
-            self.last[0] = self.jobs[0].fetch()
-            return
-        for i, j in enumerate(self.jobs):
-            if self.pending[i]:
-                self.last[i] = j.fetch()
+        for j in self.jobs:
             j.run()
-            self.pending[i] = True
-
-    def drain(self):
-        for i, j in enumerate(self.jobs):
-            if self.pending[i]:
-                self.last[i] = j.fetch()
-                self.pending[i] = False
-        return [r for part in self.last for r in part]
+        out = []
+        for j in self.jobs:
+            out += j.fetch()
+        return out
 
     def results_in_order(self, res):
         out = [None] * len(res)
@@ -250,15 +232,14 @@ class Runner:
         return tot
 
     def timed(self, steps, warmup):
+        res = []
         for _ in range(warmup):
-            self.step()
-        self.drain()
+            res = self.step()
         self.profile(True)
         self.rig.barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
-            self.step()
-        res = self.drain()
+            res = self.step()
         self.rig.barrier()
         dt = time.perf_counter() - t0
         st = self.stage_ms()
@@ -311,7 +292,7 @@ def run_impute(args, rig):
         store = full_store.index_select(0, torch.from_numpy(rows_of).cuda()) if len(rows_of) else full_store[:1]
     torch.cuda.synchronize()
     rig.ctx.set_gram_dtype(args.gram_dtype)
-    runner = Runner(rig, window_descs(ch, my_wins, store, ld2, args.mode, rows_of), args.streams, args.jobs)
+    runner = Runner(rig, window_descs(ch, my_wins, store, ld2, args.mode, rows_of), args.streams)
     work, stats = runner.work, runner.stats
 
     dt, st, res = runner.timed(args.steps, args.warmup)
@@ -328,8 +309,7 @@ def run_impute(args, rig):
         parts = rig.gather({piece: (r["z"], r["info"]) for piece, r in zip(mine, res)})
         if rig.rank == 0:
             allr = Runner(rig, window_descs(ch, wins, full_store, ld2, args.mode), 1)
-            allr.step()
-            ref = allr.drain()
+            ref = allr.step()
             allr.close()
             shard_check = pieces_equal_whole(parts, ref, wins)
 
@@ -366,7 +346,7 @@ def run_impute(args, rig):
         per_rank, parts_e = [], []
         for r in range(args.emulate_world):
             wr = workload.pieces_of(wins, shares_e[r])
-            rr = Runner(rig, window_descs(ch, wr, store, ld2, args.mode), 1, args.jobs)
+            rr = Runner(rig, window_descs(ch, wr, store, ld2, args.mode), 1)
             dtr, str_, res_r = rr.timed(args.steps, max(1, args.warmup))
             parts_e.append({piece: (q["z"], q["info"]) for piece, q in zip(shares_e[r], rr.results_in_order(res_r))})
             per_rank.append({"rank": r, "windows": len(wr), "ms_per_step": dtr / args.steps * 1e3,

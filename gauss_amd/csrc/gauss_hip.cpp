@@ -68,10 +68,6 @@ struct BlockCache {
 struct gauss_ctx {
     int device;
     hipStream_t stream;
-    // The factorisation and solve of a job (few, dependent, latency-bound launches) are queued here behind an event,
-    // so that they run under the NEXT job's Gram kernel, which the main stream starts at once (GAUSS_TAIL_STREAM=0:
-    // everything on `stream`).
-    hipStream_t tail = nullptr;
     int gram_i8 = 0;
     std::map<const void*, size_t> stores;    // row stores made by gauss_store_upload: base pointer -> bytes
     std::mutex mu;
@@ -182,7 +178,6 @@ struct gauss_job {
     char* h_pin = nullptr;                                 // pinned block: [table image | results | status]
     hipEvent_t begin = nullptr;                            // recorded when gauss_job_run starts queuing
     hipEvent_t done = nullptr;                             // recorded after the result copies of gauss_job_run
-    hipEvent_t mid = nullptr;                              // LD matrices written (main stream) -> tails may start (tail stream)
     Prob* d_probs = nullptr;
     Item* d_items = nullptr;    int n_items = 0;
     int2* d_rowmap = nullptr;   int n_rows = 0;
@@ -667,7 +662,6 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
     job->h_status = (int*)(job->h_pin + pin_tab + pin_res);
     HIPCHK(hipEventCreate(&job->begin));
     HIPCHK(hipEventCreate(&job->done));
-    HIPCHK(hipEventCreateWithFlags(&job->mid, hipEventDisableTiming));
 
     hipStream_t st = ctx->stream;
     // zero once: operand padding, B21 padding and the solve matrices rely on it
@@ -816,8 +810,6 @@ static int job_run(gauss_job* job, bool solve)
 {
     hipStream_t st = job->ctx->stream;
     HIPCHK(hipSetDevice(job->ctx->device));
-    // a job run again: its LD matrices and result block are still being read by the previous run's tails
-    if (job->ran && job->ctx->tail) HIPCHK(hipStreamWaitEvent(st, job->done, 0));
     HIPCHK(hipEventRecord(job->begin, st));
     HIPCHK(hipMemsetAsync(job->d_status, 0, sizeof(int) * 4 * job->n, st));
     prof_begin(job, 1, st);
@@ -838,11 +830,6 @@ static int job_run(gauss_job* job, bool solve)
             Plan& pl = job->plans[i];
             if (pl.out_b11 && pl.p.npanel > 0)
                 HIPCHK(hipMemcpyAsync(pl.d_b11_copy, pl.p.A, sizeof(double) * pl.p.Mld * pl.p.Mld, hipMemcpyDeviceToDevice, st));
-        }
-        if (job->ctx->tail) {
-            HIPCHK(hipEventRecord(job->mid, st));
-            st = job->ctx->tail;
-            HIPCHK(hipStreamWaitEvent(st, job->mid, 0));
         }
         // fused (default): the solve's block rows ride in the factorisation's update launches (k_solve.hip); the stage
         // timers then read "factor" = factorisation + all solve rows but the last, "solve" = the closing launch
@@ -1004,9 +991,6 @@ static void job_free(gauss_job* job)
 {
     if (!job) return;
     if (job->ctx) hipSetDevice(job->ctx->device);
-    // the workspace goes back to the context's cache: nothing of this job may still be queued (its tails run on
-    // their own stream, so the next owner's first write is not ordered behind them)
-    if (job->ran && job->done) (void)hipEventSynchronize(job->done);
     for (ProfSlot& s : job->slots) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
     if (job->ctx) {
         ctx_dev_release(job->ctx, job->d_ws);
@@ -1015,7 +999,6 @@ static void job_free(gauss_job* job)
     }
     if (job->begin) hipEventDestroy(job->begin);
     if (job->done) hipEventDestroy(job->done);
-    if (job->mid) hipEventDestroy(job->mid);
     delete job;
 }
 
@@ -1052,15 +1035,6 @@ int gauss_hip_init(int device, gauss_ctx** out_ctx)
     const char* e = getenv("GAUSS_GRAM_DTYPE");
     c->gram_i8 = (e && (strcmp(e, "i8") == 0 || strcmp(e, "int8") == 0)) ? 1 : 0;
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    const char* ts = getenv("GAUSS_TAIL_STREAM");
-    if (!(ts && atoi(ts) == 0)) {
-        // highest priority: the tails' few workgroups must get the slots the Gram kernel's workgroups free, or every
-        // dependent launch of the chain waits behind the Gram kernel's own backlog
-        int lo = 0, hi = 0;
-        HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        const char* tp = getenv("GAUSS_TAIL_PRIORITY");
-        HIPCHK(hipStreamCreateWithPriority(&c->tail, hipStreamNonBlocking, (tp && atoi(tp) == 0) ? lo : hi));
-    }
     *out_ctx = c;
     return GAUSS_OK;
 }
@@ -1083,7 +1057,6 @@ void gauss_hip_destroy(gauss_ctx* ctx)
     if (!ctx) return;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
-    if (ctx->tail) { hipStreamSynchronize(ctx->tail); hipStreamDestroy(ctx->tail); }
     for (auto& kv : ctx->dev_cache.free_blocks) (void)hipFree(kv.second);
     for (auto& kv : ctx->pin_cache.free_blocks) (void)hipHostFree(kv.second);
     hipStreamDestroy(ctx->stream);
@@ -1233,7 +1206,6 @@ int gauss_job_profile_get(gauss_job* job, int kernel, double* out_ms, int64_t* o
 {
     if (!job || kernel < 0 || kernel > 4) return fail(GAUSS_E_INVALID, "bad arguments");
     hipStreamSynchronize(job->ctx->stream);
-    if (job->ctx->tail) hipStreamSynchronize(job->ctx->tail);
     prof_collect(job);
     if (out_ms) *out_ms = job->prof_ms[kernel];
     if (out_launches) *out_launches = job->prof_n[kernel];

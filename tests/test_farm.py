@@ -45,6 +45,48 @@ def test_assign_windows_is_balanced_and_deterministic():
     assert farm.make_windows(1, 2_500_000, 1_000_000) == [(1, 1_000_000), (1_000_001, 2_000_000), (2_000_001, 2_500_000)]
 
 
+def _check_shares(shares, mu, world):
+    assert len(shares) == world
+    cover = {}
+    for sh in shares:
+        for k, u0, u1 in sh:
+            assert 0 <= u0 < u1 <= mu[k][1]
+            cover.setdefault(k, []).append((u0, u1))
+    assert sorted(cover) == list(range(len(mu)))                       # every window, and ...
+    for k, segs in cover.items():
+        segs.sort()
+        assert segs[0][0] == 0 and segs[-1][1] == mu[k][1]             # ... all of its unmeasured SNPs, once
+        assert all(a[1] == b[0] for a, b in zip(segs, segs[1:]))
+
+
+@pytest.mark.parametrize("splitter", ["level", "balance"])
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_shares_with_window_cuts_cover_every_snp_once_and_are_balanced(splitter, world):
+    """farm.level_windows / farm.balance_windows: pieces (window, u0, u1) tile every window's unmeasured SNPs exactly
+    once, the plan is deterministic, and the modelled loads are closer than whole-window LPT leaves them."""
+    rng = np.random.default_rng(5)
+    mu = [(int(m), int(u)) for m, u in zip(rng.integers(150, 1250, 36), rng.integers(500, 2600, 36))]
+    N = 32147
+    fn = farm.level_windows if splitter == "level" else farm.balance_windows
+    shares, loads = fn(mu, N, world)
+    assert (shares, loads) == fn(list(mu), N, world)
+    _check_shares(shares, mu, world)
+    if world > 1:
+        full = [b + u * r for (b, r), (_, u) in zip((farm.piece_cost(N, m, u) for m, u in mu), mu)]
+        own = farm.assign_windows(full, world)
+        chain = (lambda r: farm.CHAIN_STEP_COST * max(((mu[k][0] + 63) // 64 for k in range(len(mu)) if own[k] == r), default=0)) \
+            if splitter == "level" else (lambda r: 0.0)
+        lpt = [sum(c for c, o in zip(full, own) if o == r) + chain(r) for r in range(world)]
+        assert max(loads) / (sum(loads) / world) <= (1.03 if splitter == "level" else 1.10)
+        assert max(loads) <= max(lpt) * (1.0 if splitter == "level" else 1.10)     # contiguity costs: balance_windows repeats a B11 per boundary
+    cuts = sum(1 for sh in shares for _, u0, _ in sh if u0 > 0)
+    assert cuts <= 2 * world
+    # degenerate inputs
+    assert fn([], N, 4)[0] == [[], [], [], []]
+    one = fn([(300, 900)], N, 4)[0]
+    _check_shares(one, [(300, 900)], 4)
+
+
 def test_farm_single_process_matches_per_window_calls(tmp_path):
     st = make_study(tmp_path)
     p = st["paths"]

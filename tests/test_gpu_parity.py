@@ -482,3 +482,65 @@ def test_solve_forms_agree(ctx, mode, monkeypatch):
             assert relerr(r["info"], want["info"]) <= Z_TOL
             assert np.max(np.abs(r["z"] - want["z"]) / np.maximum(1.0, np.abs(want["z"]))) <= Z_TOL
         assert np.array_equal(a["info"], b["info"]) and np.array_equal(a["z"], b["z"])
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_pieces_of_a_cut_window_equal_the_whole_window(ctx, mode):
+    """A window's unmeasured SNPs are imputed independently given its measured set (dist.cpp:181-198), so the
+    multi-GPU planner may cut a window between two ranks (farm.level_windows): the pieces -- same measured SNPs, a
+    slice of the unmeasured ones, each in a job of its own with other windows around it -- must return the whole
+    window's z / info bit for bit."""
+    p = small_panel(n_snp=520, scale=0.03, seed=9)
+    G, off = p["G"], p["off"]
+    rng = np.random.default_rng(7)
+    idx = rng.permutation(G.shape[0])
+    m, u = 200, 300
+    gm, gu = np.ascontiguousarray(G[np.sort(idx[:m])]), np.ascontiguousarray(G[np.sort(idx[m:m + u])])
+    z1 = rng.standard_normal(m) * 2
+    other = dict(mode=mode, geno_m=np.ascontiguousarray(G[:90]), geno_u=np.ascontiguousarray(G[90:160]), pop_off=off,
+                 pop_wgt=p["w"], z1=rng.standard_normal(90))
+
+    def run(wins):
+        job = hotpath.Job(wins, ctx=ctx)
+        job.run()
+        out = job.fetch()
+        job.close()
+        return out
+    whole = run([dict(mode=mode, geno_m=gm, geno_u=gu, pop_off=off, pop_wgt=p["w"], z1=z1)])[0]
+    want = oracle.run_impute(mode, gm, gu, off, p["w"], z1)
+    assert relerr(whole["info"], want["info"]) <= Z_TOL
+    cuts = [0, 64, 193, u]                                     # a tile-aligned and a ragged cut
+    z, info = [], []
+    for a, b in zip(cuts, cuts[1:]):
+        piece = dict(mode=mode, geno_m=gm, geno_u=np.ascontiguousarray(gu[a:b]), pop_off=off, pop_wgt=p["w"], z1=z1)
+        res = run([other, piece] if a else [piece, other])
+        r = res[1] if a else res[0]
+        assert r["status"] == 0
+        z.append(r["z"]); info.append(r["info"])
+    assert np.array_equal(np.concatenate(z), whole["z"]) and np.array_equal(np.concatenate(info), whole["info"])
+
+
+def test_jobs_queued_back_to_back_keep_their_results_apart(ctx):
+    """Pipelines (the chromosome driver): three jobs of one context queued before any fetch, twice over, must each
+    return what they return alone -- a job's result mirrors travel with its own run and its fetch waits for its
+    own event only."""
+    p = small_panel(n_snp=400, scale=0.03, seed=13)
+    rng = np.random.default_rng(3)
+    jobs, alone = [], []
+    for k, (m, u) in enumerate([(150, 120), (70, 200), (260, 90)]):
+        idx = rng.permutation(p["G"].shape[0])
+        w = dict(mode=k % 2, geno_m=np.ascontiguousarray(p["G"][np.sort(idx[:m])]),
+                 geno_u=np.ascontiguousarray(p["G"][np.sort(idx[m:m + u])]), pop_off=p["off"], pop_wgt=p["w"],
+                 z1=rng.standard_normal(m))
+        j = hotpath.Job([w], ctx=ctx)
+        j.run()
+        alone.append(j.fetch()[0])
+        jobs.append(j)
+    for _ in range(2):
+        for j in jobs:
+            j.run()
+        for j, want in zip(jobs, alone):
+            got = j.fetch()[0]
+            assert np.array_equal(got["z"], want["z"]) and np.array_equal(got["info"], want["info"])
+    for j in jobs:
+        j.close()

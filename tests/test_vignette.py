@@ -74,6 +74,27 @@ def test_single_snp_genes_of_the_vignette_pin_the_jepeg_tail(fn, row):
             assert r["top_categ"] == cat and r["top_snp"] == 0
 
 
+def test_printed_z_pval_pairs_of_the_dist_vignettes_pin_the_normal_tail():
+    """dist() / distmix() print z and pval = 2 * pnorm(|z|, lower = FALSE) side by side (dist.cpp:101,
+    distmix.cpp:110; dist_example.md:163-170,267-274): twelve (z, pval) pairs that need no panel.  The C oracle's
+    tail, scipy's, and the product's host tail (reached through a one-SNP gene, whose top_snp_pval is that very
+    expression, gene.cpp:522) must all print as the reference did."""
+    from scipy.stats import norm
+    n = 0
+    for fn in ("dist", "distmix"):
+        for row in KA[fn]["head"]:
+            z, shown = row["z"], row["pval"]
+            got = {"oracle": 2 * oracle.pnorm_upper(abs(z)), "scipy": 2 * norm.sf(abs(z)),
+                   "product": api.jepeg_gene_tail(np.array([[1.1]]), [z], [1.0], np.array([[1, 0, 0, 0, 0, 0]], dtype=np.int32),
+                                                  np.array([[1.0, 0, 0, 0, 0, 0]]))["top_snp_pval"]}
+            # both columns are rounded to 7 decimals: |dp| <= 0.5e-7 (pval) + 2 phi(z) * 0.5e-7 (z)
+            tol = 0.51e-7 * (1.0 + 2.0 * norm.pdf(z))
+            for who, p in got.items():
+                assert abs(p - shown) <= tol, (fn, row["rsid"], who, p, shown)
+            n += 1
+    assert n == 12
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("fn", ["jepeg", "jepegmix"])
 def test_gpu_product_reproduces_the_vignette_rows_of_single_snp_genes(ctx, tmp_path, fn):
