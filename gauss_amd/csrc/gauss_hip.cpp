@@ -182,10 +182,14 @@ struct gauss_job {
     Item* d_items = nullptr;    int n_items = 0;
     int2* d_rowmap = nullptr;   int n_rows = 0;
     int2* d_tilemap = nullptr;  int n_tiles = 0;
-    int2* d_panelmap = nullptr; int n_panels = 0;
+    int2* d_panelmap = nullptr; int n_panels = 0;          // fused path: (window, panel of [I | z1])
+    int2* d_dpanelmap = nullptr; int n_dpanels = 0;        // stand-alone solve: (window, panel of right-hand sides)
+    int2* d_gemmmap = nullptr;  int n_gemm = 0;            // (window, rhs panel of gemm_ut << 8 | k block of 128), longest first
+    int gemm_ut = 128;                                     // right-hand sides per tile of the product: 128, small jobs 64
+    int2* d_finmap = nullptr;   int n_fin = 0;             // (window, chunk of 256 right-hand sides)
     int max_nblk = 0;
     int max_npanel = 0;                                    // most solve panels of any one window
-    int solve_split = 0;                                   // 1: small job, solve rows are cut in partial sums + combine (k_solve.hip)
+    int solve_split = 0;                                   // rows of the inverse with at least this many products are cut (0: none)
     int max_pop = 1;
     int gram_i8 = 0;
     int* d_status = nullptr;                               // [n][4]
@@ -435,6 +439,8 @@ static int plan_problem(const WinSpec& w, Plan& pl, int seg_max, int group_targe
     p.Mld = (int)rup((size_t)w.M, NB);
     p.nblk = p.Mld / NB;
     p.npanel = (w.ld_only || w.kind == GAUSS_WIN_LD) ? 0 : (p.n_rhs + NRU - 1) / NRU;
+    p.npi = p.npanel > 0 ? (w.M + 1 + NR - 1) / NR : 0;
+    p.Up128 = (int)rup((size_t)std::max(p.n_rhs, 1), 128);
     pl.U_user = w.U;
     if (w.z1) pl.z1.assign(w.z1, w.z1 + w.M);
     pl.h_geno_m = w.geno_m; pl.h_geno_u = w.geno_u; pl.user_ld = w.ld;
@@ -535,8 +541,19 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
     // work lists
     struct ItemH { int prob, pair, group, len; };
     std::vector<ItemH> items;
-    std::vector<int2> rowmap, tilemap, panelmap;
+    std::vector<int2> rowmap, tilemap, panelmap, dpanelmap, gemmmap, finmap;
     job->max_nblk = 0;
+    {
+        // tiles of the closing product at 128 right-hand sides each: a small job (an 8-rank share: ~570) cannot fill the
+        // chip's 512 workgroup slots with them and is bound by the tiles' K loops, so it takes 64 (k_solve.hip)
+        size_t t128 = 0;
+        for (int i = 0; i < job->n; i++) {
+            const Prob& p = job->plans[i].p;
+            if (p.npanel > 0) t128 += (size_t)(p.Up128 / 128) * ((p.Mld + 127) / 128);
+        }
+        const int small = env_int("GAUSS_GEMM_SMALL_TILES", 1600);         // read per job: tests drive both tile widths
+        job->gemm_ut = t128 < (size_t)small ? 64 : 128;
+    }
     for (int i = 0; i < job->n; i++) {
         const Prob& p = job->plans[i].p;
         for (int pr = 0; pr < p.npair; pr++)
@@ -547,8 +564,14 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
         for (int r = 0; r < p.M + p.U; r++) rowmap.push_back(make_int2(i, r));
         if (!p.n_gene)
             for (int pr = 0; pr < p.npair; pr++) tilemap.push_back(make_int2(i, pr));
-        for (int pn = 0; pn < p.npanel; pn++) panelmap.push_back(make_int2(i, pn));
-        if (p.npanel > 0) { job->max_nblk = std::max(job->max_nblk, p.nblk); job->max_npanel = std::max(job->max_npanel, p.npanel); }
+        for (int pn = 0; pn < p.npi; pn++) panelmap.push_back(make_int2(i, pn));
+        for (int pn = 0; pn < p.npanel; pn++) dpanelmap.push_back(make_int2(i, pn));
+        if (p.npanel > 0) {
+            job->max_nblk = std::max(job->max_nblk, p.nblk); job->max_npanel = std::max(job->max_npanel, p.npi);
+            for (int up = 0; up < p.Up128 / job->gemm_ut; up++)
+                for (int kb = 0; kb < (p.Mld + 127) / 128; kb++) gemmmap.push_back(make_int2(i, (up << 8) | kb));
+            for (int c = 0; c < (p.n_rhs + 255) / 256; c++) finmap.push_back(make_int2(i, c));
+        }
         if (p.mode != 0) job->max_pop = std::max(job->max_pop, p.P);
     }
     // longest segments first: the tail of the launch is then made of short items
@@ -580,27 +603,36 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
     const size_t o_items = ta.take(sizeof(Item) * std::max<size_t>(items.size(), 1));
     const size_t o_rowmap = put(blob, ta, rowmap);
     const size_t o_tilemap = put(blob, ta, tilemap);
+    // the product's tiles with the longest K loop (highest k block) first
+    std::stable_sort(gemmmap.begin(), gemmmap.end(), [](const int2& a, const int2& b) { return (a.y & 255) > (b.y & 255); });
     const size_t o_panelmap = put(blob, ta, panelmap);
+    const size_t o_dpanelmap = put(blob, ta, dpanelmap);
+    const size_t o_gemmmap = put(blob, ta, gemmmap);
+    const size_t o_finmap = put(blob, ta, finmap);
     const size_t o_probs = ta.take(sizeof(Prob) * job->n);
     blob.resize(ta.off);
     job->n_items = (int)items.size();
     job->n_rows = (int)rowmap.size();
     job->n_tiles = (int)tilemap.size();
     job->n_panels = (int)panelmap.size();
+    job->n_dpanels = (int)dpanelmap.size();
+    job->n_gemm = (int)gemmmap.size();
+    job->n_fin = (int)finmap.size();
 
     // ---- workspace arena ----
     Arena wa;         // zeroed once per job: operand padding, B21 padding and the solve matrices rely on it
     Arena wslab;      // partial slabs: every entry a reader keeps is written by the Gram kernel first, so no zeroing
-    struct WsOff { size_t raw_m, raw_u, packed, sx, sxx, slab, sd, wm, mu, wmu, A, Linv, B21, V, ld, b11c, sacc, part; long long ldraw; };
+    struct WsOff { size_t raw_m, raw_u, packed, sx, sxx, slab, sd, wm, mu, wmu, A, Linv, B21, V, ld, b11c, gsum, part; long long ldraw; };
     std::vector<WsOff> wo(job->n);
     size_t res = 0;
     {
-        // few panels in the whole job: the launches are latency bound and the solve's rows are split so that they hide
-        // behind the tile Cholesky (k_solve.hip); many panels: throughput bound, one workgroup per row.  The cut-off
-        // sits between the 4-5 windows an 8-rank share of a chromosome holds and a whole chromosome.
-        const char* e = getenv("GAUSS_SOLVE_SPLIT_MAX_PANELS");
-        const int cut = e ? atoi(e) : 400;
-        job->solve_split = (job->n_panels > 0 && job->n_panels <= cut) ? 1 : 0;
+        // A row of the inverse that rides in an update launch is a chain of dependent products (k_solve.hip): rows with
+        // at least `solve_split` products are cut into SOLVE_SPLIT partial sums + a combine in the next launch, shorter
+        // rows stay whole; 0 = never cut.  Measured on 36 windows (factorisation + riding rows): never 1.72 ms, >= 8
+        // 1.70, >= 4 1.49, >= 2 1.46; on the 4-5 windows of an 8-rank share the cut rows were what made the rows hide
+        // behind the tile Cholesky in the first place.  Either form sums in the same order.
+        const int thr = env_int("GAUSS_SOLVE_SPLIT_MIN", 2);               // read per job: tests drive both forms
+        job->solve_split = job->n_panels > 0 ? thr : 0;
     }
     for (int i = 0; i < job->n; i++) {
         Plan& pl = job->plans[i];
@@ -632,9 +664,9 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
         }
         if (p.npanel > 0) {
             w.Linv = wa.take((size_t)2 * p.nblk * NB * NB * sizeof(double));
-            w.V = wa.take((size_t)p.npanel * p.Mld * NR * sizeof(double));
-            w.sacc = wa.take((size_t)p.npanel * 768 * sizeof(double));
-            w.part = job->solve_split ? wa.take((size_t)p.npanel * 4 * NB * NR * sizeof(double)) : 0;
+            w.V = wa.take((size_t)std::max(p.npanel, p.npi) * p.Mld * NR * sizeof(double));
+            w.gsum = wa.take((size_t)((p.Mld + 127) / 128) * p.Up128 * 3 * sizeof(double));
+            w.part = job->solve_split ? wa.take((size_t)p.npi * 4 * NB * NR * sizeof(double)) : 0;
             w.b11c = wa.take((size_t)p.Mld * p.Mld * sizeof(double));
         }
         w.ld = wa.take(std::max<size_t>(pl.out_ld_count, 1) * sizeof(double));
@@ -706,7 +738,7 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
         p.z1 = (const double*)(T + to[i].z1);
         if (!p.ld_only) { p.A = (double*)(W + w.A); p.B21 = (double*)(W + w.B21); }
         if (p.npanel > 0) {
-            p.Linv = (double*)(W + w.Linv); p.V = (double*)(W + w.V); p.Sacc = (double*)(W + w.sacc);
+            p.Linv = (double*)(W + w.Linv); p.V = (double*)(W + w.V); p.Gsum = (double*)(W + w.gsum);
             p.Part = job->solve_split ? (double*)(W + w.part) : nullptr;
             pl.d_b11_copy = (double*)(W + w.b11c);
         }
@@ -767,6 +799,9 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
     job->d_rowmap = (int2*)(job->d_tab + o_rowmap);
     job->d_tilemap = (int2*)(job->d_tab + o_tilemap);
     job->d_panelmap = (int2*)(job->d_tab + o_panelmap);
+    job->d_dpanelmap = (int2*)(job->d_tab + o_dpanelmap);
+    job->d_gemmmap = (int2*)(job->d_tab + o_gemmmap);
+    job->d_finmap = (int2*)(job->d_tab + o_finmap);
     if (!on_device) HIPCHK(hipStreamSynchronize(st));   // uploads from pageable user memory are complete
     std::vector<char>().swap(job->h_tab);
     *out = guard.release();
@@ -839,8 +874,10 @@ static int job_run(gauss_job* job, bool solve)
             launch_factor_step(job->d_probs, job->n, s, job->max_nblk, fused ? job->max_npanel : 0, job->solve_split, st);
         prof_end(job, st);
         prof_begin(job, 4, st);
-        if (fused) launch_solve_last(job->d_probs, job->d_panelmap, job->n_panels, job->max_nblk, job->solve_split, st);
-        else launch_solve(job->d_probs, job->d_panelmap, job->n_panels, st);
+        if (fused) {
+            launch_solve_last(job->d_probs, job->d_panelmap, job->n_panels, job->max_nblk, job->solve_split, st);
+            launch_impute_gemm(job->d_probs, job->d_gemmmap, job->n_gemm, job->gemm_ut, job->d_finmap, job->n_fin, st);
+        } else launch_solve(job->d_probs, job->d_dpanelmap, job->n_dpanels, st);
         prof_end(job, st);
     }
     HIPCHK(hipGetLastError());

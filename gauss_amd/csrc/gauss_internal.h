@@ -37,7 +37,9 @@ struct Prob {
     int Kp;                 // packed row length in bytes (multiple of KC)
     int nseg, npair, nT;    // K segments, tile pairs, row tiles (Sp / TILE)
     int Mld, nblk;          // solve leading dimension (M padded to NB) and block count
-    int npanel;             // solve panels (ceil(U / NRU)), 0 for LD-only problems
+    int npanel;             // panels of the stand-alone solve (ceil(n_rhs / NRU)), 0 for LD-only problems
+    int npi;                // panels of the fused path's right-hand sides [I | z1]: ceil((M + 1) / NR) (k_solve.hip)
+    int Up128;              // n_rhs rounded up to 128: row count of a k block of Gsum
     int ld_only;            // 1: write out_ld (S x S) instead of B11/B21
     int kind;               // 0 imputation (z, info), 1 QCAT (correlation of whitened vectors)
     int n_head, n_predm;    // QCAT: measured rows before / inside the prediction window
@@ -83,9 +85,9 @@ struct Prob {
     GP(double) A;              // [5][Mld x Mld] row-major: B11, B11 - eps*I, their factors L0, L1, working copy W0 of B11
     GP(double) Linv;           // [2][nblk][NB x NB] inverses of the diagonal Cholesky blocks
     GP(double) B21;            // [Upad x Mld] row-major (Upad = npanel*NRU rounded)
-    GP(double) V;              // [npanel][Mld][NR]
-    GP(double) Part;           // [npanel][SOLVE_SPLIT][NB x NR] partial sums of a split solve row (small jobs only), else null
-    GP(double) Sacc;           // [npanel][3][256] per-thread partial sums of z / info / v between the launches of a fused solve
+    GP(double) V;              // [max(npanel, npi)][Mld][NR]: fused path: [X | y] = L^-1 [I | z1] by panels of NR columns
+    GP(double) Gsum;           // [ceil(Mld / 128)][Up128][3] z / info / v sums of every k block (impute_gemm_kernel)
+    GP(double) Part;           // [npi][SOLVE_SPLIT][NB x NR] partial sums of a split row (small jobs only), else null
     GP(double) out_z;          // [U]
     GP(double) out_info;       // [U]
     GP(int) status;            // [4]: [0] fail flag matrix 0, [1] fail flag matrix 1, [2] nonfinite
@@ -138,6 +140,7 @@ void launch_gene_epilogue(const Prob* d_probs, int prob, int n_gene, hipStream_t
 void launch_factor_step(const Prob* d_probs, int n_prob, int step, int max_nblk, int max_npanel, int split, hipStream_t s);
 void launch_shift_cert(const Prob* d_probs, int n_prob, hipStream_t s);
 void launch_solve(const Prob* d_probs, const int2* d_panelmap, int n_panels, hipStream_t s);
+void launch_impute_gemm(const Prob* d_probs, const int2* d_gmap, int n_tiles, int u_tile, const int2* d_fmap, int n_chunks, hipStream_t s);
 void launch_solve_last(const Prob* d_probs, const int2* d_panelmap, int n_panels, int max_nblk, int split, hipStream_t s);
 void launch_counts(const Prob* d_probs, int prob, int npair, long long* d_out, hipStream_t s);
 void launch_pack2bit(const uint8_t* d_in, long long ld_in, uint8_t* d_out, long long ld_out, int n_snp,

@@ -384,11 +384,29 @@ static const size_t SOLVE_SMEM = ((size_t)NB * LDT + (size_t)NB * LDV + 768) * s
 
 struct SolveSums { double z, info, v; };       // per-thread partial sums: column tid % NR, rows of group tid / NR
 
+// The fused path does not push the window's U right-hand sides through the substitution: the rows that ride in the
+// factorisation launches solve  L [X | y] = [I | z1]  instead -- M + 1 right-hand sides, in panels of NR columns -- and
+// impute_gemm_kernel then forms  W = B21 X^T  as a plain product with the z / info sums in its epilogue.
+// Column g < M of the right-hand side is e_g, so block (kb, panel) of X is a structural zero for kb < panel and is
+// never computed, stored or read; the panel that holds column M (z1) is dense.
+__device__ __forceinline__ int inv_first_row(const Prob& pb, int panel) { return panel == pb.M / NR ? 0 : panel; }
+
+// First block row of a right-hand-side panel that holds anything (INV: the inverse's panels, see inv_first_row).
+template <bool INV>
+__device__ __forceinline__ int solve_first_row(const Prob& pb, int panel) { return INV ? inv_first_row(pb, panel) : 0; }
+
 // acc -= sum_{j = j0, j0 + jstep, ... < kb} L[kb][j] V[j]   (the products of block row kb; TL / TV: the workgroup's LDS tiles)
+// INV: block rows above the panel's first one are structural zeros that were never written -- their products are
+// skipped, which leaves every sum as it is (they would add exact zeros).
+template <bool INV>
 __device__ __forceinline__ void solve_products(const Prob& pb, int panel, int kb, int j0, int jstep, f64x4 (&acc)[SOLVE_NT],
                                                double* __restrict__ TL, double* __restrict__ TV, int tid)
 {
     constexpr int NT = SOLVE_NT;
+    if (INV) {
+        const int first = inv_first_row(pb, panel);
+        if (j0 < first) j0 += (first - j0 + jstep - 1) / jstep * jstep;
+    }
     const int lane = tid & 63, wave = tid >> 6;
     const int ld = pb.Mld;
     const auto Lm = pb.A + (size_t)2 * ld * ld;               // factor of A[0]
@@ -418,9 +436,22 @@ __device__ __forceinline__ void solve_products(const Prob& pb, int panel, int kb
 // caller can overlap them with other loads; solve_tail commits them to LDS.
 struct SolveRhs { double b[(NB * NR) / 256]; TileRegs li; };
 
+template <bool INV>
 __device__ __forceinline__ void solve_rhs_fetch(const Prob& pb, int panel, int kb, SolveRhs& q, int tid)
 {
     const int ld = pb.Mld;
+    if (INV) {
+        // right-hand sides [ I | z1 ]: column g = 64 panel + c is e_g for g < M and z1 for g == M
+#pragma unroll
+        for (int i = 0; i < (NB * NR) / 256; i++) {
+            const int e = tid + 256 * i;
+            const int c = e >> 6, r = e & 63;
+            const int k = kb * NB + r, g = panel * NR + c;
+            q.b[i] = (g < pb.M) ? ((g == k) ? 1.0 : 0.0) : ((g == pb.M && k < pb.M) ? pb.z1[k] : 0.0);
+        }
+        tile_fetch(q.li, pb.Linv + (size_t)kb * NB * NB, NB, tid);
+        return;
+    }
     const int u0 = panel * NRU;
     const bool qcat = pb.kind == WIN_QCAT;
     const int n_predm = pb.n_predm;
@@ -446,6 +477,7 @@ __device__ __forceinline__ void solve_rhs_fetch(const Prob& pb, int panel, int k
 }
 
 // X = B_kb + acc;  V_kb = Linv_kk X  (stored);  z / info sums of the block's rows
+template <bool INV>
 __device__ __forceinline__ void solve_tail(const Prob& pb, int panel, int kb, f64x4 (&acc)[SOLVE_NT], const SolveRhs& q,
                                            double* __restrict__ TL, double* __restrict__ TV, SolveSums& sums, int tid)
 {
@@ -476,9 +508,10 @@ __device__ __forceinline__ void solve_tail(const Prob& pb, int panel, int kb, f6
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int row = acc_row(wave, lane, r), col = acc_col(lane, n);
-            TV[row * LDV + col] = acc[n][r];
+            if (!INV) TV[row * LDV + col] = acc[n][r];
             V[(size_t)(kb * NB + row) * NR + col] = acc[n][r];
         }
+    if (INV) return;                                  // the inverse's rows carry no z / info sums (impute_gemm_kernel forms them)
     __syncthreads();
     // accumulate z and info for column cc over this block's rows RG rg .. RG rg + RG - 1
 #pragma unroll
@@ -494,6 +527,7 @@ __device__ __forceinline__ void solve_tail(const Prob& pb, int panel, int kb, f6
 // block row kb of one panel, all of it in this workgroup.  The products are summed in SOLVE_SPLIT interleaved classes
 // (j = g, g + SOLVE_SPLIT, ...) that are then added in class order -- the association the split form (below) needs for
 // its partial sums -- so that every driver of the solve returns the same bits.
+template <bool INV>
 __device__ __forceinline__ void solve_row(const Prob& pb, int panel, int kb, double* __restrict__ TL, double* __restrict__ TV,
                                           SolveSums& sums, int tid)
 {
@@ -504,15 +538,15 @@ __device__ __forceinline__ void solve_row(const Prob& pb, int panel, int kb, dou
         f64x4 part[SOLVE_NT];
 #pragma unroll
         for (int n = 0; n < SOLVE_NT; n++) part[n] = f64x4{0.0, 0.0, 0.0, 0.0};
-        solve_products(pb, panel, kb, g, SOLVE_SPLIT, part, TL, TV, tid);
+        solve_products<INV>(pb, panel, kb, g, SOLVE_SPLIT, part, TL, TV, tid);
 #pragma unroll
         for (int n = 0; n < SOLVE_NT; n++)
 #pragma unroll
             for (int r = 0; r < 4; r++) acc[n][r] += part[n][r];
     }
     SolveRhs q;
-    solve_rhs_fetch(pb, panel, kb, q, tid);
-    solve_tail(pb, panel, kb, acc, q, TL, TV, sums, tid);
+    solve_rhs_fetch<INV>(pb, panel, kb, q, tid);
+    solve_tail<INV>(pb, panel, kb, acc, q, TL, TV, sums, tid);
 }
 
 // after the last block row: combine the per-thread sums and write z / info (or the QCAT correlation)
@@ -555,18 +589,13 @@ __device__ __forceinline__ void solve_finish(const Prob& pb, int panel, double* 
     }
 }
 
-// one block row of one panel inside a multi-launch solve: the partial sums travel through pb.Sacc [panel][3][256]
+// one block row of one panel of the inverse, riding in a factorisation launch
 __device__ __forceinline__ void solve_row_fused(const Prob& pb, int panel, int kb, double* __restrict__ smem, int tid)
 {
     double* TL = smem;
     double* TV = TL + NB * LDT;
-    double* red = TV + NB * LDV;
-    const auto S = pb.Sacc + (size_t)panel * 768;
     SolveSums sums{0.0, 0.0, 0.0};
-    if (kb > 0) { sums.z = S[tid]; sums.info = S[256 + tid]; sums.v = S[512 + tid]; }
-    solve_row(pb, panel, kb, TL, TV, sums, tid);
-    if (kb == pb.nblk - 1) solve_finish(pb, panel, red, sums, tid);
-    else { S[tid] = sums.z; S[256 + tid] = sums.info; S[512 + tid] = sums.v; }
+    solve_row<true>(pb, panel, kb, TL, TV, sums, tid);
 }
 
 // ---- split form of a fused block row (small batches) ------------------------------------------------------------
@@ -583,7 +612,7 @@ __device__ __forceinline__ void solve_partial(const Prob& pb, int panel, int kb,
     f64x4 acc[SOLVE_NT];
 #pragma unroll
     for (int n = 0; n < SOLVE_NT; n++) acc[n] = f64x4{0.0, 0.0, 0.0, 0.0};
-    solve_products(pb, panel, kb, g, SOLVE_SPLIT, acc, TL, TV, tid);
+    solve_products<true>(pb, panel, kb, g, SOLVE_SPLIT, acc, TL, TV, tid);
     const auto P = pb.Part + ((size_t)panel * SOLVE_SPLIT + g) * (NB * NR);
 #pragma unroll
     for (int n = 0; n < SOLVE_NT; n++)
@@ -600,7 +629,7 @@ __device__ __forceinline__ void solve_combine(const Prob& pb, int panel, int kb,
 #pragma unroll
     for (int n = 0; n < SOLVE_NT; n++) acc[n] = f64x4{0.0, 0.0, 0.0, 0.0};
     SolveRhs q;
-    solve_rhs_fetch(pb, panel, kb, q, tid);                       // in flight together with the partial sums
+    solve_rhs_fetch<true>(pb, panel, kb, q, tid);                 // in flight together with the partial sums
     const int np = kb < SOLVE_SPLIT ? kb : SOLVE_SPLIT;           // partial sums that exist for this row
     // every partial tile is requested before the first is added (four dependent round trips to tiles that other CUs
     // have just written cost ~4 us each); the additions keep the class order
@@ -624,18 +653,13 @@ __device__ __forceinline__ void solve_combine(const Prob& pb, int panel, int kb,
                 for (int r = 0; r < 4; r++) acc[n][r] += part[g][n][r];
         }
     }
-    solve_tail(pb, panel, kb, acc, q, TL, TV, sums, tid);
+    solve_tail<true>(pb, panel, kb, acc, q, TL, TV, sums, tid);
 }
 
 __device__ __forceinline__ void solve_combine_fused(const Prob& pb, int panel, int kb, double* __restrict__ smem, int tid)
 {
-    double* red = smem + NB * LDT + NB * LDV;
-    const auto S = pb.Sacc + (size_t)panel * 768;
     SolveSums sums{0.0, 0.0, 0.0};
-    if (kb > 0) { sums.z = S[tid]; sums.info = S[256 + tid]; sums.v = S[512 + tid]; }
     solve_combine(pb, panel, kb, smem, sums, tid);
-    if (kb == pb.nblk - 1) solve_finish(pb, panel, red, sums, tid);
-    else { S[tid] = sums.z; S[256 + tid] = sums.info; S[512 + tid] = sums.v; }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -718,7 +742,7 @@ __global__ __launch_bounds__(256) void factor_init_kernel(const Prob* __restrict
 }
 
 // panel(s): grid.x = max_nblk - 1 - s (block row k = s + 1 + x), grid.y = problem * 2 + matrix
-__global__ __launch_bounds__(256) void factor_panel_kernel(const Prob* __restrict__ probs, int s, int T)
+__global__ __launch_bounds__(256) void factor_panel_kernel(const Prob* __restrict__ probs, int s, int T, int split, int n_comb)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* TA = smem;                 // W[k][s]
@@ -726,15 +750,17 @@ __global__ __launch_bounds__(256) void factor_panel_kernel(const Prob* __restric
     const Prob& pb = probs[blockIdx.y >> 1];
     const int mat = blockIdx.y & 1;
     if (pb.ld_only || pb.npanel == 0) return;
-    if ((int)blockIdx.x >= T) {
-        // split solve: second half of block row s - 1 (its partial sums were formed in update(s - 1))
-        const int panel = (int)blockIdx.x - T;
-        if (mat == 0 && s >= 1 && panel < pb.npanel && s - 1 < pb.nblk) solve_combine_fused(pb, panel, s - 1, smem, threadIdx.x);
+    if ((int)blockIdx.x < n_comb) {
+        // split rows: second half of block row s - 1 (its partial sums were formed in update(s - 1)).  These workgroups
+        // are the long ones of the launch, so they are dispatched first and the short tile products fill in behind
+        const int panel = (int)blockIdx.x;
+        if (mat == 0 && s >= 1 && panel < pb.npi && s - 1 < pb.nblk && s - 1 - inv_first_row(pb, panel) >= split)
+            solve_combine_fused(pb, panel, s - 1, smem, threadIdx.x);
         return;
     }
     if (mat == 1 && pb.status[3]) return;              // certified: lambda_min(B11) > eps
     const int nb = pb.nblk;
-    const int k = s + 1 + blockIdx.x;
+    const int k = s + 1 + ((int)blockIdx.x - n_comb);
     if (k >= nb) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ld = pb.Mld;
@@ -760,7 +786,7 @@ __global__ __launch_bounds__(256) void factor_panel_kernel(const Prob* __restric
 }
 
 // update(s): grid.x = T (T + 1) / 2 with T = max_nblk - 1 - s; x = 0 is tile (s+1, s+1)
-__global__ __launch_bounds__(256) void factor_update_kernel(const Prob* __restrict__ probs, int s, int T, int n_tri, int split)
+__global__ __launch_bounds__(256) void factor_update_kernel(const Prob* __restrict__ probs, int s, int T, int n_tri, int split, int n_ride)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* TA = smem;                 // L[k][s]            | D (next diagonal tile)
@@ -769,22 +795,32 @@ __global__ __launch_bounds__(256) void factor_update_kernel(const Prob* __restri
     const Prob& pb = probs[blockIdx.y >> 1];
     const int mat = blockIdx.y & 1;
     if (pb.ld_only || pb.npanel == 0) return;
-    if ((int)blockIdx.x >= n_tri) {
-        // block row s of the forward solve riding in this launch: one workgroup per right-hand-side panel, or (split
-        // form) SOLVE_SPLIT workgroups per panel that only form partial sums
-        const int idx = (int)blockIdx.x - n_tri;
+    // launch order: x = 0 the next diagonal tile (the longest workgroup: tile Cholesky), x = 1 .. n_ride the rows of the
+    // inverse that ride in this launch (chains of dependent products), then the one-product trailing tiles, which fill
+    // in behind them -- with the riding rows last, every launch ended on a 15-20 us tail of theirs
+    if ((int)blockIdx.x >= 1 && (int)blockIdx.x <= n_ride) {
+        // block row s of the inverse: one workgroup per right-hand-side panel, or (split form) SOLVE_SPLIT workgroups
+        // per panel that only form partial sums
+        const int idx = (int)blockIdx.x - 1;
         if (!split) {
-            if (mat == 0 && idx < pb.npanel && s < pb.nblk) solve_row_fused(pb, idx, s, smem, threadIdx.x);
+            if (mat == 0 && idx < pb.npi && s < pb.nblk && s >= inv_first_row(pb, idx)) solve_row_fused(pb, idx, s, smem, threadIdx.x);
         } else {
+            // rows with fewer than `split` products stay whole (class 0's workgroup runs them): cutting them would only
+            // add workgroups and a round trip through Part; either form sums in the same order
             const int panel = idx / SOLVE_SPLIT, g = idx % SOLVE_SPLIT;
-            if (mat == 0 && panel < pb.npanel && s < pb.nblk && g < s) solve_partial(pb, panel, s, g, smem, threadIdx.x);
+            if (mat != 0 || panel >= pb.npi || s >= pb.nblk) return;
+            const int nprod = s - inv_first_row(pb, panel);
+            if (nprod < 0) return;
+            if (nprod < split) { if (g == 0) solve_row_fused(pb, panel, s, smem, threadIdx.x); }
+            else if (g < s) solve_partial(pb, panel, s, g, smem, threadIdx.x);
         }
         return;
     }
     if (mat == 1 && pb.status[3]) return;              // certified: lambda_min(B11) > eps
     const int nb = pb.nblk;
     // x -> (jj, kk), 0 <= jj <= kk < T, column-major over the lower triangle: x = 0 is (0, 0)
-    int jj = 0, rem = blockIdx.x;
+    int jj = 0, rem = blockIdx.x == 0 ? 0 : (int)blockIdx.x - n_ride;
+    if (rem >= n_tri) return;
     while (rem >= T - jj) { rem -= T - jj; jj++; }
     const int kk = jj + rem;
     const int j = s + 1 + jj, k = s + 1 + kk;
@@ -854,10 +890,11 @@ void launch_factor_step(const Prob* d_probs, int n_prob, int step, int max_nblk,
     const int n_tri = T * (T + 1) / 2;
     const bool fuse = max_npanel > 0;
     const bool sp = fuse && split;
-    hipLaunchKernelGGL(factor_panel_kernel, dim3(T + (sp ? max_npanel : 0), n_prob * 2), dim3(256), sp ? upd_smem : FACTOR_SMEM, st,
-                       d_probs, s, T);
-    hipLaunchKernelGGL(factor_update_kernel, dim3(n_tri + (fuse ? max_npanel * (sp ? SOLVE_SPLIT : 1) : 0), n_prob * 2), dim3(256),
-                       upd_smem, st, d_probs, s, T, n_tri, sp ? 1 : 0);
+    const int n_comb = sp ? max_npanel : 0, n_ride = fuse ? max_npanel * (sp ? SOLVE_SPLIT : 1) : 0;
+    hipLaunchKernelGGL(factor_panel_kernel, dim3(T + n_comb, n_prob * 2), dim3(256), sp ? upd_smem : FACTOR_SMEM, st,
+                       d_probs, s, T, split, n_comb);
+    hipLaunchKernelGGL(factor_update_kernel, dim3(n_tri + n_ride, n_prob * 2), dim3(256),
+                       upd_smem, st, d_probs, s, T, n_tri, sp ? split : 0, n_ride);
 }
 
 __global__ __launch_bounds__(256) void solve_kernel(const Prob* __restrict__ probs,
@@ -871,7 +908,7 @@ __global__ __launch_bounds__(256) void solve_kernel(const Prob* __restrict__ pro
     const Prob& pb = probs[pm.x];
     const int tid = threadIdx.x;
     SolveSums sums{0.0, 0.0, 0.0};
-    for (int kb = 0; kb < pb.nblk; kb++) solve_row(pb, pm.y, kb, TL, TV, sums, tid);
+    for (int kb = 0; kb < pb.nblk; kb++) solve_row<false>(pb, pm.y, kb, TL, TV, sums, tid);
     solve_finish(pb, pm.y, red, sums, tid);
 }
 
@@ -884,24 +921,225 @@ __global__ __launch_bounds__(256) void solve_last_kernel(const Prob* __restrict_
     const int2 pm = panelmap[blockIdx.x];
     const Prob& pb = probs[pm.x];
     const int last = pb.nblk - 1, tid = threadIdx.x, panel = pm.y;
-    if (!split) {
-        if (last == s_last) solve_row_fused(pb, panel, s_last, smem, tid);
-        return;
-    }
+    const int first = inv_first_row(pb, panel);
     if (last < s_last - 1) return;                          // this window finished in an earlier launch
     double* TL = smem;
     double* TV = TL + NB * LDT;
-    double* red = TV + NB * LDV;
-    const auto S = pb.Sacc + (size_t)panel * 768;
     SolveSums sums{0.0, 0.0, 0.0};
-    if (s_last >= 1) {
-        const int r = s_last - 1;                           // partial sums from update(r), the batch's last update launch
-        if (r > 0) { sums.z = S[tid]; sums.info = S[256 + tid]; sums.v = S[512 + tid]; }
-        solve_combine(pb, panel, r, smem, sums, tid);
-        if (r == last) { solve_finish(pb, panel, red, sums, tid); return; }
+    if (split && s_last >= 1) {
+        const int r = s_last - 1;                           // a row cut in update(r), the batch's last update launch
+        if (r - first >= split) solve_combine(pb, panel, r, smem, sums, tid);
     }
-    solve_row(pb, panel, s_last, TL, TV, sums, tid);        // last == s_last
-    solve_finish(pb, panel, red, sums, tid);
+    if (last == s_last && s_last >= first) solve_row<true>(pb, panel, s_last, TL, TV, sums, tid);
+}
+
+// ------------------------------------------------------------------------------------------
+// K7: W = R X^T with the imputation sums in the epilogue (fused path).
+//   R   right-hand sides, one per row: the window's B21 rows (QCAT: first the B11 columns of the tested measured SNPs)
+//   X   = L^-1, block (kb, p) at pb.V[p][64 kb ..][64], lower block triangle; y = L^-1 z1 is column M of [X | y]
+//   w_u = X r_u  (= L^-1 b21_u^T);   z_u = w_u . y,  info_u = w_u . w_u,  v_u = sum(w_u)
+// One workgroup = UT right-hand sides x 128 rows of X (k), 4 waves of 64 (k) x UT / 2 (4 x 4 or 4 x 2
+// v_mfma_f64_16x16x4_f64 tiles; 8 LDS fragment reads per 16 MFMAs at UT = 128); K runs over the columns
+// j < 64 (block + 1) of X in stages of 16, double buffered in LDS, the next stage's tiles in flight in registers.
+// Nothing of W is stored: each workgroup reduces its tile to three sums per right-hand side in a fixed order and
+// parks them in pb.Gsum[k block][rhs][3]; impute_finish_kernel adds the k blocks in order.  A right-hand side's sums
+// depend on its own column of the tile only, so UT is free: large jobs take 128 (throughput), small jobs 64 -- twice
+// the workgroups, each with half the matrix work per stage of its (latency-bound) K loop -- and the result does not
+// depend on the choice or on what else the job holds.
+// ------------------------------------------------------------------------------------------
+constexpr int GK = 16;                 // K per stage
+constexpr int GLD = GK + 2;            // LDS row stride in doubles: 144 B puts the 16 rows of a b128 fragment read on distinct banks
+constexpr int GT = 128;                // tile edge (rows of X, and right-hand sides)
+static const size_t GEMM_SMEM = (size_t)(2 * 2 * GT * GLD + GT) * sizeof(double);
+
+struct GemmRegs { f64x2 v[4]; };       // 8 doubles: half a 16-column tile row
+
+template <int UT>
+__global__ __launch_bounds__(256, 2) void impute_gemm_kernel(const Prob* __restrict__ probs, const int2* __restrict__ gmap)
+{
+    constexpr int NU = UT / 32;                                 // 16-column tiles of a wave along u
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int2 gm = gmap[blockIdx.x];
+    const Prob& pb = probs[gm.x];
+    const int kblock = gm.y & 255, upanel = gm.y >> 8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wk = wave & 1, wu = wave >> 1;
+    const int ld = pb.Mld, nb = pb.nblk;
+    const int k0 = kblock * GT, u0 = upanel * UT;
+    double* ys = smem + 2 * 2 * GT * GLD;
+
+    // ---- operand rows of this thread: row tid / 2 of both tiles, columns 8 (tid % 2) .. + 7 of a stage
+    const int trow = tid >> 1, tcol = (tid & 1) * 8;
+    const int xk = k0 + trow;                                   // row of X
+    const bool x_live = xk < ld;
+    const int u = u0 + trow;                                    // right-hand side
+    const bool qcat = pb.kind == WIN_QCAT;
+    const int n_predm = qcat ? pb.n_predm : 0;
+    const bool r_live = trow < UT && u < pb.n_rhs;
+    // QCAT right-hand sides (qcat.cpp:216-243): the B11 columns of the tested measured SNPs (rows n_head .. of the
+    // symmetric A[0], which the factorisation leaves intact), then the B21 rows
+    const auto rrow = !r_live ? pb.B21 : (u < n_predm ? pb.A + (size_t)(pb.n_head + u) * ld : pb.B21 + (size_t)(u - n_predm) * ld);
+    auto fetch = [&](GemmRegs& rx, GemmRegs& rr, int j0) {
+        const auto xp = pb.V + ((size_t)(j0 >> 6) * ld + xk) * NR + (j0 & 63) + tcol;
+        const auto rp = rrow + j0 + tcol;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            rx.v[q] = x_live ? f64x2{xp[2 * q], xp[2 * q + 1]} : f64x2{0.0, 0.0};
+            rr.v[q] = r_live ? f64x2{rp[2 * q], rp[2 * q + 1]} : f64x2{0.0, 0.0};
+        }
+    };
+    auto commit = [&](const GemmRegs& rx, const GemmRegs& rr, int buf) {
+        double* xa = smem + (size_t)buf * 2 * GT * GLD + trow * GLD + tcol;
+        double* rb = xa + GT * GLD;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            *reinterpret_cast<f64x2*>(xa + 2 * q) = rx.v[q];
+            *reinterpret_cast<f64x2*>(rb + 2 * q) = rr.v[q];
+        }
+    };
+
+    // columns of X this workgroup needs: blocks 0 .. (last block row it holds); a wave stops at its own block row
+    const int kb_hi = min(2 * kblock + 1, nb - 1);
+    const int n_stage = (kb_hi + 1) * (NB / GK);
+    const int my_kb = 2 * kblock + wk;
+    const int my_stages = my_kb < nb ? (my_kb + 1) * (NB / GK) : 0;
+
+    f64x4 acc[4][NU];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int n = 0; n < NU; n++) acc[i][n] = f64x4{0.0, 0.0, 0.0, 0.0};
+
+    GemmRegs rx, rr;
+    fetch(rx, rr, 0);
+    if (tid < GT) {
+        const int k = k0 + tid;
+        ys[tid] = k < ld ? pb.V[((size_t)(pb.M / NR) * ld + k) * NR + (pb.M % NR)] : 0.0;
+    }
+    commit(rx, rr, 0);
+    __syncthreads();
+    const int fr = lane & 15, fg = lane >> 4;
+    for (int st = 0; st < n_stage; st++) {
+        const int buf = st & 1;
+        if (st + 1 < n_stage) fetch(rx, rr, (st + 1) * GK);
+        if (st < my_stages) {
+            const double* xa = smem + (size_t)buf * 2 * GT * GLD + (64 * wk + fr) * GLD + 4 * fg;
+            const double* rb = smem + (size_t)buf * 2 * GT * GLD + GT * GLD + (16 * NU * wu + fr) * GLD + 4 * fg;
+            f64x2 a[4][2], b[NU][2];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                a[i][0] = *reinterpret_cast<const f64x2*>(xa + 16 * i * GLD);
+                a[i][1] = *reinterpret_cast<const f64x2*>(xa + 16 * i * GLD + 2);
+            }
+#pragma unroll
+            for (int n = 0; n < NU; n++) {
+                b[n][0] = *reinterpret_cast<const f64x2*>(rb + 16 * n * GLD);
+                b[n][1] = *reinterpret_cast<const f64x2*>(rb + 16 * n * GLD + 2);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++)
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int n = 0; n < NU; n++)
+                        acc[i][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][ks >> 1][ks & 1], b[n][ks >> 1][ks & 1], acc[i][n], 0, 0, 0);
+        }
+        if (st + 1 < n_stage) commit(rx, rr, buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: per lane the 16 rows (k) it holds of each of its 4 columns (u), in a fixed order
+    double pz[NU], pi[NU], pv[NU];
+#pragma unroll
+    for (int n = 0; n < NU; n++) { pz[n] = 0.0; pi[n] = 0.0; pv[n] = 0.0; }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const double y = ys[64 * wk + 16 * i + fg + 4 * r];
+#pragma unroll
+            for (int n = 0; n < NU; n++) {
+                const double w = acc[i][n][r];
+                pz[n] = fma(w, y, pz[n]);
+                pi[n] = fma(w, w, pi[n]);
+                pv[n] += w;
+            }
+        }
+    double* red = smem;                                         // [wave][n][lane][3], the tiles are no longer read
+#pragma unroll
+    for (int n = 0; n < NU; n++) {
+        double* q = red + ((size_t)(wave * 4 + n) * 64 + lane) * 3;
+        q[0] = pz[n]; q[1] = pi[n]; q[2] = pv[n];
+    }
+    __syncthreads();
+    if (tid < UT) {
+        const int tu = tid / (16 * NU), n = (tid >> 4) % NU, c = tid & 15;
+        double z = 0.0, info = 0.0, v = 0.0;
+#pragma unroll
+        for (int w = 0; w < 2; w++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const double* q = red + ((size_t)((w + 2 * tu) * 4 + n) * 64 + 16 * g + c) * 3;
+                z += q[0]; info += q[1]; v += q[2];
+            }
+        const auto o = pb.Gsum + ((size_t)kblock * pb.Up128 + u0 + tid) * 3;
+        o[0] = z; o[1] = info; o[2] = v;
+    }
+}
+
+// z / info of every right-hand side from the k blocks' sums (block order), and the QCAT correlation
+__global__ __launch_bounds__(256) void impute_finish_kernel(const Prob* __restrict__ probs, const int2* __restrict__ fmap)
+{
+    __shared__ double s_y[2];
+    const int2 fm = fmap[blockIdx.x];
+    const Prob& pb = probs[fm.x];
+    const int tid = threadIdx.x;
+    const int u = fm.y * 256 + tid;
+    const bool qcat = pb.kind == WIN_QCAT;
+    if (qcat) {
+        // sums of y = L^-1 z1 over its Mld entries (the padding rows hold zeros), in index order
+        if (tid == 0) {
+            double sy = 0.0, syy = 0.0;
+            const auto yp = pb.V + (size_t)(pb.M / NR) * pb.Mld * NR + (pb.M % NR);
+            for (int k = 0; k < pb.Mld; k++) { const double y = yp[(size_t)k * NR]; sy += y; syy = fma(y, y, syy); }
+            s_y[0] = sy; s_y[1] = syy;
+        }
+        __syncthreads();
+    }
+    if (u >= pb.n_rhs) return;
+    const int nkb = (pb.Mld + GT - 1) / GT;
+    double z = 0.0, info = 0.0, sv = 0.0;
+    for (int kb = 0; kb < nkb; kb++) {
+        const auto q = pb.Gsum + ((size_t)kb * pb.Up128 + u) * 3;
+        z += q[0]; info += q[1]; sv += q[2];
+    }
+    if (qcat) {
+        // r = CalCor(Linv z1, Linv b)  (util.cpp:72-101; qcat.cpp:221,239), vectors of length M
+        const double n = (double)pb.M;
+        const double mx = s_y[0] / n, mv = sv / n;
+        const double cxx = s_y[1] - n * mx * mx;
+        const double cvv = info - n * mv * mv;
+        const double cxv = z - n * mx * mv;
+        pb.out_z[u] = cxv / sqrt(cxx * cvv);
+        pb.out_info[u] = cvv;
+    } else {
+        info = fabs(info);                         // dist.cpp:198
+        pb.out_z[u] = z / sqrt(info);              // dist.cpp:200
+        pb.out_info[u] = info;                     // dist.cpp:202
+    }
+}
+
+void launch_impute_gemm(const Prob* d_probs, const int2* d_gmap, int n_tiles, int u_tile, const int2* d_fmap, int n_chunks, hipStream_t s)
+{
+    if (n_tiles <= 0) return;
+    static std::atomic<unsigned long long> attr_set{0};
+    if (first_use_on_device(attr_set)) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(impute_gemm_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_SMEM);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(impute_gemm_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_SMEM);
+    }
+    if (u_tile == 64) hipLaunchKernelGGL(impute_gemm_kernel<64>, dim3(n_tiles), dim3(256), GEMM_SMEM, s, d_probs, d_gmap);
+    else hipLaunchKernelGGL(impute_gemm_kernel<128>, dim3(n_tiles), dim3(256), GEMM_SMEM, s, d_probs, d_gmap);
+    hipLaunchKernelGGL(impute_finish_kernel, dim3(n_chunks), dim3(256), 0, s, d_probs, d_fmap);
 }
 
 // The certificate only needs the row tables: it is launched right after row_stats, ahead of the Gram kernel, so that

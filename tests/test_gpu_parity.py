@@ -455,10 +455,10 @@ def test_ld_and_gene_batches_over_row_stores_equal_the_byte_calls(ctx, mode):
 
 @pytest.mark.parametrize("mode", [0, 1])
 def test_solve_forms_agree(ctx, mode, monkeypatch):
-    """The forward solve has three drivers for the same block-row routine (k_solve.hip): rows riding whole in the
-    factorisation's update launches (large jobs), rows split into partial sums + combine (small jobs, the default
-    for anything a test builds) and the stand-alone kernel.  Same windows through all three: each within 1e-8 of
-    the oracle, and within 1e-11 of each other (the split form adds its partial sums in a different order)."""
+    """The fused path (k_solve.hip) has job-size dependent forms of the same arithmetic: rows of the inverse riding
+    whole in the factorisation's update launches or cut into partial sums + combine, and the closing product in tiles
+    of 128 or 64 right-hand sides.  The same windows through every combination: each within 1e-8 of the oracle and
+    bit-identical to the others (every form sums in the same order)."""
     p = small_panel(n_snp=420, scale=0.03, seed=5)
     G, off = p["G"], p["off"]
     rng = np.random.default_rng(2)
@@ -468,19 +468,22 @@ def test_solve_forms_agree(ctx, mode, monkeypatch):
         gm, gu = np.ascontiguousarray(G[np.sort(idx[:m])]), np.ascontiguousarray(G[np.sort(idx[m:m + u])])
         wins.append(dict(mode=mode, geno_m=gm, geno_u=gu, pop_off=off, pop_wgt=p["w"], z1=rng.standard_normal(m) * 2))
     out = {}
-    for name, env in (("split", {"GAUSS_SOLVE_SPLIT_MAX_PANELS": "100000"}), ("rows", {"GAUSS_SOLVE_SPLIT_MAX_PANELS": "0"})):
+    for name, env in (("split", {"GAUSS_SOLVE_SPLIT_MIN": "2", "GAUSS_GEMM_SMALL_TILES": "1000000"}),
+                      ("rows", {"GAUSS_SOLVE_SPLIT_MIN": "0", "GAUSS_GEMM_SMALL_TILES": "0"}),
+                      ("mixed", {"GAUSS_SOLVE_SPLIT_MIN": "3", "GAUSS_GEMM_SMALL_TILES": "0"})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         job = hotpath.Job(wins, ctx=ctx)
         job.run()
         out[name] = job.fetch()
         job.close()
-    for w, a, b in zip(wins, out["split"], out["rows"]):
+    for w, a, b, c in zip(wins, out["split"], out["rows"], out["mixed"]):
         want = oracle.run_impute(mode, w["geno_m"], w["geno_u"], off, p["w"], w["z1"])
-        for r in (a, b):
+        for r in (a, b, c):
             assert r["status"] == 0
             assert relerr(r["info"], want["info"]) <= Z_TOL
             assert np.max(np.abs(r["z"] - want["z"]) / np.maximum(1.0, np.abs(want["z"]))) <= Z_TOL
+        assert np.array_equal(a["info"], c["info"]) and np.array_equal(a["z"], c["z"])
         assert np.array_equal(a["info"], b["info"]) and np.array_equal(a["z"], b["z"])
 
 
