@@ -998,11 +998,18 @@ __global__ __launch_bounds__(256, 2) void impute_gemm_kernel(const Prob* __restr
         }
     };
 
-    // columns of X this workgroup needs: blocks 0 .. (last block row it holds); a wave stops at its own block row
+    // columns of X this workgroup needs: blocks 0 .. (last block row it holds), and nothing from column M on (the
+    // right-hand sides are zero there).  A wave stops at its own block row, and inside that diagonal block X is lower
+    // triangular: its row tile i (16 rows) has nothing right of column 16 (i + 1), and no work at all if it starts
+    // at or below row M (padding) -- lim[i] = stages row tile i takes part in.
     const int kb_hi = min(2 * kblock + 1, nb - 1);
-    const int n_stage = (kb_hi + 1) * (NB / GK);
+    const int n_stage = min((kb_hi + 1) * (NB / GK), (pb.M + GK - 1) / GK);
     const int my_kb = 2 * kblock + wk;
-    const int my_stages = my_kb < nb ? (my_kb + 1) * (NB / GK) : 0;
+    int lim[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        lim[i] = (my_kb < nb && my_kb * NB + 16 * i < pb.M) ? min(my_kb * (NB / GK) + i + 1, n_stage) : 0;
+    const int my_stages = max(max(lim[0], lim[1]), max(lim[2], lim[3]));
 
     f64x4 acc[4][NU];
 #pragma unroll
@@ -1025,24 +1032,25 @@ __global__ __launch_bounds__(256, 2) void impute_gemm_kernel(const Prob* __restr
         if (st < my_stages) {
             const double* xa = smem + (size_t)buf * 2 * GT * GLD + (64 * wk + fr) * GLD + 4 * fg;
             const double* rb = smem + (size_t)buf * 2 * GT * GLD + GT * GLD + (16 * NU * wu + fr) * GLD + 4 * fg;
-            f64x2 a[4][2], b[NU][2];
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                a[i][0] = *reinterpret_cast<const f64x2*>(xa + 16 * i * GLD);
-                a[i][1] = *reinterpret_cast<const f64x2*>(xa + 16 * i * GLD + 2);
-            }
+            f64x2 b[NU][2];
 #pragma unroll
             for (int n = 0; n < NU; n++) {
                 b[n][0] = *reinterpret_cast<const f64x2*>(rb + 16 * n * GLD);
                 b[n][1] = *reinterpret_cast<const f64x2*>(rb + 16 * n * GLD + 2);
             }
 #pragma unroll
-            for (int ks = 0; ks < 4; ks++)
+            for (int i = 0; i < 4; i++) {
+                if (st < lim[i]) {                              // wave-uniform
+                    const f64x2 a0 = *reinterpret_cast<const f64x2*>(xa + 16 * i * GLD);
+                    const f64x2 a1 = *reinterpret_cast<const f64x2*>(xa + 16 * i * GLD + 2);
 #pragma unroll
-                for (int i = 0; i < 4; i++)
+                    for (int ks = 0; ks < 4; ks++)
 #pragma unroll
-                    for (int n = 0; n < NU; n++)
-                        acc[i][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][ks >> 1][ks & 1], b[n][ks >> 1][ks & 1], acc[i][n], 0, 0, 0);
+                        for (int n = 0; n < NU; n++)
+                            acc[i][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(ks < 2 ? a0[ks & 1] : a1[ks & 1], b[n][ks >> 1][ks & 1],
+                                                                             acc[i][n], 0, 0, 0);
+                }
+            }
         }
         if (st + 1 < n_stage) commit(rx, rr, buf ^ 1);
         __syncthreads();
