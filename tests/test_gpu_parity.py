@@ -547,3 +547,38 @@ def test_jobs_queued_back_to_back_keep_their_results_apart(ctx):
             assert np.array_equal(got["z"], want["z"]) and np.array_equal(got["info"], want["info"])
     for j in jobs:
         j.close()
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_tail_block_edges(ctx, mode):
+    """The fused tail works in 64-blocks of the measured SNPs (factor, inverse panels [I | z1]) and 128-blocks of the
+    product's tiles: shapes on every side of those edges -- M = 64 k puts the z1 column in a panel of its own, M < 64
+    is a single block, U = 1 a single right-hand side -- for dist/distmix and for QCAT (whose first right-hand sides
+    are columns of B11), all windows of one job, against the oracle."""
+    shapes = [(11, 1), (63, 5), (64, 64), (65, 63), (127, 130), (128, 1), (129, 70), (192, 129), (200, 257)]
+    p = small_panel(n_snp=480, scale=0.03, seed=77)
+    G, off = p["G"], p["off"]
+    rng = np.random.default_rng(11)
+    wins, wants = [], []
+    for m, u in shapes:
+        idx = rng.permutation(G.shape[0])
+        gm, gu = np.ascontiguousarray(G[np.sort(idx[:m])]), np.ascontiguousarray(G[np.sort(idx[m:m + u])])
+        z1 = rng.standard_normal(m) * 2
+        wins.append(dict(mode=mode, geno_m=gm, geno_u=gu, pop_off=off, pop_wgt=p["w"], z1=z1))
+        wants.append(("impute", oracle.run_impute(mode, gm, gu, off, p["w"], z1)))
+        n_head, n_pred = m // 5, m - m // 5 - m // 7
+        wins.append(dict(mode=mode, geno_m=gm, geno_u=gu, pop_off=off, pop_wgt=p["w"], z1=z1, qcat=(n_head, n_pred, 0.01)))
+        wants.append(("qcat", oracle.run_qcat(mode, gm, gu, off, p["w"], z1, n_head, n_pred)))
+    job = hotpath.Job(wins, ctx=ctx)
+    job.run()
+    res = job.fetch()
+    job.close()
+    for (kind, want), got, w in zip(wants, res, wins):
+        shape = (w["geno_m"].shape[0], w["geno_u"].shape[0])
+        assert got["status"] == 0, shape
+        if kind == "impute":
+            assert relerr(got["info"], want["info"]) <= Z_TOL, shape
+            assert np.max(np.abs(got["z"] - want["z"]) / np.maximum(1.0, np.abs(want["z"]))) <= Z_TOL, shape
+        else:
+            assert got["num_eig"] == want["num_eig"], shape
+            assert np.max(np.abs(got["r"] - want["r"])) <= R_TOL, shape
