@@ -2,7 +2,7 @@
 """bench.py -- imputed SNPs/sec of the DISTMIX hot path on the chr22 study (BASELINE.json configs[3]).
 
 One "step" = one full pass of the hot path (pack/stats -> fp32-MFMA LD Gram -> fp64 LD epilogue ->
-Cholesky -> solve) over every 1 Mb window of ONE chromosome whose panel is already resident in HBM.
+Cholesky + inverse factor -> product with the z / info sums) over every 1 Mb window of ONE chromosome whose panel is already resident in HBM.
 Measured SNPs (positions, z) are the reference's own chr22 study file; unmeasured SNPs and genotypes
 are synthetic (gauss_amd/workload.py).
 
@@ -431,7 +431,7 @@ def run_impute(args, rig):
                 "work_items": stats["items"], "partial_slab_bytes": stats["slab_bytes"],
             },
             "roofline_solve": {
-                "kernel": "factor_*_kernel + solve_kernel (v_mfma_f64_16x16x4_f64)", "bound": "mfma",
+                "kernel": "factor_*_kernel (Cholesky + rows of L^-1) + impute_gemm_kernel (v_mfma_f64_16x16x4_f64)", "bound": "mfma",
                 "achieved": solve_ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": solve_ach / FP64_MFMA_PEAK_TFLOPS,
                 "algorithmic_flops_per_step": work["solve_flops"], "ms_per_step": tail_s * 1e3,
                 "definition": "sum over windows of M^3/3 + 2 U M^2 + 4 U M (SURVEY.md 8d) / (factor + solve time)",

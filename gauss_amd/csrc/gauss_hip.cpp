@@ -68,6 +68,9 @@ struct BlockCache {
 struct gauss_ctx {
     int device;
     hipStream_t stream;
+    // B21's half of the LD epilogue runs here, beside the factorisation chain on `stream` (which only needs B11): the
+    // chain's launches are few, short and dependent and leave most of the chip idle (GAUSS_SIDE_STREAM=0: one stream)
+    hipStream_t side = nullptr;
     int gram_i8 = 0;
     std::map<const void*, size_t> stores;    // row stores made by gauss_store_upload: base pointer -> bytes
     std::mutex mu;
@@ -178,10 +181,12 @@ struct gauss_job {
     char* h_pin = nullptr;                                 // pinned block: [table image | results | status]
     hipEvent_t begin = nullptr;                            // recorded when gauss_job_run starts queuing
     hipEvent_t done = nullptr;                             // recorded after the result copies of gauss_job_run
+    hipEvent_t ev_gram = nullptr, ev_side = nullptr;       // Gram kernel finished (main stream) / B21 written (side stream)
     Prob* d_probs = nullptr;
     Item* d_items = nullptr;    int n_items = 0;
     int2* d_rowmap = nullptr;   int n_rows = 0;
-    int2* d_tilemap = nullptr;  int n_tiles = 0;
+    int2* d_tilemap = nullptr;  int n_tiles = 0;            // LD epilogue tiles: B11's first (n_tiles_b11 of them), then B21's
+    int n_tiles_b11 = 0;
     int2* d_panelmap = nullptr; int n_panels = 0;          // fused path: (window, panel of [I | z1])
     int2* d_dpanelmap = nullptr; int n_dpanels = 0;        // stand-alone solve: (window, panel of right-hand sides)
     int2* d_gemmmap = nullptr;  int n_gemm = 0;            // (window, rhs panel of gemm_ut << 8 | k block of 128), longest first
@@ -541,7 +546,7 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
     // work lists
     struct ItemH { int prob, pair, group, len; };
     std::vector<ItemH> items;
-    std::vector<int2> rowmap, tilemap, panelmap, dpanelmap, gemmmap, finmap;
+    std::vector<int2> rowmap, tilemap, tilemap_b21, panelmap, dpanelmap, gemmmap, finmap;
     job->max_nblk = 0;
     {
         // tiles of the closing product at 128 right-hand sides each: a small job (an 8-rank share: ~570) cannot fill the
@@ -563,7 +568,10 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
             }
         for (int r = 0; r < p.M + p.U; r++) rowmap.push_back(make_int2(i, r));
         if (!p.n_gene)
-            for (int pr = 0; pr < p.npair; pr++) tilemap.push_back(make_int2(i, pr));
+            for (int pr = 0; pr < p.npair; pr++) {
+                const bool b21 = !p.ld_only && job->plans[i].pair_ti[pr] >= p.Mp / TILE;      // a tile of U rows x M columns
+                (b21 ? tilemap_b21 : tilemap).push_back(make_int2(i, pr));
+            }
         for (int pn = 0; pn < p.npi; pn++) panelmap.push_back(make_int2(i, pn));
         for (int pn = 0; pn < p.npanel; pn++) dpanelmap.push_back(make_int2(i, pn));
         if (p.npanel > 0) {
@@ -602,6 +610,8 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
     }
     const size_t o_items = ta.take(sizeof(Item) * std::max<size_t>(items.size(), 1));
     const size_t o_rowmap = put(blob, ta, rowmap);
+    job->n_tiles_b11 = (int)tilemap.size();
+    tilemap.insert(tilemap.end(), tilemap_b21.begin(), tilemap_b21.end());
     const size_t o_tilemap = put(blob, ta, tilemap);
     // the product's tiles with the longest K loop (highest k block) first
     std::stable_sort(gemmmap.begin(), gemmmap.end(), [](const int2& a, const int2& b) { return (a.y & 255) > (b.y & 255); });
@@ -694,6 +704,8 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
     job->h_status = (int*)(job->h_pin + pin_tab + pin_res);
     HIPCHK(hipEventCreate(&job->begin));
     HIPCHK(hipEventCreate(&job->done));
+    HIPCHK(hipEventCreateWithFlags(&job->ev_gram, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&job->ev_side, hipEventDisableTiming));
 
     hipStream_t st = ctx->stream;
     // zero once: operand padding, B21 padding and the solve matrices rely on it
@@ -855,8 +867,18 @@ static int job_run(gauss_job* job, bool solve)
     prof_begin(job, 0, st);
     launch_gram(job->d_items, job->n_items, job->gram_i8, st);
     prof_end(job, st);
+    // fused tail: the factorisation chain needs B11 only and the closing product is the first reader of B21, so B21's
+    // tiles of the epilogue (85 % of them) go to the side stream and run beside the chain
+    static const bool fused = !(getenv("GAUSS_FUSED_SOLVE") && atoi(getenv("GAUSS_FUSED_SOLVE")) == 0);
+    hipStream_t side = (solve && fused && job->n_panels > 0 && job->n_tiles > job->n_tiles_b11) ? job->ctx->side : nullptr;
+    if (side) {
+        HIPCHK(hipEventRecord(job->ev_gram, st));
+        HIPCHK(hipStreamWaitEvent(side, job->ev_gram, 0));
+        launch_epilogue(job->d_probs, job->d_tilemap + job->n_tiles_b11, job->n_tiles - job->n_tiles_b11, job->max_pop, job->gram_i8, side);
+        HIPCHK(hipEventRecord(job->ev_side, side));
+    }
     prof_begin(job, 2, st);
-    launch_epilogue(job->d_probs, job->d_tilemap, job->n_tiles, job->max_pop, job->gram_i8, st);
+    launch_epilogue(job->d_probs, job->d_tilemap, side ? job->n_tiles_b11 : job->n_tiles, job->max_pop, job->gram_i8, st);
     for (int i = 0; i < job->n; i++)
         if (job->plans[i].p.n_gene) launch_gene_epilogue(job->d_probs, i, job->plans[i].p.n_gene, st);
     prof_end(job, st);
@@ -868,7 +890,6 @@ static int job_run(gauss_job* job, bool solve)
         }
         // fused (default): the solve's block rows ride in the factorisation's update launches (k_solve.hip); the stage
         // timers then read "factor" = factorisation + all solve rows but the last, "solve" = the closing launch
-        static const bool fused = !(getenv("GAUSS_FUSED_SOLVE") && atoi(getenv("GAUSS_FUSED_SOLVE")) == 0);
         prof_begin(job, 3, st);
         for (int s = 0; s < job->max_nblk; s++)
             launch_factor_step(job->d_probs, job->n, s, job->max_nblk, fused ? job->max_npanel : 0, job->solve_split, st);
@@ -876,6 +897,7 @@ static int job_run(gauss_job* job, bool solve)
         prof_begin(job, 4, st);
         if (fused) {
             launch_solve_last(job->d_probs, job->d_panelmap, job->n_panels, job->max_nblk, job->solve_split, st);
+            if (side) HIPCHK(hipStreamWaitEvent(st, job->ev_side, 0));
             launch_impute_gemm(job->d_probs, job->d_gemmmap, job->n_gemm, job->gemm_ut, job->d_finmap, job->n_fin, st);
         } else launch_solve(job->d_probs, job->d_dpanelmap, job->n_dpanels, st);
         prof_end(job, st);
@@ -1036,6 +1058,8 @@ static void job_free(gauss_job* job)
     }
     if (job->begin) hipEventDestroy(job->begin);
     if (job->done) hipEventDestroy(job->done);
+    if (job->ev_gram) hipEventDestroy(job->ev_gram);
+    if (job->ev_side) hipEventDestroy(job->ev_side);
     delete job;
 }
 
@@ -1071,7 +1095,13 @@ int gauss_hip_init(int device, gauss_ctx** out_ctx)
     c->device = device;
     const char* e = getenv("GAUSS_GRAM_DTYPE");
     c->gram_i8 = (e && (strcmp(e, "i8") == 0 || strcmp(e, "int8") == 0)) ? 1 : 0;
-    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    if (env_int("GAUSS_SIDE_STREAM", 1)) {
+        // the chain gets the higher priority: a workgroup of its next launch must win the CU an epilogue workgroup frees
+        int lo = 0, hi = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIPCHK(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi));
+        HIPCHK(hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, lo));
+    } else HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     *out_ctx = c;
     return GAUSS_OK;
 }
@@ -1094,6 +1124,7 @@ void gauss_hip_destroy(gauss_ctx* ctx)
     if (!ctx) return;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
+    if (ctx->side) { hipStreamSynchronize(ctx->side); hipStreamDestroy(ctx->side); }
     for (auto& kv : ctx->dev_cache.free_blocks) (void)hipFree(kv.second);
     for (auto& kv : ctx->pin_cache.free_blocks) (void)hipHostFree(kv.second);
     hipStreamDestroy(ctx->stream);
