@@ -1859,7 +1859,9 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
         w.owner = 0; w.status = -1; w.M = (int)m; w.U = (int)u;
         wins.push_back(w);
     }
-    {   // longest processing time first, ties by index: farm.assign_windows
+    {   // farm.level_windows without the cuts: longest processing time first (ties by index), then a local search.
+        // A rank's load is the cost of its windows plus the factorisation chain of its tallest one (the chain is
+        // latency bound on the few windows a rank holds: DESIGN.md section 6; farm.CHAIN_STEP_COST, here per sample).
         std::vector<int> order(wins.size());
         for (size_t i = 0; i < order.size(); i++) order[i] = (int)i;
         std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return wins[a].cost > wins[b].cost; });
@@ -1868,6 +1870,36 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
             int r = 0;
             for (int k = 1; k < world; k++) if (load[k] < load[r]) r = k;
             wins[i].owner = r; load[r] += wins[i].cost;
+        }
+        double n_samples = 0;
+        for (uint32_t q = 0; q < pk->header().n_pop; q++) n_samples += pk->pop((int)q).size;
+        const double chain = 2.4e9 / std::max(1.0, n_samples);
+        auto load_of = [&](int r, int drop, int add) {            // rank r's load without window `drop`, with window `add`
+            double c = 0; int tall = 0;
+            for (size_t i = 0; i < wins.size(); i++) {
+                const bool in = ((int)i == add) || (wins[i].owner == r && (int)i != drop);
+                if (in) { c += wins[i].cost; tall = std::max(tall, (wins[i].M + 63) / 64); }
+            }
+            return c + chain * tall;
+        };
+        for (size_t it = 0; world > 1 && it < 4 * wins.size(); it++) {
+            int hi = 0; double top = -1;
+            for (int r = 0; r < world; r++) { const double l = load_of(r, -1, -1); if (l > top) { top = l; hi = r; } }
+            double best = top * (1 - 1e-9); int ba = -1, bb = -1, br = -1;
+            for (size_t a = 0; a < wins.size(); a++) {
+                if (wins[a].owner != hi) continue;
+                for (int r = 0; r < world; r++) {
+                    if (r == hi) continue;
+                    for (int b = -1; b < (int)wins.size(); b++) {      // b = -1: move a to r; else trade a for b
+                        if (b >= 0 && wins[b].owner != r) continue;
+                        const double m = std::max(load_of(hi, (int)a, b), load_of(r, b, (int)a));
+                        if (m < best) { best = m; ba = (int)a; bb = b; br = r; }
+                    }
+                }
+            }
+            if (ba < 0) break;
+            wins[ba].owner = br;
+            if (bb >= 0) wins[bb].owner = hi;
         }
     }
     std::vector<int> mine;
