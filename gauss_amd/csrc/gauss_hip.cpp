@@ -676,7 +676,7 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
             w.Linv = wa.take((size_t)2 * p.nblk * NB * NB * sizeof(double));
             w.V = wa.take((size_t)std::max(p.npanel, p.npi) * p.Mld * NR * sizeof(double));
             w.gsum = wa.take((size_t)((p.Mld + 127) / 128) * p.Up128 * 3 * sizeof(double));
-            w.part = job->solve_split ? wa.take((size_t)p.npi * 4 * NB * NR * sizeof(double)) : 0;
+            w.part = wa.take((size_t)2 * p.npi * 4 * NB * NR * sizeof(double));      // double buffered by row parity
             w.b11c = wa.take((size_t)p.Mld * p.Mld * sizeof(double));
         }
         w.ld = wa.take(std::max<size_t>(pl.out_ld_count, 1) * sizeof(double));
@@ -751,7 +751,7 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
         if (!p.ld_only) { p.A = (double*)(W + w.A); p.B21 = (double*)(W + w.B21); }
         if (p.npanel > 0) {
             p.Linv = (double*)(W + w.Linv); p.V = (double*)(W + w.V); p.Gsum = (double*)(W + w.gsum);
-            p.Part = job->solve_split ? (double*)(W + w.part) : nullptr;
+            p.Part = (double*)(W + w.part);
             pl.d_b11_copy = (double*)(W + w.b11c);
         }
         p.out_z = job->d_results + pl.res_off;

@@ -87,7 +87,7 @@ struct Prob {
     GP(double) B21;            // [Upad x Mld] row-major (Upad = npanel*NRU rounded)
     GP(double) V;              // [max(npanel, npi)][Mld][NR]: fused path: [X | y] = L^-1 [I | z1] by panels of NR columns
     GP(double) Gsum;           // [ceil(Mld / 128)][Up128][3] z / info / v sums of every k block (impute_gemm_kernel)
-    GP(double) Part;           // [npi][SOLVE_SPLIT][NB x NR] partial sums of a split row (small jobs only), else null
+    GP(double) Part;           // [2][npi][SOLVE_SPLIT][NB x NR] parked sums of a row's early products, by row parity
     GP(double) out_z;          // [U]
     GP(double) out_info;       // [U]
     GP(int) status;            // [4]: [0] fail flag matrix 0, [1] fail flag matrix 1, [2] nonfinite

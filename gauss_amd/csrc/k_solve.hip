@@ -589,77 +589,165 @@ __device__ __forceinline__ void solve_finish(const Prob& pb, int panel, double* 
     }
 }
 
-// one block row of one panel of the inverse, riding in a factorisation launch
-__device__ __forceinline__ void solve_row_fused(const Prob& pb, int panel, int kb, double* __restrict__ smem, int tid)
+// ---- rows of the inverse riding in the factorisation's launches ------------------------------------------------
+// Block row r of [X | y] for one panel p:  V_r = Linv_rr (B_r - sum_{j = first}^{r-1} L_rj V_j).  Row r needs row
+// r - 1, so the rows form a chain next to the factorisation's own; to keep a link of that chain short the sum is
+// taken in two launches:
+//   pre(r)  in update(r - 1):  the EARLY products j <= r - 2 (they need rows <= r - 2 only), summed in SOLVE_SPLIT
+//           interleaved classes (j = g, g + SOLVE_SPLIT, ...): rows with at least `split` early products give one
+//           workgroup to each class, shorter rows run the classes one after the other in one workgroup and park their
+//           sum (added up in class order, as fin does) -- the same bits either way;
+//   fin(r)  in update(r):      the parked sums in class order, then the LAST product j = r - 1 accumulated on top, the
+//           right-hand side, Linv_rr, and the store of V_r -- one product and one triangular block: ~12 us.
+// update(s) therefore carries fin(s) and pre(s + 1); both read only what earlier launches wrote (L rows <= s + 1 from
+// panel(<= s), Linv_ss from update(s - 1), V rows <= s - 1 and pre(s)'s sums from update(s - 1)).  Part is double
+// buffered by row parity (pre(s + 1) writes while fin(s) reads).  solve_last_kernel runs fin of the batch's last row.
+__device__ __forceinline__ GP(double) ride_part(const Prob& pb, int panel, int r, int g)
 {
-    double* TL = smem;
-    double* TV = TL + NB * LDT;
-    SolveSums sums{0.0, 0.0, 0.0};
-    solve_row<true>(pb, panel, kb, TL, TV, sums, tid);
+    return pb.Part + (((size_t)(r & 1) * pb.npi + panel) * SOLVE_SPLIT + g) * (NB * NR);
 }
 
-// ---- split form of a fused block row (small batches) ------------------------------------------------------------
-// With few windows per job the launches are latency bound and a row's kb dependent products (kb up to 18) outlast the
-// tile Cholesky they are meant to hide behind.  The row is then cut in two launches: SOLVE_SPLIT workgroups form the
-// partial sums of every SOLVE_SPLIT-th product in update(kb) (at most 5 products each) and park them in pb.Part;
-// one workgroup per panel adds them up (fixed order), applies Linv_kk and does the row's bookkeeping in the next
-// launch, panel(kb + 1), or in solve_last_kernel for the last two rows of the batch.  Large batches are throughput
-// bound and keep the one-workgroup row (the partial tiles would add two thirds to its traffic).
-__device__ __forceinline__ void solve_partial(const Prob& pb, int panel, int kb, int g, double* __restrict__ smem, int tid)
+// acc -= sum over j = j0, j0 + jstep, ... <= jlast of L[r][j] V[j], skipping j below the panel's first row
+__device__ __forceinline__ void ride_products(const Prob& pb, int panel, int r, int j0, int jstep, int jlast, f64x4 (&acc)[SOLVE_NT],
+                                              double* __restrict__ TL, double* __restrict__ TV, int tid)
 {
+    constexpr int NT = SOLVE_NT;
+    const int first = inv_first_row(pb, panel);
+    if (j0 < first) j0 += (first - j0 + jstep - 1) / jstep * jstep;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int ld = pb.Mld;
+    const auto Lm = pb.A + (size_t)2 * ld * ld;               // factor of A[0]
+    const auto V = pb.V + (size_t)panel * ld * NR;
+    TileRegs rl, rv;
+    if (j0 <= jlast) {
+        tile_fetch(rl, Lm + (size_t)r * NB * ld + (size_t)j0 * NB, ld, tid);
+        tile_fetch(rv, V + (size_t)j0 * NB * NR, NR, tid);
+    }
+    for (int jb = j0; jb <= jlast; jb += jstep) {
+        __syncthreads();                                  // previous tiles are no longer being read
+        tile_commit<LDT>(TL, rl, tid);
+        tile_commit<LDV>(TV, rv, tid);
+        __syncthreads();
+        if (jb + jstep <= jlast) {                        // next tiles fly during the product
+            tile_fetch(rl, Lm + (size_t)r * NB * ld + (size_t)(jb + jstep) * NB, ld, tid);
+            tile_fetch(rv, V + (size_t)(jb + jstep) * NB * NR, NR, tid);
+        }
+        mfma_nn<NT, true>(acc, TL, TV, wave, lane);
+    }
+}
+
+__device__ __forceinline__ void ride_pre(const Prob& pb, int panel, int r, int g, int split, double* __restrict__ smem, int tid)
+{
+    const int n_early = r - 1 - inv_first_row(pb, panel);     // products j = first .. r - 2
+    if (n_early < 1) return;
+    const bool cut = split > 0 && n_early >= split;
+    if (!cut && g != 0) return;
     double* TL = smem;
     double* TV = TL + NB * LDT;
     f64x4 acc[SOLVE_NT];
 #pragma unroll
     for (int n = 0; n < SOLVE_NT; n++) acc[n] = f64x4{0.0, 0.0, 0.0, 0.0};
-    solve_products<true>(pb, panel, kb, g, SOLVE_SPLIT, acc, TL, TV, tid);
-    const auto P = pb.Part + ((size_t)panel * SOLVE_SPLIT + g) * (NB * NR);
+    if (cut) ride_products(pb, panel, r, g, SOLVE_SPLIT, r - 2, acc, TL, TV, tid);
+    else {
+        for (int gg = 0; gg < SOLVE_SPLIT; gg++) {
+            f64x4 part[SOLVE_NT];
+#pragma unroll
+            for (int n = 0; n < SOLVE_NT; n++) part[n] = f64x4{0.0, 0.0, 0.0, 0.0};
+            ride_products(pb, panel, r, gg, SOLVE_SPLIT, r - 2, part, TL, TV, tid);
+#pragma unroll
+            for (int n = 0; n < SOLVE_NT; n++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) acc[n][q] += part[n][q];
+        }
+    }
+    const auto P = ride_part(pb, panel, r, g);
 #pragma unroll
     for (int n = 0; n < SOLVE_NT; n++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) P[(size_t)(n * 4 + r) * 256 + tid] = acc[n][r];      // register layout, coalesced
+        for (int q = 0; q < 4; q++) P[(size_t)(n * 4 + q) * 256 + tid] = acc[n][q];      // register layout, coalesced
 }
 
-// second half of a split row: sums may be carried in registers by the caller (carry = true) or through pb.Sacc
-__device__ __forceinline__ void solve_combine(const Prob& pb, int panel, int kb, double* __restrict__ smem, SolveSums& sums, int tid)
+__device__ __forceinline__ void ride_fin(const Prob& pb, int panel, int r, int split, double* __restrict__ smem, int tid)
 {
+    const int first = inv_first_row(pb, panel);
+    if (r < first) return;
     double* TL = smem;
     double* TV = TL + NB * LDT;
-    f64x4 acc[SOLVE_NT];
+    const int lane = tid & 63, wave = tid >> 6;
+    const int n_early = r - 1 - first;
+    const int np = n_early < 1 ? 0 : ((split > 0 && n_early >= split) ? SOLVE_SPLIT : 1);
+    // Loads are requested well ahead of their use, but in two rounds so that the workgroup stays within 256 registers
+    // (two workgroups per CU): first the right-hand side with Linv_rr and the first two parked sums, then the other two
+    // together with the last product's two tiles.
+    const bool has_last = r - 1 >= first;
+    TileRegs li;
+    tile_fetch(li, pb.Linv + (size_t)r * NB * NB, NB, tid);
+    f64x4 acc[SOLVE_NT], part[2][SOLVE_NT];
 #pragma unroll
     for (int n = 0; n < SOLVE_NT; n++) acc[n] = f64x4{0.0, 0.0, 0.0, 0.0};
-    SolveRhs q;
-    solve_rhs_fetch<true>(pb, panel, kb, q, tid);                 // in flight together with the partial sums
-    const int np = kb < SOLVE_SPLIT ? kb : SOLVE_SPLIT;           // partial sums that exist for this row
-    // every partial tile is requested before the first is added (four dependent round trips to tiles that other CUs
-    // have just written cost ~4 us each); the additions keep the class order
-    f64x4 part[SOLVE_SPLIT][SOLVE_NT];
+    auto load2 = [&](int g0) {
 #pragma unroll
-    for (int g = 0; g < SOLVE_SPLIT; g++) {
-        if (g < np) {
-            const auto P = pb.Part + ((size_t)panel * SOLVE_SPLIT + g) * (NB * NR);
+        for (int g = 0; g < 2; g++) {
+            if (g0 + g < np) {
+                const auto P = ride_part(pb, panel, r, g0 + g);
 #pragma unroll
-            for (int n = 0; n < SOLVE_NT; n++)
+                for (int n = 0; n < SOLVE_NT; n++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) part[g][n][r] = P[(size_t)(n * 4 + r) * 256 + tid];
+                    for (int c = 0; c < 4; c++) part[g][n][c] = P[(size_t)(n * 4 + c) * 256 + tid];
+            }
         }
-    }
+    };
+    auto add2 = [&](int g0) {
 #pragma unroll
-    for (int g = 0; g < SOLVE_SPLIT; g++) {
-        if (g < np) {
+        for (int g = 0; g < 2; g++) {
+            if (g0 + g < np) {
 #pragma unroll
-            for (int n = 0; n < SOLVE_NT; n++)
+                for (int n = 0; n < SOLVE_NT; n++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) acc[n][r] += part[g][n][r];
+                    for (int c = 0; c < 4; c++) acc[n][c] += part[g][n][c];
+            }
         }
+    };
+    load2(0);
+    TileRegs rl, rv;
+    add2(0);
+    load2(2);
+    if (has_last) {
+        const int ld = pb.Mld;
+        tile_fetch(rl, pb.A + (size_t)2 * ld * ld + (size_t)r * NB * ld + (size_t)(r - 1) * NB, ld, tid);
+        tile_fetch(rv, pb.V + (size_t)panel * ld * NR + (size_t)(r - 1) * NB * NR, NR, tid);
     }
-    solve_tail<true>(pb, panel, kb, acc, q, TL, TV, sums, tid);
-}
-
-__device__ __forceinline__ void solve_combine_fused(const Prob& pb, int panel, int kb, double* __restrict__ smem, int tid)
-{
-    SolveSums sums{0.0, 0.0, 0.0};
-    solve_combine(pb, panel, kb, smem, sums, tid);
+    add2(2);
+    if (has_last) {
+        tile_commit<LDT>(TL, rl, tid);
+        tile_commit<LDV>(TV, rv, tid);
+        __syncthreads();
+        mfma_nn<SOLVE_NT, true>(acc, TL, TV, wave, lane);
+    }
+    // X = B_r + acc with B = [I | z1] (column g = 64 panel + c is e_g for g < M and z1 for g == M);  V_r = Linv_rr X
+    const auto V = pb.V + (size_t)panel * pb.Mld * NR;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < (NB * NR) / 256; i++) {
+        const int e = tid + 256 * i;
+        const int c = e >> 6, rr = e & 63;
+        const int k = r * NB + rr, g = panel * NR + c;
+        TV[rr * LDV + c] = (g < pb.M) ? ((g == k) ? 1.0 : 0.0) : ((g == pb.M && k < pb.M) ? pb.z1[k] : 0.0);
+    }
+    tile_commit<LDT>(TL, li, tid);
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < SOLVE_NT; n++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) TV[acc_row(wave, lane, c) * LDV + acc_col(lane, n)] += acc[n][c];
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < SOLVE_NT; n++) acc[n] = f64x4{0.0, 0.0, 0.0, 0.0};
+    mfma_nn<SOLVE_NT, false>(acc, TL, TV, wave, lane);
+#pragma unroll
+    for (int n = 0; n < SOLVE_NT; n++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) V[(size_t)(r * NB + acc_row(wave, lane, c)) * NR + acc_col(lane, n)] = acc[n][c];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -750,14 +838,7 @@ __global__ __launch_bounds__(256) void factor_panel_kernel(const Prob* __restric
     const Prob& pb = probs[blockIdx.y >> 1];
     const int mat = blockIdx.y & 1;
     if (pb.ld_only || pb.npanel == 0) return;
-    if ((int)blockIdx.x < n_comb) {
-        // split rows: second half of block row s - 1 (its partial sums were formed in update(s - 1)).  These workgroups
-        // are the long ones of the launch, so they are dispatched first and the short tile products fill in behind
-        const int panel = (int)blockIdx.x;
-        if (mat == 0 && s >= 1 && panel < pb.npi && s - 1 < pb.nblk && s - 1 - inv_first_row(pb, panel) >= split)
-            solve_combine_fused(pb, panel, s - 1, smem, threadIdx.x);
-        return;
-    }
+    (void)split;
     if (mat == 1 && pb.status[3]) return;              // certified: lambda_min(B11) > eps
     const int nb = pb.nblk;
     const int k = s + 1 + ((int)blockIdx.x - n_comb);
@@ -786,7 +867,7 @@ __global__ __launch_bounds__(256) void factor_panel_kernel(const Prob* __restric
 }
 
 // update(s): grid.x = T (T + 1) / 2 with T = max_nblk - 1 - s; x = 0 is tile (s+1, s+1)
-__global__ __launch_bounds__(256) void factor_update_kernel(const Prob* __restrict__ probs, int s, int T, int n_tri, int split, int n_ride)
+__global__ __launch_bounds__(256, 2) void factor_update_kernel(const Prob* __restrict__ probs, int s, int T, int n_tri, int split, int n_ride)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* TA = smem;                 // L[k][s]            | D (next diagonal tile)
@@ -799,21 +880,12 @@ __global__ __launch_bounds__(256) void factor_update_kernel(const Prob* __restri
     // inverse that ride in this launch (chains of dependent products), then the one-product trailing tiles, which fill
     // in behind them -- with the riding rows last, every launch ended on a 15-20 us tail of theirs
     if ((int)blockIdx.x >= 1 && (int)blockIdx.x <= n_ride) {
-        // block row s of the inverse: one workgroup per right-hand-side panel, or (split form) SOLVE_SPLIT workgroups
-        // per panel that only form partial sums
+        // riding rows of the inverse: per panel one workgroup for fin(s) and SOLVE_SPLIT for pre(s + 1)
         const int idx = (int)blockIdx.x - 1;
-        if (!split) {
-            if (mat == 0 && idx < pb.npi && s < pb.nblk && s >= inv_first_row(pb, idx)) solve_row_fused(pb, idx, s, smem, threadIdx.x);
-        } else {
-            // rows with fewer than `split` products stay whole (class 0's workgroup runs them): cutting them would only
-            // add workgroups and a round trip through Part; either form sums in the same order
-            const int panel = idx / SOLVE_SPLIT, g = idx % SOLVE_SPLIT;
-            if (mat != 0 || panel >= pb.npi || s >= pb.nblk) return;
-            const int nprod = s - inv_first_row(pb, panel);
-            if (nprod < 0) return;
-            if (nprod < split) { if (g == 0) solve_row_fused(pb, panel, s, smem, threadIdx.x); }
-            else if (g < s) solve_partial(pb, panel, s, g, smem, threadIdx.x);
-        }
+        const int panel = idx / (SOLVE_SPLIT + 1), g = idx % (SOLVE_SPLIT + 1);
+        if (mat != 0 || panel >= pb.npi) return;
+        if (g == SOLVE_SPLIT) { if (s < pb.nblk) ride_fin(pb, panel, s, split, smem, threadIdx.x); }
+        else if (s + 1 < pb.nblk) ride_pre(pb, panel, s + 1, g, split, smem, threadIdx.x);
         return;
     }
     if (mat == 1 && pb.status[3]) return;              // certified: lambda_min(B11) > eps
@@ -889,12 +961,11 @@ void launch_factor_step(const Prob* d_probs, int n_prob, int step, int max_nblk,
     if (T <= 0) return;
     const int n_tri = T * (T + 1) / 2;
     const bool fuse = max_npanel > 0;
-    const bool sp = fuse && split;
-    const int n_comb = sp ? max_npanel : 0, n_ride = fuse ? max_npanel * (sp ? SOLVE_SPLIT : 1) : 0;
-    hipLaunchKernelGGL(factor_panel_kernel, dim3(T + n_comb, n_prob * 2), dim3(256), sp ? upd_smem : FACTOR_SMEM, st,
+    const int n_comb = 0, n_ride = fuse ? max_npanel * (SOLVE_SPLIT + 1) : 0;
+    hipLaunchKernelGGL(factor_panel_kernel, dim3(T + n_comb, n_prob * 2), dim3(256), FACTOR_SMEM, st,
                        d_probs, s, T, split, n_comb);
     hipLaunchKernelGGL(factor_update_kernel, dim3(n_tri + n_ride, n_prob * 2), dim3(256),
-                       upd_smem, st, d_probs, s, T, n_tri, sp ? split : 0, n_ride);
+                       upd_smem, st, d_probs, s, T, n_tri, split, n_ride);
 }
 
 __global__ __launch_bounds__(256) void solve_kernel(const Prob* __restrict__ probs,
@@ -914,23 +985,14 @@ __global__ __launch_bounds__(256) void solve_kernel(const Prob* __restrict__ pro
 
 // What the update launches could not carry: the last block row of the windows that are as tall as the batch's tallest
 // one and, in the split form, the second half of the row before it.
-__global__ __launch_bounds__(256) void solve_last_kernel(const Prob* __restrict__ probs, const int2* __restrict__ panelmap,
+__global__ __launch_bounds__(256, 2) void solve_last_kernel(const Prob* __restrict__ probs, const int2* __restrict__ panelmap,
                                                          int s_last, int split)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int2 pm = panelmap[blockIdx.x];
     const Prob& pb = probs[pm.x];
     const int last = pb.nblk - 1, tid = threadIdx.x, panel = pm.y;
-    const int first = inv_first_row(pb, panel);
-    if (last < s_last - 1) return;                          // this window finished in an earlier launch
-    double* TL = smem;
-    double* TV = TL + NB * LDT;
-    SolveSums sums{0.0, 0.0, 0.0};
-    if (split && s_last >= 1) {
-        const int r = s_last - 1;                           // a row cut in update(r), the batch's last update launch
-        if (r - first >= split) solve_combine(pb, panel, r, smem, sums, tid);
-    }
-    if (last == s_last && s_last >= first) solve_row<true>(pb, panel, s_last, TL, TV, sums, tid);
+    if (last == s_last) ride_fin(pb, panel, s_last, split, smem, tid);     // pre(s_last) rode in update(s_last - 1)
 }
 
 // ------------------------------------------------------------------------------------------
