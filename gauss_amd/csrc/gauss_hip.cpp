@@ -636,11 +636,11 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
     std::vector<WsOff> wo(job->n);
     size_t res = 0;
     {
-        // A row of the inverse that rides in an update launch is a chain of dependent products (k_solve.hip): rows with
-        // at least `solve_split` products are cut into SOLVE_SPLIT partial sums + a combine in the next launch, shorter
-        // rows stay whole; 0 = never cut.  Measured on 36 windows (factorisation + riding rows): never 1.72 ms, >= 8
-        // 1.70, >= 4 1.49, >= 2 1.46; on the 4-5 windows of an 8-rank share the cut rows were what made the rows hide
-        // behind the tile Cholesky in the first place.  Either form sums in the same order.
+        // The early products of a row of the inverse (k_solve.hip, ride_pre) are a chain of dependent tile products:
+        // rows with at least `solve_split` of them give one workgroup to each of their SOLVE_SPLIT classes, shorter rows
+        // run the classes in one workgroup; 0 = never cut.  Either form sums in the same order.  Cutting from two
+        // products on is what keeps every riding workgroup shorter than the diagonal tile's (36 windows, factorisation
+        // with riding rows: never 1.72 ms, >= 8 1.70, >= 4 1.49, >= 2 1.46 before the pre / fin form, 1.31 with it; factorisation alone 1.10).
         const int thr = env_int("GAUSS_SOLVE_SPLIT_MIN", 2);               // read per job: tests drive both forms
         job->solve_split = job->n_panels > 0 ? thr : 0;
     }
@@ -888,8 +888,9 @@ static int job_run(gauss_job* job, bool solve)
             if (pl.out_b11 && pl.p.npanel > 0)
                 HIPCHK(hipMemcpyAsync(pl.d_b11_copy, pl.p.A, sizeof(double) * pl.p.Mld * pl.p.Mld, hipMemcpyDeviceToDevice, st));
         }
-        // fused (default): the solve's block rows ride in the factorisation's update launches (k_solve.hip); the stage
-        // timers then read "factor" = factorisation + all solve rows but the last, "solve" = the closing launch
+        // fused (default): the rows of [X | y] = L^-1 [I | z1] ride in the factorisation's update launches and the
+        // closing product forms z / info (k_solve.hip); the stage timers read "factor" = factorisation + riding rows,
+        // "solve" = closing row + product + finish
         prof_begin(job, 3, st);
         for (int s = 0; s < job->max_nblk; s++)
             launch_factor_step(job->d_probs, job->n, s, job->max_nblk, fused ? job->max_npanel : 0, job->solve_split, st);

@@ -362,51 +362,32 @@ __device__ __forceinline__ GP(double) factor_work(const Prob& pb, int mat)
 }
 
 // ------------------------------------------------------------------------------------------
-// K6/K7: forward substitution for one panel of NR right-hand sides (NR - 1 unmeasured SNPs'
-// b21 rows + the z1 column), left-looking over the 64-blocks of L, then z / info.
-//   V_k = Linv_kk * (B_k - sum_{j<k} L_kj V_j)
-// V blocks live in the problem's V scratch ([panel][Mld][NR]) for reuse by later block rows.
-//
-// Two drivers run the same row routine (identical arithmetic, identical results):
-//   * fused (default): block row k of every panel rides in the factorisation's update(k) launch -- it needs
-//     L[k][0..k-1] (finished by panel(k-1)), Linv_kk (finished by update(k-1)) and V[0..k-1] (earlier launches), all
-//     of which are complete when update(k) starts.  The solve's chain of k products per row then hides behind the
-//     tile Cholesky on the factorisation's critical path instead of following it; the per-thread partial sums of
-//     z / info cross the launches through a small scratch (pb.Sacc).  solve_last_kernel finishes the windows whose
-//     last row has no update launch (nblk == max_nblk).
-//   * solve_kernel: all rows of a panel in one workgroup (single-window redo of the clamp path, GAUSS_FUSED_SOLVE=0).
+// K6/K7, two ways to z / info of a window:
+//   * fused (default, every batched job): the rows that ride in the factorisation's launches solve
+//     L [X | y] = [I | z1]  -- M + 1 right-hand sides in panels of NR columns (ride_pre / ride_fin below) -- and
+//     impute_gemm_kernel forms  W = B21 X^T  as a plain product with the z / info sums in its epilogue.
+//   * solve_kernel (single-window redo of the clamp path, GAUSS_FUSED_SOLVE=0): forward substitution of the window's
+//     own right-hand sides, one panel of NR - 1 b21 rows + the z1 column per workgroup, left-looking over the
+//     64-blocks of L:  V_k = Linv_kk * (B_k - sum_{j<k} L_kj V_j),  then z / info from the V blocks.
+// Both keep their V blocks in the problem's V scratch ([panel][Mld][NR]).
 // ------------------------------------------------------------------------------------------
 constexpr int SOLVE_NT = NR / 16;              // accumulator tiles (16 columns each) per wave
 constexpr int SOLVE_NG = 256 / NR;             // row groups of the z / info reduction
 constexpr int SOLVE_RG = NB / SOLVE_NG;        // rows per group
-constexpr int SOLVE_SPLIT = 4;                 // interleaved classes of a row's products (see solve_row / the split form)
+constexpr int SOLVE_SPLIT = 4;                 // interleaved classes of a row's products (solve_row, ride_pre)
 static const size_t SOLVE_SMEM = ((size_t)NB * LDT + (size_t)NB * LDV + 768) * sizeof(double);
 
 struct SolveSums { double z, info, v; };       // per-thread partial sums: column tid % NR, rows of group tid / NR
 
-// The fused path does not push the window's U right-hand sides through the substitution: the rows that ride in the
-// factorisation launches solve  L [X | y] = [I | z1]  instead -- M + 1 right-hand sides, in panels of NR columns -- and
-// impute_gemm_kernel then forms  W = B21 X^T  as a plain product with the z / info sums in its epilogue.
-// Column g < M of the right-hand side is e_g, so block (kb, panel) of X is a structural zero for kb < panel and is
-// never computed, stored or read; the panel that holds column M (z1) is dense.
+// Fused path: column g < M of the right-hand side [I | z1] is e_g, so block (kb, panel) of X is a structural zero for
+// kb < panel and is never computed, stored or read; the panel that holds column M (z1) is dense.
 __device__ __forceinline__ int inv_first_row(const Prob& pb, int panel) { return panel == pb.M / NR ? 0 : panel; }
 
-// First block row of a right-hand-side panel that holds anything (INV: the inverse's panels, see inv_first_row).
-template <bool INV>
-__device__ __forceinline__ int solve_first_row(const Prob& pb, int panel) { return INV ? inv_first_row(pb, panel) : 0; }
-
 // acc -= sum_{j = j0, j0 + jstep, ... < kb} L[kb][j] V[j]   (the products of block row kb; TL / TV: the workgroup's LDS tiles)
-// INV: block rows above the panel's first one are structural zeros that were never written -- their products are
-// skipped, which leaves every sum as it is (they would add exact zeros).
-template <bool INV>
 __device__ __forceinline__ void solve_products(const Prob& pb, int panel, int kb, int j0, int jstep, f64x4 (&acc)[SOLVE_NT],
                                                double* __restrict__ TL, double* __restrict__ TV, int tid)
 {
     constexpr int NT = SOLVE_NT;
-    if (INV) {
-        const int first = inv_first_row(pb, panel);
-        if (j0 < first) j0 += (first - j0 + jstep - 1) / jstep * jstep;
-    }
     const int lane = tid & 63, wave = tid >> 6;
     const int ld = pb.Mld;
     const auto Lm = pb.A + (size_t)2 * ld * ld;               // factor of A[0]
@@ -436,22 +417,9 @@ __device__ __forceinline__ void solve_products(const Prob& pb, int panel, int kb
 // caller can overlap them with other loads; solve_tail commits them to LDS.
 struct SolveRhs { double b[(NB * NR) / 256]; TileRegs li; };
 
-template <bool INV>
 __device__ __forceinline__ void solve_rhs_fetch(const Prob& pb, int panel, int kb, SolveRhs& q, int tid)
 {
     const int ld = pb.Mld;
-    if (INV) {
-        // right-hand sides [ I | z1 ]: column g = 64 panel + c is e_g for g < M and z1 for g == M
-#pragma unroll
-        for (int i = 0; i < (NB * NR) / 256; i++) {
-            const int e = tid + 256 * i;
-            const int c = e >> 6, r = e & 63;
-            const int k = kb * NB + r, g = panel * NR + c;
-            q.b[i] = (g < pb.M) ? ((g == k) ? 1.0 : 0.0) : ((g == pb.M && k < pb.M) ? pb.z1[k] : 0.0);
-        }
-        tile_fetch(q.li, pb.Linv + (size_t)kb * NB * NB, NB, tid);
-        return;
-    }
     const int u0 = panel * NRU;
     const bool qcat = pb.kind == WIN_QCAT;
     const int n_predm = pb.n_predm;
@@ -477,7 +445,6 @@ __device__ __forceinline__ void solve_rhs_fetch(const Prob& pb, int panel, int k
 }
 
 // X = B_kb + acc;  V_kb = Linv_kk X  (stored);  z / info sums of the block's rows
-template <bool INV>
 __device__ __forceinline__ void solve_tail(const Prob& pb, int panel, int kb, f64x4 (&acc)[SOLVE_NT], const SolveRhs& q,
                                            double* __restrict__ TL, double* __restrict__ TV, SolveSums& sums, int tid)
 {
@@ -508,10 +475,9 @@ __device__ __forceinline__ void solve_tail(const Prob& pb, int panel, int kb, f6
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int row = acc_row(wave, lane, r), col = acc_col(lane, n);
-            if (!INV) TV[row * LDV + col] = acc[n][r];
+            TV[row * LDV + col] = acc[n][r];
             V[(size_t)(kb * NB + row) * NR + col] = acc[n][r];
         }
-    if (INV) return;                                  // the inverse's rows carry no z / info sums (impute_gemm_kernel forms them)
     __syncthreads();
     // accumulate z and info for column cc over this block's rows RG rg .. RG rg + RG - 1
 #pragma unroll
@@ -524,10 +490,8 @@ __device__ __forceinline__ void solve_tail(const Prob& pb, int panel, int kb, f6
     }
 }
 
-// block row kb of one panel, all of it in this workgroup.  The products are summed in SOLVE_SPLIT interleaved classes
-// (j = g, g + SOLVE_SPLIT, ...) that are then added in class order -- the association the split form (below) needs for
-// its partial sums -- so that every driver of the solve returns the same bits.
-template <bool INV>
+// block row kb of one panel, all of it in this workgroup; the products are summed in SOLVE_SPLIT interleaved classes
+// (j = g, g + SOLVE_SPLIT, ...) that are then added in class order
 __device__ __forceinline__ void solve_row(const Prob& pb, int panel, int kb, double* __restrict__ TL, double* __restrict__ TV,
                                           SolveSums& sums, int tid)
 {
@@ -538,15 +502,15 @@ __device__ __forceinline__ void solve_row(const Prob& pb, int panel, int kb, dou
         f64x4 part[SOLVE_NT];
 #pragma unroll
         for (int n = 0; n < SOLVE_NT; n++) part[n] = f64x4{0.0, 0.0, 0.0, 0.0};
-        solve_products<INV>(pb, panel, kb, g, SOLVE_SPLIT, part, TL, TV, tid);
+        solve_products(pb, panel, kb, g, SOLVE_SPLIT, part, TL, TV, tid);
 #pragma unroll
         for (int n = 0; n < SOLVE_NT; n++)
 #pragma unroll
             for (int r = 0; r < 4; r++) acc[n][r] += part[n][r];
     }
     SolveRhs q;
-    solve_rhs_fetch<INV>(pb, panel, kb, q, tid);
-    solve_tail<INV>(pb, panel, kb, acc, q, TL, TV, sums, tid);
+    solve_rhs_fetch(pb, panel, kb, q, tid);
+    solve_tail(pb, panel, kb, acc, q, TL, TV, sums, tid);
 }
 
 // after the last block row: combine the per-thread sums and write z / info (or the QCAT correlation)
@@ -940,8 +904,8 @@ __global__ __launch_bounds__(256, 2) void factor_update_kernel(const Prob* __res
 static const size_t FACTOR_SMEM = (size_t)2 * NB * LDT * sizeof(double);
 
 // step 0 factors the first diagonal block; step s >= 1 builds block column s-1 and updates the trailing matrix.
-// max_npanel > 0: the update launch of block column c also carries block row c of the forward solve for every
-// right-hand-side panel (see the K6/K7 notes above); 0: factorisation only.
+// max_npanel > 0: update(c) also carries fin(c) and pre(c + 1) of the inverse's rows for every panel of [I | z1]
+// (ride_pre / ride_fin above); 0: factorisation only.
 void launch_factor_step(const Prob* d_probs, int n_prob, int step, int max_nblk, int max_npanel, int split, hipStream_t st)
 {
     if (n_prob <= 0 || step >= max_nblk) return;
@@ -979,12 +943,12 @@ __global__ __launch_bounds__(256) void solve_kernel(const Prob* __restrict__ pro
     const Prob& pb = probs[pm.x];
     const int tid = threadIdx.x;
     SolveSums sums{0.0, 0.0, 0.0};
-    for (int kb = 0; kb < pb.nblk; kb++) solve_row<false>(pb, pm.y, kb, TL, TV, sums, tid);
+    for (int kb = 0; kb < pb.nblk; kb++) solve_row(pb, pm.y, kb, TL, TV, sums, tid);
     solve_finish(pb, pm.y, red, sums, tid);
 }
 
-// What the update launches could not carry: the last block row of the windows that are as tall as the batch's tallest
-// one and, in the split form, the second half of the row before it.
+// What the update launches could not carry: fin of the last block row of the windows that are as tall as the batch's
+// tallest one (there is no update(max_nblk - 1)).
 __global__ __launch_bounds__(256, 2) void solve_last_kernel(const Prob* __restrict__ probs, const int2* __restrict__ panelmap,
                                                          int s_last, int split)
 {
