@@ -471,7 +471,7 @@ def test_full_size_dist_window_at_the_largest_real_window(ctx):
     info = np.abs(np.einsum("ij,ij->i", y, b21))
     assert relerr(r["info"], info) <= 1e-9
     assert np.max(np.abs(r["z"] - (y @ z1) / np.sqrt(info))) <= 1e-8
-    # the same window inside a batch of others (shared launches, fused solve rows) gives the same bits
+    # the same window inside a batch of others (shared launches, riding rows of the inverse, shared tiles of the closing product) gives the same bits
     small = dict(mode=0, geno_m=gm[:200], geno_u=gu[:300], pop_off=off, pop_wgt=None, z1=z1[:200])
     job = hotpath.Job([small, dict(mode=0, geno_m=gm, geno_u=gu, pop_off=off, pop_wgt=None, z1=z1), small], ctx=ctx)
     job.run()
