@@ -231,18 +231,29 @@ class Runner:
             tot[k] = (ms, n)
         return tot
 
-    def timed(self, steps, warmup):
+    def timed(self, steps, warmup, events_in_region=True):
+        """events_in_region: the library's per-stage HIP events are recorded during the timed steps (N = 1: the roofline
+        is measured live over the timed region).  With several ranks the events would only slow the rank that
+        records them (~0.04 ms per step, and the slowest rank is the result), so the stages are timed on a few
+        extra steps after the region instead."""
         res = []
         for _ in range(warmup):
             res = self.step()
-        self.profile(True)
+        self.profile(events_in_region)
         self.rig.barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
             res = self.step()
         self.rig.barrier()
         dt = time.perf_counter() - t0
-        st = self.stage_ms()
+        if events_in_region:
+            st = self.stage_ms()
+        else:
+            extra = 3
+            self.profile(True)
+            for _ in range(extra):
+                self.step()
+            st = {k: (ms * steps / extra, n * steps // extra) for k, (ms, n) in self.stage_ms().items()}
         self.profile(False)
         return dt, st, res
 
@@ -295,7 +306,7 @@ def run_impute(args, rig):
     runner = Runner(rig, window_descs(ch, my_wins, store, ld2, args.mode, rows_of), args.streams)
     work, stats = runner.work, runner.stats
 
-    dt, st, res = runner.timed(args.steps, args.warmup)
+    dt, st, res = runner.timed(args.steps, args.warmup, events_in_region=rig.world == 1)
     res = runner.results_in_order(res) if runner.jobs else []
     gram_ms, gram_n = st["gram"]
     tmax = rig.reduce(dt, "max")
@@ -452,6 +463,8 @@ def run_impute(args, rig):
                 "issued_flops_per_launch": stats["executed_flops"],
                 "issued_tflops": stats["executed_flops"] / avg_gram_s / 1e12 if avg_gram_s > 0 else 0.0,
                 "work_items": stats["items"], "partial_slab_bytes": stats["slab_bytes"],
+                "measured_on": "HIP events of every launch in the timed region" if rig.world == 1 else
+                               "HIP events of 3 extra steps on rank 0 after the timed region (no events inside it: they would slow rank 0 only)",
             },
             "roofline_solve": {
                 "kernel": "factor_*_kernel (Cholesky + rows of L^-1) + impute_gemm_kernel (v_mfma_f64_16x16x4_f64)", "bound": "mfma",
