@@ -350,6 +350,7 @@ __device__ __forceinline__ void epilogue_tile(const Prob& pb, int pair, int lds_
     const int mt = pb.Mp / TILE;        // number of measured row tiles
     const bool sym = (ti < mt);         // measured x measured tile (ti <= tj < mt)
     const int Mld = pb.Mld;
+    const bool need_a1 = !(pb.npanel > 0 && pb.status[3] != 0);      // status[3]: lambda_min(B11) > eps is certified
     const int tid = threadIdx.x;
     const bool weighted = pb.mode != 0;
     const bool lds_tables = weighted && P <= lds_pop_cap;
@@ -504,7 +505,9 @@ __device__ __forceinline__ void epilogue_tile(const Prob& pb, int pair, int lds_
                 const auto A0 = pb.A;
                 const auto A1 = pb.A + (size_t)Mld * Mld;
                 A0[(size_t)ri * Mld + rj] = v0; A0[(size_t)rj * Mld + ri] = v0;
-                A1[(size_t)ri * Mld + rj] = v1; A1[(size_t)rj * Mld + ri] = v1;
+                // the shifted twin is only ever read by its own factorisation, which the certificate (shift_cert_kernel,
+                // ahead of the Gram kernel on this stream) has already ruled out for most windows
+                if (need_a1) { A1[(size_t)ri * Mld + rj] = v1; A1[(size_t)rj * Mld + ri] = v1; }
                 if (pb.npanel > 0) {                              // working copy of B11 for the in-place factorisation
                     const auto W0 = pb.A + (size_t)4 * Mld * Mld;
                     W0[(size_t)ri * Mld + rj] = v0; W0[(size_t)rj * Mld + ri] = v0;
