@@ -182,6 +182,7 @@ struct gauss_job {
     hipEvent_t begin = nullptr;                            // recorded when gauss_job_run starts queuing
     hipEvent_t done = nullptr;                             // recorded after the result copies of gauss_job_run
     hipEvent_t ev_gram = nullptr, ev_side = nullptr;       // Gram kernel finished (main stream) / B21 written (side stream)
+    hipEvent_t ev_pack = nullptr, ev_rows = nullptr;       // operands packed (main) / row tables + certificate done (side)
     Prob* d_probs = nullptr;
     Item* d_items = nullptr;    int n_items = 0;
     int2* d_rowmap = nullptr;   int n_rows = 0;
@@ -706,6 +707,8 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
     HIPCHK(hipEventCreate(&job->done));
     HIPCHK(hipEventCreateWithFlags(&job->ev_gram, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&job->ev_side, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&job->ev_pack, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&job->ev_rows, hipEventDisableTiming));
 
     hipStream_t st = ctx->stream;
     // zero once: operand padding, B21 padding and the solve matrices rely on it
@@ -859,18 +862,28 @@ static int job_run(gauss_job* job, bool solve)
     HIPCHK(hipSetDevice(job->ctx->device));
     HIPCHK(hipEventRecord(job->begin, st));
     HIPCHK(hipMemsetAsync(job->d_status, 0, sizeof(int) * 4 * job->n, st));
+    // fused tail: the factorisation chain needs B11 only and the closing product is the first reader of B21, so B21's
+    // tiles of the epilogue (85 % of them) go to the side stream and run beside the chain; the row tables and the
+    // certificate, which only the epilogue and the factorisation read, go there too and slip in while the Gram kernel
+    // starts up
+    static const bool fused = !(getenv("GAUSS_FUSED_SOLVE") && atoi(getenv("GAUSS_FUSED_SOLVE")) == 0);
+    static const bool rows_aside = env_int("GAUSS_ROWS_ASIDE", 1) != 0;
+    hipStream_t side = (solve && fused && job->n_panels > 0 && job->n_tiles > job->n_tiles_b11) ? job->ctx->side : nullptr;
     prof_begin(job, 1, st);
     launch_pack_stats(job->d_probs, job->d_rowmap, job->n_rows, st);
-    launch_row_stats(job->d_probs, job->d_rowmap, job->n_rows, st);
-    if (solve && job->n_panels > 0) launch_shift_cert(job->d_probs, job->n, st);      // needs the row tables only
+    hipStream_t rs = (side && rows_aside) ? side : st;
+    if (rs != st) {
+        HIPCHK(hipEventRecord(job->ev_pack, st));
+        HIPCHK(hipStreamWaitEvent(rs, job->ev_pack, 0));
+    }
+    launch_row_stats(job->d_probs, job->d_rowmap, job->n_rows, rs);
+    if (solve && job->n_panels > 0) launch_shift_cert(job->d_probs, job->n, rs);      // needs the row tables only
+    if (rs != st) HIPCHK(hipEventRecord(job->ev_rows, rs));
     prof_end(job, st);
     prof_begin(job, 0, st);
     launch_gram(job->d_items, job->n_items, job->gram_i8, st);
     prof_end(job, st);
-    // fused tail: the factorisation chain needs B11 only and the closing product is the first reader of B21, so B21's
-    // tiles of the epilogue (85 % of them) go to the side stream and run beside the chain
-    static const bool fused = !(getenv("GAUSS_FUSED_SOLVE") && atoi(getenv("GAUSS_FUSED_SOLVE")) == 0);
-    hipStream_t side = (solve && fused && job->n_panels > 0 && job->n_tiles > job->n_tiles_b11) ? job->ctx->side : nullptr;
+    if (rs != st) HIPCHK(hipStreamWaitEvent(st, job->ev_rows, 0));
     if (side) {
         HIPCHK(hipEventRecord(job->ev_gram, st));
         HIPCHK(hipStreamWaitEvent(side, job->ev_gram, 0));
@@ -1061,6 +1074,8 @@ static void job_free(gauss_job* job)
     if (job->done) hipEventDestroy(job->done);
     if (job->ev_gram) hipEventDestroy(job->ev_gram);
     if (job->ev_side) hipEventDestroy(job->ev_side);
+    if (job->ev_pack) hipEventDestroy(job->ev_pack);
+    if (job->ev_rows) hipEventDestroy(job->ev_rows);
     delete job;
 }
 

@@ -582,3 +582,35 @@ def test_tail_block_edges(ctx, mode):
         else:
             assert got["num_eig"] == want["num_eig"], shape
             assert np.max(np.abs(got["r"] - want["r"])) <= R_TOL, shape
+
+
+def test_side_stream_does_not_change_results(monkeypatch):
+    """A context created with GAUSS_SIDE_STREAM=0 runs every kernel of a job on one stream; the default context runs
+    B21's epilogue tiles, the row tables and the certificate on its side stream beside the main one.  Same windows,
+    same bits -- including a re-run of the same job, whose side-stream work must not overtake the previous run."""
+    p = small_panel(n_snp=460, scale=0.03, seed=21)
+    rng = np.random.default_rng(5)
+    wins = []
+    for k, (m, u) in enumerate([(210, 150), (90, 260), (140, 40)]):
+        idx = rng.permutation(p["G"].shape[0])
+        wins.append(dict(mode=k % 2, geno_m=np.ascontiguousarray(p["G"][np.sort(idx[:m])]),
+                         geno_u=np.ascontiguousarray(p["G"][np.sort(idx[m:m + u])]), pop_off=p["off"], pop_wgt=p["w"],
+                         z1=rng.standard_normal(m)))
+    out = {}
+    for name, val in (("two", "1"), ("one", "0")):
+        monkeypatch.setenv("GAUSS_SIDE_STREAM", val)
+        c = hotpath.Context(0)
+        job = hotpath.Job(wins, ctx=c)
+        runs = []
+        for _ in range(3):
+            job.run()
+            runs.append(job.fetch())
+        job.close()
+        c.close()
+        for r in runs[1:]:
+            for a, b in zip(runs[0], r):
+                assert np.array_equal(a["z"], b["z"]) and np.array_equal(a["info"], b["info"])
+        out[name] = runs[0]
+    for a, b in zip(out["two"], out["one"]):
+        assert a["status"] == b["status"] == 0
+        assert np.array_equal(a["z"], b["z"]) and np.array_equal(a["info"], b["info"])
