@@ -196,6 +196,7 @@ struct gauss_job {
     int max_nblk = 0;
     int max_npanel = 0;                                    // most solve panels of any one window
     int solve_split = 0;                                   // rows of the inverse with at least this many products are cut (0: none)
+    int own_panel = 0;                                     // 1: small job, the update launches form their own panel tiles (no panel launches)
     int max_pop = 1;
     int gram_i8 = 0;
     int* d_status = nullptr;                               // [n][4]
@@ -643,6 +644,13 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
         // products on is what keeps every riding workgroup shorter than the diagonal tile's (36 windows, factorisation
         // with riding rows: never 1.72 ms, >= 8 1.70, >= 4 1.49, >= 2 1.46 before the pre / fin form, 1.31 with it; factorisation alone 1.10).
         const int thr = env_int("GAUSS_SOLVE_SPLIT_MIN", 2);               // read per job: tests drive both forms
+        // few windows: every launch of the factorisation is a latency-bound link of a chain -- drop the panel launches
+        // (k_solve.hip, factor_update_kernel own_panel); same bits either way.  Factorisation + riding rows, with /
+        // without panel launches: 5 windows 0.65 / 0.58 ms, 9 windows 0.82 / 0.78, 18 windows 0.87 / 0.84, 36 windows
+        // 1.31 / 1.42 (the repeated panel products start to cost workgroup slots)
+        int n_solve = 0;
+        for (int i = 0; i < job->n; i++) n_solve += job->plans[i].p.npanel > 0 ? 1 : 0;
+        job->own_panel = (n_solve > 0 && n_solve <= env_int("GAUSS_OWN_PANEL_MAX_WINDOWS", 20)) ? 1 : 0;
         job->solve_split = job->n_panels > 0 ? thr : 0;
     }
     for (int i = 0; i < job->n; i++) {
@@ -906,7 +914,8 @@ static int job_run(gauss_job* job, bool solve)
         // "solve" = closing row + product + finish
         prof_begin(job, 3, st);
         for (int s = 0; s < job->max_nblk; s++)
-            launch_factor_step(job->d_probs, job->n, s, job->max_nblk, fused ? job->max_npanel : 0, job->solve_split, st);
+            launch_factor_step(job->d_probs, job->n, s, job->max_nblk, fused ? job->max_npanel : 0, job->solve_split,
+                               job->own_panel, st);
         prof_end(job, st);
         prof_begin(job, 4, st);
         if (fused) {
@@ -956,7 +965,7 @@ static int job_clamp_window(gauss_job* job, int i, int* status_bits)
     HIPCHK(hipMemcpyAsync(p.A + 4 * n * n, p.A, sizeof(double) * n * n, hipMemcpyDeviceToDevice, st));   // W0 = clamped B11
     for (int s = 0; s < p.nblk; s++) {
         // launch over all problems would redo the others; use a single-problem launch instead
-        launch_factor_step(job->d_probs + i, 1, s, p.nblk, 0, 0, st);
+        launch_factor_step(job->d_probs + i, 1, s, p.nblk, 0, 0, 0, st);
     }
     launch_solve(job->d_probs, d_pm.as<int2>(), (int)pm.size(), st);
     HIPCHK(hipGetLastError());

@@ -831,7 +831,8 @@ __global__ __launch_bounds__(256) void factor_panel_kernel(const Prob* __restric
 }
 
 // update(s): grid.x = T (T + 1) / 2 with T = max_nblk - 1 - s; x = 0 is tile (s+1, s+1)
-__global__ __launch_bounds__(256, 2) void factor_update_kernel(const Prob* __restrict__ probs, int s, int T, int n_tri, int split, int n_ride)
+__global__ __launch_bounds__(256, 2) void factor_update_kernel(const Prob* __restrict__ probs, int s, int T, int n_tri, int split, int n_ride,
+                                                               int own_panel)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* TA = smem;                 // L[k][s]            | D (next diagonal tile)
@@ -868,16 +869,55 @@ __global__ __launch_bounds__(256, 2) void factor_update_kernel(const Prob* __res
     const auto W = factor_work(pb, mat);
     const auto Lm = pb.A + (size_t)(2 + mat) * ld * ld;
     TileRegs ra, rb;
-    tile_fetch(ra, Lm + (size_t)k * NB * ld + (size_t)s * NB, ld, tid);
-    if (k != j) tile_fetch(rb, Lm + (size_t)j * NB * ld + (size_t)s * NB, ld, tid);
     f64x4 acc[4];
+    if (own_panel) {
+        // Small jobs: no panel launch.  This workgroup forms the two tiles of block column s it needs itself,
+        // L[k][s] = W[k][s] Linv_ss^T and L[j][s] = W[j][s] Linv_ss^T (the products panel(s) does, same arithmetic,
+        // done again by every workgroup that needs them); the workgroups of the first trailing column (j = s + 1)
+        // store theirs for the rows of the inverse and for later steps' readers.  One launch and one round trip of
+        // tiles between CUs less per block step; the extra products are noise on a latency-bound job.
+        TileRegs rli;
+        tile_fetch(ra, W + (size_t)k * NB * ld + (size_t)s * NB, ld, tid);
+        if (k != j) tile_fetch(rb, W + (size_t)j * NB * ld + (size_t)s * NB, ld, tid);
+        tile_fetch(rli, pb.Linv + ((size_t)mat * nb + s) * NB * NB, NB, tid);
 #pragma unroll
-    for (int n = 0; n < 4; n++)
+        for (int n = 0; n < 4; n++)
 #pragma unroll
-        for (int r = 0; r < 4; r++)
-            acc[n][r] = W[(size_t)(k * NB + acc_row(wave, lane, r)) * ld + j * NB + acc_col(lane, n)];
-    tile_commit<LDT>(TA, ra, tid);
-    if (k != j) tile_commit<LDT>(TB, rb, tid);
+            for (int r = 0; r < 4; r++)
+                acc[n][r] = W[(size_t)(k * NB + acc_row(wave, lane, r)) * ld + j * NB + acc_col(lane, n)];
+        tile_commit<LDT>(TA, ra, tid);
+        tile_commit<LDT>(TB, rli, tid);
+        __syncthreads();
+        f64x4 lk[4], lj[4];
+#pragma unroll
+        for (int n = 0; n < 4; n++) { lk[n] = f64x4{0.0, 0.0, 0.0, 0.0}; lj[n] = f64x4{0.0, 0.0, 0.0, 0.0}; }
+        mfma_nt<4, false>(lk, TA, TB, wave, lane);
+        if (k != j) {
+            __syncthreads();
+            tile_commit<LDT>(TA, rb, tid);
+            __syncthreads();
+            mfma_nt<4, false>(lj, TA, TB, wave, lane);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int n = 0; n < 4; n++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                TA[acc_row(wave, lane, r) * LDT + acc_col(lane, n)] = lk[n][r];
+                if (k != j) TB[acc_row(wave, lane, r) * LDT + acc_col(lane, n)] = lj[n][r];
+                if (jj == 0) Lm[(size_t)(k * NB + acc_row(wave, lane, r)) * ld + s * NB + acc_col(lane, n)] = lk[n][r];
+            }
+    } else {
+        tile_fetch(ra, Lm + (size_t)k * NB * ld + (size_t)s * NB, ld, tid);
+        if (k != j) tile_fetch(rb, Lm + (size_t)j * NB * ld + (size_t)s * NB, ld, tid);
+#pragma unroll
+        for (int n = 0; n < 4; n++)
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                acc[n][r] = W[(size_t)(k * NB + acc_row(wave, lane, r)) * ld + j * NB + acc_col(lane, n)];
+        tile_commit<LDT>(TA, ra, tid);
+        if (k != j) tile_commit<LDT>(TB, rb, tid);
+    }
     __syncthreads();
     mfma_nt<4, true>(acc, TA, (k != j) ? TB : TA, wave, lane);       // W[k][j] -= L[k][s] L[j][s]^T
     if (!next_diag) {
@@ -906,7 +946,7 @@ static const size_t FACTOR_SMEM = (size_t)2 * NB * LDT * sizeof(double);
 // step 0 factors the first diagonal block; step s >= 1 builds block column s-1 and updates the trailing matrix.
 // max_npanel > 0: update(c) also carries fin(c) and pre(c + 1) of the inverse's rows for every panel of [I | z1]
 // (ride_pre / ride_fin above); 0: factorisation only.
-void launch_factor_step(const Prob* d_probs, int n_prob, int step, int max_nblk, int max_npanel, int split, hipStream_t st)
+void launch_factor_step(const Prob* d_probs, int n_prob, int step, int max_nblk, int max_npanel, int split, int own_panel, hipStream_t st)
 {
     if (n_prob <= 0 || step >= max_nblk) return;
     const size_t upd_smem = std::max(FACTOR_SMEM, SOLVE_SMEM);
@@ -926,10 +966,11 @@ void launch_factor_step(const Prob* d_probs, int n_prob, int step, int max_nblk,
     const int n_tri = T * (T + 1) / 2;
     const bool fuse = max_npanel > 0;
     const int n_comb = 0, n_ride = fuse ? max_npanel * (SOLVE_SPLIT + 1) : 0;
-    hipLaunchKernelGGL(factor_panel_kernel, dim3(T + n_comb, n_prob * 2), dim3(256), FACTOR_SMEM, st,
-                       d_probs, s, T, split, n_comb);
+    if (!own_panel)
+        hipLaunchKernelGGL(factor_panel_kernel, dim3(T + n_comb, n_prob * 2), dim3(256), FACTOR_SMEM, st,
+                           d_probs, s, T, split, n_comb);
     hipLaunchKernelGGL(factor_update_kernel, dim3(n_tri + n_ride, n_prob * 2), dim3(256),
-                       upd_smem, st, d_probs, s, T, n_tri, split, n_ride);
+                       upd_smem, st, d_probs, s, T, n_tri, split, n_ride, own_panel);
 }
 
 __global__ __launch_bounds__(256) void solve_kernel(const Prob* __restrict__ probs,

@@ -455,9 +455,9 @@ def test_ld_and_gene_batches_over_row_stores_equal_the_byte_calls(ctx, mode):
 
 @pytest.mark.parametrize("mode", [0, 1])
 def test_solve_forms_agree(ctx, mode, monkeypatch):
-    """The fused path (k_solve.hip) has job-size dependent forms of the same arithmetic: rows of the inverse riding
-    whole in the factorisation's update launches or cut into partial sums + combine, and the closing product in tiles
-    of 128 or 64 right-hand sides.  The same windows through every combination: each within 1e-8 of the oracle and
+    """The fused path (k_solve.hip) has job-size dependent forms of the same arithmetic: the early products of a row of
+    the inverse in one workgroup or one per class, the factorisation with or without panel launches, and the closing
+    product in tiles of 128 or 64 right-hand sides.  The same windows through every combination: each within 1e-8 of the oracle and
     bit-identical to the others (every form sums in the same order)."""
     p = small_panel(n_snp=420, scale=0.03, seed=5)
     G, off = p["G"], p["off"]
@@ -468,9 +468,9 @@ def test_solve_forms_agree(ctx, mode, monkeypatch):
         gm, gu = np.ascontiguousarray(G[np.sort(idx[:m])]), np.ascontiguousarray(G[np.sort(idx[m:m + u])])
         wins.append(dict(mode=mode, geno_m=gm, geno_u=gu, pop_off=off, pop_wgt=p["w"], z1=rng.standard_normal(m) * 2))
     out = {}
-    for name, env in (("split", {"GAUSS_SOLVE_SPLIT_MIN": "2", "GAUSS_GEMM_SMALL_TILES": "1000000"}),
-                      ("rows", {"GAUSS_SOLVE_SPLIT_MIN": "0", "GAUSS_GEMM_SMALL_TILES": "0"}),
-                      ("mixed", {"GAUSS_SOLVE_SPLIT_MIN": "3", "GAUSS_GEMM_SMALL_TILES": "0"})):
+    for name, env in (("split", {"GAUSS_SOLVE_SPLIT_MIN": "2", "GAUSS_GEMM_SMALL_TILES": "1000000", "GAUSS_OWN_PANEL_MAX_WINDOWS": "20"}),
+                      ("rows", {"GAUSS_SOLVE_SPLIT_MIN": "0", "GAUSS_GEMM_SMALL_TILES": "0", "GAUSS_OWN_PANEL_MAX_WINDOWS": "0"}),
+                      ("mixed", {"GAUSS_SOLVE_SPLIT_MIN": "3", "GAUSS_GEMM_SMALL_TILES": "0", "GAUSS_OWN_PANEL_MAX_WINDOWS": "0"})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         job = hotpath.Job(wins, ctx=ctx)
