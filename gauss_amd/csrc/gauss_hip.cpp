@@ -875,7 +875,9 @@ static int job_run(gauss_job* job, bool solve)
     // certificate, which only the epilogue and the factorisation read, go there too and slip in while the Gram kernel
     // starts up
     static const bool fused = !(getenv("GAUSS_FUSED_SOLVE") && atoi(getenv("GAUSS_FUSED_SOLVE")) == 0);
-    static const bool rows_aside = env_int("GAUSS_ROWS_ASIDE", 1) != 0;
+    // (off by default: worth 0.04 ms on an 8-rank share, nothing on 36 windows -- the Gram kernel gets that much slower --
+    // and one profiled launch in a hundred saw the two small kernels and the Gram kernel's start tangle for 28 ms)
+    static const bool rows_aside = env_int("GAUSS_ROWS_ASIDE", 0) != 0;
     hipStream_t side = (solve && fused && job->n_panels > 0 && job->n_tiles > job->n_tiles_b11) ? job->ctx->side : nullptr;
     prof_begin(job, 1, st);
     launch_pack_stats(job->d_probs, job->d_rowmap, job->n_rows, st);
