@@ -145,6 +145,11 @@ struct Args {                       // Arguments, gauss.h:18-69 with the default
     double af1_cutoff = 0.01;
     int min_num_measured_snp = 10, min_num_unmeasured_snp = 10;
     std::shared_ptr<PackedPanel> pk;   // set when reference_data_file is a packed panel (packed_panel.h)
+    // dist / distmix on a packed panel: a panel SNP that no study SNP shares its position with and that lies in a wing
+    // would enter the map as type 0 (gauss.cpp:373-385), pass the AF filter and then be dropped by the partition
+    // (dist.cpp:132-140 imputes type-0 SNPs of the prediction window only; the output is cut to it, dist.cpp:91-93) --
+    // nothing ever reads it, so it is not entered at all (about half of an extended window's panel SNPs)
+    bool drop_wing_unmeasured = false;
     int total_num_categ = 6;
     double categ_cor_cutoff = 0.8;
     int denorm_norm_w = 3;
@@ -411,6 +416,10 @@ static int ReadReferenceIndex(SnpMap& m, const Args& a, bool All)
         }
         for (int64_t i = i0; i < i1; i++) {
             const PkSnp& s = pk.snp(i);
+            if (a.drop_wing_unmeasured && !All && (s.bp < a.start_bp || s.bp > a.end_bp)) {
+                auto pos = m.lower_bound(MapKey{s.chr, s.bp, std::string(), std::string()});
+                if (pos == m.end() || pos->first.chr != s.chr || pos->first.bp != s.bp) continue;
+            }
             if (merge_index_entry(m, a, All, pk.str(s.rsid), s.chr, s.bp, pk.str(s.a1), pk.str(s.a2), i)) return -1;
         }
         return 0;
@@ -1233,6 +1242,7 @@ int gauss_host_prepare(int kind, int chr, int64_t start_bp, int64_t end_bp, int6
         std::string err;
         a.pk = open_packed_shared(a.reference_data_file, err);
         if (!a.pk) return herr("%s", err.c_str());
+        a.drop_wing_unmeasured = (kind == GAUSS_KIND_DIST || kind == GAUSS_KIND_DISTMIX) && !getenv("GAUSS_KEEP_WING_SNPS");
     }
     a.af1_cutoff = std::isnan(af1_cutoff) ? (kind == GAUSS_KIND_QCAT ? 0.05 : 0.01) : af1_cutoff;   // dist.cpp:53-57, qcat.cpp:53-57
     const bool mix = (kind == GAUSS_KIND_COMPUTELD || kind == GAUSS_KIND_DISTMIX || kind == GAUSS_KIND_JEPEGMIX ||

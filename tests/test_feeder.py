@@ -252,9 +252,19 @@ def packed(study):
     return out
 
 
-def _same_prepared(a, b):
+def _same_prepared(a, b, window=None):
+    """window = (start_bp, end_bp): `b` is the packed feeder of dist / distmix, which does not enter panel SNPs that no
+    study SNP shares a position with and that lie in a wing (type 0 outside the prediction window: the partition drops
+    them, dist.cpp:132-140, and the output is cut to the window, dist.cpp:91-93) -- `a`'s SNP list is compared without
+    them and its row numbers are renumbered accordingly."""
     da, db = a.snps(), b.snps()
     assert list(da.columns) == list(db.columns)
+    rows_a = np.arange(len(da))
+    if window is not None:
+        keep = (da["type"].to_numpy() != 0) | ((da["bp"].to_numpy() >= window[0]) & (da["bp"].to_numpy() <= window[1]))
+        assert keep.sum() < len(da)                    # the wings do hold such SNPs
+        rows_a = np.cumsum(keep) - 1                   # old row -> row among the kept ones
+        da = da[keep].reset_index(drop=True)
     for c in da.columns:
         if c == "fpos":
             continue                                   # virtual file offset vs row number
@@ -263,7 +273,7 @@ def _same_prepared(a, b):
         else:
             assert list(da[c]) == list(db[c]), c
     assert (a.M, a.U, a.N, a.P, a.n_gene) == (b.M, b.U, b.N, b.P, b.n_gene)
-    assert np.array_equal(a.measured_rows(), b.measured_rows()) and np.array_equal(a.unmeasured_rows(), b.unmeasured_rows())
+    assert np.array_equal(rows_a[a.measured_rows()], b.measured_rows()) and np.array_equal(rows_a[a.unmeasured_rows()], b.unmeasured_rows())
     assert np.array_equal(a.geno_m(), b.geno_m()) and np.array_equal(a.geno_u(), b.geno_u())
     assert np.array_equal(a.z1(), b.z1()) and np.array_equal(a.pop_off(), b.pop_off())
     assert np.array_equal(a.pop_wgt(), b.pop_wgt()) and np.array_equal(a.gene_off(), b.gene_off())
@@ -280,7 +290,7 @@ def test_packed_panel_feeder_equals_text_feeder(study, packed, kind):
               pop_wgt_df=WGT if mix else None, input_file=inp, reference_index_file=idx, reference_pop_desc_file=desc)
     a = api.Prepared(k, reference_data_file=dat, **kw)
     b = api.Prepared(k, reference_data_file=packed, **dict(kw, reference_index_file="(ignored)"))
-    _same_prepared(a, b)
+    _same_prepared(a, b, window=(kw["start_bp"], kw["end_bp"]) if kind in ("DIST", "DISTMIX") else None)
     if kind in ("DIST", "DISTMIX", "QCAT", "QCATMIX", "PREP_QCAT"):
         d = b.window_desc()
         assert d.geno_format == 1 and bool(d.rows_m) and bool(d.pop_src_off) and d.ld % 16 == 0
@@ -442,7 +452,9 @@ def test_feeder_fuzz_against_python_feeder(tmp_path, seed):
         pr = api.Prepared(api.KIND_DISTMIX if mix else api.KIND_DIST, chr=22, start_bp=lo, end_bp=hi, wing_size=wing,
                           study_pop=None if mix else "EUR", pop_wgt_df=wgt, input_file=inp, reference_index_file=idx,
                           reference_data_file=data, reference_pop_desc_file=desc, af1_cutoff=cutoff)
-        _check_prepared(pr, vec, meas, unme, mix)
+        # the packed feeder does not enter wing SNPs that nothing reads (type 0 outside the prediction window)
+        seen = vec if data == dat else [s for s in vec if s.type != 0 or lo <= s.bp <= hi]
+        _check_prepared(pr, seen, meas, unme, mix)
         assert np.array_equal(pr.pop_off(), fp._selected_off(ref_pops, flags))
         pr.close()
 
