@@ -226,7 +226,10 @@ int gauss_host_prepare(int kind, int chr, int64_t start_bp, int64_t end_bp, int6
                        const char* reference_pop_desc_file, double af1_cutoff,
                        gauss_prepared** out);
 /* SNP list after the AF filter (snp_vec of the reference), columns:
- * rsid chr bp a1 a2 af1 z info type fpos geneid */
+ * rsid chr bp a1 a2 af1 z info type fpos geneid
+ * dist / distmix on a PACKED panel: wing SNPs of the panel that no study SNP shares a position with are not listed
+ * (the reference enters them as type 0, filters them, and then neither imputes nor prints them: dist.cpp:91-93,132-140;
+ * GAUSS_KEEP_WING_SNPS=1 lists them as the text feeder does).  The window's result table is the same either way. */
 const gauss_table* gauss_prepared_snps(const gauss_prepared* p);
 int gauss_prepared_counts(const gauss_prepared* p, int* n_measured, int* n_unmeasured,
                           int* n_samples, int* n_pop, int* n_gene);
