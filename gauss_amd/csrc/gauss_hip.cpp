@@ -201,8 +201,15 @@ struct gauss_job {
     int gram_i8 = 0;
     int* d_status = nullptr;                               // [n][4]
     double* d_results = nullptr; size_t n_results = 0;     // z then info per problem
-    double* h_results = nullptr;                           // inside h_pin
-    int* h_status = nullptr;                               // inside h_pin
+    // Two runs may be in flight: run k + 1 can be queued before run k has been fetched, so that the host's share of a
+    // step (waking up, copying results out, queuing the next run) overlaps GPU work.  Result mirrors and completion
+    // events alternate by run parity; gauss_job_fetch collects the oldest run that has not been fetched.
+    double* h_res2[2] = {nullptr, nullptr};                // inside h_pin
+    int* h_st2[2] = {nullptr, nullptr};                    // inside h_pin
+    hipEvent_t done2[2] = {nullptr, nullptr};
+    unsigned run_seq = 0, fetch_seq = 0;
+    double* h_results = nullptr;                           // mirror of the run being fetched
+    int* h_status = nullptr;
     bool prof = false;
     std::vector<ProfSlot> slots;
     double prof_ms[5] = {0, 0, 0, 0, 0};
@@ -707,12 +714,18 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
     // one pinned block for the table image and the result mirrors: the table upload is then a true asynchronous
     // DMA and a job over resident rows is created without waiting for the stream (another job may be running on it)
     const size_t pin_tab = rup(job->tab_bytes, 256), pin_res = rup(sizeof(double) * std::max<size_t>(res, 1), 256);
-    e = ctx_pin_alloc(ctx, pin_tab + pin_res + sizeof(int) * 4 * job->n, (void**)&job->h_pin);
-    if (e != hipSuccess) { job->h_pin = nullptr; return fail(GAUSS_E_NOMEM, "hipHostMalloc(%zu bytes) failed", pin_tab + pin_res); }
-    job->h_results = (double*)(job->h_pin + pin_tab);
-    job->h_status = (int*)(job->h_pin + pin_tab + pin_res);
+    const size_t pin_st = rup(sizeof(int) * 4 * job->n, 256);
+    e = ctx_pin_alloc(ctx, pin_tab + 2 * (pin_res + pin_st), (void**)&job->h_pin);
+    if (e != hipSuccess) { job->h_pin = nullptr; return fail(GAUSS_E_NOMEM, "hipHostMalloc(%zu bytes) failed", pin_tab + 2 * pin_res); }
+    for (int k = 0; k < 2; k++) {
+        job->h_res2[k] = (double*)(job->h_pin + pin_tab + k * (pin_res + pin_st));
+        job->h_st2[k] = (int*)(job->h_pin + pin_tab + k * (pin_res + pin_st) + pin_res);
+        HIPCHK(hipEventCreate(&job->done2[k]));
+    }
+    job->h_results = job->h_res2[0];
+    job->h_status = job->h_st2[0];
+    job->done = job->done2[0];
     HIPCHK(hipEventCreate(&job->begin));
-    HIPCHK(hipEventCreate(&job->done));
     HIPCHK(hipEventCreateWithFlags(&job->ev_gram, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&job->ev_side, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&job->ev_pack, hipEventDisableTiming));
@@ -868,6 +881,8 @@ static int job_run(gauss_job* job, bool solve)
 {
     hipStream_t st = job->ctx->stream;
     HIPCHK(hipSetDevice(job->ctx->device));
+    if (job->run_seq - job->fetch_seq >= 2u)
+        return fail(GAUSS_E_INVALID, "gauss_job_run: two runs of this job are in flight already; fetch one first");
     HIPCHK(hipEventRecord(job->begin, st));
     HIPCHK(hipMemsetAsync(job->d_status, 0, sizeof(int) * 4 * job->n, st));
     // fused tail: the factorisation chain needs B11 only and the closing product is the first reader of B21, so B21's
@@ -930,10 +945,13 @@ static int job_run(gauss_job* job, bool solve)
     HIPCHK(hipGetLastError());
     // the result mirrors travel with the run, so that gauss_job_fetch waits for THIS job only (an event), not for
     // whatever else has been queued on the stream since (the next job of a pipeline)
+    const int par = (int)(job->run_seq & 1u);
     if (job->n_results)
-        HIPCHK(hipMemcpyAsync(job->h_results, job->d_results, sizeof(double) * job->n_results, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(job->h_status, job->d_status, sizeof(int) * 4 * job->n, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipEventRecord(job->done, st));
+        HIPCHK(hipMemcpyAsync(job->h_res2[par], job->d_results, sizeof(double) * job->n_results, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(job->h_st2[par], job->d_status, sizeof(int) * 4 * job->n, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipEventRecord(job->done2[par], st));
+    job->done = job->done2[par];
+    job->run_seq++;
     job->ran = true;
     return GAUSS_OK;
 }
@@ -1014,10 +1032,26 @@ static int job_count_small_eigs(gauss_job* job, int i, int* num_eig)
 
 static int job_fetch(gauss_job* job)
 {
-    if (!job->ran) return fail(GAUSS_E_INVALID, "gauss_job_fetch before gauss_job_run");
+    if (!job->ran || job->fetch_seq == job->run_seq) return fail(GAUSS_E_INVALID, "gauss_job_fetch: no run of this job is waiting to be fetched");
     hipStream_t st = job->ctx->stream;
     HIPCHK(hipSetDevice(job->ctx->device));
-    HIPCHK(hipEventSynchronize(job->done));
+    const int par = (int)(job->fetch_seq & 1u);
+    job->h_results = job->h_res2[par];
+    job->h_status = job->h_st2[par];
+    HIPCHK(hipEventSynchronize(job->done2[par]));
+    // With a later run of the job already queued, anything that reads the job's DEVICE buffers (matrix exports, the
+    // clamp path, the eigenvalue count) first lets that run finish: the job's inputs do not change between runs, so
+    // what it leaves on the device is what the fetched run left.
+    if (job->run_seq - job->fetch_seq > 1u) {
+        bool device_reads = false;
+        for (int i = 0; i < job->n && !device_reads; i++) {
+            const Plan& pl = job->plans[i];
+            device_reads = pl.out_b11 || pl.out_b21 || (pl.out_ld_user && pl.out_ld_count) ||
+                           job->h_status[4 * i + 0] || job->h_status[4 * i + 1];
+        }
+        if (device_reads) HIPCHK(hipEventSynchronize(job->done));
+    }
+    job->fetch_seq++;
     for (int i = 0; i < job->n; i++) {
         Plan& pl = job->plans[i];
         const Prob& p = pl.p;
@@ -1075,6 +1109,8 @@ static void job_free(gauss_job* job)
 {
     if (!job) return;
     if (job->ctx) hipSetDevice(job->ctx->device);
+    // runs that were queued and never fetched: their result copies target this job's pinned block
+    if (job->run_seq != job->fetch_seq && job->done) (void)hipEventSynchronize(job->done);
     for (ProfSlot& s : job->slots) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
     if (job->ctx) {
         ctx_dev_release(job->ctx, job->d_ws);
@@ -1082,7 +1118,7 @@ static void job_free(gauss_job* job)
         ctx_pin_release(job->ctx, job->h_pin);
     }
     if (job->begin) hipEventDestroy(job->begin);
-    if (job->done) hipEventDestroy(job->done);
+    for (int k = 0; k < 2; k++) if (job->done2[k]) hipEventDestroy(job->done2[k]);
     if (job->ev_gram) hipEventDestroy(job->ev_gram);
     if (job->ev_side) hipEventDestroy(job->ev_side);
     if (job->ev_pack) hipEventDestroy(job->ev_pack);

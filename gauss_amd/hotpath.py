@@ -400,7 +400,10 @@ class Job:
 
     def close(self):
         if self.handle:
-            self.ctx.lib.gauss_job_destroy(self.handle)
+            # a job must go before its context: if the context has been closed already (interpreter shutdown destroys
+            # objects in no particular order) the job's device blocks went with it and the handle must not be touched
+            if getattr(self.ctx, "handle", None):
+                self.ctx.lib.gauss_job_destroy(self.handle)
             self.handle = None
 
     def __del__(self):

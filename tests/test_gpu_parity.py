@@ -614,3 +614,38 @@ def test_side_stream_does_not_change_results(monkeypatch):
     for a, b in zip(out["two"], out["one"]):
         assert a["status"] == b["status"] == 0
         assert np.array_equal(a["z"], b["z"]) and np.array_equal(a["info"], b["info"])
+
+
+def test_two_runs_of_a_job_in_flight(ctx):
+    """gauss_job_run may be called again before the previous run has been fetched (two result mirrors per job): the
+    fetches then return the runs in order, with the bits a run-fetch-run-fetch sequence gives -- also for a job whose
+    fetch reads device buffers (matrix export) -- and a third run without a fetch is refused."""
+    p = small_panel(n_snp=380, scale=0.03, seed=29)
+    rng = np.random.default_rng(8)
+    wins = []
+    for k, (m, u) in enumerate([(170, 120), (66, 190)]):
+        idx = rng.permutation(p["G"].shape[0])
+        wins.append(dict(mode=k % 2, geno_m=np.ascontiguousarray(p["G"][np.sort(idx[:m])]),
+                         geno_u=np.ascontiguousarray(p["G"][np.sort(idx[m:m + u])]), pop_off=p["off"], pop_wgt=p["w"],
+                         z1=rng.standard_normal(m)))
+    for want_mats in (False, True):
+        job = hotpath.Job(wins, ctx=ctx, want_mats=want_mats)
+        job.run()
+        ref = job.fetch()
+        job.run()
+        job.run()
+        with pytest.raises(Exception) as ei:
+            job.run()
+        assert "in flight" in str(ei.value)
+        a = job.fetch()
+        job.run()
+        b = job.fetch()
+        c = job.fetch()
+        with pytest.raises(Exception):
+            job.fetch()
+        for got in (a, b, c):
+            for r, w in zip(got, ref):
+                assert np.array_equal(r["z"], w["z"]) and np.array_equal(r["info"], w["info"])
+                if want_mats:
+                    assert np.array_equal(r["b11"], w["b11"]) and np.array_equal(r["b21"], w["b21"])
+        job.close()
