@@ -202,10 +202,13 @@ int gauss_gram_counts(gauss_ctx* ctx, const uint8_t* geno, int n_snp, int n_samp
  * All windows of a job run through the same batched launches. */
 int gauss_job_create(gauss_ctx* ctx, const gauss_window_desc* wins, int n_win, int on_device,
                      gauss_job** out_job);
-/* Enqueue one full pass (pack -> Gram -> LD epilogue -> factor -> solve) on the job's stream. */
+/* Enqueue one full pass (pack -> Gram -> LD epilogue -> factorisation + inverse factor -> closing product) on the
+ * context's streams; returns at once.  Up to TWO runs of a job may be in flight: a second gauss_job_run before the first
+ * has been fetched is allowed (the job keeps two result mirrors), a third is refused (GAUSS_E_INVALID). */
 int gauss_job_run(gauss_job* job);
-/* Wait for the last run and copy z / info / status (and optional b11/b21) to the host pointers
- * of each window descriptor. */
+/* Wait for the OLDEST run that has not been fetched and copy its z / info / status (and optional b11/b21) to the host
+ * pointers of each window descriptor.  run, fetch, run, fetch ... behaves as before; run, run, fetch, run, fetch ...
+ * keeps the GPU busy while the host handles the previous run's results. */
 int gauss_job_fetch(gauss_job* job);
 void gauss_job_destroy(gauss_job* job);
 /* Device time from the moment `first` started to run until `last` had delivered its results (HIP events on the
