@@ -1,13 +1,15 @@
-// K5 blocked Cholesky (fp64), K6/K7 forward solve + imputation finalize -- fp64 matrix cores.
+// K5 blocked Cholesky (fp64), K6/K7 inverse factor + imputation product -- fp64 matrix cores.
 //
 // Replaces  MakePosDef + InvMat + per-SNP MpMatMat  of run_dist / run_distmix
 // (dist.cpp:181-202, distmix.cpp:203-228, util.cpp:262-264,298-318):
 //     B11 = L L^T                       (B11 already carries lambda on its diagonal)
-//     v_u = L^-1 b21_u^T ,  y = L^-1 Z1
-//     z_u = v_u . y   ( = b21_u B11^-1 Z1 )          dist.cpp:193-194
-//     info_u = v_u . v_u ( = b21_u B11^-1 b12_u )    dist.cpp:197-198
+//     [X | y] = L^-1 [I | Z1]           (rows ride in the factorisation's launches)
+//     w_u = X b21_u^T                   (one product W = B21 X^T, impute_gemm_kernel)
+//     z_u = w_u . y   ( = b21_u B11^-1 Z1 )          dist.cpp:193-194
+//     info_u = w_u . w_u ( = b21_u B11^-1 b12_u )    dist.cpp:197-198
 //     out_z = z_u / sqrt(info_u), out_info = |info_u| dist.cpp:200-202
-// In fp64 this agrees with the reference's full-pivot-LU inverse to ~1e-12 relative.
+// In fp64 this agrees with the reference's full-pivot-LU inverse to ~1e-13 relative.  (The stand-alone solve_kernel
+// of the clamp path substitutes the window's own right-hand sides instead: v_u = L^-1 b21_u^T.)
 //
 // MakePosDef (util.cpp:302-318) only acts when the smallest eigenvalue of B11 is below
 // min_abs_eig.  That condition is tested exactly, on the GPU, by factoring the shifted matrix
