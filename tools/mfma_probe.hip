@@ -58,6 +58,25 @@ __global__ __launch_bounds__(256) void probe(const unsigned* __restrict__ in, fl
                 HALF(false) HALF(true)
                 w0 = w0 * 3 + 1; w1 = w1 * 5 + 1; w2 ^= w0; w3 ^= w1;
             }
+        } else if (VARIANT == 5) {
+            // operands as fp4 (e2m1) nibbles: v_cvt_scalef32_pk_f32_fp4 expands one byte = two values per instruction
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+#define QUART(SEL)                                                                                     \
+    {                                                                                                  \
+        const f32x2 fa0 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(w0, 1.0f, SEL), fa1 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(w1, 1.0f, SEL); \
+        const f32x2 fb0 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(w2, 1.0f, SEL), fb1 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(w3, 1.0f, SEL); \
+        _Pragma("unroll") for (int e = 0; e < 2; e++) {                                              \
+            a00 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[e], fb0[e], a00, 0, 0, 0);                  \
+            a01 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[e], fb1[e], a01, 0, 0, 0);                  \
+            a10 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[e], fb0[e], a10, 0, 0, 0);                  \
+            a11 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[e], fb1[e], a11, 0, 0, 0);                  \
+        }                                                                                              \
+    }
+                QUART(0) QUART(1) QUART(2) QUART(3)
+                w0 = w0 * 3 + 1; w1 = w1 * 5 + 1; w2 ^= w0; w3 ^= w1;
+            }
         } else {
 #pragma unroll
             for (int q = 0; q < 4; q++) {
@@ -86,7 +105,7 @@ int main()
     hipMalloc(&in, 4096); hipMemset(in, 0x38, 4096);
     const int iters = 2000;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int variant = 3; variant < 5; variant++)
+    for (int variant = 3; variant < 6; variant++)
         for (int wg_per_cu = 1; wg_per_cu <= 4; wg_per_cu++) {
             const int blocks = 256 * wg_per_cu;
             hipMalloc(&out, (size_t)blocks * 256 * 4);
@@ -96,6 +115,7 @@ int main()
                 if (variant == 1) hipLaunchKernelGGL(probe<1>, dim3(blocks), dim3(256), 0, 0, in, out, iters);
                 if (variant == 4) hipLaunchKernelGGL(probe<4>, dim3(blocks), dim3(256), 0, 0, in, out, iters);
                 if (variant == 3) hipLaunchKernelGGL(probe<3>, dim3(blocks), dim3(256), 0, 0, in, out, iters);
+                if (variant == 5) hipLaunchKernelGGL(probe<5>, dim3(blocks), dim3(256), 0, 0, in, out, iters);
                 if (variant == 2) hipLaunchKernelGGL(probe<2>, dim3(blocks), dim3(256), 0, 0, in, out, iters);
                 hipEventRecord(e1); hipEventSynchronize(e1);
             }
