@@ -331,3 +331,30 @@ def test_gpu_native_chromosome_run_other_kinds_equal_per_window_calls(ctx, tmp_p
         else:
             assert list(got[c]) == list(want[c]), c
     api.panel_evict(ctx=ctx)
+
+
+def test_bench_pieces_are_put_together_per_window():
+    """bench.py's shard check (pure Python): pieces (window, u0, u1) from several ranks must tile every window and
+    reproduce the one-rank z / info bit for bit; a gap, an overlap or a changed bit is reported."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from gauss_amd import workload
+    rng = np.random.default_rng(1)
+    wins = [(1 + 1_000_000 * k, np.arange(5 + k), np.arange(100 * k, 100 * k + 30 + 7 * k)) for k in range(4)]
+    ref = [dict(z=rng.standard_normal(len(w[2])), info=rng.random(len(w[2]))) for w in wins]
+    shares = [[(0, 0, 30), (2, 0, 20)], [(1, 0, 37), (2, 20, 44)], [(3, 0, 51)]]
+    assert [len(w[2]) for w in workload.pieces_of(wins, shares[0])] == [30, 20]
+    assert np.array_equal(workload.pieces_of(wins, shares[1])[1][2], wins[2][2][20:44])
+    parts = [{pc: (ref[pc[0]]["z"][pc[1]:pc[2]].copy(), ref[pc[0]]["info"][pc[1]:pc[2]].copy()) for pc in sh} for sh in shares]
+    assert bench.pieces_equal_whole(parts, ref, wins)
+    bad = [dict(p) for p in parts]
+    z, info = bad[1][(2, 20, 44)]
+    z = z.copy(); z[3] = np.nextafter(z[3], 1.0)
+    bad[1][(2, 20, 44)] = (z, info)
+    assert not bench.pieces_equal_whole(bad, ref, wins)                 # one bit off
+    gap = [dict(p) for p in parts]
+    del gap[1][(2, 20, 44)]
+    assert not bench.pieces_equal_whole(gap, ref, wins)                 # window 2 is not covered
+    lap = [dict(p) for p in parts]
+    lap[2][(2, 10, 44)] = (ref[2]["z"][10:44], ref[2]["info"][10:44])
+    assert not bench.pieces_equal_whole(lap, ref, wins)                 # pieces overlap
