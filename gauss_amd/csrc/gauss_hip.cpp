@@ -143,7 +143,8 @@ struct Plan {
     std::vector<int> pop_raw_off, pop_pk_off, seg_pop, seg_k0, seg_k1, pop_seg0;
     std::vector<int> pair_ti, pair_tj, pair_lut;
     std::vector<double> pop_w, pop_wf, pop_md, z1;
-    std::vector<uint8_t> word_pop, word_run, chunk_half;
+    std::vector<uint8_t> word_pop, word_run;
+    std::vector<uint32_t> chunk_half;      // bit per K chunk (Item::chunk_half)
     std::vector<int> run_pk_off, run_src;
     std::vector<int32_t> rows_m, rows_u;     // store rows; empty = contiguous
     size_t row_bytes = 0;                    // bytes of a source row that the kernels read
@@ -375,16 +376,17 @@ static int plan_problem(const WinSpec& w, Plan& pl, int seg_max, int group_targe
     pl.word_pop.assign(p.Kp / 16, 0);
     // K chunks whose upper 32 samples are padding: the last chunk of every zero-padded block (a population, or a 2-bit
     // source block) whose size leaves a remainder of 1..32 samples
-    pl.chunk_half.assign(p.Kp / KC, 0);
+    pl.chunk_half.assign((p.Kp / KC + 31) / 32 + 1, 0u);
+    auto set_half = [&](int chunk) { pl.chunk_half[chunk >> 5] |= 1u << (chunk & 31); };
     if (w.geno_fmt == GAUSS_GENO_2BIT) {
         for (int q = 0; q < w.n_pop; q++) {
             const int m = w.pop_off[q + 1] - w.pop_off[q], rem = m % KC;
-            if (m > 0 && rem >= 1 && rem <= 32) pl.chunk_half[pl.run_pk_off[q + 1] / KC - 1] = 1;
+            if (m > 0 && rem >= 1 && rem <= 32) set_half(pl.run_pk_off[q + 1] / KC - 1);
         }
     } else {
         for (int q = 0; q < P; q++) {
             const int m = pl.pop_raw_off[q + 1] - pl.pop_raw_off[q], rem = m % KC;
-            if (m > 0 && rem >= 1 && rem <= 32) pl.chunk_half[pl.pop_pk_off[q + 1] / KC - 1] = 1;
+            if (m > 0 && rem >= 1 && rem <= 32) set_half(pl.pop_pk_off[q + 1] / KC - 1);
         }
     }
     pl.pop_seg0.assign(P + 1, 0);
@@ -823,7 +825,7 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
         it.b = p.packed + (size_t)tj * TILE * p.Kp;
         it.slab = p.slab + ((size_t)h.pair * p.nseg + gr.first) * (p.slab16 ? TILE * TILE / 2 : TILE * TILE);
         it.seg_k1 = p.seg_k1 + gr.first;
-        it.chunk_half = (const uint8_t*)(job->d_tab + to[h.prob].ch);
+        it.chunk_half = (const uint32_t*)(job->d_tab + to[h.prob].ch);
         it.Kp = p.Kp; it.k0 = pl.seg_k0[gr.first]; it.nseg = gr.second - gr.first;
         it.rows_a = rows(ti); it.rows_b = rows(tj); it.flags = (ti == tj ? 1 : 0) | (p.slab16 ? 2 : 0);
         memcpy(blob.data() + o_items + sizeof(Item) * n, &it, sizeof(Item));

@@ -106,8 +106,9 @@ struct Item {
     GP(const uint8_t) b;     // packed rows of tile tj
     GP(float) slab;          // slab of (pair, first segment of the run); later segments follow
     GP(const int) seg_k1;    // end column of each segment of the run
-    GP(const uint8_t) chunk_half;  // [Kp / KC] 1: only the first 32 samples of that K chunk are live (the rest is the zero
-                             // padding that ends a population block): half of the chunk's MFMAs are not issued
+    GP(const uint32_t) chunk_half; // bit c (word c / 32, bit c % 32) 1: only the first 32 samples of K chunk c are live (the
+                             // rest is the zero padding that ends a population block): half of the chunk's MFMAs are not
+                             // issued.  Dwords, read through the scalar cache (UNIFORM_I32 / chunk_is_half below)
     int Kp;                  // packed row stride
     int k0;                  // first column of the run
     int nseg;                // segments in the run
@@ -119,6 +120,24 @@ static_assert(sizeof(Item) == 64, "work items are fetched as one 64-byte descrip
 template <typename T> using gptr = T __attribute__((address_space(1)))*;
 template <typename T> __device__ __forceinline__ gptr<T> G(T* p) { return (gptr<T>)p; }
 template <typename T> __device__ __forceinline__ gptr<T> G(gptr<T> p) { return p; }
+
+// Wave-uniform table reads inside the Gram kernels' K loops (segment ends, half-chunk flags).  The tables are reached
+// through pointers that were themselves loaded from memory, so the compiler cannot prove them read-only and emits VECTOR
+// loads -- and a vector load's s_waitcnt vmcnt(0) also waits for every LDS-DMA group issued before it, i.e. for the
+// operand chunks that were just requested for LATER iterations (round 2's half-chunk flag was a global_load_ubyte in the
+// loop: every chunk's MFMAs waited for the next chunk's DMA).  Reading them through the constant address space makes
+// them scalar loads (lgkmcnt), which leave the DMA queue alone.
+#if defined(__HIPCC__)
+template <typename T>
+__device__ __forceinline__ T uniform_load(GP(const T) p, int idx)
+{
+    return ((const T __attribute__((address_space(4)))*)p)[idx];
+}
+__device__ __forceinline__ bool chunk_is_half(GP(const uint32_t) bits, int chunk)
+{
+    return (uniform_load<uint32_t>(bits, chunk >> 5) >> (chunk & 31)) & 1u;
+}
+#endif
 
 // hipFuncSetAttribute is per device: true the first time the calling thread's current device is seen for `mask`
 // (one static mask per launcher), so a process that drives several GPUs sets the attribute on each of them.

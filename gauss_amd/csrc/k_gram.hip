@@ -21,6 +21,7 @@
 // LDS image: [128 rows][64 bytes] per operand, unpadded; the bank conflicts of the ds_read_b128 fragment
 // reads are avoided by an XOR swizzle applied to the DMA source address and to the read address.
 #include "gauss_internal.h"
+#include "k_gram_common.h"
 #include <cstdlib>
 
 namespace gauss {
@@ -116,13 +117,6 @@ __device__ __forceinline__ void chunk_mfma(const uint8_t* __restrict__ la, const
     }
 }
 
-__device__ __forceinline__ float slab_bits(float v) { return v; }
-__device__ __forceinline__ float slab_bits(int v) { return __int_as_float(v); }
-// 16-bit slabs: the exact sum as an unsigned integer; rows 2k and 2k + 1 of a column share one dword
-__device__ __forceinline__ uint32_t slab_u(float v) { return (uint32_t)v; }
-__device__ __forceinline__ uint32_t slab_u(int v) { return (uint32_t)v; }
-__device__ __forceinline__ float slab_pair(uint32_t lo, uint32_t hi) { return __uint_as_float((lo & 0xFFFFu) | (hi << 16)); }
-
 // One work item for a wave with NA x NB live 32-row halves (NA = 0: staging and barriers only).
 // The K loop runs over the whole run of segments without draining the prefetch pipeline; at each
 // segment end the accumulators are flushed to that segment's slab and cleared.
@@ -171,7 +165,11 @@ __device__ __forceinline__ void run_item(const Item& it, uint8_t* lds, int wr, i
 
     const int k0 = it.k0;
     const int nseg = it.nseg;
-    const int klast = it.seg_k1[nseg - 1];
+    // descriptor fields as values: the asm waits in the K loop clobber memory, a field read through `it` would be
+    // fetched again every chunk
+    const auto seg_k1 = it.seg_k1;
+    const auto half_bits = it.chunk_half;
+    const int klast = uniform_load<int>(seg_k1, nseg - 1);
     auto out = it.slab;
     const int obase = (wr * 64 + 4 * lh) * TILE + wc * 64 + li;
     const int obase16 = (wr * 32 + 2 * lh) * TILE + wc * 64 + li;         // row pair (wr * 64 + 4 lh) / 2
@@ -204,9 +202,10 @@ __device__ __forceinline__ void run_item(const Item& it, uint8_t* lds, int wr, i
     }
 
     int k = k0;
-    bool half_next = it.chunk_half[k0 >> 6] != 0;
+    uint32_t hbits = uniform_load<uint32_t>(half_bits, k0 >> 11);       // half-chunk flags, 32 chunks per dword
+    bool half_next = (hbits >> ((k0 >> 6) & 31)) & 1u;
     for (int seg = 0; seg < nseg; seg++) {
-        const int kend = it.seg_k1[seg];
+        const int kend = uniform_load<int>(seg_k1, seg);
         for (; k < kend; k += KC) {
             // the image consumed in the previous iteration is free: request the chunk NS - 1 ahead into it
             // (the prefetch runs across segment ends)
@@ -220,7 +219,11 @@ __device__ __forceinline__ void run_item(const Item& it, uint8_t* lds, int wr, i
             const uint8_t* la = lds + cur * 2 * LTILE;
             const uint8_t* lb = la + LTILE;
             const bool half = half_next;
-            if (k + KC < klast) half_next = it.chunk_half[(k + KC) >> 6] != 0;     // scalar load, one chunk ahead of its use
+            if (k + KC < klast) {
+                const int c1 = (k + KC) >> 6;
+                if ((c1 & 31) == 0) hbits = uniform_load<uint32_t>(half_bits, c1 >> 5);      // scalar load, once per 32 chunks
+                half_next = (hbits >> (c1 & 31)) & 1u;
+            }
             if (NA > 0) chunk_mfma<NA, NB, SK10>(la, lb, aoff, boff, acc00, acc01, acc10, acc11, half);
             wait_dma_barrier_dyn<NS>(ahead - 1);         // next chunk landed; everyone is done reading this one
             if (ahead > 0) ahead--;
@@ -230,30 +233,7 @@ __device__ __forceinline__ void run_item(const Item& it, uint8_t* lds, int wr, i
         // end of a segment: flush its exact partial sums, start the next segment from zero.
         // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
         if (NA > 0) {
-            if ((it.flags & 2)) {
-                // accumulator registers r and r + 1 (r even) are rows 2k and 2k + 1 of the same column: one dword
-#pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    const int o = obase16 + (((r & 3) + 8 * (r >> 2)) >> 1) * TILE;
-                    out[o] = slab_pair(slab_u(acc00[r]), slab_u(acc00[r + 1]));
-                    if (NB > 1) out[o + 32] = slab_pair(slab_u(acc01[r]), slab_u(acc01[r + 1]));
-                    if (NA > 1) {
-                        if (!SK10) out[o + 16 * TILE] = slab_pair(slab_u(acc10[r]), slab_u(acc10[r + 1]));
-                        if (NB > 1) out[o + 16 * TILE + 32] = slab_pair(slab_u(acc11[r]), slab_u(acc11[r + 1]));
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int o = obase + ((r & 3) + 8 * (r >> 2)) * TILE;
-                    out[o] = slab_bits(acc00[r]);
-                    if (NB > 1) out[o + 32] = slab_bits(acc01[r]);
-                    if (NA > 1) {
-                        if (!SK10) out[o + 32 * TILE] = slab_bits(acc10[r]);
-                        if (NB > 1) out[o + 32 * TILE + 32] = slab_bits(acc11[r]);
-                    }
-                }
-            }
+            flush_acc<NA, NB, SK10>(out, (it.flags & 2) != 0, obase, obase16, acc00, acc01, acc10, acc11);
 #pragma unroll
             for (int r = 0; r < 16; r++) { acc00[r] = 0; acc01[r] = 0; acc10[r] = 0; acc11[r] = 0; }
         }
