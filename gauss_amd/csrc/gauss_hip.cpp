@@ -16,6 +16,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <set>
 #include <thread>
 #include <string>
 #include <vector>
@@ -65,8 +66,11 @@ struct BlockCache {
     }
 };
 
+struct gauss_job;
+
 struct gauss_ctx {
     int device;
+    uint64_t id = 0;                         // unique per process, never reused (a new context at a freed context's address is a new id)
     hipStream_t stream;
     // B21's half of the LD epilogue runs here, beside the factorisation chain on `stream` (which only needs B11): the
     // chain's launches are few, short and dependent and leave most of the chip idle (GAUSS_SIDE_STREAM=0: one stream)
@@ -76,10 +80,40 @@ struct gauss_ctx {
     std::mutex mu;
     BlockCache dev_cache, pin_cache;
     std::map<void*, size_t> block_size;      // every live block handed out by ctx_dev_alloc / ctx_pin_alloc
+    std::set<gauss_job*> jobs;               // live jobs of this context (guarded by mu): gauss_hip_destroy orphans them
+    size_t dev_cache_limit = 0;              // bytes of freed workspace kept for reuse (a third of the device's memory)
 };
 
-static const size_t DEV_CACHE_LIMIT = (size_t)96 << 30;      // of 288 GB
+// Lifetime rule of the C ABI (include/gauss_hip.h): a context may be destroyed while jobs and row stores made on it
+// are still alive.  gauss_hip_destroy waits for their queued work, releases everything they hold on the device and
+// leaves the job handles as empty shells ("orphans": ctx == nullptr) that only gauss_job_destroy accepts; destroy hooks
+// let the host layer drop what it cached per context.  An Rcpp driver whose objects unwind in any order
+// (Rcpp::stop between create and destroy) therefore never touches freed memory.
+static std::mutex g_hook_mu;
+static std::vector<std::pair<void (*)(gauss_ctx*, uint64_t, void*), void*>> g_destroy_hooks;
+static std::atomic<uint64_t> g_next_ctx_id{1};
+
 static const size_t PIN_CACHE_LIMIT = (size_t)1 << 30;
+
+static void ctx_flush_dev_cache_locked(gauss_ctx* c)
+{
+    for (auto& kv : c->dev_cache.free_blocks) { (void)hipFree(kv.second); c->block_size.erase(kv.second); }
+    c->dev_cache.free_blocks.clear(); c->dev_cache.held = 0;
+    (void)hipGetLastError();
+}
+// hipMalloc that gives the context's cached workspaces back to the device before it reports failure (a row store of
+// tens of GB, a scratch buffer or another context on the same device may need the room the cache is sitting on)
+static hipError_t ctx_malloc_retry(gauss_ctx* c, void** out, size_t bytes)
+{
+    hipError_t e = hipMalloc(out, bytes);
+    if (e == hipSuccess) return e;
+    {
+        std::lock_guard<std::mutex> lock(c->mu);
+        if (c->dev_cache.free_blocks.empty()) return e;
+        ctx_flush_dev_cache_locked(c);
+    }
+    return hipMalloc(out, bytes);
+}
 
 static hipError_t ctx_dev_alloc(gauss_ctx* c, size_t bytes, void** out)
 {
@@ -87,9 +121,7 @@ static hipError_t ctx_dev_alloc(gauss_ctx* c, size_t bytes, void** out)
     if (void* p = c->dev_cache.take(bytes)) { *out = p; return hipSuccess; }
     hipError_t e = hipMalloc(out, bytes);
     if (e != hipSuccess && !c->dev_cache.free_blocks.empty()) {       // make room and retry once
-        for (auto& kv : c->dev_cache.free_blocks) { (void)hipFree(kv.second); c->block_size.erase(kv.second); }
-        c->dev_cache.free_blocks.clear(); c->dev_cache.held = 0;
-        (void)hipGetLastError();
+        ctx_flush_dev_cache_locked(c);
         e = hipMalloc(out, bytes);
     }
     if (e == hipSuccess) c->block_size[*out] = bytes;
@@ -101,7 +133,7 @@ static void ctx_dev_release(gauss_ctx* c, void* p)
     std::lock_guard<std::mutex> lock(c->mu);
     auto it = c->block_size.find(p);
     const size_t bytes = it == c->block_size.end() ? 0 : it->second;
-    if (bytes && c->dev_cache.held + bytes <= DEV_CACHE_LIMIT) { c->dev_cache.free_blocks.emplace(bytes, p); c->dev_cache.held += bytes; return; }
+    if (bytes && c->dev_cache.held + bytes <= c->dev_cache_limit) { c->dev_cache.free_blocks.emplace(bytes, p); c->dev_cache.held += bytes; return; }
     if (it != c->block_size.end()) c->block_size.erase(it);
     (void)hipFree(p);
 }
@@ -134,6 +166,7 @@ struct DevBuf {
     DevBuf& operator=(const DevBuf&) = delete;
     ~DevBuf() { if (p) (void)hipFree(p); }
     hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+    hipError_t alloc(gauss_ctx* c, size_t bytes) { return ctx_malloc_retry(c, &p, bytes ? bytes : 1); }
     template <typename T> T* as() const { return (T*)p; }
 };
 
@@ -169,7 +202,7 @@ struct Plan {
     size_t res_off = 0;                      // offset (in doubles) of this problem's z in the result block
 };
 
-struct ProfSlot { hipEvent_t a, b; int kernel; };
+struct ProfSlot { hipEvent_t a, b; int kernel; unsigned run; };      // run: gauss_job::run_seq of the run that recorded it
 
 struct gauss_job {
     gauss_ctx* ctx = nullptr;
@@ -498,6 +531,8 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
     }
     // Row lists are resolved by the pack kernel: an index beyond the store would be an out-of-bounds read on the
     // GPU.  Host stores cannot be checked (only a pointer is known), stores made by gauss_store_upload can.
+    std::map<const void*, size_t> stores;
+    { std::lock_guard<std::mutex> lock(ctx->mu); stores = ctx->stores; }
     for (int i = 0; i < job->n; i++) {
         const Plan& pl = job->plans[i];
         for (int side = 0; side < 2; side++) {
@@ -511,8 +546,8 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
             }
             if (!on_device) continue;
             // the store that contains `base` (a window may point into the middle of an uploaded store)
-            auto it = ctx->stores.upper_bound(base);
-            if (it == ctx->stores.begin()) continue;                      // not one of ours: caller's responsibility
+            auto it = stores.upper_bound(base);
+            if (it == stores.begin()) continue;                      // not one of ours: caller's responsibility
             --it;
             const uint8_t* s0 = (const uint8_t*)it->first;
             if (base >= s0 + it->second) continue;
@@ -842,6 +877,7 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
     job->d_finmap = (int2*)(job->d_tab + o_finmap);
     if (!on_device) HIPCHK(hipStreamSynchronize(st));   // uploads from pageable user memory are complete
     std::vector<char>().swap(job->h_tab);
+    { std::lock_guard<std::mutex> lock(ctx->mu); ctx->jobs.insert(job); }
     *out = guard.release();
     return GAUSS_OK;
 }
@@ -854,6 +890,7 @@ static void prof_begin(gauss_job* job, int kernel, hipStream_t st)
     if (!job->prof) return;
     ProfSlot s;
     s.kernel = kernel;
+    s.run = job->run_seq;
     hipEventCreate(&s.a);
     hipEventCreate(&s.b);
     hipEventRecord(s.a, st);
@@ -864,9 +901,14 @@ static void prof_end(gauss_job* job, hipStream_t st)
     if (!job->prof) return;
     hipEventRecord(job->slots.back().b, st);
 }
-static void prof_collect(gauss_job* job)
+// Collects the stage timers of the runs before `run_end` (default: all).  gauss_job_fetch passes the run it has just
+// fetched: with two runs in flight the later run's events are still pending, and waiting for them here would make
+// the fetch of run k block until run k + 1 has finished -- the host's share of a step would no longer overlap GPU work.
+static void prof_collect(gauss_job* job, unsigned run_end = ~0u)
 {
+    std::vector<ProfSlot> keep;
     for (ProfSlot& s : job->slots) {
+        if (run_end != ~0u && (int)(s.run - run_end) >= 0) { keep.push_back(s); continue; }
         hipEventSynchronize(s.b);
         float ms = 0.f;
         hipEventElapsedTime(&ms, s.a, s.b);
@@ -875,7 +917,7 @@ static void prof_collect(gauss_job* job)
         hipEventDestroy(s.a);
         hipEventDestroy(s.b);
     }
-    job->slots.clear();
+    job->slots.swap(keep);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -969,19 +1011,19 @@ static int job_clamp_window(gauss_job* job, int i, int* status_bits)
     std::vector<int2> tm;
     for (int pr = 0; pr < p.npair; pr++) tm.push_back(make_int2(i, pr));
     DevBuf d_tm, d_work, d_pm;
-    HIPCHK(d_tm.alloc(sizeof(int2) * tm.size()));
+    HIPCHK(d_tm.alloc(job->ctx, sizeof(int2) * tm.size()));
     HIPCHK(hipMemcpyAsync(d_tm.p, tm.data(), sizeof(int2) * tm.size(), hipMemcpyHostToDevice, st));
     launch_epilogue(job->d_probs, d_tm.as<int2>(), (int)tm.size(), job->max_pop, job->gram_i8, st);
     HIPCHK(hipGetLastError());
     const size_t n = (size_t)p.Mld;
-    HIPCHK(d_work.alloc(sizeof(double) * (2 * n * n + 4 * n)));
+    HIPCHK(d_work.alloc(job->ctx, sizeof(double) * (2 * n * n + 4 * n)));
     HIPCHK(hipMemsetAsync(p.status, 0, sizeof(int) * 4, st));
     launch_jacobi_clamp(job->d_probs, i, p, d_work.as<double>(), true, st);
     HIPCHK(hipGetLastError());
     // refactor (both matrices are factored again; only matrix 0 is used) and solve this window
     std::vector<int2> pm;
     for (int pn = 0; pn < p.npanel; pn++) pm.push_back(make_int2(i, pn));
-    HIPCHK(d_pm.alloc(sizeof(int2) * pm.size()));
+    HIPCHK(d_pm.alloc(job->ctx, sizeof(int2) * pm.size()));
     HIPCHK(hipMemcpyAsync(d_pm.p, pm.data(), sizeof(int2) * pm.size(), hipMemcpyHostToDevice, st));
     if (pl.out_b11) HIPCHK(hipMemcpyAsync(pl.d_b11_copy, p.A, sizeof(double) * n * n, hipMemcpyDeviceToDevice, st));
     HIPCHK(hipMemcpyAsync(p.A + 4 * n * n, p.A, sizeof(double) * n * n, hipMemcpyDeviceToDevice, st));   // W0 = clamped B11
@@ -1020,7 +1062,7 @@ static int job_count_small_eigs(gauss_job* job, int i, int* num_eig)
     Prob& p = pl.p;
     const size_t n = (size_t)p.Mld;
     DevBuf d_work;
-    HIPCHK(d_work.alloc(sizeof(double) * (2 * n * n + 4 * n)));
+    HIPCHK(d_work.alloc(job->ctx, sizeof(double) * (2 * n * n + 4 * n)));
     launch_jacobi_clamp(job->d_probs, i, p, d_work.as<double>(), false, st);
     HIPCHK(hipGetLastError());
     std::vector<double> delta(n);
@@ -1103,30 +1145,50 @@ static int job_fetch(gauss_job* job)
         if (pl.out_ld_user && pl.out_ld_count)
             HIPCHK(hipMemcpy(pl.out_ld_user, p.out_ld, sizeof(double) * pl.out_ld_count, hipMemcpyDeviceToHost));
     }
-    if (job->prof) prof_collect(job);
+    if (job->prof) prof_collect(job, job->fetch_seq);      // the slots of the run just fetched (fetch_seq already counts it)
     return GAUSS_OK;
 }
 
-static void job_free(gauss_job* job)
+// Everything a job holds on its context: waits for its queued runs, then gives the blocks back and destroys the events.
+// Called by job_free, and by gauss_hip_destroy for the jobs that outlive their context (the context is still whole then).
+static void job_release(gauss_job* job)
 {
-    if (!job) return;
-    if (job->ctx) hipSetDevice(job->ctx->device);
+    gauss_ctx* ctx = job->ctx;
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
     // runs that were queued and never fetched: their result copies target this job's pinned block
     if (job->run_seq != job->fetch_seq && job->done) (void)hipEventSynchronize(job->done);
     for (ProfSlot& s : job->slots) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
-    if (job->ctx) {
-        ctx_dev_release(job->ctx, job->d_ws);
-        ctx_dev_release(job->ctx, job->d_tab);
-        ctx_pin_release(job->ctx, job->h_pin);
-    }
+    job->slots.clear();
+    ctx_dev_release(ctx, job->d_ws);
+    ctx_dev_release(ctx, job->d_tab);
+    ctx_pin_release(ctx, job->h_pin);
+    job->d_ws = nullptr; job->d_tab = nullptr; job->h_pin = nullptr;
     if (job->begin) hipEventDestroy(job->begin);
     for (int k = 0; k < 2; k++) if (job->done2[k]) hipEventDestroy(job->done2[k]);
     if (job->ev_gram) hipEventDestroy(job->ev_gram);
     if (job->ev_side) hipEventDestroy(job->ev_side);
     if (job->ev_pack) hipEventDestroy(job->ev_pack);
     if (job->ev_rows) hipEventDestroy(job->ev_rows);
+    job->begin = job->done = job->ev_gram = job->ev_side = job->ev_pack = job->ev_rows = nullptr;
+    job->done2[0] = job->done2[1] = nullptr;
+    { std::lock_guard<std::mutex> lock(ctx->mu); ctx->jobs.erase(job); }
+    job->ctx = nullptr;                       // from here on the handle is an orphan: only gauss_job_destroy accepts it
+}
+
+static void job_free(gauss_job* job)
+{
+    if (!job) return;
+    job_release(job);
     delete job;
 }
+
+// entry points that need the job's context
+#define JOB_ALIVE(job)                                                                                          \
+    do {                                                                                                        \
+        if (!(job)) return fail(GAUSS_E_INVALID, "job is NULL");                                                \
+        if (!(job)->ctx) return fail(GAUSS_E_INVALID, "the job's context has been destroyed (gauss_hip_destroy)"); \
+    } while (0)
 
 static WinSpec spec_from_desc(const gauss_window_desc& d)
 {
@@ -1158,6 +1220,13 @@ int gauss_hip_init(int device, gauss_ctx** out_ctx)
     HIPCHK(hipSetDevice(device));
     gauss_ctx* c = new gauss_ctx();
     c->device = device;
+    c->id = g_next_ctx_id.fetch_add(1);
+    {
+        // freed job workspaces are kept for reuse up to a third of the device's memory (96 GB of an MI355X's 288 GB)
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { total_b = (size_t)288 << 30; (void)hipGetLastError(); }
+        c->dev_cache_limit = total_b / 3;
+    }
     const char* e = getenv("GAUSS_GRAM_DTYPE");
     c->gram_i8 = (e && (strcmp(e, "i8") == 0 || strcmp(e, "int8") == 0)) ? 1 : 0;
     if (env_int("GAUSS_SIDE_STREAM", 1)) {
@@ -1188,12 +1257,47 @@ void gauss_hip_destroy(gauss_ctx* ctx)
 {
     if (!ctx) return;
     hipSetDevice(ctx->device);
+    // 1. whoever cached something per context (the host layer's resident panels) lets go of it
+    std::vector<std::pair<void (*)(gauss_ctx*, uint64_t, void*), void*>> hooks;
+    { std::lock_guard<std::mutex> lock(g_hook_mu); hooks = g_destroy_hooks; }
+    for (auto& h : hooks) h.first(ctx, ctx->id, h.second);
+    // 2. jobs that outlive the context: wait for their work, release what they hold, leave empty shells behind
+    std::vector<gauss_job*> live;
+    { std::lock_guard<std::mutex> lock(ctx->mu); live.assign(ctx->jobs.begin(), ctx->jobs.end()); }
+    for (gauss_job* j : live) job_release(j);
     hipStreamSynchronize(ctx->stream);
     if (ctx->side) { hipStreamSynchronize(ctx->side); hipStreamDestroy(ctx->side); }
+    // 3. row stores nobody freed
+    for (auto& kv : ctx->stores) (void)hipFree(const_cast<void*>(kv.first));
+    ctx->stores.clear();
     for (auto& kv : ctx->dev_cache.free_blocks) (void)hipFree(kv.second);
     for (auto& kv : ctx->pin_cache.free_blocks) (void)hipHostFree(kv.second);
     hipStreamDestroy(ctx->stream);
     delete ctx;
+}
+
+uint64_t gauss_hip_context_id(const gauss_ctx* ctx) { return ctx ? ctx->id : 0; }
+
+int gauss_hip_add_destroy_hook(void (*fn)(gauss_ctx*, uint64_t, void*), void* user)
+{
+    if (!fn) return fail(GAUSS_E_INVALID, "hook is NULL");
+    std::lock_guard<std::mutex> lock(g_hook_mu);
+    for (auto& h : g_destroy_hooks) if (h.first == fn && h.second == user) return GAUSS_OK;
+    g_destroy_hooks.emplace_back(fn, user);
+    return GAUSS_OK;
+}
+
+int gauss_hip_trim_cache(gauss_ctx* ctx, int64_t* out_bytes_freed)
+{
+    if (!ctx) return fail(GAUSS_E_INVALID, "ctx is NULL");
+    HIPCHK(hipSetDevice(ctx->device));
+    // blocks in the cache may still be read by work queued on the streams (a retired job's last launches)
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (ctx->side) HIPCHK(hipStreamSynchronize(ctx->side));
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (out_bytes_freed) *out_bytes_freed = (int64_t)ctx->dev_cache.held;
+    ctx_flush_dev_cache_locked(ctx);
+    return GAUSS_OK;
 }
 
 int gauss_pinned_alloc(gauss_ctx* ctx, int64_t bytes, void** out_host_ptr)
@@ -1265,11 +1369,11 @@ int gauss_store_upload(gauss_ctx* ctx, const void* host_rows, int64_t bytes, voi
     if (!ctx || !host_rows || bytes <= 0 || !out_device_ptr) return fail(GAUSS_E_INVALID, "bad arguments to gauss_store_upload");
     HIPCHK(hipSetDevice(ctx->device));
     void* d = nullptr;
-    hipError_t e = hipMalloc(&d, (size_t)bytes + 64);      // slack: a row's last dword load may end on the last byte
+    hipError_t e = ctx_malloc_retry(ctx, &d, (size_t)bytes + 64);      // slack: a row's last dword load may end on the last byte
     if (e != hipSuccess) return fail(GAUSS_E_NOMEM, "hipMalloc(%lld bytes row store) failed: %s", (long long)bytes, hipGetErrorString(e));
     const int rc = upload_rows(ctx, d, host_rows, (size_t)bytes);
     if (rc) { hipFree(d); return rc; }
-    ctx->stores[d] = (size_t)bytes;
+    { std::lock_guard<std::mutex> lock(ctx->mu); ctx->stores[d] = (size_t)bytes; }
     *out_device_ptr = d;
     return GAUSS_OK;
 }
@@ -1278,7 +1382,10 @@ int gauss_store_free(gauss_ctx* ctx, void* device_ptr)
 {
     if (!ctx) return fail(GAUSS_E_INVALID, "ctx is NULL");
     HIPCHK(hipSetDevice(ctx->device));
-    if (device_ptr) { ctx->stores.erase(device_ptr); HIPCHK(hipFree(device_ptr)); }
+    if (device_ptr) {
+        { std::lock_guard<std::mutex> lock(ctx->mu); ctx->stores.erase(device_ptr); }
+        HIPCHK(hipFree(device_ptr));
+    }
     return GAUSS_OK;
 }
 
@@ -1312,13 +1419,14 @@ int gauss_job_create(gauss_ctx* ctx, const gauss_window_desc* wins, int n_win, i
     return GAUSS_OK;
 }
 
-int gauss_job_run(gauss_job* job) { return job ? job_run(job, true) : fail(GAUSS_E_INVALID, "job is NULL"); }
-int gauss_job_fetch(gauss_job* job) { return job ? job_fetch(job) : fail(GAUSS_E_INVALID, "job is NULL"); }
+int gauss_job_run(gauss_job* job) { JOB_ALIVE(job); return job_run(job, true); }
+int gauss_job_fetch(gauss_job* job) { JOB_ALIVE(job); return job_fetch(job); }
 void gauss_job_destroy(gauss_job* job) { job_free(job); }
 
 int gauss_job_span_ms(gauss_job* first, gauss_job* last, double* out_ms)
 {
-    if (!first || !last || !out_ms || !first->ran || !last->ran) return fail(GAUSS_E_INVALID, "gauss_job_span_ms: both jobs must have run");
+    JOB_ALIVE(first); JOB_ALIVE(last);
+    if (!out_ms || !first->ran || !last->ran) return fail(GAUSS_E_INVALID, "gauss_job_span_ms: both jobs must have run");
     HIPCHK(hipEventSynchronize(last->done));
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, first->begin, last->done));
@@ -1328,7 +1436,7 @@ int gauss_job_span_ms(gauss_job* first, gauss_job* last, double* out_ms)
 
 int gauss_job_profile(gauss_job* job, int enable)
 {
-    if (!job) return fail(GAUSS_E_INVALID, "job is NULL");
+    JOB_ALIVE(job);
     if (job->prof && !enable) prof_collect(job);
     job->prof = enable != 0;
     if (enable) { for (int k = 0; k < 5; k++) { job->prof_ms[k] = 0; job->prof_n[k] = 0; } }
@@ -1337,7 +1445,8 @@ int gauss_job_profile(gauss_job* job, int enable)
 
 int gauss_job_profile_get(gauss_job* job, int kernel, double* out_ms, int64_t* out_launches)
 {
-    if (!job || kernel < 0 || kernel > 4) return fail(GAUSS_E_INVALID, "bad arguments");
+    JOB_ALIVE(job);
+    if (kernel < 0 || kernel > 4) return fail(GAUSS_E_INVALID, "bad arguments");
     hipStreamSynchronize(job->ctx->stream);
     prof_collect(job);
     if (out_ms) *out_ms = job->prof_ms[kernel];
@@ -1433,7 +1542,7 @@ static int ld_common(gauss_ctx* ctx, int mode, const uint8_t* geno, int n_snp, i
     if (out_counts) {
         DevBuf d_cnt;
         const size_t bytes = sizeof(long long) * (size_t)n_snp * n_snp;
-        if (d_cnt.alloc(bytes) != hipSuccess) return fail(GAUSS_E_NOMEM, "hipMalloc(%zu bytes of counts) failed", bytes);
+        if (d_cnt.alloc(ctx, bytes) != hipSuccess) return fail(GAUSS_E_NOMEM, "hipMalloc(%zu bytes of counts) failed", bytes);
         launch_counts(job->d_probs, 0, job->plans[0].p.npair, d_cnt.as<long long>(), ctx->stream);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -1496,7 +1605,7 @@ int gauss_ld_per_pop(gauss_ctx* ctx, const uint8_t* geno, int n_snp, int64_t ld,
     const size_t npairs = (size_t)n_snp * (n_snp - 1) / 2;
     const size_t bytes = sizeof(double) * npairs * (size_t)n_pop;
     DevBuf d_out;
-    if (d_out.alloc(bytes) != hipSuccess) return fail(GAUSS_E_NOMEM, "hipMalloc(%zu bytes per-population LD) failed", bytes);
+    if (d_out.alloc(ctx, bytes) != hipSuccess) return fail(GAUSS_E_NOMEM, "hipMalloc(%zu bytes per-population LD) failed", bytes);
     launch_pop_cor(job->d_probs, 0, job->plans[0].p.npair, d_out.as<double>(), ctx->stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(ctx->stream));

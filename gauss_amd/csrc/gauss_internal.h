@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <atomic>
+#include <mutex>
 
 namespace gauss {
 
@@ -139,15 +140,24 @@ __device__ __forceinline__ bool chunk_is_half(GP(const uint32_t) bits, int chunk
 }
 #endif
 
-// hipFuncSetAttribute is per device: true the first time the calling thread's current device is seen for `mask`
-// (one static mask per launcher), so a process that drives several GPUs sets the attribute on each of them.
-inline bool first_use_on_device(std::atomic<unsigned long long>& mask)
-{
-    int d = 0;
-    (void)hipGetDevice(&d);
-    const unsigned long long bit = 1ull << (d & 63);
-    return (mask.fetch_or(bit) & bit) == 0;
-}
+// hipFuncSetAttribute is per device: `set` runs once for every device a launcher is used on (a process may drive
+// several GPUs), and a second thread that arrives on the same device meanwhile (another context of bench --streams, a
+// farm thread) waits until the attributes are in place instead of launching with the default dynamic-LDS limit.
+struct DeviceOnce {
+    std::atomic<unsigned long long> done{0};
+    std::mutex mu;
+    template <typename F> void run(F&& set)
+    {
+        int d = 0;
+        (void)hipGetDevice(&d);
+        const unsigned long long bit = 1ull << (d & 63);
+        if (done.load(std::memory_order_acquire) & bit) return;
+        std::lock_guard<std::mutex> lock(mu);
+        if (done.load(std::memory_order_relaxed) & bit) return;
+        set();
+        done.fetch_or(bit, std::memory_order_release);
+    }
+};
 
 // ---- launchers (host functions defined in the .hip files) ----
 void launch_pack_stats(const Prob* d_probs, const int2* d_rowmap, int n_rows, hipStream_t s);

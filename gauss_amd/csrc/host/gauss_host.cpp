@@ -1698,8 +1698,20 @@ struct ResidentPanel {
     void* dev = nullptr;
     int64_t bytes = 0;
 };
+// Keyed by the context's id, not its address: ids are never reused, so a context created at the address of a destroyed
+// one cannot inherit a stale entry (whose device pointer may even belong to another GPU).  The destroy hook drops a
+// context's entries while the context is still whole; the device memory itself goes with the context's stores.
 static std::mutex g_res_mu;
-static std::map<std::pair<gauss_ctx*, std::string>, ResidentPanel> g_resident;
+static std::map<std::pair<uint64_t, std::string>, ResidentPanel> g_resident;
+
+static void resident_ctx_destroyed(gauss_ctx* ctx, uint64_t id, void*)
+{
+    std::lock_guard<std::mutex> lock(g_res_mu);
+    for (auto it = g_resident.begin(); it != g_resident.end();) {
+        if (it->first.first == id) { gauss_store_free(ctx, it->second.dev); it = g_resident.erase(it); }
+        else ++it;
+    }
+}
 
 static std::string file_key(const std::string& path)
 {
@@ -1714,10 +1726,11 @@ static std::string file_key(const std::string& path)
 static int panel_make_resident(gauss_ctx* ctx, const std::string& path, void** dev, int64_t* uploaded)
 {
     if (uploaded) *uploaded = 0;
-    const std::pair<gauss_ctx*, std::string> key(ctx, file_key(path));
+    const std::pair<uint64_t, std::string> key(gauss_hip_context_id(ctx), file_key(path));
     std::lock_guard<std::mutex> lock(g_res_mu);
     auto it = g_resident.find(key);
     if (it != g_resident.end()) { *dev = it->second.dev; return 0; }
+    gauss_hip_add_destroy_hook(resident_ctx_destroyed, nullptr);
     std::string err;
     ResidentPanel rp;
     rp.pk = open_packed_shared(path, err);
@@ -1733,7 +1746,7 @@ static int panel_make_resident(gauss_ctx* ctx, const std::string& path, void** d
 
 static bool panel_is_resident(gauss_ctx* ctx, const std::string& path, void** dev)
 {
-    const std::pair<gauss_ctx*, std::string> key(ctx, file_key(path));
+    const std::pair<uint64_t, std::string> key(gauss_hip_context_id(ctx), file_key(path));
     std::lock_guard<std::mutex> lock(g_res_mu);
     auto it = g_resident.find(key);
     if (it == g_resident.end()) return false;
@@ -1798,7 +1811,7 @@ int gauss_host_panel_evict(gauss_ctx* ctx, const char* packed_file)
     std::lock_guard<std::mutex> lock(g_res_mu);
     for (auto it = g_resident.begin(); it != g_resident.end();) {
         const size_t pl = packed_file ? strlen(packed_file) : 0;      // keys are "<path>|<size>|<mtime>"
-        if (it->first.first == ctx && (!packed_file || (it->first.second.compare(0, pl, packed_file) == 0 &&
+        if (it->first.first == gauss_hip_context_id(ctx) && (!packed_file || (it->first.second.compare(0, pl, packed_file) == 0 &&
                                                          (it->first.second.size() == pl || it->first.second[pl] == '|')))) {
             gauss_store_free(ctx, it->second.dev);
             it = g_resident.erase(it);

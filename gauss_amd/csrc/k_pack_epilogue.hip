@@ -535,12 +535,12 @@ __global__ __launch_bounds__(1024) void epilogue_kernel(const Prob* __restrict__
 void launch_epilogue(const Prob* d_probs, const int2* d_tilemap, int n_tiles, int max_pop, int dtype_i8, hipStream_t s)
 {
     if (n_tiles <= 0) return;
-    static std::atomic<unsigned long long> attr_set{0};
-    if (first_use_on_device(attr_set)) {
+    static DeviceOnce attr_once;
+    attr_once.run([&] {
         const int maxb = (int)((size_t)EPI_MAXP * TILE * (2 * sizeof(double) + 2 * sizeof(int)));
         hipFuncSetAttribute(reinterpret_cast<const void*>(epilogue_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, maxb);
         hipFuncSetAttribute(reinterpret_cast<const void*>(epilogue_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, maxb);
-    }
+    });
     const int cap = max_pop > EPI_MAXP ? EPI_MAXP : (max_pop < 1 ? 1 : max_pop);   // P > cap: tables stay in global memory
     const size_t smem = (size_t)cap * TILE * (2 * sizeof(double) + 2 * sizeof(int));
     if (dtype_i8) hipLaunchKernelGGL(epilogue_kernel<true>, dim3(n_tiles), dim3(1024), smem, s, d_probs, d_tilemap, cap);

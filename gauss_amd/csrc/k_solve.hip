@@ -952,12 +952,12 @@ void launch_factor_step(const Prob* d_probs, int n_prob, int step, int max_nblk,
 {
     if (n_prob <= 0 || step >= max_nblk) return;
     const size_t upd_smem = std::max(FACTOR_SMEM, SOLVE_SMEM);
-    static std::atomic<unsigned long long> attr_set{0};
-    if (first_use_on_device(attr_set)) {
+    static DeviceOnce attr_once;
+    attr_once.run([&] {
         hipFuncSetAttribute(reinterpret_cast<const void*>(factor_init_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FACTOR_SMEM);
         hipFuncSetAttribute(reinterpret_cast<const void*>(factor_panel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)upd_smem);
         hipFuncSetAttribute(reinterpret_cast<const void*>(factor_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)upd_smem);
-    }
+    });
     if (step == 0) {
         hipLaunchKernelGGL(factor_init_kernel, dim3(n_prob * 2), dim3(256), FACTOR_SMEM, st, d_probs);
         return;
@@ -1209,11 +1209,11 @@ __global__ __launch_bounds__(256) void impute_finish_kernel(const Prob* __restri
 void launch_impute_gemm(const Prob* d_probs, const int2* d_gmap, int n_tiles, int u_tile, const int2* d_fmap, int n_chunks, hipStream_t s)
 {
     if (n_tiles <= 0) return;
-    static std::atomic<unsigned long long> attr_set{0};
-    if (first_use_on_device(attr_set)) {
+    static DeviceOnce attr_once;
+    attr_once.run([&] {
         hipFuncSetAttribute(reinterpret_cast<const void*>(impute_gemm_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_SMEM);
         hipFuncSetAttribute(reinterpret_cast<const void*>(impute_gemm_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_SMEM);
-    }
+    });
     if (u_tile == 64) hipLaunchKernelGGL(impute_gemm_kernel<64>, dim3(n_tiles), dim3(256), GEMM_SMEM, s, d_probs, d_gmap);
     else hipLaunchKernelGGL(impute_gemm_kernel<128>, dim3(n_tiles), dim3(256), GEMM_SMEM, s, d_probs, d_gmap);
     hipLaunchKernelGGL(impute_finish_kernel, dim3(n_chunks), dim3(256), 0, s, d_probs, d_fmap);
@@ -1230,18 +1230,16 @@ void launch_shift_cert(const Prob* d_probs, int n_prob, hipStream_t st)
 void launch_solve(const Prob* d_probs, const int2* d_panelmap, int n_panels, hipStream_t s)
 {
     if (n_panels <= 0) return;
-    static std::atomic<unsigned long long> attr_set{0};
-    if (first_use_on_device(attr_set))
-        hipFuncSetAttribute(reinterpret_cast<const void*>(solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SOLVE_SMEM);
+    static DeviceOnce attr_once;
+    attr_once.run([&] { hipFuncSetAttribute(reinterpret_cast<const void*>(solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SOLVE_SMEM); });
     hipLaunchKernelGGL(solve_kernel, dim3(n_panels), dim3(256), SOLVE_SMEM, s, d_probs, d_panelmap);
 }
 
 void launch_solve_last(const Prob* d_probs, const int2* d_panelmap, int n_panels, int max_nblk, int split, hipStream_t s)
 {
     if (n_panels <= 0 || max_nblk < 1) return;
-    static std::atomic<unsigned long long> attr_set{0};
-    if (first_use_on_device(attr_set))
-        hipFuncSetAttribute(reinterpret_cast<const void*>(solve_last_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SOLVE_SMEM);
+    static DeviceOnce attr_once;
+    attr_once.run([&] { hipFuncSetAttribute(reinterpret_cast<const void*>(solve_last_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SOLVE_SMEM); });
     hipLaunchKernelGGL(solve_last_kernel, dim3(n_panels), dim3(256), SOLVE_SMEM, s, d_probs, d_panelmap, max_nblk - 1, split);
 }
 

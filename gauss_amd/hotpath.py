@@ -29,8 +29,20 @@ class Context:
         code = {"f32": _lib.GRAM_F32, "i8": _lib.GRAM_I8}[dtype] if isinstance(dtype, str) else int(dtype)
         check(self.lib.gauss_hip_set_gram_dtype(self.handle, code))
 
+    @property
+    def id(self):
+        """Process-unique id of the context (gauss_hip_context_id); 0 once closed."""
+        return int(self.lib.gauss_hip_context_id(self.handle)) if self.handle else 0
+
+    def trim_cache(self):
+        """Give the context's cached job workspaces back to the device; returns the bytes freed."""
+        n = C.c_int64()
+        check(self.lib.gauss_hip_trim_cache(self.handle, C.byref(n)))
+        return n.value
+
     def close(self):
         if self.handle:
+            # jobs and row stores that are still alive are released here (gauss_hip.h, lifetime rule)
             self.lib.gauss_hip_destroy(self.handle)
             self.handle = None
 
@@ -400,10 +412,9 @@ class Job:
 
     def close(self):
         if self.handle:
-            # a job must go before its context: if the context has been closed already (interpreter shutdown destroys
-            # objects in no particular order) the job's device blocks went with it and the handle must not be touched
-            if getattr(self.ctx, "handle", None):
-                self.ctx.lib.gauss_job_destroy(self.handle)
+            # safe in any order with the context (interpreter shutdown destroys objects in no particular order):
+            # gauss_hip_destroy leaves the jobs that outlive it as empty shells, which gauss_job_destroy frees
+            self.ctx.lib.gauss_job_destroy(self.handle)
             self.handle = None
 
     def __del__(self):

@@ -140,7 +140,28 @@ int gauss_hip_init(int device, gauss_ctx** out_ctx);
  * LOCAL_RANK modulo this), and the device index a context was created on. */
 int gauss_hip_device_count(int* out_n);
 int gauss_hip_device_of(const gauss_ctx* ctx);
+/* Lifetime rule.  A context may be destroyed while jobs (gauss_job_create) and row stores (gauss_store_upload) made on
+ * it are still alive: gauss_hip_destroy waits for their queued work, frees every device / pinned block they hold and
+ * leaves the job handles behind as empty shells.  After that
+ *   - gauss_job_destroy(job) is still required (it frees the shell) and is safe in any order with the context;
+ *   - every other call on such a job returns GAUSS_E_INVALID ("the job's context has been destroyed");
+ *   - device pointers returned by gauss_store_upload are dead; gauss_store_free on them must not be called.
+ * So the destructors of an Rcpp driver's RAII wrappers may run in whatever order an Rcpp::stop unwinds them
+ * (RcppExports.cpp:66,81: exceptions leave the driver through the generated try / catch).  Destroying a context
+ * must not race with calls that use it from other threads.  (Round 2 had no such rule: a job destroyed after its
+ * context wrote into the freed context -- the heap corruption behind the one process abort of that round.) */
 void gauss_hip_destroy(gauss_ctx* ctx);
+/* A number that identifies the context for the life of the process and is never reused (a pointer may be: a new
+ * context can land at a freed context's address).  Caches keyed per context key on this. */
+uint64_t gauss_hip_context_id(const gauss_ctx* ctx);
+/* fn(ctx, id, user) is called at the start of every gauss_hip_destroy, while the context is still whole: whoever
+ * caches device memory per context (libgauss_host's resident panels) releases it there.  Process-wide, idempotent. */
+int gauss_hip_add_destroy_hook(void (*fn)(gauss_ctx* ctx, uint64_t id, void* user), void* user);
+/* Freed job workspaces are kept per context for reuse (hipFree would stall a pipeline that retires job k while job
+ * k + 1 runs), up to a third of the device's memory.  Every allocation of the library flushes this cache and retries
+ * before it reports GAUSS_E_NOMEM; gauss_hip_trim_cache gives the memory back at once (it waits for the context's
+ * streams first), e.g. before another context or another library needs the device. */
+int gauss_hip_trim_cache(gauss_ctx* ctx, int64_t* out_bytes_freed);
 const char* gauss_last_error(void);
 const char* gauss_hip_version(void);
 

@@ -1,0 +1,103 @@
+"""C-ABI lifetime rule (include/gauss_hip.h): a context may be destroyed before the jobs and row stores made on it.
+
+Round 2 had no such rule and its one process abort came from exactly that order: a failing test kept a Job alive in its
+traceback, the session fixture closed the context, and at interpreter exit gauss_job_destroy wrote into the freed
+context (mutex, block maps) -- heap corruption, "dumped core".  The scenarios run in a child process so that a
+regression shows up as that child's exit status, not as the death of the test runner."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r"""
+import ctypes as C, sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+from gauss_amd import hotpath, synth, _lib
+
+pops = synth.pop_table(scale=0.02, min_size=30)[:6]
+rng = np.random.default_rng(5)
+bp = np.sort(rng.choice(np.arange(1, 200_000), size=260, replace=False))
+G, _ = synth.synth_genotypes(bp, pops, seed=3)
+G = G[G.min(1) != G.max(1)]
+off = synth.pop_offsets([p[1] for p in pops])
+w = rng.uniform(0.05, 0.3, len(pops))
+wins = []
+for m, u in ((70, 90), (64, 40)):
+    idx = rng.permutation(G.shape[0])
+    wins.append(dict(mode=1, geno_m=np.ascontiguousarray(G[np.sort(idx[:m])]), geno_u=np.ascontiguousarray(G[np.sort(idx[m:m + u])]),
+                     pop_off=off, pop_wgt=w, z1=rng.standard_normal(m)))
+
+ctx = hotpath.Context(0)
+ref_job = hotpath.Job(wins, ctx=ctx)
+ref_job.run()
+ref = ref_job.fetch()
+
+job = hotpath.Job(wins, ctx=ctx)          # two runs queued, none fetched
+job.run()
+job.run()
+store = hotpath.RowStore(G, ctx=ctx)      # a row store nobody frees
+lib = ctx.lib
+handle = job.handle
+ctx.close()                               # context first: waits for the runs, releases the job's blocks and the store
+rc = lib.gauss_job_run(handle)            # the handle is an empty shell now
+assert rc != 0 and b"context has been destroyed" in lib.gauss_last_error(), (rc, lib.gauss_last_error())
+assert lib.gauss_job_fetch(handle) != 0
+job.close()                               # frees the shell
+ref_job.close()
+store.ptr = None                          # its memory went with the context
+
+# a new context (possibly at the old one's address) starts clean and gives the same bits
+ctx2 = hotpath.Context(0)
+assert ctx2.id != 0
+j2 = hotpath.Job(wins, ctx=ctx2)
+j2.run()
+got = j2.fetch()
+for a, b in zip(got, ref):
+    assert np.array_equal(a["z"], b["z"]) and np.array_equal(a["info"], b["info"])
+freed = ctx2.trim_cache()
+assert freed >= 0
+j2.close()
+assert ctx2.trim_cache() > 0              # the job's workspace had gone to the cache
+ctx2.close()
+print("lifetime ok")
+"""
+
+
+@pytest.mark.gpu
+def test_context_destroyed_before_its_jobs_and_stores():
+    out = subprocess.run([sys.executable, "-c", CHILD % dict(root=ROOT)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, (out.returncode, out.stdout[-2000:], out.stderr[-4000:])
+    assert "lifetime ok" in out.stdout
+
+
+@pytest.mark.gpu
+def test_resident_panel_does_not_survive_its_context(tmp_path):
+    """the host layer's resident-panel cache was keyed by the context's address and never invalidated -- a
+    context created at a destroyed context's address inherited a device pointer that was not its own.  Keys are context
+    ids now and a destroy hook drops them: the second context uploads the panel again and returns the same table."""
+    from gauss_amd import api, hotpath
+    from test_farm import make_study, WGT
+    st = make_study(tmp_path)
+    p = st["paths"]
+    gpk = str(tmp_path / "panel.gpk")
+    assert api.pack_panel(p["index.gz"], p["data.gz"], p["desc.txt"], gpk) > 0
+    kw = dict(kind=api.KIND_DISTMIX, pop_wgt_df=WGT, window_size=500_000, chr=22, start_bp=1_000_001, end_bp=4_000_000,
+              wing_size=200_000, input_file=p["gwas.txt"], reference_data_file=gpk, reference_pop_desc_file=p["desc.txt"])
+    tables = []
+    ids = []
+    for _ in range(3):
+        c = hotpath.Context(0)
+        ids.append(c.id)
+        res = api.impute_chromosome(ctx=c, **kw)
+        assert res.stats["panel_bytes_uploaded"] > 0              # never inherited from a dead context
+        again = api.impute_chromosome(ctx=c, **kw)
+        assert again.stats["panel_bytes_uploaded"] == 0           # resident on this one
+        tables.append(res.columns["z"])
+        c.close()                                                 # no panel_evict: the destroy hook lets go of it
+    assert len(set(ids)) == 3
+    assert all(np.array_equal(t, tables[0]) for t in tables[1:])
