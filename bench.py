@@ -549,24 +549,47 @@ def pieces_equal_whole(parts, ref, wins):
 def pmc_traffic(applicable, kernel="gauss::gram_kernel<float>"):
     """HBM-side bytes per launch of the Gram kernel from the committed rocprofv3 PMC passes
     (profiles/*_pmc_traffic.csv: separate FETCH_SIZE / WRITE_SIZE runs of this same command, gfx950
-    correction applied).  PMC counters cannot be collected from inside the timed run, so the source file is
-    named next to the number; null when the run is not the profiled workload."""
+    correction applied).  PMC counters cannot be collected from inside the timed run, so the number is only quoted
+    while it describes the code that is running: the newest profile's recorded source hash
+    (profiles/<tag>_provenance.json, tools/summarize_profiles.py) must equal the hash compiled into the loaded
+    library (gauss_hip_source_hash); otherwise traffic is null and traffic_stale says why.  Null too when the run
+    is not the profiled workload."""
     import csv
     import glob
     if not applicable:
         return {"traffic": None, "traffic_source": None}
-    best, src = None, None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.csv"))):
-        for r in csv.DictReader(open(f)):
-            if r["kernel"] == kernel or r["kernel"] == kernel.split("<")[0]:
-                best, src = float(r["hbm_bytes_per_launch_corrected"]), os.path.relpath(f, ROOT)
-    return {"traffic": best, "traffic_source": src}
+    from gauss_amd import _lib
+    running = _lib.load().gauss_hip_source_hash().decode()
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.csv")))
+    if not files:
+        return {"traffic": None, "traffic_source": None}
+    f = files[-1]
+    src = os.path.relpath(f, ROOT)
+    profiled = None
+    try:
+        with open(f.replace("_pmc_traffic.csv", "_provenance.json")) as fh:
+            prov = json.load(fh)
+            profiled = prov.get("csrc_hash_of_loaded_library") or prov.get("csrc_hash")
+    except Exception:
+        pass
+    if profiled != running:
+        return {"traffic": None, "traffic_source": src, "traffic_stale": True,
+                "traffic_note": f"{src} was collected on sources {profiled or 'unknown (no provenance file)'}, this library is {running}: "
+                                "not quoted; re-collect with tools/collect_profiles.sh"}
+    best = None
+    for r in csv.DictReader(open(f)):
+        if r["kernel"] == kernel or r["kernel"] == kernel.split("<")[0]:
+            best = float(r["hbm_bytes_per_launch_corrected"])
+    return {"traffic": best, "traffic_source": src, "traffic_stale": False, "traffic_sources_hash": profiled}
 
 
 def cpu_baseline(ch, wins, keep0, work, mode=1):
-    """The loop-literal CPU oracle (1 thread, like the reference) on a bounded sample, scaled to
-    the workload by its pair count: the reference's cost is N inner iterations per SNP pair
-    (util.cpp:103-124), M(M+1)/2 + U + U*M pairs per window (distmix.cpp:180-217)."""
+    """The loop-literal CPU oracle (1 thread, like the reference) on a bounded sample, scaled to the workload in two
+    parts.  (1) The pair loops: the reference's cost is N inner iterations per SNP pair (util.cpp:103-124),
+    M(M+1)/2 + U + U*M pairs per window (distmix.cpp:180-217) -- the sample run's time, less its own dense tail, scaled
+    by the workload's pair count.  (2) The dense tail, MakePosDef's eigen-decomposition + InvMat's full-pivot LU
+    (util.cpp:298-318, cubic in M): timed at the sample's, the mean and the largest window's M, and summed over the
+    windows as c * M^3."""
     import oracle
     k0, gm, gu = keep0
     _, mi, ui = wins[k0]
@@ -579,9 +602,25 @@ def cpu_baseline(ch, wins, keep0, work, mode=1):
     oracle.run_impute(mode, gm_h, gu_h, ch["off"], ch["w"], z1)
     t = time.perf_counter() - t0
     m, u = gm_h.shape[0], gu_h.shape[0]
+
+    def dense_tail_s(size):
+        rng = np.random.default_rng(size)
+        x = rng.standard_normal((size, 2 * size))
+        a = np.corrcoef(x) + 0.1 * np.eye(size)                 # B11-shaped: a correlation matrix + lambda I (dist.cpp:172)
+        t1 = time.perf_counter()
+        a2, _ = oracle.make_pos_def(a)                          # util.cpp:302-318 (decomposes whether or not it clamps)
+        oracle.inv_mat(a2)                                      # util.cpp:298-300
+        return time.perf_counter() - t1
+
+    ms_all = np.array([len(a) for _, a, _ in wins], dtype=np.float64)
+    sizes = sorted({int(m), int(round(ms_all.mean())), int(ms_all.max())})
+    tails = {s: dense_tail_s(s) for s in sizes}
+    c3 = float(np.mean([tails[s] / s ** 3 for s in sizes]))
+    tail_total = float(c3 * np.sum(ms_all ** 3))
     pairs_sample = m * (m + 1) / 2 + u + u * m
     pairs_total = sum(len(a) * (len(a) + 1) / 2 + len(b) + len(a) * len(b) for _, a, b in wins)
-    est = t * pairs_total / pairs_sample
+    t_pairs = max(t - c3 * m ** 3, 0.5 * t)
+    est = t_pairs * pairs_total / pairs_sample + tail_total
     # what an R user could do with one process per window: the same sample on several cores at once
     # (threads here: the oracle is plain C behind ctypes, which releases the GIL)
     from concurrent.futures import ThreadPoolExecutor
@@ -590,15 +629,19 @@ def cpu_baseline(ch, wins, keep0, work, mode=1):
     with ThreadPoolExecutor(max_workers=par) as pool:
         list(pool.map(lambda _: oracle.run_impute(mode, gm_h, gu_h, ch["off"], ch["w"], z1), range(par)))
     tp = time.perf_counter() - t0
-    est_par = tp / par * pairs_total / pairs_sample
+    est_par = (tp / par) * (est / t)                            # same scaling, per-copy time under memory contention
     return {
         "value": work["imputed_snps"] / est, "unit": "imputed SNPs/s", "cores": 1, "kind": "port",
         "host_cores": os.cpu_count(),
         "windows_in_parallel": {"value": work["imputed_snps"] / est_par, "unit": "imputed SNPs/s", "cores": par,
                                 "sample": f"{par} concurrent copies of the same sample in {tp:.2f} s"},
+        "dense_tail": {"what": "orc_make_pos_def + orc_inv_mat (MakePosDef eigen-decomposition + InvMat full-pivot LU, util.cpp:298-318)",
+                       "seconds_at_M": {str(s): round(tails[s], 3) for s in sizes}, "seconds_per_M3": c3,
+                       "seconds_per_chromosome": round(tail_total, 1), "share_of_estimate": round(tail_total / est, 4)},
         "sample": f"oracle run_{'distmix' if mode else 'dist'} on a sub-window of window {k0} (M={m}, U={u}, N={N}): {t:.2f} s for "
-                  f"{pairs_sample:.0f} SNP pairs; scaled by the workload's {pairs_total:.3g} pairs "
-                  f"(estimated {est:.0f} s per chromosome, dense tail of the full-size windows not included)",
+                  f"{pairs_sample:.0f} SNP pairs, pair loops scaled by the workload's {pairs_total:.3g} pairs, plus the dense tail "
+                  f"timed at M = {', '.join(str(s) for s in sizes)} and summed over the {len(wins)} windows as c M^3 "
+                  f"({tail_total:.0f} s): estimated {est:.0f} s per chromosome",
     }
 
 

@@ -54,7 +54,7 @@ SYMBOLS = [
     "gauss_impute_window", "gauss_gene_ld_batch", "gauss_gram_counts", "gauss_job_create",
     "gauss_ld_rows", "gauss_gene_ld_batch_rows", "gauss_job_run", "gauss_job_fetch", "gauss_job_destroy", "gauss_job_span_ms", "gauss_job_profile",
     "gauss_job_profile_get", "gauss_job_work", "gauss_job_stats", "gauss_synth_device",
-    "gauss_hip_context_id", "gauss_hip_add_destroy_hook", "gauss_hip_trim_cache",
+    "gauss_hip_context_id", "gauss_hip_add_destroy_hook", "gauss_hip_trim_cache", "gauss_hip_source_hash",
 ]
 
 
@@ -73,6 +73,7 @@ def load():
             raise GaussHipError(f"libgauss_hip.so does not export {name}")
     lib.gauss_last_error.restype = C.c_char_p
     lib.gauss_hip_version.restype = C.c_char_p
+    lib.gauss_hip_source_hash.restype = C.c_char_p
     lib.gauss_hip_init.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
     lib.gauss_hip_device_count.argtypes = [C.POINTER(C.c_int)]
     lib.gauss_hip_device_of.argtypes = [C.c_void_p]

@@ -31,6 +31,30 @@ def _hipcc():
     raise RuntimeError("hipcc not found: libgauss_hip.so cannot be built")
 
 
+def source_hash():
+    """sha256 (first 16 hex digits) over the sources of libgauss_hip.so, names and contents: the identity that
+    profiles/*_provenance.json records and that bench.py compares before it quotes a profile-derived number."""
+    import hashlib
+    h = hashlib.sha256()
+    names = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp", ".h")))
+    for f in names + ["../../include/gauss_hip.h"]:
+        p = os.path.join(CSRC, f)
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(p, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def git_head():
+    try:
+        head = subprocess.check_output(["git", "-C", os.path.join(HERE, ".."), "rev-parse", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+        dirty = bool(subprocess.check_output(["git", "-C", os.path.join(HERE, ".."), "status", "--porcelain", "--untracked-files=no"],
+                                             stderr=subprocess.DEVNULL).decode().strip())
+        return head, dirty
+    except Exception:
+        return None, None
+
+
 def _newer(target, deps):
     if not os.path.exists(target):
         return True
@@ -57,9 +81,30 @@ def build_hip(force=False, verbose=False):
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             subprocess.check_call(cmd)
+    # the source hash is compiled into the library (gauss_hip_source_hash): one tiny unit, rebuilt when the hash changes
+    import json
+    sh = source_hash()
+    stamp_path = os.path.join(LIBDIR, "build_stamp.json")
+    try:
+        with open(stamp_path) as fh:
+            old = json.load(fh)
+    except Exception:
+        old = {}
+    vobj = os.path.join(OBJDIR, "gauss_version.o")
+    objs.append(vobj)
+    if force or old.get("csrc_hash") != sh or not os.path.exists(vobj):
+        vsrc = os.path.join(OBJDIR, "gauss_version.cpp")
+        with open(vsrc, "w") as fh:
+            fh.write('extern "C" const char* gauss_hip_source_hash(void) { return "%s"; }\n' % sh)
+        subprocess.check_call(["g++", "-O1", "-fPIC", "-c", vsrc, "-o", vobj])
     so = os.path.join(LIBDIR, "libgauss_hip.so")
     if force or _newer(so, objs):
         subprocess.check_call([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", so] + objs)
+    head, dirty = git_head()
+    if head is None:            # no git here (the GPU box): keep what the development container wrote for these sources
+        head, dirty = (old.get("git_head"), old.get("git_dirty")) if old.get("csrc_hash") == sh else (None, None)
+    with open(stamp_path, "w") as fh:
+        json.dump({"csrc_hash": sh, "git_head": head, "git_dirty": dirty}, fh)
     return so
 
 

@@ -29,6 +29,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <set>
 #include <string>
 #include <thread>
 #include <vector>
@@ -1882,9 +1883,12 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
         w.owner = 0; w.status = -1; w.M = (int)m; w.U = (int)u;
         wins.push_back(w);
     }
-    {   // farm.level_windows without the cuts: longest processing time first (ties by index), then a local search.
-        // A rank's load is the cost of its windows plus the factorisation chain of its tallest one (the chain is
-        // latency bound on the few windows a rank holds: DESIGN.md section 6; farm.CHAIN_STEP_COST, here per sample).
+    {   // Whole windows by longest processing time first (ties by index), then a local search -- the idea of
+        // farm.level_windows without the cuts, on a simpler cost model: a window costs its LD flops per sample (the
+        // Python planner also prices B11's factorisation and the per-SNP tail, so the two plans may pick different
+        // owners; each is used consistently by every rank of its own driver).  A rank's load is the cost of its windows
+        // plus the factorisation chain of its tallest one (the chain is latency bound on the few windows a rank
+        // holds: DESIGN.md section 6; farm.CHAIN_STEP_COST, here per sample).
         std::vector<int> order(wins.size());
         for (size_t i = 0; i < order.size(); i++) order[i] = (int)i;
         std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return wins[a].cost > wins[b].cost; });
@@ -1897,32 +1901,59 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
         double n_samples = 0;
         for (uint32_t q = 0; q < pk->header().n_pop; q++) n_samples += pk->pop((int)q).size;
         const double chain = 2.4e9 / std::max(1.0, n_samples);
-        auto load_of = [&](int r, int drop, int add) {            // rank r's load without window `drop`, with window `add`
-            double c = 0; int tall = 0;
+        // Local search of moves (a window of the fullest rank goes to another rank) and trades.  Per rank: the summed cost
+        // and the block counts of its windows (the chain term needs the tallest one, also "the tallest without window
+        // x"), so a candidate costs O(1); candidates are counted and the search stops at a fixed budget -- the same
+        // on every rank, which must all arrive at the same plan (no wall-clock limits) -- so a chromosome cut into
+        // thousands of windows plans in milliseconds too (it used to be cubic in the window count).
+        auto nblk = [&](int i) { return (wins[i].M + 63) / 64; };
+        std::vector<double> rcost((size_t)world, 0.0);
+        std::vector<std::multiset<int>> rtall((size_t)world);
+        std::vector<std::vector<int>> rwin((size_t)world);
+        auto rebuild = [&]() {
+            for (int r = 0; r < world; r++) { rcost[r] = 0; rtall[r].clear(); rwin[r].clear(); }
             for (size_t i = 0; i < wins.size(); i++) {
-                const bool in = ((int)i == add) || (wins[i].owner == r && (int)i != drop);
-                if (in) { c += wins[i].cost; tall = std::max(tall, (wins[i].M + 63) / 64); }
+                const int r = wins[i].owner;
+                rcost[r] += wins[i].cost; rtall[r].insert(nblk((int)i)); rwin[r].push_back((int)i);
             }
+        };
+        auto load_of = [&](int r, int drop, int add) {            // rank r's load without window `drop`, with window `add`
+            double c = rcost[r];
+            int tall = 0;
+            if (drop >= 0) {
+                c -= wins[drop].cost;
+                auto it = rtall[r].end();
+                if (!rtall[r].empty()) {
+                    --it;                                          // the tallest; if that is `drop` itself, the next one
+                    if (*it == nblk(drop)) { if (it != rtall[r].begin()) { --it; tall = *it; } }
+                    else tall = *it;
+                }
+            } else if (!rtall[r].empty()) tall = *rtall[r].rbegin();
+            if (add >= 0) { c += wins[add].cost; tall = std::max(tall, nblk(add)); }
             return c + chain * tall;
         };
-        for (size_t it = 0; world > 1 && it < 4 * wins.size(); it++) {
+        rebuild();
+        long long budget = 4000000;                                // candidate evaluations
+        for (size_t it = 0; world > 1 && it < 4 * wins.size() && budget > 0; it++) {
             int hi = 0; double top = -1;
             for (int r = 0; r < world; r++) { const double l = load_of(r, -1, -1); if (l > top) { top = l; hi = r; } }
             double best = top * (1 - 1e-9); int ba = -1, bb = -1, br = -1;
-            for (size_t a = 0; a < wins.size(); a++) {
-                if (wins[a].owner != hi) continue;
-                for (int r = 0; r < world; r++) {
+            for (int a : rwin[hi]) {
+                for (int r = 0; r < world && budget > 0; r++) {
                     if (r == hi) continue;
-                    for (int b = -1; b < (int)wins.size(); b++) {      // b = -1: move a to r; else trade a for b
-                        if (b >= 0 && wins[b].owner != r) continue;
-                        const double m = std::max(load_of(hi, (int)a, b), load_of(r, b, (int)a));
-                        if (m < best) { best = m; ba = (int)a; bb = b; br = r; }
+                    budget -= 1 + (long long)rwin[r].size();
+                    double m = std::max(load_of(hi, a, -1), load_of(r, -1, a));          // move a to r
+                    if (m < best) { best = m; ba = a; bb = -1; br = r; }
+                    for (int b2 : rwin[r]) {                                              // trade a for b2
+                        m = std::max(load_of(hi, a, b2), load_of(r, b2, a));
+                        if (m < best) { best = m; ba = a; bb = b2; br = r; }
                     }
                 }
             }
             if (ba < 0) break;
             wins[ba].owner = br;
             if (bb >= 0) wins[bb].owner = hi;
+            rebuild();
         }
     }
     std::vector<int> mine;

@@ -170,6 +170,31 @@ void packed_window_body(gauss_ctx* ctx, const uint8_t* mapped_rows, int64_t row_
   gauss_store_free(ctx, dev);
 }
 
+
+// ---- section 3b: handles that survive Rcpp::stop ----
+struct HipContext {
+  gauss_ctx* h = nullptr;
+  explicit HipContext(int device = 0) { if (gauss_hip_init(device, &h) != GAUSS_OK) Rcpp::stop(gauss_last_error()); }
+  ~HipContext() { gauss_hip_destroy(h); }
+  HipContext(const HipContext&) = delete;  HipContext& operator=(const HipContext&) = delete;
+};
+struct HipJob {
+  gauss_job* h = nullptr;
+  HipJob(gauss_ctx* ctx, const std::vector<gauss_window_desc>& wins) {
+    if (gauss_job_create(ctx, wins.data(), (int)wins.size(), 0, &h) != GAUSS_OK) Rcpp::stop(gauss_last_error());
+  }
+  ~HipJob() { gauss_job_destroy(h); }
+  void run()   { if (gauss_job_run(h)   != GAUSS_OK) Rcpp::stop(gauss_last_error()); }
+  void fetch() { if (gauss_job_fetch(h) != GAUSS_OK) Rcpp::stop(gauss_last_error()); }
+  HipJob(const HipJob&) = delete;  HipJob& operator=(const HipJob&) = delete;
+};
+void impute_windows(std::vector<gauss_window_desc>& wins) {
+  HipContext ctx;
+  HipJob job(ctx.h, wins);
+  job.run();
+  job.fetch();
+}
+
 // ---- section 5e: a whole chromosome per call (include/gauss_host.h) ----
 #include "gauss_host.h"
 struct ChromTable { std::vector<std::string> rsid; std::vector<int> bp, window; std::vector<double> z, info; };

@@ -1,7 +1,8 @@
 """Boil the rocprofv3 output of tools/collect_profiles.sh down to the small CSVs kept under profiles/.
 
 usage: summarize_profiles.py <tag> <dir>     (dir = gpurun_out/prof_<tag>)
-Writes <dir>/summary/{tag}_kernel_stats.csv, {tag}_pmc_traffic.csv, {tag}_bench_under_rocprof.json;
+Writes <dir>/summary/{tag}_kernel_stats.csv, {tag}_pmc_traffic.csv, {tag}_sq_mfma.csv, {tag}_bench_under_rocprof.json and
+{tag}_provenance.json (source hash + git head of the profiled code);
 copy those into profiles/ (tracked)."""
 import csv
 import glob
@@ -86,10 +87,39 @@ def sq_mfma(tag, d, out):
             fh.write(",".join(row) + "\n")
 
 
+def provenance(tag, out):
+    """Which code the profiles were taken on: the source hash compiled into the profiled library (gauss_hip_source_hash)
+    and the git head the development container recorded for those sources (gauss_amd/lib/build_stamp.json; the GPU box
+    has no .git).  bench.py quotes roofline.traffic from <tag>_pmc_traffic.csv only while this hash equals the hash of
+    the library it is running."""
+    import datetime
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    stamp = {}
+    try:
+        with open(os.path.join(root, "gauss_amd", "lib", "build_stamp.json")) as fh:
+            stamp = json.load(fh)
+    except Exception:
+        pass
+    try:
+        sys.path.insert(0, root)
+        from gauss_amd import _lib
+        stamp["csrc_hash_of_loaded_library"] = _lib.load().gauss_hip_source_hash().decode()
+    except Exception as ex:      # the summary can be rebuilt off the GPU box
+        stamp["csrc_hash_of_loaded_library"] = None
+    stamp["tag"] = tag
+    stamp["collected_utc"] = datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%M:%SZ")
+    stamp["commands"] = "tools/collect_profiles.sh " + tag
+    with open(os.path.join(out, f"{tag}_provenance.json"), "w") as fh:
+        json.dump(stamp, fh, indent=1)
+    return stamp
+
+
 def main():
     tag, d = sys.argv[1], sys.argv[2]
     out = os.path.join(d, "summary")
     os.makedirs(out, exist_ok=True)
+    stamp = provenance(tag, out)
     ks = find(os.path.join(d, "stats"), "*kernel_stats.csv")
     if ks:
         shutil.copy(ks, os.path.join(out, f"{tag}_kernel_stats.csv"))
@@ -102,12 +132,12 @@ def main():
     fetch = pmc(os.path.join(d, "pmc_fetch"), "FETCH_SIZE")
     write = pmc(os.path.join(d, "pmc_write"), "WRITE_SIZE")
     with open(os.path.join(out, f"{tag}_pmc_traffic.csv"), "w") as fh:
-        fh.write("kernel,launches,FETCH_SIZE_KB_avg,WRITE_SIZE_KB_avg,hbm_bytes_per_launch_corrected\n")
+        fh.write("kernel,launches,FETCH_SIZE_KB_avg,WRITE_SIZE_KB_avg,hbm_bytes_per_launch_corrected,csrc_hash\n")
         for k in sorted(set(fetch) | set(write)):
             fa = sum(fetch[k]) / max(1, len(fetch[k]))
             wa = sum(write[k]) / max(1, len(write[k]))
             # gfx950: FETCH_SIZE under-counts wide coalesced reads by 2x (MI355X_MICROARCH.md, HBM section)
-            fh.write(f"{k},{max(len(fetch[k]), len(write[k]))},{fa:.1f},{wa:.1f},{int((2 * fa + wa) * 1024)}\n")
+            fh.write(f"{k},{max(len(fetch[k]), len(write[k]))},{fa:.1f},{wa:.1f},{int((2 * fa + wa) * 1024)},{stamp.get('csrc_hash') or ''}\n")
     sq_mfma(tag, d, out)
     print("summaries in", out, os.listdir(out))
 
