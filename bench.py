@@ -57,7 +57,7 @@ def parse_args(argv=None):
     ap.add_argument("--gram-dtype", choices=["f32", "i8"], default="f32",
                     help="LD Gram arithmetic of the headline run (f32 MFMA = north star; i8 MFMA = exact fast variant)")
     ap.add_argument("--no-i8-variant", action="store_true", help="skip the extra timing of the exact int8 variant")
-    ap.add_argument("--mode", choices=["distmix", "dist", "computeLD", "jepegmix", "e2e"], default="distmix",
+    ap.add_argument("--mode", choices=["distmix", "dist", "computeLD", "jepegmix", "e2e", "window"], default="distmix",
                     help="distmix = BASELINE configs[3], the headline; the others are the remaining configs / the file-to-table run")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
     ap.add_argument("--shard", choices=["leveled", "contiguous", "lpt"], default="leveled",
@@ -674,7 +674,7 @@ def main(argv=None):
         if args.mode == "e2e":
             out = benchmodes.run_e2e(args, rig)
         else:
-            out, sample = {"computeLD": benchmodes.run_computeld, "jepegmix": benchmodes.run_jepegmix}[args.mode](args, rig)
+            out, sample = {"computeLD": benchmodes.run_computeld, "jepegmix": benchmodes.run_jepegmix, "window": benchmodes.run_window}[args.mode](args, rig)
             if out is not None and sample is not None and not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline_computeld(sample)
             if out is not None:
