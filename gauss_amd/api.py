@@ -38,7 +38,7 @@ HOST_SYMBOLS = [
     "gauss_prepared_geno_u", "gauss_prepared_pop_off", "gauss_prepared_pop_wgt", "gauss_prepared_z1",
     "gauss_prepared_gene_off", "gauss_prepared_window_desc", "gauss_prepared_finish", "gauss_prepared_free",
     "gauss_host_bgzf_copy", "gauss_host_set_threads",
-    "gauss_host_panel_resident", "gauss_host_panel_evict", "gauss_host_impute_chromosome", "gauss_table_n_messages",
+    "gauss_host_panel_resident", "gauss_host_panel_evict", "gauss_host_impute_chromosome", "gauss_host_panel_cache", "gauss_table_n_messages",
     "gauss_table_message", "gauss_table_strcol_fixed", "gauss_host_panel_device_rows", "gauss_prepared_store_rows",
     "gauss_host_jepeg_gene_tail",
 ]
@@ -139,8 +139,9 @@ def load_host():
     h.gauss_host_panel_device_rows.argtypes = [_vp, _cp, C.POINTER(C.c_void_p)]
     ipp = C.POINTER(C.POINTER(C.c_int32))
     h.gauss_prepared_store_rows.argtypes = [_vp, ipp, ipp, ipp, C.POINTER(C.c_int)]
-    h.gauss_host_impute_chromosome.argtypes = [_vp, C.c_int, C.c_int, _i64, _i64, _i64, _i64, _cp, _strs, _dp, C.c_int, _cp, _cp, _cp,
+    h.gauss_host_impute_chromosome.argtypes = [_vp, C.c_int, C.c_int, _i64, _i64, _i64, _i64, _cp, _strs, _dp, C.c_int, _cp, _cp, _cp, _cp,
                                                _dbl, C.c_int, C.c_int, C.c_int, C.POINTER(_vp), C.POINTER(ChromStats)]
+    h.gauss_host_panel_cache.argtypes = [_cp, _cp, _cp, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int64)]
     h.gauss_table_n_messages.argtypes = [_vp]
     h.gauss_table_message.restype = _cp
     h.gauss_table_message.argtypes = [_vp, C.c_int]
@@ -438,18 +439,32 @@ def panel_evict(packed_file=None, ctx=None):
     _hcheck(load_host().gauss_host_panel_evict(_ctx(ctx), _enc(packed_file)))
 
 
+def panel_cache(reference_index_file, reference_data_file, reference_pop_desc_file, create=True):
+    """The packed form of a text panel in the panel cache (gauss_host_panel_cache): (path, SNPs packed by this call),
+    or (None, 0) when there is none and create is False."""
+    buf = C.create_string_buffer(4096)
+    n = C.c_int64()
+    rc = load_host().gauss_host_panel_cache(_enc(reference_index_file), _enc(reference_data_file), _enc(reference_pop_desc_file),
+                                            1 if create else 0, buf, len(buf), C.byref(n))
+    if rc < 0:
+        _hcheck(rc)
+    return (buf.value.decode(), n.value) if rc == 0 else (None, 0)
+
+
 def impute_chromosome(kind, chr, start_bp, end_bp, wing_size, input_file, reference_data_file, reference_pop_desc_file,
                       study_pop=None, pop_wgt_df=None, af1_cutoff=None, window_size=1_000_000, rank=0, world=1, n_batches=0,
-                      ctx=None):
+                      ctx=None, reference_index_file=None):
     """dist / distmix / qcat / qcatmix over every window of [start_bp, end_bp] as ONE native call
     (gauss_host_impute_chromosome): windows sharded over `world` ranks, this rank's windows pipelined through the
-    GPU in batches against the resident packed panel.  Returns a ChromResult."""
+    GPU in batches against the resident packed panel.  reference_data_file: a packed panel, or the reference's BGZF
+    text panel together with reference_index_file (packed on first use into the panel cache).  Returns a ChromResult."""
     h = load_host()
     names, w, n = (None, None, 0) if pop_wgt_df is None else _pop_wgt(pop_wgt_df)
     out, st = _vp(), ChromStats()
     _hcheck(h.gauss_host_impute_chromosome(_ctx(ctx), int(kind), int(chr), int(start_bp), int(end_bp), int(wing_size),
                                            int(window_size), _enc(study_pop), names, None if w is None else w.ctypes.data_as(_dp), n,
-                                           _enc(input_file), _enc(reference_data_file), _enc(reference_pop_desc_file),
+                                           _enc(input_file), _enc(reference_index_file), _enc(reference_data_file),
+                                           _enc(reference_pop_desc_file),
                                            _af(af1_cutoff), int(rank), int(world), int(n_batches), C.byref(out), C.byref(st)))
     cols = _columns(h, out)
     windows = _named(h, out)["windows"]

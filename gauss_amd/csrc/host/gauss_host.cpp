@@ -35,6 +35,10 @@
 #include <vector>
 
 #include <sys/stat.h>
+#include <sys/file.h>
+#include <fcntl.h>
+#include <unistd.h>
+#include <cerrno>
 
 #include <mutex>
 
@@ -625,6 +629,92 @@ static std::shared_ptr<PackedPanel> open_packed_shared(const std::string& path, 
     if (!sp->open(path, err)) return nullptr;
     cache[k] = sp;
     return sp;
+}
+
+// ------------------------------------------------------------------------------------------
+// Packed-panel cache ("auto-pack on first use").  The reference's panel is three files (BGZF index, BGZF data,
+// population description: gauss.cpp:293-399, 720-785); the packed panel made from them lives in a cache directory
+// under a name that carries the identity (path, size, mtime) of all three, so a changed panel is packed again and a
+// stale file is never picked up.  Directory: $GAUSS_PANEL_CACHE, else ".gauss_panel_cache" beside the data file, else
+// (read-only panel directory) /tmp/gauss_panel_cache_<uid>.  Several processes may ask at once (one rank per GPU):
+// the first one packs under an flock, the others wait for it; the file appears by rename, never half written.
+// ------------------------------------------------------------------------------------------
+static std::string file_identity(const std::string& path)
+{
+    struct stat st;
+    if (stat(path.c_str(), &st) != 0) return path + "|missing";
+    char buf[96];
+    snprintf(buf, sizeof(buf), "|%lld|%lld.%09ld", (long long)st.st_size, (long long)st.st_mtim.tv_sec, (long)st.st_mtim.tv_nsec);
+    char real[4096];
+    const char* rp = realpath(path.c_str(), real);
+    return std::string(rp ? rp : path.c_str()) + buf;
+}
+
+static bool dir_usable(const std::string& d)
+{
+    if (mkdir(d.c_str(), 0777) != 0 && errno != EEXIST) return false;
+    return access(d.c_str(), W_OK | X_OK) == 0;
+}
+
+// 0: `out` names a packed panel (the data file itself if it already is one).  1: no cached panel and create == false.
+// -1: error (message in err).
+static int resolve_packed_panel(const std::string& index_file, const std::string& data_file, const std::string& desc_file,
+                                bool create, std::string& out, std::string& err, int64_t* packed_now = nullptr)
+{
+    if (packed_now) *packed_now = 0;
+    if (PackedPanel::is_packed(data_file)) { out = data_file; return 0; }
+    const std::string ident = file_identity(index_file) + "\n" + file_identity(data_file) + "\n" + file_identity(desc_file);
+    uint64_t h1 = 1469598103934665603ull, h2 = 0x9E3779B97F4A7C15ull;           // two FNV-1a style lanes: a 128-bit name
+    for (unsigned char c : ident) { h1 = (h1 ^ c) * 1099511628211ull; h2 = (h2 ^ (c + 0x5Bu)) * 0x100000001B3ull; h2 ^= h2 >> 29; }
+    char hex[40];
+    snprintf(hex, sizeof(hex), "%016llx%016llx", (unsigned long long)h1, (unsigned long long)h2);
+    std::string base = data_file;
+    const size_t slash = base.find_last_of('/');
+    const std::string dir_of_data = slash == std::string::npos ? "." : base.substr(0, slash);
+    if (slash != std::string::npos) base = base.substr(slash + 1);
+    std::vector<std::string> dirs;
+    if (const char* e = getenv("GAUSS_PANEL_CACHE")) dirs.push_back(e);
+    else { dirs.push_back(dir_of_data + "/.gauss_panel_cache"); dirs.push_back("/tmp/gauss_panel_cache_" + std::to_string((long)getuid())); }
+    // an existing entry anywhere on the list wins
+    for (const std::string& d : dirs) {
+        const std::string p = d + "/" + base + "." + hex + ".gpk";
+        if (PackedPanel::is_packed(p)) { out = p; return 0; }
+    }
+    if (!create) return 1;
+    for (const std::string& d : dirs) {
+        if (!dir_usable(d)) continue;
+        const std::string p = d + "/" + base + "." + hex + ".gpk";
+        const std::string lockp = p + ".lock";
+        const int fd = open(lockp.c_str(), O_CREAT | O_RDWR, 0666);
+        if (fd < 0) continue;
+        if (flock(fd, LOCK_EX) != 0) { close(fd); continue; }
+        int rc = 0;
+        if (!PackedPanel::is_packed(p)) {                                 // nobody packed it while we waited for the lock
+            const std::string tmp = p + ".tmp." + std::to_string((long)getpid());
+            const int64_t n = gauss_host::pack_panel(index_file, data_file, desc_file, tmp, err);
+            if (n < 0) { unlink(tmp.c_str()); rc = -1; }
+            else if (rename(tmp.c_str(), p.c_str()) != 0) { err = "ERROR: can't move the packed panel into the cache: " + p; unlink(tmp.c_str()); rc = -1; }
+            else if (packed_now) *packed_now = n;
+        }
+        flock(fd, LOCK_UN);
+        close(fd);
+        unlink(lockp.c_str());
+        if (rc) return rc;
+        out = p;
+        return 0;
+    }
+    err = "ERROR: no writable directory for the packed-panel cache (set GAUSS_PANEL_CACHE)";
+    return -1;
+}
+
+// The policy of the entry points.  GAUSS_AUTO_PACK=0: never look at the cache.  GAUSS_AUTO_PACK=1: pack on first use,
+// everywhere.  Unset: a one-window entry point uses a cached panel when one exists but does not make one (packing a
+// genome-wide panel takes minutes; one window from the text files takes a second), the chromosome driver -- which needs
+// the packed form -- packs on first use.
+static int auto_pack_mode()
+{
+    const char* e = getenv("GAUSS_AUTO_PACK");
+    return e ? (atoi(e) != 0 ? 1 : 0) : -1;
 }
 
 static int panel_make_resident(gauss_ctx* ctx, const std::string& path, void** dev, int64_t* uploaded);
@@ -1219,6 +1309,19 @@ int64_t gauss_host_pack_panel(const char* index_file, const char* data_file, con
     return n;
 }
 
+int gauss_host_panel_cache(const char* index_file, const char* data_file, const char* desc_file, int create,
+                           char* out_path, int out_len, int64_t* snps_packed_now)
+{
+    if (!index_file || !data_file || !desc_file || !out_path || out_len < 2) return herr("bad arguments");
+    std::string out, err;
+    const int rc = resolve_packed_panel(index_file, data_file, desc_file, create != 0, out, err, snps_packed_now);
+    if (rc < 0) return herr("%s", err.c_str());
+    if (rc == 1) { out_path[0] = 0; return 1; }
+    if ((int)out.size() + 1 > out_len) return herr("path buffer too small for '%s'", out.c_str());
+    memcpy(out_path, out.c_str(), out.size() + 1);
+    return 0;
+}
+
 void gauss_host_set_threads(int n) { g_host_threads = n < 1 ? 1 : (n > 64 ? 64 : n); }
 
 int gauss_host_prepare(int kind, int chr, int64_t start_bp, int64_t end_bp, int64_t wing_size, const char* study_pop,
@@ -1238,6 +1341,14 @@ int gauss_host_prepare(int kind, int chr, int64_t start_bp, int64_t end_bp, int6
     a.input_file = input_file; a.reference_index_file = reference_index_file;
     a.reference_data_file = reference_data_file; a.reference_pop_desc_file = reference_pop_desc_file;
     if (annotation_file) a.annotation_file = annotation_file;
+    if (auto_pack_mode() != 0 && !PackedPanel::is_packed(a.reference_data_file)) {
+        // text panel: the cached packed form, if there is one (GAUSS_AUTO_PACK=1: made now)
+        std::string cached, err;
+        const int rc = resolve_packed_panel(a.reference_index_file, a.reference_data_file, a.reference_pop_desc_file,
+                                            auto_pack_mode() == 1, cached, err);
+        if (rc < 0) return herr("%s", err.c_str());
+        if (rc == 0) a.reference_data_file = cached;
+    }
     if (PackedPanel::is_packed(a.reference_data_file)) {
         // a packed panel replaces both the index and the data file (reference_index_file is not opened)
         std::string err;
@@ -1501,6 +1612,13 @@ int gauss_host_prep_zmix5(gauss_ctx* ctx, const char* input_file, const char* re
     a.reference_data_file = reference_data_file; a.reference_pop_desc_file = reference_pop_desc_file;
     const double pct = std::isnan(percentile) ? 0.99 : percentile;            // zmix.cpp:57-61
     const int step = interval > 0 ? interval : 1;                             // zmix.cpp:63-67
+    if (auto_pack_mode() != 0 && !PackedPanel::is_packed(a.reference_data_file)) {
+        std::string cached, err;
+        const int rc = resolve_packed_panel(a.reference_index_file, a.reference_data_file, a.reference_pop_desc_file,
+                                            auto_pack_mode() == 1, cached, err);
+        if (rc < 0) return herr("%s", err.c_str());
+        if (rc == 0) a.reference_data_file = cached;
+    }
     if (PackedPanel::is_packed(a.reference_data_file)) {
         std::string err;
         a.pk = open_packed_shared(a.reference_data_file, err);
@@ -1842,16 +1960,29 @@ int gauss_host_panel_evict(gauss_ctx* ctx, const char* packed_file)
 // ------------------------------------------------------------------------------------------
 int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t start_bp, int64_t end_bp, int64_t wing_size,
                                  int64_t window_size, const char* study_pop, const char* const* pop_names,
-                                 const double* pop_wgts, int n_pop_wgt, const char* input_file,
-                                 const char* reference_data_file, const char* reference_pop_desc_file, double af1_cutoff,
+                                 const double* pop_wgts, int n_pop_wgt, const char* input_file, const char* reference_index_file,
+                                 const char* reference_data_file_in, const char* reference_pop_desc_file, double af1_cutoff,
                                  int rank, int world, int n_batches, gauss_table** out, gauss_chrom_stats* stats)
 {
-    if (!ctx || !out || !input_file || !reference_data_file || !reference_pop_desc_file) return herr("bad arguments");
+    if (!ctx || !out || !input_file || !reference_data_file_in || !reference_pop_desc_file) return herr("bad arguments");
+    // the reference's own panel format is accepted: its packed form is made on first use and kept in the panel cache
+    std::string packed_path;
+    double t_autopack = 0;
+    if (!PackedPanel::is_packed(reference_data_file_in)) {
+        if (auto_pack_mode() == 0 || !reference_index_file)
+            return herr("gauss_host_impute_chromosome needs a packed panel (gauss_host_pack_panel), or the text panel's index file "
+                        "with GAUSS_AUTO_PACK not 0");
+        const double t0 = now_s();
+        std::string err;
+        if (resolve_packed_panel(reference_index_file, reference_data_file_in, reference_pop_desc_file, true, packed_path, err) != 0)
+            return herr("%s", err.c_str());
+        t_autopack = now_s() - t0;
+    } else packed_path = reference_data_file_in;
+    const char* reference_data_file = packed_path.c_str();
     if (kind != GAUSS_KIND_DIST && kind != GAUSS_KIND_DISTMIX && kind != GAUSS_KIND_QCAT && kind != GAUSS_KIND_QCATMIX)
         return herr("gauss_host_impute_chromosome: kind must be dist, distmix, qcat or qcatmix");
     if (window_size < 1 || end_bp < start_bp || world < 1 || rank < 0 || rank >= world) return herr("bad window / rank arguments");
-    if (!PackedPanel::is_packed(reference_data_file)) return herr("gauss_host_impute_chromosome needs a packed panel (gauss_host_pack_panel)");
-    const double t_begin = now_s();
+    const double t_begin = now_s() - t_autopack;
     gauss_chrom_stats st;
     memset(&st, 0, sizeof(st));
 

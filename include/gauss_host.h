@@ -154,6 +154,16 @@ int gauss_host_prep_zmix5(gauss_ctx* ctx, const char* input_file, const char* re
  * Returns the number of SNPs packed or -1. */
 int64_t gauss_host_pack_panel(const char* reference_index_file, const char* reference_data_file,
                               const char* reference_pop_desc_file, const char* out_file);
+/* The packed-panel cache ("auto-pack on first use").  The packed form of a text panel lives in a cache directory
+ * ($GAUSS_PANEL_CACHE, else ".gauss_panel_cache" beside the data file, else /tmp/gauss_panel_cache_<uid>) under a name that
+ * carries path, size and mtime of all three panel files.  Returns 0 and the packed panel's path in out_path (the data file
+ * itself when it is packed already; *snps_packed_now > 0 when this call made it), 1 when there is no cached panel and
+ * create == 0, -1 on error.  Concurrent callers (one rank per GPU) are serialised by a lock file; the panel appears by
+ * rename.  Policy of the entry points, env GAUSS_AUTO_PACK: 0 = never use the cache; 1 = pack on first use everywhere;
+ * unset = the one-window entry points use a cached panel when one exists, gauss_host_impute_chromosome makes it. */
+int gauss_host_panel_cache(const char* reference_index_file, const char* reference_data_file,
+                           const char* reference_pop_desc_file, int create, char* out_path, int out_len,
+                           int64_t* snps_packed_now);
 /* For a prepared window that reads a packed panel: the panel's genotype section (host pointer into the
  * mmap), its size and row stride, so a harness can upload it once with gauss_store_upload and run its
  * windows with on_device = 1.  base = NULL for byte-matrix windows. */
@@ -188,15 +198,16 @@ typedef struct gauss_chrom_stats {
  * caller-level loop the reference leaves to the R user (one R call = one window, dist.cpp:30-126) -- as one native
  * call per rank.  Windows are sharded over `world` ranks by LPT on their LD flops (the same plan on every rank,
  * no communication); this rank's windows run as a pipeline of n_batches jobs (<= 0: chosen here): host threads
- * prepare batch b+1 and build the tables of batch b-1 while the GPU works on batch b.  reference_data_file must
- * be a packed panel; it is made resident on first use.  The result holds the reference's output table of every
+ * prepare batch b+1 and build the tables of batch b-1 while the GPU works on batch b.  reference_data_file is a packed
+ * panel (reference_index_file may then be NULL) or the reference's BGZF text panel (gauss.cpp:293-399, 720-785), whose
+ * packed form is made on first use and kept in the panel cache (gauss_host_panel_cache); it is made resident on first use.  The result holds the reference's output table of every
  * window of this rank in window order, an extra int column "window", a named matrix "windows"
  * [n_windows x 6: start_bp end_bp owner status measured unmeasured; status 0 done, 1 skipped by the ">10" guards
  * (dist.cpp:145-151), 2 failed, -1 another rank's] and one message per failed window (gauss_table_message):
  * a window that fails never takes the others with it. */
 int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t start_bp, int64_t end_bp, int64_t wing_size,
                                  int64_t window_size, const char* study_pop, const char* const* pop_names,
-                                 const double* pop_wgts, int n_pop_wgt, const char* input_file,
+                                 const double* pop_wgts, int n_pop_wgt, const char* input_file, const char* reference_index_file,
                                  const char* reference_data_file, const char* reference_pop_desc_file, double af1_cutoff,
                                  int rank, int world, int n_batches, gauss_table** out, gauss_chrom_stats* stats);
 /* The host part of jepeg()/jepegmix() for ONE gene, given the CorG block the GPU produced (diagonal 1 + lambda):

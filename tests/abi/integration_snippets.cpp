@@ -206,7 +206,7 @@ ChromTable distmix_chromosome_body(int chr, long long start_bp, long long end_bp
   gauss_table* t = nullptr;
   gauss_chrom_stats st;
   if (gauss_host_impute_chromosome(gauss_hip_ctx(), GAUSS_KIND_DISTMIX, chr, start_bp, end_bp, wing_size, window_size, NULL,
-                                   np.data(), wgts.data(), (int)np.size(), input_file.c_str(), packed_panel.c_str(), desc.c_str(),
+                                   np.data(), wgts.data(), (int)np.size(), input_file.c_str(), /*index: only for a text panel*/NULL, packed_panel.c_str(), desc.c_str(),
                                    NAN, /*rank*/0, /*world*/1, /*n_batches*/0, &t, &st) != 0)
     Rcpp::stop(gauss_host_last_error());
   ChromTable out;

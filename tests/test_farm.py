@@ -358,3 +358,34 @@ def test_bench_pieces_are_put_together_per_window():
     lap = [dict(p) for p in parts]
     lap[2][(2, 10, 44)] = (ref[2]["z"][10:44], ref[2]["info"][10:44])
     assert not bench.pieces_equal_whole(lap, ref, wins)                 # pieces overlap
+
+
+@pytest.mark.gpu
+def test_gpu_native_chromosome_accepts_the_text_panel(ctx, tmp_path, monkeypatch):
+    """The chromosome driver takes the reference's own panel format (BGZF index + data, gauss.cpp:293-399, 720-785):
+    the packed form is made on first use in the panel cache, found again afterwards, and the table equals the one from
+    a panel packed by hand; GAUSS_AUTO_PACK=0 restores the refusal."""
+    st = make_study(tmp_path)
+    p = st["paths"]
+    monkeypatch.setenv("GAUSS_PANEL_CACHE", str(tmp_path / "cache"))
+    monkeypatch.delenv("GAUSS_AUTO_PACK", raising=False)
+    gpk = str(tmp_path / "panel.gpk")
+    api.pack_panel(p["index.gz"], p["data.gz"], p["desc.txt"], gpk)
+    kw = dict(kind=api.KIND_DISTMIX, pop_wgt_df=WGT, window_size=500_000, chr=22, start_bp=1_000_001, end_bp=4_000_000,
+              wing_size=200_000, input_file=p["gwas.txt"], reference_pop_desc_file=p["desc.txt"], ctx=ctx)
+    want = api.impute_chromosome(reference_data_file=gpk, **kw)
+    assert api.panel_cache(p["index.gz"], p["data.gz"], p["desc.txt"], create=False) == (None, 0)
+    got = api.impute_chromosome(reference_index_file=p["index.gz"], reference_data_file=p["data.gz"], **kw)
+    cached, made_now = api.panel_cache(p["index.gz"], p["data.gz"], p["desc.txt"], create=False)
+    assert cached is not None and made_now == 0
+    again = api.impute_chromosome(reference_index_file=p["index.gz"], reference_data_file=p["data.gz"], **kw)
+    assert again.stats["panel_bytes_uploaded"] == 0              # the cached panel is resident since the first call
+    for r in (got, again):
+        assert list(r.columns) == list(want.columns)
+        for c in want.columns:
+            assert np.array_equal(r.columns[c], want.columns[c]), c
+    monkeypatch.setenv("GAUSS_AUTO_PACK", "0")
+    with pytest.raises(Exception) as ei:
+        api.impute_chromosome(reference_index_file=p["index.gz"], reference_data_file=p["data.gz"], **kw)
+    assert "packed panel" in str(ei.value)
+    api.panel_evict(ctx=ctx)

@@ -497,3 +497,65 @@ def test_corrupt_packed_panels_are_refused_not_read(study, packed, tmp_path):
         with pytest.raises(api.GaussError):
             api.Prepared(api.KIND_DIST, chr=22, start_bp=1_400_000, end_bp=2_000_000, wing_size=250_000, study_pop="EUR",
                          input_file=inp, reference_index_file=idx, reference_data_file=str(path), reference_pop_desc_file=desc)
+
+
+def test_panel_cache_packs_once_and_keys_on_file_identity(tmp_path, monkeypatch):
+    """Auto-pack on first use (gauss_host_panel_cache): the text panel's packed form is made once, found again, made
+    again when a panel file changes, never picked up for a different panel; a one-window entry point uses the cached
+    panel when one exists (GAUSS_AUTO_PACK unset) and hands on exactly what the text feeder hands on."""
+    import shutil
+    import time as _t
+    (tmp_path / "s").mkdir()
+    st = panel.make_synthetic_study(str(tmp_path / "s"), [("AAA", 60, "EUR"), ("BBB", 45, "EUR"), ("CCC", 50, "ASN")], n_snp=260,
+                                    bp_lo=1_000_000, bp_hi=2_000_000, frac_measured=0.3, seed=4)
+    p = st["paths"]
+    cache = tmp_path / "cache"
+    monkeypatch.setenv("GAUSS_PANEL_CACHE", str(cache))
+    monkeypatch.delenv("GAUSS_AUTO_PACK", raising=False)
+    assert api.panel_cache(p["index.gz"], p["data.gz"], p["desc.txt"], create=False) == (None, 0)
+    kw = dict(chr=22, start_bp=1_200_000, end_bp=1_800_000, wing_size=150_000, study_pop="EUR", input_file=p["gwas.txt"],
+              reference_index_file=p["index.gz"], reference_data_file=p["data.gz"], reference_pop_desc_file=p["desc.txt"])
+    text = api.Prepared(api.KIND_DIST, **kw)                      # no cache entry yet: the text feeder
+    assert text.packed_store() is None
+    path, n = api.panel_cache(p["index.gz"], p["data.gz"], p["desc.txt"])
+    assert n == 260 and os.path.dirname(path) == str(cache) and os.path.basename(path).startswith(os.path.basename(p["data.gz"]) + ".")
+    assert api.panel_cache(p["index.gz"], p["data.gz"], p["desc.txt"]) == (path, 0)          # found, not made again
+    assert api.panel_cache("(unused)", path, p["desc.txt"]) == (path, 0)                      # a packed panel is its own cache entry
+    cached = api.Prepared(api.KIND_DIST, **kw)                    # same arguments: now through the cached packed panel
+    assert cached.packed_store() is not None
+    _same_prepared(text, cached, window=(kw["start_bp"], kw["end_bp"]))
+    monkeypatch.setenv("GAUSS_AUTO_PACK", "0")
+    again = api.Prepared(api.KIND_DIST, **kw)                     # the cache is ignored on request
+    assert again.packed_store() is None
+    monkeypatch.delenv("GAUSS_AUTO_PACK")
+    for q in (text, cached, again):
+        q.close()
+    # another panel (a copy with another mtime is another identity) gets its own entry
+    other = tmp_path / "other"
+    other.mkdir()
+    for f in ("index.gz", "data.gz", "desc.txt"):
+        shutil.copy(p[f], other / os.path.basename(p[f]))
+    _t.sleep(0.01)
+    os.utime(other / os.path.basename(p["data.gz"]), None)
+    path2, n2 = api.panel_cache(*(str(other / os.path.basename(p[f])) for f in ("index.gz", "data.gz", "desc.txt")))
+    assert n2 == 260 and path2 != path
+    assert len([f for f in os.listdir(cache) if f.endswith(".gpk")]) == 2 and not [f for f in os.listdir(cache) if ".tmp." in f or f.endswith(".lock")]
+
+
+def test_panel_cache_concurrent_callers_pack_once(tmp_path):
+    """One rank per GPU asks for the same panel at the same moment: one of them packs (under the lock file), the
+    others wait and find it."""
+    import subprocess
+    import sys
+    (tmp_path / "s").mkdir()
+    st = panel.make_synthetic_study(str(tmp_path / "s"), [("AAA", 60, "EUR"), ("BBB", 45, "ASN")], n_snp=400, bp_lo=1_000_000,
+                                    bp_hi=2_000_000, frac_measured=0.3, seed=5)
+    p = st["paths"]
+    code = ("import sys; sys.path.insert(0, %r); from gauss_amd import api; "
+            "print(*api.panel_cache(%r, %r, %r))" % (ROOT, p["index.gz"], p["data.gz"], p["desc.txt"]))
+    env = dict(os.environ, GAUSS_PANEL_CACHE=str(tmp_path / "cache"))
+    procs = [subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, text=True, env=env) for _ in range(4)]
+    outs = [q.communicate(timeout=120)[0].split() for q in procs]
+    assert all(q.returncode == 0 for q in procs)
+    assert len({o[0] for o in outs}) == 1
+    assert sorted(int(o[1]) for o in outs) == [0, 0, 0, 400]                  # exactly one of them did the packing
