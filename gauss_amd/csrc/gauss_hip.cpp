@@ -24,6 +24,8 @@
 #include <string>
 #include <vector>
 
+#include <unistd.h>
+
 using namespace gauss;
 
 namespace gauss {
@@ -115,6 +117,26 @@ struct CopyWorker {
     }
 };
 
+// A row store whose bytes are still on their way (gauss_store_upload_async): a library thread streams them through the
+// pinned double buffers in order and leaves a mark (bytes landed so far, event on the upload stream) after every chunk;
+// gauss_store_wait makes the main stream wait for the mark that covers what a job is about to read.
+struct StoreUpload {
+    void* d = nullptr;
+    size_t bytes = 0;
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<std::pair<size_t, hipEvent_t>> marks;      // (bytes issued up to here, event recorded behind that copy)
+    bool done = false;
+    int rc = 0;
+    std::string err;
+    ~StoreUpload()
+    {
+        if (th.joinable()) th.join();
+        for (auto& m : marks) if (m.second) hipEventDestroy(m.second);
+    }
+};
+
 struct gauss_ctx {
     int device;
     uint64_t id = 0;                         // unique per process, never reused (a new context at a freed context's address is a new id)
@@ -134,6 +156,8 @@ struct gauss_ctx {
     size_t landing_bytes = 0;
     std::vector<hipEvent_t> ev_pool;         // "chunk g has landed" events, reused by every streamed call
     std::mutex stream_mu;                    // one streamed call at a time per context (they share landing buffer and worker)
+    hipStream_t upload = nullptr;            // asynchronous row-store uploads (gauss_store_upload_async)
+    std::map<const void*, std::unique_ptr<StoreUpload>> uploads;      // by device pointer (guarded by mu)
     int gram_i8 = 0;
     std::map<const void*, size_t> stores;    // row stores made by gauss_store_upload: base pointer -> bytes
     std::mutex mu;
@@ -1563,7 +1587,9 @@ void gauss_hip_destroy(gauss_ctx* ctx)
         if (*q) { hipStreamSynchronize(*q); hipStreamDestroy(*q); }
     for (hipEvent_t e : ctx->ev_pool) hipEventDestroy(e);
     if (ctx->landing) (void)hipFree(ctx->landing);
-    // 3. row stores nobody freed
+    // 3. row stores nobody freed (uploads still running are finished first)
+    ctx->uploads.clear();
+    if (ctx->upload) { hipStreamSynchronize(ctx->upload); hipStreamDestroy(ctx->upload); }
     for (auto& kv : ctx->stores) (void)hipFree(const_cast<void*>(kv.first));
     ctx->stores.clear();
     for (auto& kv : ctx->dev_cache.free_blocks) (void)hipFree(kv.second);
@@ -1619,10 +1645,32 @@ int gauss_pinned_free(gauss_ctx* ctx, void* host_ptr)
 // pinned staging buffers: host threads copy chunk k+1 out of the caller's (pageable, typically mmap'd) memory while
 // chunk k travels by hipMemcpyAsync -- the staged copy the runtime would do by itself for pageable memory, made
 // parallel and overlapped with the DMA.  Small stores take one plain copy.
-static int upload_rows(gauss_ctx* ctx, void* d, const void* host_rows, size_t bytes)
+// Where the rows of an upload come from: host memory, or a section of a file that is read with pread straight into the
+// pinned staging buffers.  A memcpy out of a fresh mmap takes a page fault per 4 KB on the process's address space --
+// 206 000 of them for a chromosome -- and every other thread of the process that faults or allocates (the data layer
+// running beside the upload) queues behind them; pread touches no page tables.
+struct RowSource2 {
+    const uint8_t* ptr = nullptr;
+    int fd = -1;
+    int64_t file_off = 0;
+    bool copy(uint8_t* dst, size_t off, size_t len) const
+    {
+        if (ptr) { memcpy(dst, ptr + off, len); return true; }
+        while (len > 0) {
+            const ssize_t n = pread(fd, dst, len, (off_t)(file_off + (int64_t)off));
+            if (n <= 0) return false;
+            dst += n; off += (size_t)n; len -= (size_t)n;
+        }
+        return true;
+    }
+};
+
+static int upload_rows(gauss_ctx* ctx, void* d, const RowSource2& src, size_t bytes, hipStream_t stream = nullptr,
+                       const std::function<void(size_t)>& chunk_queued = nullptr)
 {
     const size_t CH = (size_t)32 << 20;
-    if (bytes < 2 * CH) { HIPCHK(hipMemcpy(d, host_rows, bytes, hipMemcpyHostToDevice)); return GAUSS_OK; }
+    if (!stream) stream = ctx->stream;
+    if (bytes < 2 * CH && !chunk_queued && src.ptr) { HIPCHK(hipMemcpy(d, src.ptr, bytes, hipMemcpyHostToDevice)); return GAUSS_OK; }
     void* pin[2] = {nullptr, nullptr};
     hipEvent_t ev[2] = {nullptr, nullptr};
     int rc = GAUSS_OK;
@@ -1636,8 +1684,10 @@ static int upload_rows(gauss_ctx* ctx, void* d, const void* host_rows, size_t by
         }
     }
     const unsigned hw = std::thread::hardware_concurrency();
-    const int nt = (int)std::max(1u, std::min(8u, hw ? hw / 2 : 2u));
-    const uint8_t* src = (const uint8_t*)host_rows;
+    // a background upload (chunk_queued set) shares the host with the data layer it runs beside: fewer copy threads
+    const int nt_env = env_int("GAUSS_UPLOAD_THREADS", 0);
+    const int nt = nt_env > 0 ? nt_env : (int)std::max(1u, std::min(chunk_queued ? 4u : 8u, hw ? hw / 2 : 2u));
+    std::atomic<bool> read_ok{true};
     size_t k = 0;
     for (size_t off = 0; off < bytes && rc == GAUSS_OK; off += CH, k++) {
         const int b = (int)(k & 1);
@@ -1647,15 +1697,17 @@ static int upload_rows(gauss_ctx* ctx, void* d, const void* host_rows, size_t by
         const size_t per = (len + nt - 1) / nt;
         for (int t = 1; t < nt; t++) {
             const size_t o = per * t;
-            if (o < len) th.emplace_back([=]() { memcpy((uint8_t*)pin[b] + o, src + off + o, std::min(per, len - o)); });
+            if (o < len) th.emplace_back([&, o]() { if (!src.copy((uint8_t*)pin[b] + o, off + o, std::min(per, len - o))) read_ok = false; });
         }
-        memcpy(pin[b], src + off, std::min(per, len));
+        if (!src.copy((uint8_t*)pin[b], off, std::min(per, len))) read_ok = false;
         for (std::thread& x : th) x.join();
-        if (hipMemcpyAsync((uint8_t*)d + off, pin[b], len, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-            hipEventRecord(ev[b], ctx->stream) != hipSuccess)
+        if (!read_ok) { rc = fail(GAUSS_E_INVALID, "row store upload: reading the source failed (short file?)"); break; }
+        if (hipMemcpyAsync((uint8_t*)d + off, pin[b], len, hipMemcpyHostToDevice, stream) != hipSuccess ||
+            hipEventRecord(ev[b], stream) != hipSuccess)
             rc = fail(GAUSS_E_DEVICE, "row store upload: hipMemcpyAsync failed");
+        else if (chunk_queued) chunk_queued(off + len);
     }
-    if (hipStreamSynchronize(ctx->stream) != hipSuccess && rc == GAUSS_OK) rc = fail(GAUSS_E_DEVICE, "row store upload failed");
+    if (hipStreamSynchronize(stream) != hipSuccess && rc == GAUSS_OK) rc = fail(GAUSS_E_DEVICE, "row store upload failed");
     cleanup();
     return rc;
 }
@@ -1667,10 +1719,99 @@ int gauss_store_upload(gauss_ctx* ctx, const void* host_rows, int64_t bytes, voi
     void* d = nullptr;
     hipError_t e = ctx_malloc_retry(ctx, &d, (size_t)bytes + 64);      // slack: a row's last dword load may end on the last byte
     if (e != hipSuccess) return fail(GAUSS_E_NOMEM, "hipMalloc(%lld bytes row store) failed: %s", (long long)bytes, hipGetErrorString(e));
-    const int rc = upload_rows(ctx, d, host_rows, (size_t)bytes);
+    RowSource2 src;
+    src.ptr = (const uint8_t*)host_rows;
+    const int rc = upload_rows(ctx, d, src, (size_t)bytes);
     if (rc) { hipFree(d); return rc; }
     { std::lock_guard<std::mutex> lock(ctx->mu); ctx->stores[d] = (size_t)bytes; }
     *out_device_ptr = d;
+    return GAUSS_OK;
+}
+
+static int store_upload_async(gauss_ctx* ctx, const RowSource2& src, int64_t bytes, void** out_device_ptr);
+
+int gauss_store_upload_async(gauss_ctx* ctx, const void* host_rows, int64_t bytes, void** out_device_ptr)
+{
+    if (!ctx || !host_rows || bytes <= 0 || !out_device_ptr) return fail(GAUSS_E_INVALID, "bad arguments to gauss_store_upload_async");
+    RowSource2 src;
+    src.ptr = (const uint8_t*)host_rows;
+    return store_upload_async(ctx, src, bytes, out_device_ptr);
+}
+
+int gauss_store_upload_fd_async(gauss_ctx* ctx, int fd, int64_t file_offset, int64_t bytes, void** out_device_ptr)
+{
+    if (!ctx || fd < 0 || file_offset < 0 || bytes <= 0 || !out_device_ptr) return fail(GAUSS_E_INVALID, "bad arguments to gauss_store_upload_fd_async");
+    RowSource2 src;
+    src.fd = fd; src.file_off = file_offset;
+    return store_upload_async(ctx, src, bytes, out_device_ptr);
+}
+
+static int store_upload_async(gauss_ctx* ctx, const RowSource2& src, int64_t bytes, void** out_device_ptr)
+{
+    HIPCHK(hipSetDevice(ctx->device));
+    if (!ctx->upload) HIPCHK(hipStreamCreateWithFlags(&ctx->upload, hipStreamNonBlocking));
+    void* d = nullptr;
+    hipError_t e = ctx_malloc_retry(ctx, &d, (size_t)bytes + 64);
+    if (e != hipSuccess) return fail(GAUSS_E_NOMEM, "hipMalloc(%lld bytes row store) failed: %s", (long long)bytes, hipGetErrorString(e));
+    std::unique_ptr<StoreUpload> up(new StoreUpload());
+    StoreUpload* u = up.get();
+    u->d = d; u->bytes = (size_t)bytes;
+    {
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        ctx->stores[d] = (size_t)bytes;
+        ctx->uploads[d] = std::move(up);
+    }
+    const int device = ctx->device;
+    hipStream_t us = ctx->upload;
+    u->th = std::thread([ctx, u, src, device, us]() {
+        (void)hipSetDevice(device);
+        const int rc = upload_rows(ctx, u->d, src, u->bytes, us, [u, us](size_t upto) {
+            hipEvent_t ev = nullptr;
+            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, us) != hipSuccess) return;
+            std::lock_guard<std::mutex> lock(u->mu);
+            u->marks.emplace_back(upto, ev);
+            u->cv.notify_all();
+        });
+        std::lock_guard<std::mutex> lock(u->mu);
+        u->rc = rc;
+        if (rc) u->err = g_err;
+        u->done = true;
+        u->cv.notify_all();
+    });
+    *out_device_ptr = d;
+    return GAUSS_OK;
+}
+
+int gauss_store_wait(gauss_ctx* ctx, const void* device_ptr, int64_t bytes_needed)
+{
+    if (!ctx || !device_ptr) return fail(GAUSS_E_INVALID, "bad arguments to gauss_store_wait");
+    StoreUpload* u = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        auto it = ctx->uploads.find(device_ptr);
+        if (it == ctx->uploads.end()) return GAUSS_OK;            // not an asynchronous store, or complete and retired
+        u = it->second.get();
+    }
+    const bool all = bytes_needed <= 0 || (size_t)bytes_needed >= u->bytes;
+    hipEvent_t ev = nullptr;
+    {
+        std::unique_lock<std::mutex> lock(u->mu);
+        const size_t need = all ? u->bytes : (size_t)bytes_needed;
+        u->cv.wait(lock, [&] { return u->done || (!u->marks.empty() && u->marks.back().first >= need); });
+        if (u->rc) return fail(u->rc, "%s", u->err.c_str());
+        if (!u->done || !all)
+            for (auto& m : u->marks) if (m.first >= need) { ev = m.second; break; }
+    }
+    if (u->done) {
+        // complete (upload_rows synchronised its stream): nothing to wait for, and the bookkeeping can go
+        std::unique_ptr<StoreUpload> dead;
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        auto it = ctx->uploads.find(device_ptr);
+        if (it != ctx->uploads.end()) { dead = std::move(it->second); ctx->uploads.erase(it); }
+        return GAUSS_OK;
+    }
+    HIPCHK(hipSetDevice(ctx->device));
+    if (ev) HIPCHK(hipStreamWaitEvent(ctx->stream, ev, 0));
     return GAUSS_OK;
 }
 
@@ -1679,6 +1820,11 @@ int gauss_store_free(gauss_ctx* ctx, void* device_ptr)
     if (!ctx) return fail(GAUSS_E_INVALID, "ctx is NULL");
     HIPCHK(hipSetDevice(ctx->device));
     if (device_ptr) {
+        {
+            // an upload that is still running is finished first (its destructor joins the thread)
+            std::unique_ptr<StoreUpload> dead;
+            { std::lock_guard<std::mutex> lock(ctx->mu); auto it = ctx->uploads.find(device_ptr); if (it != ctx->uploads.end()) { dead = std::move(it->second); ctx->uploads.erase(it); } }
+        }
         { std::lock_guard<std::mutex> lock(ctx->mu); ctx->stores.erase(device_ptr); }
         HIPCHK(hipFree(device_ptr));
     }

@@ -717,7 +717,7 @@ static int auto_pack_mode()
     return e ? (atoi(e) != 0 ? 1 : 0) : -1;
 }
 
-static int panel_make_resident(gauss_ctx* ctx, const std::string& path, void** dev, int64_t* uploaded);
+static int panel_make_resident(gauss_ctx* ctx, const std::string& path, void** dev, int64_t* uploaded, bool async = false);
 static bool panel_is_resident(gauss_ctx* ctx, const std::string& path, void** dev);
 
 // ------------------------------------------------------------------------------------------
@@ -1842,7 +1842,8 @@ static std::string file_key(const std::string& path)
 }
 
 // returns the device pointer of the panel's row 0 (uploading the section on first use); *uploaded = bytes moved now
-static int panel_make_resident(gauss_ctx* ctx, const std::string& path, void** dev, int64_t* uploaded)
+// async: the upload is only STARTED (gauss_store_upload_async); readers call gauss_store_wait for the rows they need
+static int panel_make_resident(gauss_ctx* ctx, const std::string& path, void** dev, int64_t* uploaded, bool async)
 {
     if (uploaded) *uploaded = 0;
     const std::pair<uint64_t, std::string> key(gauss_hip_context_id(ctx), file_key(path));
@@ -1856,7 +1857,9 @@ static int panel_make_resident(gauss_ctx* ctx, const std::string& path, void** d
     if (!rp.pk) return herr("%s", err.c_str());
     rp.bytes = rp.pk->n_snp() * rp.pk->row_bytes();
     if (rp.bytes <= 0) return herr("packed panel '%s' holds no SNPs", path.c_str());
-    if (gauss_store_upload(ctx, rp.pk->geno(), rp.bytes, &rp.dev) != 0) return herr("%s", gauss_last_error());
+    if ((async ? gauss_store_upload_fd_async(ctx, rp.pk->fd(), rp.pk->geno_file_offset(), rp.bytes, &rp.dev)
+               : gauss_store_upload(ctx, rp.pk->geno(), rp.bytes, &rp.dev)) != 0)
+        return herr("%s", gauss_last_error());
     if (uploaded) *uploaded = rp.bytes;
     *dev = rp.dev;
     g_resident[key] = rp;
@@ -2119,20 +2122,24 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
     st.n_batches = n_batches;
     st.t_plan = now_s() - t_begin;
 
-    // ---- the panel's rows in HBM ----
-    double t0 = now_s();
-    void* d_rows = nullptr;
-    if (!mine.empty() && panel_make_resident(ctx, reference_data_file, &d_rows, &st.panel_bytes_uploaded)) return -1;
-    st.t_panel_upload = now_s() - t0;
-
     // ---- feeder thread: the data layer, batch by batch ----
+    int rc_upload = 0;
     struct Slot { std::unique_ptr<gauss_prepared> p; gauss_window_desc d; bool ok = false; gauss_table* tab = nullptr; };
     std::vector<std::vector<Slot>> slots((size_t)n_batches);
     for (int b = 0; b < n_batches; b++) slots[b].resize(batches[b].size());
     std::mutex mu;
     std::condition_variable cv;
     const unsigned hw = std::thread::hardware_concurrency();
-    int nthreads = (int)std::max(1u, std::min(16u, (hw ? hw : 4u) / (unsigned)std::max(1, std::min(world, 8))));
+    // 8 rather than 16: a warm chromosome takes the same 45 ms, a process's first call 88 instead of 110 ms (the first
+    // hipMalloc of the workspaces and the cold allocator share the host with these threads; tools/cold_probe.sh)
+    int nthreads = (int)std::max(1u, std::min(8u, (hw ? hw : 4u) / (unsigned)std::max(1, std::min(world, 8))));
+    {
+        // first use of the panel on this context: the upload's copy threads (page faults on the mapping, or preads) run
+        // beside the data layer, and more than four data-layer threads slow BOTH down (cold call 73-84 ms with 4, 103-124
+        // with 8, 115-132 with 16; the data layer of a chromosome is 36 x 2 ms, well hidden either way)
+        void* dev_probe = nullptr;
+        if (!panel_is_resident(ctx, reference_data_file, &dev_probe)) nthreads = std::min(nthreads, 4);
+    }
     if (const char* e = getenv("GAUSS_CHROM_THREADS")) nthreads = std::max(1, atoi(e));
     // One pool over ALL windows in batch order (not one fork-join per batch: a batch of five windows would leave
     // eleven of sixteen threads idle); a batch is ready when its last window is.
@@ -2158,8 +2165,7 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
                     w.status = 1; w.why = gauss_host_last_error();
                     sl.p.reset();
                 } else {
-                    sl.d.geno_m = sl.d.geno_u = (const uint8_t*)d_rows;   // rows_m / rows_u are panel row indices already
-                    sl.ok = true;
+                    sl.ok = true;                                 // geno_m / geno_u: the resident panel, set when the batch is queued
                 }
             }
             bool last;
@@ -2168,10 +2174,28 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
         });
     });
 
+    // ---- the panel's rows in HBM ----
+    // First use of this panel on this context.  Small panels (a chromosome: 0.8 GB, 21 ms) are uploaded here, in one go,
+    // while the feeder thread above is already in the first batch's data layer; a panel of several GB (the whole 33KG
+    // panel is 82 GB: 2 s) is only STARTED here and the batches wait for the rows they name (gauss_store_wait): the rows
+    // travel in panel order, the batches follow the chromosome.  Measured on the chr22 panel, first call of a process:
+    // upload, then feeder 108-118 ms; feeder beside the upload (this order) see DESIGN.md; asynchronous upload 105-155 ms
+    // (its copy threads and the cold data layer slow each other down more than the overlap gains on 0.8 GB).
+    void* d_rows = nullptr;
+    const int64_t panel_row_bytes = pk->row_bytes();
+    {
+        const int64_t panel_bytes = pk->n_snp() * panel_row_bytes;
+        const char* e = getenv("GAUSS_CHROM_ASYNC_UPLOAD");
+        const bool async_upload = e ? atoi(e) != 0 : panel_bytes > ((int64_t)4 << 30);
+        const double tu = now_s();
+        if (!mine.empty() && panel_make_resident(ctx, reference_data_file, &d_rows, &st.panel_bytes_uploaded, async_upload)) rc_upload = -1;
+        st.t_panel_upload = now_s() - tu;
+    }
+
     // ---- GPU pipeline ----
     std::vector<gauss_job*> jobs((size_t)n_batches, nullptr);
     std::vector<std::vector<int>> live((size_t)n_batches);       // slots of batch b that are in its job
-    int rc_fatal = 0;
+    int rc_fatal = rc_upload;
     // the result table grows batch by batch (batches are contiguous in window order), so that only the last batch's
     // rows are appended after the GPU has finished
     std::unique_ptr<gauss_table> all(new gauss_table());
@@ -2243,8 +2267,23 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
         st.t_feeder_wait += now_s() - tw;
         std::vector<gauss_window_desc> descs;
         for (size_t k = 0; k < slots[b].size(); k++)
-            if (slots[b][k].ok) { descs.push_back(slots[b][k].d); live[b].push_back((int)k); }
+            if (slots[b][k].ok) {
+                slots[b][k].d.geno_m = slots[b][k].d.geno_u = (const uint8_t*)d_rows;   // rows_m / rows_u are panel row indices already
+                descs.push_back(slots[b][k].d); live[b].push_back((int)k);
+            }
         if (!descs.empty()) {
+            {
+                // the highest panel row this batch reads; its job may start once the upload has passed it
+                int64_t top = -1;
+                for (int k : live[b]) {
+                    const gauss_prepared* q = slots[b][(size_t)k].p.get();
+                    for (int32_t r : q->store_rows_m) top = std::max<int64_t>(top, r);
+                    for (int32_t r : q->store_rows_u) top = std::max<int64_t>(top, r);
+                }
+                const double tu = now_s();
+                if (gauss_store_wait(ctx, d_rows, (top + 1) * panel_row_bytes) != 0) { herr("%s", gauss_last_error()); rc_fatal = -1; break; }
+                st.t_panel_upload += now_s() - tu;
+            }
             double tc = now_s();
             if (gauss_job_create(ctx, descs.data(), (int)descs.size(), 1, &jobs[b]) != 0 || gauss_job_run(jobs[b]) != 0) {
                 // could not even queue the batch: fall back to single windows at retire time
@@ -2272,6 +2311,10 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
         if (jf && gauss_job_span_ms(jf, jl, &st.gpu_span_ms) != 0) st.gpu_span_ms = 0.0;
     }
     for (gauss_job* j : jobs) if (j) gauss_job_destroy(j);
+    // whoever finds this panel resident later (another study, an LD call on rows this chromosome never touched) must
+    // find all of it: the upload is complete before the call returns
+    if (d_rows && gauss_store_wait(ctx, d_rows, 0) != 0 && !rc_fatal) { herr("%s", gauss_last_error()); rc_fatal = -1; }
+    if (rc_fatal) return -1;
 
     // ---- one table, window order (batches were appended as they retired) ----
     double tt = now_s();

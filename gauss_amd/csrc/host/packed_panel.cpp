@@ -87,6 +87,24 @@ bool PackedPanel::open(const std::string& path, std::string& err)
             ok = sp[i].rsid < str_bytes && sp[i].a1 < str_bytes && sp[i].a2 < str_bytes;
         if (!ok) { err = "packed panel '" + path + "': a SNP record points outside the string table"; close(); return false; }
     }
+    // The tables in front of the genotype section (strings, per-population AF and allele counts: ~41 MB for 100 000 SNPs
+    // x 29 populations) are read by every window's data layer, from many threads at once; left to demand paging the
+    // first windows of a process spent 9-22 ms each in page faults on this mapping (0.5 ms once mapped).  Map them now,
+    // in one batched call where the kernel has it.
+    {
+        const size_t page = (size_t)sysconf(_SC_PAGESIZE);
+        const size_t lo = (size_t)h.off_pops / page * page;
+        const size_t hi = std::min((size_t)bytes_, ((size_t)h.off_geno + page - 1) / page * page);
+        bool mapped = false;
+#ifdef MADV_POPULATE_READ
+        mapped = hi > lo && madvise(const_cast<uint8_t*>(base_) + lo, hi - lo, MADV_POPULATE_READ) == 0;
+#endif
+        if (!mapped && hi > lo) {
+            (void)madvise(const_cast<uint8_t*>(base_) + lo, hi - lo, MADV_WILLNEED);
+            volatile uint8_t sink = 0;
+            for (size_t o = lo; o < hi; o += page) sink = sink + base_[o];
+        }
+    }
     pops_ = (const PkPop*)(base_ + h.off_pops);
     snps_ = (const PkSnp*)(base_ + h.off_snps);
     strings_ = (const char*)(base_ + h.off_strings);

@@ -60,6 +60,8 @@ public:
     const int32_t* cnt(int64_t i) const { return cnt_ + (size_t)i * hdr_->n_pop; }
     const uint8_t* row(int64_t i) const { return geno_ + (size_t)i * hdr_->row_bytes; }
     const uint8_t* geno() const { return geno_; }
+    int fd() const { return fd_; }                                  // the open file (pread source of the resident upload)
+    int64_t geno_file_offset() const { return (int64_t)(geno_ - base_); }
     // first row with (chr, bp) >= the key, for sorted panels
     int64_t lower_bound(int chr, int64_t bp) const;
 

@@ -346,13 +346,23 @@ class RowStore:
     """Genotype rows resident in HBM (gauss_store_upload): a whole packed chromosome is uploaded once and
     windows name their rows by index."""
 
-    def __init__(self, rows, ctx=None):
+    def __init__(self, rows, ctx=None, asynchronous=False):
+        """asynchronous: gauss_store_upload_async -- the rows travel in the background (keep `rows` alive until
+        wait() has returned); wait(n_rows) makes the context's stream wait for the first n_rows rows."""
         self.ctx = ctx or default_context()
         rows = np.ascontiguousarray(rows, dtype=np.uint8)
         self.n_rows, self.ld = rows.shape
         p = C.c_void_p()
-        check(self.ctx.lib.gauss_store_upload(self.ctx.handle, rows.ctypes.data_as(C.c_void_p), rows.nbytes, C.byref(p)))
+        if asynchronous:
+            self._host = rows
+            check(self.ctx.lib.gauss_store_upload_async(self.ctx.handle, rows.ctypes.data_as(C.c_void_p), rows.nbytes, C.byref(p)))
+        else:
+            check(self.ctx.lib.gauss_store_upload(self.ctx.handle, rows.ctypes.data_as(C.c_void_p), rows.nbytes, C.byref(p)))
         self.ptr = p.value
+
+    def wait(self, n_rows=0):
+        """Rows [0, n_rows) have landed for everything queued on the context afterwards (0: all rows, host waits)."""
+        check(self.ctx.lib.gauss_store_wait(self.ctx.handle, C.c_void_p(self.ptr), int(n_rows) * self.ld))
 
     def close(self):
         if self.ptr:

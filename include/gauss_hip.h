@@ -133,6 +133,18 @@ int gauss_pinned_free(gauss_ctx* ctx, void* host_ptr);
  * whole 2-bit panel (33 k samples x 10 M SNPs = 82 GB), so a panel is uploaded once, not per window. */
 int gauss_store_upload(gauss_ctx* ctx, const void* host_rows, int64_t bytes, void** out_device_ptr);
 int gauss_store_free(gauss_ctx* ctx, void* device_ptr);
+/* The same upload without waiting for it: returns at once with the device pointer; a library thread streams the rows
+ * IN ORDER (pinned double buffers, a stream of its own).  host_rows must stay valid until the upload is complete.
+ * gauss_store_wait(ctx, ptr, n) makes the context's main stream wait until the first n bytes have landed -- a job queued
+ * afterwards that reads rows below that mark starts while the rest of the panel is still crossing PCIe -- and blocks the
+ * host only until those bytes have been queued; n <= 0: the whole store, and the host waits for completion.  Stores
+ * made by gauss_store_upload need no wait (it is a no-op on them). */
+int gauss_store_upload_async(gauss_ctx* ctx, const void* host_rows, int64_t bytes, void** out_device_ptr);
+/* The rows are `bytes` bytes of an open file starting at file_offset (a packed panel's genotype section): read with
+ * pread straight into the pinned staging buffers -- no page of the caller's address space is touched, so the upload
+ * does not contend with the threads that parse the study beside it.  fd must stay open until the upload is complete. */
+int gauss_store_upload_fd_async(gauss_ctx* ctx, int fd, int64_t file_offset, int64_t bytes, void** out_device_ptr);
+int gauss_store_wait(gauss_ctx* ctx, const void* device_ptr, int64_t bytes_needed);
 
 /* ---- context ------------------------------------------------------------------------------- */
 int gauss_hip_init(int device, gauss_ctx** out_ctx);

@@ -101,3 +101,49 @@ def test_resident_panel_does_not_survive_its_context(tmp_path):
         c.close()                                                 # no panel_evict: the destroy hook lets go of it
     assert len(set(ids)) == 3
     assert all(np.array_equal(t, tables[0]) for t in tables[1:])
+
+
+@pytest.mark.gpu
+def test_asynchronous_row_store_upload(ctx):
+    """gauss_store_upload_async + gauss_store_wait: a job over the first rows of a store may be queued while the rest is
+    still on its way (the library's stream waits for the mark that covers the rows named), a job over all rows after
+    wait(all), and both give the bits of a synchronous store.  Large enough for several 32 MB chunks."""
+    from gauss_amd import hotpath, synth, panel
+    pops = synth.pop_table(scale=0.25, min_size=64)[:8]
+    sizes = [p[1] for p in pops]
+    off = synth.pop_offsets(sizes)
+    rng = np.random.default_rng(11)
+    n_snp = 120000
+    bp = np.sort(rng.choice(np.arange(1, 3_000_000), size=n_snp, replace=False))
+    G, _ = synth.synth_genotypes(bp[:600], pops, seed=4)
+    G = G[G.min(1) != G.max(1)][:512]
+    packed, _ = panel.pack2bit(G, off)
+    rows = np.ascontiguousarray(np.tile(packed, (n_snp // 512 + 1, 1))[:n_snp])     # 100+ MB of 2-bit rows
+    assert rows.nbytes > 3 * (32 << 20)
+    w = rng.uniform(0.05, 0.3, len(pops))
+
+    def job_over(store, lo):
+        rm = np.arange(lo, lo + 200, dtype=np.int32)
+        ru = np.arange(lo + 200, lo + 500, dtype=np.int32)
+        d = dict(mode=1, pop_off=off, pop_wgt=w, z1=np.linspace(-2, 2, 200), dev=(store.ptr, store.ptr, 200, 300, store.ld),
+                 packed=dict(fmt=1, rows_m=rm, rows_u=ru))
+        j = hotpath.Job([d], ctx=ctx, on_device=True)
+        j.run()
+        r = j.fetch()[0]
+        j.close()
+        return r
+
+    sync = hotpath.RowStore(rows, ctx=ctx)
+    want_lo, want_hi = job_over(sync, 0), job_over(sync, n_snp - 512)
+    sync.close()
+    st = hotpath.RowStore(rows, ctx=ctx, asynchronous=True)
+    st.wait(512)                                   # the first rows only: the job below starts while the upload goes on
+    got_lo = job_over(st, 0)
+    st.wait(0)
+    got_hi = job_over(st, n_snp - 512)
+    st.wait(0)                                     # a second full wait is a no-op
+    st.close()
+    for a, b in ((got_lo, want_lo), (got_hi, want_hi)):
+        assert np.array_equal(a["z"], b["z"]) and np.array_equal(a["info"], b["info"])
+    busy = hotpath.RowStore(rows, ctx=ctx, asynchronous=True)
+    busy.close()                                   # freed while the upload may still be running: it is finished first
