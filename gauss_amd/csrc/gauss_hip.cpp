@@ -303,6 +303,14 @@ struct gauss_job {
     Prob* d_probs = nullptr;
     Item* d_items = nullptr;    int n_items = 0;
     int2* d_rowmap = nullptr;   int n_rows = 0;
+    // Shared measured rows (job_build): the windows of a chromosome name their measured SNPs as rows of one resident store,
+    // each window a contiguous run of the chromosome's measured SNPs.  Those rows are then packed once into job-wide
+    // arrays ("problem" n behind the windows' descriptors), B11's tile pairs are formed on job-wide row tiles and
+    // multiplied once for all the windows they lie in (consecutive 2 Mb windows share half their measured SNPs: the
+    // reference recomputes every pair per call, dist.cpp:171-179); every window's epilogue reads the shared slabs.
+    std::unique_ptr<Plan> gplan;                           // the job-wide measured rows; null: nothing is shared
+    std::vector<int> g0;                                   // per window: job-wide index of its first measured SNP
+    std::vector<std::vector<int2>> win_tiles;              // per window: its epilogue tiles (tilemap entries)
     int2* d_tilemap = nullptr;  int n_tiles = 0;            // LD epilogue tiles: B11's first (n_tiles_b11 of them), then B21's
     int n_tiles_b11 = 0;
     int2* d_panelmap = nullptr; int n_panels = 0;          // fused path: (window, panel of [I | z1])
@@ -638,6 +646,61 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
         if (rc) return rc;
         job->plans[i].p.gram_i8 = job->gram_i8;
     }
+    // Shared measured rows: every window reads its measured SNPs from the same resident store, under the same
+    // populations, and each window's list is a run of ONE ascending job-wide list (windows of a chromosome in order).
+    if (on_device && !streamed && job->n >= 2 && env_int("GAUSS_SHARE_MEASURED", 1) != 0) {
+        const Plan& a = job->plans[0];
+        bool ok = true;
+        std::vector<int32_t> gl;
+        std::vector<int> g0((size_t)job->n, 0);
+        for (int i = 0; i < job->n && ok; i++) {
+            const Plan& b = job->plans[i];
+            ok = !b.rows_m.empty() && !b.p.ld_only && !b.p.n_gene && b.p.P <= 32 && b.h_geno_m == a.h_geno_m && b.user_ld == a.user_ld &&
+                 b.p.mode == a.p.mode && b.p.P == a.p.P && b.p.geno_fmt == a.p.geno_fmt && b.p.slab16 == a.p.slab16 && b.p.Kp == a.p.Kp &&
+                 b.pop_raw_off == a.pop_raw_off && b.pop_pk_off == a.pop_pk_off && b.pop_w == a.pop_w && b.seg_k0 == a.seg_k0 &&
+                 b.seg_k1 == a.seg_k1 && b.seg_pop == a.seg_pop && b.run_src == a.run_src && b.run_pk_off == a.run_pk_off &&
+                 b.groups == a.groups;
+            if (!ok) break;
+            // where does this window's run start in the job-wide list?  (binary search: the list is ascending)
+            const int32_t first = b.rows_m[0];
+            size_t pos = (size_t)(std::lower_bound(gl.begin(), gl.end(), first) - gl.begin());
+            if (pos < gl.size() && gl[pos] != first) { ok = false; break; }
+            g0[(size_t)i] = (int)pos;
+            for (size_t k = 0; k < b.rows_m.size() && ok; k++) {
+                if (k > 0 && b.rows_m[k] <= b.rows_m[k - 1]) ok = false;
+                else if (pos + k < gl.size()) ok = gl[pos + k] == b.rows_m[k];
+                else gl.push_back(b.rows_m[k]);
+            }
+        }
+        if (ok && (long long)gl.size() < (1 << 24)) {
+            job->gplan.reset(new Plan(a));
+            job->g0 = g0;
+            Plan& g = *job->gplan;
+            g.rows_m = gl;
+            g.rows_u.clear(); g.z1.clear(); g.gene_off.clear(); g.gene_out_off.clear();
+            Prob& q = g.p;
+            q.M = (int)gl.size(); q.U = 0; q.U_raw = 1; q.n_rhs = 0;
+            q.Mp = (int)rup((size_t)q.M, TILE); q.Up = 0; q.Sp = q.Mp; q.nT = q.Mp / TILE;
+            q.Mld = 0; q.nblk = 0; q.npanel = 0; q.npi = 0; q.kind = 0; q.ld_only = 0; q.n_head = q.n_predm = 0;
+            g.U_user = 0; g.h_geno_u = nullptr;
+            // job-wide B11 pairs: the tile pairs some window lies in
+            g.pair_ti.clear(); g.pair_tj.clear(); g.pair_lut.assign((size_t)q.nT * q.nT, -1);
+            for (int i = 0; i < job->n; i++) {
+                const int lo = g0[(size_t)i] / TILE, hi = (g0[(size_t)i] + job->plans[i].p.M - 1) / TILE;
+                for (int ti = lo; ti <= hi; ti++)
+                    for (int tj = ti; tj <= hi; tj++)
+                        if (g.pair_lut[(size_t)ti * q.nT + tj] < 0) {
+                            g.pair_lut[(size_t)ti * q.nT + tj] = g.pair_lut[(size_t)tj * q.nT + ti] = (int)g.pair_ti.size();
+                            g.pair_ti.push_back(ti); g.pair_tj.push_back(tj);
+                        }
+            }
+            q.npair = (int)g.pair_ti.size();
+        }
+    }
+    const bool shm = job->gplan != nullptr;
+    const int n_prob = job->n + (shm ? 1 : 0);             // descriptors on the device: the windows, then the job-wide rows
+    auto plan_of = [&](int i) -> Plan& { return i < job->n ? job->plans[i] : *job->gplan; };
+
     // Row lists are resolved by the pack kernel: an index beyond the store would be an out-of-bounds read on the
     // GPU.  Host stores cannot be checked (only a pointer is known), stores made by gauss_store_upload can.
     std::map<const void*, size_t> stores;
@@ -672,9 +735,9 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
     Arena ta;
     std::vector<char>& blob = job->h_tab;
     struct TabOff { size_t raw_off, pk_off, w, wf, md, seg_pop, k0, k1, seg0, ti, tj, lut, wp, z1, goff, gout, wr, rpk, rsrc, rm, ru, ch; };
-    std::vector<TabOff> to(job->n);
-    for (int i = 0; i < job->n; i++) {
-        Plan& pl = job->plans[i];
+    std::vector<TabOff> to((size_t)n_prob);
+    for (int i = 0; i < n_prob; i++) {
+        Plan& pl = plan_of(i);
         to[i].raw_off = put(blob, ta, pl.pop_raw_off);
         to[i].pk_off = put(blob, ta, pl.pop_pk_off);
         to[i].w = put(blob, ta, pl.pop_w);
@@ -714,18 +777,42 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
         const int small = env_int("GAUSS_GEMM_SMALL_TILES", 1600);         // read per job: tests drive both tile widths
         job->gemm_ut = t128 < (size_t)small ? 64 : 128;
     }
+    job->win_tiles.assign((size_t)job->n, std::vector<int2>());
+    if (shm) {
+        // the job-wide measured rows are packed once, and B11's job-wide tile pairs multiplied once
+        const Plan& g = *job->gplan;
+        for (int pr = 0; pr < g.p.npair; pr++)
+            for (size_t k = 0; k < g.groups.size(); k++)
+                items.push_back(ItemH{job->n, pr, (int)k, g.seg_k1[g.groups[k].second - 1] - g.seg_k0[g.groups[k].first]});
+        for (int r = 0; r < g.p.M; r++) rowmap.push_back(make_int2(job->n, r));
+    }
     for (int i = 0; i < job->n; i++) {
         const Prob& p = job->plans[i].p;
-        for (int pr = 0; pr < p.npair; pr++)
+        const int mt_i = p.Mp / TILE;
+        for (int pr = 0; pr < p.npair; pr++) {
+            if (shm && job->plans[i].pair_ti[pr] < mt_i) continue;       // a B11 pair: done on the job-wide tiles
             for (size_t g = 0; g < job->plans[i].groups.size(); g++) {
                 const std::pair<int, int>& gr = job->plans[i].groups[g];
                 items.push_back(ItemH{i, pr, (int)g, job->plans[i].seg_k1[gr.second - 1] - job->plans[i].seg_k0[gr.first]});
             }
-        for (int r = 0; r < p.M + p.U; r++) rowmap.push_back(make_int2(i, r));
+        }
+        for (int r = shm ? p.M : 0; r < p.M + p.U; r++) rowmap.push_back(make_int2(i, r));
+        if (shm) {
+            // this window's view of the job-wide B11 pairs it lies in
+            const Plan& g = *job->gplan;
+            const int lo = job->g0[(size_t)i] / TILE, hi = (job->g0[(size_t)i] + p.M - 1) / TILE;
+            for (int ti = lo; ti <= hi; ti++)
+                for (int tj = ti; tj <= hi; tj++) {
+                    const int2 e = make_int2(i, g.pair_lut[(size_t)ti * g.p.nT + tj] | TILE_GB11);
+                    tilemap.push_back(e); job->win_tiles[(size_t)i].push_back(e);
+                }
+        }
         if (!p.n_gene)
             for (int pr = 0; pr < p.npair; pr++) {
                 const bool b21 = !p.ld_only && job->plans[i].pair_ti[pr] >= p.Mp / TILE;      // a tile of U rows x M columns
+                if (shm && !b21) continue;
                 (b21 ? tilemap_b21 : tilemap).push_back(make_int2(i, pr));
+                job->win_tiles[(size_t)i].push_back(make_int2(i, pr));
             }
         for (int pn = 0; pn < p.npi; pn++) panelmap.push_back(make_int2(i, pn));
         for (int pn = 0; pn < p.npanel; pn++) dpanelmap.push_back(make_int2(i, pn));
@@ -800,7 +887,7 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
     const size_t o_dpanelmap = put(blob, ta, dpanelmap);
     const size_t o_gemmmap = put(blob, ta, gemmmap);
     const size_t o_finmap = put(blob, ta, finmap);
-    const size_t o_probs = ta.take(sizeof(Prob) * job->n);
+    const size_t o_probs = ta.take(sizeof(Prob) * (size_t)n_prob);
     blob.resize(ta.off);
     job->n_items = (int)items.size();
     job->n_rows = (int)rowmap.size();
@@ -873,11 +960,27 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
         pl.res_off = res;
         res += 2 * (size_t)p.n_rhs;
     }
+    // job-wide measured rows (shared measured rows): one more tile of rows than Mp, because a window's last row tile
+    // starts wherever the window starts and may reach past the chromosome's last measured SNP (zero rows there)
+    struct GOff { size_t packed, sx, sxx, sd, wm, mu, wmu, slab; } go = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (shm) {
+        const Prob& q = job->gplan->p;
+        const size_t rows = (size_t)q.Mp + TILE;
+        go.packed = wa.take(rows * q.Kp);
+        go.sx = wa.take(rows * q.P * sizeof(int));
+        go.sxx = wa.take(rows * q.P * sizeof(int));
+        go.sd = wa.take(rows * sizeof(double));
+        go.wm = wa.take(rows * sizeof(double));
+        go.mu = wa.take(rows * q.P * sizeof(double));
+        go.wmu = wa.take(rows * q.P * sizeof(double));
+        go.slab = wslab.take((size_t)q.npair * q.nseg * TILE * TILE * (q.slab16 ? sizeof(uint16_t) : sizeof(float)));
+    }
     const size_t o_status = wa.take(sizeof(int) * 4 * job->n);
     const size_t o_results = wa.take(sizeof(double) * std::max<size_t>(res, 1));
     job->n_results = res;
     const size_t slab_base = rup(wa.off, 4096);
     for (WsOff& w : wo) w.slab += slab_base;
+    go.slab += slab_base;
     job->ws_bytes = slab_base + wslab.off;
     job->tab_bytes = blob.size();
 
@@ -963,6 +1066,24 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
         p.out_ld = (double*)(W + w.ld);
         p.gene_off = p.n_gene ? (const int*)(T + to[i].goff) : nullptr;
         p.gene_out_off = p.n_gene ? (long long*)(T + to[i].gout) : nullptr;
+        // the unmeasured part of every row array follows the measured part ...
+        p.packed_u = p.packed + (size_t)p.Mp * p.Kp;
+        p.sx_u = p.sx + (size_t)p.Mp * p.P; p.sxx_u = p.sxx + (size_t)p.Mp * p.P;
+        p.rt_sd_u = p.rt_sd + p.Mp; p.rt_wm_u = p.rt_wm + p.Mp;
+        p.rt_mu_u = p.rt_mu + (size_t)p.Mp * p.P; p.rt_wmu_u = p.rt_wmu + (size_t)p.Mp * p.P;
+        p.g0 = 0; p.n_gpair = 0; p.gpair_ti = p.pair_ti; p.gpair_tj = p.pair_tj; p.slab_g = p.slab;
+        if (shm) {
+            // ... unless the measured rows are the job-wide ones: this window's run starts at g0
+            const Prob& q = job->gplan->p;
+            const size_t g0 = (size_t)job->g0[(size_t)i];
+            p.g0 = (int)g0; p.n_gpair = q.npair;
+            p.packed = (uint8_t*)(W + go.packed) + g0 * q.Kp;
+            p.sx = (int*)(W + go.sx) + g0 * q.P; p.sxx = (int*)(W + go.sxx) + g0 * q.P;
+            p.rt_sd = (double*)(W + go.sd) + g0; p.rt_wm = (double*)(W + go.wm) + g0;
+            p.rt_mu = (double*)(W + go.mu) + g0 * q.P; p.rt_wmu = (double*)(W + go.wmu) + g0 * q.P;
+            p.gpair_ti = (const int*)(T + to[(size_t)job->n].ti); p.gpair_tj = (const int*)(T + to[(size_t)job->n].tj);
+            p.slab_g = (float*)(W + go.slab);
+        }
         memcpy(blob.data() + o_probs + sizeof(Prob) * i, &p, sizeof(Prob));
         if (!on_device && !streamed) {
             auto upload = [&](size_t dst_off, const uint8_t* src, const std::vector<int32_t>& rows, int nrows) -> int {
@@ -988,18 +1109,48 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
             if (rc) return rc;
         }
     }
+    if (shm) {
+        // descriptor n: the job-wide measured rows (pack_stats / row_stats work on it; nothing else is launched for it)
+        Plan& g = *job->gplan;
+        Prob& q = g.p;
+        const size_t n = (size_t)job->n;
+        char* T = job->d_tab;
+        char* W = job->d_ws;
+        q.ld_raw = g.user_ld;
+        q.raw_m = g.h_geno_m; q.raw_u = nullptr;
+        q.packed = (uint8_t*)(W + go.packed); q.packed_u = q.packed;
+        q.sx = (int*)(W + go.sx); q.sxx = (int*)(W + go.sxx); q.sx_u = q.sx; q.sxx_u = q.sxx;
+        q.rt_sd = (double*)(W + go.sd); q.rt_wm = (double*)(W + go.wm); q.rt_sd_u = q.rt_sd; q.rt_wm_u = q.rt_wm;
+        q.rt_mu = (double*)(W + go.mu); q.rt_wmu = (double*)(W + go.wmu); q.rt_mu_u = q.rt_mu; q.rt_wmu_u = q.rt_wmu;
+        q.pop_raw_off = (const int*)(T + to[n].raw_off); q.pop_pk_off = (const int*)(T + to[n].pk_off);
+        q.pop_w = (const double*)(T + to[n].w); q.pop_wf = (const double*)(T + to[n].wf); q.pop_md = (const double*)(T + to[n].md);
+        q.seg_pop = (const int*)(T + to[n].seg_pop); q.seg_k0 = (const int*)(T + to[n].k0); q.seg_k1 = (const int*)(T + to[n].k1);
+        q.pop_seg0 = (const int*)(T + to[n].seg0);
+        q.pair_ti = (const int*)(T + to[n].ti); q.pair_tj = (const int*)(T + to[n].tj); q.pair_lut = (const int*)(T + to[n].lut);
+        q.word_pop = (const uint8_t*)(T + to[n].wp); q.word_run = (const uint8_t*)(T + to[n].wr);
+        q.rows_m = (const int*)(T + to[n].rm); q.rows_u = nullptr;
+        q.run_pk_off = (const int*)(T + to[n].rpk); q.run_src = (const int*)(T + to[n].rsrc);
+        q.slab = (float*)(W + go.slab); q.slab_g = q.slab; q.gpair_ti = q.pair_ti; q.gpair_tj = q.pair_tj; q.g0 = 0; q.n_gpair = q.npair;
+        q.z1 = nullptr; q.A = nullptr; q.B21 = nullptr; q.Linv = nullptr; q.V = nullptr; q.Gsum = nullptr; q.Part = nullptr;
+        q.out_z = q.out_info = nullptr; q.out_ld = nullptr; q.status = job->d_status;      // never written for this descriptor
+        q.gene_off = nullptr; q.gene_out_off = nullptr; q.n_gene = 0;
+        memcpy(blob.data() + o_probs + sizeof(Prob) * n, &q, sizeof(Prob));
+    }
     // device work items: every pointer is resolved here so the kernel starts loading operands at once
     for (size_t n = 0; n < items.size(); n++) {
         const ItemH& h = items[n];
-        const Plan& pl = job->plans[h.prob];
+        const Plan& pl = plan_of(h.prob);
         const Prob& p = pl.p;
         const std::pair<int, int>& gr = pl.groups[h.group];
         const int ti = pl.pair_ti[h.pair], tj = pl.pair_tj[h.pair];
         const int mt = p.Mp / TILE;
         auto rows = [&](int t) { int left = (t < mt) ? p.M - t * TILE : p.U - (t - mt) * TILE; return left > TILE ? TILE : left; };
+        // a row tile of the measured part (for a window that shares its measured rows: inside the job-wide array, from
+        // wherever the window starts) or of the unmeasured part
+        auto tile_rows = [&](int t) { return t < mt ? p.packed + (size_t)t * TILE * p.Kp : p.packed_u + (size_t)(t - mt) * TILE * p.Kp; };
         Item it;
-        it.a = p.packed + (size_t)ti * TILE * p.Kp;
-        it.b = p.packed + (size_t)tj * TILE * p.Kp;
+        it.a = tile_rows(ti);
+        it.b = tile_rows(tj);
         it.slab = p.slab + ((size_t)h.pair * p.nseg + gr.first) * (p.slab16 ? TILE * TILE / 2 : TILE * TILE);
         it.seg_k1 = p.seg_k1 + gr.first;
         it.chunk_half = (const uint32_t*)(job->d_tab + to[h.prob].ch);
@@ -1319,7 +1470,7 @@ static int job_clamp_window(gauss_job* job, int i, int* status_bits)
     Prob& p = pl.p;
     // Re-run the epilogue for this problem only to restore A[0] (the factorisation overwrote it)
     std::vector<int2> tm;
-    for (int pr = 0; pr < p.npair; pr++) tm.push_back(make_int2(i, pr));
+    tm = job->win_tiles[(size_t)i];                   // this window's epilogue tiles (job-wide B11 pairs included)
     DevBuf d_tm, d_work, d_pm;
     HIPCHK(d_tm.alloc(job->ctx, sizeof(int2) * tm.size()));
     HIPCHK(hipMemcpyAsync(d_tm.p, tm.data(), sizeof(int2) * tm.size(), hipMemcpyHostToDevice, st));
@@ -1919,13 +2070,17 @@ int gauss_job_stats(gauss_job* job, double* out4)
 {
     if (!job || !out4) return fail(GAUSS_E_INVALID, "bad arguments");
     double flops = 0, slab = 0;
-    for (const Plan& pl : job->plans) {
+    const bool shm = job->gplan != nullptr;
+    auto add = [&](const Plan& pl, bool skip_b11) {
         const Prob& p = pl.p;
         const int mt = p.Mp / TILE;
         auto rows = [&](int t) { int left = (t < mt) ? p.M - t * TILE : p.U - (t - mt) * TILE; return left > TILE ? TILE : left; };
         auto halves = [](int r, int w) { int n = (r - w * 64 + 31) / 32; return n < 0 ? 0 : (n > 2 ? 2 : n); };
+        int pairs = 0;
         for (int pr = 0; pr < p.npair; pr++) {
             const int ti = pl.pair_ti[pr], tj = pl.pair_tj[pr];
+            if (skip_b11 && ti < mt) continue;               // multiplied once, on the job-wide tiles
+            pairs++;
             double tiles32 = 0;
             for (int wr = 0; wr < 2; wr++)
                 for (int wc = 0; wc < 2; wc++) {
@@ -1936,8 +2091,10 @@ int gauss_job_stats(gauss_job* job, double* out4)
                 }
             flops += tiles32 * 32.0 * 32.0 * 2.0 * p.Kp;
         }
-        slab += (double)p.npair * p.nseg * TILE * TILE * (p.slab16 ? sizeof(uint16_t) : sizeof(float));
-    }
+        slab += (double)pairs * p.nseg * TILE * TILE * (p.slab16 ? sizeof(uint16_t) : sizeof(float));
+    };
+    for (const Plan& pl : job->plans) add(pl, shm);
+    if (shm) add(*job->gplan, false);
     out4[0] = job->n_items; out4[1] = flops; out4[2] = slab; out4[3] = (double)job->ws_bytes;
     return GAUSS_OK;
 }

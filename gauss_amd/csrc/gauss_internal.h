@@ -18,6 +18,7 @@ constexpr int NR = 64;         // right-hand sides per solve panel (63 SNPs + th
 constexpr int NRU = NR - 1;
 constexpr int WIN_QCAT = 1;          // gauss_window_desc.kind == GAUSS_WIN_QCAT
 constexpr int WIN_LD = 2;            // gauss_window_desc.kind == GAUSS_WIN_LD
+constexpr int TILE_GB11 = 1 << 30;   // tilemap.y flag: the entry is a job-wide B11 pair (Prob::gpair_*), seen from this window
 
 // Pointers stored inside a Prob are loaded from memory, so the compiler could not infer their
 // address space and would emit flat_* accesses.  Everything a Prob points to is device global
@@ -56,9 +57,17 @@ struct Prob {
     long long ld_raw;
     GP(const uint8_t) raw_m;   // [M x ld_raw]
     GP(const uint8_t) raw_u;   // [U x ld_raw]
-    GP(uint8_t) packed;        // [Sp x Kp]
-    GP(int) sx;                // [Sp x P] per-population sum x
-    GP(int) sxx;               // [Sp x P] per-population sum x^2
+    // Row arrays come in two parts: the measured rows [0, Mp) behind `X`, the unmeasured rows [Mp, Sp) behind `X_u`
+    // (indexed from 0).  Ordinarily X_u = X + Mp rows of one array.  In a job whose windows share their measured SNPs
+    // (gauss_hip.cpp: shared measured rows) X points INTO the job-wide arrays of the chromosome's measured SNPs, at this
+    // window's first one (g0): rows the windows have in common are packed once, and the tile pairs of B11 -- formed on
+    // job-wide row tiles, `gpair_*` / `slab_g` -- are multiplied once for all the windows they lie in.
+    GP(uint8_t) packed;        // [Mp x Kp]
+    GP(uint8_t) packed_u;      // [Up x Kp]
+    GP(int) sx;                // [.. x P] per-population sum x
+    GP(int) sxx;               // [.. x P] per-population sum x^2
+    GP(int) sx_u;
+    GP(int) sxx_u;
     GP(const int) pop_raw_off; // [P+1]
     GP(const int) pop_pk_off;  // [P+1] packed column offsets (multiples of KC)
     GP(const double) pop_w;    // [P]
@@ -78,10 +87,19 @@ struct Prob {
     GP(const int) run_pk_off;  // [n_run+1] packed column range of each run
     GP(const int) run_src;     // [n_run] byte offset of each run inside a source row
     GP(float) slab;            // [npair*nseg][TILE*TILE] exact integer partial Grams
-    GP(double) rt_sd;          // [Sp] weighted: sqrt(self cov); pooled: sqrt(n*Sxx - Sx^2)
-    GP(double) rt_wm;          // [Sp] weighted: sum_p w_p mu_p ; pooled: Sx (as double)
-    GP(double) rt_mu;          // [Sp x P] Sx_p / m_p
-    GP(double) rt_wmu;         // [Sp x P] w_p * mu_p
+    GP(double) rt_sd;          // [..] weighted: sqrt(self cov); pooled: sqrt(n*Sxx - Sx^2)
+    GP(double) rt_wm;          // [..] weighted: sum_p w_p mu_p ; pooled: Sx (as double)
+    GP(double) rt_mu;          // [.. x P] Sx_p / m_p
+    GP(double) rt_wmu;         // [.. x P] w_p * mu_p
+    GP(double) rt_sd_u;
+    GP(double) rt_wm_u;
+    GP(double) rt_mu_u;
+    GP(double) rt_wmu_u;
+    int g0;                    // shared measured rows: job-wide index of this window's first measured SNP (else 0)
+    int n_gpair;               // shared measured rows: job-wide B11 tile pairs (0: B11's pairs are pair_ti / pair_tj / slab)
+    GP(const int) gpair_ti;    // [n_gpair] job-wide row tiles of the pair (gi <= gj)
+    GP(const int) gpair_tj;
+    GP(float) slab_g;          // [n_gpair * nseg][TILE*TILE] partial Grams of the job-wide B11 pairs
     GP(const double) z1;       // [M]
     GP(double) A;              // [5][Mld x Mld] row-major: B11, B11 - eps*I, their factors L0, L1, working copy W0 of B11
     GP(double) Linv;           // [2][nblk][NB x NB] inverses of the diagonal Cholesky blocks

@@ -26,9 +26,10 @@ __global__ __launch_bounds__(256) void pack_stats_kernel(const Prob* __restrict_
     const Prob& pb = probs[rm.x];
     const int r = rm.y;
     const uint8_t* src;
-    int prow;
+    int prow;                       // row inside its part: measured rows [0, M), unmeasured rows [0, U)
+    const bool um = r >= pb.M;
     int code = 0;
-    if (r < pb.M) {
+    if (!um) {
         const long long srow = pb.rows_m ? pb.rows_m[r] : r;            // row lists gather from a resident store
         src = pb.raw_m + (size_t)srow * pb.ld_raw; prow = r;
     } else {
@@ -38,10 +39,10 @@ __global__ __launch_bounds__(256) void pack_stats_kernel(const Prob* __restrict_
         const int rr = ur - blk * pb.U_raw;
         const long long srow = pb.rows_u ? pb.rows_u[rr] : rr;
         src = pb.raw_u + (size_t)srow * pb.ld_raw;
-        prow = pb.Mp + ur;
+        prow = ur;
         code = pb.code_blk[blk];
     }
-    uint4* dst = reinterpret_cast<uint4*>(pb.packed + (size_t)prow * pb.Kp);
+    uint4* dst = reinterpret_cast<uint4*>((um ? pb.packed_u : pb.packed) + (size_t)prow * pb.Kp);
 
     __shared__ int s_sx[64];
     __shared__ int s_sxx[64];
@@ -184,8 +185,8 @@ __global__ __launch_bounds__(256) void pack_stats_kernel(const Prob* __restrict_
     }
     __syncthreads();
     if (threadIdx.x < pb.P) {
-        pb.sx[(size_t)prow * pb.P + threadIdx.x] = s_sx[threadIdx.x];
-        pb.sxx[(size_t)prow * pb.P + threadIdx.x] = s_sxx[threadIdx.x];
+        (um ? pb.sx_u : pb.sx)[(size_t)prow * pb.P + threadIdx.x] = s_sx[threadIdx.x];
+        (um ? pb.sxx_u : pb.sxx)[(size_t)prow * pb.P + threadIdx.x] = s_sxx[threadIdx.x];
     }
 }
 
@@ -210,10 +211,15 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const Prob* __restrict__
     const int2 rm = rowmap[idx];
     const Prob& pb = probs[rm.x];
     const int r = rm.y;
-    const int prow = (r < pb.M) ? r : pb.Mp + (r - pb.M);
+    const bool um = r >= pb.M;
+    const int prow = um ? r - pb.M : r;            // row inside its part (Prob: measured / unmeasured row arrays)
     const int P = pb.P;
-    const int* sx = pb.sx + (size_t)prow * P;
-    const int* sxx = pb.sxx + (size_t)prow * P;
+    const int* sx = (um ? pb.sx_u : pb.sx) + (size_t)prow * P;
+    const int* sxx = (um ? pb.sxx_u : pb.sxx) + (size_t)prow * P;
+    const auto rt_wm = um ? pb.rt_wm_u : pb.rt_wm;
+    const auto rt_sd = um ? pb.rt_sd_u : pb.rt_sd;
+    const auto rt_mu = um ? pb.rt_mu_u : pb.rt_mu;
+    const auto rt_wmu = um ? pb.rt_wmu_u : pb.rt_wmu;
     if (pb.mode == 0) {
         double sumx = 0, sumxsq = 0;
         int num_samples = 0;
@@ -222,8 +228,8 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const Prob* __restrict__
             sumxsq += (double)sxx[p];
             num_samples += pb.pop_raw_off[p + 1] - pb.pop_raw_off[p];
         }
-        pb.rt_wm[prow] = sumx;
-        pb.rt_sd[prow] = sqrt((num_samples) * sumxsq - sumx * sumx);
+        rt_wm[prow] = sumx;
+        rt_sd[prow] = sqrt((num_samples) * sumxsq - sumx * sumx);
     } else {
         double wsumcov = 0, wsum_mi_mj = 0, wsum_mi = 0;
         for (int p = 0; p < P; p++) {
@@ -237,11 +243,11 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const Prob* __restrict__
             const double wmu = wgt_val * mu;
             wsum_mi_mj += wmu * mu;
             wsum_mi += wmu;
-            pb.rt_mu[(size_t)prow * P + p] = mu;
-            pb.rt_wmu[(size_t)prow * P + p] = wmu;
+            rt_mu[(size_t)prow * P + p] = mu;
+            rt_wmu[(size_t)prow * P + p] = wmu;
         }
-        pb.rt_wm[prow] = wsum_mi;
-        pb.rt_sd[prow] = sqrt(wsumcov + wsum_mi_mj - wsum_mi * wsum_mi);
+        rt_wm[prow] = wsum_mi;
+        rt_sd[prow] = sqrt(wsumcov + wsum_mi_mj - wsum_mi * wsum_mi);
     }
 }
 
@@ -258,23 +264,26 @@ void launch_row_stats(const Prob* d_probs, const int2* d_rowmap, int n_rows, hip
 // A partial slab holds exact integers, as f32 (f32 MFMA path) or int32 (i8 MFMA path).
 __device__ __forceinline__ double slab_val(float v, int is_int) { return is_int ? (double)__float_as_int(v) : (double)v; }
 
+// ri: row of the first argument inside its part -- a measured row, or (ri_unmeasured) an unmeasured one; rj: measured row.
 __device__ __forceinline__ double cor_entry(const Prob& pb, const float* __restrict__ tile_slab,
-                                            int off, int ri, int rj)
+                                            int off, int ri, int rj, bool ri_unmeasured = false)
 {
     const int P = pb.P;
+    const auto rt_wm_i = ri_unmeasured ? pb.rt_wm_u : pb.rt_wm;
+    const auto rt_sd_i = ri_unmeasured ? pb.rt_sd_u : pb.rt_sd;
     const size_t seg_stride = (size_t)TILE * TILE;
     if (pb.mode == 0) {
         double sumxy = 0;
         for (int s = 0; s < pb.nseg; s++) sumxy += slab_val(tile_slab[s * seg_stride + off], pb.gram_i8);
         const int num_samples = pb.N;
-        const double numer = num_samples * sumxy - pb.rt_wm[ri] * pb.rt_wm[rj];   // util.cpp:66
-        const double denor = pb.rt_sd[ri] * pb.rt_sd[rj];                         // util.cpp:67
+        const double numer = num_samples * sumxy - rt_wm_i[ri] * pb.rt_wm[rj];    // util.cpp:66
+        const double denor = rt_sd_i[ri] * pb.rt_sd[rj];                          // util.cpp:67
         return numer / denor;                                                     // util.cpp:68
     }
     double wsumcov = 0, wsum_mi_mj = 0;
-    const int* sxi = pb.sx + (size_t)ri * P;
+    const int* sxi = (ri_unmeasured ? pb.sx_u : pb.sx) + (size_t)ri * P;
     const int* sxj = pb.sx + (size_t)rj * P;
-    const double* wmui = pb.rt_wmu + (size_t)ri * P;
+    const double* wmui = (ri_unmeasured ? pb.rt_wmu_u : pb.rt_wmu) + (size_t)ri * P;
     const double* muj = pb.rt_mu + (size_t)rj * P;
     for (int p = 0; p < P; p++) {
         double sumxy = 0;
@@ -285,8 +294,8 @@ __device__ __forceinline__ double cor_entry(const Prob& pb, const float* __restr
         wsumcov += pb.pop_wf[p] * (pb.pop_md[p] * sumxy - sumx * sumy);            // util.cpp:118
         wsum_mi_mj += wmui[p] * muj[p];                                            // util.cpp:119
     }
-    const double cov = wsumcov + wsum_mi_mj - pb.rt_wm[ri] * pb.rt_wm[rj];        // util.cpp:123
-    return cov / (pb.rt_sd[ri] * pb.rt_sd[rj]);                                   // distmix.cpp:196
+    const double cov = wsumcov + wsum_mi_mj - rt_wm_i[ri] * pb.rt_wm[rj];         // util.cpp:123
+    return cov / (rt_sd_i[ri] * pb.rt_sd[rj]);                                    // distmix.cpp:196
 }
 
 // ------------------------------------------------------------------------------------------
@@ -341,19 +350,33 @@ template <bool ISINT, bool S16> struct SlabBlock {
 };
 
 template <bool ISINT, bool S16>
-__device__ __forceinline__ void epilogue_tile(const Prob& pb, int pair, int lds_pop_cap, char* esm)
+__device__ __forceinline__ void epilogue_tile(const Prob& pb, int pair_in, int lds_pop_cap, char* esm)
 {
-    const int ti = pb.pair_ti[pair], tj = pb.pair_tj[pair];
+    // A B11 tile pair of a job whose windows share their measured rows lies on JOB-WIDE row tiles (gpair_*, slab_g); this
+    // window sees it shifted by g0, its first measured SNP: tile row r of job-wide tile gi is the window's measured row
+    // gi * TILE + r - g0, which may fall outside [0, M) (another window's SNP: skipped below).  The row tables are
+    // reached through the window's `X` pointers, which point into the job-wide arrays at g0, so the same (possibly
+    // negative) window-relative index addresses them.
+    const bool gb11 = (pair_in & TILE_GB11) != 0;
+    const int pair = pair_in & ~TILE_GB11;
+    const int ti = gb11 ? pb.gpair_ti[pair] : pb.pair_ti[pair], tj = gb11 ? pb.gpair_tj[pair] : pb.pair_tj[pair];
     const int P = pb.P, nseg = pb.nseg;
     // the pair's slabs; 16-bit slabs take half the floats (the planner only selects them when P fits the LDS tables)
-    const auto tile_slab = pb.slab + (size_t)pair * nseg * (S16 ? TILE * TILE / 2 : TILE * TILE);
+    const auto tile_slab = (gb11 ? pb.slab_g : pb.slab) + (size_t)pair * nseg * (S16 ? TILE * TILE / 2 : TILE * TILE);
     const int mt = pb.Mp / TILE;        // number of measured row tiles
-    const bool sym = (ti < mt);         // measured x measured tile (ti <= tj < mt)
+    const bool sym = gb11 || (ti < mt); // measured x measured tile (ti <= tj)
     const int Mld = pb.Mld;
     const bool need_a1 = !(pb.npanel > 0 && pb.status[3] != 0);      // status[3]: lambda_min(B11) > eps is certified
     const int tid = threadIdx.x;
     const bool weighted = pb.mode != 0;
     const bool lds_tables = weighted && P <= lds_pop_cap;
+    // first row of the tile inside its part (measured rows / unmeasured rows), and the row arrays of that part
+    const int row0_i = gb11 ? ti * TILE - pb.g0 : (sym ? ti * TILE : (ti - mt) * TILE);
+    const int row0_j = gb11 ? tj * TILE - pb.g0 : tj * TILE;
+    const auto i_wmu = sym ? pb.rt_wmu : pb.rt_wmu_u;
+    const auto i_sx = sym ? pb.sx : pb.sx_u;
+    const auto i_wm = sym ? pb.rt_wm : pb.rt_wm_u;
+    const auto i_sd = sym ? pb.rt_sd : pb.rt_sd_u;
 
     double* s_wmui = reinterpret_cast<double*>(esm);          // [P][128]  w_p * mu_p(row i)
     double* s_muj = s_wmui + P * TILE;                        // [P][128]  mu_p(col j)
@@ -362,10 +385,10 @@ __device__ __forceinline__ void epilogue_tile(const Prob& pb, int pair, int lds_
     if (lds_tables) {
         for (int idx = tid; idx < P * TILE; idx += 1024) {
             const int r = idx / P, p = idx % P;               // consecutive threads: consecutive p of a row
-            s_wmui[p * TILE + r] = pb.rt_wmu[(size_t)(ti * TILE + r) * P + p];
-            s_sxi[p * TILE + r] = pb.sx[(size_t)(ti * TILE + r) * P + p];
-            s_muj[p * TILE + r] = pb.rt_mu[(size_t)(tj * TILE + r) * P + p];
-            s_sxj[p * TILE + r] = pb.sx[(size_t)(tj * TILE + r) * P + p];
+            s_wmui[p * TILE + r] = i_wmu[(ptrdiff_t)(row0_i + r) * P + p];
+            s_sxi[p * TILE + r] = i_sx[(ptrdiff_t)(row0_i + r) * P + p];
+            s_muj[p * TILE + r] = pb.rt_mu[(ptrdiff_t)(row0_j + r) * P + p];
+            s_sxj[p * TILE + r] = pb.sx[(ptrdiff_t)(row0_j + r) * P + p];
         }
         __syncthreads();
     }
@@ -379,7 +402,7 @@ __device__ __forceinline__ void epilogue_tile(const Prob& pb, int pair, int lds_
     double cov[4][4];
     double sd_j[4], wm_j[4];
 #pragma unroll
-    for (int c = 0; c < 4; c++) { sd_j[c] = pb.rt_sd[tj * TILE + c0 + c]; wm_j[c] = pb.rt_wm[tj * TILE + c0 + c]; }
+    for (int c = 0; c < 4; c++) { sd_j[c] = pb.rt_sd[row0_j + c0 + c]; wm_j[c] = pb.rt_wm[row0_j + c0 + c]; }
     const int num_samples = pb.N;
 
     if (!weighted) {
@@ -406,8 +429,8 @@ __device__ __forceinline__ void epilogue_tile(const Prob& pb, int pair, int lds_
             for (int c = 0; c < 4; c++) sumxy[q][c] = acc[q][c].get();
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const int ri = ti * TILE + rows[q];
-            const double wm_i = pb.rt_wm[ri], sd_i = pb.rt_sd[ri];
+            const int ri = row0_i + rows[q];
+            const double wm_i = i_wm[ri], sd_i = i_sd[ri];
 #pragma unroll
             for (int c = 0; c < 4; c++) {
                 const double numer = num_samples * sumxy[q][c] - wm_i * wm_j[c];
@@ -466,8 +489,8 @@ __device__ __forceinline__ void epilogue_tile(const Prob& pb, int pair, int lds_
         }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const int ri = ti * TILE + rows[q];
-            const double wm_i = pb.rt_wm[ri], sd_i = pb.rt_sd[ri];
+            const int ri = row0_i + rows[q];
+            const double wm_i = i_wm[ri], sd_i = i_sd[ri];
 #pragma unroll
             for (int c = 0; c < 4; c++) {
                 const double cv = wsumcov[q][c] + wmm[q][c] - wm_i * wm_j[c];                                // util.cpp:123
@@ -479,17 +502,17 @@ __device__ __forceinline__ void epilogue_tile(const Prob& pb, int pair, int lds_
         for (int q = 0; q < 4; q++)
 #pragma unroll
             for (int c = 0; c < 4; c++)
-                cov[q][c] = cor_entry(pb, (const float*)tile_slab, rows[q] * TILE + c0 + c, ti * TILE + rows[q], tj * TILE + c0 + c);
+                cov[q][c] = cor_entry(pb, (const float*)tile_slab, rows[q] * TILE + c0 + c, row0_i + rows[q], row0_j + c0 + c, !sym);
     }
 
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        const int ri = ti * TILE + rows[q];
+        const int ri = row0_i + rows[q];
 #pragma unroll
         for (int c = 0; c < 4; c++) {
-            const int rj = tj * TILE + c0 + c;
+            const int rj = row0_j + c0 + c;
             if (sym) {
-                if (ri > rj) continue;                            // mirror handles the lower part
+                if (ri > rj || ri < 0) continue;                  // mirror handles the lower part; ri < 0: not this window's SNP
                 if (pb.ld_only) {
                     if (ri >= pb.M || rj >= pb.M) continue;
                     const double v = (ri == rj) ? pb.diag : cov[q][c];
@@ -513,10 +536,22 @@ __device__ __forceinline__ void epilogue_tile(const Prob& pb, int pair, int lds_
                     W0[(size_t)ri * Mld + rj] = v0; W0[(size_t)rj * Mld + ri] = v0;
                 }
             } else {
-                const int u = ri - pb.Mp;                         // unmeasured row (x), measured col (y)
+                const int u = ri;                                 // unmeasured row (x), measured col (y)
                 if (u >= pb.U || rj >= pb.M) continue;
                 pb.B21[(size_t)u * Mld + rj] = cov[q][c];         // dist.cpp:188-191
             }
+        }
+    }
+    // Job-wide tiles end where the chromosome's measured SNPs end, not where this window's do: the identity padding of
+    // B11 between M and Mld (rows of no SNP; the tiles of an unshared window write it as part of their own padding) is
+    // written by the workgroup of the window's LAST diagonal tile.
+    if (gb11 && ti == tj && !pb.ld_only && pb.g0 + pb.M - 1 >= ti * TILE && pb.g0 + pb.M - 1 < (ti + 1) * TILE) {
+        for (int e = tid; e < (Mld - pb.M) * Mld; e += 1024) {
+            const int r = pb.M + e / Mld, c = e % Mld;
+            const double v = (r == c) ? 1.0 : 0.0;
+            pb.A[(size_t)r * Mld + c] = v; pb.A[(size_t)c * Mld + r] = v;
+            if (need_a1) { pb.A[(size_t)Mld * Mld + (size_t)r * Mld + c] = v; pb.A[(size_t)Mld * Mld + (size_t)c * Mld + r] = v; }
+            if (pb.npanel > 0) { pb.A[(size_t)4 * Mld * Mld + (size_t)r * Mld + c] = v; pb.A[(size_t)4 * Mld * Mld + (size_t)c * Mld + r] = v; }
         }
     }
 }

@@ -9,6 +9,7 @@ import pytest
 
 import oracle
 from gauss_amd import hotpath
+from gauss_amd import panel as panel_mod
 from helpers import relerr, small_panel, split_window
 
 pytestmark = pytest.mark.gpu
@@ -649,3 +650,60 @@ def test_two_runs_of_a_job_in_flight(ctx):
                 if want_mats:
                     assert np.array_equal(r["b11"], w["b11"]) and np.array_equal(r["b21"], w["b21"])
         job.close()
+
+
+@pytest.mark.gpu
+def test_shared_measured_rows_give_the_bits_of_separate_windows(ctx, monkeypatch):
+    """Windows of a chromosome name their measured SNPs as runs of one ascending list of store rows: the job packs those
+    rows once and multiplies B11's tile pairs once on job-wide row tiles (gauss_hip.cpp, shared measured rows) -- LD
+    entries depend on the SNP pair only (distmix.cpp:190-200), so z, info, B11 and B21 must equal, bit for bit, what the
+    same windows give when every window packs and multiplies its own copy.  Window starts fall inside row tiles (not
+    multiples of 128), windows overlap by half, one window ends the list, one QCAT window shares the job."""
+    p = small_panel(n_snp=1500, scale=0.05, seed=31)
+    G = p["G"]
+    rows2, src_off = panel_mod.pack2bit(G, p["off"])
+    store = hotpath.RowStore(rows2, ctx=ctx)
+    rng = np.random.default_rng(12)
+    n = G.shape[0]
+    measured = np.sort(rng.choice(n, size=n // 3, replace=False))
+    unmeasured = np.setdiff1d(np.arange(n), measured)
+    z = rng.standard_normal(n)
+    wins = []
+    for k, (a, b) in enumerate([(0, 230), (97, 340), (211, 455), (330, len(measured))]):
+        mi = measured[a:b]
+        lo, hi = mi[len(mi) // 4], mi[3 * len(mi) // 4]
+        ui = unmeasured[(unmeasured > lo) & (unmeasured < hi)]
+        d = dict(mode=k % 2 if k < 3 else 1, pop_off=p["off"], pop_wgt=p["w"], z1=z[mi], dev=(store.ptr, store.ptr, len(mi), len(ui), store.ld),
+                 packed=dict(fmt=1, rows_m=mi.astype(np.int32), rows_u=ui.astype(np.int32), pop_src_off=src_off))
+        wins.append(d)
+    # the same populations and mode are a condition for sharing: use one mode for the job proper
+    for d in wins:
+        d["mode"] = 1
+    wins[1] = dict(wins[1], qcat=(20, 60, 0.01))
+
+    def run(share):
+        monkeypatch.setenv("GAUSS_SHARE_MEASURED", "1" if share else "0")
+        job = hotpath.Job(wins, ctx=ctx, on_device=True, want_mats=True)
+        st = job.stats()
+        job.run()
+        a = job.fetch()
+        job.run()                                   # a second run of the same job: nothing stale is left behind
+        b = job.fetch()
+        job.close()
+        for x, y in zip(a, b):
+            for key in x:
+                if isinstance(x[key], np.ndarray):
+                    assert np.array_equal(x[key], y[key], equal_nan=True), key
+        return a, st
+
+    own, st_own = run(False)
+    shared, st_sh = run(True)
+    assert all("b11" in r and "b21" in r for r in own)
+    assert st_sh["executed_flops"] < st_own["executed_flops"] and st_sh["items"] < st_own["items"]
+    for x, y in zip(own, shared):
+        for key in x:
+            if isinstance(x[key], np.ndarray):
+                assert np.array_equal(x[key], y[key], equal_nan=True), key
+            else:
+                assert x[key] == y[key], key
+    store.close()
