@@ -695,6 +695,14 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
                         }
             }
             q.npair = (int)g.pair_ti.size();
+            // Job-wide tiles start where the list starts, not where a window does: a window of M rows lies in up to
+            // M / 128 + 2 of them, where its own tiles would be M / 128 + 1 -- more B11 pairs per window, which only
+            // pays when neighbouring windows share pairs.  The scattered windows of an LPT share (a multi-GPU rank)
+            // share nothing: 8-rank shares measured 5.98-6.04 ms per rank unshared against 6.0-6.4 shared.  Shared
+            // rows are used when they save at least 3 % of the job's B11 pairs.
+            size_t own_pairs = 0;
+            for (int i = 0; i < job->n; i++) { const size_t mt = (size_t)job->plans[i].p.Mp / TILE; own_pairs += mt * (mt + 1) / 2; }
+            if ((double)q.npair > 0.97 * (double)own_pairs && env_int("GAUSS_SHARE_MEASURED", 1) != 2) { job->gplan.reset(); job->g0.clear(); }
         }
     }
     const bool shm = job->gplan != nullptr;
@@ -1695,7 +1703,20 @@ int gauss_hip_init(int device, gauss_ctx** out_ctx)
     }
     const char* e = getenv("GAUSS_GRAM_DTYPE");
     c->gram_i8 = (e && (strcmp(e, "i8") == 0 || strcmp(e, "int8") == 0)) ? 1 : 0;
-    if (env_int("GAUSS_SIDE_STREAM", 1)) {
+    const int cu_main = env_int("GAUSS_CU_MASK_MAIN", 0);
+    if (cu_main > 0) {
+        // experiment (tools/experiments/README.md, round 3): every launch of the context confined to the first `cu_main`
+        // CUs (hipExtStreamCreateWithCUMask) -- what the Gram kernel loses when CUs are set aside for a tail stream,
+        // and what the factorisation chain takes on a handful of CUs.  One stream; never the default.
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, device));
+        const int total = prop.multiProcessorCount;
+        std::vector<uint32_t> mask((size_t)(total + 31) / 32, 0u);
+        // mask bit i is CU i / 8 of XCD i % 8 (measured: clearing bits 0, 32, 64, ... slows the Gram kernel by a third --
+        // one XCD short of 8 CUs): the first n bits are n / 8 CUs of every XCD
+        for (int cu = 0; cu < std::min(cu_main, total); cu++) mask[(size_t)cu / 32] |= 1u << (cu % 32);
+        HIPCHK(hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)mask.size(), mask.data()));
+    } else if (env_int("GAUSS_SIDE_STREAM", 1)) {
         // the chain gets the higher priority: a workgroup of its next launch must win the CU an epilogue workgroup frees
         int lo = 0, hi = 0;
         HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
