@@ -50,7 +50,7 @@ _lib = None
 
 # every symbol include/gauss_hip.h declares
 SYMBOLS = [
-    "gauss_hip_init", "gauss_hip_device_count", "gauss_hip_device_of", "gauss_hip_destroy", "gauss_last_error", "gauss_hip_version", "gauss_hip_set_gram_dtype", "gauss_pinned_alloc", "gauss_pinned_free", "gauss_store_upload", "gauss_store_free", "gauss_pack2bit_device", "gauss_ld", "gauss_ld_per_pop",
+    "gauss_hip_init", "gauss_hip_device_count", "gauss_hip_device_of", "gauss_hip_destroy", "gauss_last_error", "gauss_hip_version", "gauss_hip_set_gram_dtype", "gauss_pinned_alloc", "gauss_pinned_free", "gauss_store_upload", "gauss_store_free", "gauss_pack2bit_device", "gauss_ld", "gauss_ld_per_pop", "gauss_ld_per_pop_pairs",
     "gauss_impute_window", "gauss_gene_ld_batch", "gauss_gram_counts", "gauss_job_create",
     "gauss_ld_rows", "gauss_gene_ld_batch_rows", "gauss_job_run", "gauss_job_fetch", "gauss_job_destroy", "gauss_job_span_ms", "gauss_job_profile",
     "gauss_job_profile_get", "gauss_job_work", "gauss_job_stats", "gauss_synth_device",
@@ -90,6 +90,7 @@ def load():
                              C.c_double, _dp]
     lib.gauss_pack2bit_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, _ip, C.c_int]
     lib.gauss_ld_per_pop.argtypes = [C.c_void_p, _u8p, C.c_int, C.c_int64, _ip, C.c_int, _dp]
+    lib.gauss_ld_per_pop_pairs.argtypes = [C.c_void_p, _u8p, C.c_int, C.c_int64, _ip, C.c_int, _ip, C.c_int, _ip, _ip, C.c_int64, _dp]
     lib.gauss_impute_window.argtypes = [C.c_void_p, C.POINTER(WindowDesc)]
     lib.gauss_gene_ld_batch.argtypes = [C.c_void_p, C.c_int, _u8p, C.c_int, C.c_int64, _ip, _dp,
                                         C.c_int, _ip, C.c_int, C.c_double, _dp]

@@ -32,7 +32,7 @@ HOST_SYMBOLS = [
     "gauss_table_coltype", "gauss_table_str", "gauss_table_int", "gauss_table_dbl", "gauss_table_matrix",
     "gauss_table_free", "gauss_table_strcol", "gauss_host_computeLD", "gauss_host_dist", "gauss_host_distmix", "gauss_host_jepeg",
     "gauss_host_jepegmix", "gauss_host_qcat", "gauss_host_qcatmix", "gauss_prepared_qcat_counts",
-    "gauss_host_prep_qcat", "gauss_host_prep_recessive_impute", "gauss_host_pack_panel", "gauss_prepared_packed_store", "gauss_host_prep_zmix5", "gauss_table_n_named", "gauss_table_named_name",
+    "gauss_host_prep_qcat", "gauss_host_prep_recessive_impute", "gauss_host_pack_panel", "gauss_prepared_packed_store", "gauss_host_prep_zmix5", "gauss_host_prep_zmix", "gauss_host_prep_zmix2", "gauss_host_prep_zmix3", "gauss_host_prep_zmix4", "gauss_host_prep_zmix5_sup", "gauss_table_n_named", "gauss_table_named_name",
     "gauss_table_named", "gauss_host_prepare", "gauss_prepared_snps", "gauss_prepared_counts",
     "gauss_prepared_measured_rows", "gauss_prepared_unmeasured_rows", "gauss_prepared_geno_m",
     "gauss_prepared_geno_u", "gauss_prepared_pop_off", "gauss_prepared_pop_wgt", "gauss_prepared_z1",
@@ -98,6 +98,10 @@ def load_host():
     h.gauss_host_jepeg.argtypes = [_vp, _cp, _cp] + files4 + [_dbl, C.POINTER(_vp)]
     h.gauss_host_jepegmix.argtypes = [_vp, _strs, _dp, C.c_int, _cp] + files4 + [_dbl, C.POINTER(_vp)]
     h.gauss_host_prep_zmix5.argtypes = [_vp, _cp, _cp, _cp, _cp, _dbl, C.c_int, C.POINTER(_vp)]
+    h.gauss_host_prep_zmix5_sup.argtypes = [_vp, _cp, _cp, _cp, _cp, _dbl, C.c_int, C.POINTER(_vp)]
+    h.gauss_host_prep_zmix.argtypes = [_vp, _cp, _cp, _cp, _cp, C.c_int, C.POINTER(_vp)]
+    for f in (h.gauss_host_prep_zmix2, h.gauss_host_prep_zmix3, h.gauss_host_prep_zmix4):
+        f.argtypes = [_vp, _cp, _cp, _cp, _cp, C.c_int, C.c_int, C.POINTER(_vp)]
     h.gauss_host_pack_panel.restype = _i64
     h.gauss_host_pack_panel.argtypes = [_cp, _cp, _cp, _cp]
     h.gauss_prepared_packed_store.argtypes = [_vp, C.POINTER(C.c_void_p), C.POINTER(_i64), C.POINTER(_i64)]
@@ -331,6 +335,27 @@ def prep_zmix5(input_file, reference_index_file, reference_data_file, reference_
     named = _named(h, out)
     df = _table(h, out)[0]
     return (named["data_mat"], df) if with_snps else named["data_mat"]
+
+
+def prep_zmix_variant(variant, input_file, reference_index_file, reference_data_file, reference_pop_desc_file, percentile=None,
+                      interval=None, p2=None, ctx=None):
+    """prep_zmix() / prep_zmix2() / prep_zmix3() / prep_zmix4() / prep_zmix5_sup() of the reference (zmix.cpp:201-1076;
+    variant "zmix", "zmix2", "zmix3", "zmix4", "zmix5_sup"; p2 = offset or steps).  Returns dict(data_mat, snps (DataFrame),
+    pairs [n_pairs x 2] rows of snps, groups: the names of the correlation columns)."""
+    h = load_host()
+    out = _vp()
+    files = (_enc(input_file), _enc(reference_index_file), _enc(reference_data_file), _enc(reference_pop_desc_file))
+    if variant == "zmix":
+        _hcheck(h.gauss_host_prep_zmix(_ctx(ctx), *files, int(interval or 0), C.byref(out)))
+    elif variant == "zmix5_sup":
+        _hcheck(h.gauss_host_prep_zmix5_sup(_ctx(ctx), *files, _af(percentile), int(interval or 0), C.byref(out)))
+    else:
+        fn = {"zmix2": h.gauss_host_prep_zmix2, "zmix3": h.gauss_host_prep_zmix3, "zmix4": h.gauss_host_prep_zmix4}[variant]
+        _hcheck(fn(_ctx(ctx), *files, int(interval or 0), int(p2 or 0), C.byref(out)))
+    named = _named(h, out)
+    groups = [h.gauss_table_message(out, k).decode() for k in range(h.gauss_table_n_messages(out))]
+    df = _table(h, out)[0]
+    return dict(data_mat=named["data_mat"], pairs=named["pairs"].astype(np.int64), snps=df, groups=groups)
 
 
 def jepeg(study_pop, input_file, annotation_file, reference_index_file, reference_data_file, reference_pop_desc_file,

@@ -388,6 +388,9 @@ struct WinSpec {
     const int32_t* rows_u = nullptr;
     const int32_t* pop_src_off = nullptr;    // 2-bit: byte offset of each population block in a row
     double eig_cutoff = 0.01;
+    const int32_t* pair_i = nullptr;         // LD-only: only these SNP pairs are wanted (tile pairs they touch), else all
+    const int32_t* pair_j = nullptr;
+    int64_t n_pairs = 0;
 };
 
 // K segment length: short segments give a single window enough work items to fill 256 CUs;
@@ -591,6 +594,14 @@ static int plan_problem(const WinSpec& w, Plan& pl, int seg_max, int group_targe
         }
         pl.out_ld_count = (size_t)off;
         p.n_gene = w.n_gene;
+    } else if (w.pair_i) {
+        // listed pairs (prep_zmix selectors): the tile pairs they touch
+        for (int64_t k = 0; k < w.n_pairs; k++) {
+            const int i = w.pair_i[k], j = w.pair_j[k];
+            if (i < 0 || j <= i || j >= w.M) return fail(GAUSS_E_INVALID, "pair %lld = (%d, %d) is not i < j < n_snp", (long long)k, i, j);
+            add_pair(i / TILE, j / TILE);
+        }
+        pl.out_ld_count = 0;
     } else {
         for (int ti = 0; ti < mt; ti++)
             for (int tj = ti; tj < mt; tj++) add_pair(ti, tj);          // B11 (upper tiles)
@@ -2289,6 +2300,49 @@ int gauss_ld_per_pop(gauss_ctx* ctx, const uint8_t* geno, int n_snp, int64_t ld,
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipMemcpy(out, d_out.p, bytes, hipMemcpyDeviceToHost));
+    return GAUSS_OK;
+}
+
+int gauss_ld_per_pop_pairs(gauss_ctx* ctx, const uint8_t* geno, int n_snp, int64_t ld, const int32_t* pop_off, int n_pop,
+                           const int32_t* pop_group, int n_group, const int32_t* pair_i, const int32_t* pair_j, int64_t n_pairs,
+                           double* out)
+{
+    if (!ctx || !geno || !pop_off || !out || !pair_i || !pair_j) return fail(GAUSS_E_INVALID, "bad arguments to gauss_ld_per_pop_pairs");
+    if (n_snp < 2 || n_pairs < 1) return fail(GAUSS_E_INVALID, "need at least two SNPs and one pair");
+    if (!pop_group) n_group = n_pop;
+    if (n_group < 1) return fail(GAUSS_E_INVALID, "n_group < 1");
+    if (pop_group)
+        for (int p = 0; p < n_pop; p++)
+            if (pop_group[p] < 0 || pop_group[p] >= n_group) return fail(GAUSS_E_INVALID, "pop_group[%d] = %d is outside 0..%d", p, pop_group[p], n_group - 1);
+    std::vector<double> ones((size_t)std::max(n_pop, 1), 1.0);
+    WinSpec w;
+    w.mode = GAUSS_MODE_WEIGHTED; w.n_pop = n_pop; w.pop_off = pop_off; w.pop_wgt = ones.data();
+    w.M = n_snp; w.U = 0; w.geno_m = geno; w.geno_u = nullptr; w.ld = ld; w.z1 = nullptr;
+    w.lambda = 0; w.eps = 0; w.diag = 1.0; w.ld_only = 1; w.gene_off = nullptr; w.n_gene = 0;
+    w.pair_i = pair_i; w.pair_j = pair_j; w.n_pairs = n_pairs;
+    gauss_job* job = nullptr;
+    std::vector<WinSpec> specs{w};
+    int rc = job_build(ctx, specs, 0, &job);
+    if (rc) return rc;
+    std::unique_ptr<gauss_job, void (*)(gauss_job*)> guard(job, job_free);
+    // pack + Gram only: the LD epilogue has nothing to write for a pair list
+    hipStream_t st = ctx->stream;
+    launch_pack_stats(job->d_probs, job->d_rowmap, job->n_rows, st);
+    launch_gram(job->d_items, job->n_items, job->gram_i8, st);
+    HIPCHK(hipGetLastError());
+    std::vector<int2> pairs((size_t)n_pairs);
+    for (int64_t k = 0; k < n_pairs; k++) pairs[(size_t)k] = make_int2(pair_i[k], pair_j[k]);
+    DevBuf d_pairs, d_grp, d_out;
+    const size_t out_bytes = sizeof(double) * (size_t)n_pairs * (size_t)n_group;
+    if (d_pairs.alloc(ctx, sizeof(int2) * pairs.size()) != hipSuccess || d_grp.alloc(ctx, sizeof(int) * (size_t)std::max(n_pop, 1)) != hipSuccess ||
+        d_out.alloc(ctx, out_bytes) != hipSuccess)
+        return fail(GAUSS_E_NOMEM, "hipMalloc(%zu bytes of pair correlations) failed", out_bytes);
+    HIPCHK(hipMemcpyAsync(d_pairs.p, pairs.data(), sizeof(int2) * pairs.size(), hipMemcpyHostToDevice, st));
+    if (pop_group) HIPCHK(hipMemcpyAsync(d_grp.p, pop_group, sizeof(int) * (size_t)n_pop, hipMemcpyHostToDevice, st));
+    launch_pair_cor(job->d_probs, 0, d_pairs.as<int2>(), n_pairs, pop_group ? d_grp.as<int>() : nullptr, n_group, d_out.as<double>(), st);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipMemcpy(out, d_out.p, out_bytes, hipMemcpyDeviceToHost));
     return GAUSS_OK;
 }
 

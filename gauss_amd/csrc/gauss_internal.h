@@ -183,6 +183,8 @@ void launch_row_stats(const Prob* d_probs, const int2* d_rowmap, int n_rows, hip
 void launch_gram(const Item* d_items, int n_items, int dtype_i8, hipStream_t s);
 void launch_epilogue(const Prob* d_probs, const int2* d_tilemap, int n_tiles, int max_pop, int dtype_i8, hipStream_t s);
 void launch_pop_cor(const Prob* d_probs, int prob, int npair, double* d_out, hipStream_t s);
+void launch_pair_cor(const Prob* d_probs, int prob, const int2* d_pairs, long long n_pairs, const int* d_pop_group, int n_group,
+                     double* d_out, hipStream_t s);
 void launch_gene_epilogue(const Prob* d_probs, int prob, int n_gene, hipStream_t s);
 void launch_factor_step(const Prob* d_probs, int n_prob, int step, int max_nblk, int max_npanel, int split, int own_panel, hipStream_t s);
 void launch_shift_cert(const Prob* d_probs, int n_prob, hipStream_t s);

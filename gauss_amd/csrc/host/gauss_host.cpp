@@ -1706,6 +1706,211 @@ int gauss_host_prep_zmix5(gauss_ctx* ctx, const char* input_file, const char* re
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------
+// The other prep_zmix selectors (zmix.cpp:201-1076).  They share prep_zmix5's reading (read_input_zmix /
+// read_ref_index_zmix, every population) and its output (one row per SNP pair: z_i * z_j, then the pair's genotype
+// correlation inside each population) and differ in WHICH pairs they list:
+//   prep_zmix      zmix.cpp:940-1076   every interval-th measured SNP (default 1), all pairs
+//   prep_zmix2     zmix.cpp:651-760    pairs (i, i + offset) for i = 0, interval, 2 interval, ...   (1000, 3)
+//   prep_zmix3     zmix.cpp:511-650    every interval-th SNP, each with its next `steps` neighbours  (1000, 5)
+//   prep_zmix4     zmix.cpp:363-510    for h = 0 .. interval-1: pairs (i, i + offset), i = h, h + interval, ...; an extra
+//                                      leading column holds h                                        (1000, 3)
+//   prep_zmix5_sup zmix.cpp:201-361    prep_zmix5's ancestry-informative SNPs, correlations pooled per SUPER-population
+//                                      (CalCorSup zmix.cpp:1221-1246), super-populations in order of first appearance
+// The GPU part is gauss_ld_per_pop_pairs: only the tile pairs the listed pairs touch are multiplied.
+// ------------------------------------------------------------------------------------------
+enum ZmixVariant { ZMIX_ALL = 0, ZMIX_2 = 2, ZMIX_3 = 3, ZMIX_4 = 4, ZMIX_5SUP = 6 };
+
+static int prep_zmix_variant(gauss_ctx* ctx, int variant, const char* input_file, const char* reference_index_file,
+                             const char* reference_data_file, const char* reference_pop_desc_file, double percentile, int interval,
+                             int p2, gauss_table** out)
+{
+    if (!ctx || !out) return herr("bad arguments");
+    if (!input_file || !reference_index_file || !reference_data_file || !reference_pop_desc_file) return herr("file name is NULL");
+    Args a;
+    a.input_file = input_file; a.reference_index_file = reference_index_file;
+    a.reference_data_file = reference_data_file; a.reference_pop_desc_file = reference_pop_desc_file;
+    // defaults: zmix.cpp:953-957 (1), 664-675 / 376-387 / 524-535 (1000 and 3 / 3 / 5), 214-224 (0.99, 1)
+    const int step = interval > 0 ? interval : ((variant == ZMIX_ALL || variant == ZMIX_5SUP) ? 1 : 1000);
+    const int par2 = p2 > 0 ? p2 : (variant == ZMIX_3 ? 5 : 3);
+    const double pct = std::isnan(percentile) ? 0.99 : percentile;
+    if (auto_pack_mode() != 0 && !PackedPanel::is_packed(a.reference_data_file)) {
+        std::string cached, err;
+        const int rc = resolve_packed_panel(a.reference_index_file, a.reference_data_file, a.reference_pop_desc_file,
+                                            auto_pack_mode() == 1, cached, err);
+        if (rc < 0) return herr("%s", err.c_str());
+        if (rc == 0) a.reference_data_file = cached;
+    }
+    if (PackedPanel::is_packed(a.reference_data_file)) {
+        std::string err;
+        a.pk = open_packed_shared(a.reference_data_file, err);
+        if (!a.pk) return herr("%s", err.c_str());
+    }
+    if (read_ref_desc(a)) return -1;
+    if (a.pk && a.pk->n_pop() != a.num_pops) return herr("packed panel has %d populations, the description file %d", a.pk->n_pop(), a.num_pops);
+    a.pop_flag_vec.assign(a.num_pops, 1);
+    SnpMap m;
+    if (ReadInputZ(m, a, true)) return -1;
+    if (ReadReferenceIndex(m, a, true)) return -1;
+    std::vector<Snp*> measured;
+    for (auto& kv : m) if (kv.second->type == 1) measured.push_back(kv.second.get());
+    const int n = (int)measured.size();
+
+    // ---- which SNPs, which pairs (indices into `measured`) ----
+    std::vector<std::pair<int, int>> pairs;
+    std::vector<double> lead;                                    // prep_zmix4's leading column
+    std::vector<double> sub_nv;                                  // prep_zmix5_sup: norm_var of the kept SNPs
+    if (variant == ZMIX_ALL || variant == ZMIX_3 || variant == ZMIX_5SUP) {
+        std::vector<int> sub;
+        for (int i = 0; i < n; i += step) sub.push_back(i);      // zmix.cpp:996-1004, 567-575, 257-265
+        if (variant == ZMIX_5SUP) {
+            // cal_af_norm_var + the percentile cut, as in prep_zmix5 (zmix.cpp:268-285)
+            std::vector<double> norm_var;
+            BgzfReader fp;
+            if (!a.pk && !fp.open(a.reference_data_file)) return herr("ERROR: can't open reference data file '%s'", a.reference_data_file.c_str());
+            std::vector<double> af;
+            for (int i : sub) {
+                Snp* s = measured[(size_t)i];
+                if (a.pk) af.assign(a.pk->af(s->fpos), a.pk->af(s->fpos) + a.num_pops);
+                else load_line(fp, *s, a, &af);
+                const int k = (int)af.size();
+                double sum = 0.0, sq = 0.0;
+                for (double v : af) sum += v;
+                for (double v : af) sq += v * v;
+                const double mean = sum / k;
+                norm_var.push_back((sq / k - mean * mean) / (mean * (1 - mean)));
+            }
+            double cutoff = 0;
+            if (r_quantile7(norm_var, pct, &cutoff)) return -1;
+            std::vector<int> kept;
+            for (size_t i = 0; i < sub.size(); i++) if (norm_var[i] > cutoff) { kept.push_back(sub[i]); sub_nv.push_back(norm_var[i]); }
+            sub.swap(kept);
+        }
+        const int S = (int)sub.size();
+        for (int i = 0; i < S; i++) {
+            const int jend = variant == ZMIX_3 ? std::min(i + 1 + par2, S) : S;      // zmix.cpp:592-594
+            for (int j = i + 1; j < jend; j++) pairs.emplace_back(sub[(size_t)i], sub[(size_t)j]);
+        }
+    } else if (variant == ZMIX_2) {
+        for (int i = 0; i < n; i += step) {                      // zmix.cpp:721-745
+            if (i + par2 < n) pairs.emplace_back(i, i + par2);
+            else break;
+        }
+    } else {                                                     // ZMIX_4, zmix.cpp:440-465
+        for (int h = 0; h < step; h++)
+            for (int i = h; i < n; i += step) {
+                if (i + par2 < n) { pairs.emplace_back(i, i + par2); lead.push_back((double)h); }
+                else break;
+            }
+    }
+    // the SNPs that occur in some pair, in list order; a pair is (smaller row, larger row) -- the reference's pairs are
+    // (earlier SNP, later SNP) already, and the correlation is symmetric
+    std::vector<int> row_of((size_t)n, -1);
+    std::vector<Snp*> sel;
+    {
+        std::vector<char> used((size_t)n, 0);
+        for (auto& pr : pairs) { used[(size_t)pr.first] = 1; used[(size_t)pr.second] = 1; }
+        for (int i = 0; i < n; i++) if (used[(size_t)i]) { row_of[(size_t)i] = (int)sel.size(); sel.push_back(measured[(size_t)i]); }
+    }
+    const int S = (int)sel.size(), P = a.num_pops;
+    // population groups: each population (all but _sup), or its super-population in order of first appearance
+    std::vector<int32_t> pop_group;
+    int n_group = P;
+    std::vector<std::string> group_names = a.ref_pop_vec;
+    if (variant == ZMIX_5SUP) {
+        group_names.clear();
+        for (int k = 0; k < P; k++) {
+            const std::string& sp = a.ref_sup_pop_vec[(size_t)k];
+            size_t g = 0;
+            while (g < group_names.size() && group_names[g] != sp) g++;
+            if (g == group_names.size()) group_names.push_back(sp);
+            pop_group.push_back((int32_t)g);
+        }
+        n_group = (int)group_names.size();
+    }
+    int N = 0;
+    std::vector<int32_t> pop_off(1, 0);
+    for (int k = 0; k < P; k++) { N += a.ref_pop_size_vec[(size_t)k]; pop_off.push_back(pop_off.back() + a.ref_pop_size_vec[(size_t)k]); }
+    const size_t np = pairs.size();
+    const int nlead = variant == ZMIX_4 ? 1 : 0;
+    std::unique_ptr<gauss_table> t(new gauss_table());
+    NamedMat dm;
+    dm.name = "data_mat"; dm.nrow = (int)np; dm.ncol = nlead + 1 + n_group;
+    dm.d.assign(np * (size_t)dm.ncol, 0.0);
+    if (np > 0) {
+        gauss_prepared tmp;
+        tmp.args = a; tmp.N = N; tmp.ld = ((int64_t)N + 15) / 16 * 16;
+        std::vector<uint8_t> G;
+        if (a.pk) unpack_rows(tmp, sel, G);
+        else {
+            BgzfReader fp;
+            if (!fp.open(a.reference_data_file)) return herr("ERROR: can't open reference data file '%s'", a.reference_data_file.c_str());
+            for (Snp* s : sel) {
+                load_line(fp, *s, a, nullptr);
+                int k = 0;
+                for (auto& g : s->geno) k += g.second;
+                if (k != N) return herr("ERROR: genotype line of %s has %d samples, population table says %d", s->rsid.c_str(), k, N);
+            }
+            fill_matrix(G, sel, tmp.ld);
+        }
+        std::vector<int32_t> pi(np), pj(np);
+        for (size_t k = 0; k < np; k++) {
+            pi[k] = row_of[(size_t)pairs[k].first]; pj[k] = row_of[(size_t)pairs[k].second];
+            if (nlead) dm.d[k] = lead[k];
+            dm.d[(size_t)nlead * np + k] = measured[(size_t)pairs[k].first]->z * measured[(size_t)pairs[k].second]->z;
+        }
+        if (gauss_ld_per_pop_pairs(ctx, G.data(), S, tmp.ld, pop_off.data(), P, pop_group.empty() ? nullptr : pop_group.data(), n_group,
+                                   pi.data(), pj.data(), (int64_t)np, dm.d.data() + (size_t)(nlead + 1) * np) != 0)
+            return herr("%s", gauss_last_error());
+    }
+    Column rsid{"rsid", GAUSS_COL_STR, {}, {}, {}}, chr{"chr", GAUSS_COL_INT, {}, {}, {}}, bp{"bp", GAUSS_COL_INT, {}, {}, {}};
+    Column a1{"a1", GAUSS_COL_STR, {}, {}, {}}, a2{"a2", GAUSS_COL_STR, {}, {}, {}}, z{"z", GAUSS_COL_DBL, {}, {}, {}};
+    for (Snp* s : sel) {
+        rsid.s.push_back(s->rsid); chr.i.push_back(s->chr); bp.i.push_back((int)s->bp);
+        a1.s.push_back(s->a1); a2.s.push_back(s->a2); z.d.push_back(s->z);
+    }
+    t->cols = {rsid, chr, bp, a1, a2, z};
+    if (variant == ZMIX_5SUP) { Column nv{"norm_var", GAUSS_COL_DBL, {}, {}, {}}; nv.d = sub_nv; t->cols.push_back(nv); }
+    t->named.push_back(std::move(dm));
+    {
+        // the groups the correlation columns stand for, and the pairs as rows of the SNP table
+        NamedMat pm;
+        pm.name = "pairs"; pm.nrow = (int)np; pm.ncol = 2;
+        pm.d.assign(np * 2, 0.0);
+        for (size_t k = 0; k < np; k++) { pm.d[k] = row_of[(size_t)pairs[k].first]; pm.d[np + k] = row_of[(size_t)pairs[k].second]; }
+        t->named.push_back(std::move(pm));
+        for (const std::string& g : group_names) t->messages.push_back(g);
+    }
+    *out = t.release();
+    return 0;
+}
+
+int gauss_host_prep_zmix(gauss_ctx* ctx, const char* input_file, const char* reference_index_file, const char* reference_data_file,
+                         const char* reference_pop_desc_file, int interval, gauss_table** out)
+{
+    return prep_zmix_variant(ctx, ZMIX_ALL, input_file, reference_index_file, reference_data_file, reference_pop_desc_file, NAN, interval, 0, out);
+}
+int gauss_host_prep_zmix2(gauss_ctx* ctx, const char* input_file, const char* reference_index_file, const char* reference_data_file,
+                          const char* reference_pop_desc_file, int interval, int offset, gauss_table** out)
+{
+    return prep_zmix_variant(ctx, ZMIX_2, input_file, reference_index_file, reference_data_file, reference_pop_desc_file, NAN, interval, offset, out);
+}
+int gauss_host_prep_zmix3(gauss_ctx* ctx, const char* input_file, const char* reference_index_file, const char* reference_data_file,
+                          const char* reference_pop_desc_file, int interval, int steps, gauss_table** out)
+{
+    return prep_zmix_variant(ctx, ZMIX_3, input_file, reference_index_file, reference_data_file, reference_pop_desc_file, NAN, interval, steps, out);
+}
+int gauss_host_prep_zmix4(gauss_ctx* ctx, const char* input_file, const char* reference_index_file, const char* reference_data_file,
+                          const char* reference_pop_desc_file, int interval, int offset, gauss_table** out)
+{
+    return prep_zmix_variant(ctx, ZMIX_4, input_file, reference_index_file, reference_data_file, reference_pop_desc_file, NAN, interval, offset, out);
+}
+int gauss_host_prep_zmix5_sup(gauss_ctx* ctx, const char* input_file, const char* reference_index_file, const char* reference_data_file,
+                              const char* reference_pop_desc_file, double percentile, int interval, gauss_table** out)
+{
+    return prep_zmix_variant(ctx, ZMIX_5SUP, input_file, reference_index_file, reference_data_file, reference_pop_desc_file, percentile, interval, 0, out);
+}
+
 int gauss_host_computeLD(gauss_ctx* ctx, int chr, int64_t start_bp, int64_t end_bp, const char* const* pop_names,
                          const double* pop_wgts, int n_pop_wgt, const char* input_file, const char* reference_index_file,
                          const char* reference_data_file, const char* reference_pop_desc_file, double af1_cutoff,

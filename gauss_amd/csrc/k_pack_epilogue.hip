@@ -664,6 +664,54 @@ __global__ __launch_bounds__(256) void pop_cor_kernel(const Prob* __restrict__ p
     }
 }
 
+
+// Pearson correlation of LISTED SNP pairs inside each population -- or inside each GROUP of populations pooled (the
+// super-populations of prep_zmix5_sup, CalCorSup zmix.cpp:1221-1246) -- the selectors prep_zmix / prep_zmix2 / prep_zmix3 /
+// prep_zmix4 (zmix.cpp:201-1076) differ from prep_zmix5 only in which pairs they list.  Sums over a group are exact
+// integers (per-population partial Grams, per-population sum x and sum x^2 from the pack kernel); the tail is CalCor's
+// (util.cpp:165-167): numer = n * Sxy - Sx * Sy, denor = sqrt(n * Sxx - Sx^2) * sqrt(n * Syy - Sy^2).
+// pairs[k] = (i, j), i < j, rows of the problem; out is [n_group][n_pairs].
+__global__ __launch_bounds__(256) void pair_cor_kernel(const Prob* __restrict__ probs, int prob, const int2* __restrict__ pairs,
+                                                       long long n_pairs, const int* __restrict__ pop_group, int n_group,
+                                                       double* __restrict__ out)
+{
+    const Prob& pb = probs[prob];
+    const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n_pairs) return;
+    const int ri = pairs[k].x, rj = pairs[k].y;
+    const int ti = ri / TILE, tj = rj / TILE;
+    const int pair = pb.pair_lut[ti * pb.nT + tj];
+    const float* tile_slab = pb.slab + (size_t)pair * pb.nseg * TILE * TILE;
+    const int e = (ri % TILE) * TILE + (rj % TILE);
+    const int P = pb.P;
+    const int* sxi = pb.sx + (size_t)ri * P;
+    const int* sxj = pb.sx + (size_t)rj * P;
+    const int* sxxi = pb.sxx + (size_t)ri * P;
+    const int* sxxj = pb.sxx + (size_t)rj * P;
+    for (int g = 0; g < n_group; g++) {
+        double n = 0, sumxy = 0, sumx = 0, sumy = 0, sumxsq = 0, sumysq = 0;          // exact integers in fp64
+        for (int p = 0; p < P; p++) {
+            if ((pop_group ? pop_group[p] : p) != g) continue;
+            for (int s = pb.pop_seg0[p]; s < pb.pop_seg0[p + 1]; s++)
+                sumxy += slab_val(tile_slab[(size_t)s * TILE * TILE + e], pb.gram_i8);
+            n += (double)(pb.pop_raw_off[p + 1] - pb.pop_raw_off[p]);
+            sumx += (double)sxi[p]; sumy += (double)sxj[p];
+            sumxsq += (double)sxxi[p]; sumysq += (double)sxxj[p];
+        }
+        const double numer = n * sumxy - sumx * sumy;
+        const double denor = sqrt(n * sumxsq - sumx * sumx) * sqrt(n * sumysq - sumy * sumy);
+        out[(size_t)g * n_pairs + k] = numer / denor;
+    }
+}
+
+void launch_pair_cor(const Prob* d_probs, int prob, const int2* d_pairs, long long n_pairs, const int* d_pop_group, int n_group,
+                     double* d_out, hipStream_t s)
+{
+    if (n_pairs > 0)
+        hipLaunchKernelGGL(pair_cor_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, s, d_probs, prob, d_pairs, n_pairs,
+                           d_pop_group, n_group, d_out);
+}
+
 void launch_pop_cor(const Prob* d_probs, int prob, int npair, double* d_out, hipStream_t s)
 {
     if (npair > 0) hipLaunchKernelGGL(pop_cor_kernel, dim3(npair), dim3(256), 0, s, d_probs, prob, d_out);

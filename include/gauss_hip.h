@@ -226,6 +226,16 @@ int gauss_gene_ld_batch_rows(gauss_ctx* ctx, int mode, const uint8_t* store, int
 int gauss_ld_per_pop(gauss_ctx* ctx, const uint8_t* geno, int n_snp, int64_t ld,
                      const int32_t* pop_off, int n_pop, double* out);
 
+/* The same correlations for LISTED pairs only, per population or per GROUP of populations pooled: what the other
+ * prep_zmix selectors need (zmix.cpp:201-1076 -- prep_zmix, prep_zmix2, prep_zmix3, prep_zmix4 list pairs by interval /
+ * offset / steps; prep_zmix5_sup pools the populations of a super-population, CalCorSup zmix.cpp:1221-1246).  pair k is
+ * (pair_i[k], pair_j[k]) with 0 <= i < j < n_snp; pop_group[p] in 0..n_group-1 names the group of population p (NULL:
+ * every population its own group, n_group ignored).  Only the tile pairs the listed pairs touch are multiplied.
+ * out is [n_group][n_pairs]. */
+int gauss_ld_per_pop_pairs(gauss_ctx* ctx, const uint8_t* geno, int n_snp, int64_t ld, const int32_t* pop_off, int n_pop,
+                           const int32_t* pop_group, int n_group, const int32_t* pair_i, const int32_t* pair_j, int64_t n_pairs,
+                           double* out);
+
 /* Exact co-occurrence counts sum_n x_i[n] x_j[n] over all columns -- the integer the reference
  * accumulates as `sumxy` (util.cpp:62,114).  out: S x S int64, row-major.  Integer parity hook. */
 int gauss_gram_counts(gauss_ctx* ctx, const uint8_t* geno, int n_snp, int n_samples, int64_t ld,

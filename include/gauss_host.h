@@ -144,6 +144,28 @@ int gauss_host_prep_recessive_impute(gauss_ctx* ctx, int chr, int64_t start_bp, 
 int gauss_host_prep_zmix5(gauss_ctx* ctx, const char* input_file, const char* reference_index_file,
                           const char* reference_data_file, const char* reference_pop_desc_file,
                           double percentile, int interval, gauss_table** out);
+/* The other pair selectors of the family (R/RcppExports.R:231-311, zmix.cpp:201-1076); same files, same output layout
+ * (named matrix "data_mat": one row per listed SNP pair, z_i * z_j then one correlation column per population), which
+ * pairs they list differs:
+ *   prep_zmix      every interval-th measured SNP (<= 0: 1), all pairs                       zmix.cpp:940-1076
+ *   prep_zmix2     pairs (i, i + offset), i = 0, interval, 2 interval, ... (<= 0: 1000, 3)   zmix.cpp:651-760
+ *   prep_zmix3     every interval-th SNP with its next `steps` neighbours (<= 0: 1000, 5)    zmix.cpp:511-650
+ *   prep_zmix4     for h = 0 .. interval-1: pairs (i, i + offset), i = h, h + interval, ...; data_mat has a leading
+ *                  column h (<= 0: 1000, 3)                                                  zmix.cpp:363-510
+ *   prep_zmix5_sup prep_zmix5's SNPs; correlations pooled per super-population, columns in order of first
+ *                  appearance in the description file (CalCorSup)                            zmix.cpp:201-361, 1221-1246
+ * The table lists the SNPs that occur in some pair (rsid chr bp a1 a2 z [norm_var]); named matrix "pairs" [n_pairs x 2]
+ * gives each pair as rows of that table; the table's messages name the correlation columns (populations / groups). */
+int gauss_host_prep_zmix(gauss_ctx* ctx, const char* input_file, const char* reference_index_file, const char* reference_data_file,
+                         const char* reference_pop_desc_file, int interval, gauss_table** out);
+int gauss_host_prep_zmix2(gauss_ctx* ctx, const char* input_file, const char* reference_index_file, const char* reference_data_file,
+                          const char* reference_pop_desc_file, int interval, int offset, gauss_table** out);
+int gauss_host_prep_zmix3(gauss_ctx* ctx, const char* input_file, const char* reference_index_file, const char* reference_data_file,
+                          const char* reference_pop_desc_file, int interval, int steps, gauss_table** out);
+int gauss_host_prep_zmix4(gauss_ctx* ctx, const char* input_file, const char* reference_index_file, const char* reference_data_file,
+                          const char* reference_pop_desc_file, int interval, int offset, gauss_table** out);
+int gauss_host_prep_zmix5_sup(gauss_ctx* ctx, const char* input_file, const char* reference_index_file, const char* reference_data_file,
+                              const char* reference_pop_desc_file, double percentile, int interval, gauss_table** out);
 
 /* ---- packed panel -------------------------------------------------
  * Converts the reference's BGZF text panel (index + data + population description) into one mmap-able

@@ -499,3 +499,92 @@ def jepeg(study_pop, input_file, annot, index, data, desc, af1_cutoff=None):
 
 def jepegmix(pop_wgt, input_file, annot, index, data, desc, af1_cutoff=None):
     return _jepeg(True, None, pop_wgt, input_file, annot, index, data, desc, af1_cutoff)
+
+
+def _pearson_strings(xs, ys):
+    """CalCor on one population's genotype strings (util.cpp:153-169) / CalCorSup on several concatenated
+    (zmix.cpp:1221-1246): plain sums over the samples, then (n Sxy - Sx Sy) / (sqrt(n Sxx - Sx^2) sqrt(n Syy - Sy^2))."""
+    x = np.frombuffer(xs.encode(), dtype=np.uint8).astype(np.float64) - 48.0
+    y = np.frombuffer(ys.encode(), dtype=np.uint8).astype(np.float64) - 48.0
+    n = len(x)
+    sx, sy, sxx, syy, sxy = x.sum(), y.sum(), (x * x).sum(), (y * y).sum(), (x * y).sum()
+    with np.errstate(invalid="ignore", divide="ignore"):
+        return (n * sxy - sx * sy) / (np.sqrt(n * sxx - sx * sx) * np.sqrt(n * syy - sy * sy))
+
+
+def prep_zmix_variant(variant, input_file, index, data, desc, percentile=None, interval=None, p2=None):
+    """The other prep_zmix selectors, loop for loop: "zmix" zmix.cpp:940-1076, "zmix2" :651-760, "zmix3" :511-650,
+    "zmix4" :363-510, "zmix5_sup" :201-361.  Returns dict(data_mat, pairs as (rsid_i, rsid_j), groups)."""
+    pops = read_ref_desc(desc)
+    P = len(pops)
+    m = read_input_z(input_file, 0, 0, 0, True)
+    read_reference_index(m, index, 0, 0, 0, True)
+    measured = [s for _, s in sorted(m.items()) if s.type == 1]
+    n = len(measured)
+    bg = Bgzf(data)
+
+    def load(s):
+        if s.geno is None:
+            toks = bg.line_at(s.fpos).split()
+            s.geno = toks[:P]
+            s.af = [float(x) for x in toks[P:2 * P]]
+        return s
+
+    step = interval if interval else (1 if variant in ("zmix", "zmix5_sup") else 1000)
+    par2 = p2 if p2 else (5 if variant == "zmix3" else 3)
+    pairs, lead = [], []
+    if variant in ("zmix", "zmix3", "zmix5_sup"):
+        sub = measured[::step]
+        if variant == "zmix5_sup":
+            pct = 0.99 if percentile is None else percentile
+            nv = []
+            for s in sub:
+                af = load(s).af
+                mean = 0.0
+                for v in af:
+                    mean += v
+                mean /= len(af)
+                sq = 0.0
+                for v in af:
+                    sq += v * v
+                nv.append((sq / len(af) - mean * mean) / (mean * (1 - mean)))
+            cutoff = r_quantile7(nv, pct)
+            sub = [s for s, v in zip(sub, nv) if v > cutoff]
+        S = len(sub)
+        for i in range(S):
+            for j in range(i + 1, min(i + 1 + par2, S) if variant == "zmix3" else S):
+                pairs.append((sub[i], sub[j]))
+    elif variant == "zmix2":
+        i = 0
+        while i + par2 < n:
+            pairs.append((measured[i], measured[i + par2]))
+            i += step
+    elif variant == "zmix4":
+        for h in range(step):
+            i = h
+            while i < n and i + par2 < n:
+                pairs.append((measured[i], measured[i + par2]))
+                lead.append(float(h))
+                i += step
+    else:
+        raise ValueError(variant)
+    if variant == "zmix5_sup":
+        groups = []
+        for p in pops:
+            if p[2] not in groups:
+                groups.append(p[2])
+        members = [[k for k, p in enumerate(pops) if p[2] == g] for g in groups]
+    else:
+        groups = [p[0] for p in pops]
+        members = [[k] for k in range(P)]
+    nl = 1 if variant == "zmix4" else 0
+    out = np.zeros((len(pairs), nl + 1 + len(groups)))
+    for r, (a, b) in enumerate(pairs):
+        load(a)
+        load(b)
+        if nl:
+            out[r, 0] = lead[r]
+        out[r, nl] = a.z * b.z
+        for g, mem in enumerate(members):
+            out[r, nl + 1 + g] = _pearson_strings("".join(a.geno[k] for k in mem), "".join(b.geno[k] for k in mem))
+    return dict(data_mat=out, pairs=[(a.rsid, b.rsid) for a, b in pairs], groups=groups)

@@ -220,3 +220,29 @@ def test_prep_zmix5_end_to_end(ctx, study, packed, use_packed):
     nan = np.isnan(want["data_mat"])
     assert np.array_equal(np.isnan(got), nan)
     assert np.max(np.abs(got[~nan] - want["data_mat"][~nan])) <= 1e-12
+
+
+@pytest.mark.parametrize("use_packed", [False, True])
+@pytest.mark.parametrize("variant,kw", [("zmix", dict(interval=7)), ("zmix2", dict(interval=5, p2=3)), ("zmix2", dict(interval=2, p2=4)),
+                                        ("zmix3", dict(interval=3, p2=4)), ("zmix4", dict(interval=6, p2=2)),
+                                        ("zmix5_sup", dict(percentile=0.7, interval=2))])
+def test_prep_zmix_selectors_end_to_end(ctx, study, packed, use_packed, variant, kw):
+    """prep_zmix / prep_zmix2 / prep_zmix3 / prep_zmix4 / prep_zmix5_sup (zmix.cpp:201-1076): the pairs each selector lists,
+    z_i * z_j, and the pair's genotype correlation per population (per super-population for _sup) against the loop-literal
+    restatement; only the tile pairs the listed pairs touch are multiplied on the GPU (gauss_ld_per_pop_pairs)."""
+    inp, idx, dat, desc = _files(study)
+    want = fp.prep_zmix_variant(variant, inp, idx, dat, desc, **kw)
+    got = api.prep_zmix_variant(variant, inp, idx, packed if use_packed else dat, desc, ctx=ctx, **kw)
+    assert len(want["pairs"]) > 10
+    rs = list(got["snps"]["rsid"])
+    assert [(rs[i], rs[j]) for i, j in got["pairs"]] == want["pairs"]
+    assert got["groups"] == want["groups"]
+    g, w = got["data_mat"], want["data_mat"]
+    assert g.shape == w.shape
+    lead = 2 if variant == "zmix4" else 1
+    assert np.array_equal(g[:, :lead], w[:, :lead])                  # h (zmix4) and z_i * z_j: exact
+    nan = np.isnan(w)
+    assert np.array_equal(np.isnan(g), nan)
+    assert np.max(np.abs(g[~nan] - w[~nan])) <= 1e-12
+    if variant == "zmix5_sup":
+        assert len(want["groups"]) < len(POPS) and "norm_var" in got["snps"]
