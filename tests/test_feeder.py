@@ -554,6 +554,7 @@ def test_panel_cache_concurrent_callers_pack_once(tmp_path):
     code = ("import sys; sys.path.insert(0, %r); from gauss_amd import api; "
             "print(*api.panel_cache(%r, %r, %r))" % (ROOT, p["index.gz"], p["data.gz"], p["desc.txt"]))
     env = dict(os.environ, GAUSS_PANEL_CACHE=str(tmp_path / "cache"))
+    env.pop("LD_PRELOAD", None)                 # under tools/tsan_host.sh / asan_host.sh the children run the plain library
     procs = [subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, text=True, env=env) for _ in range(4)]
     outs = [q.communicate(timeout=120)[0].split() for q in procs]
     assert all(q.returncode == 0 for q in procs)
