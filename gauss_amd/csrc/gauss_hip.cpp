@@ -2188,7 +2188,13 @@ int gauss_impute_window(gauss_ctx* ctx, const gauss_window_desc* win)
         StreamSetup su;
         rc = stream_start_copies(ctx, *win, row_bytes, su);
         if (rc) return rc;
-        struct Waiter { CopyWorker* w; ~Waiter() { w->wait(); } } waiter{ctx->worker};      // `su` outlives the worker's task on every path
+        // On every path out of here the worker has finished its task (`su` lives on this stack) AND the copies it queued
+        // have left the caller's matrices: from pinned memory they are true asynchronous DMAs, and the caller may free
+        // the matrices the moment this call returns.  A successful fetch has waited for them already (`landed`).
+        struct Waiter {
+            gauss_ctx* c; bool landed = false;
+            ~Waiter() { c->worker->wait(); if (!landed) (void)hipStreamSynchronize(c->copy); }
+        } waiter{ctx};
         lap("copies started");
         std::vector<WinSpec> specs{spec_from_desc(*win)};
         rc = job_build(ctx, specs, 0, &job, &su);
@@ -2201,7 +2207,8 @@ int gauss_impute_window(gauss_ctx* ctx, const gauss_window_desc* win)
         lap("run queued");
         if (!rc) rc = job_fetch(job);
         lap("fetched");
-        if (rc) {
+        if (!rc) waiter.landed = true;             // the results were computed from every chunk: all copies are complete
+        else {
             // nothing may still be writing into the landing buffer or reading it when the next call reuses it
             ctx->worker->wait();
             for (hipStream_t q : {ctx->copy, ctx->aux, ctx->chain, ctx->stream}) (void)hipStreamSynchronize(q);

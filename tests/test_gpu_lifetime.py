@@ -147,3 +147,53 @@ def test_asynchronous_row_store_upload(ctx):
         assert np.array_equal(a["z"], b["z"]) and np.array_equal(a["info"], b["info"])
     busy = hotpath.RowStore(rows, ctx=ctx, asynchronous=True)
     busy.close()                                   # freed while the upload may still be running: it is finished first
+
+
+@pytest.mark.gpu
+def test_streamed_window_call_strided_rows_and_error_paths(ctx, monkeypatch):
+    """The blocking call on host bytes is streamed (copy worker + landing buffer): same bits as
+    upload-then-run, also for matrices whose row stride is far from the row length (pitched chunk copies), for a 2-bit
+    host store, and a call that fails after its copies have started leaves the context usable."""
+    import ctypes as C
+    from gauss_amd import hotpath, synth, _lib, panel
+    pops = synth.pop_table(scale=0.03, min_size=40)[:9]
+    off = synth.pop_offsets([p[1] for p in pops])
+    N = int(off[-1])
+    rng = np.random.default_rng(21)
+    bp = np.sort(rng.choice(np.arange(1, 900_000), size=1100, replace=False))
+    G, _ = synth.synth_genotypes(bp, pops, seed=6)
+    G = G[G.min(1) != G.max(1)]
+    idx = rng.permutation(G.shape[0])
+    gm = np.ascontiguousarray(G[np.sort(idx[:300])])
+    gu = np.ascontiguousarray(G[np.sort(idx[300:300 + 700])])          # six row tiles: several chunks
+    w = rng.uniform(0.05, 0.3, len(pops))
+    z1 = rng.standard_normal(gm.shape[0])
+
+    def call(stream, a=gm, b=gu, ld=None, mode=1):
+        monkeypatch.setenv("GAUSS_STREAM_WINDOW", "1" if stream else "0")
+        desc = _lib.WindowDesc()
+        win = hotpath._Win(desc, mode, gm, gu, off, w, z1, 0.1, 1e-5, False)
+        if ld is not None:
+            desc.geno_m, desc.geno_u, desc.ld = a.ctypes.data, b.ctypes.data, ld
+        _lib.check(ctx.lib.gauss_impute_window(ctx.handle, C.byref(desc)))
+        return win.result()
+
+    want = call(False)
+    got = call(True)
+    assert np.array_equal(got["z"], want["z"]) and np.array_equal(got["info"], want["info"])
+    # rows inside much wider host matrices: pitched copies, chunk by chunk
+    wide = N + N // 4 + 512
+    wm = np.full((gm.shape[0], wide), 7, dtype=np.uint8)
+    wu = np.full((gu.shape[0], wide), 7, dtype=np.uint8)
+    wm[:, :N] = gm
+    wu[:, :N] = gu
+    for stream in (False, True):
+        r = call(stream, wm, wu, wide)
+        assert np.array_equal(r["z"], want["z"]) and np.array_equal(r["info"], want["info"])
+    # a call that fails in the planner, after the copy worker has been set going
+    monkeypatch.setenv("GAUSS_STREAM_WINDOW", "1")
+    with pytest.raises(Exception) as ei:
+        call(True, mode=7)
+    assert "bad mode" in str(ei.value)
+    again = call(True)
+    assert np.array_equal(again["z"], want["z"]) and np.array_equal(again["info"], want["info"])
