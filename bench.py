@@ -354,7 +354,8 @@ def run_impute(args, rig):
         same = all(np.array_equal(a["z"], b["z"]) and np.array_equal(a["info"], b["info"]) for a, b in zip(res, res8))
         g8, n8 = st8["gram"]
         i8_variant = {"ms_per_step": dt8 / args.steps * 1e3, "imputed_snps_per_s_this_rank": work["imputed_snps"] / (dt8 / args.steps),
-                      "gram_ms": g8 / max(1, n8), "gram_tops_algorithmic": work["ld_flops"] / (g8 / max(1, n8) * 1e-3) / 1e12,
+                      "gram_ms": g8 / args.steps, "gram_launches_per_step": max(1, round(n8 / args.steps)),
+                      "gram_tops_algorithmic": work["ld_flops"] / (g8 / args.steps * 1e-3) / 1e12,
                       "kernel": "gram_kernel<i32x16> (v_mfma_i32_32x32x32_i8)", "bit_identical_to_f32_path": bool(same)}
         r8.close()
 
@@ -403,7 +404,7 @@ def run_impute(args, rig):
             parts_e.append({piece: (q["z"], q["info"]) for piece, q in zip(shares_e[r], rr.results_in_order(res_r))})
             per_rank.append({"rank": r, "windows": len(wr), "ms_per_step": dtr / args.steps * 1e3,
                              "stage_ms": {k: v[0] / args.steps for k, v in str_.items()},
-                             "gram_frac_of_peak": (rr.work["ld_flops"] / (str_["gram"][0] / max(1, str_["gram"][1]) * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS)
+                             "gram_frac_of_peak": (rr.work["ld_flops"] * args.steps / (str_["gram"][0] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS)
                              if str_["gram"][0] > 0 else 0.0})
             rr.close()
         slow = max(q["ms_per_step"] for q in per_rank)
@@ -427,8 +428,11 @@ def run_impute(args, rig):
     out = None
     if rig.rank == 0:
         nsteps = max(1, args.steps)
+        # the Gram kernel may take two launches per step (B11's tile pairs, then B21's with the factorisation chain beside
+        # it): per-launch figures are averages over the launches, flops per launch = flops per step / launches per step
+        gram_lps = max(1, round(gram_n / nsteps))
         avg_gram_s = gram_ms / max(1, gram_n) * 1e-3
-        achieved = work["ld_flops"] / avg_gram_s / 1e12 if avg_gram_s > 0 else 0.0
+        achieved = work["ld_flops"] / gram_lps / avg_gram_s / 1e12 if avg_gram_s > 0 else 0.0
         per_step = {k: v[0] / nsteps for k, v in st.items()}
         alone = tails_alone["stage_ms_per_step"] if tails_alone else per_step
         tail_s = (alone["factor"] + alone["solve"]) * 1e-3
@@ -477,10 +481,11 @@ def run_impute(args, rig):
                 "kernel": "gram_kernel (LD GEMM, v_mfma_f32_32x32x2_f32)" + (" on rank 0" if rig.world > 1 else ""),
                 "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
-                "algorithmic_flops_per_launch": work["ld_flops"],
-                "avg_launch_ms": gram_ms / max(1, gram_n), "launches": int(gram_n),
-                "issued_flops_per_launch": stats["executed_flops"],
-                "issued_tflops": stats["executed_flops"] / avg_gram_s / 1e12 if avg_gram_s > 0 else 0.0,
+                "algorithmic_flops_per_launch": work["ld_flops"] / gram_lps, "algorithmic_flops_per_step": work["ld_flops"],
+                "avg_launch_ms": gram_ms / max(1, gram_n), "launches": int(gram_n), "launches_per_step": gram_lps,
+                "kernel_ms_per_step": gram_ms / nsteps,
+                "issued_flops_per_launch": stats["executed_flops"] / gram_lps,
+                "issued_tflops": stats["executed_flops"] / gram_lps / avg_gram_s / 1e12 if avg_gram_s > 0 else 0.0,
                 "work_items": stats["items"], "partial_slab_bytes": stats["slab_bytes"],
                 "measured_on": "HIP events of every launch in the timed region" if rig.world == 1 else
                                "HIP events of 3 extra steps on rank 0 after the timed region (no events inside it: they would slow rank 0 only)",
@@ -495,8 +500,10 @@ def run_impute(args, rig):
                                 % (tails_alone["steps"], tails_alone["ms_per_step"])) if tails_alone else "the headline run's stage timers",
             },
             "stage_ms_per_step": per_step,
-            "stage_note": "HIP-event time per stage on the main stream; ld_epilogue = B11's tiles, B21's tiles run on the side "
-                          "stream beside `factor` (the stages are not additive)",
+            "stage_note": "HIP-event time per stage on the stream it runs on.  With the chain beside the Gram kernel (default for "
+                          "jobs whose B21 launch can cover it): gram = both launches, ld_epilogue = B11's + B21's tiles, `factor` = the "
+                          "small-footprint chain on the chain queue UNDER the second Gram launch (hidden: not part of the step's "
+                          "critical path); otherwise ld_epilogue = B11's tiles and B21's run on the side stream beside `factor`",
         }
         out["roofline"].update(pmc_traffic(len(wins) == 36 and len(ch["bp"]) == 100_000 and rig.world == 1))
         if shard_check is not None:

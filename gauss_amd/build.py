@@ -20,6 +20,7 @@ HIP_UNITS = {
     "k_gram.hip": [],
     "k_pack_epilogue.hip": ["-ffp-contract=off"],   # reference-order fp64 tails: no fused multiply-add
     "k_solve.hip": [],
+    "k_solve_lite.hip": [],
     "k_misc.hip": [],
 }
 
@@ -65,7 +66,7 @@ def _newer(target, deps):
 def build_hip(force=False, verbose=False):
     os.makedirs(OBJDIR, exist_ok=True)
     hipcc = _hipcc()
-    hdrs = [os.path.join(CSRC, "gauss_internal.h"), os.path.join(CSRC, "k_gram_common.h"), os.path.join(HERE, "..", "include", "gauss_hip.h")]
+    hdrs = [os.path.join(CSRC, "gauss_internal.h"), os.path.join(CSRC, "k_gram_common.h"), os.path.join(CSRC, "k_solve_common.h"), os.path.join(HERE, "..", "include", "gauss_hip.h")]
     objs = []
     for unit, extra in HIP_UNITS.items():
         src = os.path.join(CSRC, unit)

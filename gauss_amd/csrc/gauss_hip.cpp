@@ -314,6 +314,8 @@ struct gauss_job {
     std::vector<std::vector<int2>> win_tiles;              // per window: its epilogue tiles (tilemap entries)
     int2* d_tilemap = nullptr;  int n_tiles = 0;            // LD epilogue tiles: B11's first (n_tiles_b11 of them), then B21's
     int n_tiles_b11 = 0;
+    int n_items_b11 = 0;                                   // chain_aside: B11's work items come first and are a launch of their own
+    bool chain_aside = false;                              // the factorisation chain runs beside the Gram launch of B21's items (job_run)
     int2* d_panelmap = nullptr; int n_panels = 0;          // fused path: (window, panel of [I | z1])
     int2* d_dpanelmap = nullptr; int n_dpanels = 0;        // stand-alone solve: (window, panel of right-hand sides)
     int2* d_gemmmap = nullptr;  int n_gemm = 0;            // (window, rhs panel of gemm_ut << 8 | k block of 128), longest first
@@ -861,6 +863,28 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
     }
     // longest segments first: the tail of the launch is then made of short items
     std::stable_sort(items.begin(), items.end(), [](const ItemH& a, const ItemH& b) { return a.len > b.len; });
+    // B11's items of the job (job-wide pairs, or the windows' own measured x measured pairs)
+    auto is_b11 = [&](const ItemH& h) {
+        return h.prob == job->n || job->plans[(size_t)h.prob].pair_ti[(size_t)h.pair] < job->plans[(size_t)h.prob].p.Mp / TILE;
+    };
+    {
+        // Chain beside the Gram kernel (k_solve_lite.hip): B11's items become a launch of their own, B11's epilogue tiles and
+        // the factorisation chain follow it on the chain queue, and the chain's latency hides under the Gram launch of
+        // B21's items.  Worth it when that launch is long enough to cover the chain, which runs 2-3 x slower beside it
+        // than alone (~55 us per block step); GAUSS_CHAIN_ASIDE = 0 never, 2 always (tests), 1 (default) by this estimate.
+        const int mode = env_int("GAUSS_CHAIN_ASIDE", 1);
+        bool genes = false;
+        double b21_len = 0.0;
+        for (const ItemH& h : items) if (!is_b11(h)) b21_len += (double)h.len;
+        for (int i = 0; i < job->n; i++) genes = genes || job->plans[i].p.n_gene > 0;
+        const double t_b21 = b21_len * 2.0 * TILE * TILE / 120e12, t_chain = 55e-6 * job->max_nblk;
+        job->chain_aside = !streamed && mode != 0 && !panelmap.empty() && !tilemap_b21.empty() && !genes && job->ctx->chain &&
+                           job->ctx->side && (mode == 2 || t_b21 >= 1.5 * t_chain);
+        if (job->chain_aside) {
+            std::stable_sort(items.begin(), items.end(), [&](const ItemH& a, const ItemH& b) { return is_b11(a) && !is_b11(b); });
+            for (const ItemH& h : items) job->n_items_b11 += is_b11(h) ? 1 : 0;
+        }
+    }
     std::vector<int> sgroup_of_item;
     if (streamed) {
         // streamed window: B11's items (measured rows only) first, then B21's items by chunk of `ct` unmeasured row
@@ -899,16 +923,19 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
         // the 8-rank shares 5.10 -> 5.03 ms; 36 windows: 38.5 ms either way, but 36 reads 27 % less from the fabric).
         static const int xcd_env = [] { const char* e = getenv("GAUSS_XCD_BLOCK"); return e ? atoi(e) : -1; }();
         const int xcd_block = xcd_env >= 0 ? xcd_env : (items.size() >= 20000 ? 36 : 8);
-        if (!streamed && xcd_block > 0 && items.size() > (size_t)8 * xcd_block) {
+        // (a job whose B11 items are a launch of their own interleaves each launch's list by itself)
+        auto interleave = [&](size_t i0, size_t i1) {
+            if (xcd_block <= 0 || i1 - i0 <= (size_t)8 * xcd_block) return;
             std::vector<std::vector<ItemH>> q(8);
-            for (size_t i = 0; i < items.size(); i++) q[(i / xcd_block) % 8].push_back(items[i]);
-            std::vector<ItemH> out;
-            out.reserve(items.size());
-            size_t pos[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            while (out.size() < items.size())
+            for (size_t i = i0; i < i1; i++) q[((i - i0) / xcd_block) % 8].push_back(items[i]);
+            size_t pos[8] = {0, 0, 0, 0, 0, 0, 0, 0}, n = i0;
+            while (n < i1)
                 for (int x = 0; x < 8; x++)
-                    if (pos[x] < q[x].size()) out.push_back(q[x][pos[x]++]);
-            items.swap(out);
+                    if (pos[x] < q[x].size()) items[n++] = q[x][pos[x]++];
+        };
+        if (!streamed) {
+            interleave(0, (size_t)job->n_items_b11);
+            interleave((size_t)job->n_items_b11, items.size());
         }
     }
     const size_t o_items = ta.take(sizeof(Item) * std::max<size_t>(items.size(), 1));
@@ -1249,6 +1276,22 @@ static void prof_collect(gauss_job* job, unsigned run_end = ~0u)
 }
 
 // ------------------------------------------------------------------------------------------
+static int job_run_finish(gauss_job* job, hipStream_t st)
+{
+    HIPCHK(hipGetLastError());
+    // the result mirrors travel with the run, so that gauss_job_fetch waits for THIS job only (an event), not for
+    // whatever else has been queued on the stream since (the next job of a pipeline)
+    const int par = (int)(job->run_seq & 1u);
+    if (job->n_results)
+        HIPCHK(hipMemcpyAsync(job->h_res2[par], job->d_results, sizeof(double) * job->n_results, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(job->h_st2[par], job->d_status, sizeof(int) * 4 * job->n, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipEventRecord(job->done2[par], st));
+    job->done = job->done2[par];
+    job->run_seq++;
+    job->ran = true;
+    return GAUSS_OK;
+}
+
 static int job_run(gauss_job* job, bool solve)
 {
     hipStream_t st = job->ctx->stream;
@@ -1277,6 +1320,45 @@ static int job_run(gauss_job* job, bool solve)
     if (solve && job->n_panels > 0) launch_shift_cert(job->d_probs, job->n, rs);      // needs the row tables only
     if (rs != st) HIPCHK(hipEventRecord(job->ev_rows, rs));
     prof_end(job, st);
+    if (solve && job->chain_aside) {
+        // Chain beside the Gram kernel.  main: Gram(B11's items) -> B11's epilogue tiles -> Gram(B21's items) -> B21's epilogue
+        // tiles -> closing product; chain queue: the whole factorisation with the riding rows of the inverse, in its
+        // small-footprint form (k_solve_lite.hip), from the moment B11 is written: its workgroups fit into what the Gram
+        // kernel's four workgroups per CU leave free, so its ~19 dependent block steps run UNDER the second Gram launch
+        // instead of behind it.  Same arithmetic, same bits as the path below.
+        hipStream_t ch = job->ctx->chain;
+        prof_begin(job, 0, st);
+        launch_gram(job->d_items, job->n_items_b11, job->gram_i8, st);
+        prof_end(job, st);
+        prof_begin(job, 2, st);
+        launch_epilogue(job->d_probs, job->d_tilemap, job->n_tiles_b11, job->max_pop, job->gram_i8, st);
+        prof_end(job, st);
+        for (int i = 0; i < job->n; i++) {
+            Plan& pl = job->plans[i];
+            if (pl.out_b11 && pl.p.npanel > 0)
+                HIPCHK(hipMemcpyAsync(pl.d_b11_copy, pl.p.A, sizeof(double) * pl.p.Mld * pl.p.Mld, hipMemcpyDeviceToDevice, st));
+        }
+        HIPCHK(hipEventRecord(job->ev_gram, st));
+        HIPCHK(hipStreamWaitEvent(ch, job->ev_gram, 0));
+        prof_begin(job, 3, ch);
+        static const bool exp_skip = env_int("GAUSS_EXP_SKIP_CHAIN", 0) != 0;      // timing experiment: wrong results
+        for (int s = 0; s < job->max_nblk && !exp_skip; s++)
+            launch_factor_step_lite(job->d_probs, job->n, s, job->max_nblk, job->max_npanel, job->solve_split, ch);
+        launch_solve_last_lite(job->d_probs, job->d_panelmap, job->n_panels, job->max_nblk, job->solve_split, ch);
+        prof_end(job, ch);
+        HIPCHK(hipEventRecord(job->ev_side, ch));
+        prof_begin(job, 0, st);
+        launch_gram(job->d_items + job->n_items_b11, job->n_items - job->n_items_b11, job->gram_i8, st);
+        prof_end(job, st);
+        prof_begin(job, 2, st);
+        launch_epilogue(job->d_probs, job->d_tilemap + job->n_tiles_b11, job->n_tiles - job->n_tiles_b11, job->max_pop, job->gram_i8, st);
+        prof_end(job, st);
+        HIPCHK(hipStreamWaitEvent(st, job->ev_side, 0));
+        prof_begin(job, 4, st);
+        launch_impute_gemm(job->d_probs, job->d_gemmmap, job->n_gemm, job->gemm_ut, job->d_finmap, job->n_fin, st);
+        prof_end(job, st);
+        return job_run_finish(job, st);
+    }
     prof_begin(job, 0, st);
     launch_gram(job->d_items, job->n_items, job->gram_i8, st);
     prof_end(job, st);
@@ -1314,18 +1396,7 @@ static int job_run(gauss_job* job, bool solve)
         } else launch_solve(job->d_probs, job->d_dpanelmap, job->n_dpanels, st);
         prof_end(job, st);
     }
-    HIPCHK(hipGetLastError());
-    // the result mirrors travel with the run, so that gauss_job_fetch waits for THIS job only (an event), not for
-    // whatever else has been queued on the stream since (the next job of a pipeline)
-    const int par = (int)(job->run_seq & 1u);
-    if (job->n_results)
-        HIPCHK(hipMemcpyAsync(job->h_res2[par], job->d_results, sizeof(double) * job->n_results, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(job->h_st2[par], job->d_status, sizeof(int) * 4 * job->n, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipEventRecord(job->done2[par], st));
-    job->done = job->done2[par];
-    job->run_seq++;
-    job->ran = true;
-    return GAUSS_OK;
+    return job_run_finish(job, st);
 }
 
 // One window whose genotype rows are still in HOST memory (the blocking call the Rcpp drivers bind).  Four queues:
@@ -1346,7 +1417,7 @@ static int ctx_stream_init(gauss_ctx* ctx)
     HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
     HIPCHK(hipStreamCreateWithFlags(&ctx->copy, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithPriority(&ctx->aux, hipStreamNonBlocking, hi));
-    HIPCHK(hipStreamCreateWithPriority(&ctx->chain, hipStreamNonBlocking, hi));
+    if (!ctx->chain) HIPCHK(hipStreamCreateWithPriority(&ctx->chain, hipStreamNonBlocking, hi));
     ctx->worker = new CopyWorker(ctx->device);
     return GAUSS_OK;
 }
@@ -1749,6 +1820,8 @@ int gauss_hip_init(int device, gauss_ctx** out_ctx)
         HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
         HIPCHK(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi));
         HIPCHK(hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, lo));
+        // the queue of the factorisation chain when it runs beside the Gram kernel (job_run, k_solve_lite.hip)
+        HIPCHK(hipStreamCreateWithPriority(&c->chain, hipStreamNonBlocking, hi));
     } else HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     *out_ctx = c;
     return GAUSS_OK;

@@ -187,6 +187,9 @@ void launch_pair_cor(const Prob* d_probs, int prob, const int2* d_pairs, long lo
                      double* d_out, hipStream_t s);
 void launch_gene_epilogue(const Prob* d_probs, int prob, int n_gene, hipStream_t s);
 void launch_factor_step(const Prob* d_probs, int n_prob, int step, int max_nblk, int max_npanel, int split, int own_panel, hipStream_t s);
+// small-footprint twins (k_solve_lite.hip): same bits, built to run beside the Gram kernel
+void launch_factor_step_lite(const Prob* d_probs, int n_prob, int step, int max_nblk, int max_npanel, int split, hipStream_t s);
+void launch_solve_last_lite(const Prob* d_probs, const int2* d_panelmap, int n_panels, int max_nblk, int split, hipStream_t s);
 void launch_shift_cert(const Prob* d_probs, int n_prob, hipStream_t s);
 void launch_solve(const Prob* d_probs, const int2* d_panelmap, int n_panels, hipStream_t s);
 void launch_impute_gemm(const Prob* d_probs, const int2* d_gmap, int n_tiles, int u_tile, const int2* d_fmap, int n_chunks, hipStream_t s);

@@ -21,18 +21,11 @@
 // rows (lane>>4) + 4*reg, column lane&15).  A workgroup is 4 waves; wave w owns rows 16w..16w+15
 // of a 64-row block.
 #include "gauss_internal.h"
+#include "k_solve_common.h"
 #include <algorithm>
 #include <cstdlib>
 
 namespace gauss {
-
-typedef double f64x4 __attribute__((ext_vector_type(4)));
-
-constexpr int LDT = NB + 2;    // LDS leading dimension of a 64 x 64 [row][k] tile: 66 doubles = 528 B;
-                               // 528 mod 256 = 16 puts the 32 lanes of a ds_read_b64 group on distinct banks
-constexpr int LDV = NR + 2;     // LDS leading dimension of the 64 x NR [k][col] tile of the solve
-
-#define WAVE_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
 // acc[n] += sign * A(rows 16w.., K=64) * B^T, A and B both [row][k] tiles with leading dimension LDT.
 template <int NT, bool NEG>
@@ -66,10 +59,6 @@ __device__ __forceinline__ void mfma_nn(f64x4 (&acc)[NT], const double* __restri
     }
 }
 
-// accumulator tile element (reg r of tile n) -> (row, col) inside the 64 x (16 NT) block
-__device__ __forceinline__ int acc_row(int wave, int lane, int r) { return 16 * wave + (lane >> 4) + 4 * r; }
-__device__ __forceinline__ int acc_col(int lane, int n) { return 16 * n + (lane & 15); }
-
 template <typename P>
 __device__ __forceinline__ void tile_load(double* __restrict__ T, P g, int ld, int tid)
 {
@@ -84,7 +73,6 @@ __device__ __forceinline__ void tile_store(P g, int ld, const double* __restrict
 // Register-staged tile transfer: fetch() issues the global loads of a 64 x 64 tile (8 x 16 bytes per
 // thread) and returns at once; commit() stores them into an LDS image later, so the loads fly while
 // the matrix cores work on the previous tile.
-typedef double f64x2 __attribute__((ext_vector_type(2)));
 struct TileRegs { f64x2 v[8]; };
 
 template <typename P>
@@ -190,13 +178,6 @@ __device__ int tile_chol_inv(double* __restrict__ D, double* __restrict__ X, int
 //                   forward substitution with wave-uniform L entries), the off-diagonal blocks follow by distance
 //                   from the diagonal:  X_ij = -X_ii * sum_{m=j}^{i-1} L_im X_mj   (two small MFMA products).
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ double readlane_f64(double v, int lane)
-{
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-    return __hiloint2double(hi, lo);
-}
-
 // wave 0: the 16 pivot steps of block column K on the 64-row panel (lane = row).  `bad` is wave-uniform.
 template <int K>
 __device__ __forceinline__ void chol_block_column(double* __restrict__ D, double* __restrict__ s_rinv, int lane, int& bad)
@@ -207,26 +188,7 @@ __device__ __forceinline__ void chol_block_column(double* __restrict__ D, double
         const f64x2 v = *reinterpret_cast<const f64x2*>(D + lane * LDT + 16 * K + c);
         a[c] = v[0]; a[c + 1] = v[1];
     }
-#pragma unroll
-    for (int j = 0; j < 16; j++) {
-        const int jj = 16 * K + j;
-        const double piv = readlane_f64(a[j], jj);
-        if (!(piv > 0.0)) bad = 1;
-        double r = __builtin_amdgcn_rsq(piv);
-        const double h = 0.5 * piv;
-        r = fma(r, fma(-h * r, r, 0.5), r);
-        r = fma(r, fma(-h * r, r, 0.5), r);
-        double d = piv * r;
-        d = fma(fma(-d, d, piv), 0.5 * r, d);
-        const double l = (lane == jj) ? d : a[j] * r;        // rows above jj hold junk that is never stored
-        a[j] = l;
-        if (lane == jj) s_rinv[jj] = r;                      // 1 / L[jj][jj]
-#pragma unroll
-        for (int c = j + 1; c < 16; c++) {
-            const double lc = readlane_f64(l, 16 * K + c);   // L[16K + c][jj], wave-uniform
-            a[c] = fma(-l, lc, a[c]);
-        }
-    }
+    chol_pivots<K>(a, s_rinv, lane, bad);
 #pragma unroll
     for (int c = 0; c < 16; c += 2) {
         f64x2 v;
@@ -357,11 +319,6 @@ __device__ int tile_chol_inv_blk(double* __restrict__ D, double* __restrict__ X,
 // Every step is the same short dependency chain (one product, one product + 64x64 Cholesky) whatever s is;
 // the left-looking variant this replaces chained s products per workgroup.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ GP(double) factor_work(const Prob& pb, int mat)
-{
-    const size_t ld2 = (size_t)pb.Mld * pb.Mld;
-    return mat == 0 ? pb.A + 4 * ld2 : pb.A + ld2;
-}
 
 // ------------------------------------------------------------------------------------------
 // K6/K7, two ways to z / info of a window:
@@ -373,17 +330,11 @@ __device__ __forceinline__ GP(double) factor_work(const Prob& pb, int mat)
 //     64-blocks of L:  V_k = Linv_kk * (B_k - sum_{j<k} L_kj V_j),  then z / info from the V blocks.
 // Both keep their V blocks in the problem's V scratch ([panel][Mld][NR]).
 // ------------------------------------------------------------------------------------------
-constexpr int SOLVE_NT = NR / 16;              // accumulator tiles (16 columns each) per wave
 constexpr int SOLVE_NG = 256 / NR;             // row groups of the z / info reduction
 constexpr int SOLVE_RG = NB / SOLVE_NG;        // rows per group
-constexpr int SOLVE_SPLIT = 4;                 // interleaved classes of a row's products (solve_row, ride_pre)
 static const size_t SOLVE_SMEM = ((size_t)NB * LDT + (size_t)NB * LDV + 768) * sizeof(double);
 
 struct SolveSums { double z, info, v; };       // per-thread partial sums: column tid % NR, rows of group tid / NR
-
-// Fused path: column g < M of the right-hand side [I | z1] is e_g, so block (kb, panel) of X is a structural zero for
-// kb < panel and is never computed, stored or read; the panel that holds column M (z1) is dense.
-__device__ __forceinline__ int inv_first_row(const Prob& pb, int panel) { return panel == pb.M / NR ? 0 : panel; }
 
 // acc -= sum_{j = j0, j0 + jstep, ... < kb} L[kb][j] V[j]   (the products of block row kb; TL / TV: the workgroup's LDS tiles)
 __device__ __forceinline__ void solve_products(const Prob& pb, int panel, int kb, int j0, int jstep, f64x4 (&acc)[SOLVE_NT],
@@ -568,11 +519,6 @@ __device__ __forceinline__ void solve_finish(const Prob& pb, int panel, double* 
 // update(s) therefore carries fin(s) and pre(s + 1); both read only what earlier launches wrote (L rows <= s + 1 from
 // panel(<= s), Linv_ss from update(s - 1), V rows <= s - 1 and pre(s)'s sums from update(s - 1)).  Part is double
 // buffered by row parity (pre(s + 1) writes while fin(s) reads).  solve_last_kernel runs fin of the batch's last row.
-__device__ __forceinline__ GP(double) ride_part(const Prob& pb, int panel, int r, int g)
-{
-    return pb.Part + (((size_t)(r & 1) * pb.npi + panel) * SOLVE_SPLIT + g) * (NB * NR);
-}
-
 // acc -= sum over j = j0, j0 + jstep, ... <= jlast of L[r][j] V[j], skipping j below the panel's first row
 __device__ __forceinline__ void ride_products(const Prob& pb, int panel, int r, int j0, int jstep, int jlast, f64x4 (&acc)[SOLVE_NT],
                                               double* __restrict__ TL, double* __restrict__ TV, int tid)

@@ -707,3 +707,59 @@ def test_shared_measured_rows_give_the_bits_of_separate_windows(ctx, monkeypatch
             else:
                 assert x[key] == y[key], key
     store.close()
+
+
+@pytest.mark.gpu
+def test_chain_beside_the_gram_kernel_gives_the_same_bits(ctx, monkeypatch):
+    """The factorisation chain in its small-footprint form (k_solve_lite.hip), queued beside the Gram launch of B21's items
+    (GAUSS_CHAIN_ASIDE=2 forces it), against the chain behind one Gram launch (=0): z, info, status, B11 and B21 bit for bit.
+    Windows of 2 to 9 factor blocks (M not a multiple of 64), shared and unshared measured rows, a QCAT window, a window
+    whose lambda is too small for the certificate (the shifted matrix is factored too), and one whose B11 is not positive
+    definite at all (lambda = 0 on duplicated rows: the clamp path reruns it)."""
+    p = small_panel(n_snp=2600, scale=0.05, seed=41)
+    G = p["G"].copy()
+    G[7] = G[3]                                    # two identical SNPs: singular B11 at lambda = 0
+    rows2, src_off = panel_mod.pack2bit(G, p["off"])
+    store = hotpath.RowStore(rows2, ctx=ctx)
+    rng = np.random.default_rng(5)
+    n = G.shape[0]
+    measured = np.sort(np.concatenate([np.arange(12), 12 + rng.choice(n - 12, size=n // 3, replace=False)]))
+    unmeasured = np.setdiff1d(np.arange(n), measured)
+    z = rng.standard_normal(n)
+    wins = []
+    for k, (a, b) in enumerate([(0, 131), (97, 340), (211, 760), (330, len(measured)), (500, 640)]):
+        mi = measured[a:b]
+        lo, hi = mi[len(mi) // 4], mi[3 * len(mi) // 4]
+        ui = unmeasured[(unmeasured > lo) & (unmeasured < hi)]
+        wins.append(dict(mode=1, pop_off=p["off"], pop_wgt=p["w"], z1=z[mi], dev=(store.ptr, store.ptr, len(mi), len(ui), store.ld),
+                         packed=dict(fmt=1, rows_m=mi.astype(np.int32), rows_u=ui.astype(np.int32), pop_src_off=src_off)))
+    wins[1] = dict(wins[1], qcat=(20, 60, 0.01))
+    wins[4] = dict(wins[4], lam=1e-7)              # no certificate: the exact test factors B11 - eps I as well
+    wins[0] = dict(wins[0], lam=0.0)               # singular: status says clamp, the host reruns the window
+
+    def run(aside, share):
+        monkeypatch.setenv("GAUSS_CHAIN_ASIDE", "2" if aside else "0")
+        monkeypatch.setenv("GAUSS_SHARE_MEASURED", "1" if share else "0")
+        job = hotpath.Job(wins, ctx=ctx, on_device=True, want_mats=True)
+        job.run()
+        job.run()                                   # two runs in flight
+        a = job.fetch()
+        b = job.fetch()
+        job.close()
+        for x, y in zip(a, b):
+            for key in x:
+                if isinstance(x[key], np.ndarray):
+                    assert np.array_equal(x[key], y[key], equal_nan=True), key
+        return a
+
+    for share in (False, True):
+        behind = run(False, share)
+        beside = run(True, share)
+        assert any(r["status"] != 0 for r in behind)
+        for k, (x, y) in enumerate(zip(behind, beside)):
+            for key in x:
+                if isinstance(x[key], np.ndarray):
+                    assert np.array_equal(x[key], y[key], equal_nan=True), (share, k, key)
+                else:
+                    assert x[key] == y[key], (share, k, key)
+    store.close()
