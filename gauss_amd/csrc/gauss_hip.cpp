@@ -286,7 +286,8 @@ struct Plan {
     size_t res_off = 0;                      // offset (in doubles) of this problem's z in the result block
 };
 
-struct ProfSlot { hipEvent_t a, b; int kernel; unsigned run; };      // run: gauss_job::run_seq of the run that recorded it
+struct ProfSlot { hipEvent_t a, b; int kernel; unsigned run; int launches = 1; };      // run: gauss_job::run_seq of the run that recorded it;
+                                                                                        // launches: kernel launches the slot spans
 
 struct gauss_job {
     gauss_ctx* ctx = nullptr;
@@ -405,7 +406,10 @@ static int seg_max_for(size_t n_windows)
 {
     static const int ov = env_int("GAUSS_SEG_MAX", 0);          // experiment override (multiple of 64)
     if (ov > 0) return ov / KC * KC;
-    return n_windows >= 4 ? 8192 : SEG_MAX;
+    // 4096 for batched jobs (8192 until the chain moved beside the Gram kernel: with B11's and B21's items in launches of their
+    // own the shorter items balance each launch's last round better -- 5 / 9 / 18 / 36 windows: step 4.86 -> 4.75, 8.97 -> 8.93,
+    // 19.47 -> 19.29, 41.00 -> 40.96 ms -- for 19 % more work items)
+    return n_windows >= 4 ? 4096 : SEG_MAX;
 }
 // Consecutive segments are chained into one work item until the run reaches this many samples
 // (a fresh item costs a pipeline fill: descriptor, first operand tiles, barrier).  0 = no chaining.
@@ -1240,11 +1244,12 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
 // ------------------------------------------------------------------------------------------
 // profiling helpers
 // ------------------------------------------------------------------------------------------
-static void prof_begin(gauss_job* job, int kernel, hipStream_t st)
+static void prof_begin(gauss_job* job, int kernel, hipStream_t st, int launches = 1)
 {
     if (!job->prof) return;
     ProfSlot s;
     s.kernel = kernel;
+    s.launches = launches;
     s.run = job->run_seq;
     hipEventCreate(&s.a);
     hipEventCreate(&s.b);
@@ -1268,7 +1273,7 @@ static void prof_collect(gauss_job* job, unsigned run_end = ~0u)
         float ms = 0.f;
         hipEventElapsedTime(&ms, s.a, s.b);
         job->prof_ms[s.kernel] += ms;
-        job->prof_n[s.kernel] += 1;
+        job->prof_n[s.kernel] += s.launches;
         hipEventDestroy(s.a);
         hipEventDestroy(s.b);
     }
@@ -1321,35 +1326,37 @@ static int job_run(gauss_job* job, bool solve)
     if (rs != st) HIPCHK(hipEventRecord(job->ev_rows, rs));
     prof_end(job, st);
     if (solve && job->chain_aside) {
-        // Chain beside the Gram kernel.  main: Gram(B11's items) -> B11's epilogue tiles -> Gram(B21's items) -> B21's epilogue
-        // tiles -> closing product; chain queue: the whole factorisation with the riding rows of the inverse, in its
-        // small-footprint form (k_solve_lite.hip), from the moment B11 is written: its workgroups fit into what the Gram
-        // kernel's four workgroups per CU leave free, so its ~19 dependent block steps run UNDER the second Gram launch
-        // instead of behind it.  Same arithmetic, same bits as the path below.
+        // Chain beside the Gram kernel.
+        //   main:   Gram(B11's items) -> Gram(B21's items) -> B21's epilogue tiles -> closing product.  (The second launch queued
+        //           "any order" through hipExtLaunchKernelGGL, with the first launch's own completion event for the chain queue,
+        //           starts 5 us earlier and gains 0.08 ms of 41 -- the first launch's last workgroups are dispatched at its very
+        //           end -- not worth a launch path of its own);
+        //   chain:  from the moment the FIRST launch has finished: B11's epilogue tiles, then the whole
+        //           factorisation with the riding rows of the inverse, all in small-footprint form (k_pack_epilogue.hip
+        //           epilogue_b11_lite_kernel, k_solve_lite.hip): their workgroups fit into what the Gram kernel's four workgroups
+        //           per CU leave free, so the ~19 dependent block steps run UNDER the second Gram launch instead of behind it.
+        // Same arithmetic, same bits as the path below.
         hipStream_t ch = job->ctx->chain;
-        prof_begin(job, 0, st);
+        prof_begin(job, 0, st, 2);
         launch_gram(job->d_items, job->n_items_b11, job->gram_i8, st);
+        HIPCHK(hipEventRecord(job->ev_gram, st));
+        launch_gram(job->d_items + job->n_items_b11, job->n_items - job->n_items_b11, job->gram_i8, st);
         prof_end(job, st);
-        prof_begin(job, 2, st);
-        launch_epilogue(job->d_probs, job->d_tilemap, job->n_tiles_b11, job->max_pop, job->gram_i8, st);
-        prof_end(job, st);
+        HIPCHK(hipStreamWaitEvent(ch, job->ev_gram, 0));
+        prof_begin(job, 2, ch);
+        launch_epilogue_b11_lite(job->d_probs, job->d_tilemap, job->n_tiles_b11, job->gram_i8, ch);
+        prof_end(job, ch);
         for (int i = 0; i < job->n; i++) {
             Plan& pl = job->plans[i];
             if (pl.out_b11 && pl.p.npanel > 0)
-                HIPCHK(hipMemcpyAsync(pl.d_b11_copy, pl.p.A, sizeof(double) * pl.p.Mld * pl.p.Mld, hipMemcpyDeviceToDevice, st));
+                HIPCHK(hipMemcpyAsync(pl.d_b11_copy, pl.p.A, sizeof(double) * pl.p.Mld * pl.p.Mld, hipMemcpyDeviceToDevice, ch));
         }
-        HIPCHK(hipEventRecord(job->ev_gram, st));
-        HIPCHK(hipStreamWaitEvent(ch, job->ev_gram, 0));
         prof_begin(job, 3, ch);
-        static const bool exp_skip = env_int("GAUSS_EXP_SKIP_CHAIN", 0) != 0;      // timing experiment: wrong results
-        for (int s = 0; s < job->max_nblk && !exp_skip; s++)
+        for (int s = 0; s < job->max_nblk; s++)
             launch_factor_step_lite(job->d_probs, job->n, s, job->max_nblk, job->max_npanel, job->solve_split, ch);
         launch_solve_last_lite(job->d_probs, job->d_panelmap, job->n_panels, job->max_nblk, job->solve_split, ch);
         prof_end(job, ch);
         HIPCHK(hipEventRecord(job->ev_side, ch));
-        prof_begin(job, 0, st);
-        launch_gram(job->d_items + job->n_items_b11, job->n_items - job->n_items_b11, job->gram_i8, st);
-        prof_end(job, st);
         prof_begin(job, 2, st);
         launch_epilogue(job->d_probs, job->d_tilemap + job->n_tiles_b11, job->n_tiles - job->n_tiles_b11, job->max_pop, job->gram_i8, st);
         prof_end(job, st);

@@ -9,8 +9,8 @@ namespace gauss {
 
 constexpr int TILE = 128;      // Gram output tile edge per workgroup (4 waves x 64x64)
 constexpr int KC = 64;         // packed K chunk in bytes (= samples); pops are padded to it
-constexpr int SEG_MAX = 2048;  // K segment cap for small jobs (< 4 windows); larger jobs use 8192 (seg_max_for); both keep
-                               // a partial sum below 2^24 (15 * 15 * 8192), the exactness bound of the f32 accumulators
+constexpr int SEG_MAX = 2048;  // K segment cap for small jobs (< 4 windows); larger jobs use 4096 (seg_max_for); any cap up to 8192
+                               // keeps a partial sum below 2^24 (15 * 15 * 8192), the exactness bound of the f32 accumulators
 constexpr int NB = 64;         // fp64 factor / solve block edge
 constexpr int NR = 64;         // right-hand sides per solve panel (63 SNPs + the z1 column); the solve kernel is
                                // written for any multiple of 64 -- 128 was measured slower (2.23 vs 1.80 ms: half as
@@ -182,6 +182,7 @@ void launch_pack_stats(const Prob* d_probs, const int2* d_rowmap, int n_rows, hi
 void launch_row_stats(const Prob* d_probs, const int2* d_rowmap, int n_rows, hipStream_t s);
 void launch_gram(const Item* d_items, int n_items, int dtype_i8, hipStream_t s);
 void launch_epilogue(const Prob* d_probs, const int2* d_tilemap, int n_tiles, int max_pop, int dtype_i8, hipStream_t s);
+void launch_epilogue_b11_lite(const Prob* d_probs, const int2* d_tilemap, int n_tiles, int dtype_i8, hipStream_t s);
 void launch_pop_cor(const Prob* d_probs, int prob, int npair, double* d_out, hipStream_t s);
 void launch_pair_cor(const Prob* d_probs, int prob, const int2* d_pairs, long long n_pairs, const int* d_pop_group, int n_group,
                      double* d_out, hipStream_t s);

@@ -8,7 +8,8 @@
 // Exactness: operands are genotype codes (0..15 admitted, 0..2 in practice); a segment (the run of samples whose
 // products one accumulator sums before it is flushed) never spans more than 8192 samples of ONE population -- the
 // planner cuts longer populations, at SEG_MAX = 2048 for jobs of fewer than four windows (more work items) and at
-// 8192 otherwise (gauss_hip.cpp:seg_max_for) -- so every partial sum is an integer <= 15 * 15 * 8192 < 2^24 and the
+// 4096 otherwise (gauss_hip.cpp:seg_max_for; any cap up to 8192 is admissible) -- so every partial sum is an integer
+// <= 15 * 15 * 8192 < 2^24 and the
 // f32 MFMA accumulation (bitwise a k-ordered fmaf chain) is exact in any summation order.  The k order inside a
 // chunk is therefore permuted freely to make the LDS reads wide.
 //

@@ -349,6 +349,52 @@ template <bool ISINT, bool S16> struct SlabBlock {
     }
 };
 
+// One entry (ri <= rj, window-relative measured rows) of a measured x measured tile goes to its places: LD export, or
+// A[0] = B11 (diag 1 + lambda), A[1] = B11 - eps I and the factorisation's working copy, identity padded to Mld.
+__device__ __forceinline__ void epi_store_sym(const Prob& pb, int ri, int rj, double cv, bool need_a1)
+{
+    const int Mld = pb.Mld;
+    if (ri > rj || ri < 0) return;                        // mirror handles the lower part; ri < 0: not this window's SNP
+    if (pb.ld_only) {
+        if (ri >= pb.M || rj >= pb.M) return;
+        const double v = (ri == rj) ? pb.diag : cv;
+        pb.out_ld[(size_t)ri * pb.M + rj] = v;
+        pb.out_ld[(size_t)rj * pb.M + ri] = v;
+        return;
+    }
+    if (ri >= Mld || rj >= Mld) return;
+    double v0, v1;
+    if (ri >= pb.M || rj >= pb.M) { v0 = v1 = (ri == rj) ? 1.0 : 0.0; }
+    else if (ri == rj) { v0 = 1.0 + pb.lambda; v1 = v0 - pb.eps; }   // dist.cpp:172
+    else { v0 = v1 = cv; }                                            // dist.cpp:174-177
+    const auto A0 = pb.A;
+    const auto A1 = pb.A + (size_t)Mld * Mld;
+    A0[(size_t)ri * Mld + rj] = v0; A0[(size_t)rj * Mld + ri] = v0;
+    // the shifted twin is only ever read by its own factorisation, which the certificate (shift_cert_kernel,
+    // ahead of the Gram kernel on this stream) has already ruled out for most windows
+    if (need_a1) { A1[(size_t)ri * Mld + rj] = v1; A1[(size_t)rj * Mld + ri] = v1; }
+    if (pb.npanel > 0) {                                  // working copy of B11 for the in-place factorisation
+        const auto W0 = pb.A + (size_t)4 * Mld * Mld;
+        W0[(size_t)ri * Mld + rj] = v0; W0[(size_t)rj * Mld + ri] = v0;
+    }
+}
+
+// Job-wide tiles end where the chromosome's measured SNPs end, not where this window's do: the identity padding of B11
+// between M and Mld (rows of no SNP; the tiles of an unshared window write it as part of their own padding) is written
+// by the workgroup (nthreads threads) of the window's LAST diagonal tile.
+__device__ __forceinline__ void epi_pad_identity(const Prob& pb, int ti, int tj, bool need_a1, int tid, int nthreads)
+{
+    const int Mld = pb.Mld;
+    if (!(ti == tj && !pb.ld_only && pb.g0 + pb.M - 1 >= ti * TILE && pb.g0 + pb.M - 1 < (ti + 1) * TILE)) return;
+    for (int e = tid; e < (Mld - pb.M) * Mld; e += nthreads) {
+        const int r = pb.M + e / Mld, c = e % Mld;
+        const double v = (r == c) ? 1.0 : 0.0;
+        pb.A[(size_t)r * Mld + c] = v; pb.A[(size_t)c * Mld + r] = v;
+        if (need_a1) { pb.A[(size_t)Mld * Mld + (size_t)r * Mld + c] = v; pb.A[(size_t)Mld * Mld + (size_t)c * Mld + r] = v; }
+        if (pb.npanel > 0) { pb.A[(size_t)4 * Mld * Mld + (size_t)r * Mld + c] = v; pb.A[(size_t)4 * Mld * Mld + (size_t)c * Mld + r] = v; }
+    }
+}
+
 template <bool ISINT, bool S16>
 __device__ __forceinline__ void epilogue_tile(const Prob& pb, int pair_in, int lds_pop_cap, char* esm)
 {
@@ -511,49 +557,15 @@ __device__ __forceinline__ void epilogue_tile(const Prob& pb, int pair_in, int l
 #pragma unroll
         for (int c = 0; c < 4; c++) {
             const int rj = row0_j + c0 + c;
-            if (sym) {
-                if (ri > rj || ri < 0) continue;                  // mirror handles the lower part; ri < 0: not this window's SNP
-                if (pb.ld_only) {
-                    if (ri >= pb.M || rj >= pb.M) continue;
-                    const double v = (ri == rj) ? pb.diag : cov[q][c];
-                    pb.out_ld[(size_t)ri * pb.M + rj] = v;
-                    pb.out_ld[(size_t)rj * pb.M + ri] = v;
-                    continue;
-                }
-                if (ri >= Mld || rj >= Mld) continue;
-                double v0, v1;
-                if (ri >= pb.M || rj >= pb.M) { v0 = v1 = (ri == rj) ? 1.0 : 0.0; }
-                else if (ri == rj) { v0 = 1.0 + pb.lambda; v1 = v0 - pb.eps; }   // dist.cpp:172
-                else { v0 = v1 = cov[q][c]; }                                     // dist.cpp:174-177
-                const auto A0 = pb.A;
-                const auto A1 = pb.A + (size_t)Mld * Mld;
-                A0[(size_t)ri * Mld + rj] = v0; A0[(size_t)rj * Mld + ri] = v0;
-                // the shifted twin is only ever read by its own factorisation, which the certificate (shift_cert_kernel,
-                // ahead of the Gram kernel on this stream) has already ruled out for most windows
-                if (need_a1) { A1[(size_t)ri * Mld + rj] = v1; A1[(size_t)rj * Mld + ri] = v1; }
-                if (pb.npanel > 0) {                              // working copy of B11 for the in-place factorisation
-                    const auto W0 = pb.A + (size_t)4 * Mld * Mld;
-                    W0[(size_t)ri * Mld + rj] = v0; W0[(size_t)rj * Mld + ri] = v0;
-                }
-            } else {
+            if (sym) epi_store_sym(pb, ri, rj, cov[q][c], need_a1);
+            else {
                 const int u = ri;                                 // unmeasured row (x), measured col (y)
                 if (u >= pb.U || rj >= pb.M) continue;
                 pb.B21[(size_t)u * Mld + rj] = cov[q][c];         // dist.cpp:188-191
             }
         }
     }
-    // Job-wide tiles end where the chromosome's measured SNPs end, not where this window's do: the identity padding of
-    // B11 between M and Mld (rows of no SNP; the tiles of an unshared window write it as part of their own padding) is
-    // written by the workgroup of the window's LAST diagonal tile.
-    if (gb11 && ti == tj && !pb.ld_only && pb.g0 + pb.M - 1 >= ti * TILE && pb.g0 + pb.M - 1 < (ti + 1) * TILE) {
-        for (int e = tid; e < (Mld - pb.M) * Mld; e += 1024) {
-            const int r = pb.M + e / Mld, c = e % Mld;
-            const double v = (r == c) ? 1.0 : 0.0;
-            pb.A[(size_t)r * Mld + c] = v; pb.A[(size_t)c * Mld + r] = v;
-            if (need_a1) { pb.A[(size_t)Mld * Mld + (size_t)r * Mld + c] = v; pb.A[(size_t)Mld * Mld + (size_t)c * Mld + r] = v; }
-            if (pb.npanel > 0) { pb.A[(size_t)4 * Mld * Mld + (size_t)r * Mld + c] = v; pb.A[(size_t)4 * Mld * Mld + (size_t)c * Mld + r] = v; }
-        }
-    }
+    if (gb11) epi_pad_identity(pb, ti, tj, need_a1, tid, 1024);
 }
 
 template <bool ISINT>
@@ -580,6 +592,166 @@ void launch_epilogue(const Prob* d_probs, const int2* d_tilemap, int n_tiles, in
     const size_t smem = (size_t)cap * TILE * (2 * sizeof(double) + 2 * sizeof(int));
     if (dtype_i8) hipLaunchKernelGGL(epilogue_kernel<true>, dim3(n_tiles), dim3(1024), smem, s, d_probs, d_tilemap, cap);
     else hipLaunchKernelGGL(epilogue_kernel<false>, dim3(n_tiles), dim3(1024), smem, s, d_probs, d_tilemap, cap);
+}
+
+// ------------------------------------------------------------------------------------------
+// B11's epilogue tiles in a small-footprint form: 256 threads, 18 KB of LDS, <= 96 registers, so that a workgroup fits into
+// what gram_kernel's four workgroups per CU leave free and the tiles run BESIDE the Gram launch of B21's items, ahead of
+// the factorisation chain on the chain queue (gauss_hip.cpp:job_run, k_solve_lite.hip).  Entry for entry the arithmetic of
+// epilogue_tile -- integer sum of a population's partials, util.cpp:118 / :119 in population order, util.cpp:123,
+// distmix.cpp:196 (pooled: util.cpp:66-68) -- hence the same bits.  What differs is the staging: the tile is walked in
+// 2 column halves x 4 passes of 32 rows (thread = one row pair x 4 columns), and the per-population tables come through
+// LDS in chunks of 16 populations (64 columns + 32 rows at a time) instead of all at once (78 KB at 26 populations).
+// ------------------------------------------------------------------------------------------
+constexpr int ELP = 16;                                    // populations per table chunk
+struct EpiLiteTables {
+    double muj[ELP][64];                                   // mu_p(col j)
+    double wmui[ELP][32];                                  // w_p * mu_p(row i)
+    int sxj[ELP][64];
+    int sxi[ELP][32];
+};
+
+template <bool ISINT, bool S16>
+__device__ __forceinline__ void epilogue_b11_lite_tile(const Prob& pb, int pair_in, EpiLiteTables& tb)
+{
+    const bool gb11 = (pair_in & TILE_GB11) != 0;
+    const int pair = pair_in & ~TILE_GB11;
+    const int ti = gb11 ? pb.gpair_ti[pair] : pb.pair_ti[pair], tj = gb11 ? pb.gpair_tj[pair] : pb.pair_tj[pair];
+    const int P = pb.P, nseg = pb.nseg;
+    const auto tile_slab = (gb11 ? pb.slab_g : pb.slab) + (size_t)pair * nseg * (S16 ? TILE * TILE / 2 : TILE * TILE);
+    const bool need_a1 = !(pb.npanel > 0 && pb.status[3] != 0);
+    const int tid = threadIdx.x;
+    const bool weighted = pb.mode != 0;
+    const int row0_i = gb11 ? ti * TILE - pb.g0 : ti * TILE;
+    const int row0_j = gb11 ? tj * TILE - pb.g0 : tj * TILE;
+    const int cg = tid & 15, rp = tid >> 4;
+    const int num_samples = pb.N;
+    // the thread's two rows x four columns of one partial slab, as raw dwords (16-bit slabs: one dword = a row pair)
+    auto load = [&](u32x4e (&raw)[2], int s, int q, int c0) {
+        if (S16) raw[0] = *(GP(const u32x4e))((GP(const uint32_t))tile_slab + (size_t)s * (TILE * TILE / 2) + q * TILE + c0);
+        else {
+            const auto base = (GP(const uint32_t))tile_slab + (size_t)s * (TILE * TILE);
+            raw[0] = *(GP(const u32x4e))(base + (2 * q) * TILE + c0);
+            raw[1] = *(GP(const u32x4e))(base + (2 * q + 1) * TILE + c0);
+        }
+    };
+    auto get = [&](const u32x4e (&raw)[2], int h, int c) -> int {
+        if (S16) { const uint32_t d = raw[0][c]; return (int)(h ? (d >> 16) : (d & 0xFFFFu)); }
+        return ISINT ? (int)raw[h][c] : (int)__uint_as_float(raw[h][c]);
+    };
+#pragma unroll 1
+    for (int half = 0; half < 2; half++) {
+        const int c0 = 64 * half + 4 * cg;
+        double sd_j[4], wm_j[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) { sd_j[c] = pb.rt_sd[row0_j + c0 + c]; wm_j[c] = pb.rt_wm[row0_j + c0 + c]; }
+#pragma unroll 1
+        for (int pass = 0; pass < 4; pass++) {
+            const int q = rp + 16 * pass;                  // row pair: tile rows 2 q, 2 q + 1
+            double cov[2][4];
+            if (!weighted) {
+                int acc[2][4] = {};
+                u32x4e nxt[2];
+                load(nxt, 0, q, c0);
+                for (int sgm = 0; sgm < nseg; sgm++) {
+                    u32x4e cur[2] = {nxt[0], nxt[1]};
+                    if (sgm + 1 < nseg) load(nxt, sgm + 1, q, c0);
+#pragma unroll
+                    for (int h = 0; h < 2; h++)
+#pragma unroll
+                        for (int c = 0; c < 4; c++) acc[h][c] += get(cur, h, c);
+                }
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int ri = row0_i + 2 * q + h;
+                    const double wm_i = pb.rt_wm[ri], sd_i = pb.rt_sd[ri];
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        const double numer = num_samples * (double)acc[h][c] - wm_i * wm_j[c];
+                        const double denor = sd_i * sd_j[c];
+                        cov[h][c] = numer / denor;
+                    }
+                }
+            } else {
+                double wsumcov[2][4] = {}, wmm[2][4] = {};
+                u32x4e nxt[2];
+                load(nxt, 0, q, c0);
+                for (int p0 = 0; p0 < P; p0 += ELP) {
+                    const int pn = min(ELP, P - p0);
+                    __syncthreads();                       // the previous chunk's tables are no longer being read
+                    for (int idx = tid; idx < pn * 64; idx += 256) {
+                        const int r = idx / pn, p = idx % pn;             // consecutive threads: consecutive p of a row
+                        tb.muj[p][r] = pb.rt_mu[(ptrdiff_t)(row0_j + 64 * half + r) * P + p0 + p];
+                        tb.sxj[p][r] = pb.sx[(ptrdiff_t)(row0_j + 64 * half + r) * P + p0 + p];
+                    }
+                    for (int idx = tid; idx < pn * 32; idx += 256) {
+                        const int r = idx / pn, p = idx % pn;
+                        tb.wmui[p][r] = pb.rt_wmu[(ptrdiff_t)(row0_i + 32 * pass + r) * P + p0 + p];
+                        tb.sxi[p][r] = pb.sx[(ptrdiff_t)(row0_i + 32 * pass + r) * P + p0 + p];
+                    }
+                    __syncthreads();
+                    for (int p = 0; p < pn; p++) {
+                        int acc[2][4] = {};
+                        for (int sgm = pb.pop_seg0[p0 + p]; sgm < pb.pop_seg0[p0 + p + 1]; sgm++) {
+                            u32x4e cur[2] = {nxt[0], nxt[1]};
+                            if (sgm + 1 < nseg) load(nxt, sgm + 1, q, c0);          // segments are stored in population order
+#pragma unroll
+                            for (int h = 0; h < 2; h++)
+#pragma unroll
+                                for (int c = 0; c < 4; c++) acc[h][c] += get(cur, h, c);
+                        }
+                        const double md = pb.pop_md[p0 + p], wf = pb.pop_wf[p0 + p];
+#pragma unroll
+                        for (int h = 0; h < 2; h++) {
+                            const int lr = 2 * rp + h;                                 // row inside the pass
+                            const double sumx = (double)tb.sxi[p][lr];
+                            const double wmu_x = tb.wmui[p][lr];
+#pragma unroll
+                            for (int c = 0; c < 4; c++) {
+                                const double sumy = (double)tb.sxj[p][4 * cg + c];
+                                wsumcov[h][c] += wf * (md * (double)acc[h][c] - sumx * sumy);      // util.cpp:118
+                                wmm[h][c] += wmu_x * tb.muj[p][4 * cg + c];                         // util.cpp:119
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int ri = row0_i + 2 * q + h;
+                    const double wm_i = pb.rt_wm[ri], sd_i = pb.rt_sd[ri];
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        const double cv = wsumcov[h][c] + wmm[h][c] - wm_i * wm_j[c];               // util.cpp:123
+                        cov[h][c] = cv / (sd_i * sd_j[c]);                                          // distmix.cpp:196
+                    }
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+#pragma unroll
+                for (int c = 0; c < 4; c++) epi_store_sym(pb, row0_i + 2 * q + h, row0_j + c0 + c, cov[h][c], need_a1);
+        }
+    }
+    if (gb11) epi_pad_identity(pb, ti, tj, need_a1, tid, 256);
+}
+
+template <bool ISINT>
+__global__ __launch_bounds__(256, 5) void epilogue_b11_lite_kernel(const Prob* __restrict__ probs, const int2* __restrict__ tilemap)
+{
+    __shared__ EpiLiteTables tb;
+    __builtin_amdgcn_s_setprio(3);
+    const int2 tm = tilemap[blockIdx.x];
+    const Prob& pb = probs[tm.x];
+    if (pb.slab16) epilogue_b11_lite_tile<ISINT, true>(pb, tm.y, tb);
+    else epilogue_b11_lite_tile<ISINT, false>(pb, tm.y, tb);
+}
+
+// measured x measured tiles only (the first n_tiles_b11 entries of a job's tile map)
+void launch_epilogue_b11_lite(const Prob* d_probs, const int2* d_tilemap, int n_tiles, int dtype_i8, hipStream_t s)
+{
+    if (n_tiles <= 0) return;
+    if (dtype_i8) hipLaunchKernelGGL(epilogue_b11_lite_kernel<true>, dim3(n_tiles), dim3(256), 0, s, d_probs, d_tilemap);
+    else hipLaunchKernelGGL(epilogue_b11_lite_kernel<false>, dim3(n_tiles), dim3(256), 0, s, d_probs, d_tilemap);
 }
 
 // Gene batches (gene.cpp:305-315, 571-586): block g is n_g x n_g with pb.diag on the diagonal.
