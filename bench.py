@@ -403,6 +403,8 @@ def run_impute(args, rig):
             dtr, str_, res_r = rr.timed(args.steps, max(1, args.warmup))
             parts_e.append({piece: (q["z"], q["info"]) for piece, q in zip(shares_e[r], rr.results_in_order(res_r))})
             per_rank.append({"rank": r, "windows": len(wr), "ms_per_step": dtr / args.steps * 1e3,
+                             "executed_flops": rr.stats["executed_flops"], "work_items": rr.stats["items"], "algorithmic_flops": rr.work["ld_flops"],
+                             "mu": [(int(len(w[1])), int(len(w[2]))) for w in wr],
                              "stage_ms": {k: v[0] / args.steps for k, v in str_.items()},
                              "gram_frac_of_peak": (rr.work["ld_flops"] * args.steps / (str_["gram"][0] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS)
                              if str_["gram"][0] > 0 else 0.0})

@@ -874,16 +874,17 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
     {
         // Chain beside the Gram kernel (k_solve_lite.hip): B11's items become a launch of their own, B11's epilogue tiles and
         // the factorisation chain follow it on the chain queue, and the chain's latency hides under the Gram launch of
-        // B21's items.  Worth it when that launch is long enough to cover the chain, which runs 2-3 x slower beside it
-        // than alone (~55 us per block step); GAUSS_CHAIN_ASIDE = 0 never, 2 always (tests), 1 (default) by this estimate.
+        // B21's items.  Worth it when that launch is long enough to cover B11's small-footprint epilogue tiles (~0.5 ms) and
+        // the chain, which runs ~3 x slower beside the Gram kernel than alone (~100 us per block step: two launches);
+        // GAUSS_CHAIN_ASIDE = 0 never, 2 always (tests), 1 (default) by this estimate.
         const int mode = env_int("GAUSS_CHAIN_ASIDE", 1);
         bool genes = false;
         double b21_len = 0.0;
         for (const ItemH& h : items) if (!is_b11(h)) b21_len += (double)h.len;
         for (int i = 0; i < job->n; i++) genes = genes || job->plans[i].p.n_gene > 0;
-        const double t_b21 = b21_len * 2.0 * TILE * TILE / 120e12, t_chain = 55e-6 * job->max_nblk;
+        const double t_b21 = b21_len * 2.0 * TILE * TILE / 120e12, t_chain = 0.5e-3 + 100e-6 * job->max_nblk;
         job->chain_aside = !streamed && mode != 0 && !panelmap.empty() && !tilemap_b21.empty() && !genes && job->ctx->chain &&
-                           job->ctx->side && (mode == 2 || t_b21 >= 1.5 * t_chain);
+                           job->ctx->side && (mode == 2 || t_b21 >= 1.2 * t_chain);
         if (job->chain_aside) {
             std::stable_sort(items.begin(), items.end(), [&](const ItemH& a, const ItemH& b) { return is_b11(a) && !is_b11(b); });
             for (const ItemH& h : items) job->n_items_b11 += is_b11(h) ? 1 : 0;

@@ -99,7 +99,9 @@ def balance_windows(mu, n_samples, world_size, granule=64):
 
 # One block step (64 measured SNPs) of a job's factorisation chain in piece_cost units: the chain is as long as the
 # job's tallest window and latency-bound on small jobs (measured on MI355X: 19 us per step against 8.06 ms per 1e12
-# cost units, bench.py --emulate-world fits)
+# cost units, bench.py --emulate-world fits).  Round 3: with the chain hidden under the Gram kernel (k_solve_lite.hip) the term no longer
+# describes time on the critical path of a large share, but 0, 6e8 and 2.4e9 give the same emulated 8-rank efficiency (0.883-0.891:
+# the ranks' times differ by +-2 % for reasons no flop count explains -- the last round of each rank's Gram launches), so it stays.
 CHAIN_STEP_COST = 2.4e9
 
 
