@@ -737,8 +737,9 @@ def test_chain_beside_the_gram_kernel_gives_the_same_bits(ctx, monkeypatch):
     wins[4] = dict(wins[4], lam=1e-7)              # no certificate: the exact test factors B11 - eps I as well
     wins[0] = dict(wins[0], lam=0.0)               # singular: status says clamp, the host reruns the window
 
-    def run(aside, share):
-        monkeypatch.setenv("GAUSS_CHAIN_ASIDE", "2" if aside else "0")
+    def run(aside, share, split=False):
+        monkeypatch.setenv("GAUSS_CHAIN_ASIDE", "2" if aside else ("1" if split else "0"))
+        monkeypatch.setenv("GAUSS_GRAM_SPLIT", "1" if split else "0")       # two Gram launches, chain behind them (bench's one-stream pass)
         monkeypatch.setenv("GAUSS_SHARE_MEASURED", "1" if share else "0")
         job = hotpath.Job(wins, ctx=ctx, on_device=True, want_mats=True)
         job.run()
@@ -754,12 +755,12 @@ def test_chain_beside_the_gram_kernel_gives_the_same_bits(ctx, monkeypatch):
 
     for share in (False, True):
         behind = run(False, share)
-        beside = run(True, share)
         assert any(r["status"] != 0 for r in behind)
-        for k, (x, y) in enumerate(zip(behind, beside)):
-            for key in x:
-                if isinstance(x[key], np.ndarray):
-                    assert np.array_equal(x[key], y[key], equal_nan=True), (share, k, key)
-                else:
-                    assert x[key] == y[key], (share, k, key)
+        for other in (run(True, share), run(False, share, split=True)):
+            for k, (x, y) in enumerate(zip(behind, other)):
+                for key in x:
+                    if isinstance(x[key], np.ndarray):
+                        assert np.array_equal(x[key], y[key], equal_nan=True), (share, k, key)
+                    else:
+                        assert x[key] == y[key], (share, k, key)
     store.close()
