@@ -516,6 +516,11 @@ def run_impute(args, rig):
                           "small-footprint chain on the chain queue UNDER the second Gram launch (hidden: not part of the step's "
                           "critical path); otherwise ld_epilogue = B11's tiles and B21's run on the side stream beside `factor`",
         }
+        if tails_alone is None and gram_lps > 1:
+            # no stand-alone pass (N > 1), and in the headline run the chain is timed UNDER the Gram kernel: its stage timer says
+            # nothing about the fp64 kernels' own speed
+            out["roofline_solve"] = None
+            out["roofline_solve_note"] = "measured at N = 1 only (a one-stream pass of the same job)"
         out["roofline"].update(pmc_traffic(len(wins) == 36 and len(ch["bp"]) == 100_000 and rig.world == 1))
         if shard_check is not None:
             out["config"]["shards_bit_identical_to_one_rank"] = shard_check
