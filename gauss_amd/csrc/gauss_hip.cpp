@@ -1950,12 +1950,15 @@ struct RowSource2 {
     }
 };
 
+// by_kernel: the staged chunks cross PCIe through launch_h2d_copy (a small-footprint kernel that reads the pinned staging
+// buffer itself) instead of hipMemcpyAsync, which stalls behind any kernel that holds every CU (k_misc.hip): the form for
+// uploads that are meant to run BESIDE compute.
 static int upload_rows(gauss_ctx* ctx, void* d, const RowSource2& src, size_t bytes, hipStream_t stream = nullptr,
-                       const std::function<void(size_t)>& chunk_queued = nullptr)
+                       const std::function<void(size_t)>& chunk_queued = nullptr, bool by_kernel = false)
 {
     const size_t CH = (size_t)32 << 20;
     if (!stream) stream = ctx->stream;
-    if (bytes < 2 * CH && !chunk_queued && src.ptr) { HIPCHK(hipMemcpy(d, src.ptr, bytes, hipMemcpyHostToDevice)); return GAUSS_OK; }
+    if (bytes < 2 * CH && !chunk_queued && src.ptr && stream == ctx->stream) { HIPCHK(hipMemcpy(d, src.ptr, bytes, hipMemcpyHostToDevice)); return GAUSS_OK; }
     void* pin[2] = {nullptr, nullptr};
     hipEvent_t ev[2] = {nullptr, nullptr};
     int rc = GAUSS_OK;
@@ -1987,7 +1990,11 @@ static int upload_rows(gauss_ctx* ctx, void* d, const RowSource2& src, size_t by
         if (!src.copy((uint8_t*)pin[b], off, std::min(per, len))) read_ok = false;
         for (std::thread& x : th) x.join();
         if (!read_ok) { rc = fail(GAUSS_E_INVALID, "row store upload: reading the source failed (short file?)"); break; }
-        if (hipMemcpyAsync((uint8_t*)d + off, pin[b], len, hipMemcpyHostToDevice, stream) != hipSuccess ||
+        hipError_t ce = hipSuccess;
+        const size_t body = (by_kernel && ((uintptr_t)((uint8_t*)d + off) & 15) == 0) ? len / 16 * 16 : 0;
+        if (body) { launch_h2d_copy((uint8_t*)d + off, pin[b], body, stream); ce = hipGetLastError(); }
+        if (ce == hipSuccess && body < len) ce = hipMemcpyAsync((uint8_t*)d + off + body, (uint8_t*)pin[b] + body, len - body, hipMemcpyHostToDevice, stream);
+        if (ce != hipSuccess ||
             hipEventRecord(ev[b], stream) != hipSuccess)
             rc = fail(GAUSS_E_DEVICE, "row store upload: hipMemcpyAsync failed");
         else if (chunk_queued) chunk_queued(off + len);
@@ -2013,6 +2020,45 @@ int gauss_store_upload(gauss_ctx* ctx, const void* host_rows, int64_t bytes, voi
     return GAUSS_OK;
 }
 
+int gauss_store_alloc(gauss_ctx* ctx, int64_t bytes, void** out_device_ptr)
+{
+    if (!ctx || bytes <= 0 || !out_device_ptr) return fail(GAUSS_E_INVALID, "bad arguments to gauss_store_alloc");
+    HIPCHK(hipSetDevice(ctx->device));
+    void* d = nullptr;
+    hipError_t e = ctx_malloc_retry(ctx, &d, (size_t)bytes + 64);      // slack: a row's last dword load may end on the last byte
+    if (e != hipSuccess) return fail(GAUSS_E_NOMEM, "hipMalloc(%lld bytes row store) failed: %s", (long long)bytes, hipGetErrorString(e));
+    { std::lock_guard<std::mutex> lock(ctx->mu); ctx->stores[d] = (size_t)bytes; }
+    *out_device_ptr = d;
+    return GAUSS_OK;
+}
+
+// Bytes [offset, offset + len) of a store made by gauss_store_alloc, from the same offsets of host_rows; returns when they have
+// landed.  The copy travels on the context's upload queue, so whatever the main queue is computing keeps running.
+int gauss_store_fill(gauss_ctx* ctx, void* device_ptr, const void* host_rows, int64_t offset, int64_t len)
+{
+    if (!ctx || !device_ptr || !host_rows || offset < 0 || len < 0) return fail(GAUSS_E_INVALID, "bad arguments to gauss_store_fill");
+    if (len == 0) return GAUSS_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    {
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        auto it = ctx->stores.find(device_ptr);
+        if (it == ctx->stores.end()) return fail(GAUSS_E_INVALID, "gauss_store_fill: not a row store of this context");
+        if ((size_t)(offset + len) > it->second) return fail(GAUSS_E_INVALID, "gauss_store_fill: bytes [%lld, %lld) lie outside the store (%zu bytes)",
+                                                             (long long)offset, (long long)(offset + len), it->second);
+        if (!ctx->upload) {
+            // at least the main queue's priority: a lower one is not dispatched while the Gram grid has workgroups left
+            int lo = 0, hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+            hipError_t e = hipStreamCreateWithPriority(&ctx->upload, hipStreamNonBlocking, hi);
+            if (e != hipSuccess) return fail(GAUSS_E_DEVICE, "gauss_store_fill: %s", hipGetErrorString(e));
+        }
+    }
+    RowSource2 src;
+    src.ptr = (const uint8_t*)host_rows + offset;
+    static const bool by_kernel = env_int("GAUSS_FILL_BY_KERNEL", 1) != 0;
+    return upload_rows(ctx, (uint8_t*)device_ptr + offset, src, (size_t)len, ctx->upload, nullptr, by_kernel);
+}
+
 static int store_upload_async(gauss_ctx* ctx, const RowSource2& src, int64_t bytes, void** out_device_ptr);
 
 int gauss_store_upload_async(gauss_ctx* ctx, const void* host_rows, int64_t bytes, void** out_device_ptr)
@@ -2034,7 +2080,14 @@ int gauss_store_upload_fd_async(gauss_ctx* ctx, int fd, int64_t file_offset, int
 static int store_upload_async(gauss_ctx* ctx, const RowSource2& src, int64_t bytes, void** out_device_ptr)
 {
     HIPCHK(hipSetDevice(ctx->device));
-    if (!ctx->upload) HIPCHK(hipStreamCreateWithFlags(&ctx->upload, hipStreamNonBlocking));
+    {
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        if (!ctx->upload) {
+            int lo = 0, hi = 0;
+            HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            HIPCHK(hipStreamCreateWithPriority(&ctx->upload, hipStreamNonBlocking, hi));       // see gauss_store_fill
+        }
+    }
     void* d = nullptr;
     hipError_t e = ctx_malloc_retry(ctx, &d, (size_t)bytes + 64);
     if (e != hipSuccess) return fail(GAUSS_E_NOMEM, "hipMalloc(%lld bytes row store) failed: %s", (long long)bytes, hipGetErrorString(e));
@@ -2050,13 +2103,15 @@ static int store_upload_async(gauss_ctx* ctx, const RowSource2& src, int64_t byt
     hipStream_t us = ctx->upload;
     u->th = std::thread([ctx, u, src, device, us]() {
         (void)hipSetDevice(device);
+        // a background upload runs beside whatever the context computes: its chunks cross PCIe by kernel (upload_rows)
+        static const bool by_kernel = env_int("GAUSS_FILL_BY_KERNEL", 1) != 0;
         const int rc = upload_rows(ctx, u->d, src, u->bytes, us, [u, us](size_t upto) {
             hipEvent_t ev = nullptr;
             if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, us) != hipSuccess) return;
             std::lock_guard<std::mutex> lock(u->mu);
             u->marks.emplace_back(upto, ev);
             u->cv.notify_all();
-        });
+        }, by_kernel);
         std::lock_guard<std::mutex> lock(u->mu);
         u->rc = rc;
         if (rc) u->err = g_err;

@@ -198,6 +198,7 @@ void launch_solve_last(const Prob* d_probs, const int2* d_panelmap, int n_panels
 void launch_counts(const Prob* d_probs, int prob, int npair, long long* d_out, hipStream_t s);
 void launch_pack2bit(const uint8_t* d_in, long long ld_in, uint8_t* d_out, long long ld_out, int n_snp,
                      const int* d_pop_off, const int* d_blk_off, int n_pop, hipStream_t s);
+void launch_h2d_copy(void* d_dst, const void* pinned_src, size_t bytes, hipStream_t s);
 void launch_synth(uint8_t* d_out, int n_snp, long long ld, const int* d_pop_off, int n_pop,
                   int n_samples, const float* d_thr, const float* d_rho, uint64_t seed,
                   hipStream_t s);

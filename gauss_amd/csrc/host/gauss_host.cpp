@@ -717,7 +717,7 @@ static int auto_pack_mode()
     return e ? (atoi(e) != 0 ? 1 : 0) : -1;
 }
 
-static int panel_make_resident(gauss_ctx* ctx, const std::string& path, void** dev, int64_t* uploaded, bool async = false);
+static int panel_make_resident(gauss_ctx* ctx, const std::string& path, void** dev, int64_t* uploaded, bool async = false, bool reserve_only = false);
 static bool panel_is_resident(gauss_ctx* ctx, const std::string& path, void** dev);
 
 // ------------------------------------------------------------------------------------------
@@ -2021,6 +2021,9 @@ struct ResidentPanel {
     std::shared_ptr<PackedPanel> pk;       // keeps the mapping (and so the file identity) alive
     void* dev = nullptr;
     int64_t bytes = 0;
+    // a store that is filled piece by piece (the chromosome driver's first call on a panel): rows [0, filled) have landed
+    std::shared_ptr<std::mutex> fill_mu;
+    std::shared_ptr<int64_t> filled;
 };
 // Keyed by the context's id, not its address: ids are never reused, so a context created at the address of a destroyed
 // one cannot inherit a stale entry (whose device pointer may even belong to another GPU).  The destroy hook drops a
@@ -2046,15 +2049,42 @@ static std::string file_key(const std::string& path)
     return path + key;
 }
 
+// Rows [0, upto) of a piecewise store are brought up (whole 32 MB pieces, in order); *uploaded += bytes moved now.
+static int panel_fill_to(gauss_ctx* ctx, const ResidentPanel& rp, int64_t upto, int64_t* uploaded)
+{
+    if (!rp.filled) return 0;                                       // uploaded in one go
+    const int64_t piece = (int64_t)32 << 20;
+    upto = std::min(rp.bytes, upto <= 0 ? rp.bytes : (upto + piece - 1) / piece * piece);
+    std::lock_guard<std::mutex> lock(*rp.fill_mu);
+    if (*rp.filled >= upto) return 0;
+    if (gauss_store_fill(ctx, rp.dev, rp.pk->geno(), *rp.filled, upto - *rp.filled) != 0) return herr("%s", gauss_last_error());
+    if (uploaded) *uploaded += upto - *rp.filled;
+    *rp.filled = upto;
+    return 0;
+}
+
 // returns the device pointer of the panel's row 0 (uploading the section on first use); *uploaded = bytes moved now
 // async: the upload is only STARTED (gauss_store_upload_async); readers call gauss_store_wait for the rows they need
-static int panel_make_resident(gauss_ctx* ctx, const std::string& path, void** dev, int64_t* uploaded, bool async)
+// reserve_only: the store is only ALLOCATED; the caller brings the rows up piece by piece (panel_fill_to) ahead of the jobs
+// that read them.  Whoever asks for the panel later without reserve_only gets all of it.
+static int panel_make_resident(gauss_ctx* ctx, const std::string& path, void** dev, int64_t* uploaded, bool async, bool reserve_only)
 {
     if (uploaded) *uploaded = 0;
     const std::pair<uint64_t, std::string> key(gauss_hip_context_id(ctx), file_key(path));
+    ResidentPanel found;
+    bool have = false;
+    {
+        std::lock_guard<std::mutex> lock(g_res_mu);
+        auto it = g_resident.find(key);
+        if (it != g_resident.end()) { found = it->second; have = true; }
+    }
+    if (have) {
+        *dev = found.dev;
+        return reserve_only ? 0 : panel_fill_to(ctx, found, 0, uploaded);
+    }
     std::lock_guard<std::mutex> lock(g_res_mu);
     auto it = g_resident.find(key);
-    if (it != g_resident.end()) { *dev = it->second.dev; return 0; }
+    if (it != g_resident.end()) { *dev = it->second.dev; return 0; }           // (a racing first use: the other caller's mode stands)
     gauss_hip_add_destroy_hook(resident_ctx_destroyed, nullptr);
     std::string err;
     ResidentPanel rp;
@@ -2062,22 +2092,39 @@ static int panel_make_resident(gauss_ctx* ctx, const std::string& path, void** d
     if (!rp.pk) return herr("%s", err.c_str());
     rp.bytes = rp.pk->n_snp() * rp.pk->row_bytes();
     if (rp.bytes <= 0) return herr("packed panel '%s' holds no SNPs", path.c_str());
-    if ((async ? gauss_store_upload_fd_async(ctx, rp.pk->fd(), rp.pk->geno_file_offset(), rp.bytes, &rp.dev)
-               : gauss_store_upload(ctx, rp.pk->geno(), rp.bytes, &rp.dev)) != 0)
+    if (reserve_only) {
+        if (gauss_store_alloc(ctx, rp.bytes, &rp.dev) != 0) return herr("%s", gauss_last_error());
+        rp.fill_mu = std::make_shared<std::mutex>();
+        rp.filled = std::make_shared<int64_t>(0);
+    } else if ((async ? gauss_store_upload_fd_async(ctx, rp.pk->fd(), rp.pk->geno_file_offset(), rp.bytes, &rp.dev)
+                      : gauss_store_upload(ctx, rp.pk->geno(), rp.bytes, &rp.dev)) != 0)
         return herr("%s", gauss_last_error());
-    if (uploaded) *uploaded = rp.bytes;
+    if (uploaded && !reserve_only) *uploaded = rp.bytes;
     *dev = rp.dev;
     g_resident[key] = rp;
     return 0;
 }
 
-static bool panel_is_resident(gauss_ctx* ctx, const std::string& path, void** dev)
+// the entry of a panel that is (being made) resident on this context
+static bool panel_entry(gauss_ctx* ctx, const std::string& path, ResidentPanel& out)
 {
     const std::pair<uint64_t, std::string> key(gauss_hip_context_id(ctx), file_key(path));
     std::lock_guard<std::mutex> lock(g_res_mu);
     auto it = g_resident.find(key);
     if (it == g_resident.end()) return false;
-    *dev = it->second.dev;
+    out = it->second;
+    return true;
+}
+
+static bool panel_is_resident(gauss_ctx* ctx, const std::string& path, void** dev)
+{
+    ResidentPanel rp;
+    if (!panel_entry(ctx, path, rp)) return false;
+    if (rp.filled) {                                  // a store that is still being filled piece by piece is not resident yet
+        std::lock_guard<std::mutex> lock(*rp.fill_mu);
+        if (*rp.filled < rp.bytes) return false;
+    }
+    *dev = rp.dev;
     return true;
 }
 
@@ -2386,16 +2433,41 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
     // travel in panel order, the batches follow the chromosome.  Measured on the chr22 panel, first call of a process:
     // upload, then feeder 108-118 ms; feeder beside the upload (this order) see DESIGN.md; asynchronous upload 105-155 ms
     // (its copy threads and the cold data layer slow each other down more than the overlap gains on 0.8 GB).
+    // Round 3, second form (GAUSS_CHROM_PIECEWISE_UPLOAD=1, off by default; panels sorted by position): the store is only
+    // RESERVED here and this thread brings the rows up piece by piece, always one batch ahead of the GPU -- the rows batch
+    // b + 1 will read (up to the panel row of its last window's end, a binary search) travel while batch b computes (by kernel:
+    // hipMemcpyAsync does not run beside a kernel that holds every CU, k_misc.hip:h2d_copy_kernel); before a batch is queued its
+    // exact top row is checked against what has landed.  Measured on the chr22 panel, first call of a process: 96-103 ms against
+    // 77-86 ms in one go -- the pieces cross PCIe at 55 GB/s beside the Gram kernel, but filling the staging buffers out of the
+    // page cache shares the host's cores with the data layer and the result tables, and that is what the first call waits for.
     void* d_rows = nullptr;
     const int64_t panel_row_bytes = pk->row_bytes();
+    ResidentPanel piecewise;                                       // .filled set: this call fills the store piece by piece
     {
         const int64_t panel_bytes = pk->n_snp() * panel_row_bytes;
         const char* e = getenv("GAUSS_CHROM_ASYNC_UPLOAD");
         const bool async_upload = e ? atoi(e) != 0 : panel_bytes > ((int64_t)4 << 30);
+        const char* ep = getenv("GAUSS_CHROM_PIECEWISE_UPLOAD");
+        const bool reserve_only = !async_upload && (ep ? atoi(ep) != 0 : false) && pk->header().sorted && chr > 0;
         const double tu = now_s();
-        if (!mine.empty() && panel_make_resident(ctx, reference_data_file, &d_rows, &st.panel_bytes_uploaded, async_upload)) rc_upload = -1;
+        if (!mine.empty() && panel_make_resident(ctx, reference_data_file, &d_rows, &st.panel_bytes_uploaded, async_upload, reserve_only)) rc_upload = -1;
+        if (!rc_upload && reserve_only && panel_entry(ctx, reference_data_file, piecewise) && !piecewise.filled) piecewise = ResidentPanel();
         st.t_panel_upload = now_s() - tu;
     }
+    // rows [0, fill_est(b)) cover every SNP up to the end of batch b's last window (with its wing)
+    auto fill_est = [&](int b) -> int64_t {
+        int64_t e_bp = 0;
+        for (int k : batches[(size_t)b]) e_bp = std::max<int64_t>(e_bp, wins[(size_t)k].e + wing_size);
+        return pk->lower_bound(chr, e_bp + 1) * panel_row_bytes;
+    };
+    auto fill_to = [&](int64_t upto) -> int {
+        if (!piecewise.filled) return 0;
+        const double tu = now_s();
+        const int rc = panel_fill_to(ctx, piecewise, upto, &st.panel_bytes_uploaded);
+        st.t_panel_upload += now_s() - tu;
+        return rc;
+    };
+    if (!rc_upload && n_batches > 0 && fill_to(fill_est(0)) != 0) rc_upload = -1;
 
     // ---- GPU pipeline ----
     std::vector<gauss_job*> jobs((size_t)n_batches, nullptr);
@@ -2488,6 +2560,7 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
                 const double tu = now_s();
                 if (gauss_store_wait(ctx, d_rows, (top + 1) * panel_row_bytes) != 0) { herr("%s", gauss_last_error()); rc_fatal = -1; break; }
                 st.t_panel_upload += now_s() - tu;
+                if (fill_to((top + 1) * panel_row_bytes) != 0) { rc_fatal = -1; break; }      // (already there unless the estimate fell short)
             }
             double tc = now_s();
             if (gauss_job_create(ctx, descs.data(), (int)descs.size(), 1, &jobs[b]) != 0 || gauss_job_run(jobs[b]) != 0) {
@@ -2506,6 +2579,8 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
             }
             st.t_job_create += now_s() - tc;
         }
+        // the next batch's rows travel while this one computes
+        if (b + 1 < n_batches && fill_to(fill_est(b + 1)) != 0) { rc_fatal = -1; break; }
         if (b > 0) retire(b - 1);
     }
     if (!rc_fatal && n_batches > 0) retire(n_batches - 1);
@@ -2519,6 +2594,7 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
     // whoever finds this panel resident later (another study, an LD call on rows this chromosome never touched) must
     // find all of it: the upload is complete before the call returns
     if (d_rows && gauss_store_wait(ctx, d_rows, 0) != 0 && !rc_fatal) { herr("%s", gauss_last_error()); rc_fatal = -1; }
+    if (fill_to(0) != 0 && !rc_fatal) rc_fatal = -1;                 // (rows past this chromosome's last window, if any)
     if (rc_fatal) return -1;
 
     // ---- one table, window order (batches were appended as they retired) ----

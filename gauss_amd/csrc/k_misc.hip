@@ -1,6 +1,7 @@
 // Rare-path MakePosDef on the device (one-sided Jacobi eigen-clamp) and the synthetic panel
 // generator used by bench.py.
 #include "gauss_internal.h"
+#include <algorithm>
 
 namespace gauss {
 
@@ -217,6 +218,41 @@ void launch_synth(uint8_t* d_out, int n_snp, long long ld, const int* d_pop_off,
 {
     hipLaunchKernelGGL(synth_kernel, dim3((n_samples + 255) / 256), dim3(256), 0, s, d_out, n_snp, ld, d_pop_off,
                        n_pop, n_samples, d_thr, d_rho, seed);
+}
+
+// ------------------------------------------------------------------------------------------
+// Host -> HBM copy as a small-footprint kernel.  hipMemcpyAsync from pinned memory does NOT run beside a kernel that
+// holds every CU: measured on MI355X (tools/h2d_under_load_probe.py), 256 MB take 4.7 ms with the chip idle (56 GB/s) and
+// 40 ms -- the rest of the step -- while the Gram kernel runs, whatever the stream, its priority or the number of
+// hardware queues.  Pinned host memory is mapped into the device's address space, so a kernel can read it over PCIe
+// itself; one of 256 threads, a handful of registers and no LDS fits into what the Gram kernel's workgroups leave free
+// on every CU (k_solve_lite.hip) and moves the same 256 MB in 4.8 ms (55 GB/s) alone AND beside the Gram kernel.
+// ------------------------------------------------------------------------------------------
+typedef uint32_t h2d_u32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void h2d_copy_kernel(const h2d_u32x4* __restrict__ src, h2d_u32x4* __restrict__ dst, size_t n16)
+{
+    __builtin_amdgcn_s_setprio(3);
+    constexpr int UN = 4;
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + (UN - 1) * stride < n16; i += UN * stride) {
+        h2d_u32x4 v[UN];
+#pragma unroll
+        for (int u = 0; u < UN; u++) v[u] = __builtin_nontemporal_load(src + i + u * stride);
+#pragma unroll
+        for (int u = 0; u < UN; u++) dst[i + u * stride] = v[u];
+    }
+    for (; i < n16; i += stride) dst[i] = __builtin_nontemporal_load(src + i);
+}
+
+// bytes: a multiple of 16; both pointers 16-byte aligned; pinned_src from hipHostMalloc (device-visible)
+void launch_h2d_copy(void* d_dst, const void* pinned_src, size_t bytes, hipStream_t s)
+{
+    if (bytes < 16) return;
+    const size_t n16 = bytes / 16;
+    const int n_wg = (int)std::min<size_t>(512, (n16 + 255) / 256);
+    hipLaunchKernelGGL(h2d_copy_kernel, dim3(n_wg), dim3(256), 0, s, (const h2d_u32x4*)pinned_src, (h2d_u32x4*)d_dst, n16);
 }
 
 }  // namespace gauss

@@ -346,19 +346,28 @@ class RowStore:
     """Genotype rows resident in HBM (gauss_store_upload): a whole packed chromosome is uploaded once and
     windows name their rows by index."""
 
-    def __init__(self, rows, ctx=None, asynchronous=False):
+    def __init__(self, rows, ctx=None, asynchronous=False, reserve_only=False):
         """asynchronous: gauss_store_upload_async -- the rows travel in the background (keep `rows` alive until
-        wait() has returned); wait(n_rows) makes the context's stream wait for the first n_rows rows."""
+        wait() has returned); wait(n_rows) makes the context's stream wait for the first n_rows rows.
+        reserve_only: gauss_store_alloc -- the store is only reserved; fill(r0, r1) brings rows [r0, r1) up (gauss_store_fill)."""
         self.ctx = ctx or default_context()
         rows = np.ascontiguousarray(rows, dtype=np.uint8)
         self.n_rows, self.ld = rows.shape
         p = C.c_void_p()
-        if asynchronous:
+        if reserve_only:
+            self._host = rows
+            check(self.ctx.lib.gauss_store_alloc(self.ctx.handle, rows.nbytes, C.byref(p)))
+        elif asynchronous:
             self._host = rows
             check(self.ctx.lib.gauss_store_upload_async(self.ctx.handle, rows.ctypes.data_as(C.c_void_p), rows.nbytes, C.byref(p)))
         else:
             check(self.ctx.lib.gauss_store_upload(self.ctx.handle, rows.ctypes.data_as(C.c_void_p), rows.nbytes, C.byref(p)))
         self.ptr = p.value
+
+    def fill(self, r0, r1):
+        """Rows [r0, r1) of a reserve_only store travel now (on a queue of their own); returns when they have landed."""
+        check(self.ctx.lib.gauss_store_fill(self.ctx.handle, C.c_void_p(self.ptr), self._host.ctypes.data_as(C.c_void_p),
+                                            int(r0) * self.ld, (int(r1) - int(r0)) * self.ld))
 
     def wait(self, n_rows=0):
         """Rows [0, n_rows) have landed for everything queued on the context afterwards (0: all rows, host waits)."""

@@ -133,6 +133,13 @@ int gauss_pinned_free(gauss_ctx* ctx, void* host_ptr);
  * whole 2-bit panel (33 k samples x 10 M SNPs = 82 GB), so a panel is uploaded once, not per window. */
 int gauss_store_upload(gauss_ctx* ctx, const void* host_rows, int64_t bytes, void** out_device_ptr);
 int gauss_store_free(gauss_ctx* ctx, void* device_ptr);
+/* The same store filled piece by piece: gauss_store_alloc reserves `bytes` on the GPU (contents undefined until filled) and
+ * gauss_store_fill copies host_rows[offset .. offset + len) to the same offsets of the store, returning when they have landed.
+ * The copy travels through the pinned double buffers on a queue of its own, so whatever the context's other queues are
+ * computing keeps running: a driver that walks a chromosome fills the rows of batch k + 1 while batch k computes
+ * (gauss_host_impute_chromosome on a panel that is not resident yet).  A job may only name rows that have been filled. */
+int gauss_store_alloc(gauss_ctx* ctx, int64_t bytes, void** out_device_ptr);
+int gauss_store_fill(gauss_ctx* ctx, void* device_ptr, const void* host_rows, int64_t offset, int64_t len);
 /* The same upload without waiting for it: returns at once with the device pointer; a library thread streams the rows
  * IN ORDER (pinned double buffers, a stream of its own).  host_rows must stay valid until the upload is complete.
  * gauss_store_wait(ctx, ptr, n) makes the context's main stream wait until the first n bytes have landed -- a job queued

@@ -145,6 +145,22 @@ def test_asynchronous_row_store_upload(ctx):
     st.close()
     for a, b in ((got_lo, want_lo), (got_hi, want_hi)):
         assert np.array_equal(a["z"], b["z"]) and np.array_equal(a["info"], b["info"])
+    # the same store reserved and filled piece by piece (gauss_store_alloc / gauss_store_fill: the chromosome driver's first
+    # call on a panel brings the rows of batch k + 1 up while batch k computes): a job over the first rows runs while a later
+    # piece is still to come; pieces of less than a staging chunk, of several chunks, and an empty one
+    pw = hotpath.RowStore(rows, ctx=ctx, reserve_only=True)
+    pw.fill(0, 700)
+    job_lo = job_over(pw, 0)
+    pw.fill(700, 700)
+    pw.fill(700, n_snp - 9000)
+    pw.fill(n_snp - 9000, n_snp)
+    job_hi = job_over(pw, n_snp - 512)
+    with pytest.raises(Exception) as ei:
+        pw.fill(n_snp - 10, n_snp + 1)
+    assert "outside the store" in str(ei.value)
+    pw.close()
+    for a, b in ((job_lo, want_lo), (job_hi, want_hi)):
+        assert np.array_equal(a["z"], b["z"]) and np.array_equal(a["info"], b["info"])
     busy = hotpath.RowStore(rows, ctx=ctx, asynchronous=True)
     busy.close()                                   # freed while the upload may still be running: it is finished first
 
