@@ -20,6 +20,11 @@
 // All block products run on v_mfma_f64_16x16x4_f64 (one f64 A and one f64 B value per lane; result
 // rows (lane>>4) + 4*reg, column lane&15).  A workgroup is 4 waves; wave w owns rows 16w..16w+15
 // of a 64-row block.
+//
+// The factorisation kernels of this file have small-footprint twins in k_solve_lite.hip (same arithmetic, same bits,
+// 23 KB of LDS and <= 96 registers) that run BESIDE the Gram kernel on jobs large enough to hide them; what the two
+// families share lives in k_solve_common.h.  These are the forms with the chip to themselves: single windows, the clamp
+// path's redo, GAUSS_CHAIN_ASIDE=0.
 #include "gauss_internal.h"
 #include "k_solve_common.h"
 #include <algorithm>

@@ -183,7 +183,7 @@ int gauss_hip_add_destroy_hook(void (*fn)(gauss_ctx* ctx, uint64_t id, void* use
 int gauss_hip_trim_cache(gauss_ctx* ctx, int64_t* out_bytes_freed);
 const char* gauss_last_error(void);
 const char* gauss_hip_version(void);
-/* Hash of the sources this library was built from (gauss_amd/build.py:source_hash): profiles/*_provenance.json record it,
+/* Hash of the sources this library was built from (gauss_amd/build.py:source_hash): profiles/<tag>_provenance.json record it,
  * and bench.py only quotes a profile-derived figure (roofline.traffic) when it matches. */
 const char* gauss_hip_source_hash(void);
 
