@@ -1226,7 +1226,8 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
         it.seg_k1 = p.seg_k1 + gr.first;
         it.chunk_half = (const uint32_t*)(job->d_tab + to[h.prob].ch);
         it.Kp = p.Kp; it.k0 = pl.seg_k0[gr.first]; it.nseg = gr.second - gr.first;
-        it.rows_a = rows(ti); it.rows_b = rows(tj); it.flags = (ti == tj ? 1 : 0) | (p.slab16 ? 2 : 0);
+        static const int no_edge16 = env_int("GAUSS_GRAM_EDGE16", 1) == 0 ? 8 : 0;
+        it.rows_a = rows(ti); it.rows_b = rows(tj); it.flags = (ti == tj ? 1 : 0) | (p.slab16 ? 2 : 0) | no_edge16;
         memcpy(blob.data() + o_items + sizeof(Item) * n, &it, sizeof(Item));
     }
     memcpy(job->h_pin, blob.data(), blob.size());
@@ -2260,6 +2261,7 @@ int gauss_job_stats(gauss_job* job, double* out4)
     if (!job || !out4) return fail(GAUSS_E_INVALID, "bad arguments");
     double flops = 0, slab = 0;
     const bool shm = job->gplan != nullptr;
+    const bool edge16 = env_int("GAUSS_GRAM_EDGE16", 1) != 0;
     auto add = [&](const Plan& pl, bool skip_b11) {
         const Prob& p = pl.p;
         const int mt = p.Mp / TILE;
@@ -2274,7 +2276,13 @@ int gauss_job_stats(gauss_job* job, double* out4)
             for (int wr = 0; wr < 2; wr++)
                 for (int wc = 0; wc < 2; wc++) {
                     if (ti == tj && wr == 1 && wc == 0) continue;
-                    double t32 = halves(rows(ti), wr) * halves(rows(tj), wc);
+                    const int na = halves(rows(ti), wr);
+                    // f32 path: a wave whose last live 32-column half holds at most 16 live columns multiplies 16-column groups
+                    // (k_gram.hip, chunk_mfma_edge): 1 or 3 of them
+                    int nb16 = (rows(tj) - wc * 64 + 15) / 16;
+                    nb16 = nb16 < 0 ? 0 : (nb16 > 4 ? 4 : nb16);
+                    if (edge16 && !job->gram_i8 && na > 0 && (nb16 & 1)) { tiles32 += na * nb16 * 0.5; continue; }
+                    double t32 = na * halves(rows(tj), wc);
                     if (ti == tj && wr == wc && t32 == 4) t32 = 3;      // mirrored 32 x 32 sub-block of a diagonal quadrant
                     tiles32 += t32;
                 }

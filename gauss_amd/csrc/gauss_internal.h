@@ -132,7 +132,8 @@ struct Item {
     int k0;                  // first column of the run
     int nseg;                // segments in the run
     int rows_a, rows_b;      // live rows of the two tiles (the rest is zero padding)
-    int flags;               // bit 0: ti == tj (diagonal tile); bit 1: slabs are uint16 pairs (Prob::slab16)
+    int flags;               // bit 0: ti == tj (diagonal tile); bit 1: slabs are uint16 pairs (Prob::slab16); bit 3: no 16-column
+                             // edge routine (GAUSS_GRAM_EDGE16=0: every live 32-column half takes the 32 x 32 MFMA)
 };
 static_assert(sizeof(Item) == 64, "work items are fetched as one 64-byte descriptor");
 

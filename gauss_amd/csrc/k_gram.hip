@@ -24,6 +24,11 @@
 #include "gauss_internal.h"
 #include "k_gram_common.h"
 #include <cstdlib>
+#include <type_traits>
+
+#ifndef GAUSS_GRAM_EDGE16
+#define GAUSS_GRAM_EDGE16 1
+#endif
 
 namespace gauss {
 
@@ -118,6 +123,76 @@ __device__ __forceinline__ void chunk_mfma(const uint8_t* __restrict__ la, const
     }
 }
 
+// ---- 16-column edge (f32 path) -------------------------------------------------------------------------------------
+// A tile's live B rows (= output columns: a window's measured SNPs) are rounded up to 32 by the 32 x 32 MFMA; on the real
+// chr22 windows that rounding is 2 % of the issued flops.  A wave whose last live 32-column half holds at most 16 live
+// columns -- 1 or 3 live groups of 16 among its 64 columns -- multiplies all its columns with v_mfma_f32_16x16x4_f32
+// instead: NC groups of 16 columns against the wave's 2 NA groups of 16 A rows, the same matrix-pipe time per flop and no
+// work on the dead group.  Operand layout of that instruction (tools/mfma16_layout_probe.hip):
+// lane l supplies A[row l % 16][k = l / 16] and B[k = l / 16][column l % 16] and holds D[row 4 (l / 16) + reg][column l % 16].
+// Lane (r, q) therefore reads piece q (16 samples) of row r of the chunk image -- one ds_read_b128 per 16-row group covers
+// the chunk's 64 samples across the four lane groups -- and MFMA j of the chunk consumes byte j of every lane's 16.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int NA, int NC>
+__device__ __forceinline__ void chunk_mfma_edge(const uint8_t* __restrict__ la, const uint8_t* __restrict__ lb, int eoffa,
+                                                int eoffb, f32x4 (&acce)[4][NC])
+{
+    // (the B words are converted again for every A group: keeping the converted pairs would take the kernel past the 104
+    // registers that leave room for a fifth, small-footprint workgroup per CU -- k_solve_lite.hip)
+    uint32_t b[NC][4];
+#pragma unroll
+    for (int nc = 0; nc < NC; nc++) {
+        const u32x4 bw = *reinterpret_cast<const u32x4*>(lb + eoffb + nc * 16 * LROW);
+        b[nc][0] = bw.x; b[nc][1] = bw.y; b[nc][2] = bw.z; b[nc][3] = bw.w;
+    }
+#pragma unroll
+    for (int ga = 0; ga < 2 * NA; ga++) {
+        const u32x4 aw = *reinterpret_cast<const u32x4*>(la + eoffa + ga * 16 * LROW);      // the next 16 rows: same swizzle
+        const uint32_t a[4] = {aw.x, aw.y, aw.z, aw.w};
+        if (NC > 1) {
+            // the B words pass through an empty asm per A group, or the compiler recognises the conversions of one group in the
+            // next (common subexpressions) and keeps all 8 NC converted pairs alive: 48 registers at NC = 3
+#pragma unroll
+            for (int nc = 0; nc < NC; nc++) asm volatile("" : "+v"(b[nc][0]), "+v"(b[nc][1]), "+v"(b[nc][2]), "+v"(b[nc][3]));
+        }
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+#pragma unroll
+            for (int hi = 0; hi < 2; hi++) {
+                const f32x2 fa = hi ? __builtin_amdgcn_cvt_pk_f32_fp8((int)a[w], true) : __builtin_amdgcn_cvt_pk_f32_fp8((int)a[w], false);
+#pragma unroll
+                for (int nc = 0; nc < NC; nc++) {
+                    const f32x2 fb = hi ? __builtin_amdgcn_cvt_pk_f32_fp8((int)b[nc][w], true) : __builtin_amdgcn_cvt_pk_f32_fp8((int)b[nc][w], false);
+#pragma unroll
+                    for (int e = 0; e < 2; e++) acce[ga][nc] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[e], fb[e], acce[ga][nc], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);       // one word's conversions at a time (left alone the compiler converts everything first)
+        }
+    }
+}
+
+// the edge accumulators of a segment to its slab: rows erow0 + 16 ga + reg (erow0 = wr * 64 + 4 (lane / 16)), columns
+// ecol0 + 16 nc (ecol0 = wc * 64 + lane % 16)
+template <int NA, int NC, typename OUT>
+__device__ __forceinline__ void flush_edge(OUT out, bool slab16, int erow0, int ecol0, const f32x4 (&acce)[4][NC])
+{
+#pragma unroll
+    for (int ga = 0; ga < 2 * NA; ga++)
+#pragma unroll
+        for (int nc = 0; nc < NC; nc++) {
+            const int row = erow0 + 16 * ga, col = ecol0 + 16 * nc;
+            if (slab16) {
+                out[(row >> 1) * TILE + col] = slab_pair(slab_u(acce[ga][nc][0]), slab_u(acce[ga][nc][1]));
+                out[((row >> 1) + 1) * TILE + col] = slab_pair(slab_u(acce[ga][nc][2]), slab_u(acce[ga][nc][3]));
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; r++) out[(row + r) * TILE + col] = slab_bits(acce[ga][nc][r]);
+            }
+        }
+}
+
 // One work item for a wave with NA x NB live 32-row halves (NA = 0: staging and barriers only).
 // The K loop runs over the whole run of segments without draining the prefetch pipeline; at each
 // segment end the accumulators are flushed to that segment's slab and cleared.
@@ -138,7 +213,9 @@ __device__ __forceinline__ void wait_dma_barrier_dyn(int groups_newer)
     else wait_dma_barrier<8>();
 }
 
-template <int NA, int NB, typename ACC, int NS, bool SK10 = false>
+// NC > 0 (f32 only, then NB = 0): the wave's live B rows are NC groups of 16 with the last one at most half a 32-row half --
+// 1 or 3 groups -- and all of them go through chunk_mfma_edge.
+template <int NA, int NB, typename ACC, int NS, bool SK10 = false, int NC = 0>
 __device__ __forceinline__ void run_item(const Item& it, uint8_t* lds, int wr, int wc)
 {
     const int Kp = it.Kp;
@@ -202,6 +279,22 @@ __device__ __forceinline__ void run_item(const Item& it, uint8_t* lds, int wr, i
         boff[g] = (wc * 64 + li) * LROW + 16 * ((2 * g + lh) ^ sw);
     }
 
+    // 16-column edge: fragment offsets in the (row lane % 16, piece lane / 16) layout, and where its results go
+    constexpr bool BE = NC > 0;
+    f32x4 acce[4][BE ? NC : 1];
+    int eoffa = 0, eoffb = 0, erow0 = 0, ecol0 = 0;
+    if (BE) {
+        const int r16 = lane & 15, q16 = lane >> 4, sw16 = (r16 >> 2) & 3;
+#pragma unroll
+        for (int ga = 0; ga < 4; ga++)
+#pragma unroll
+            for (int nc = 0; nc < (BE ? NC : 1); nc++) acce[ga][nc] = f32x4{0.f, 0.f, 0.f, 0.f};
+        eoffa = (wr * 64 + r16) * LROW + 16 * (q16 ^ sw16);
+        eoffb = (wc * 64 + r16) * LROW + 16 * (q16 ^ sw16);
+        erow0 = wr * 64 + 4 * q16;
+        ecol0 = wc * 64 + r16;
+    }
+
     int k = k0;
     uint32_t hbits = uniform_load<uint32_t>(half_bits, k0 >> 11);       // half-chunk flags, 32 chunks per dword
     bool half_next = (hbits >> ((k0 >> 6) & 31)) & 1u;
@@ -225,7 +318,8 @@ __device__ __forceinline__ void run_item(const Item& it, uint8_t* lds, int wr, i
                 if ((c1 & 31) == 0) hbits = uniform_load<uint32_t>(half_bits, c1 >> 5);      // scalar load, once per 32 chunks
                 half_next = (hbits >> (c1 & 31)) & 1u;
             }
-            if (NA > 0) chunk_mfma<NA, NB, SK10>(la, lb, aoff, boff, acc00, acc01, acc10, acc11, half);
+            if (NA > 0 && NB > 0) chunk_mfma<NA, (NB > 0 ? NB : 1), SK10>(la, lb, aoff, boff, acc00, acc01, acc10, acc11, half);
+            if (BE) chunk_mfma_edge<(NA > 0 ? NA : 1), (BE ? NC : 1)>(la, lb, eoffa, eoffb, acce);
             wait_dma_barrier_dyn<NS>(ahead - 1);         // next chunk landed; everyone is done reading this one
             if (ahead > 0) ahead--;
             cur = (cur + 1 == NS) ? 0 : cur + 1;
@@ -233,17 +327,29 @@ __device__ __forceinline__ void run_item(const Item& it, uint8_t* lds, int wr, i
 #undef GAUSS_STAGE
         // end of a segment: flush its exact partial sums, start the next segment from zero.
         // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-        if (NA > 0) {
-            flush_acc<NA, NB, SK10>(out, (it.flags & 2) != 0, obase, obase16, acc00, acc01, acc10, acc11);
+        if (NA > 0 && NB > 0) {
+            flush_acc<NA, (NB > 0 ? NB : 1), SK10>(out, (it.flags & 2) != 0, obase, obase16, acc00, acc01, acc10, acc11);
 #pragma unroll
             for (int r = 0; r < 16; r++) { acc00[r] = 0; acc01[r] = 0; acc10[r] = 0; acc11[r] = 0; }
+        }
+        if (BE) {
+            // (the store addresses are formed here, not ahead of the K loop: twelve 64-bit pointers held across it would spill)
+            int er = erow0, ec = ecol0;
+            asm volatile("" : "+v"(er), "+v"(ec));
+            flush_edge<(NA > 0 ? NA : 1), (BE ? NC : 1)>(out, (it.flags & 2) != 0, er, ec, acce);
+#pragma unroll
+            for (int ga = 0; ga < 4; ga++)
+#pragma unroll
+                for (int nc = 0; nc < (BE ? NC : 1); nc++) acce[ga][nc] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         out += (it.flags & 2) ? TILE * TILE / 2 : TILE * TILE;
     }
 }
 
+// 104 registers at most: four workgroups per CU then leave 96 per lane for the small-footprint kernels that run beside this one
+// (k_solve_lite.hip); the common paths need 104, the 16-column edge path would take 107 if left alone.
 template <typename ACC, int NS, int OCC>
-__global__ __launch_bounds__(256, OCC) void gram_kernel(const Item* __restrict__ items)
+__global__ __launch_bounds__(256, OCC) __attribute__((amdgpu_num_vgpr(52))) void gram_kernel(const Item* __restrict__ items)
 {
     __shared__ __attribute__((aligned(16))) uint8_t lds[NS * 2 * LTILE];
 
@@ -259,6 +365,16 @@ __global__ __launch_bounds__(256, OCC) void gram_kernel(const Item* __restrict__
     // diagonal tile: the lower-left 64 x 64 quadrant mirrors the upper-right one and is never read
     const bool diag = (it.flags & 1) != 0;
     if (diag && wr == 1 && wc == 0) na = 0;
+    // f32 path: a last half of at most 16 live B rows goes to the 16-column edge routine (GAUSS_GRAM_EDGE16 compiled in)
+    if (std::is_same<ACC, f32x16>::value && GAUSS_GRAM_EDGE16 && na > 0 && !(it.flags & 8)) {
+        int nb16 = (it.rows_b - wc * 64 + 15) / 16;
+        nb16 = nb16 < 0 ? 0 : (nb16 > 4 ? 4 : nb16);
+        if (nb16 & 1) {
+            if (nb16 == 3) { if (na == 2) run_item<2, 0, ACC, NS, false, 3>(it, lds, wr, wc); else run_item<1, 0, ACC, NS, false, 3>(it, lds, wr, wc); }
+            else { if (na == 2) run_item<2, 0, ACC, NS, false, 1>(it, lds, wr, wc); else run_item<1, 0, ACC, NS, false, 1>(it, lds, wr, wc); }
+            return;
+        }
+    }
     if (na == 0 || nb == 0) run_item<0, 0, ACC, NS>(it, lds, wr, wc);
     else if (na == 2 && nb == 2 && diag && wr == wc) run_item<2, 2, ACC, NS, true>(it, lds, wr, wc);
     else if (na == 2 && nb == 2) run_item<2, 2, ACC, NS>(it, lds, wr, wc);

@@ -495,3 +495,44 @@ def test_tail_accuracy_level_against_the_oracle(ctx, mode):
         want = oracle.run_impute(mode, gm, gu, p["off"], p["w"], z1)
         assert np.max(np.abs(got["z"] - want["z"]) / np.maximum(1.0, np.abs(want["z"]))) <= 1e-12, M
         assert relerr(got["info"], want["info"]) <= 1e-12, M
+
+
+@pytest.mark.gpu
+def test_sixteen_column_edge_of_the_gram_kernel(ctx):
+    """A wave of the f32 Gram kernel whose last live 32-column half holds at most 16 live columns multiplies its columns with
+    v_mfma_f32_16x16x4_f32 (k_gram.hip, chunk_mfma_edge): row counts on both sides of every 16 / 32 / 64 / 128 boundary give the
+    oracle's integers (f32 slabs: one-byte codes up to 15), and windows over a 2-bit store (16-bit slabs) with such M give the
+    bits of the int8 path, which has no edge routine."""
+    from gauss_amd import panel as panel_mod
+    rng = np.random.default_rng(77)
+    N = 700
+    for S in (1, 9, 16, 17, 31, 33, 40, 48, 49, 64, 65, 77, 80, 81, 97, 112, 113, 129, 140, 144, 145, 161, 176, 177, 200, 209):
+        G = rng.integers(0, 16 if S % 2 else 3, size=(S, N)).astype(np.uint8)
+        want = G.astype(np.int64) @ G.astype(np.int64).T
+        assert np.array_equal(hotpath.gram_counts(G, ctx=ctx), want), S
+    p = small_panel(n_snp=900, scale=0.04, seed=13)
+    rows2, src_off = panel_mod.pack2bit(p["G"], p["off"])
+    store = hotpath.RowStore(rows2, ctx=ctx)
+    wins = []
+    for k, M in enumerate((7, 16, 17, 40, 47, 73, 80, 100, 139, 145, 176, 205)):
+        mi = np.arange(k, k + 2 * M, 2, dtype=np.int32)
+        ui = np.arange(k + 1, k + 1 + 2 * 150, 2, dtype=np.int32)
+        wins.append(dict(mode=k % 2, pop_off=p["off"], pop_wgt=p["w"], z1=rng.standard_normal(M), dev=(store.ptr, store.ptr, M, len(ui), store.ld),
+                         packed=dict(fmt=1, rows_m=mi, rows_u=ui, pop_src_off=src_off)))
+    out = {}
+    try:
+        for dt in ("f32", "i8"):
+            ctx.set_gram_dtype(dt)
+            res = []
+            for grp in (wins[0::2], wins[1::2]):                 # one mode per job
+                job = hotpath.Job(grp, ctx=ctx, on_device=True, want_mats=True)
+                job.run()
+                res += job.fetch()
+                job.close()
+            out[dt] = res
+    finally:
+        ctx.set_gram_dtype("f32")
+    for a, b in zip(out["f32"], out["i8"]):
+        for key in ("z", "info", "b11", "b21"):
+            assert np.array_equal(a[key], b[key], equal_nan=True), key
+    store.close()
