@@ -1,7 +1,7 @@
 """Boil the rocprofv3 output of tools/collect_profiles.sh down to the small CSVs kept under profiles/.
 
 usage: summarize_profiles.py <tag> <dir>     (dir = gpurun_out/prof_<tag>)
-Writes <dir>/summary/{tag}_kernel_stats.csv, {tag}_pmc_traffic.csv, {tag}_sq_mfma.csv, {tag}_bench_under_rocprof.json and
+Writes <dir>/summary/{tag}_kernel_stats.csv, {tag}_pmc_traffic.csv, {tag}_sq_mfma.csv, {tag}_step_timeline.txt, {tag}_bench_under_rocprof.json and
 {tag}_provenance.json (source hash + git head of the profiled code);
 copy those into profiles/ (tracked)."""
 import csv
@@ -139,6 +139,17 @@ def main():
             # gfx950: FETCH_SIZE under-counts wide coalesced reads by 2x (MI355X_MICROARCH.md, HBM section)
             fh.write(f"{k},{max(len(fetch[k]), len(write[k]))},{fa:.1f},{wa:.1f},{int((2 * fa + wa) * 1024)},{stamp.get('csrc_hash') or ''}\n")
     sq_mfma(tag, d, out)
+    # one step of the headline run, kernel by kernel and queue by queue (what runs under the second Gram launch)
+    try:
+        import subprocess
+        tl = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "step_timeline.py"),
+                             os.path.join(d, "stats"), "8"], capture_output=True, text=True, timeout=120)
+        if tl.returncode == 0 and tl.stdout.strip():
+            with open(os.path.join(out, f"{tag}_step_timeline.txt"), "w") as fh:
+                fh.write("# one step of the --kernel-trace run (tools/step_timeline.py): start / end per kernel and hardware queue, ms from the step's first launch\n")
+                fh.write(tl.stdout)
+    except Exception:
+        pass
     print("summaries in", out, os.listdir(out))
 
 
