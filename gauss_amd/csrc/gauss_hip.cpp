@@ -882,7 +882,8 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
         double b21_len = 0.0;
         for (const ItemH& h : items) if (!is_b11(h)) b21_len += (double)h.len;
         for (int i = 0; i < job->n; i++) genes = genes || job->plans[i].p.n_gene > 0;
-        const double t_b21 = b21_len * 2.0 * TILE * TILE / 120e12, t_chain = 0.5e-3 + 100e-6 * job->max_nblk;
+        // (the int8 Gram kernel is ~8 x faster: an 8-rank share's B21 launch, 0.5 ms, no longer covers its chain)
+        const double t_b21 = b21_len * 2.0 * TILE * TILE / (job->gram_i8 ? 960e12 : 120e12), t_chain = 0.5e-3 + 100e-6 * job->max_nblk;
         job->chain_aside = !streamed && mode != 0 && !panelmap.empty() && !tilemap_b21.empty() && !genes && job->ctx->chain &&
                            job->ctx->side && (mode == 2 || t_b21 >= 1.2 * t_chain);
         // (GAUSS_GRAM_SPLIT=1: the two-launch form of the Gram kernel without the chain beside it -- bench.py's one-stream pass,
