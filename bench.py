@@ -68,9 +68,12 @@ def parse_args(argv=None):
     ap.add_argument("--verify-shards", action="store_true",
                     help="N > 1, strong: rank 0 also runs every window itself and checks the ranks' z / info bit for bit")
     ap.add_argument("--no-e2e", action="store_true", help="N = 1: skip the end_to_end block (files on disk -> result table)")
-    ap.add_argument("--emulate-world", type=int, default=0,
-                    help="single GPU: time every rank's LPT share of an N-rank strong-scaling run one after the other "
-                         "(what one rank of N would do per step); printed as `emulated_strong_scaling`, never as `value`")
+    ap.add_argument("--emulate-world", type=int, default=-1,
+                    help="single GPU: time every rank's share of an N-rank strong-scaling run one after the other "
+                         "(what one rank of N would do per step); printed as `emulated_strong_scaling`, never as `value`.  "
+                         "Default (-1): 8 on the whole-chromosome N = 1 run, with at most --emulate-steps steps per share; 0 = off")
+    ap.add_argument("--emulate-steps", type=int, default=10, help="timed steps per emulated share (each share also gets 3 warm-up steps)")
+    ap.add_argument("--no-parity-spot", action="store_true", help="skip the oracle spot check of the timed job's own results")
     ap.add_argument("--streams", type=int, default=1, help="split a rank's windows over this many contexts (one stream pair each)")
     return ap.parse_args(argv)
 
@@ -291,6 +294,53 @@ def result_digest(res):
             int(sum(int(r["status"] != 0) for r in res)), bool(np.all(np.isfinite(z)) and np.all(np.isfinite(info)))]
 
 
+SPOT_TOL = 1e-8
+
+
+def spot_inputs(torch, panel, wins, n_unmeasured=16, mid_m=330):
+    """Host copies of the genotype rows the parity spot check needs: ALL measured rows and `n_unmeasured` evenly spaced
+    unmeasured rows of the smallest window and of a mid-size one (the window whose measured count is nearest `mid_m`:
+    the oracle's pair loops over it stay under ~2 s at N = 32 147)."""
+    ms = [len(w[1]) for w in wins]
+    k_small = int(np.argmin(ms))
+    k_mid = int(np.argmin([abs(m - mid_m) + (10 ** 9 if k == k_small else 0) for k, m in enumerate(ms)]))
+    out = []
+    for k in sorted({k_small, k_mid}):
+        _, mi, ui = wins[k]
+        sel = np.unique(np.linspace(0, len(ui) - 1, num=min(n_unmeasured, len(ui))).round().astype(np.int64))
+        out.append((k, sel, panel.index_select(0, torch.from_numpy(mi).cuda()).cpu().numpy(),
+                    panel.index_select(0, torch.from_numpy(ui[sel]).cuda()).cpu().numpy()))
+    return out
+
+
+def parity_spot(ch, wins, spot, res, mode):
+    """The numbers the bench has just timed, against the CPU oracle (outside the timed region): z / info of the selected
+    unmeasured SNPs of the spot windows as the HEADLINE job returned them (resident 2-bit store, shared measured rows, two
+    Gram launches, chain beside the second, wide product tiles) vs oracle.run_impute on the same genotypes at full N
+    (distmix.cpp:165-228 / dist.cpp:156-202; an unmeasured SNP's z / info depend on the window's measured set and on its
+    own row only, so a subset of them is imputed exactly as inside the whole window)."""
+    import oracle
+    N = int(ch["off"][-1])
+    t0 = time.perf_counter()
+    worst_z = worst_i = 0.0
+    snps = 0
+    detail = []
+    for k, sel, gm, gu in spot:
+        _, mi, ui = wins[k]
+        want = oracle.run_impute(mode, np.ascontiguousarray(gm[:, :N]), np.ascontiguousarray(gu[:, :N]), ch["off"], ch["w"], ch["z"][mi])
+        got_z, got_i = res[k]["z"][sel], res[k]["info"][sel]
+        dz = float(np.max(np.abs(got_z - want["z"]) / np.maximum(1.0, np.abs(want["z"]))))
+        di = float(np.max(np.abs(got_i - want["info"]) / np.abs(want["info"])))
+        worst_z, worst_i = max(worst_z, dz), max(worst_i, di)
+        snps += len(sel)
+        detail.append({"window": int(k), "measured": int(len(mi)), "unmeasured_checked": int(len(sel)), "max_rel_z": dz, "max_rel_info": di})
+    return {"windows": len(spot), "snps": snps, "max_rel_z": worst_z, "max_rel_info": worst_i, "tolerance": SPOT_TOL,
+            "ok": bool(worst_z <= SPOT_TOL and worst_i <= SPOT_TOL), "oracle_seconds": round(time.perf_counter() - t0, 2),
+            "per_window": detail,
+            "what": "z / info of the timed job's own results vs the CPU oracle on the same rows at full N (all measured SNPs of the "
+                    "window, a spread of its unmeasured ones); |dz| / max(1, |z|) and |dinfo| / info"}
+
+
 def run_impute(args, rig):
     """--mode distmix / dist: the headline."""
     from gauss_amd import workload
@@ -312,6 +362,9 @@ def run_impute(args, rig):
         _, mi, ui = wins[k0]                                  # this window also feeds the CPU baseline sample
         keep0 = (k0, panel.index_select(0, torch.from_numpy(mi[:600]).cuda()).cpu().numpy(),
                  panel.index_select(0, torch.from_numpy(ui[:600]).cuda()).cpu().numpy())
+    spot = None
+    if rig.rank == 0 and rig.world == 1 and not args.no_parity_spot and wins:
+        spot = spot_inputs(torch, panel, wins)
     del panel
     full_store = store
     rows_of = None
@@ -403,26 +456,31 @@ def run_impute(args, rig):
         wr.close()
 
     emu = None
-    if rig.world == 1 and args.emulate_world > 1:
-        shares_e, load_e = shares_of(args, wins, N, args.emulate_world)
+    emu_world = args.emulate_world
+    if emu_world < 0:           # default: the driver's N = 1 line records the 8-rank prediction (whole chromosome only)
+        emu_world = 8 if (rig.world == 1 and strong and not args.windows and args.streams == 1 and len(wins) >= 16) else 0
+    if rig.world == 1 and emu_world > 1:
+        e_steps = max(1, min(args.steps, args.emulate_steps)) if args.emulate_world < 0 else args.steps
+        e_warm = 3 if args.emulate_world < 0 else max(1, args.warmup)
+        shares_e, load_e = shares_of(args, wins, N, emu_world)
         per_rank, parts_e = [], []
-        for r in range(args.emulate_world):
+        for r in range(emu_world):
             wr = workload.pieces_of(wins, shares_e[r])
             rr = Runner(rig, window_descs(ch, wr, store, ld2, args.mode), 1)
-            dtr, str_, res_r = rr.timed(args.steps, max(1, args.warmup))
+            dtr, str_, res_r = rr.timed(e_steps, e_warm)
             parts_e.append({piece: (q["z"], q["info"]) for piece, q in zip(shares_e[r], rr.results_in_order(res_r))})
-            per_rank.append({"rank": r, "windows": len(wr), "ms_per_step": dtr / args.steps * 1e3,
+            per_rank.append({"rank": r, "windows": len(wr), "ms_per_step": dtr / e_steps * 1e3,
                              "executed_flops": rr.stats["executed_flops"], "work_items": rr.stats["items"], "algorithmic_flops": rr.work["ld_flops"],
                              "mu": [(int(len(w[1])), int(len(w[2]))) for w in wr],
-                             "stage_ms": {k: v[0] / args.steps for k, v in str_.items()},
-                             "gram_frac_of_peak": (rr.work["ld_flops"] * args.steps / (str_["gram"][0] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS)
+                             "stage_ms": {k: v[0] / e_steps for k, v in str_.items()},
+                             "gram_frac_of_peak": (rr.work["ld_flops"] * e_steps / (str_["gram"][0] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS)
                              if str_["gram"][0] > 0 else 0.0})
             rr.close()
         slow = max(q["ms_per_step"] for q in per_rank)
-        emu = {"world": args.emulate_world, "per_rank": per_rank, "slowest_rank_ms": slow,
+        emu = {"world": emu_world, "steps_per_share": e_steps, "per_rank": per_rank, "slowest_rank_ms": slow,
                "one_gpu_ms": dt / args.steps * 1e3, "predicted_speedup": dt / args.steps * 1e3 / slow,
-               "predicted_efficiency": dt / args.steps * 1e3 / slow / args.emulate_world,
-               "load_imbalance": max(load_e) / (sum(load_e) / len(load_e)), "shard": shard_mode(args, args.emulate_world),
+               "predicted_efficiency": dt / args.steps * 1e3 / slow / emu_world,
+               "load_imbalance": max(load_e) / (sum(load_e) / len(load_e)), "shard": shard_mode(args, emu_world),
                "cut_windows": sum(1 for sh in shares_e for _, u0, _ in sh if u0 > 0),
                "pieces_bit_identical_to_one_job": pieces_equal_whole(parts_e, res, wins),
                "note": "each rank's share timed alone on ONE GPU, one after the other: an emulation of the per-rank step time, "
@@ -516,6 +574,27 @@ def run_impute(args, rig):
                           "small-footprint chain on the chain queue UNDER the second Gram launch (hidden: not part of the step's "
                           "critical path); otherwise ld_epilogue = B11's tiles and B21's run on the side stream beside `factor`",
         }
+        # the HBM-bound kernels (K1 pack, K4 LD epilogue), timed stand-alone in the one-stream pass (in the
+        # headline run B11's epilogue tiles run beside the Gram kernel): algorithmic bytes = the 2-bit source rows in
+        # ((M + U) N / 4 per window) for pack, the fp64 LD entries out ((M^2 + U M) 8 per window) for the epilogue
+        if tails_alone is not None:
+            n_m = np.array([len(mi) for _, mi, _ in my_wins], dtype=np.float64)
+            n_u = np.array([len(ui) for _, _, ui in my_wins], dtype=np.float64)
+            for key, kern, alg, what in (
+                    ("roofline_pack", "gauss::pack_stats_kernel", float(np.sum((n_m + n_u) * N * 0.25)),
+                     "sum over windows of (M + U) N / 4 bytes of 2-bit source rows in (the kernel also writes one operand byte per genotype)"),
+                    ("roofline_epilogue", "gauss::epilogue_kernel<false>", float(np.sum((n_m * n_m + n_u * n_m) * 8.0)),
+                     "sum over windows of (M^2 + U M) 8 bytes of fp64 LD entries out (the kernel also reads the exact partial slabs)")):
+                ms = alone["pack_stats" if key == "roofline_pack" else "ld_epilogue"]
+                tr = pmc_traffic(len(wins) == 36 and len(ch["bp"]) == 100_000, kernel=kern)
+                ach = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+                out[key] = {"kernel": kern.replace("gauss::", ""), "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg, "launch_ms": ms, "definition": what,
+                            "traffic": tr.get("traffic"),
+                            "moved_gbs": (tr["traffic"] / (ms * 1e-3) / 1e9) if tr.get("traffic") and ms > 0 else None,
+                            "measured_on": "the one-stream pass of the same job (one launch per step for all windows)"}
+                if tr.get("traffic_stale"):
+                    out[key]["traffic_stale"] = True
         if tails_alone is None and gram_lps > 1:
             # no stand-alone pass (N > 1), and in the headline run the chain is timed UNDER the Gram kernel: its stage timer says
             # nothing about the fp64 kernels' own speed
@@ -532,6 +611,8 @@ def run_impute(args, rig):
             out["emulated_strong_scaling"] = emu
         if e2e is not None:
             out["end_to_end"] = e2e
+        if spot is not None and res:
+            out["parity_spot"] = parity_spot(ch, wins, spot, res, 0 if args.mode == "dist" else 1)
         if keep0 is not None:
             out["cpu_baseline"] = cpu_baseline(ch, wins, keep0, work, 0 if args.mode == "dist" else 1)
         print(json.dumps(out), flush=True)
@@ -617,6 +698,30 @@ def pmc_traffic(applicable, kernel="gauss::gram_kernel<float>"):
     return {"traffic": best, "traffic_source": src, "traffic_stale": False, "traffic_sources_hash": profiled}
 
 
+def usable_cores():
+    """Cores this process may really use: its affinity mask, cut by a cgroup CPU quota if one is set."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as fh:
+                t = fh.read().split()
+            if path.endswith("cpu.max"):
+                if t[0] != "max":
+                    n = min(n, max(1, int(int(t[0]) / int(t[1]))))
+            else:
+                q = int(t[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh:
+                        n = min(n, max(1, q // int(fh.read())))
+            break
+        except Exception:
+            continue
+    return max(1, n)
+
+
 def cpu_baseline(ch, wins, keep0, work, mode=1):
     """The loop-literal CPU oracle (1 thread, like the reference) on a bounded sample, scaled to the workload in two
     parts.  (1) The pair loops: the reference's cost is N inner iterations per SNP pair (util.cpp:103-124),
@@ -658,7 +763,9 @@ def cpu_baseline(ch, wins, keep0, work, mode=1):
     # what an R user could do with one process per window: the same sample on several cores at once
     # (threads here: the oracle is plain C behind ctypes, which releases the GIL)
     from concurrent.futures import ThreadPoolExecutor
-    par = max(1, min(16, (os.cpu_count() or 1)))
+    # one process per window on every core the host gives us ("a windows-in-parallel run on all cores"): as
+    # many concurrent copies as there are windows to hand out, at most one per usable core
+    par = max(1, min(usable_cores(), len(wins)))
     t0 = time.perf_counter()
     with ThreadPoolExecutor(max_workers=par) as pool:
         list(pool.map(lambda _: oracle.run_impute(mode, gm_h, gu_h, ch["off"], ch["w"], z1), range(par)))
@@ -666,9 +773,10 @@ def cpu_baseline(ch, wins, keep0, work, mode=1):
     est_par = (tp / par) * (est / t)                            # same scaling, per-copy time under memory contention
     return {
         "value": work["imputed_snps"] / est, "unit": "imputed SNPs/s", "cores": 1, "kind": "port",
-        "host_cores": os.cpu_count(),
+        "host_cores": os.cpu_count(), "usable_cores": usable_cores(),
         "windows_in_parallel": {"value": work["imputed_snps"] / est_par, "unit": "imputed SNPs/s", "cores": par,
-                                "sample": f"{par} concurrent copies of the same sample in {tp:.2f} s"},
+                                "speedup_over_one_core": est / est_par,
+                                "sample": f"{par} concurrent copies of the same sample (min(usable cores, windows)) in {tp:.2f} s"},
         "dense_tail": {"what": "orc_make_pos_def + orc_inv_mat (MakePosDef eigen-decomposition + InvMat full-pivot LU, util.cpp:298-318)",
                        "seconds_at_M": {str(s): round(tails[s], 3) for s in sizes}, "seconds_per_M3": c3,
                        "seconds_per_chromosome": round(tail_total, 1), "share_of_estimate": round(tail_total / est, 4)},
@@ -714,6 +822,9 @@ def main(argv=None):
             if out is not None:
                 print(json.dumps(out), flush=True)
     rig.close()           # not in a `finally`: a rank that failed must not wait in a barrier for the others
+    if isinstance(out, dict) and isinstance(out.get("parity_spot"), dict) and not out["parity_spot"]["ok"]:
+        print("bench.py: the timed job's results differ from the CPU oracle beyond %g (parity_spot)" % SPOT_TOL, file=sys.stderr)
+        sys.exit(4)
     return out
 
 

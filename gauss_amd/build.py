@@ -32,9 +32,39 @@ def _hipcc():
     raise RuntimeError("hipcc not found: libgauss_hip.so cannot be built")
 
 
+_HIPCC_VERSION = None
+
+
+def hipcc_version():
+    """First line of `hipcc --version` that names the compiler (part of the build identity)."""
+    global _HIPCC_VERSION
+    if _HIPCC_VERSION is None:
+        try:
+            out = subprocess.check_output([_hipcc(), "--version"], stderr=subprocess.STDOUT).decode()
+            _HIPCC_VERSION = " ".join(l.strip() for l in out.splitlines() if "version" in l.lower())[:200]
+        except Exception:
+            _HIPCC_VERSION = "unknown"
+    return _HIPCC_VERSION
+
+
+def _unit_cmd(hipcc, unit, src, obj):
+    cmd = [hipcc, "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj, "-Wno-unused-result", "-Wno-unused-value"] + HIP_UNITS[unit] + EXTRA_FLAGS
+    if unit.endswith(".hip"):
+        cmd.insert(3, f"--offload-arch={ARCH}")
+    else:   # plain host C++ against the HIP runtime API (no device pass)
+        cmd[1:1] = ["-x", "c++", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include"]
+    return cmd
+
+
+# -D overrides for experiments (GAUSS_HIPCC_FLAGS="-DGAUSS_GRAM_EDGE16=0"): part of every unit's command line AND of the hash
+EXTRA_FLAGS = os.environ.get("GAUSS_HIPCC_FLAGS", "").split()
+
+
 def source_hash():
-    """sha256 (first 16 hex digits) over the sources of libgauss_hip.so, names and contents: the identity that
-    profiles/*_provenance.json records and that bench.py compares before it quotes a profile-derived number."""
+    """sha256 (first 16 hex digits) over everything that decides what libgauss_hip.so contains: the sources (names and
+    contents), every unit's compile flags (HIP_UNITS, GAUSS_HIPCC_FLAGS), the target architecture and the compiler's
+    version.  profiles/*_provenance.json records it and bench.py compares it before it quotes a profile-derived number:
+    a library built from the same sources with other flags is a different library."""
     import hashlib
     h = hashlib.sha256()
     names = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp", ".h")))
@@ -43,6 +73,22 @@ def source_hash():
         h.update(os.path.basename(f).encode() + b"\0")
         with open(p, "rb") as fh:
             h.update(fh.read())
+    for unit in sorted(HIP_UNITS):
+        h.update(("|" + unit + ":" + " ".join(_unit_cmd("hipcc", unit, unit, unit + ".o"))).encode())
+    h.update(("|arch=" + ARCH + "|cc=" + hipcc_version()).encode())
+    return h.hexdigest()[:16]
+
+
+def _unit_hash(unit, hdrs):
+    """Identity of one object file: its source, the shared headers, its command line, the compiler."""
+    import hashlib
+    h = hashlib.sha256()
+    for p in [os.path.join(CSRC, unit)] + hdrs:
+        with open(p, "rb") as fh:
+            h.update(fh.read())
+        h.update(b"\0")
+    h.update(" ".join(_unit_cmd("hipcc", unit, unit, unit + ".o")).encode())
+    h.update(hipcc_version().encode())
     return h.hexdigest()[:16]
 
 
@@ -64,26 +110,35 @@ def _newer(target, deps):
 
 
 def build_hip(force=False, verbose=False):
+    import json
     os.makedirs(OBJDIR, exist_ok=True)
     hipcc = _hipcc()
     hdrs = [os.path.join(CSRC, "gauss_internal.h"), os.path.join(CSRC, "k_gram_common.h"), os.path.join(CSRC, "k_solve_common.h"), os.path.join(HERE, "..", "include", "gauss_hip.h")]
+    # an object is rebuilt when its recorded identity (source + headers + command line + compiler) differs -- not by mtime: a
+    # flag change or a checkout that restores old timestamps must not link stale objects under a fresh source hash
+    ids_path = os.path.join(OBJDIR, "unit_ids.json")
+    try:
+        with open(ids_path) as fh:
+            ids = json.load(fh)
+    except Exception:
+        ids = {}
     objs = []
-    for unit, extra in HIP_UNITS.items():
+    relink = False
+    for unit in HIP_UNITS:
         src = os.path.join(CSRC, unit)
         obj = os.path.join(OBJDIR, os.path.splitext(unit)[0] + ".o")
         objs.append(obj)
-        if force or _newer(obj, [src] + hdrs):
-            cmd = [hipcc, "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj,
-                   "-Wno-unused-result", "-Wno-unused-value"] + extra
-            if unit.endswith(".hip"):
-                cmd.insert(3, f"--offload-arch={ARCH}")
-            else:   # plain host C++ against the HIP runtime API (no device pass)
-                cmd[1:1] = ["-x", "c++", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include"]
+        uid = _unit_hash(unit, hdrs)
+        if force or not os.path.exists(obj) or ids.get(unit) != uid:
+            cmd = _unit_cmd(hipcc, unit, src, obj)
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             subprocess.check_call(cmd)
+            ids[unit] = uid
+            relink = True
+            with open(ids_path, "w") as fh:
+                json.dump(ids, fh)
     # the source hash is compiled into the library (gauss_hip_source_hash): one tiny unit, rebuilt when the hash changes
-    import json
     sh = source_hash()
     stamp_path = os.path.join(LIBDIR, "build_stamp.json")
     try:
@@ -99,7 +154,7 @@ def build_hip(force=False, verbose=False):
             fh.write('extern "C" const char* gauss_hip_source_hash(void) { return "%s"; }\n' % sh)
         subprocess.check_call(["g++", "-O1", "-fPIC", "-c", vsrc, "-o", vobj])
     so = os.path.join(LIBDIR, "libgauss_hip.so")
-    if force or _newer(so, objs):
+    if force or relink or _newer(so, objs):
         subprocess.check_call([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", so] + objs)
     head, dirty = git_head()
     if head is None:            # no git here (the GPU box): keep what the development container wrote for these sources

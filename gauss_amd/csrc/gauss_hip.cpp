@@ -130,9 +130,11 @@ struct StoreUpload {
     bool done = false;
     int rc = 0;
     std::string err;
+    std::mutex join_mu;
+    void finish() { std::lock_guard<std::mutex> lock(join_mu); if (th.joinable()) th.join(); }      // the upload thread has ended
     ~StoreUpload()
     {
-        if (th.joinable()) th.join();
+        finish();
         for (auto& m : marks) if (m.second) hipEventDestroy(m.second);
     }
 };
@@ -157,7 +159,7 @@ struct gauss_ctx {
     std::vector<hipEvent_t> ev_pool;         // "chunk g has landed" events, reused by every streamed call
     std::mutex stream_mu;                    // one streamed call at a time per context (they share landing buffer and worker)
     hipStream_t upload = nullptr;            // asynchronous row-store uploads (gauss_store_upload_async)
-    std::map<const void*, std::unique_ptr<StoreUpload>> uploads;      // by device pointer (guarded by mu)
+    std::map<const void*, std::shared_ptr<StoreUpload>> uploads;      // by device pointer (guarded by mu); shared: a waiter keeps its entry alive
     int gram_i8 = 0;
     std::map<const void*, size_t> stores;    // row stores made by gauss_store_upload: base pointer -> bytes
     std::mutex mu;
@@ -300,8 +302,16 @@ struct gauss_job {
     char* h_pin = nullptr;                                 // pinned block: [table image | results | status]
     hipEvent_t begin = nullptr;                            // recorded when gauss_job_run starts queuing
     hipEvent_t done = nullptr;                             // recorded after the result copies of gauss_job_run
-    hipEvent_t ev_gram = nullptr, ev_side = nullptr;       // Gram kernel finished (main stream) / B21 written (side stream)
-    hipEvent_t ev_pack = nullptr, ev_rows = nullptr;       // operands packed (main) / row tables + certificate done (side)
+    // Cross-queue events of a run, one set per run parity (two runs of a job may be in flight, see run_seq below):
+    //   gram  B11's Gram launch (chain-aside) / the Gram kernel (otherwise) has been queued behind on the main queue
+    //   side  the chain queue / side queue has finished what the closing product reads
+    //   pack  operands packed (main)            rows  row tables + certificate done (GAUSS_ROWS_ASIDE: side queue)
+    // Every one is armed by a plain hipEventRecord in stream order and consumed by a hipStreamWaitEvent issued LATER IN
+    // HOST ORDER by the same call of job_run: the wait captures the record that precedes it, so re-arming the event for the
+    // next run could never redirect an earlier wait.  Each parity still owns its set: no event object is ever re-armed
+    // while a wait on its previous record may be pending in another queue (tools/experiments/README.md, "any-order launch").
+    struct RunEvents { hipEvent_t gram = nullptr, side = nullptr, pack = nullptr, rows = nullptr; };
+    RunEvents rev[2];
     Prob* d_probs = nullptr;
     Item* d_items = nullptr;    int n_items = 0;
     int2* d_rowmap = nullptr;   int n_rows = 0;
@@ -1075,10 +1085,9 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
     job->h_status = job->h_st2[0];
     job->done = job->done2[0];
     HIPCHK(hipEventCreate(&job->begin));
-    HIPCHK(hipEventCreateWithFlags(&job->ev_gram, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&job->ev_side, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&job->ev_pack, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&job->ev_rows, hipEventDisableTiming));
+    for (int k = 0; k < 2; k++)
+        for (hipEvent_t* e : {&job->rev[k].gram, &job->rev[k].side, &job->rev[k].pack, &job->rev[k].rows})
+            HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
 
     hipStream_t st = ctx->stream;
     // zero once: operand padding, B21 padding and the solve matrices rely on it
@@ -1310,27 +1319,28 @@ static int job_run(gauss_job* job, bool solve)
     HIPCHK(hipSetDevice(job->ctx->device));
     if (job->run_seq - job->fetch_seq >= 2u)
         return fail(GAUSS_E_INVALID, "gauss_job_run: two runs of this job are in flight already; fetch one first");
+    const gauss_job::RunEvents& ev = job->rev[job->run_seq & 1u];      // this run's cross-queue events (the parity's own set)
     HIPCHK(hipEventRecord(job->begin, st));
     HIPCHK(hipMemsetAsync(job->d_status, 0, sizeof(int) * 4 * job->n, st));
     // fused tail: the factorisation chain needs B11 only and the closing product is the first reader of B21, so B21's
     // tiles of the epilogue (85 % of them) go to the side stream and run beside the chain; the row tables and the
     // certificate, which only the epilogue and the factorisation read, go there too and slip in while the Gram kernel
     // starts up
-    static const bool fused = !(getenv("GAUSS_FUSED_SOLVE") && atoi(getenv("GAUSS_FUSED_SOLVE")) == 0);
+    const bool fused = env_int("GAUSS_FUSED_SOLVE", 1) != 0;           // read per run: the tests drive both forms
     // (off by default: worth 0.04 ms on an 8-rank share, nothing on 36 windows -- the Gram kernel gets that much slower --
     // and one profiled launch in a hundred saw the two small kernels and the Gram kernel's start tangle for 28 ms)
-    static const bool rows_aside = env_int("GAUSS_ROWS_ASIDE", 0) != 0;
+    const bool rows_aside = env_int("GAUSS_ROWS_ASIDE", 0) != 0;        // read per run: the tests drive both forms
     hipStream_t side = (solve && fused && job->n_panels > 0 && job->n_tiles > job->n_tiles_b11) ? job->ctx->side : nullptr;
     prof_begin(job, 1, st);
     launch_pack_stats(job->d_probs, job->d_rowmap, job->n_rows, st);
     hipStream_t rs = (side && rows_aside) ? side : st;
     if (rs != st) {
-        HIPCHK(hipEventRecord(job->ev_pack, st));
-        HIPCHK(hipStreamWaitEvent(rs, job->ev_pack, 0));
+        HIPCHK(hipEventRecord(ev.pack, st));
+        HIPCHK(hipStreamWaitEvent(rs, ev.pack, 0));
     }
     launch_row_stats(job->d_probs, job->d_rowmap, job->n_rows, rs);
     if (solve && job->n_panels > 0) launch_shift_cert(job->d_probs, job->n, rs);      // needs the row tables only
-    if (rs != st) HIPCHK(hipEventRecord(job->ev_rows, rs));
+    if (rs != st) HIPCHK(hipEventRecord(ev.rows, rs));
     prof_end(job, st);
     if (solve && job->chain_aside) {
         // Chain beside the Gram kernel.
@@ -1346,10 +1356,17 @@ static int job_run(gauss_job* job, bool solve)
         hipStream_t ch = job->ctx->chain;
         prof_begin(job, 0, st, 2);
         launch_gram(job->d_items, job->n_items_b11, job->gram_i8, st);
-        HIPCHK(hipEventRecord(job->ev_gram, st));
+        HIPCHK(hipEventRecord(ev.gram, st));
         launch_gram(job->d_items + job->n_items_b11, job->n_items - job->n_items_b11, job->gram_i8, st);
         prof_end(job, st);
-        HIPCHK(hipStreamWaitEvent(ch, job->ev_gram, 0));
+        if (rs != st) {
+            // GAUSS_ROWS_ASIDE: the row tables and the certificate were made on the side queue; everything that reads them
+            // joins it here -- B11's epilogue tiles and the chain (status[3]) on the chain queue, B21's epilogue tiles on the
+            // main queue (behind both Gram launches, which read neither)
+            HIPCHK(hipStreamWaitEvent(ch, ev.rows, 0));
+            HIPCHK(hipStreamWaitEvent(st, ev.rows, 0));
+        }
+        HIPCHK(hipStreamWaitEvent(ch, ev.gram, 0));
         prof_begin(job, 2, ch);
         launch_epilogue_b11_lite(job->d_probs, job->d_tilemap, job->n_tiles_b11, job->gram_i8, ch);
         prof_end(job, ch);
@@ -1363,11 +1380,11 @@ static int job_run(gauss_job* job, bool solve)
             launch_factor_step_lite(job->d_probs, job->n, s, job->max_nblk, job->max_npanel, job->solve_split, ch);
         launch_solve_last_lite(job->d_probs, job->d_panelmap, job->n_panels, job->max_nblk, job->solve_split, ch);
         prof_end(job, ch);
-        HIPCHK(hipEventRecord(job->ev_side, ch));
+        HIPCHK(hipEventRecord(ev.side, ch));
         prof_begin(job, 2, st);
         launch_epilogue(job->d_probs, job->d_tilemap + job->n_tiles_b11, job->n_tiles - job->n_tiles_b11, job->max_pop, job->gram_i8, st);
         prof_end(job, st);
-        HIPCHK(hipStreamWaitEvent(st, job->ev_side, 0));
+        HIPCHK(hipStreamWaitEvent(st, ev.side, 0));
         prof_begin(job, 4, st);
         launch_impute_gemm(job->d_probs, job->d_gemmmap, job->n_gemm, job->gemm_ut, job->d_finmap, job->n_fin, st);
         prof_end(job, st);
@@ -1377,12 +1394,12 @@ static int job_run(gauss_job* job, bool solve)
     launch_gram(job->d_items, job->n_items_b11, job->gram_i8, st);             // (none unless GAUSS_GRAM_SPLIT: B11's items first)
     launch_gram(job->d_items + job->n_items_b11, job->n_items - job->n_items_b11, job->gram_i8, st);
     prof_end(job, st);
-    if (rs != st) HIPCHK(hipStreamWaitEvent(st, job->ev_rows, 0));
+    if (rs != st) HIPCHK(hipStreamWaitEvent(st, ev.rows, 0));
     if (side) {
-        HIPCHK(hipEventRecord(job->ev_gram, st));
-        HIPCHK(hipStreamWaitEvent(side, job->ev_gram, 0));
+        HIPCHK(hipEventRecord(ev.gram, st));
+        HIPCHK(hipStreamWaitEvent(side, ev.gram, 0));
         launch_epilogue(job->d_probs, job->d_tilemap + job->n_tiles_b11, job->n_tiles - job->n_tiles_b11, job->max_pop, job->gram_i8, side);
-        HIPCHK(hipEventRecord(job->ev_side, side));
+        HIPCHK(hipEventRecord(ev.side, side));
     }
     prof_begin(job, 2, st);
     launch_epilogue(job->d_probs, job->d_tilemap, side ? job->n_tiles_b11 : job->n_tiles, job->max_pop, job->gram_i8, st);
@@ -1406,7 +1423,7 @@ static int job_run(gauss_job* job, bool solve)
         prof_begin(job, 4, st);
         if (fused) {
             launch_solve_last(job->d_probs, job->d_panelmap, job->n_panels, job->max_nblk, job->solve_split, st);
-            if (side) HIPCHK(hipStreamWaitEvent(st, job->ev_side, 0));
+            if (side) HIPCHK(hipStreamWaitEvent(st, ev.side, 0));
             launch_impute_gemm(job->d_probs, job->d_gemmmap, job->n_gemm, job->gemm_ut, job->d_finmap, job->n_fin, st);
         } else launch_solve(job->d_probs, job->d_dpanelmap, job->n_dpanels, st);
         prof_end(job, st);
@@ -1527,11 +1544,12 @@ static int job_run_streamed(gauss_job* job, StreamSetup& su)
     Plan& pl = job->plans[0];
     const Prob& p = pl.p;
     const size_t ng = job->sgroups.size();
+    const gauss_job::RunEvents& ev = job->rev[job->run_seq & 1u];
     HIPCHK(hipEventRecord(job->begin, st));
     HIPCHK(hipMemsetAsync(job->d_status, 0, sizeof(int) * 4 * job->n, st));
     // what job_build queued on the main stream (zeroing, tables) comes before anything on the other queues
-    HIPCHK(hipEventRecord(job->ev_pack, st));
-    HIPCHK(hipStreamWaitEvent(ax, job->ev_pack, 0));
+    HIPCHK(hipEventRecord(ev.pack, st));
+    HIPCHK(hipStreamWaitEvent(ax, ev.pack, 0));
     for (size_t g = 0; g < ng; g++) {
         const gauss_job::StreamGroup& sg = job->sgroups[g];
         {
@@ -1555,8 +1573,8 @@ static int job_run_streamed(gauss_job* job, StreamSetup& su)
         launch_gram(job->d_items + sg.item0, sg.n_items, job->gram_i8, st);
         if (g == 0) {
             if (ch != st) {
-                HIPCHK(hipEventRecord(job->ev_gram, st));
-                HIPCHK(hipStreamWaitEvent(ch, job->ev_gram, 0));
+                HIPCHK(hipEventRecord(ev.gram, st));
+                HIPCHK(hipStreamWaitEvent(ch, ev.gram, 0));
             }
             launch_epilogue(job->d_probs, job->d_tilemap, job->n_tiles_b11, job->max_pop, job->gram_i8, ch);
             if (pl.out_b11)
@@ -1564,11 +1582,11 @@ static int job_run_streamed(gauss_job* job, StreamSetup& su)
             for (int s = 0; s < job->max_nblk; s++)
                 launch_factor_step(job->d_probs, job->n, s, job->max_nblk, job->max_npanel, job->solve_split, job->own_panel, ch);
             launch_solve_last(job->d_probs, job->d_panelmap, job->n_panels, job->max_nblk, job->solve_split, ch);
-            if (ch != st) HIPCHK(hipEventRecord(job->ev_side, ch));
+            if (ch != st) HIPCHK(hipEventRecord(ev.side, ch));
         }
     }
     launch_epilogue(job->d_probs, job->d_tilemap + job->n_tiles_b11, job->n_tiles - job->n_tiles_b11, job->max_pop, job->gram_i8, st);
-    if (ch != st) HIPCHK(hipStreamWaitEvent(st, job->ev_side, 0));
+    if (ch != st) HIPCHK(hipStreamWaitEvent(st, ev.side, 0));
     launch_impute_gemm(job->d_probs, job->d_gemmmap, job->n_gemm, job->gemm_ut, job->d_finmap, job->n_fin, st);
     HIPCHK(hipGetLastError());
     const int par = (int)(job->run_seq & 1u);
@@ -1751,13 +1769,12 @@ static void job_release(gauss_job* job)
     job->d_ws = nullptr; job->d_tab = nullptr; job->h_pin = nullptr;
     if (job->begin) hipEventDestroy(job->begin);
     for (int k = 0; k < 2; k++) if (job->done2[k]) hipEventDestroy(job->done2[k]);
-    if (job->ev_gram) hipEventDestroy(job->ev_gram);
-    if (job->ev_side) hipEventDestroy(job->ev_side);
-    if (job->ev_pack) hipEventDestroy(job->ev_pack);
-    if (job->ev_rows) hipEventDestroy(job->ev_rows);
+    for (int k = 0; k < 2; k++)
+        for (hipEvent_t* e : {&job->rev[k].gram, &job->rev[k].side, &job->rev[k].pack, &job->rev[k].rows})
+            if (*e) { hipEventDestroy(*e); *e = nullptr; }
     for (hipEvent_t e : job->sevp) if (e) hipEventDestroy(e);
     job->sevp.clear();
-    job->begin = job->done = job->ev_gram = job->ev_side = job->ev_pack = job->ev_rows = nullptr;
+    job->begin = job->done = nullptr;
     job->done2[0] = job->done2[1] = nullptr;
     { std::lock_guard<std::mutex> lock(ctx->mu); ctx->jobs.erase(job); }
     job->ctx = nullptr;                       // from here on the handle is an orphan: only gauss_job_destroy accepts it
@@ -1875,6 +1892,7 @@ void gauss_hip_destroy(gauss_ctx* ctx)
     for (hipEvent_t e : ctx->ev_pool) hipEventDestroy(e);
     if (ctx->landing) (void)hipFree(ctx->landing);
     // 3. row stores nobody freed (uploads still running are finished first)
+    for (auto& kv : ctx->uploads) kv.second->finish();
     ctx->uploads.clear();
     if (ctx->upload) { hipStreamSynchronize(ctx->upload); hipStreamDestroy(ctx->upload); }
     for (auto& kv : ctx->stores) (void)hipFree(const_cast<void*>(kv.first));
@@ -1976,7 +1994,9 @@ static int upload_rows(gauss_ctx* ctx, void* d, const RowSource2& src, size_t by
     const unsigned hw = std::thread::hardware_concurrency();
     // a background upload (chunk_queued set) shares the host with the data layer it runs beside: fewer copy threads
     const int nt_env = env_int("GAUSS_UPLOAD_THREADS", 0);
-    const int nt = nt_env > 0 ? nt_env : (int)std::max(1u, std::min(chunk_queued ? 4u : 8u, hw ? hw / 2 : 2u));
+    // one process per GPU (torchrun exports LOCAL_WORLD_SIZE): the ranks of a node share its cores
+    const unsigned ranks = (unsigned)std::max(1, env_int("LOCAL_WORLD_SIZE", 1));
+    const int nt = nt_env > 0 ? nt_env : (int)std::max(1u, std::min(chunk_queued ? 4u : 8u, (hw ? hw / 2 : 2u) / ranks));
     std::atomic<bool> read_ok{true};
     size_t k = 0;
     for (size_t off = 0; off < bytes && rc == GAUSS_OK; off += CH, k++) {
@@ -2093,7 +2113,7 @@ static int store_upload_async(gauss_ctx* ctx, const RowSource2& src, int64_t byt
     void* d = nullptr;
     hipError_t e = ctx_malloc_retry(ctx, &d, (size_t)bytes + 64);
     if (e != hipSuccess) return fail(GAUSS_E_NOMEM, "hipMalloc(%lld bytes row store) failed: %s", (long long)bytes, hipGetErrorString(e));
-    std::unique_ptr<StoreUpload> up(new StoreUpload());
+    std::shared_ptr<StoreUpload> up(new StoreUpload());
     StoreUpload* u = up.get();
     u->d = d; u->bytes = (size_t)bytes;
     {
@@ -2127,32 +2147,40 @@ static int store_upload_async(gauss_ctx* ctx, const RowSource2& src, int64_t byt
 int gauss_store_wait(gauss_ctx* ctx, const void* device_ptr, int64_t bytes_needed)
 {
     if (!ctx || !device_ptr) return fail(GAUSS_E_INVALID, "bad arguments to gauss_store_wait");
-    StoreUpload* u = nullptr;
+    // the waiter holds the bookkeeping alive: another waiter (or gauss_store_free) may retire the entry meanwhile
+    std::shared_ptr<StoreUpload> u;
     {
         std::lock_guard<std::mutex> lock(ctx->mu);
         auto it = ctx->uploads.find(device_ptr);
         if (it == ctx->uploads.end()) return GAUSS_OK;            // not an asynchronous store, or complete and retired
-        u = it->second.get();
+        u = it->second;
     }
     const bool all = bytes_needed <= 0 || (size_t)bytes_needed >= u->bytes;
     hipEvent_t ev = nullptr;
+    bool done = false;
     {
         std::unique_lock<std::mutex> lock(u->mu);
         const size_t need = all ? u->bytes : (size_t)bytes_needed;
-        u->cv.wait(lock, [&] { return u->done || (!u->marks.empty() && u->marks.back().first >= need); });
+        // the whole store: until the upload thread has synchronised its queue (`done`), as the header promises -- the
+        // host may read the rows' consequences right after; a prefix: until the mark that covers it has been queued
+        u->cv.wait(lock, [&] { return u->done || (!all && !u->marks.empty() && u->marks.back().first >= need); });
         if (u->rc) return fail(u->rc, "%s", u->err.c_str());
-        if (!u->done || !all)
+        done = u->done;
+        if (!done)
             for (auto& m : u->marks) if (m.first >= need) { ev = m.second; break; }
     }
-    if (u->done) {
+    if (done) {
         // complete (upload_rows synchronised its stream): nothing to wait for, and the bookkeeping can go
-        std::unique_ptr<StoreUpload> dead;
-        std::lock_guard<std::mutex> lock(ctx->mu);
-        auto it = ctx->uploads.find(device_ptr);
-        if (it != ctx->uploads.end()) { dead = std::move(it->second); ctx->uploads.erase(it); }
-        return GAUSS_OK;
+        std::shared_ptr<StoreUpload> dead;
+        {
+            std::lock_guard<std::mutex> lock(ctx->mu);
+            auto it = ctx->uploads.find(device_ptr);
+            if (it != ctx->uploads.end() && it->second == u) { dead = std::move(it->second); ctx->uploads.erase(it); }
+        }
+        return GAUSS_OK;                                          // (`dead` and `u` let go of the entry here, outside ctx->mu)
     }
     HIPCHK(hipSetDevice(ctx->device));
+    // (the event belongs to `u`, which this call holds; marks are only destroyed with it)
     if (ev) HIPCHK(hipStreamWaitEvent(ctx->stream, ev, 0));
     return GAUSS_OK;
 }
@@ -2164,8 +2192,9 @@ int gauss_store_free(gauss_ctx* ctx, void* device_ptr)
     if (device_ptr) {
         {
             // an upload that is still running is finished first (its destructor joins the thread)
-            std::unique_ptr<StoreUpload> dead;
+            std::shared_ptr<StoreUpload> dead;
             { std::lock_guard<std::mutex> lock(ctx->mu); auto it = ctx->uploads.find(device_ptr); if (it != ctx->uploads.end()) { dead = std::move(it->second); ctx->uploads.erase(it); } }
+            if (dead) dead->finish();             // (a concurrent gauss_store_wait may hold the entry a little longer: the thread has ended either way)
         }
         { std::lock_guard<std::mutex> lock(ctx->mu); ctx->stores.erase(device_ptr); }
         HIPCHK(hipFree(device_ptr));
@@ -2303,7 +2332,7 @@ int gauss_impute_window(gauss_ctx* ctx, const gauss_window_desc* win)
     // Streamed form (default): upload and compute overlap (job_run_streamed).  It covers the windows the drivers make --
     // contiguous host matrices, additive coding, something to solve; the clamp path re-reads the job's buffers and works
     // on either form.  GAUSS_STREAM_WINDOW=0 (or GAUSS_FUSED_SOLVE=0): upload everything, then run.
-    static const bool fused = !(getenv("GAUSS_FUSED_SOLVE") && atoi(getenv("GAUSS_FUSED_SOLVE")) == 0);
+    const bool fused = env_int("GAUSS_FUSED_SOLVE", 1) != 0;           // read per run: the tests drive both forms
     bool streamed = env_int("GAUSS_STREAM_WINDOW", 1) != 0 && fused && !win->rows_m && !win->rows_u && win->n_unmeasured >= 1 &&
                     win->n_measured >= 1 && win->kind != GAUSS_WIN_LD && (win->u_codings & ~GAUSS_CODE_ADDITIVE) == 0 &&
                     win->geno_m && win->geno_u && win->pop_off && win->n_pop >= 1 && win->n_pop <= 64;

@@ -650,10 +650,18 @@ static std::string file_identity(const std::string& path)
     return std::string(rp ? rp : path.c_str()) + buf;
 }
 
-static bool dir_usable(const std::string& d)
+// A cache directory this process may create, use and TRUST: made with mode 0700 when missing; an existing one must be a
+// real directory (no symlink), owned by this user and writable by nobody else -- a packed panel found in a directory
+// that someone else can write to (the predictable /tmp fallback, pre-created by another local user) is hostile data.
+// `trusted_shared`: a directory the user named (GAUSS_PANEL_CACHE) or one beside the panel files may be group-shared on
+// purpose (a lab's panel directory); only the ownership-free checks apply there.
+static bool dir_usable(const std::string& d, bool create, bool private_only)
 {
-    if (mkdir(d.c_str(), 0777) != 0 && errno != EEXIST) return false;
-    return access(d.c_str(), W_OK | X_OK) == 0;
+    if (create && mkdir(d.c_str(), private_only ? 0700 : 0777) != 0 && errno != EEXIST) return false;
+    struct stat st;
+    if (lstat(d.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) return false;
+    if (private_only && (st.st_uid != getuid() || (st.st_mode & (S_IWGRP | S_IWOTH)))) return false;
+    return access(d.c_str(), (create ? W_OK : R_OK) | X_OK) == 0;
 }
 
 // 0: `out` names a packed panel (the data file itself if it already is one).  1: no cached panel and create == false.
@@ -672,22 +680,34 @@ static int resolve_packed_panel(const std::string& index_file, const std::string
     const size_t slash = base.find_last_of('/');
     const std::string dir_of_data = slash == std::string::npos ? "." : base.substr(0, slash);
     if (slash != std::string::npos) base = base.substr(slash + 1);
-    std::vector<std::string> dirs;
-    if (const char* e = getenv("GAUSS_PANEL_CACHE")) dirs.push_back(e);
-    else { dirs.push_back(dir_of_data + "/.gauss_panel_cache"); dirs.push_back("/tmp/gauss_panel_cache_" + std::to_string((long)getuid())); }
-    // an existing entry anywhere on the list wins
-    for (const std::string& d : dirs) {
-        const std::string p = d + "/" + base + "." + hex + ".gpk";
+    std::vector<std::pair<std::string, bool>> dirs;                               // (directory, must be private to this user)
+    if (const char* e = getenv("GAUSS_PANEL_CACHE")) dirs.emplace_back(e, false);
+    else { dirs.emplace_back(dir_of_data + "/.gauss_panel_cache", false); dirs.emplace_back("/tmp/gauss_panel_cache_" + std::to_string((long)getuid()), true); }
+    // an existing entry anywhere on the list wins (in a directory that passes the trust check)
+    for (const auto& dp : dirs) {
+        if (!dir_usable(dp.first, false, dp.second)) continue;
+        const std::string p = dp.first + "/" + base + "." + hex + ".gpk";
         if (PackedPanel::is_packed(p)) { out = p; return 0; }
     }
     if (!create) return 1;
-    for (const std::string& d : dirs) {
-        if (!dir_usable(d)) continue;
+    for (const auto& dp : dirs) {
+        const std::string& d = dp.first;
+        if (!dir_usable(d, true, dp.second)) continue;
         const std::string p = d + "/" + base + "." + hex + ".gpk";
         const std::string lockp = p + ".lock";
-        const int fd = open(lockp.c_str(), O_CREAT | O_RDWR, 0666);
+        // The lock file is removed by its holder WHILE it holds the lock; whoever gets the lock next checks that the file it
+        // locked is still the one the name points at (same inode) and starts over otherwise -- so a waiter on the old inode
+        // and a newcomer that created a new file can never both "hold the lock".
+        int fd = -1;
+        for (int attempt = 0; attempt < 100 && fd < 0; attempt++) {
+            const int f = open(lockp.c_str(), O_CREAT | O_RDWR | O_NOFOLLOW, 0600);
+            if (f < 0) break;
+            if (flock(f, LOCK_EX) != 0) { close(f); break; }
+            struct stat a, b;
+            if (fstat(f, &a) == 0 && stat(lockp.c_str(), &b) == 0 && a.st_ino == b.st_ino && a.st_dev == b.st_dev) fd = f;
+            else close(f);                                             // unlinked under us: the name is a new file now
+        }
         if (fd < 0) continue;
-        if (flock(fd, LOCK_EX) != 0) { close(fd); continue; }
         int rc = 0;
         if (!PackedPanel::is_packed(p)) {                                 // nobody packed it while we waited for the lock
             const std::string tmp = p + ".tmp." + std::to_string((long)getpid());
@@ -696,9 +716,9 @@ static int resolve_packed_panel(const std::string& index_file, const std::string
             else if (rename(tmp.c_str(), p.c_str()) != 0) { err = "ERROR: can't move the packed panel into the cache: " + p; unlink(tmp.c_str()); rc = -1; }
             else if (packed_now) *packed_now = n;
         }
+        unlink(lockp.c_str());                                        // still locked: see above
         flock(fd, LOCK_UN);
         close(fd);
-        unlink(lockp.c_str());
         if (rc) return rc;
         out = p;
         return 0;
@@ -2082,27 +2102,36 @@ static int panel_make_resident(gauss_ctx* ctx, const std::string& path, void** d
         *dev = found.dev;
         return reserve_only ? 0 : panel_fill_to(ctx, found, 0, uploaded);
     }
-    std::lock_guard<std::mutex> lock(g_res_mu);
-    auto it = g_resident.find(key);
-    if (it != g_resident.end()) { *dev = it->second.dev; return 0; }           // (a racing first use: the other caller's mode stands)
-    gauss_hip_add_destroy_hook(resident_ctx_destroyed, nullptr);
-    std::string err;
-    ResidentPanel rp;
-    rp.pk = open_packed_shared(path, err);
-    if (!rp.pk) return herr("%s", err.c_str());
-    rp.bytes = rp.pk->n_snp() * rp.pk->row_bytes();
-    if (rp.bytes <= 0) return herr("packed panel '%s' holds no SNPs", path.c_str());
-    if (reserve_only) {
-        if (gauss_store_alloc(ctx, rp.bytes, &rp.dev) != 0) return herr("%s", gauss_last_error());
-        rp.fill_mu = std::make_shared<std::mutex>();
-        rp.filled = std::make_shared<int64_t>(0);
-    } else if ((async ? gauss_store_upload_fd_async(ctx, rp.pk->fd(), rp.pk->geno_file_offset(), rp.bytes, &rp.dev)
-                      : gauss_store_upload(ctx, rp.pk->geno(), rp.bytes, &rp.dev)) != 0)
-        return herr("%s", gauss_last_error());
-    if (uploaded && !reserve_only) *uploaded = rp.bytes;
-    *dev = rp.dev;
-    g_resident[key] = rp;
-    return 0;
+    {
+        std::lock_guard<std::mutex> lock(g_res_mu);
+        auto it = g_resident.find(key);
+        if (it != g_resident.end()) {
+            // a racing first use: the other caller made the entry between the two looks.  Its MODE stands (whole / async /
+            // reserved), but this caller's NEED is its own: whoever asks without reserve_only gets every row (below)
+            found = it->second; have = true;
+        } else {
+            gauss_hip_add_destroy_hook(resident_ctx_destroyed, nullptr);
+            std::string err;
+            ResidentPanel rp;
+            rp.pk = open_packed_shared(path, err);
+            if (!rp.pk) return herr("%s", err.c_str());
+            rp.bytes = rp.pk->n_snp() * rp.pk->row_bytes();
+            if (rp.bytes <= 0) return herr("packed panel '%s' holds no SNPs", path.c_str());
+            if (reserve_only) {
+                if (gauss_store_alloc(ctx, rp.bytes, &rp.dev) != 0) return herr("%s", gauss_last_error());
+                rp.fill_mu = std::make_shared<std::mutex>();
+                rp.filled = std::make_shared<int64_t>(0);
+            } else if ((async ? gauss_store_upload_fd_async(ctx, rp.pk->fd(), rp.pk->geno_file_offset(), rp.bytes, &rp.dev)
+                              : gauss_store_upload(ctx, rp.pk->geno(), rp.bytes, &rp.dev)) != 0)
+                return herr("%s", gauss_last_error());
+            if (uploaded && !reserve_only) *uploaded = rp.bytes;
+            *dev = rp.dev;
+            g_resident[key] = rp;
+            return 0;
+        }
+    }
+    *dev = found.dev;
+    return reserve_only ? 0 : panel_fill_to(ctx, found, 0, uploaded);
 }
 
 // the entry of a panel that is (being made) resident on this context
@@ -2473,6 +2502,7 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
     std::vector<gauss_job*> jobs((size_t)n_batches, nullptr);
     std::vector<std::vector<int>> live((size_t)n_batches);       // slots of batch b that are in its job
     int rc_fatal = rc_upload;
+    bool upload_failed = rc_upload != 0;
     // the result table grows batch by batch (batches are contiguous in window order), so that only the last batch's
     // rows are appended after the GPU has finished
     std::unique_ptr<gauss_table> all(new gauss_table());
@@ -2558,7 +2588,7 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
                     for (int32_t r : q->store_rows_u) top = std::max<int64_t>(top, r);
                 }
                 const double tu = now_s();
-                if (gauss_store_wait(ctx, d_rows, (top + 1) * panel_row_bytes) != 0) { herr("%s", gauss_last_error()); rc_fatal = -1; break; }
+                if (gauss_store_wait(ctx, d_rows, (top + 1) * panel_row_bytes) != 0) { herr("%s", gauss_last_error()); rc_fatal = -1; upload_failed = true; break; }
                 st.t_panel_upload += now_s() - tu;
                 if (fill_to((top + 1) * panel_row_bytes) != 0) { rc_fatal = -1; break; }      // (already there unless the estimate fell short)
             }
@@ -2593,9 +2623,20 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
     for (gauss_job* j : jobs) if (j) gauss_job_destroy(j);
     // whoever finds this panel resident later (another study, an LD call on rows this chromosome never touched) must
     // find all of it: the upload is complete before the call returns
-    if (d_rows && gauss_store_wait(ctx, d_rows, 0) != 0 && !rc_fatal) { herr("%s", gauss_last_error()); rc_fatal = -1; }
-    if (fill_to(0) != 0 && !rc_fatal) rc_fatal = -1;                 // (rows past this chromosome's last window, if any)
-    if (rc_fatal) return -1;
+    if (d_rows && !upload_failed && gauss_store_wait(ctx, d_rows, 0) != 0) { if (!rc_fatal) herr("%s", gauss_last_error()); rc_fatal = -1; upload_failed = true; }
+    if (!upload_failed && fill_to(0) != 0 && !rc_fatal) rc_fatal = -1;      // (rows past this chromosome's last window, if any)
+    if (rc_fatal) {
+        // tables of windows that retired before the failure
+        for (auto& bs : slots) for (Slot& sl : bs) { delete sl.tab; sl.tab = nullptr; }
+        if (upload_failed) {
+            // a failed background upload must not poison the context: without this every later call on this panel would find
+            // the half-made store "resident" and fail on the stored error until gauss_host_panel_evict.  The message survives.
+            const std::string keep = gauss_host_last_error();
+            gauss_host_panel_evict(ctx, reference_data_file);
+            herr("%s", keep.c_str());
+        }
+        return -1;
+    }
 
     // ---- one table, window order (batches were appended as they retired) ----
     double tt = now_s();

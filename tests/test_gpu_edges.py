@@ -536,3 +536,115 @@ def test_sixteen_column_edge_of_the_gram_kernel(ctx):
         for key in ("z", "info", "b11", "b21"):
             assert np.array_equal(a[key], b[key], equal_nan=True), key
     store.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [0, 1])
+def test_more_samples_than_the_pack_kernels_lds_word_table(ctx, mode):
+    """N = 140 000 samples in 3 populations: a packed row has more than 8 192 words of 16 samples, so pack_stats_kernel
+    looks its word -> block table up in global memory (`tab_lds == false`, k_pack_epilogue.hip) -- a branch no panel of
+    33KG size reaches.  One-byte and 2-bit sources against the whole oracle (util.cpp:49-70 / 103-124 at N = 140 000;
+    dist.cpp:181-202), the two sources bit for bit against each other."""
+    from gauss_amd import panel as panel_mod
+    rng = np.random.default_rng(140)
+    sizes = [70_001, 40_000, 29_999]
+    off = synth.pop_offsets(sizes)
+    N = int(off[-1])
+    assert N == 140_000 and (N + 63) // 64 * 64 // 16 > 8192
+    M, U = 40, 40
+    G = rand_geno(rng, M + U, N)
+    gm, gu = np.ascontiguousarray(G[:M]), np.ascontiguousarray(G[M:])
+    w = np.array([0.5, 0.361, 0.2])
+    z1 = rng.standard_normal(M) * 2
+    got = hotpath.impute_window(mode, gm, gu, off, w, z1, want_mats=True, ctx=ctx)
+    want = oracle.run_impute(mode, gm, gu, off, w, z1, want_mats=True)
+    assert got["status"] == 0 and want["mpd"] == 0
+    assert np.max(np.abs(got["b11"] - want["b11"])) <= 1e-12 and np.max(np.abs(got["b21"] - want["b21"])) <= 1e-12
+    assert relerr(got["info"], want["info"]) <= 1e-8
+    assert np.max(np.abs(got["z"] - want["z"]) / np.maximum(1.0, np.abs(want["z"]))) <= 1e-8
+    cnt = hotpath.gram_counts(gm[:20], ctx=ctx)                      # exact integers over 140 000 samples
+    assert np.array_equal(cnt, gm[:20].astype(np.int64) @ gm[:20].astype(np.int64).T)
+    rows2, src_off = panel_mod.pack2bit(G, off)
+    job = hotpath.Job([dict(mode=mode, geno_m=rows2[:M], geno_u=rows2[M:], pop_off=off, pop_wgt=w, z1=z1, packed=dict(fmt=1))],
+                      ctx=ctx, want_mats=True)
+    job.run()
+    two = job.fetch()[0]
+    job.close()
+    for key in ("z", "info", "b11", "b21"):
+        assert np.array_equal(two[key], got[key]), key
+
+
+@pytest.mark.gpu
+def test_window_of_sixty_four_factor_blocks(ctx):
+    """M = 4 096 measured SNPs (a 2 Mb window of a dense array): 64 factor blocks, 65 panels of [I | z1], 32 k blocks of the
+    closing product and Mld-sized workspaces no chr22 window reaches (M <= 1 213 there).  N = 2 000, U = 1 024.  The oracle's
+    eigen-decomposition of a 4 096 x 4 096 matrix is out of a test's reach, so: LD entries spot-checked against the oracle's pair
+    function (util.cpp:103-124), structure of B11, and the solve against numpy on the GPU's own B11 / B21 (dist.cpp:181-202)."""
+    rng = np.random.default_rng(4096)
+    sizes = [700, 650, 650]
+    off = synth.pop_offsets(sizes)
+    N = int(off[-1])
+    M, U = 4096, 1024
+    G = rand_geno(rng, M + U, N)
+    gm, gu = np.ascontiguousarray(G[:M]), np.ascontiguousarray(G[M:])
+    w = np.array([0.4, 0.4, 0.261])
+    z1 = rng.standard_normal(M) * 2
+    r = hotpath.impute_window(1, gm, gu, off, w, z1, want_mats=True, ctx=ctx)
+    assert r["status"] == 0
+    b11, b21 = r["b11"], r["b21"]
+    assert b11.shape == (M, M) and b21.shape == (U, M)
+    assert np.array_equal(b11, b11.T) and np.all(np.diag(b11) == 1.1)
+
+    def std(row):
+        return np.sqrt(oracle.calwgtcov(row, row, off, w))
+    for (i, j) in [(0, 1), (63, 64), (4095, 0), (2048, 4094), (1000, 3001)]:
+        want = oracle.calwgtcov(gm[i], gm[j], off, w) / (std(gm[i]) * std(gm[j]))
+        assert abs(b11[i, j] - want) <= 1e-13, (i, j)
+    for (u, j) in [(0, 0), (1023, 4095), (512, 64), (77, 4032)]:
+        want = oracle.calwgtcov(gu[u], gm[j], off, w) / (std(gu[u]) * std(gm[j]))
+        assert abs(b21[u, j] - want) <= 1e-13, (u, j)
+    y = np.linalg.solve(b11, b21.T).T                              # b21 B11^-1  (B11 symmetric)
+    info = np.abs(np.einsum("ij,ij->i", y, b21))
+    assert relerr(r["info"], info) <= 1e-9
+    assert np.max(np.abs(r["z"] - (y @ z1) / np.sqrt(info))) <= 1e-8
+    # the same window in a job of its own kind of company: a small window beside it must not change its bits
+    small = dict(mode=1, geno_m=gm[:70], geno_u=gu[:30], pop_off=off, pop_wgt=w, z1=z1[:70])
+    job = hotpath.Job([small, dict(mode=1, geno_m=gm, geno_u=gu, pop_off=off, pop_wgt=w, z1=z1)], ctx=ctx)
+    job.run()
+    res = job.fetch()
+    job.close()
+    assert np.array_equal(res[1]["z"], r["z"]) and np.array_equal(res[1]["info"], r["info"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [0, 1])
+def test_standalone_solver_against_the_oracle(ctx, mode, monkeypatch):
+    """GAUSS_FUSED_SOLVE=0 (README: a supported fallback) factors B11 and pushes the window's own right-hand sides through the
+    substitution (solve_kernel, the clamp path's solver) instead of inverse rows + closing product: the shapes of
+    test_tail_block_edges -- every side of the 64- and 128-block edges -- as one job and as single-window calls (which then
+    upload, then run: no streamed form), against the oracle (dist.cpp:181-202, distmix.cpp:165-228)."""
+    monkeypatch.setenv("GAUSS_FUSED_SOLVE", "0")
+    shapes = [(11, 1), (63, 5), (64, 64), (65, 63), (127, 130), (128, 1), (129, 70), (192, 129), (200, 257)]
+    p = small_panel(n_snp=480, scale=0.03, seed=77)
+    G, off = p["G"], p["off"]
+    rng = np.random.default_rng(11)
+    wins, wants = [], []
+    for m, u in shapes:
+        idx = rng.permutation(G.shape[0])
+        gm, gu = np.ascontiguousarray(G[np.sort(idx[:m])]), np.ascontiguousarray(G[np.sort(idx[m:m + u])])
+        z1 = rng.standard_normal(m) * 2
+        wins.append(dict(mode=mode, geno_m=gm, geno_u=gu, pop_off=off, pop_wgt=p["w"], z1=z1))
+        wants.append(oracle.run_impute(mode, gm, gu, off, p["w"], z1))
+    job = hotpath.Job(wins, ctx=ctx)
+    job.run()
+    res = job.fetch()
+    job.close()
+    for want, got, wn in zip(wants, res, wins):
+        shape = (wn["geno_m"].shape[0], wn["geno_u"].shape[0])
+        assert got["status"] == 0, shape
+        assert relerr(got["info"], want["info"]) <= 1e-8, shape
+        assert np.max(np.abs(got["z"] - want["z"]) / np.maximum(1.0, np.abs(want["z"]))) <= 1e-8, shape
+    for k in (0, 3, 8):
+        wn = wins[k]
+        one = hotpath.impute_window(mode, wn["geno_m"], wn["geno_u"], off, p["w"], wn["z1"], ctx=ctx)
+        assert np.array_equal(one["z"], res[k]["z"]) and np.array_equal(one["info"], res[k]["info"]), k

@@ -715,7 +715,8 @@ def test_chain_beside_the_gram_kernel_gives_the_same_bits(ctx, monkeypatch):
     (GAUSS_CHAIN_ASIDE=2 forces it), against the chain behind one Gram launch (=0): z, info, status, B11 and B21 bit for bit.
     Windows of 2 to 9 factor blocks (M not a multiple of 64), shared and unshared measured rows, a QCAT window, a window
     whose lambda is too small for the certificate (the shifted matrix is factored too), and one whose B11 is not positive
-    definite at all (lambda = 0 on duplicated rows: the clamp path reruns it)."""
+    definite at all (lambda = 0 on duplicated rows: the clamp path reruns it).  Also with the row tables and the certificate made
+    on the side queue (GAUSS_ROWS_ASIDE=1): every reader joins that queue first, so the bits are the same."""
     p = small_panel(n_snp=2600, scale=0.05, seed=41)
     G = p["G"].copy()
     G[7] = G[3]                                    # two identical SNPs: singular B11 at lambda = 0
@@ -737,7 +738,8 @@ def test_chain_beside_the_gram_kernel_gives_the_same_bits(ctx, monkeypatch):
     wins[4] = dict(wins[4], lam=1e-7)              # no certificate: the exact test factors B11 - eps I as well
     wins[0] = dict(wins[0], lam=0.0)               # singular: status says clamp, the host reruns the window
 
-    def run(aside, share, split=False):
+    def run(aside, share, split=False, rows_aside=False):
+        monkeypatch.setenv("GAUSS_ROWS_ASIDE", "1" if rows_aside else "0")   # row tables + certificate on the side queue (job_run joins them)
         monkeypatch.setenv("GAUSS_CHAIN_ASIDE", "2" if aside else ("1" if split else "0"))
         monkeypatch.setenv("GAUSS_GRAM_SPLIT", "1" if split else "0")       # two Gram launches, chain behind them (bench's one-stream pass)
         monkeypatch.setenv("GAUSS_SHARE_MEASURED", "1" if share else "0")
@@ -756,7 +758,7 @@ def test_chain_beside_the_gram_kernel_gives_the_same_bits(ctx, monkeypatch):
     for share in (False, True):
         behind = run(False, share)
         assert any(r["status"] != 0 for r in behind)
-        for other in (run(True, share), run(False, share, split=True)):
+        for other in (run(True, share), run(False, share, split=True), run(True, share, rows_aside=True), run(False, share, rows_aside=True)):
             for k, (x, y) in enumerate(zip(behind, other)):
                 for key in x:
                     if isinstance(x[key], np.ndarray):
