@@ -72,6 +72,7 @@ def parse_args(argv=None):
                     help="single GPU: time every rank's share of an N-rank strong-scaling run one after the other "
                          "(what one rank of N would do per step); printed as `emulated_strong_scaling`, never as `value`.  "
                          "Default (-1): 8 on the whole-chromosome N = 1 run, with at most --emulate-steps steps per share; 0 = off")
+    ap.add_argument("--emulate-rank", type=int, default=-1, help="probe: emulate only this rank's share (no efficiency is derived)")
     ap.add_argument("--emulate-steps", type=int, default=10, help="timed steps per emulated share (each share also gets 3 warm-up steps)")
     ap.add_argument("--no-parity-spot", action="store_true", help="skip the oracle spot check of the timed job's own results")
     ap.add_argument("--streams", type=int, default=1, help="split a rank's windows over this many contexts (one stream pair each)")
@@ -465,6 +466,8 @@ def run_impute(args, rig):
         shares_e, load_e = shares_of(args, wins, N, emu_world)
         per_rank, parts_e = [], []
         for r in range(emu_world):
+            if args.emulate_rank >= 0 and r != args.emulate_rank:
+                continue
             wr = workload.pieces_of(wins, shares_e[r])
             rr = Runner(rig, window_descs(ch, wr, store, ld2, args.mode), 1)
             dtr, str_, res_r = rr.timed(e_steps, e_warm)
@@ -482,7 +485,7 @@ def run_impute(args, rig):
                "predicted_efficiency": dt / args.steps * 1e3 / slow / emu_world,
                "load_imbalance": max(load_e) / (sum(load_e) / len(load_e)), "shard": shard_mode(args, emu_world),
                "cut_windows": sum(1 for sh in shares_e for _, u0, _ in sh if u0 > 0),
-               "pieces_bit_identical_to_one_job": pieces_equal_whole(parts_e, res, wins),
+               "pieces_bit_identical_to_one_job": pieces_equal_whole(parts_e, res, wins) if args.emulate_rank < 0 else None,
                "note": "each rank's share timed alone on ONE GPU, one after the other: an emulation of the per-rank step time, "
                        "not a multi-GPU measurement (no 8-GPU node is available to the builder)"}
 

@@ -343,7 +343,10 @@ struct gauss_job {
     std::vector<hipEvent_t> sevp;                          // "group g's rows are packed, their tables made" (aux stream)
     int max_pop = 1;
     int gram_i8 = 0;
-    int* d_status = nullptr;                               // [n][4]
+    int* d_status = nullptr;                               // [n][4] + 4 job-wide ints
+    unsigned long long* d_b11_done = nullptr;              // merged Gram launch: B11's items that have finished, over all runs so far
+    bool merged = false;                                   // chain_aside as ONE Gram launch (B11's items first, counted; job_run)
+    unsigned long long merged_runs = 0;                    // merged Gram launches queued so far (the counter's target is this x n_items_b11)
     double* d_results = nullptr; size_t n_results = 0;     // z then info per problem
     // Two runs may be in flight: run k + 1 can be queued before run k has been fetched, so that the host's share of a
     // step (waking up, copying results out, queuing the next run) overlaps GPU work.  Result mirrors and completion
@@ -904,6 +907,10 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
             std::stable_sort(items.begin(), items.end(), [&](const ItemH& a, const ItemH& b) { return is_b11(a) && !is_b11(b); });
             for (const ItemH& h : items) job->n_items_b11 += is_b11(h) ? 1 : 0;
         }
+        // Merged launch (round 4): B11's items and B21's items are ONE launch, B11's first; they count themselves off and the
+        // chain queue starts when the count is complete (k_gram.hip: wait_count_kernel) -- the chip is never drained between
+        // the two halves (two launches: 37.1 ms, one: 36.6 on the 36-window job).  GAUSS_CHAIN_MERGED=0: two launches + event.
+        job->merged = job->chain_aside && env_int("GAUSS_CHAIN_MERGED", 1) != 0;
     }
     std::vector<int> sgroup_of_item;
     if (streamed) {
@@ -1057,7 +1064,8 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
         go.wmu = wa.take(rows * q.P * sizeof(double));
         go.slab = wslab.take((size_t)q.npair * q.nseg * TILE * TILE * (q.slab16 ? sizeof(uint16_t) : sizeof(float)));
     }
-    const size_t o_status = wa.take(sizeof(int) * 4 * job->n);
+    const size_t o_status = wa.take(sizeof(int) * (4 * job->n + 4));    // [n][4], then 4 job-wide ints ([4 n]: the chain queue timed out)
+    const size_t o_count = wa.take(64);                                  // b11_done counter of the merged Gram launch (zeroed once; only grows)
     const size_t o_results = wa.take(sizeof(double) * std::max<size_t>(res, 1));
     job->n_results = res;
     const size_t slab_base = rup(wa.off, 4096);
@@ -1073,7 +1081,7 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
     // one pinned block for the table image and the result mirrors: the table upload is then a true asynchronous
     // DMA and a job over resident rows is created without waiting for the stream (another job may be running on it)
     const size_t pin_tab = rup(job->tab_bytes, 256), pin_res = rup(sizeof(double) * std::max<size_t>(res, 1), 256);
-    const size_t pin_st = rup(sizeof(int) * 4 * job->n, 256);
+    const size_t pin_st = rup(sizeof(int) * (4 * job->n + 4), 256);
     e = ctx_pin_alloc(ctx, pin_tab + 2 * (pin_res + pin_st), (void**)&job->h_pin);
     if (e != hipSuccess) { job->h_pin = nullptr; return fail(GAUSS_E_NOMEM, "hipHostMalloc(%zu bytes) failed", pin_tab + 2 * pin_res); }
     for (int k = 0; k < 2; k++) {
@@ -1098,6 +1106,7 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
     }
 
     job->d_status = (int*)(job->d_ws + o_status);
+    job->d_b11_done = (unsigned long long*)(job->d_ws + o_count);
     job->d_results = (double*)(job->d_ws + o_results);
     std::deque<std::vector<uint8_t>> stage;      // host gather buffers, alive until the copies have drained
     for (int i = 0; i < job->n; i++) {
@@ -1238,6 +1247,7 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
         it.Kp = p.Kp; it.k0 = pl.seg_k0[gr.first]; it.nseg = gr.second - gr.first;
         static const int no_edge16 = env_int("GAUSS_GRAM_EDGE16", 1) == 0 ? 8 : 0;
         it.rows_a = rows(ti); it.rows_b = rows(tj); it.flags = (ti == tj ? 1 : 0) | (p.slab16 ? 2 : 0) | no_edge16;
+        if (job->merged && (int)n < job->n_items_b11) it.flags |= 16;         // counts itself off in b11_done
         memcpy(blob.data() + o_items + sizeof(Item) * n, &it, sizeof(Item));
     }
     memcpy(job->h_pin, blob.data(), blob.size());
@@ -1305,7 +1315,7 @@ static int job_run_finish(gauss_job* job, hipStream_t st)
     const int par = (int)(job->run_seq & 1u);
     if (job->n_results)
         HIPCHK(hipMemcpyAsync(job->h_res2[par], job->d_results, sizeof(double) * job->n_results, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(job->h_st2[par], job->d_status, sizeof(int) * 4 * job->n, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(job->h_st2[par], job->d_status, sizeof(int) * (4 * job->n + 4), hipMemcpyDeviceToHost, st));
     HIPCHK(hipEventRecord(job->done2[par], st));
     job->done = job->done2[par];
     job->run_seq++;
@@ -1321,7 +1331,7 @@ static int job_run(gauss_job* job, bool solve)
         return fail(GAUSS_E_INVALID, "gauss_job_run: two runs of this job are in flight already; fetch one first");
     const gauss_job::RunEvents& ev = job->rev[job->run_seq & 1u];      // this run's cross-queue events (the parity's own set)
     HIPCHK(hipEventRecord(job->begin, st));
-    HIPCHK(hipMemsetAsync(job->d_status, 0, sizeof(int) * 4 * job->n, st));
+    HIPCHK(hipMemsetAsync(job->d_status, 0, sizeof(int) * (4 * job->n + 4), st));
     // fused tail: the factorisation chain needs B11 only and the closing product is the first reader of B21, so B21's
     // tiles of the epilogue (85 % of them) go to the side stream and run beside the chain; the row tables and the
     // certificate, which only the epilogue and the factorisation read, go there too and slip in while the Gram kernel
@@ -1354,6 +1364,19 @@ static int job_run(gauss_job* job, bool solve)
         //           per CU leave free, so the ~19 dependent block steps run UNDER the second Gram launch instead of behind it.
         // Same arithmetic, same bits as the path below.
         hipStream_t ch = job->ctx->chain;
+        if (job->merged) {
+            // ONE launch: B11's items first (they count themselves off in d_b11_done), B21's items behind them in the same grid.
+            // The chain queue joins the main queue right BEFORE the launch (operands, row tables and certificate are complete)
+            // and then waits for the count of this run: the counter only grows, run r is complete at (r + 1) x n_items_b11.
+            if (rs != st) HIPCHK(hipStreamWaitEvent(st, ev.rows, 0));
+            HIPCHK(hipEventRecord(ev.gram, st));
+            prof_begin(job, 0, st, 1);
+            launch_gram(job->d_items, job->n_items, job->gram_i8, st, job->d_b11_done);
+            job->merged_runs++;                            // counted per LAUNCH, not per completed call: a later error must not shift the target
+            prof_end(job, st);
+            HIPCHK(hipStreamWaitEvent(ch, ev.gram, 0));
+            launch_wait_count(job->d_b11_done, job->merged_runs * (unsigned long long)job->n_items_b11, job->d_status + 4 * job->n, 1, ch);
+        } else {
         prof_begin(job, 0, st, 2);
         launch_gram(job->d_items, job->n_items_b11, job->gram_i8, st);
         HIPCHK(hipEventRecord(ev.gram, st));
@@ -1367,6 +1390,7 @@ static int job_run(gauss_job* job, bool solve)
             HIPCHK(hipStreamWaitEvent(st, ev.rows, 0));
         }
         HIPCHK(hipStreamWaitEvent(ch, ev.gram, 0));
+        }
         prof_begin(job, 2, ch);
         launch_epilogue_b11_lite(job->d_probs, job->d_tilemap, job->n_tiles_b11, job->gram_i8, ch);
         prof_end(job, ch);
@@ -1546,7 +1570,7 @@ static int job_run_streamed(gauss_job* job, StreamSetup& su)
     const size_t ng = job->sgroups.size();
     const gauss_job::RunEvents& ev = job->rev[job->run_seq & 1u];
     HIPCHK(hipEventRecord(job->begin, st));
-    HIPCHK(hipMemsetAsync(job->d_status, 0, sizeof(int) * 4 * job->n, st));
+    HIPCHK(hipMemsetAsync(job->d_status, 0, sizeof(int) * (4 * job->n + 4), st));
     // what job_build queued on the main stream (zeroing, tables) comes before anything on the other queues
     HIPCHK(hipEventRecord(ev.pack, st));
     HIPCHK(hipStreamWaitEvent(ax, ev.pack, 0));
@@ -1592,7 +1616,7 @@ static int job_run_streamed(gauss_job* job, StreamSetup& su)
     const int par = (int)(job->run_seq & 1u);
     if (job->n_results)
         HIPCHK(hipMemcpyAsync(job->h_res2[par], job->d_results, sizeof(double) * job->n_results, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(job->h_st2[par], job->d_status, sizeof(int) * 4 * job->n, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(job->h_st2[par], job->d_status, sizeof(int) * (4 * job->n + 4), hipMemcpyDeviceToHost, st));
     HIPCHK(hipEventRecord(job->done2[par], st));
     job->done = job->done2[par];
     job->run_seq++;
@@ -1683,6 +1707,10 @@ static int job_fetch(gauss_job* job)
     job->h_results = job->h_res2[par];
     job->h_status = job->h_st2[par];
     HIPCHK(hipEventSynchronize(job->done2[par]));
+    if (job->h_status[4 * job->n] != 0) {
+        job->fetch_seq++;
+        return fail(GAUSS_E_DEVICE, "the chain queue gave up waiting for B11's tile pairs of this run (merged Gram launch): results are not valid");
+    }
     // With a later run of the job already queued, anything that reads the job's DEVICE buffers (matrix exports, the
     // clamp path, the eigenvalue count) first lets that run finish: the job's inputs do not change between runs, so
     // what it leaves on the device is what the fetched run left.

@@ -133,7 +133,8 @@ struct Item {
     int nseg;                // segments in the run
     int rows_a, rows_b;      // live rows of the two tiles (the rest is zero padding)
     int flags;               // bit 0: ti == tj (diagonal tile); bit 1: slabs are uint16 pairs (Prob::slab16); bit 3: no 16-column
-                             // edge routine (GAUSS_GRAM_EDGE16=0: every live 32-column half takes the 32 x 32 MFMA)
+                             // edge routine (GAUSS_GRAM_EDGE16=0: every live 32-column half takes the 32 x 32 MFMA); bit 4: a B11
+                             // item of a merged launch: counts itself off in the launch's `b11_done` (k_gram.hip)
 };
 static_assert(sizeof(Item) == 64, "work items are fetched as one 64-byte descriptor");
 
@@ -181,7 +182,10 @@ struct DeviceOnce {
 // ---- launchers (host functions defined in the .hip files) ----
 void launch_pack_stats(const Prob* d_probs, const int2* d_rowmap, int n_rows, hipStream_t s);
 void launch_row_stats(const Prob* d_probs, const int2* d_rowmap, int n_rows, hipStream_t s);
-void launch_gram(const Item* d_items, int n_items, int dtype_i8, hipStream_t s);
+// d_b11_done (may be null): items with flag bit 4 count themselves off there when their slabs are out (k_gram.hip)
+void launch_gram(const Item* d_items, int n_items, int dtype_i8, hipStream_t s, unsigned long long* d_b11_done = nullptr);
+// one wave that returns when *d_count >= target (bounded; on timeout status[4 i + 2] = 1 for the job's n_status windows)
+void launch_wait_count(const unsigned long long* d_count, unsigned long long target, int* d_status, int n_status, hipStream_t s);
 void launch_epilogue(const Prob* d_probs, const int2* d_tilemap, int n_tiles, int max_pop, int dtype_i8, hipStream_t s);
 void launch_epilogue_b11_lite(const Prob* d_probs, const int2* d_tilemap, int n_tiles, int dtype_i8, hipStream_t s);
 void launch_pop_cor(const Prob* d_probs, int prob, int npair, double* d_out, hipStream_t s);

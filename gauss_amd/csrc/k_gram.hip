@@ -348,12 +348,9 @@ __device__ __forceinline__ void run_item(const Item& it, uint8_t* lds, int wr, i
 
 // 104 registers at most: four workgroups per CU then leave 96 per lane for the small-footprint kernels that run beside this one
 // (k_solve_lite.hip); the common paths need 104, the 16-column edge path would take 107 if left alone.
-template <typename ACC, int NS, int OCC>
-__global__ __launch_bounds__(256, OCC) __attribute__((amdgpu_num_vgpr(52))) void gram_kernel(const Item* __restrict__ items)
+template <typename ACC, int NS>
+__device__ __forceinline__ void gram_item(const Item& it, uint8_t* lds)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[NS * 2 * LTILE];
-
-    const Item& it = items[blockIdx.x];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = wave >> 1, wc = wave & 1;
 
@@ -383,7 +380,62 @@ __global__ __launch_bounds__(256, OCC) __attribute__((amdgpu_num_vgpr(52))) void
     else run_item<1, 1, ACC, NS>(it, lds, wr, wc);
 }
 
-void launch_gram(const Item* d_items, int n_items, int dtype_i8, hipStream_t s)
+// 104 registers at most: four workgroups per CU then leave 96 per lane for the small-footprint kernels that run beside this one
+// (k_solve_lite.hip); the common paths need 104, the 16-column edge path would take 107 if left alone.
+//
+// `b11_done` (may be null): items with flag bit 4 -- B11's tile pairs of a job whose factorisation chain runs beside this launch
+// (gauss_hip.cpp:job_run) -- count themselves off there when their slabs are out, so that the chain queue can start on B11 while
+// this SAME launch goes on with B21's items: no second launch, no drained chip between the two.  The hand-off follows the
+// producer recipe for data another kernel reads (MI355X_MICROARCH.md, inter-workgroup visibility): every storing wave waits for
+// its stores, the workgroup meets at a barrier, one lane releases at agent scope (writes the XCD L2's dirty lines back), waits
+// for that, and only then adds to the counter; the reader is a LATER KERNEL on the chain queue (its launch is the acquire),
+// started by wait_count_kernel below.
+template <typename ACC, int NS, int OCC>
+__global__ __launch_bounds__(256, OCC) __attribute__((amdgpu_num_vgpr(52))) void gram_kernel(const Item* __restrict__ items,
+                                                                                             unsigned long long* __restrict__ b11_done)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds[NS * 2 * LTILE];
+
+    const Item& it = items[blockIdx.x];
+    const bool counted = (it.flags & 16) != 0;                        // scalar: read before the K loop's memory clobbers
+    gram_item<ACC, NS>(it, lds);
+    if (counted && b11_done) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's slab stores have reached the L2
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");        // buffer_wbl2 sc1: visible to the other XCDs
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the compiler may drop the fence's own wait: guide, compiler hazard)
+            __hip_atomic_fetch_add(b11_done, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// Head of the chain queue in a merged launch: ONE wave that returns when `*count >= target` (the counted items of this run are
+// done; the counter only grows, run r waits for (r + 1) x items, so a stale value of the run before can never satisfy it).  A relaxed agent-scope
+// poll (an sc1 load: served by the L2 / fabric, never by this CU's L1) every ~3 us; the kernels queued behind it start through an
+// ordinary launch, which is their acquire.  Bounded: after `timeout_ticks` of the 100 MHz wall clock it gives up and raises the
+// job's failure flags instead of holding the queue forever (a Gram launch that never ran: the host reports the run as failed).
+__global__ __launch_bounds__(64) void wait_count_kernel(const unsigned long long* __restrict__ count, unsigned long long target,
+                                                        unsigned long long timeout_ticks, int* __restrict__ status, int n_status)
+{
+    if (threadIdx.x != 0) return;
+    __builtin_amdgcn_s_setprio(3);
+    const unsigned long long t0 = wall_clock64();
+    for (;;) {
+        if (__hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return;
+        if (wall_clock64() - t0 > timeout_ticks) break;
+        __builtin_amdgcn_s_sleep(127);
+    }
+    for (int i = 0; i < n_status; i++) status[4 * i + 2] = 1;         // "non-finite": every window of the run is reported failed
+}
+
+void launch_wait_count(const unsigned long long* d_count, unsigned long long target, int* d_status, int n_status, hipStream_t s)
+{
+    const unsigned long long two_seconds = 200000000ull;               // wall_clock64 ticks at 100 MHz
+    hipLaunchKernelGGL(wait_count_kernel, dim3(1), dim3(64), 0, s, d_count, target, two_seconds, d_status, n_status);
+}
+
+void launch_gram(const Item* d_items, int n_items, int dtype_i8, hipStream_t s, unsigned long long* d_b11_done)
 {
     if (n_items <= 0) return;
     // two chunk images (32 KB), four workgroups per CU for both paths.  Deeper rings were measured for the int8
@@ -393,8 +445,8 @@ void launch_gram(const Item* d_items, int n_items, int dtype_i8, hipStream_t s)
 #define GAUSS_I8_NS 2
 #define GAUSS_I8_OCC 4
 #endif
-    if (dtype_i8) hipLaunchKernelGGL((gram_kernel<i32x16, GAUSS_I8_NS, GAUSS_I8_OCC>), dim3(n_items), dim3(256), 0, s, d_items);
-    else hipLaunchKernelGGL((gram_kernel<f32x16, 2, 4>), dim3(n_items), dim3(256), 0, s, d_items);
+    if (dtype_i8) hipLaunchKernelGGL((gram_kernel<i32x16, GAUSS_I8_NS, GAUSS_I8_OCC>), dim3(n_items), dim3(256), 0, s, d_items, d_b11_done);
+    else hipLaunchKernelGGL((gram_kernel<f32x16, 2, 4>), dim3(n_items), dim3(256), 0, s, d_items, d_b11_done);
 }
 
 }  // namespace gauss

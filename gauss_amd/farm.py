@@ -36,13 +36,60 @@ def assign_windows(costs, world_size):
     return owner
 
 
+def _units32(rows, edge16=False):
+    """32-row units the Gram kernel ISSUES for `rows` live rows of ONE operand side, tile by tile (k_gram.hip): every 64-row
+    wave half rounds its live rows up to 32; on the column side a half whose last 32 hold at most 16 live columns works in
+    groups of 16 (the 16-column edge routine) -- the rule gauss_job_stats applies to a built job."""
+    total = 0.0
+    for t0 in range(0, rows, 128):
+        r = min(128, rows - t0)
+        for w in (0, 1):
+            left = r - 64 * w
+            if left <= 0:
+                continue
+            n16 = min(4, (left + 15) // 16)
+            total += n16 * 0.5 if (edge16 and n16 % 2) else min(2, (left + 31) // 32)
+    return total
+
+
+def _b11_units(m):
+    """32 x 32 MFMA tiles the Gram kernel issues for a window's own B11 (upper tile triangle; a diagonal tile skips its mirrored
+    quadrant and the mirrored sub-block of its two diagonal quadrants)."""
+    nt = (m + 127) // 128
+    rows = [min(128, m - 128 * t) for t in range(nt)]
+    total = 0.0
+    for ti in range(nt):
+        a = [min(2, max(0, (rows[ti] - 64 * w + 31) // 32)) for w in (0, 1)]
+        for tj in range(ti, nt):
+            for wr in (0, 1):
+                for wc in (0, 1):
+                    if ti == tj and wr == 1 and wc == 0:
+                        continue
+                    left = rows[tj] - 64 * wc
+                    if left <= 0 or a[wr] == 0:
+                        continue
+                    n16 = min(4, (left + 15) // 16)
+                    if n16 % 2:
+                        total += a[wr] * n16 * 0.5
+                        continue
+                    t32 = a[wr] * min(2, (left + 31) // 32)
+                    total += 3 if (ti == tj and wr == wc and t32 == 4) else t32
+    return total
+
+
+# What the ranks' step times follow (round 4, 8-rank emulation on MI355X: Gram time per ISSUED flop agrees to +-2 % between
+# shares whose algorithmic flops differ by 4.5 %; everything that is not the Gram kernel is 0.58-0.61 ms on every rank): the
+# flops the Gram kernel issues for the rank's pieces -- 128-row tiles with the kernel's 32 / 16 granular edges, B11's tile
+# triangle -- plus 8 % on B21's share for what follows it per entry (B21's epilogue tiles, the closing product).  The
+# factorisation chain runs UNDER the Gram kernel (k_solve_lite.hip), so B11's fp64 work no longer costs a rank time.
+TAIL_PER_B21 = 0.08
+
+
 def piece_cost(n_samples, m, u):
-    """Cost of imputing `u` unmeasured SNPs of a window with `m` measured ones, in fp32-matrix-flop units:
-    (setup, per unmeasured SNP).  The setup -- B11's Gram and its Cholesky factor -- is paid by every rank that
-    holds a piece of the window; fp64 matrix flops are priced at four fp32 ones (78.6 vs 157.3 TFLOP/s peak, and
-    the factor/solve kernels run at about half the Gram kernel's fraction of it)."""
-    setup = float(n_samples) * m * (m + 1.0) + 4.0 * m ** 3 / 3.0
-    per_u = 2.0 * n_samples * m + 8.0 * float(m) * m
+    """Cost of imputing `u` unmeasured SNPs of a window with `m` measured ones, in issued fp32-matrix-flop units:
+    (setup, per unmeasured SNP).  The setup -- B11's tile pairs -- is paid by every rank that holds a piece of the window."""
+    setup = 2048.0 * n_samples * _b11_units(m)
+    per_u = 2.0 * n_samples * 32.0 * _units32(m, edge16=True) * (1.0 + TAIL_PER_B21)
     return setup, per_u
 
 
@@ -98,11 +145,12 @@ def balance_windows(mu, n_samples, world_size, granule=64):
 
 
 # One block step (64 measured SNPs) of a job's factorisation chain in piece_cost units: the chain is as long as the
-# job's tallest window and latency-bound on small jobs (measured on MI355X: 19 us per step against 8.06 ms per 1e12
-# cost units, bench.py --emulate-world fits).  Round 3: with the chain hidden under the Gram kernel (k_solve_lite.hip) the term no longer
-# describes time on the critical path of a large share, but 0, 6e8 and 2.4e9 give the same emulated 8-rank efficiency (0.883-0.891:
-# the ranks' times differ by +-2 % for reasons no flop count explains -- the last round of each rank's Gram launches), so it stays.
-CHAIN_STEP_COST = 2.4e9
+# job's tallest window.  It used to be latency on the critical path of a small job (19 us per step against 8.06 ms per 1e12
+# cost units: 2.4e9); since round 3 it runs UNDER the Gram kernel (k_solve_lite.hip) and costs the rank only the vector
+# instructions it takes from the matrix pipe.  At 2.4e9 the planner kept Gram work away from the ranks that hold the tall windows --
+# 7 % of a rank's load that no longer exists: their Gram kernels finished 4 % early (round 4 emulation) -- so the term is
+# down to a tie-breaker that still steers tall windows onto the same ranks.
+CHAIN_STEP_COST = 2.0e8
 
 
 def level_windows(mu, n_samples, world_size, granule=64):

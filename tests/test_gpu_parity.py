@@ -716,7 +716,9 @@ def test_chain_beside_the_gram_kernel_gives_the_same_bits(ctx, monkeypatch):
     Windows of 2 to 9 factor blocks (M not a multiple of 64), shared and unshared measured rows, a QCAT window, a window
     whose lambda is too small for the certificate (the shifted matrix is factored too), and one whose B11 is not positive
     definite at all (lambda = 0 on duplicated rows: the clamp path reruns it).  Also with the row tables and the certificate made
-    on the side queue (GAUSS_ROWS_ASIDE=1): every reader joins that queue first, so the bits are the same."""
+    on the side queue (GAUSS_ROWS_ASIDE=1): every reader joins that queue first, so the bits are the same.  The chain beside the
+    Gram kernel comes in two launch forms -- ONE Gram launch whose B11 items count themselves off for the chain queue (default,
+    k_gram.hip: wait_count_kernel), or two launches joined by an event (GAUSS_CHAIN_MERGED=0) -- both are driven."""
     p = small_panel(n_snp=2600, scale=0.05, seed=41)
     G = p["G"].copy()
     G[7] = G[3]                                    # two identical SNPs: singular B11 at lambda = 0
@@ -738,7 +740,8 @@ def test_chain_beside_the_gram_kernel_gives_the_same_bits(ctx, monkeypatch):
     wins[4] = dict(wins[4], lam=1e-7)              # no certificate: the exact test factors B11 - eps I as well
     wins[0] = dict(wins[0], lam=0.0)               # singular: status says clamp, the host reruns the window
 
-    def run(aside, share, split=False, rows_aside=False):
+    def run(aside, share, split=False, rows_aside=False, merged=True):
+        monkeypatch.setenv("GAUSS_CHAIN_MERGED", "1" if merged else "0")     # B11's and B21's items as ONE launch (counted items) or two
         monkeypatch.setenv("GAUSS_ROWS_ASIDE", "1" if rows_aside else "0")   # row tables + certificate on the side queue (job_run joins them)
         monkeypatch.setenv("GAUSS_CHAIN_ASIDE", "2" if aside else ("1" if split else "0"))
         monkeypatch.setenv("GAUSS_GRAM_SPLIT", "1" if split else "0")       # two Gram launches, chain behind them (bench's one-stream pass)
@@ -758,7 +761,8 @@ def test_chain_beside_the_gram_kernel_gives_the_same_bits(ctx, monkeypatch):
     for share in (False, True):
         behind = run(False, share)
         assert any(r["status"] != 0 for r in behind)
-        for other in (run(True, share), run(False, share, split=True), run(True, share, rows_aside=True), run(False, share, rows_aside=True)):
+        for other in (run(True, share), run(True, share, merged=False), run(False, share, split=True), run(True, share, rows_aside=True),
+                      run(True, share, rows_aside=True, merged=False), run(False, share, rows_aside=True)):
             for k, (x, y) in enumerate(zip(behind, other)):
                 for key in x:
                     if isinstance(x[key], np.ndarray):
