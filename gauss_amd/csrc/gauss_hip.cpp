@@ -262,8 +262,9 @@ struct Plan {
     std::vector<int> pair_ti, pair_tj, pair_lut;
     std::vector<double> pop_w, pop_wf, pop_md, z1;
     std::vector<uint8_t> word_pop, word_run;
-    std::vector<uint32_t> chunk_half;      // bit per K chunk (Item::chunk_half)
-    std::vector<int> run_pk_off, run_src;
+    std::vector<uint32_t> chunk_live;      // nibble per K chunk (Item::chunk_live)
+    std::vector<int> run_pk_off, run_src, run_len;     // 2-bit source blocks: packed column range, byte offset in a source row, live samples
+    bool run_len_known(size_t q) const { return q < run_len.size(); }
     std::vector<int32_t> rows_m, rows_u;     // store rows; empty = contiguous
     size_t row_bytes = 0;                    // bytes of a source row that the kernels read
     std::vector<int> gene_off;
@@ -525,6 +526,7 @@ static int plan_problem(const WinSpec& w, Plan& pl, int seg_max, int group_targe
             pl.run_pk_off[q + 1] = pl.run_pk_off[q] + blk;
             const long long off = w.pop_src_off ? w.pop_src_off[q] : end;
             pl.run_src.push_back((int)off);
+            pl.run_len.push_back(w.pop_off[q + 1] - w.pop_off[q]);
             if (!w.pop_src_off) end = off + blk / 4;
             pl.row_bytes = std::max(pl.row_bytes, (size_t)(off + blk / 4));
         }
@@ -544,19 +546,22 @@ static int plan_problem(const WinSpec& w, Plan& pl, int seg_max, int group_targe
     p.slab16 = (!no16 && w.geno_fmt == GAUSS_GENO_2BIT && !w.ld_only && !w.gene_off && P <= 32) ? 1 : 0;
     if (p.slab16) seg_max = std::min(seg_max, 7168);
     pl.word_pop.assign(p.Kp / 16, 0);
-    // K chunks whose upper 32 samples are padding: the last chunk of every zero-padded block (a population, or a 2-bit
-    // source block) whose size leaves a remainder of 1..32 samples
-    pl.chunk_half.assign((p.Kp / KC + 31) / 32 + 1, 0u);
-    auto set_half = [&](int chunk) { pl.chunk_half[chunk >> 5] |= 1u << (chunk & 31); };
+    // K chunks that end a zero-padded block (a population, or a 2-bit source block) with fewer than 64 live samples: how many
+    // units of 8 samples are live (Item::chunk_live; 0 = the whole chunk)
+    pl.chunk_live.assign((p.Kp / KC + 7) / 8 + 1, 0u);
+    auto set_live = [&](int chunk, int samples) {
+        const int units = (samples + 7) / 8;
+        if (units >= 1 && units < 8) pl.chunk_live[chunk >> 3] |= (uint32_t)units << (4 * (chunk & 7));
+    };
     if (w.geno_fmt == GAUSS_GENO_2BIT) {
         for (int q = 0; q < w.n_pop; q++) {
             const int m = w.pop_off[q + 1] - w.pop_off[q], rem = m % KC;
-            if (m > 0 && rem >= 1 && rem <= 32) set_half(pl.run_pk_off[q + 1] / KC - 1);
+            if (m > 0 && rem) set_live(pl.run_pk_off[q + 1] / KC - 1, rem);
         }
     } else {
         for (int q = 0; q < P; q++) {
             const int m = pl.pop_raw_off[q + 1] - pl.pop_raw_off[q], rem = m % KC;
-            if (m > 0 && rem >= 1 && rem <= 32) set_half(pl.pop_pk_off[q + 1] / KC - 1);
+            if (m > 0 && rem) set_live(pl.pop_pk_off[q + 1] / KC - 1, rem);
         }
     }
     pl.pop_seg0.assign(P + 1, 0);
@@ -799,7 +804,7 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
         to[i].rsrc = put(blob, ta, pl.run_src);
         to[i].rm = put(blob, ta, pl.rows_m);
         to[i].ru = put(blob, ta, pl.rows_u);
-        to[i].ch = put(blob, ta, pl.chunk_half);
+        to[i].ch = put(blob, ta, pl.chunk_live);
     }
     // work lists
     struct ItemH { int prob, pair, group, len; };
@@ -1243,7 +1248,7 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
         it.b = tile_rows(tj);
         it.slab = p.slab + ((size_t)h.pair * p.nseg + gr.first) * (p.slab16 ? TILE * TILE / 2 : TILE * TILE);
         it.seg_k1 = p.seg_k1 + gr.first;
-        it.chunk_half = (const uint32_t*)(job->d_tab + to[h.prob].ch);
+        it.chunk_live = (const uint32_t*)(job->d_tab + to[h.prob].ch);
         it.Kp = p.Kp; it.k0 = pl.seg_k0[gr.first]; it.nseg = gr.second - gr.first;
         static const int no_edge16 = env_int("GAUSS_GRAM_EDGE16", 1) == 0 ? 8 : 0;
         it.rows_a = rows(ti); it.rows_b = rows(tj); it.flags = (ti == tj ? 1 : 0) | (p.slab16 ? 2 : 0) | no_edge16;
@@ -2325,12 +2330,28 @@ int gauss_job_stats(gauss_job* job, double* out4)
         const int mt = p.Mp / TILE;
         auto rows = [&](int t) { int left = (t < mt) ? p.M - t * TILE : p.U - (t - mt) * TILE; return left > TILE ? TILE : left; };
         auto halves = [](int r, int w) { int n = (r - w * 64 + 31) / 32; return n < 0 ? 0 : (n > 2 ? 2 : n); };
+        // samples per row the kernel multiplies: every zero-padded block (population, or 2-bit source block) rounded up to
+        // the units the K loop can skip -- 8 samples on the f32 path (Item::chunk_live), 32 on the int8 path (whole groups);
+        // the 16-column edge routine takes every chunk whole
+        double k_main = 0;
+        {
+            const int gran = job->gram_i8 ? 32 : 8;
+            const std::vector<int>& blk = (p.geno_fmt == GAUSS_GENO_2BIT && !pl.run_pk_off.empty()) ? pl.run_pk_off : pl.pop_pk_off;
+            const bool runs = &blk == &pl.run_pk_off;
+            for (size_t q = 0; q + 1 < blk.size(); q++) {
+                // live samples of the block: its real size where known (populations), else its padded size
+                int live = blk[q + 1] - blk[q];
+                if (!runs && q + 1 < pl.pop_raw_off.size()) live = pl.pop_raw_off[q + 1] - pl.pop_raw_off[q];
+                else if (runs && pl.run_len_known(q)) live = pl.run_len[q];
+                k_main += (double)((live + gran - 1) / gran * gran);
+            }
+        }
         int pairs = 0;
         for (int pr = 0; pr < p.npair; pr++) {
             const int ti = pl.pair_ti[pr], tj = pl.pair_tj[pr];
             if (skip_b11 && ti < mt) continue;               // multiplied once, on the job-wide tiles
             pairs++;
-            double tiles32 = 0;
+            double tiles32 = 0, tiles_edge = 0;
             for (int wr = 0; wr < 2; wr++)
                 for (int wc = 0; wc < 2; wc++) {
                     if (ti == tj && wr == 1 && wc == 0) continue;
@@ -2339,12 +2360,12 @@ int gauss_job_stats(gauss_job* job, double* out4)
                     // (k_gram.hip, chunk_mfma_edge): 1 or 3 of them
                     int nb16 = (rows(tj) - wc * 64 + 15) / 16;
                     nb16 = nb16 < 0 ? 0 : (nb16 > 4 ? 4 : nb16);
-                    if (edge16 && !job->gram_i8 && na > 0 && (nb16 & 1)) { tiles32 += na * nb16 * 0.5; continue; }
+                    if (edge16 && !job->gram_i8 && na > 0 && (nb16 & 1)) { tiles_edge += na * nb16 * 0.5; continue; }
                     double t32 = na * halves(rows(tj), wc);
                     if (ti == tj && wr == wc && t32 == 4) t32 = 3;      // mirrored 32 x 32 sub-block of a diagonal quadrant
                     tiles32 += t32;
                 }
-            flops += tiles32 * 32.0 * 32.0 * 2.0 * p.Kp;
+            flops += 32.0 * 32.0 * 2.0 * (tiles32 * k_main + tiles_edge * p.Kp);
         }
         slab += (double)pairs * p.nseg * TILE * TILE * (p.slab16 ? sizeof(uint16_t) : sizeof(float));
     };

@@ -9,6 +9,11 @@ namespace gauss {
 
 constexpr int TILE = 128;      // Gram output tile edge per workgroup (4 waves x 64x64)
 constexpr int KC = 64;         // packed K chunk in bytes (= samples); pops are padded to it
+// chunk_unit_layout: inside every 32-sample group of a packed row the eight dwords (4 samples each) are stored transposed --
+// sample dword d = 2 q + h sits at position 4 h + q -- so that the two lane halves of the 32 x 32 x 2 MFMA (half h reads bytes
+// 16 h .. 16 h + 15 of the group) meet samples 8 q .. 8 q + 7 of the group in their dword q: a population whose last chunk
+// holds r live samples needs only the first ceil(r / 8) dword steps of it (Item::chunk_live).  Sums over k do not depend on
+// the order, every row is stored the same way, and nothing but the Gram kernels reads packed rows.
 constexpr int SEG_MAX = 2048;  // K segment cap for small jobs (< 4 windows); larger jobs use 4096 (seg_max_for); any cap up to 8192
                                // keeps a partial sum below 2^24 (15 * 15 * 8192), the exactness bound of the f32 accumulators
 constexpr int NB = 64;         // fp64 factor / solve block edge
@@ -125,9 +130,11 @@ struct Item {
     GP(const uint8_t) b;     // packed rows of tile tj
     GP(float) slab;          // slab of (pair, first segment of the run); later segments follow
     GP(const int) seg_k1;    // end column of each segment of the run
-    GP(const uint32_t) chunk_half; // bit c (word c / 32, bit c % 32) 1: only the first 32 samples of K chunk c are live (the
-                             // rest is the zero padding that ends a population block): half of the chunk's MFMAs are not
-                             // issued.  Dwords, read through the scalar cache (UNIFORM_I32 / chunk_is_half below)
+    GP(const uint32_t) chunk_live; // nibble c (word c / 8, bits 4 (c % 8) ..): 0 = all 64 samples of K chunk c are live; n = 1..7:
+                             // only the chunk's first n UNITS of 8 samples are (the rest is the zero padding that ends a population
+                             // block).  The pack kernel stores every 32-sample group dword-transposed (chunk_unit_layout below), which
+                             // puts unit u of a chunk into dword u % 4 of BOTH lane halves of group u / 4 -- the MFMAs of a dead
+                             // unit are not issued.  Dwords, read through the scalar cache (uniform_load)
     int Kp;                  // packed row stride
     int k0;                  // first column of the run
     int nseg;                // segments in the run
@@ -154,9 +161,11 @@ __device__ __forceinline__ T uniform_load(GP(const T) p, int idx)
 {
     return ((const T __attribute__((address_space(4)))*)p)[idx];
 }
-__device__ __forceinline__ bool chunk_is_half(GP(const uint32_t) bits, int chunk)
+// live units (1..8) of K chunk `chunk` from the nibble table
+__device__ __forceinline__ int chunk_live_units(uint32_t word, int chunk)
 {
-    return (uniform_load<uint32_t>(bits, chunk >> 5) >> (chunk & 31)) & 1u;
+    const int n = (int)((word >> (4 * (chunk & 7))) & 15u);
+    return n ? n : 8;
 }
 #endif
 

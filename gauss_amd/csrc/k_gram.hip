@@ -52,7 +52,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int NA, int NB, bool SK10>
 __device__ __forceinline__ void chunk_mfma(const uint8_t* __restrict__ la, const uint8_t* __restrict__ lb,
                                            const int (&aoff)[2], const int (&boff)[2], f32x16& acc00, f32x16& acc01,
-                                           f32x16& acc10, f32x16& acc11, bool half)
+                                           f32x16& acc10, f32x16& acc11, int nl)
 {
 #define GAUSS_MFMA_PAIR(AW0, AW1, BW0, BW1, HI)                                                       \
     {                                                                                                  \
@@ -72,7 +72,7 @@ __device__ __forceinline__ void chunk_mfma(const uint8_t* __restrict__ la, const
     }
 #pragma unroll
     for (int g = 0; g < 2; g++) {
-        if (g == 1 && half) break;         // samples 32..63 of the chunk are padding zeros (wave-uniform)
+        if (4 * g >= nl) break;            // units 4 g .. of the chunk are padding zeros (wave-uniform; nl = live units of 8 samples)
         const u32x4 a0 = *reinterpret_cast<const u32x4*>(la + aoff[g]);
         const u32x4 b0 = *reinterpret_cast<const u32x4*>(lb + boff[g]);
         u32x4 a1 = a0, b1 = b0;
@@ -84,6 +84,7 @@ __device__ __forceinline__ void chunk_mfma(const uint8_t* __restrict__ la, const
         const uint32_t bw1[4] = {b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
         for (int q = 0; q < 4; q++) {
+            if (4 * g + q >= nl) break;    // dword q of both lane halves = unit 4 g + q (gauss_internal.h: chunk_unit_layout)
             GAUSS_MFMA_PAIR(aw0[q], aw1[q], bw0[q], bw1[q], false)
             GAUSS_MFMA_PAIR(aw0[q], aw1[q], bw0[q], bw1[q], true)
         }
@@ -100,11 +101,11 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 template <int NA, int NB, bool SK10>
 __device__ __forceinline__ void chunk_mfma(const uint8_t* __restrict__ la, const uint8_t* __restrict__ lb,
                                            const int (&aoff)[2], const int (&boff)[2], i32x16& acc00, i32x16& acc01,
-                                           i32x16& acc10, i32x16& acc11, bool half)
+                                           i32x16& acc10, i32x16& acc11, int nl)
 {
 #pragma unroll
     for (int g = 0; g < 2; g++) {
-        if (g == 1 && half) break;
+        if (4 * g >= nl) break;            // (the instruction takes a lane's 16 bytes whole: only a dead group can be skipped)
         const i32x4 a0 = *reinterpret_cast<const i32x4*>(la + aoff[g]);
         const i32x4 b0 = *reinterpret_cast<const i32x4*>(lb + boff[g]);
         acc00 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b0, acc00, 0, 0, 0);
@@ -246,7 +247,7 @@ __device__ __forceinline__ void run_item(const Item& it, uint8_t* lds, int wr, i
     // descriptor fields as values: the asm waits in the K loop clobber memory, a field read through `it` would be
     // fetched again every chunk
     const auto seg_k1 = it.seg_k1;
-    const auto half_bits = it.chunk_half;
+    const auto live_tab = it.chunk_live;
     const int klast = uniform_load<int>(seg_k1, nseg - 1);
     auto out = it.slab;
     const int obase = (wr * 64 + 4 * lh) * TILE + wc * 64 + li;
@@ -296,8 +297,8 @@ __device__ __forceinline__ void run_item(const Item& it, uint8_t* lds, int wr, i
     }
 
     int k = k0;
-    uint32_t hbits = uniform_load<uint32_t>(half_bits, k0 >> 11);       // half-chunk flags, 32 chunks per dword
-    bool half_next = (hbits >> ((k0 >> 6) & 31)) & 1u;
+    uint32_t lbits = uniform_load<uint32_t>(live_tab, k0 >> 9);         // live units per chunk, 8 chunks per dword
+    int nl_next = chunk_live_units(lbits, k0 >> 6);
     for (int seg = 0; seg < nseg; seg++) {
         const int kend = uniform_load<int>(seg_k1, seg);
         for (; k < kend; k += KC) {
@@ -312,13 +313,13 @@ __device__ __forceinline__ void run_item(const Item& it, uint8_t* lds, int wr, i
             }
             const uint8_t* la = lds + cur * 2 * LTILE;
             const uint8_t* lb = la + LTILE;
-            const bool half = half_next;
+            const int nl = nl_next;
             if (k + KC < klast) {
                 const int c1 = (k + KC) >> 6;
-                if ((c1 & 31) == 0) hbits = uniform_load<uint32_t>(half_bits, c1 >> 5);      // scalar load, once per 32 chunks
-                half_next = (hbits >> (c1 & 31)) & 1u;
+                if ((c1 & 7) == 0) lbits = uniform_load<uint32_t>(live_tab, c1 >> 3);        // scalar load, once per 8 chunks
+                nl_next = chunk_live_units(lbits, c1);
             }
-            if (NA > 0 && NB > 0) chunk_mfma<NA, (NB > 0 ? NB : 1), SK10>(la, lb, aoff, boff, acc00, acc01, acc10, acc11, half);
+            if (NA > 0 && NB > 0) chunk_mfma<NA, (NB > 0 ? NB : 1), SK10>(la, lb, aoff, boff, acc00, acc01, acc10, acc11, nl);
             if (BE) chunk_mfma_edge<(NA > 0 ? NA : 1), (BE ? NC : 1)>(la, lb, eoffa, eoffb, acce);
             wait_dma_barrier_dyn<NS>(ahead - 1);         // next chunk landed; everyone is done reading this one
             if (ahead > 0) ahead--;

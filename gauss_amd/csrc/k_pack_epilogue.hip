@@ -104,7 +104,17 @@ __global__ __launch_bounds__(256) void pack_stats_kernel(const Prob* __restrict_
             }
             v[q] = c;
         }
-        if (live) dst[w] = make_uint4(v[0], v[1], v[2], v[3]);
+        // chunk_unit_layout (gauss_internal.h): the eight dwords of a 32-sample group leave transposed -- this word (even w:
+        // sample dwords 0..3 of the group, odd w: 4..7) keeps two of its dwords and trades the other two with the neighbouring
+        // lane, which holds the group's other word: even words end up with sample dwords 0, 2, 4, 6, odd ones with 1, 3, 5, 7.
+        // (Groups start on even words: blocks are padded to 64 samples.  Lane pairs are always in the loop together.)
+        {
+            const bool odd = (w & 1) != 0;
+            const uint32_t s0 = odd ? v[0] : v[1], s1 = odd ? v[2] : v[3];
+            const uint32_t r0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s0, 0xB1, 0xF, 0xF, true);    // quad_perm [1, 0, 3, 2]: lane ^ 1
+            const uint32_t r1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s1, 0xB1, 0xF, 0xF, true);
+            if (live) dst[w] = odd ? make_uint4(r0, r1, v[1], v[3]) : make_uint4(v[0], v[2], r0, r1);
+        }
         // per-population sums: the 64 lanes of a wave cover 1 KiB of one row, almost always inside one
         // population -- reduce across the wave first instead of 64 colliding LDS atomics
         const int p0 = __builtin_amdgcn_readfirstlane(p);
