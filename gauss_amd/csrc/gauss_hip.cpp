@@ -1354,7 +1354,10 @@ static int job_run(gauss_job* job, bool solve)
         HIPCHK(hipStreamWaitEvent(rs, ev.pack, 0));
     }
     launch_row_stats(job->d_probs, job->d_rowmap, job->n_rows, rs);
-    if (solve && job->n_panels > 0) launch_shift_cert(job->d_probs, job->n, rs);      // needs the row tables only
+    // the certificate needs the row tables only and is read by B11's epilogue tiles and the chain: in a merged launch it
+    // moves to the head of the chain queue, beside the Gram kernel's start (23 us off the main queue's critical path)
+    const bool cert_on_chain = solve && job->chain_aside && job->merged && rs == st;
+    if (solve && job->n_panels > 0 && !cert_on_chain) launch_shift_cert(job->d_probs, job->n, rs);
     if (rs != st) HIPCHK(hipEventRecord(ev.rows, rs));
     prof_end(job, st);
     if (solve && job->chain_aside) {
@@ -1380,6 +1383,7 @@ static int job_run(gauss_job* job, bool solve)
             job->merged_runs++;                            // counted per LAUNCH, not per completed call: a later error must not shift the target
             prof_end(job, st);
             HIPCHK(hipStreamWaitEvent(ch, ev.gram, 0));
+            if (cert_on_chain) launch_shift_cert(job->d_probs, job->n, ch);
             launch_wait_count(job->d_b11_done, job->merged_runs * (unsigned long long)job->n_items_b11, job->d_status + 4 * job->n, 1, ch);
         } else {
         prof_begin(job, 0, st, 2);
@@ -1410,10 +1414,13 @@ static int job_run(gauss_job* job, bool solve)
         launch_solve_last_lite(job->d_probs, job->d_panelmap, job->n_panels, job->max_nblk, job->solve_split, ch);
         prof_end(job, ch);
         HIPCHK(hipEventRecord(ev.side, ch));
+        // (the epilogue reads status[3], which the chain queue wrote in that case: join first -- the chain has long finished
+        // when the Gram kernel ends, or the job would not have taken this path)
+        if (cert_on_chain) HIPCHK(hipStreamWaitEvent(st, ev.side, 0));
         prof_begin(job, 2, st);
         launch_epilogue(job->d_probs, job->d_tilemap + job->n_tiles_b11, job->n_tiles - job->n_tiles_b11, job->max_pop, job->gram_i8, st);
         prof_end(job, st);
-        HIPCHK(hipStreamWaitEvent(st, ev.side, 0));
+        if (!cert_on_chain) HIPCHK(hipStreamWaitEvent(st, ev.side, 0));
         prof_begin(job, 4, st);
         launch_impute_gemm(job->d_probs, job->d_gemmmap, job->n_gemm, job->gemm_ut, job->d_finmap, job->n_fin, st);
         prof_end(job, st);

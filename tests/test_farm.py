@@ -111,10 +111,10 @@ sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests")
 import torch.distributed as dist
 from gauss_amd import api, farm
 from test_farm import oracle_compute, WGT
-dist.init_process_group("gloo", init_method="tcp://127.0.0.1:{port}", rank=int(sys.argv[1]), world_size=2)
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:{port}", rank=int(sys.argv[1]), world_size={world})
 files = pickle.load(open({files!r}, "rb"))
 res = farm.impute_chromosome(api.KIND_DISTMIX, 22, 1_000_001, 4_000_000, 200_000, pop_wgt_df=WGT,
-                             compute=oracle_compute, window_size=500_000, **files)
+                             compute=oracle_compute, window_size={window}, **files)
 if dist.get_rank() == 0:
     pickle.dump(dict(bp=list(res["table"]["bp"]), z=list(res["table"]["z"]), owner=res["owner"],
                      skipped=res["skipped"]), open({out!r}, "wb"))
@@ -125,24 +125,29 @@ dist.destroy_process_group()
 """
 
 
-def test_farm_two_ranks_gloo_equals_one_rank(tmp_path):
+@pytest.mark.parametrize("world,window", [(2, 500_000), (8, 250_000)])
+def test_farm_ranks_gloo_equal_one_rank(tmp_path, world, window):
+    """One process per rank over gloo, windows sharded with no data-path collective: the gathered table equals the one-rank
+    table bit for bit.  World 2, and world 8 -- the node size of BASELINE.json configs[3] (eight real processes, twelve
+    windows: the rendezvous, the plan every rank derives for itself and the gather at the size the driver's SCALE run uses;
+    the GPU box admits at most 6 processes on its card, so the 8-rank case can only be rehearsed on the CPU)."""
     import pickle
     st = make_study(tmp_path)
     p = st["paths"]
     files = dict(input_file=p["gwas.txt"], reference_index_file=p["index.gz"], reference_data_file=p["data.gz"],
                  reference_pop_desc_file=p["desc.txt"])
     one = farm.impute_chromosome(api.KIND_DISTMIX, 22, 1_000_001, 4_000_000, 200_000, pop_wgt_df=WGT,
-                                 compute=oracle_compute, window_size=500_000, **files)
+                                 compute=oracle_compute, window_size=window, **files)
     fpath, opath = str(tmp_path / "files.pkl"), str(tmp_path / "out.pkl")
     pickle.dump(files, open(fpath, "wb"))
-    port = 29500 + (os.getpid() % 2000)
+    port = 29500 + (os.getpid() % 2000) + world
     script = str(tmp_path / "worker.py")
-    open(script, "w").write(WORKER.format(root=ROOT, port=port, files=fpath, out=opath))
-    procs = [subprocess.Popen([sys.executable, script, str(r)]) for r in range(2)]
+    open(script, "w").write(WORKER.format(root=ROOT, port=port, files=fpath, out=opath, world=world, window=window))
+    procs = [subprocess.Popen([sys.executable, script, str(r)]) for r in range(world)]
     for pr in procs:
         assert pr.wait(timeout=300) == 0
     two = pickle.load(open(opath, "rb"))
-    assert sorted(set(two["owner"])) == [0, 1]                    # both ranks really had windows
+    assert sorted(set(two["owner"])) == list(range(world))        # every rank really had windows
     assert two["bp"] == list(one["table"]["bp"])
     assert np.array_equal(np.array(two["z"]), one["table"]["z"].to_numpy())
     assert two["skipped"] == one["skipped"]
