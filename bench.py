@@ -67,6 +67,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-weak-line", action="store_true", help="N > 1, strong: skip the extra weak-scaling pass")
     ap.add_argument("--verify-shards", action="store_true",
                     help="N > 1, strong: rank 0 also runs every window itself and checks the ranks' z / info bit for bit")
+    ap.add_argument("--no-from-text", action="store_true", help="end_to_end: skip the leg that starts from a BGZF TEXT panel")
+    ap.add_argument("--text-snps", type=int, default=20_000, help="end_to_end.from_text: SNPs of the text panel")
+    ap.add_argument("--no-tails-alone", action="store_true", help="skip the one-stream pass that times the fp64 tails and the HBM-bound kernels stand-alone (probes)")
     ap.add_argument("--no-e2e", action="store_true", help="N = 1: skip the end_to_end block (files on disk -> result table)")
     ap.add_argument("--emulate-world", type=int, default=-1,
                     help="single GPU: time every rank's share of an N-rank strong-scaling run one after the other "
@@ -417,7 +420,7 @@ def run_impute(args, rig):
     # chain on the library's side stream, so their stage timers overlap; a short pass on a one-stream context gives
     # the stand-alone figures `roofline_solve` quotes (never `value`)
     tails_alone = None
-    if rig.world == 1 and rig.rank == 0 and runner.jobs:
+    if rig.world == 1 and rig.rank == 0 and runner.jobs and not args.no_tails_alone:
         from gauss_amd import hotpath
         old_env = os.environ.get("GAUSS_SIDE_STREAM")
         os.environ["GAUSS_SIDE_STREAM"] = "0"

@@ -114,6 +114,92 @@ def e2e_measure(rig, ch, files, steps, wing, n_batches=0):
     return cold_s, cold, warm, res
 
 
+def from_text_block(rig, ch, files, tmp, wing, n_snp=20_000, warm_runs=3):
+    """The reference's OWN on-disk format at chromosome scale (gauss.cpp:293-399, 720-785: BGZF text index + data, one ~33 kB
+    line per SNP): the first `n_snp` SNPs of the study's panel written as a BGZF text panel (all 29 populations, N = 32 953),
+    then text -> packed panel in the cache (the feeder: inflate + parse + 2-bit pack) -> upload -> distmix over its windows,
+    cold and warm.  Harness only: the genotype rows are the ones write_study_files made."""
+    import zlib
+    n = int(min(n_snp, len(ch["bp"])))
+    pops_all = files["pops_all"]
+    sizes = [q[1] for q in pops_all]
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        cores = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    G = panel.unpack2bit(files["rows2bit"][:n], sizes)
+    idx, dat = os.path.join(tmp, "text_index.gz"), os.path.join(tmp, "text_data.gz")
+    inflated = panel.write_panel_fast(idx, dat, files["rsid"][:n], np.full(n, 22), ch["bp"][:n], files["a1"][:n], files["a2"][:n], G,
+                                      files["af"][:n], sizes, threads=min(16, cores))
+    del G
+    m = np.nonzero(ch["measured"][:n])[0]
+    gwas = os.path.join(tmp, "text_gwas.txt")
+    panel.write_gwas(gwas, files["rsid"][m], np.full(len(m), 22), ch["bp"][m], files["a1"][m], files["a2"][m], ch["z"][m])
+    make_s = time.perf_counter() - t0
+    # what plain zlib inflates on one core (the feeder's inflate is this plus parsing and packing): the first members
+    raw = open(dat, "rb").read(64 << 20)
+    t0 = time.perf_counter()
+    got, pos, members = 0, 0, 0
+    while pos + 18 <= len(raw) and members < 400:
+        bsize = int.from_bytes(raw[pos + 16:pos + 18], "little") + 1
+        if pos + bsize > len(raw):
+            break
+        got += len(zlib.decompress(raw[pos + 18:pos + bsize - 8], -15))
+        pos += bsize
+        members += 1
+    zlib_rate = got / max(time.perf_counter() - t0, 1e-9)
+    old_cache = os.environ.get("GAUSS_PANEL_CACHE")
+    os.environ["GAUSS_PANEL_CACHE"] = os.path.join(tmp, "panel_cache")
+    try:
+        sa = study_args(ch, files)
+        lo, _ = chromosome_span(ch)
+        kw = dict(chr=22, start_bp=lo, end_bp=int(ch["bp"][n - 1]), wing_size=wing, input_file=gwas, reference_index_file=idx,
+                  reference_data_file=dat, reference_pop_desc_file=files["desc"], ctx=rig.ctx, **sa)
+
+        def once():
+            t = time.perf_counter()
+            r = api.impute_chromosome(**kw)
+            return time.perf_counter() - t, r
+        api.panel_evict(ctx=rig.ctx)
+        t0 = time.perf_counter()
+        packed_path, n_packed = api.panel_cache(idx, dat, files["desc"])          # the feeder: text -> packed panel (first use)
+        pack_s = time.perf_counter() - t0
+        cold_s, cold = once()                                                   # cached, not resident: upload + impute
+        warm = []
+        res = cold
+        for _ in range(warm_runs):
+            t, res = once()
+            warm.append(t)
+        api.panel_evict(ctx=rig.ctx)
+    finally:
+        if old_cache is None:
+            os.environ.pop("GAUSS_PANEL_CACHE", None)
+        else:
+            os.environ["GAUSS_PANEL_CACHE"] = old_cache
+    threads = min(16, cores)
+    imputed = int(res.stats["imputed"])
+    z = res.columns["z"]
+    return {
+        "what": f"BGZF text panel in the reference's format ({n} SNPs x {int(sum(sizes))} samples, 29 populations: "
+                f"{inflated / 1e6:.0f} MB of text in {(os.path.getsize(dat) + os.path.getsize(idx)) / 1e6:.0f} MB of BGZF) + GWAS text file -> "
+                "gauss_host_impute_chromosome: packed into the panel cache on first use, uploaded, distmix over every 1 Mb window",
+        "snps": n, "samples": int(sum(sizes)), "inflated_text_bytes": int(inflated), "packed_snps": int(n_packed),
+        "pack_s": pack_s, "pack_threads": threads,
+        "feeder_inflated_MB_per_s": inflated / pack_s / 1e6, "feeder_inflated_MB_per_s_per_core": inflated / pack_s / 1e6 / threads,
+        "zlib_inflate_alone_MB_per_s_one_core": zlib_rate / 1e6,
+        "feeder_over_zlib_per_core": (inflated / pack_s / threads) / zlib_rate if zlib_rate > 0 else None,
+        "ms_per_snp_line": pack_s / n * 1e3,
+        "cold_from_text_s": pack_s + cold_s, "cold_cached_not_resident_s": cold_s, "warm_s_median": float(np.median(warm)), "warm_s_all": warm,
+        "imputed_snps": imputed, "table_rows": int(len(z)), "all_finite": bool(np.all(np.isfinite(z))),
+        "same_table_cold_and_warm": bool(np.array_equal(cold.columns["z"], res.columns["z"])),
+        "imputed_snps_per_s_cold_from_text": imputed / (pack_s + cold_s), "imputed_snps_per_s_warm": imputed / float(np.median(warm)),
+        "make_files_s": make_s,
+        "note": "pack_s is paid once per panel (the cache is keyed by the three files' identity); zlib_inflate_alone is Python's zlib "
+                "on the same members, one core, no parsing",
+    }
+
+
 def e2e_block(args, rig, ch=None, steps=5):
     """The end_to_end object of the bench line: a chr22-sized packed panel FILE (100 000 SNPs x 32 953 samples, 29
     populations) and the GWAS text file on disk -> distmix over all 1 Mb windows -> one result table.  Never the
@@ -150,6 +236,8 @@ def e2e_block(args, rig, ch=None, steps=5):
                 "stats_last_warm_run": st, "stats_cold_run": cold.stats if cold is not None else None,
                 "make_files_s": make_s,
             }
+            if rig.world == 1 and not getattr(args, "no_from_text", False):
+                blk["from_text"] = from_text_block(rig, ch, files, tmp, args.wing, n_snp=getattr(args, "text_snps", 20_000))
     finally:
         rig.barrier()
         if rig.rank == 0:

@@ -1353,7 +1353,6 @@ static int job_run(gauss_job* job, bool solve)
         HIPCHK(hipEventRecord(ev.pack, st));
         HIPCHK(hipStreamWaitEvent(rs, ev.pack, 0));
     }
-    launch_row_stats(job->d_probs, job->d_rowmap, job->n_rows, rs);
     // the certificate needs the row tables only and is read by B11's epilogue tiles and the chain: in a merged launch it
     // moves to the head of the chain queue, beside the Gram kernel's start (23 us off the main queue's critical path)
     const bool cert_on_chain = solve && job->chain_aside && job->merged && rs == st;
@@ -1600,7 +1599,6 @@ static int job_run_streamed(gauss_job* job, StreamSetup& su)
         hipStream_t ps = pack_aside ? ax : st;
         HIPCHK(hipStreamWaitEvent(ps, su.ev[g], 0));
         launch_pack_stats(job->d_probs, job->d_rowmap + sg.row0, sg.n_rows, ps);
-        launch_row_stats(job->d_probs, job->d_rowmap + sg.row0, sg.n_rows, ps);
         if (g == 0) launch_shift_cert(job->d_probs, job->n, ps);
         if (ps != st) {
             HIPCHK(hipEventRecord(job->sevp[g], ps));

@@ -2422,6 +2422,10 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
         if (!panel_is_resident(ctx, reference_data_file, &dev_probe)) nthreads = std::min(nthreads, 4);
     }
     if (const char* e = getenv("GAUSS_CHROM_THREADS")) nthreads = std::max(1, atoi(e));
+    // the result tables are built after the upload has finished: they keep the full count (a first call built its tables on the
+    // four threads meant for the time of the upload: 20 ms of tables instead of 11)
+    int nthreads_tables = (int)std::max(1u, std::min(8u, (hw ? hw : 4u) / (unsigned)std::max(1, std::min(world, 8))));
+    if (const char* e = getenv("GAUSS_CHROM_THREADS")) nthreads_tables = std::max(1, atoi(e));
     // One pool over ALL windows in batch order (not one fork-join per batch: a batch of five windows would leave
     // eleven of sixteen threads idle); a batch is ready when its last window is.
     std::vector<std::pair<int, int>> order;                       // (batch, slot)
@@ -2557,7 +2561,7 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
             }
         }
         double tt = now_s();
-        parallel_for((int)slots[b].size(), nthreads, [&](int k) {
+        parallel_for((int)slots[b].size(), nthreads_tables, [&](int k) {
             Slot& sl = slots[b][k];
             if (!sl.ok) return;
             gauss_table* t = nullptr;

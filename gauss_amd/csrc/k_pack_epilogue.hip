@@ -194,77 +194,63 @@ __global__ __launch_bounds__(256) void pack_stats_kernel(const Prob* __restrict_
         }
     }
     __syncthreads();
-    if (threadIdx.x < pb.P) {
-        (um ? pb.sx_u : pb.sx)[(size_t)prow * pb.P + threadIdx.x] = s_sx[threadIdx.x];
-        (um ? pb.sxx_u : pb.sxx)[(size_t)prow * pb.P + threadIdx.x] = s_sxx[threadIdx.x];
+    const int P = pb.P;
+    if (threadIdx.x < P) {
+        (um ? pb.sx_u : pb.sx)[(size_t)prow * P + threadIdx.x] = s_sx[threadIdx.x];
+        (um ? pb.sxx_u : pb.sxx)[(size_t)prow * P + threadIdx.x] = s_sxx[threadIdx.x];
+    }
+    // ---- the row's fp64 tables (K1b: what row_stats_kernel did in a launch of its own; the sums are in LDS right here) ----
+    //  weighted (CalWgtCov(x,x), distmix.cpp:180-187 / computeLD.cpp:100-103):
+    //     rt_mu[p]  = sumx_p / m_p            rt_wmu[p] = w_p * (sumx_p / m_p)
+    //     rt_wm     = sum_p w_p * mu_p        rt_sd     = sqrt(CalWgtCov(x,x))
+    //  pooled (CalCor, util.cpp:66-67):
+    //     rt_wm = sumx (all samples)          rt_sd = sqrt(n*sumxsq - sumx*sumx)
+    // Every population's terms are formed by a lane of its own -- the same expressions, operation for operation -- and one
+    // lane adds them in population order, as the reference's loop does (util.cpp:113-122): the same bits.
+    const auto rt_wm = um ? pb.rt_wm_u : pb.rt_wm;
+    const auto rt_sd = um ? pb.rt_sd_u : pb.rt_sd;
+    if (pb.mode == 0) {
+        if (threadIdx.x == 0) {
+            double sumx = 0, sumxsq = 0;
+            int num_samples = 0;
+            for (int p = 0; p < P; p++) {
+                sumx += (double)s_sx[p];
+                sumxsq += (double)s_sxx[p];
+                num_samples += pb.pop_raw_off[p + 1] - pb.pop_raw_off[p];
+            }
+            rt_wm[prow] = sumx;
+            rt_sd[prow] = sqrt((num_samples) * sumxsq - sumx * sumx);
+        }
+        return;
+    }
+    __shared__ double s_cov[64], s_mm[64], s_wmu[64];
+    if (threadIdx.x < P) {
+        const int p = threadIdx.x;
+        const int m = pb.pop_raw_off[p + 1] - pb.pop_raw_off[p];
+        const double wgt_val = pb.pop_w[p];
+        const double sumx = (double)s_sx[p];
+        const double sumxy = (double)s_sxx[p];
+        const double factor = ((double)m) / (m - 1);
+        s_cov[p] = wgt_val * factor * (m * sumxy - sumx * sumx);          // util.cpp:118
+        const double mu = sumx / m;
+        const double wmu = wgt_val * mu;
+        s_mm[p] = wmu * mu;                                               // util.cpp:119
+        s_wmu[p] = wmu;
+        (um ? pb.rt_mu_u : pb.rt_mu)[(size_t)prow * P + p] = mu;
+        (um ? pb.rt_wmu_u : pb.rt_wmu)[(size_t)prow * P + p] = wmu;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double wsumcov = 0, wsum_mi_mj = 0, wsum_mi = 0;
+        for (int p = 0; p < P; p++) { wsumcov += s_cov[p]; wsum_mi_mj += s_mm[p]; wsum_mi += s_wmu[p]; }
+        rt_wm[prow] = wsum_mi;
+        rt_sd[prow] = sqrt(wsumcov + wsum_mi_mj - wsum_mi * wsum_mi);     // util.cpp:123; distmix.cpp:181-182
     }
 }
 
 void launch_pack_stats(const Prob* d_probs, const int2* d_rowmap, int n_rows, hipStream_t s)
 {
     if (n_rows > 0) hipLaunchKernelGGL(pack_stats_kernel, dim3(n_rows), dim3(256), 0, s, d_probs, d_rowmap);
-}
-
-// ------------------------------------------------------------------------------------------
-// K1b: per-row fp64 tables.
-//  weighted (CalWgtCov(x,x), distmix.cpp:180-187 / computeLD.cpp:100-103):
-//     rt_mu[p]  = sumx_p / m_p            rt_wmu[p] = w_p * (sumx_p / m_p)
-//     rt_wm     = sum_p w_p * mu_p        rt_sd     = sqrt(CalWgtCov(x,x))
-//  pooled (CalCor, util.cpp:66-67):
-//     rt_wm = sumx (all samples)          rt_sd = sqrt(n*sumxsq - sumx*sumx)
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void row_stats_kernel(const Prob* __restrict__ probs,
-                                                        const int2* __restrict__ rowmap, int n_rows)
-{
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= n_rows) return;
-    const int2 rm = rowmap[idx];
-    const Prob& pb = probs[rm.x];
-    const int r = rm.y;
-    const bool um = r >= pb.M;
-    const int prow = um ? r - pb.M : r;            // row inside its part (Prob: measured / unmeasured row arrays)
-    const int P = pb.P;
-    const int* sx = (um ? pb.sx_u : pb.sx) + (size_t)prow * P;
-    const int* sxx = (um ? pb.sxx_u : pb.sxx) + (size_t)prow * P;
-    const auto rt_wm = um ? pb.rt_wm_u : pb.rt_wm;
-    const auto rt_sd = um ? pb.rt_sd_u : pb.rt_sd;
-    const auto rt_mu = um ? pb.rt_mu_u : pb.rt_mu;
-    const auto rt_wmu = um ? pb.rt_wmu_u : pb.rt_wmu;
-    if (pb.mode == 0) {
-        double sumx = 0, sumxsq = 0;
-        int num_samples = 0;
-        for (int p = 0; p < P; p++) {
-            sumx += (double)sx[p];
-            sumxsq += (double)sxx[p];
-            num_samples += pb.pop_raw_off[p + 1] - pb.pop_raw_off[p];
-        }
-        rt_wm[prow] = sumx;
-        rt_sd[prow] = sqrt((num_samples) * sumxsq - sumx * sumx);
-    } else {
-        double wsumcov = 0, wsum_mi_mj = 0, wsum_mi = 0;
-        for (int p = 0; p < P; p++) {
-            const int m = pb.pop_raw_off[p + 1] - pb.pop_raw_off[p];
-            const double wgt_val = pb.pop_w[p];
-            const double sumx = (double)sx[p];
-            const double sumxy = (double)sxx[p];
-            const double factor = ((double)m) / (m - 1);
-            wsumcov += wgt_val * factor * (m * sumxy - sumx * sumx);
-            const double mu = sumx / m;
-            const double wmu = wgt_val * mu;
-            wsum_mi_mj += wmu * mu;
-            wsum_mi += wmu;
-            rt_mu[(size_t)prow * P + p] = mu;
-            rt_wmu[(size_t)prow * P + p] = wmu;
-        }
-        rt_wm[prow] = wsum_mi;
-        rt_sd[prow] = sqrt(wsumcov + wsum_mi_mj - wsum_mi * wsum_mi);
-    }
-}
-
-void launch_row_stats(const Prob* d_probs, const int2* d_rowmap, int n_rows, hipStream_t s)
-{
-    if (n_rows > 0)
-        hipLaunchKernelGGL(row_stats_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, s, d_probs, d_rowmap, n_rows);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -344,6 +344,22 @@ def test_python_packed_writer_is_byte_identical_to_the_converter(study, packed, 
     assert open(out, "rb").read() == open(packed, "rb").read()
 
 
+def test_fast_text_panel_writer_equals_the_line_by_line_writer(study, packed, tmp_path):
+    """panel.write_panel_fast (bench.py's chromosome-sized text panels: array-built lines, members deflated on a thread pool)
+    writes the same text as panel.write_panel, and the converter makes the same packed panel from it, byte for byte -- so
+    its virtual offsets (other members sizes: another deflate level) name the same lines (gauss.cpp:328-330, 755-763)."""
+    import gzip
+    sizes = [q[1] for q in POPS]
+    idx, dat = str(tmp_path / "fast_index.gz"), str(tmp_path / "fast_data.gz")
+    n = panel.write_panel_fast(idx, dat, study["rsid"], np.full(len(study["G"]), 22), study["bp"], study["a1"], study["a2"], study["G"],
+                               study["af"], sizes, threads=3)
+    text = gzip.open(study["paths"]["data.gz"]).read()
+    assert gzip.open(dat).read() == text and n == len(text)
+    out = str(tmp_path / "fast.gpk")
+    assert api.pack_panel(idx, dat, study["paths"]["desc.txt"], out) == len(study["G"])
+    assert open(out, "rb").read() == open(packed, "rb").read()
+
+
 # ---- feeder edge cases the reference's drivers hit (no GPU involved) --------------------------------------
 def _prep(kind, inp, idx, dat, desc, **kw):
     base = dict(chr=22, start_bp=1_400_000, end_bp=2_000_000, wing_size=250_000, study_pop="EUR", input_file=inp,
