@@ -54,7 +54,7 @@ SYMBOLS = [
     "gauss_impute_window", "gauss_gene_ld_batch", "gauss_gram_counts", "gauss_job_create",
     "gauss_ld_rows", "gauss_gene_ld_batch_rows", "gauss_job_run", "gauss_job_fetch", "gauss_job_destroy", "gauss_job_span_ms", "gauss_job_profile",
     "gauss_job_profile_get", "gauss_job_work", "gauss_job_stats", "gauss_synth_device",
-    "gauss_store_upload_async", "gauss_store_upload_fd_async", "gauss_store_wait", "gauss_store_alloc", "gauss_store_fill", "gauss_hip_context_id", "gauss_hip_add_destroy_hook", "gauss_hip_trim_cache", "gauss_hip_source_hash",
+    "gauss_store_upload_async", "gauss_store_upload_fd_async", "gauss_store_wait", "gauss_store_alloc", "gauss_store_fill", "gauss_store_fill_fd", "gauss_store_upload_fd", "gauss_hip_context_id", "gauss_hip_add_destroy_hook", "gauss_hip_trim_cache", "gauss_hip_source_hash",
 ]
 
 
@@ -88,6 +88,8 @@ def load():
     lib.gauss_store_wait.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
     lib.gauss_store_alloc.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]
     lib.gauss_store_fill.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64]
+    lib.gauss_store_fill_fd.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int64]
+    lib.gauss_store_upload_fd.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.POINTER(C.c_void_p)]
     lib.gauss_ld.argtypes = [C.c_void_p, C.c_int, _u8p, C.c_int, C.c_int64, _ip, _dp, C.c_int,
                              C.c_double, _dp]
     lib.gauss_pack2bit_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, _ip, C.c_int]

@@ -179,6 +179,7 @@ static std::vector<std::pair<void (*)(gauss_ctx*, uint64_t, void*), void*>> g_de
 static std::atomic<uint64_t> g_next_ctx_id{1};
 
 static const size_t PIN_CACHE_LIMIT = (size_t)1 << 30;
+static const size_t UPLOAD_CHUNK = (size_t)32 << 20;       // staging buffer of a row-store upload (upload_rows)
 
 static void ctx_flush_dev_cache_locked(gauss_ctx* c)
 {
@@ -2014,8 +2015,9 @@ struct RowSource2 {
 static int upload_rows(gauss_ctx* ctx, void* d, const RowSource2& src, size_t bytes, hipStream_t stream = nullptr,
                        const std::function<void(size_t)>& chunk_queued = nullptr, bool by_kernel = false)
 {
-    const size_t CH = (size_t)32 << 20;
+    const size_t CH = UPLOAD_CHUNK;
     if (!stream) stream = ctx->stream;
+
     if (bytes < 2 * CH && !chunk_queued && src.ptr && stream == ctx->stream) { HIPCHK(hipMemcpy(d, src.ptr, bytes, hipMemcpyHostToDevice)); return GAUSS_OK; }
     void* pin[2] = {nullptr, nullptr};
     hipEvent_t ev[2] = {nullptr, nullptr};
@@ -2080,6 +2082,25 @@ int gauss_store_upload(gauss_ctx* ctx, const void* host_rows, int64_t bytes, voi
     return GAUSS_OK;
 }
 
+// The rows are a section of an open FILE (a packed panel's genotype section), read with pread straight into the pinned
+// staging buffers: a memcpy out of a fresh mapping of the file takes a page fault per 4 KB on the process's address space
+// (206 000 for a chromosome) -- pread touches no page table of the caller.
+int gauss_store_upload_fd(gauss_ctx* ctx, int fd, int64_t file_offset, int64_t bytes, void** out_device_ptr)
+{
+    if (!ctx || fd < 0 || file_offset < 0 || bytes <= 0 || !out_device_ptr) return fail(GAUSS_E_INVALID, "bad arguments to gauss_store_upload_fd");
+    HIPCHK(hipSetDevice(ctx->device));
+    void* d = nullptr;
+    hipError_t e = ctx_malloc_retry(ctx, &d, (size_t)bytes + 64);
+    if (e != hipSuccess) return fail(GAUSS_E_NOMEM, "hipMalloc(%lld bytes row store) failed: %s", (long long)bytes, hipGetErrorString(e));
+    RowSource2 src;
+    src.fd = fd; src.file_off = file_offset;
+    const int rc = upload_rows(ctx, d, src, (size_t)bytes);
+    if (rc) { hipFree(d); return rc; }
+    { std::lock_guard<std::mutex> lock(ctx->mu); ctx->stores[d] = (size_t)bytes; }
+    *out_device_ptr = d;
+    return GAUSS_OK;
+}
+
 int gauss_store_alloc(gauss_ctx* ctx, int64_t bytes, void** out_device_ptr)
 {
     if (!ctx || bytes <= 0 || !out_device_ptr) return fail(GAUSS_E_INVALID, "bad arguments to gauss_store_alloc");
@@ -2094,9 +2115,27 @@ int gauss_store_alloc(gauss_ctx* ctx, int64_t bytes, void** out_device_ptr)
 
 // Bytes [offset, offset + len) of a store made by gauss_store_alloc, from the same offsets of host_rows; returns when they have
 // landed.  The copy travels on the context's upload queue, so whatever the main queue is computing keeps running.
+static int store_fill(gauss_ctx* ctx, void* device_ptr, const RowSource2& src0, int64_t offset, int64_t len);
+
 int gauss_store_fill(gauss_ctx* ctx, void* device_ptr, const void* host_rows, int64_t offset, int64_t len)
 {
     if (!ctx || !device_ptr || !host_rows || offset < 0 || len < 0) return fail(GAUSS_E_INVALID, "bad arguments to gauss_store_fill");
+    RowSource2 src;
+    src.ptr = (const uint8_t*)host_rows;
+    return store_fill(ctx, device_ptr, src, offset, len);
+}
+
+// the same piece from a file: bytes [file_offset + offset, + len) of fd (see gauss_store_upload_fd)
+int gauss_store_fill_fd(gauss_ctx* ctx, void* device_ptr, int fd, int64_t file_offset, int64_t offset, int64_t len)
+{
+    if (!ctx || !device_ptr || fd < 0 || file_offset < 0 || offset < 0 || len < 0) return fail(GAUSS_E_INVALID, "bad arguments to gauss_store_fill_fd");
+    RowSource2 src;
+    src.fd = fd; src.file_off = file_offset;
+    return store_fill(ctx, device_ptr, src, offset, len);
+}
+
+static int store_fill(gauss_ctx* ctx, void* device_ptr, const RowSource2& src0, int64_t offset, int64_t len)
+{
     if (len == 0) return GAUSS_OK;
     HIPCHK(hipSetDevice(ctx->device));
     {
@@ -2113,8 +2152,8 @@ int gauss_store_fill(gauss_ctx* ctx, void* device_ptr, const void* host_rows, in
             if (e != hipSuccess) return fail(GAUSS_E_DEVICE, "gauss_store_fill: %s", hipGetErrorString(e));
         }
     }
-    RowSource2 src;
-    src.ptr = (const uint8_t*)host_rows + offset;
+    RowSource2 src = src0;
+    if (src.ptr) src.ptr += offset; else src.file_off += offset;
     static const bool by_kernel = env_int("GAUSS_FILL_BY_KERNEL", 1) != 0;
     return upload_rows(ctx, (uint8_t*)device_ptr + offset, src, (size_t)len, ctx->upload, nullptr, by_kernel);
 }

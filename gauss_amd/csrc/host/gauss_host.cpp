@@ -2077,7 +2077,8 @@ static int panel_fill_to(gauss_ctx* ctx, const ResidentPanel& rp, int64_t upto, 
     upto = std::min(rp.bytes, upto <= 0 ? rp.bytes : (upto + piece - 1) / piece * piece);
     std::lock_guard<std::mutex> lock(*rp.fill_mu);
     if (*rp.filled >= upto) return 0;
-    if (gauss_store_fill(ctx, rp.dev, rp.pk->geno(), *rp.filled, upto - *rp.filled) != 0) return herr("%s", gauss_last_error());
+    // (from the FILE, not from the mapping: no page faults on the process's address space beside the data layer's threads)
+    if (gauss_store_fill_fd(ctx, rp.dev, rp.pk->fd(), rp.pk->geno_file_offset(), *rp.filled, upto - *rp.filled) != 0) return herr("%s", gauss_last_error());
     if (uploaded) *uploaded += upto - *rp.filled;
     *rp.filled = upto;
     return 0;
@@ -2122,7 +2123,7 @@ static int panel_make_resident(gauss_ctx* ctx, const std::string& path, void** d
                 rp.fill_mu = std::make_shared<std::mutex>();
                 rp.filled = std::make_shared<int64_t>(0);
             } else if ((async ? gauss_store_upload_fd_async(ctx, rp.pk->fd(), rp.pk->geno_file_offset(), rp.bytes, &rp.dev)
-                              : gauss_store_upload(ctx, rp.pk->geno(), rp.bytes, &rp.dev)) != 0)
+                              : gauss_store_upload_fd(ctx, rp.pk->fd(), rp.pk->geno_file_offset(), rp.bytes, &rp.dev)) != 0)
                 return herr("%s", gauss_last_error());
             if (uploaded && !reserve_only) *uploaded = rp.bytes;
             *dev = rp.dev;
@@ -2474,14 +2475,24 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
     // 77-86 ms in one go -- the pieces cross PCIe at 55 GB/s beside the Gram kernel, but filling the staging buffers out of the
     // page cache shares the host's cores with the data layer and the result tables, and that is what the first call waits for.
     void* d_rows = nullptr;
+    int piece_mode = 0;
     const int64_t panel_row_bytes = pk->row_bytes();
     ResidentPanel piecewise;                                       // .filled set: this call fills the store piece by piece
     {
         const int64_t panel_bytes = pk->n_snp() * panel_row_bytes;
         const char* e = getenv("GAUSS_CHROM_ASYNC_UPLOAD");
         const bool async_upload = e ? atoi(e) != 0 : panel_bytes > ((int64_t)4 << 30);
+        // 0 (default): in one go before the first batch; 1: piece by piece, always one batch ahead; 2: TWO pieces -- the rows of
+        // the first batches (about half of the chromosome's work) before the first batch is queued, the rest while the GPU
+        // computes those batches.  Measured on the chr22 panel, first call of a fresh process (tools/cold_probe2.sh, round 4):
+        // one go 71-86 ms, two pieces 83-85, per batch 84-86 -- a FIRST piece of 503 MB takes 31-34 ms (15 GB/s) where the
+        // second one, beside the Gram kernel, takes 13-16 ms for 343 MB: whatever is staged first in a process is slow (cold page
+        // cache walk, cold allocator, the data layer's threads on the same sixteen cores), so splitting the upload only moves
+        // GPU work behind a slower first piece.
         const char* ep = getenv("GAUSS_CHROM_PIECEWISE_UPLOAD");
-        const bool reserve_only = !async_upload && (ep ? atoi(ep) != 0 : false) && pk->header().sorted && chr > 0;
+        piece_mode = async_upload || !pk->header().sorted || chr <= 0 ? 0 : (ep ? atoi(ep) : 0);
+        if (piece_mode == 2 && n_batches < 3) piece_mode = 0;
+        const bool reserve_only = piece_mode != 0;
         const double tu = now_s();
         if (!mine.empty() && panel_make_resident(ctx, reference_data_file, &d_rows, &st.panel_bytes_uploaded, async_upload, reserve_only)) rc_upload = -1;
         if (!rc_upload && reserve_only && panel_entry(ctx, reference_data_file, piecewise) && !piecewise.filled) piecewise = ResidentPanel();
@@ -2496,11 +2507,27 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
     auto fill_to = [&](int64_t upto) -> int {
         if (!piecewise.filled) return 0;
         const double tu = now_s();
+        const int64_t before = st.panel_bytes_uploaded;
         const int rc = panel_fill_to(ctx, piecewise, upto, &st.panel_bytes_uploaded);
         st.t_panel_upload += now_s() - tu;
+        if (getenv("GAUSS_CHROM_TRACE"))
+            fprintf(stderr, "[chrom] fill to %lld: %.1f MB in %.2f ms (at %.2f ms)\n", (long long)upto, (st.panel_bytes_uploaded - before) / 1e6,
+                    (now_s() - tu) * 1e3, (now_s() - t_begin) * 1e3);
         return rc;
     };
-    if (!rc_upload && n_batches > 0 && fill_to(fill_est(0)) != 0) rc_upload = -1;
+    // two pieces: the first one covers the batches that hold the first ~45 % of this rank's work
+    int piece_a_last = 0;
+    if (piece_mode == 2) {
+        double total = 0, acc = 0;
+        for (int i : mine) total += wins[(size_t)i].cost;
+        for (int b = 0; b < n_batches; b++) {
+            for (int k : batches[(size_t)b]) acc += wins[(size_t)k].cost;
+            piece_a_last = b;
+            if (acc >= 0.45 * total) break;
+        }
+        piece_a_last = std::min(piece_a_last, n_batches - 2);            // (something is left for the second piece)
+    }
+    if (!rc_upload && n_batches > 0 && fill_to(fill_est(piece_mode == 2 ? std::max(0, piece_a_last) : 0)) != 0) rc_upload = -1;
 
     // ---- GPU pipeline ----
     std::vector<gauss_job*> jobs((size_t)n_batches, nullptr);
@@ -2613,8 +2640,9 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
             }
             st.t_job_create += now_s() - tc;
         }
-        // the next batch's rows travel while this one computes
-        if (b + 1 < n_batches && fill_to(fill_est(b + 1)) != 0) { rc_fatal = -1; break; }
+        // the next batch's rows travel while this one computes (two pieces: everything else, once the first piece's batches are queued)
+        if (piece_mode == 2) { if (b == piece_a_last && fill_to(0) != 0) { rc_fatal = -1; break; } }
+        else if (b + 1 < n_batches && fill_to(fill_est(b + 1)) != 0) { rc_fatal = -1; break; }
         if (b > 0) retire(b - 1);
     }
     if (!rc_fatal && n_batches > 0) retire(n_batches - 1);

@@ -346,6 +346,28 @@ class RowStore:
     """Genotype rows resident in HBM (gauss_store_upload): a whole packed chromosome is uploaded once and
     windows name their rows by index."""
 
+    @classmethod
+    def from_file(cls, path, file_offset, n_rows, ld, ctx=None, reserve_only=False):
+        """The rows are a section of a FILE (a packed panel's genotype section): gauss_store_upload_fd, or with reserve_only
+        gauss_store_alloc + fill() through gauss_store_fill_fd -- pread straight into the pinned staging buffers."""
+        import os
+        self = cls.__new__(cls)
+        self.ctx = ctx or default_context()
+        self.n_rows, self.ld = int(n_rows), int(ld)
+        self._host = None
+        self._fd, self._file_off = os.open(path, os.O_RDONLY), int(file_offset)
+        p = C.c_void_p()
+        try:
+            if reserve_only:
+                check(self.ctx.lib.gauss_store_alloc(self.ctx.handle, self.n_rows * self.ld, C.byref(p)))
+            else:
+                check(self.ctx.lib.gauss_store_upload_fd(self.ctx.handle, self._fd, C.c_int64(self._file_off), C.c_int64(self.n_rows * self.ld), C.byref(p)))
+        except Exception:
+            os.close(self._fd)
+            raise
+        self.ptr = p.value
+        return self
+
     def __init__(self, rows, ctx=None, asynchronous=False, reserve_only=False):
         """asynchronous: gauss_store_upload_async -- the rows travel in the background (keep `rows` alive until
         wait() has returned); wait(n_rows) makes the context's stream wait for the first n_rows rows.
@@ -353,6 +375,7 @@ class RowStore:
         self.ctx = ctx or default_context()
         rows = np.ascontiguousarray(rows, dtype=np.uint8)
         self.n_rows, self.ld = rows.shape
+        self._fd = None
         p = C.c_void_p()
         if reserve_only:
             self._host = rows
@@ -366,6 +389,10 @@ class RowStore:
 
     def fill(self, r0, r1):
         """Rows [r0, r1) of a reserve_only store travel now (on a queue of their own); returns when they have landed."""
+        if self._fd is not None:
+            check(self.ctx.lib.gauss_store_fill_fd(self.ctx.handle, C.c_void_p(self.ptr), self._fd, C.c_int64(self._file_off),
+                                                   C.c_int64(int(r0) * self.ld), C.c_int64((int(r1) - int(r0)) * self.ld)))
+            return
         check(self.ctx.lib.gauss_store_fill(self.ctx.handle, C.c_void_p(self.ptr), self._host.ctypes.data_as(C.c_void_p),
                                             int(r0) * self.ld, (int(r1) - int(r0)) * self.ld))
 
@@ -377,6 +404,10 @@ class RowStore:
         if self.ptr:
             self.ctx.lib.gauss_store_free(self.ctx.handle, C.c_void_p(self.ptr))
             self.ptr = None
+        if getattr(self, "_fd", None) is not None:
+            import os
+            os.close(self._fd)
+            self._fd = None
 
     def __del__(self):
         try:

@@ -132,6 +132,10 @@ int gauss_pinned_free(gauss_ctx* ctx, void* host_ptr);
  * geno_m / geno_u (with gauss_job_create's on_device = 1 and rows_m / rows_u).  288 GB of HBM hold a
  * whole 2-bit panel (33 k samples x 10 M SNPs = 82 GB), so a panel is uploaded once, not per window. */
 int gauss_store_upload(gauss_ctx* ctx, const void* host_rows, int64_t bytes, void** out_device_ptr);
+/* The rows are `bytes` bytes of an open file from file_offset on (a packed panel's genotype section): read with pread
+ * straight into the pinned staging buffers -- no page of a mapping of the file is touched (a memcpy out of a fresh mapping
+ * costs a page fault per 4 KB).  Blocking, like gauss_store_upload. */
+int gauss_store_upload_fd(gauss_ctx* ctx, int fd, int64_t file_offset, int64_t bytes, void** out_device_ptr);
 int gauss_store_free(gauss_ctx* ctx, void* device_ptr);
 /* The same store filled piece by piece: gauss_store_alloc reserves `bytes` on the GPU (contents undefined until filled) and
  * gauss_store_fill copies host_rows[offset .. offset + len) to the same offsets of the store, returning when they have landed.
@@ -140,6 +144,8 @@ int gauss_store_free(gauss_ctx* ctx, void* device_ptr);
  * (gauss_host_impute_chromosome on a panel that is not resident yet).  A job may only name rows that have been filled. */
 int gauss_store_alloc(gauss_ctx* ctx, int64_t bytes, void** out_device_ptr);
 int gauss_store_fill(gauss_ctx* ctx, void* device_ptr, const void* host_rows, int64_t offset, int64_t len);
+/* gauss_store_fill from a file: store bytes [offset, offset + len) come from file bytes [file_offset + offset, ...). */
+int gauss_store_fill_fd(gauss_ctx* ctx, void* device_ptr, int fd, int64_t file_offset, int64_t offset, int64_t len);
 /* The same upload without waiting for it: returns at once with the device pointer; a library thread streams the rows
  * IN ORDER (pinned double buffers, a stream of its own).  host_rows must stay valid until the upload is complete.
  * gauss_store_wait(ctx, ptr, n) makes the context's main stream wait until the first n bytes have landed -- a job queued

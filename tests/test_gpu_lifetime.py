@@ -104,7 +104,7 @@ def test_resident_panel_does_not_survive_its_context(tmp_path):
 
 
 @pytest.mark.gpu
-def test_asynchronous_row_store_upload(ctx):
+def test_asynchronous_row_store_upload(ctx, tmp_path):
     """gauss_store_upload_async + gauss_store_wait: a job over the first rows of a store may be queued while the rest is
     still on its way (the library's stream waits for the mark that covers the rows named), a job over all rows after
     wait(all), and both give the bits of a synchronous store.  Large enough for several 32 MB chunks."""
@@ -163,6 +163,26 @@ def test_asynchronous_row_store_upload(ctx):
         assert np.array_equal(a["z"], b["z"]) and np.array_equal(a["info"], b["info"])
     busy = hotpath.RowStore(rows, ctx=ctx, asynchronous=True)
     busy.close()                                   # freed while the upload may still be running: it is finished first
+    # the rows as a section of a FILE (what the chromosome driver uploads: a packed panel's genotype section, read with pread
+    # into the pinned staging buffers): in one go (gauss_store_upload_fd) and piece by piece (gauss_store_fill_fd), at an offset
+    # that is not page aligned
+    path = str(tmp_path / "rows.bin")
+    with open(path, "wb") as fh:
+        fh.write(b"x" * 1000)
+        rows.tofile(fh)
+    ff = hotpath.RowStore.from_file(path, 1000, n_snp, rows.shape[1], ctx=ctx)
+    f_lo, f_hi = job_over(ff, 0), job_over(ff, n_snp - 512)
+    ff.close()
+    fp_ = hotpath.RowStore.from_file(path, 1000, n_snp, rows.shape[1], ctx=ctx, reserve_only=True)
+    fp_.fill(0, 900)
+    p_lo = job_over(fp_, 0)
+    fp_.fill(900, n_snp)
+    p_hi = job_over(fp_, n_snp - 512)
+    fp_.close()
+    with pytest.raises(Exception):
+        hotpath.RowStore.from_file(path, 1000, n_snp + 5, rows.shape[1], ctx=ctx)       # the file is shorter than that
+    for a, b in ((f_lo, want_lo), (f_hi, want_hi), (p_lo, want_lo), (p_hi, want_hi)):
+        assert np.array_equal(a["z"], b["z"]) and np.array_equal(a["info"], b["info"])
 
 
 @pytest.mark.gpu
