@@ -167,6 +167,8 @@ struct gauss_ctx {
     std::map<void*, size_t> block_size;      // every live block handed out by ctx_dev_alloc / ctx_pin_alloc
     std::set<gauss_job*> jobs;               // live jobs of this context (guarded by mu): gauss_hip_destroy orphans them
     size_t dev_cache_limit = 0;              // bytes of freed workspace kept for reuse (a third of the device's memory)
+    std::thread prepin;                      // makes the upload staging buffers in the background (gauss_hip_init)
+    std::mutex prepin_mu;
 };
 
 // Lifetime rule of the C ABI (include/gauss_hip.h): a context may be destroyed while jobs and row stores made on it
@@ -1894,6 +1896,24 @@ int gauss_hip_init(int device, gauss_ctx** out_ctx)
         // the queue of the factorisation chain when it runs beside the Gram kernel (job_run, k_solve_lite.hip)
         HIPCHK(hipStreamCreateWithPriority(&c->chain, hipStreamNonBlocking, hi));
     } else HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    // What a session's FIRST row-store upload would otherwise pay in front of its first byte (measured on MI355X, round 4): the
+    // queue of its own that piecewise / background uploads travel on (creating a stream: ~15 ms the first time) and the two
+    // pinned staging buffers (hipHostMalloc of 2 x 32 MB: 4-14 ms).  The queue is made here; the buffers are made in the
+    // background and parked in the context's pinned-block cache.  GAUSS_PREPIN=0: both on first use.
+    if (env_int("GAUSS_PREPIN", 1) != 0) {
+        int lo = 0, hi = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIPCHK(hipStreamCreateWithPriority(&c->upload, hipStreamNonBlocking, hi));       // see gauss_store_fill
+        c->prepin = std::thread([c]() {
+            (void)hipSetDevice(c->device);
+            for (int b = 0; b < 2; b++) {
+                void* p = nullptr;                             // (outside c->mu: the main thread may be building its first job meanwhile)
+                if (hipHostMalloc(&p, UPLOAD_CHUNK, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); break; }
+                { std::lock_guard<std::mutex> lock(c->mu); c->block_size[p] = UPLOAD_CHUNK; }
+                ctx_pin_release(c, p);                         // parked in the pinned-block cache
+            }
+        });
+    }
     *out_ctx = c;
     return GAUSS_OK;
 }
@@ -1915,6 +1935,7 @@ void gauss_hip_destroy(gauss_ctx* ctx)
 {
     if (!ctx) return;
     hipSetDevice(ctx->device);
+    if (ctx->prepin.joinable()) ctx->prepin.join();
     // 1. whoever cached something per context (the host layer's resident panels) lets go of it
     std::vector<std::pair<void (*)(gauss_ctx*, uint64_t, void*), void*>> hooks;
     { std::lock_guard<std::mutex> lock(g_hook_mu); hooks = g_destroy_hooks; }
@@ -2017,6 +2038,10 @@ static int upload_rows(gauss_ctx* ctx, void* d, const RowSource2& src, size_t by
 {
     const size_t CH = UPLOAD_CHUNK;
     if (!stream) stream = ctx->stream;
+    if (ctx->prepin.joinable()) {                          // the staging buffers made at init are in the pinned cache (or about to be)
+        std::lock_guard<std::mutex> lock(ctx->prepin_mu);
+        if (ctx->prepin.joinable()) ctx->prepin.join();
+    }
 
     if (bytes < 2 * CH && !chunk_queued && src.ptr && stream == ctx->stream) { HIPCHK(hipMemcpy(d, src.ptr, bytes, hipMemcpyHostToDevice)); return GAUSS_OK; }
     void* pin[2] = {nullptr, nullptr};
@@ -2025,12 +2050,16 @@ static int upload_rows(gauss_ctx* ctx, void* d, const RowSource2& src, size_t by
     auto cleanup = [&]() {
         for (int b = 0; b < 2; b++) { if (ev[b]) hipEventDestroy(ev[b]); ctx_pin_release(ctx, pin[b]); }
     };
+    const bool trace = getenv("GAUSS_UPLOAD_TRACE") != nullptr;
+    const auto t_up0 = std::chrono::steady_clock::now();
     for (int b = 0; b < 2; b++) {
         if (ctx_pin_alloc(ctx, CH, &pin[b]) != hipSuccess || hipEventCreateWithFlags(&ev[b], hipEventDisableTiming) != hipSuccess) {
             cleanup();
             return fail(GAUSS_E_NOMEM, "pinned staging buffers for the row store upload could not be allocated");
         }
     }
+    const auto t_up1 = std::chrono::steady_clock::now();
+    double t_stage = 0, t_wait = 0;
     const unsigned hw = std::thread::hardware_concurrency();
     // a background upload (chunk_queued set) shares the host with the data layer it runs beside: fewer copy threads
     const int nt_env = env_int("GAUSS_UPLOAD_THREADS", 0);
@@ -2042,7 +2071,10 @@ static int upload_rows(gauss_ctx* ctx, void* d, const RowSource2& src, size_t by
     for (size_t off = 0; off < bytes && rc == GAUSS_OK; off += CH, k++) {
         const int b = (int)(k & 1);
         const size_t len = std::min(CH, bytes - off);
+        const auto tw0 = std::chrono::steady_clock::now();
         if (k >= 2 && hipEventSynchronize(ev[b]) != hipSuccess) { rc = fail(GAUSS_E_DEVICE, "row store upload: event wait failed"); break; }
+        const auto tw1 = std::chrono::steady_clock::now();
+        t_wait += std::chrono::duration<double, std::milli>(tw1 - tw0).count();
         std::vector<std::thread> th;
         const size_t per = (len + nt - 1) / nt;
         for (int t = 1; t < nt; t++) {
@@ -2051,6 +2083,7 @@ static int upload_rows(gauss_ctx* ctx, void* d, const RowSource2& src, size_t by
         }
         if (!src.copy((uint8_t*)pin[b], off, std::min(per, len))) read_ok = false;
         for (std::thread& x : th) x.join();
+        t_stage += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw1).count();
         if (!read_ok) { rc = fail(GAUSS_E_INVALID, "row store upload: reading the source failed (short file?)"); break; }
         hipError_t ce = hipSuccess;
         const size_t body = (by_kernel && ((uintptr_t)((uint8_t*)d + off) & 15) == 0) ? len / 16 * 16 : 0;
@@ -2062,6 +2095,10 @@ static int upload_rows(gauss_ctx* ctx, void* d, const RowSource2& src, size_t by
         else if (chunk_queued) chunk_queued(off + len);
     }
     if (hipStreamSynchronize(stream) != hipSuccess && rc == GAUSS_OK) rc = fail(GAUSS_E_DEVICE, "row store upload failed");
+    if (trace)
+        fprintf(stderr, "[upload] %.1f MB: pinned buffers %.2f ms, staging %.2f ms (%d threads), waiting for the copies %.2f ms, total %.2f ms\n", bytes / 1e6,
+                std::chrono::duration<double, std::milli>(t_up1 - t_up0).count(), t_stage, nt, t_wait,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_up0).count());
     cleanup();
     return rc;
 }
