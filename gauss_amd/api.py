@@ -40,7 +40,7 @@ HOST_SYMBOLS = [
     "gauss_host_bgzf_copy", "gauss_host_set_threads",
     "gauss_host_panel_resident", "gauss_host_panel_evict", "gauss_host_impute_chromosome", "gauss_host_panel_cache", "gauss_table_n_messages",
     "gauss_table_message", "gauss_table_strcol_fixed", "gauss_host_panel_device_rows", "gauss_prepared_store_rows",
-    "gauss_host_jepeg_gene_tail",
+    "gauss_host_jepeg_gene_tail", "gauss_host_plan_cost",
 ]
 
 

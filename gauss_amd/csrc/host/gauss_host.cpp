@@ -2224,6 +2224,53 @@ int gauss_host_panel_evict(gauss_ctx* ctx, const char* packed_file)
     return 0;
 }
 
+// Planner cost of a window (the C++ twin of gauss_amd/farm.py:piece_cost; tests/test_farm.py compares them): the flops the Gram
+// kernel ISSUES per sample -- 128-row tiles with the kernel's 32 / 16 granular edges, B11's tile triangle with the mirrored parts of
+// its diagonal tiles skipped -- plus 8 % on B21's share for what follows it per entry (B21's epilogue tiles, the closing
+// product).  The 8-rank emulation on MI355X (round 4) showed the ranks' Gram times following their issued flops to +-2 % while
+// their algorithmic flops differed by 4.5 %; the factorisation chain runs under the Gram kernel and costs a rank no time.
+static double units32(int rows, bool edge16)
+{
+    double total = 0;
+    for (int t0 = 0; t0 < rows; t0 += 128) {
+        const int r = std::min(128, rows - t0);
+        for (int w = 0; w < 2; w++) {
+            const int left = r - 64 * w;
+            if (left <= 0) continue;
+            const int n16 = std::min(4, (left + 15) / 16);
+            total += (edge16 && (n16 & 1)) ? n16 * 0.5 : std::min(2, (left + 31) / 32);
+        }
+    }
+    return total;
+}
+static double b11_units(int m)
+{
+    const int nt = (m + 127) / 128;
+    double total = 0;
+    for (int ti = 0; ti < nt; ti++) {
+        const int ri = std::min(128, m - 128 * ti);
+        for (int tj = ti; tj < nt; tj++) {
+            const int rj = std::min(128, m - 128 * tj);
+            for (int wr = 0; wr < 2; wr++)
+                for (int wc = 0; wc < 2; wc++) {
+                    if (ti == tj && wr == 1 && wc == 0) continue;
+                    const int a = std::min(2, std::max(0, (ri - 64 * wr + 31) / 32)), left = rj - 64 * wc;
+                    if (left <= 0 || a == 0) continue;
+                    const int n16 = std::min(4, (left + 15) / 16);
+                    if (n16 & 1) { total += a * n16 * 0.5; continue; }
+                    const int t32 = a * std::min(2, (left + 31) / 32);
+                    total += (ti == tj && wr == wc && t32 == 4) ? 3 : t32;
+                }
+        }
+    }
+    return total;
+}
+static double issued_cost_per_sample(int m, int u)
+{
+    return 2048.0 * b11_units(m) + 2.0 * 32.0 * units32(m, true) * 1.08 * (double)u;
+}
+double gauss_host_plan_cost(int n_measured, int n_unmeasured) { return issued_cost_per_sample(n_measured, n_unmeasured); }
+
 // ------------------------------------------------------------------------------------------
 // A whole chromosome: the caller-level loop over windows that the reference leaves to the R user
 // (docs/articles/dist_example.md:144-153 calls one window), as ONE native call per rank.
@@ -2295,7 +2342,7 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
                                            std::lower_bound(gbp.begin(), gbp.end(), (long long)w.s));
             u = std::max(0.0, in_panel - m_pred);
         }
-        w.cost = m * (m + 1.0 + 2.0 * u) + 1.0;        // LD flops / N
+        w.cost = issued_cost_per_sample((int)m, (int)u) + 1.0;   // what the Gram kernel issues for the window, per sample (above)
         w.owner = 0; w.status = -1; w.M = (int)m; w.U = (int)u;
         wins.push_back(w);
     }
@@ -2316,7 +2363,7 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
         }
         double n_samples = 0;
         for (uint32_t q = 0; q < pk->header().n_pop; q++) n_samples += pk->pop((int)q).size;
-        const double chain = 2.4e9 / std::max(1.0, n_samples);
+        const double chain = 2.0e8 / std::max(1.0, n_samples);       // (a tie-breaker since the chain runs under the Gram kernel: farm.CHAIN_STEP_COST)
         // Local search of moves (a window of the fullest rank goes to another rank) and trades.  Per rank: the summed cost
         // and the block counts of its windows (the chain term needs the tallest one, also "the tallest without window
         // x"), so a candidate costs O(1); candidates are counted and the search stops at a fixed budget -- the same

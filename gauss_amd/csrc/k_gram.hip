@@ -415,7 +415,8 @@ __global__ __launch_bounds__(256, OCC) __attribute__((amdgpu_num_vgpr(52))) void
 // done; the counter only grows, run r waits for (r + 1) x items, so a stale value of the run before can never satisfy it).  A relaxed agent-scope
 // poll (an sc1 load: served by the L2 / fabric, never by this CU's L1) every ~3 us; the kernels queued behind it start through an
 // ordinary launch, which is their acquire.  Bounded: after `timeout_ticks` of the 100 MHz wall clock it gives up and raises the
-// job's failure flags instead of holding the queue forever (a Gram launch that never ran: the host reports the run as failed).
+// job-wide failure flag (`status[0 .. n_status)`) instead of holding the queue forever (a Gram launch that never ran: the host
+// reports the run as failed).
 __global__ __launch_bounds__(64) void wait_count_kernel(const unsigned long long* __restrict__ count, unsigned long long target,
                                                         unsigned long long timeout_ticks, int* __restrict__ status, int n_status)
 {
@@ -427,13 +428,20 @@ __global__ __launch_bounds__(64) void wait_count_kernel(const unsigned long long
         if (wall_clock64() - t0 > timeout_ticks) break;
         __builtin_amdgcn_s_sleep(127);
     }
-    for (int i = 0; i < n_status; i++) status[4 * i + 2] = 1;         // "non-finite": every window of the run is reported failed
+    for (int i = 0; i < n_status; i++) status[i] = 1;                 // the job-wide failure flag (gauss_job_fetch reports the run as failed)
 }
 
 void launch_wait_count(const unsigned long long* d_count, unsigned long long target, int* d_status, int n_status, hipStream_t s)
 {
-    const unsigned long long two_seconds = 200000000ull;               // wall_clock64 ticks at 100 MHz
-    hipLaunchKernelGGL(wait_count_kernel, dim3(1), dim3(64), 0, s, d_count, target, two_seconds, d_status, n_status);
+    // two seconds of wall_clock64 ticks (100 MHz); GAUSS_WAIT_COUNT_TIMEOUT_US overrides; a NEGATIVE value is the tests' way into
+    // the give-up path: the wait is for a count that never comes and ends after that many microseconds
+    unsigned long long ticks = 200000000ull;
+    if (const char* e = getenv("GAUSS_WAIT_COUNT_TIMEOUT_US")) {
+        const long long us = atoll(e);
+        if (us < 0) target = ~0ull;
+        ticks = (unsigned long long)(us < 0 ? -us : us) * 100ull;
+    }
+    hipLaunchKernelGGL(wait_count_kernel, dim3(1), dim3(64), 0, s, d_count, target, ticks, d_status, n_status);
 }
 
 void launch_gram(const Item* d_items, int n_items, int dtype_i8, hipStream_t s, unsigned long long* d_b11_done)

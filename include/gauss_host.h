@@ -227,6 +227,10 @@ typedef struct gauss_chrom_stats {
  * [n_windows x 6: start_bp end_bp owner status measured unmeasured; status 0 done, 1 skipped by the ">10" guards
  * (dist.cpp:145-151), 2 failed, -1 another rank's] and one message per failed window (gauss_table_message):
  * a window that fails never takes the others with it. */
+/* The planner's cost of a window with n_measured / n_unmeasured SNPs, per sample: the fp32 matrix flops the Gram kernel issues
+ * for it (128-row tiles, 32 / 16 granular edges, B11's tile triangle) plus 8 % on B21's share for the per-entry tails.  What
+ * gauss_host_impute_chromosome balances the ranks on; gauss_amd/farm.py:piece_cost is its Python twin. */
+double gauss_host_plan_cost(int n_measured, int n_unmeasured);
 int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t start_bp, int64_t end_bp, int64_t wing_size,
                                  int64_t window_size, const char* study_pop, const char* const* pop_names,
                                  const double* pop_wgts, int n_pop_wgt, const char* input_file, const char* reference_index_file,

@@ -394,3 +394,20 @@ def test_gpu_native_chromosome_accepts_the_text_panel(ctx, tmp_path, monkeypatch
         api.impute_chromosome(reference_index_file=p["index.gz"], reference_data_file=p["data.gz"], **kw)
     assert "packed panel" in str(ei.value)
     api.panel_evict(ctx=ctx)
+
+
+def test_native_planner_cost_equals_the_python_planner():
+    """gauss_host_impute_chromosome balances its ranks on gauss_host_plan_cost; bench.py's strong-scaling shares and the
+    Python farm on farm.piece_cost: the same model (flops the Gram kernel issues: 128-row tiles, 32 / 16 granular edges, B11's
+    tile triangle; + 8 % on B21's share), two statements -- they must agree on every shape, tile edges included."""
+    import ctypes as C
+    h = api.load_host()
+    h.gauss_host_plan_cost.restype = C.c_double
+    h.gauss_host_plan_cost.argtypes = [C.c_int, C.c_int]
+    N = 32147
+    for m in (1, 15, 16, 17, 31, 33, 64, 65, 100, 127, 128, 129, 156, 200, 300, 423, 594, 742, 941, 1213, 2500, 4096):
+        for u in (0, 1, 64, 513, 2407):
+            b, r = farm.piece_cost(N, m, u)
+            want = (b + u * r) / N
+            got = h.gauss_host_plan_cost(m, u)
+            assert abs(got - want) <= 1e-9 * max(1.0, want), (m, u, got, want)

@@ -233,3 +233,43 @@ def test_streamed_window_call_strided_rows_and_error_paths(ctx, monkeypatch):
     assert "bad mode" in str(ei.value)
     again = call(True)
     assert np.array_equal(again["z"], want["z"]) and np.array_equal(again["info"], want["info"])
+
+
+@pytest.mark.gpu
+def test_merged_launch_gives_up_instead_of_hanging(ctx, monkeypatch):
+    """The chain queue of a merged Gram launch waits for a COUNT of finished B11 items (k_gram.hip: wait_count_kernel), and
+    that wait is bounded: made to wait for a count that never comes (the test hook), it gives up after its bound, the run is reported as failed by
+    gauss_job_fetch (no hang, no silent garbage), and the same job runs correctly afterwards -- the counter's target is per
+    launch, so a failed run does not shift the next one's."""
+    from gauss_amd import hotpath, panel
+    import oracle
+    from helpers import small_panel
+    p = small_panel(n_snp=1500, scale=0.05, seed=17)
+    rows2, src_off = panel.pack2bit(p["G"], p["off"])
+    store = hotpath.RowStore(rows2, ctx=ctx)
+    rng = np.random.default_rng(3)
+    n = p["G"].shape[0]
+    wins = []
+    for k in range(3):
+        mi = np.arange(100 * k, 100 * k + 700, 2, dtype=np.int32)
+        ui = np.arange(100 * k + 1, 100 * k + 601, 2, dtype=np.int32)
+        wins.append(dict(mode=1, pop_off=p["off"], pop_wgt=p["w"], z1=rng.standard_normal(len(mi)), dev=(store.ptr, store.ptr, len(mi), len(ui), store.ld),
+                         packed=dict(fmt=1, rows_m=mi, rows_u=ui, pop_src_off=src_off)))
+    monkeypatch.setenv("GAUSS_CHAIN_ASIDE", "2")              # the merged form on a job this small
+    job = hotpath.Job(wins, ctx=ctx, on_device=True)
+    monkeypatch.setenv("GAUSS_WAIT_COUNT_TIMEOUT_US", "-2000")     # wait 2 ms for a count that never comes
+    job.run()
+    with pytest.raises(Exception) as ei:
+        job.fetch()
+    assert "gave up waiting" in str(ei.value)
+    monkeypatch.delenv("GAUSS_WAIT_COUNT_TIMEOUT_US")
+    job.run()
+    res = job.fetch()
+    job.close()
+    for w, r in zip(wins, res):
+        gm, gu = p["G"][w["packed"]["rows_m"]], p["G"][w["packed"]["rows_u"]]
+        want = oracle.run_impute(1, np.ascontiguousarray(gm), np.ascontiguousarray(gu), p["off"], p["w"], w["z1"])
+        assert r["status"] == 0
+        assert np.max(np.abs(r["z"] - want["z"]) / np.maximum(1.0, np.abs(want["z"]))) <= 1e-8
+        assert np.max(np.abs(r["info"] - want["info"]) / want["info"]) <= 1e-8
+    store.close()
