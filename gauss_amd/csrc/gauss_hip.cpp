@@ -918,7 +918,12 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
         // Merged launch (round 4): B11's items and B21's items are ONE launch, B11's first; they count themselves off and the
         // chain queue starts when the count is complete (k_gram.hip: wait_count_kernel) -- the chip is never drained between
         // the two halves (two launches: 37.1 ms, one: 36.6 on the 36-window job).  GAUSS_CHAIN_MERGED=0: two launches + event.
-        job->merged = job->chain_aside && env_int("GAUSS_CHAIN_MERGED", 1) != 0;
+        // (f32 only: the int8 Gram kernel is operand-delivery bound and the chain's memory traffic beside ALL of it costs more than
+        // the second launch's start-up -- measured 8.70 ms per step merged against 8.35 ms as two launches; =2 forces it for both)
+        {
+            const int mm = env_int("GAUSS_CHAIN_MERGED", 1);
+            job->merged = job->chain_aside && mm != 0 && (!job->gram_i8 || mm == 2);
+        }
     }
     std::vector<int> sgroup_of_item;
     if (streamed) {
@@ -1416,13 +1421,12 @@ static int job_run(gauss_job* job, bool solve)
         launch_solve_last_lite(job->d_probs, job->d_panelmap, job->n_panels, job->max_nblk, job->solve_split, ch);
         prof_end(job, ch);
         HIPCHK(hipEventRecord(ev.side, ch));
-        // (the epilogue reads status[3], which the chain queue wrote in that case: join first -- the chain has long finished
-        // when the Gram kernel ends, or the job would not have taken this path)
-        if (cert_on_chain) HIPCHK(hipStreamWaitEvent(st, ev.side, 0));
+        // (B21's tiles read neither B11 nor the certificate -- epilogue_tile looks at status[3] for B11's tiles only -- so they
+        // need not wait for the chain queue; the closing product does)
         prof_begin(job, 2, st);
         launch_epilogue(job->d_probs, job->d_tilemap + job->n_tiles_b11, job->n_tiles - job->n_tiles_b11, job->max_pop, job->gram_i8, st);
         prof_end(job, st);
-        if (!cert_on_chain) HIPCHK(hipStreamWaitEvent(st, ev.side, 0));
+        HIPCHK(hipStreamWaitEvent(st, ev.side, 0));
         prof_begin(job, 4, st);
         launch_impute_gemm(job->d_probs, job->d_gemmmap, job->n_gemm, job->gemm_ut, job->d_finmap, job->n_fin, st);
         prof_end(job, st);

@@ -408,7 +408,9 @@ __device__ __forceinline__ void epilogue_tile(const Prob& pb, int pair_in, int l
     const int mt = pb.Mp / TILE;        // number of measured row tiles
     const bool sym = gb11 || (ti < mt); // measured x measured tile (ti <= tj)
     const int Mld = pb.Mld;
-    const bool need_a1 = !(pb.npanel > 0 && pb.status[3] != 0);      // status[3]: lambda_min(B11) > eps is certified
+    // status[3]: lambda_min(B11) > eps is certified.  Only B11's tiles read it (B21's tiles may run while the chain queue,
+    // which makes the certificate in a merged launch, is still busy: gauss_hip.cpp:job_run)
+    const bool need_a1 = !sym || !(pb.npanel > 0 && pb.status[3] != 0);
     const int tid = threadIdx.x;
     const bool weighted = pb.mode != 0;
     const bool lds_tables = weighted && P <= lds_pop_cap;
