@@ -87,6 +87,28 @@ def sq_mfma(tag, d, out):
             fh.write(",".join(row) + "\n")
 
 
+def by_grid(tag, d, out):
+    """Launch statistics per (kernel, grid size) from the kernel trace: the default bench command launches the same kernel on the
+    36-window headline job, on the eight emulated 8-rank shares and in the one-stream pass -- rocprofv3's own --stats table
+    averages a kernel's launches over all of them; here the headline job's launches are a line of their own."""
+    f = find(os.path.join(d, "stats"), "*kernel_trace.csv")
+    if not f:
+        return
+    acc = defaultdict(list)
+    with open(f) as fh:
+        for r in csv.DictReader(fh):
+            if "gauss" not in r["Kernel_Name"]:
+                continue
+            grid = r.get("Grid_Size_X") or r.get("Grid_Size") or ""
+            acc[(short(r["Kernel_Name"]), grid)].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    with open(os.path.join(out, f"{tag}_kernel_stats_by_grid.csv"), "w") as fh:
+        fh.write("kernel,grid_size_x_threads,calls,avg_us,min_us,max_us,total_ms\n")
+        for (k, g), v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
+            if sum(v) < 200.0 and len(v) < 4:        # (the long tail of one-off launches)
+                continue
+            fh.write(f"{k},{g},{len(v)},{sum(v) / len(v):.1f},{min(v):.1f},{max(v):.1f},{sum(v) / 1e3:.3f}\n")
+
+
 def provenance(tag, out):
     """Which code the profiles were taken on: the source hash compiled into the profiled library (gauss_hip_source_hash)
     and the git head the development container recorded for those sources (gauss_amd/lib/build_stamp.json; the GPU box
@@ -123,6 +145,7 @@ def main():
     ks = find(os.path.join(d, "stats"), "*kernel_stats.csv")
     if ks:
         shutil.copy(ks, os.path.join(out, f"{tag}_kernel_stats.csv"))
+    by_grid(tag, d, out)
     bj = os.path.join(d, "bench_under_rocprof.json")
     if os.path.exists(bj):
         with open(bj) as fh:
