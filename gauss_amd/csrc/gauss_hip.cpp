@@ -274,6 +274,7 @@ struct Plan {
     std::vector<long long> gene_out_off;
     std::vector<std::pair<int, int>> groups;   // runs of consecutive segments handled by one work item
     std::vector<std::pair<int, int>> fine;     // one run per segment: the short work items that fill the end of the launch
+    std::vector<int> tile_live;                // job-wide measured rows: live rows of every row tile (clusters end in padding rows)
     // user pointers
     const uint8_t* h_geno_m = nullptr;
     const uint8_t* h_geno_u = nullptr;
@@ -686,13 +687,21 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
         if (rc) return rc;
         job->plans[i].p.gram_i8 = job->gram_i8;
     }
-    // Shared measured rows: every window reads its measured SNPs from the same resident store, under the same
-    // populations, and each window's list is a run of ONE ascending job-wide list (windows of a chromosome in order).
+    // Shared measured rows: every window reads its measured SNPs from the same resident store under the same populations.
+    // The job keeps ONE list of measured rows, made of CLUSTERS: a window whose rows continue a run of the current cluster
+    // (the next window of a chromosome: half its measured SNPs are the previous window's) joins it at that offset -- when
+    // that costs no more B11 tile pairs than tiles of its own would -- and every other window starts a new cluster on a
+    // tile boundary (padding rows in between: never packed, all zero), where it costs exactly what its own tiles would.
+    // So sharing can only save work: the scattered windows of a multi-GPU share keep their own tiles, two neighbours that
+    // landed on the same rank share theirs (round 3 had one all-or-nothing list whose tiles started where the LIST started:
+    // a share's scattered windows paid an extra row tile each and sharing was switched off for them).
     if (on_device && !streamed && job->n >= 2 && env_int("GAUSS_SHARE_MEASURED", 1) != 0) {
         const Plan& a = job->plans[0];
         bool ok = true;
         std::vector<int32_t> gl;
         std::vector<int> g0((size_t)job->n, 0);
+        std::set<std::pair<int, int>> have;                     // job-wide B11 tile pairs so far
+        size_t cl0 = 0, own_pairs = 0;                          // start of the current cluster in gl
         for (int i = 0; i < job->n && ok; i++) {
             const Plan& b = job->plans[i];
             ok = !b.rows_m.empty() && !b.p.ld_only && !b.p.n_gene && b.p.P <= 32 && b.h_geno_m == a.h_geno_m && b.user_ld == a.user_ld &&
@@ -701,18 +710,45 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
                  b.seg_k1 == a.seg_k1 && b.seg_pop == a.seg_pop && b.run_src == a.run_src && b.run_pk_off == a.run_pk_off &&
                  b.groups == a.groups;
             if (!ok) break;
-            // where does this window's run start in the job-wide list?  (binary search: the list is ascending)
-            const int32_t first = b.rows_m[0];
-            size_t pos = (size_t)(std::lower_bound(gl.begin(), gl.end(), first) - gl.begin());
-            if (pos < gl.size() && gl[pos] != first) { ok = false; break; }
-            g0[(size_t)i] = (int)pos;
-            for (size_t k = 0; k < b.rows_m.size() && ok; k++) {
-                if (k > 0 && b.rows_m[k] <= b.rows_m[k - 1]) ok = false;
-                else if (pos + k < gl.size()) ok = gl[pos + k] == b.rows_m[k];
-                else gl.push_back(b.rows_m[k]);
+            const size_t M = b.rows_m.size(), mt = (M + TILE - 1) / TILE;
+            own_pairs += mt * (mt + 1) / 2;
+            // does the window continue a run of the current cluster?  (the cluster is ascending where that matters: a window
+            // only joins through a binary search for its first row and an element-wise comparison of the overlap)
+            size_t pos = gl.size();
+            bool join = false;
+            if (gl.size() > cl0 && std::is_sorted(gl.begin() + (ptrdiff_t)cl0, gl.end())) {
+                const int32_t first = b.rows_m[0];
+                const size_t p0 = (size_t)(std::lower_bound(gl.begin() + (ptrdiff_t)cl0, gl.end(), first) - gl.begin());
+                if (p0 < gl.size() && gl[p0] == first) {
+                    join = true;
+                    for (size_t k = 0; k < M && join; k++) {
+                        if (k > 0 && b.rows_m[k] <= b.rows_m[k - 1]) join = false;
+                        else if (p0 + k < gl.size() && gl[p0 + k] != b.rows_m[k]) join = false;
+                    }
+                    if (join) {
+                        // tile pairs the window would ADD as part of the cluster, against tiles of its own
+                        const int lo = (int)(p0 / TILE), hi = (int)((p0 + M - 1) / TILE);
+                        size_t add = 0;
+                        for (int ti = lo; ti <= hi; ti++)
+                            for (int tj = ti; tj <= hi; tj++) add += have.count(std::make_pair(ti, tj)) ? 0 : 1;
+                        join = add <= mt * (mt + 1) / 2;
+                        pos = p0;
+                    }
+                }
             }
+            if (!join) {
+                gl.resize(rup(gl.size(), TILE), -1);               // a new cluster on a tile boundary (padding rows: never packed)
+                cl0 = pos = gl.size();
+            }
+            g0[(size_t)i] = (int)pos;
+            for (size_t k = 0; k < M; k++)
+                if (pos + k >= gl.size()) gl.push_back(b.rows_m[k]);
+            const int lo = (int)(pos / TILE), hi = (int)((pos + M - 1) / TILE);
+            for (int ti = lo; ti <= hi; ti++)
+                for (int tj = ti; tj <= hi; tj++) have.insert(std::make_pair(ti, tj));
         }
-        if (ok && (long long)gl.size() < (1 << 24)) {
+        // worth the extra descriptor only if something IS shared (GAUSS_SHARE_MEASURED=2: always, for the tests)
+        if (ok && (long long)gl.size() < (1 << 24) && (have.size() < own_pairs || env_int("GAUSS_SHARE_MEASURED", 1) == 2)) {
             job->gplan.reset(new Plan(a));
             job->g0 = g0;
             Plan& g = *job->gplan;
@@ -735,14 +771,11 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
                         }
             }
             q.npair = (int)g.pair_ti.size();
-            // Job-wide tiles start where the list starts, not where a window does: a window of M rows lies in up to
-            // M / 128 + 2 of them, where its own tiles would be M / 128 + 1 -- more B11 pairs per window, which only
-            // pays when neighbouring windows share pairs.  The scattered windows of an LPT share (a multi-GPU rank)
-            // share nothing: 8-rank shares measured 5.98-6.04 ms per rank unshared against 6.0-6.4 shared.  Shared
-            // rows are used when they save at least 3 % of the job's B11 pairs.
-            size_t own_pairs = 0;
-            for (int i = 0; i < job->n; i++) { const size_t mt = (size_t)job->plans[i].p.Mp / TILE; own_pairs += mt * (mt + 1) / 2; }
-            if ((double)q.npair > 0.97 * (double)own_pairs && env_int("GAUSS_SHARE_MEASURED", 1) != 2) { job->gplan.reset(); job->g0.clear(); }
+            // live rows per job-wide row tile: up to the last real row in it (a cluster's last tile ends in padding rows, whose
+            // dead 32-row halves the Gram kernel skips exactly as it does in a window's own last tile)
+            g.tile_live.assign((size_t)q.nT, 0);
+            for (size_t r = 0; r < gl.size(); r++)
+                if (gl[r] >= 0) g.tile_live[r / TILE] = (int)(r % TILE) + 1;
         }
     }
     const bool shm = job->gplan != nullptr;
@@ -832,7 +865,8 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
         for (int pr = 0; pr < g.p.npair; pr++)
             for (size_t k = 0; k < g.groups.size(); k++)
                 items.push_back(ItemH{job->n, pr, (int)k, g.seg_k1[g.groups[k].second - 1] - g.seg_k0[g.groups[k].first]});
-        for (int r = 0; r < g.p.M; r++) rowmap.push_back(make_int2(job->n, r));
+        for (int r = 0; r < g.p.M; r++)
+            if (g.rows_m[(size_t)r] >= 0) rowmap.push_back(make_int2(job->n, r));      // (padding rows between clusters stay zero)
     }
     // Every `fine_every`-th tile pair is cut into one work item per K segment (a population: 64 ... 3 600 samples)
     // instead of runs of >= 2048 samples: sorted by length they end up last and fill the launch's final round, in which
@@ -1247,7 +1281,10 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
         const std::pair<int, int>& gr = h.group >= 0 ? pl.groups[h.group] : pl.fine[(size_t)(-1 - h.group)];
         const int ti = pl.pair_ti[h.pair], tj = pl.pair_tj[h.pair];
         const int mt = p.Mp / TILE;
-        auto rows = [&](int t) { int left = (t < mt) ? p.M - t * TILE : p.U - (t - mt) * TILE; return left > TILE ? TILE : left; };
+        auto rows = [&](int t) {
+            if (!pl.tile_live.empty()) return pl.tile_live[(size_t)t];
+            int left = (t < mt) ? p.M - t * TILE : p.U - (t - mt) * TILE; return left > TILE ? TILE : left;
+        };
         // a row tile of the measured part (for a window that shares its measured rows: inside the job-wide array, from
         // wherever the window starts) or of the unmeasured part
         auto tile_rows = [&](int t) { return t < mt ? p.packed + (size_t)t * TILE * p.Kp : p.packed_u + (size_t)(t - mt) * TILE * p.Kp; };
@@ -2413,7 +2450,10 @@ int gauss_job_stats(gauss_job* job, double* out4)
     auto add = [&](const Plan& pl, bool skip_b11) {
         const Prob& p = pl.p;
         const int mt = p.Mp / TILE;
-        auto rows = [&](int t) { int left = (t < mt) ? p.M - t * TILE : p.U - (t - mt) * TILE; return left > TILE ? TILE : left; };
+        auto rows = [&](int t) {
+            if (!pl.tile_live.empty()) return pl.tile_live[(size_t)t];
+            int left = (t < mt) ? p.M - t * TILE : p.U - (t - mt) * TILE; return left > TILE ? TILE : left;
+        };
         auto halves = [](int r, int w) { int n = (r - w * 64 + 31) / 32; return n < 0 ? 0 : (n > 2 ? 2 : n); };
         // samples per row the kernel multiplies: every zero-padded block (population, or 2-bit source block) rounded up to
         // the units the K loop can skip -- 8 samples on the f32 path (Item::chunk_live), 32 on the int8 path (whole groups);

@@ -153,7 +153,27 @@ def balance_windows(mu, n_samples, world_size, granule=64):
 CHAIN_STEP_COST = 2.0e8
 
 
-def level_windows(mu, n_samples, world_size, granule=64):
+def adjacency_saving(n_samples, m_a, m_b, shared):
+    """What a rank saves when it holds BOTH of two neighbouring windows (m_a, m_b measured SNPs, the last `shared` of a's being the
+    first of b's): the job then keeps one list of measured rows for the two (gauss_hip.cpp: shared measured rows, clusters) and
+    multiplies the B11 tile pairs that lie in both windows once.  Counted the way the job builder decides it: window b joins
+    a's cluster at row offset m_a - shared if that adds no more tile pairs than tiles of its own would; the saving is the
+    difference, priced like B11's other pairs (piece_cost's setup per pair of full tiles, less the average edge skipping)."""
+    if shared <= 0 or m_b <= 0:
+        return 0.0
+    pos = m_a - shared
+    lo, hi = pos // 128, (pos + m_b - 1) // 128
+    a_hi = (m_a - 1) // 128
+    add = sum(1 for ti in range(lo, hi + 1) for tj in range(ti, hi + 1) if not (tj <= a_hi))
+    mt = (m_b + 127) // 128
+    own = mt * (mt + 1) // 2
+    if add > own:
+        return 0.0
+    per_pair = 2048.0 * n_samples * _b11_units(m_b) / own          # B11's issued units of window b, per tile pair of its own
+    return (own - add) * per_pair
+
+
+def level_windows(mu, n_samples, world_size, granule=64, shared=None):
     """Whole windows by LPT, a local search, then LEVELLING with window cuts.
 
     A rank's load is the cost of its pieces plus the factorisation chain of its tallest window (CHAIN_STEP_COST per
@@ -169,8 +189,18 @@ def level_windows(mu, n_samples, world_size, granule=64):
     costs = [piece_cost(n_samples, m, u) for m, u in mu]
     nblk = [(m + 63) // 64 for m, _ in mu]
 
+    # shared[k]: measured SNPs windows k and k + 1 have in common (None: unknown, no adjacency term).  A rank that holds two
+    # neighbouring windows multiplies their common B11 tile pairs once (adjacency_saving); pieces of a cut window count too --
+    # every piece carries the window's whole B11.
+    adj = [0.0] * len(mu)
+    if shared is not None:
+        for k in range(len(mu) - 1):
+            adj[k] = adjacency_saving(n_samples, mu[k][0], mu[k + 1][0], int(shared[k]))
+
     def load_of(pieces):
+        held = {k for k, _, _ in pieces}
         return (sum(costs[k][0] + (u1 - u0) * costs[k][1] for k, u0, u1 in pieces)
+                - sum(adj[k] for k in held if k + 1 in held)
                 + CHAIN_STEP_COST * max((nblk[k] for k, _, _ in pieces), default=0))
 
     owner = assign_windows([b + u * r for (b, r), (_, u) in zip(costs, mu)], world_size)
@@ -194,6 +224,28 @@ def level_windows(mu, n_samples, world_size, granule=64):
             if best is None:
                 break
             _, r, shares[hi], shares[r] = best
+        if shared is not None:
+            # (2b) neighbours together: any two ranks trade or move a window when that lowers the LARGER of their two loads (the
+            # largest load of all never grows); with the adjacency term this is what collects neighbouring windows on one rank
+            for _ in range(8 * len(mu)):
+                loads = [load_of(sh) for sh in shares]
+                best = None
+                for ra in range(world_size):
+                    for rb in range(ra + 1, world_size):
+                        cur = max(loads[ra], loads[rb])
+                        for a in [None] + shares[ra]:
+                            for b in [None] + shares[rb]:
+                                if a is None and b is None:
+                                    continue
+                                g_a = [p for p in shares[ra] if p != a] + ([b] if b else [])
+                                g_b = [p for p in shares[rb] if p != b] + ([a] if a else [])
+                                m = max(load_of(g_a), load_of(g_b))
+                                gain = cur - m
+                                if gain > 1e-9 * cur and (best is None or gain > best[0]):
+                                    best = (gain, ra, rb, g_a, g_b)
+                if best is None:
+                    break
+                _, ra, rb, shares[ra], shares[rb] = best
         for _ in range(2 * world_size):                                  # (3) cuts
             loads = [load_of(sh) for sh in shares]
             hi = max(range(world_size), key=lambda r: (loads[r], -r))

@@ -411,3 +411,22 @@ def test_native_planner_cost_equals_the_python_planner():
             want = (b + u * r) / N
             got = h.gauss_host_plan_cost(m, u)
             assert abs(got - want) <= 1e-9 * max(1.0, want), (m, u, got, want)
+
+
+def test_planner_adjacency_term_collects_neighbours_and_keeps_the_tiling():
+    """farm.level_windows with the measured SNPs consecutive windows share: neighbours on one rank are priced at what the job
+    builder saves for them (farm.adjacency_saving), the second phase of the local search collects them, and the shares still
+    tile every window exactly; without the list nothing changes."""
+    rng = np.random.default_rng(5)
+    N = 32147
+    mu = [(int(rng.integers(150, 1200)), int(rng.integers(500, 2600))) for _ in range(36)]
+    shared = [min(mu[k][0], mu[k + 1][0]) // 2 for k in range(35)]
+    plain, _ = farm.level_windows(mu, N, 8)
+    adj, loads = farm.level_windows(mu, N, 8, shared=shared)
+    for shares in (plain, adj):
+        _check_shares(shares, mu, 8)
+    pairs = lambda shares: sum(1 for s in shares for k, _, _ in s if any(q[0] == k + 1 for q in s))
+    assert pairs(adj) > pairs(plain)
+    assert max(loads) / (sum(loads) / len(loads)) < 1.02
+    assert farm.adjacency_saving(N, 700, 700, 0) == 0.0 and farm.adjacency_saving(N, 700, 700, 350) > 0.0
+    assert farm.adjacency_saving(N, 700, 640, 1) == 0.0             # one common SNP: joining at row 699 would cost 640 rows a sixth tile, the builder declines
