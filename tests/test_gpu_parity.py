@@ -706,6 +706,35 @@ def test_shared_measured_rows_give_the_bits_of_separate_windows(ctx, monkeypatch
                 assert np.array_equal(x[key], y[key], equal_nan=True), key
             else:
                 assert x[key] == y[key], key
+    # Clusters (round 4): the windows of a multi-GPU share are scattered -- a window that does not continue the previous one's
+    # rows starts a cluster of its own on a tile boundary, two neighbours share theirs.  Here: windows 0 and 1 (neighbours), a
+    # far one, then windows 2 and 3 out of chromosome order (3 before 2: not a run of the cluster, a cluster of its own) and a
+    # window whose measured rows are not even ascending.  Same bits as separate windows, and never more issued work.
+    far = measured[len(measured) - 140:]
+    ui_far = unmeasured[unmeasured > far[70]][:90]
+    w_far = dict(mode=1, pop_off=p["off"], pop_wgt=p["w"], z1=z[far], dev=(store.ptr, store.ptr, len(far), len(ui_far), store.ld),
+                 packed=dict(fmt=1, rows_m=far.astype(np.int32), rows_u=ui_far.astype(np.int32), pop_src_off=src_off))
+    perm = rng.permutation(150)
+    mi_p = measured[250:400][perm]
+    w_perm = dict(mode=1, pop_off=p["off"], pop_wgt=p["w"], z1=z[mi_p], dev=(store.ptr, store.ptr, len(mi_p), len(ui_far), store.ld),
+                  packed=dict(fmt=1, rows_m=mi_p.astype(np.int32), rows_u=ui_far.astype(np.int32), pop_src_off=src_off))
+    keep = wins
+    wins = [keep[0], keep[1], w_far, keep[3], keep[2], w_perm]
+    own2, st_own2 = run(False)
+    shared2, st_sh2 = run(True)
+    assert st_sh2["executed_flops"] <= st_own2["executed_flops"]         # neighbours share where it saves tile pairs; nobody pays for it
+    for x, y in zip(own2, shared2):
+        for key in x:
+            if isinstance(x[key], np.ndarray):
+                assert np.array_equal(x[key], y[key], equal_nan=True), key
+            else:
+                assert x[key] == y[key], key
+    wins = [keep[0], w_far, w_perm]                                          # nothing to share at all: the job keeps the windows' own tiles
+    own3, st_own3 = run(False)
+    shared3, st_sh3 = run(True)
+    assert st_sh3["executed_flops"] == st_own3["executed_flops"] and st_sh3["items"] == st_own3["items"]
+    for x, y in zip(own3, shared3):
+        assert np.array_equal(x["z"], y["z"]) and np.array_equal(x["info"], y["info"])
     store.close()
 
 
