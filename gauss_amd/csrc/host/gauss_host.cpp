@@ -34,6 +34,7 @@
 #include <thread>
 #include <vector>
 
+#include <sys/resource.h>
 #include <sys/stat.h>
 #include <sys/file.h>
 #include <fcntl.h>
@@ -2635,6 +2636,8 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
             }
         }
         double tt = now_s();
+        struct rusage ru0;
+        getrusage(RUSAGE_SELF, &ru0);
         parallel_for((int)slots[b].size(), nthreads_tables, [&](int k) {
             Slot& sl = slots[b][k];
             if (!sl.ok) return;
@@ -2643,8 +2646,15 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
             else { wins[batches[b][k]].status = 2; wins[batches[b][k]].why = gauss_host_last_error(); }
             sl.p.reset();
         });
+        const double t_fin = now_s();
         append_batch(b);
         st.t_tables += now_s() - tt;
+        if (getenv("GAUSS_CHROM_TRACE")) {
+            struct rusage ru1;
+            getrusage(RUSAGE_SELF, &ru1);
+            fprintf(stderr, "[chrom] retire batch %d: tables %.2f ms (finish %.2f, append %.2f), %ld minor faults, %d windows\n", b, (now_s() - tt) * 1e3,
+                    (t_fin - tt) * 1e3, (now_s() - t_fin) * 1e3, ru1.ru_minflt - ru0.ru_minflt, (int)slots[b].size());
+        }
     };
     for (int b = 0; b < n_batches && !rc_fatal; b++) {
         double tw = now_s();
