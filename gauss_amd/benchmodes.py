@@ -321,7 +321,18 @@ def run_computeld(args, rig):
     one = hotpath.Job([desc()], ctx=ctx, on_device=True)
     dt1, st1, r1 = _time_job(rig, one, steps, args.warmup)
     B = 32
-    many = hotpath.Job([desc() for _ in range(B)], ctx=ctx, on_device=True)
+    # (the 32 windows are 32 copies of the config's one window: a job would recognise their common measured rows and multiply the
+    # B11 tile pairs ONCE for all of them -- shared measured rows, DESIGN.md section 3 -- which is not what 32 different
+    # computeLD() windows cost; built with sharing off, every copy packs and multiplies its own rows)
+    old_share = os.environ.get("GAUSS_SHARE_MEASURED")
+    os.environ["GAUSS_SHARE_MEASURED"] = "0"
+    try:
+        many = hotpath.Job([desc() for _ in range(B)], ctx=ctx, on_device=True)
+    finally:
+        if old_share is None:
+            del os.environ["GAUSS_SHARE_MEASURED"]
+        else:
+            os.environ["GAUSS_SHARE_MEASURED"] = old_share
     dtb, stb, rb = _time_job(rig, many, steps, args.warmup)
     ok = bool(np.array_equal(r1[0]["b11"], ref) and all(np.array_equal(x["b11"], ref) for x in rb) and
               np.allclose(np.diag(ref), 1.0) and np.array_equal(ref, ref.T))
