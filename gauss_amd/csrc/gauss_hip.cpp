@@ -315,7 +315,7 @@ struct gauss_job {
     // HOST ORDER by the same call of job_run: the wait captures the record that precedes it, so re-arming the event for the
     // next run could never redirect an earlier wait.  Each parity still owns its set: no event object is ever re-armed
     // while a wait on its previous record may be pending in another queue (tools/experiments/README.md, "any-order launch").
-    struct RunEvents { hipEvent_t gram = nullptr, side = nullptr, pack = nullptr, rows = nullptr; };
+    struct RunEvents { hipEvent_t gram = nullptr, side = nullptr, pack = nullptr, rows = nullptr, epi = nullptr; };     // epi: the early windows' epilogue tiles done (low-priority queue)
     RunEvents rev[2];
     Prob* d_probs = nullptr;
     Item* d_items = nullptr;    int n_items = 0;
@@ -352,6 +352,11 @@ struct gauss_job {
     unsigned long long* d_b11_done = nullptr;              // merged Gram launch: B11's items that have finished, over all runs so far
     bool merged = false;                                   // chain_aside as ONE Gram launch (B11's items first, counted; job_run)
     unsigned long long merged_runs = 0;                    // merged Gram launches queued so far (the counter's target is this x n_items_b11)
+    // Early epilogue (merged launches): B21's items of the "early" windows come before those of the "late" ones and count
+    // themselves off in a second counter; their epilogue tiles wait for that count on the LOW-priority queue, whose workgroups
+    // the hardware dispatches when the Gram grid has none left to hand out -- i.e. they fill the Gram launch's last round.
+    int n_items_b21_early = 0;                             // B21 items of the early windows (right behind B11's items)
+    int n_tiles_b21_early = 0;                             // their epilogue tiles (first among B21's tiles)
     double* d_results = nullptr; size_t n_results = 0;     // z then info per problem
     // Two runs may be in flight: run k + 1 can be queued before run k has been fetched, so that the host's share of a
     // step (waking up, copying results out, queuing the next run) overlaps GPU work.  Result mirrors and completion
@@ -845,6 +850,7 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
     // work lists
     struct ItemH { int prob, pair, group, len; };
     std::vector<ItemH> items;
+    std::vector<char> late_window;                         // early epilogue: windows whose B21 items end the merged launch
     std::vector<int2> rowmap, tilemap, tilemap_b21, panelmap, dpanelmap, gemmmap, finmap;
     job->max_nblk = 0;
     {
@@ -958,6 +964,30 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
             const int mm = env_int("GAUSS_CHAIN_MERGED", 1);
             job->merged = job->chain_aside && mm != 0 && (!job->gram_i8 || mm == 2);
         }
+        // Early epilogue: the smallest windows of the job that together hold about a third of B21's Gram work are "late" -- their
+        // items end the launch -- and every other window is "early" (GAUSS_EPI_EARLY=0: off; GAUSS_EPI_LATE_PCT: the share.  Measured,
+        // 36-window step / slowest 8-rank share: off 40.04 / 5.45 ms; 6 % 39.89 / 5.51; 12 % 39.76 / 5.51; 25 % 39.75 / 5.45; 35 %
+        // 39.67 / 5.40; 50 % 39.64 / 5.47 -- a late part that is too small opens the gate only when the launch is all but over and
+        // the two epilogue launches cost their event hops).  One window: nothing to split.
+        late_window.assign((size_t)job->n + 1, 0);
+        if (job->merged && job->n >= 2 && job->ctx->side && env_int("GAUSS_EPI_EARLY", 1) != 0) {
+            std::vector<double> w21((size_t)job->n, 0.0);
+            double tot = 0;
+            for (const ItemH& h : items) if (!is_b11(h)) { w21[(size_t)h.prob] += h.len; tot += h.len; }
+            const double want = tot * env_int("GAUSS_EPI_LATE_PCT", 35) / 100.0;
+            double acc = 0;
+            int n_late = 0;
+            // (the windows with the least B21 work: a share of four windows gives up its smallest one, not whichever comes last)
+            std::vector<int> by_work((size_t)job->n);
+            for (int i = 0; i < job->n; i++) by_work[(size_t)i] = i;
+            std::stable_sort(by_work.begin(), by_work.end(), [&](int a, int b) { return w21[(size_t)a] < w21[(size_t)b]; });
+            for (int k = 0; k + 1 < job->n && acc < want; k++) { late_window[(size_t)by_work[(size_t)k]] = 1; acc += w21[(size_t)by_work[(size_t)k]]; n_late++; }
+            if (n_late > 0 && acc < tot) {
+                auto is_late = [&](const ItemH& h) { return !is_b11(h) && late_window[(size_t)h.prob] != 0; };
+                std::stable_sort(items.begin() + job->n_items_b11, items.end(), [&](const ItemH& a, const ItemH& b) { return !is_late(a) && is_late(b); });
+                for (size_t n = (size_t)job->n_items_b11; n < items.size(); n++) job->n_items_b21_early += is_late(items[n]) ? 0 : 1;
+            } else late_window.assign((size_t)job->n + 1, 0);
+        }
     }
     std::vector<int> sgroup_of_item;
     if (streamed) {
@@ -1009,12 +1039,19 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
         };
         if (!streamed) {
             interleave(0, (size_t)job->n_items_b11);
-            interleave((size_t)job->n_items_b11, items.size());
+            if (job->n_items_b21_early > 0) {
+                interleave((size_t)job->n_items_b11, (size_t)(job->n_items_b11 + job->n_items_b21_early));
+                interleave((size_t)(job->n_items_b11 + job->n_items_b21_early), items.size());
+            } else interleave((size_t)job->n_items_b11, items.size());
         }
     }
     const size_t o_items = ta.take(sizeof(Item) * std::max<size_t>(items.size(), 1));
     const size_t o_rowmap = put(blob, ta, rowmap);
     job->n_tiles_b11 = (int)tilemap.size();
+    if (job->n_items_b21_early > 0) {
+        std::stable_sort(tilemap_b21.begin(), tilemap_b21.end(), [&](const int2& a, const int2& b) { return !late_window[(size_t)a.x] && late_window[(size_t)b.x]; });
+        for (const int2& t : tilemap_b21) job->n_tiles_b21_early += late_window[(size_t)t.x] ? 0 : 1;
+    }
     tilemap.insert(tilemap.end(), tilemap_b21.begin(), tilemap_b21.end());
     const size_t o_tilemap = put(blob, ta, tilemap);
     // the product's tiles with the longest K loop (highest k block) first
@@ -1112,7 +1149,7 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
         go.slab = wslab.take((size_t)q.npair * q.nseg * TILE * TILE * (q.slab16 ? sizeof(uint16_t) : sizeof(float)));
     }
     const size_t o_status = wa.take(sizeof(int) * (4 * job->n + 4));    // [n][4], then 4 job-wide ints ([4 n]: the chain queue timed out)
-    const size_t o_count = wa.take(64);                                  // b11_done counter of the merged Gram launch (zeroed once; only grows)
+    const size_t o_count = wa.take(128);                                 // counters of the merged Gram launch, a cache line each: [0] B11's items, [8] the early windows' B21 items (zeroed once; they only grow)
     const size_t o_results = wa.take(sizeof(double) * std::max<size_t>(res, 1));
     job->n_results = res;
     const size_t slab_base = rup(wa.off, 4096);
@@ -1141,7 +1178,7 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
     job->done = job->done2[0];
     HIPCHK(hipEventCreate(&job->begin));
     for (int k = 0; k < 2; k++)
-        for (hipEvent_t* e : {&job->rev[k].gram, &job->rev[k].side, &job->rev[k].pack, &job->rev[k].rows})
+        for (hipEvent_t* e : {&job->rev[k].gram, &job->rev[k].side, &job->rev[k].pack, &job->rev[k].rows, &job->rev[k].epi})
             HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
 
     hipStream_t st = ctx->stream;
@@ -1297,7 +1334,8 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
         it.Kp = p.Kp; it.k0 = pl.seg_k0[gr.first]; it.nseg = gr.second - gr.first;
         static const int no_edge16 = env_int("GAUSS_GRAM_EDGE16", 1) == 0 ? 8 : 0;
         it.rows_a = rows(ti); it.rows_b = rows(tj); it.flags = (ti == tj ? 1 : 0) | (p.slab16 ? 2 : 0) | no_edge16;
-        if (job->merged && (int)n < job->n_items_b11) it.flags |= 16;         // counts itself off in b11_done
+        if (job->merged && (int)n < job->n_items_b11) it.flags |= 16;         // counts itself off in b11_done[0]
+        else if (job->merged && (int)n < job->n_items_b11 + job->n_items_b21_early) it.flags |= 32;      // ... in b11_done[8] (the early windows' B21 items)
         memcpy(blob.data() + o_items + sizeof(Item) * n, &it, sizeof(Item));
     }
     memcpy(job->h_pin, blob.data(), blob.size());
@@ -1460,9 +1498,26 @@ static int job_run(gauss_job* job, bool solve)
         HIPCHK(hipEventRecord(ev.side, ch));
         // (B21's tiles read neither B11 nor the certificate -- epilogue_tile looks at status[3] for B11's tiles only -- so they
         // need not wait for the chain queue; the closing product does)
+        if (job->merged && job->n_tiles_b21_early > 0) {
+            // Early epilogue: the tiles of the windows whose B21 items are done before the launch's last round go to the LOW-priority
+            // queue behind a wait for their count.  The hardware hands a lower-priority queue's workgroups out when the Gram grid
+            // has none left to dispatch: they run in the slots the launch's last round leaves idle (measured: 0.16 ms of the
+            // 36-window step, 0.09 ms of an 8-rank share's).  The late windows' tiles follow the launch on the main queue.
+            hipStream_t lo = job->ctx->side;
+            HIPCHK(hipStreamWaitEvent(lo, ev.gram, 0));
+            launch_wait_count(job->d_b11_done + 8, job->merged_runs * (unsigned long long)job->n_items_b21_early, job->d_status + 4 * job->n, 1, lo);
+            launch_epilogue(job->d_probs, job->d_tilemap + job->n_tiles_b11, job->n_tiles_b21_early, job->max_pop, job->gram_i8, lo);
+            HIPCHK(hipEventRecord(ev.epi, lo));
+            prof_begin(job, 2, st);
+            launch_epilogue(job->d_probs, job->d_tilemap + job->n_tiles_b11 + job->n_tiles_b21_early,
+                            job->n_tiles - job->n_tiles_b11 - job->n_tiles_b21_early, job->max_pop, job->gram_i8, st);
+            prof_end(job, st);
+            HIPCHK(hipStreamWaitEvent(st, ev.epi, 0));
+        } else {
         prof_begin(job, 2, st);
         launch_epilogue(job->d_probs, job->d_tilemap + job->n_tiles_b11, job->n_tiles - job->n_tiles_b11, job->max_pop, job->gram_i8, st);
         prof_end(job, st);
+        }
         HIPCHK(hipStreamWaitEvent(st, ev.side, 0));
         prof_begin(job, 4, st);
         launch_impute_gemm(job->d_probs, job->d_gemmmap, job->n_gemm, job->gemm_ut, job->d_finmap, job->n_fin, st);
@@ -1852,7 +1907,7 @@ static void job_release(gauss_job* job)
     if (job->begin) hipEventDestroy(job->begin);
     for (int k = 0; k < 2; k++) if (job->done2[k]) hipEventDestroy(job->done2[k]);
     for (int k = 0; k < 2; k++)
-        for (hipEvent_t* e : {&job->rev[k].gram, &job->rev[k].side, &job->rev[k].pack, &job->rev[k].rows})
+        for (hipEvent_t* e : {&job->rev[k].gram, &job->rev[k].side, &job->rev[k].pack, &job->rev[k].rows, &job->rev[k].epi})
             if (*e) { hipEventDestroy(*e); *e = nullptr; }
     for (hipEvent_t e : job->sevp) if (e) hipEventDestroy(e);
     job->sevp.clear();

@@ -385,7 +385,8 @@ __device__ __forceinline__ void gram_item(const Item& it, uint8_t* lds)
 // (k_solve_lite.hip); the common paths need 104, the 16-column edge path would take 107 if left alone.
 //
 // `b11_done` (may be null): items with flag bit 4 -- B11's tile pairs of a job whose factorisation chain runs beside this launch
-// (gauss_hip.cpp:job_run) -- count themselves off there when their slabs are out, so that the chain queue can start on B11 while
+// (gauss_hip.cpp:job_run) -- and items with flag bit 5 -- B21's tile pairs of the windows whose epilogue tiles fill this launch's
+// last round -- count themselves off there (counters [0] and [8]) when their slabs are out, so that the chain queue can start on B11 while
 // this SAME launch goes on with B21's items: no second launch, no drained chip between the two.  The hand-off follows the
 // producer recipe for data another kernel reads (MI355X_MICROARCH.md, inter-workgroup visibility): every storing wave waits for
 // its stores, the workgroup meets at a barrier, one lane releases at agent scope (writes the XCD L2's dirty lines back), waits
@@ -398,7 +399,7 @@ __global__ __launch_bounds__(256, OCC) __attribute__((amdgpu_num_vgpr(52))) void
     __shared__ __attribute__((aligned(16))) uint8_t lds[NS * 2 * LTILE];
 
     const Item& it = items[blockIdx.x];
-    const bool counted = (it.flags & 16) != 0;                        // scalar: read before the K loop's memory clobbers
+    const int counted = it.flags & 48;                                // scalar: read before the K loop's memory clobbers
     gram_item<ACC, NS>(it, lds);
     if (counted && b11_done) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's slab stores have reached the L2
@@ -406,7 +407,8 @@ __global__ __launch_bounds__(256, OCC) __attribute__((amdgpu_num_vgpr(52))) void
         if (threadIdx.x == 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");        // buffer_wbl2 sc1: visible to the other XCDs
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the compiler may drop the fence's own wait: guide, compiler hazard)
-            __hip_atomic_fetch_add(b11_done, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // counter 0: B11's items (the chain queue waits for them); counter 1, a cache line on: the early windows' B21 items
+            __hip_atomic_fetch_add(b11_done + ((counted & 32) ? 8 : 0), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
