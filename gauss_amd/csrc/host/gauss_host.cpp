@@ -1173,6 +1173,11 @@ static gauss_table* dist_output(gauss_prepared& p)     // dist.cpp:91-124 / dist
     Column a1{"a1", GAUSS_COL_STR, {}, {}, {}}, a2{"a2", GAUSS_COL_STR, {}, {}, {}};
     Column af{mix ? "af1mix" : "af1ref", GAUSS_COL_DBL, {}, {}, {}}, z{"z", GAUSS_COL_DBL, {}, {}, {}};
     Column pval{"pval", GAUSS_COL_DBL, {}, {}, {}}, info{"info", GAUSS_COL_DBL, {}, {}, {}}, type{"type", GAUSS_COL_INT, {}, {}, {}};
+    size_t n_out = 0;
+    for (Snp* s : p.snp_vec) { const int ibp = (int)s->bp; n_out += (ibp >= a.start_bp && ibp <= a.end_bp) ? 1 : 0; }
+    for (Column* c : {&rsid, &a1, &a2}) c->s.reserve(n_out);
+    for (Column* c : {&chr, &bp, &type}) c->i.reserve(n_out);
+    for (Column* c : {&af, &z, &pval, &info}) c->d.reserve(n_out);
     for (Snp* s : p.snp_vec) {
         const int ibp = (int)s->bp;                               // dist.cpp:92
         if (ibp >= a.start_bp && ibp <= a.end_bp) {
@@ -1184,7 +1189,8 @@ static gauss_table* dist_output(gauss_prepared& p)     // dist.cpp:91-124 / dist
             info.d.push_back(s->info); type.i.push_back(s->type);
         }
     }
-    t->cols = {rsid, chr, bp, a1, a2, af, z, pval, info, type};
+    t->cols.reserve(10);                                          // (moved, not copied: a chromosome's tables are 92 000 rows)
+    for (Column* c : {&rsid, &chr, &bp, &a1, &a2, &af, &z, &pval, &info, &type}) t->cols.push_back(std::move(*c));
     return t;
 }
 
@@ -1211,7 +1217,8 @@ static gauss_table* qcat_output(gauss_prepared& p)     // qcat.cpp:94-131 / qcat
             type.i.push_back(s->type);
         }
     }
-    t->cols = {rsid, chr, bp, a1, a2, af, z, qm, qt, qc, qp, type};
+    t->cols.reserve(12);
+    for (Column* c : {&rsid, &chr, &bp, &a1, &a2, &af, &z, &qm, &qt, &qc, &qp, &type}) t->cols.push_back(std::move(*c));
     return t;
 }
 
