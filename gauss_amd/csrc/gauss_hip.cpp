@@ -351,6 +351,7 @@ struct gauss_job {
     int* d_status = nullptr;                               // [n][4] + 4 job-wide ints
     unsigned long long* d_b11_done = nullptr;              // merged Gram launch: B11's items that have finished, over all runs so far
     bool merged = false;                                   // chain_aside as ONE Gram launch (B11's items first, counted; job_run)
+    double wait_bound_us = 0.0;                            // give-up bound of the merged launch's waits: 50 x the launch's estimated time (>= 2 s)
     unsigned long long merged_runs = 0;                    // merged Gram launches queued so far (the counter's target is this x n_items_b11)
     // Early epilogue (merged launches): B21's items of the "early" windows come before those of the "late" ones and count
     // themselves off in a second counter; their epilogue tiles wait for that count on the LOW-priority queue, whose workgroups
@@ -945,6 +946,11 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
         for (int i = 0; i < job->n; i++) genes = genes || job->plans[i].p.n_gene > 0;
         // (the int8 Gram kernel is ~8 x faster: an 8-rank share's B21 launch, 0.5 ms, no longer covers its chain)
         const double t_b21 = b21_len * 2.0 * TILE * TILE / (job->gram_i8 ? 960e12 : 120e12), t_chain = 0.5e-3 + 100e-6 * job->max_nblk;
+        {
+            double all_len = 0.0;
+            for (const ItemH& h : items) all_len += (double)h.len;
+            job->wait_bound_us = 50.0 * 1e6 * all_len * 2.0 * TILE * TILE / (job->gram_i8 ? 960e12 : 120e12);      // a whole-genome job must not trip a fixed bound
+        }
         job->chain_aside = !streamed && mode != 0 && !panelmap.empty() && !tilemap_b21.empty() && !genes && job->ctx->chain &&
                            job->ctx->side && (mode == 2 || t_b21 >= 1.2 * t_chain);
         // (GAUSS_GRAM_SPLIT=1: the two-launch form of the Gram kernel without the chain beside it -- bench.py's one-stream pass,
@@ -1466,7 +1472,7 @@ static int job_run(gauss_job* job, bool solve)
             prof_end(job, st);
             HIPCHK(hipStreamWaitEvent(ch, ev.gram, 0));
             if (cert_on_chain) launch_shift_cert(job->d_probs, job->n, ch);
-            launch_wait_count(job->d_b11_done, job->merged_runs * (unsigned long long)job->n_items_b11, job->d_status + 4 * job->n, 1, ch);
+            launch_wait_count(job->d_b11_done, job->merged_runs * (unsigned long long)job->n_items_b11, job->d_status + 4 * job->n, 1, ch, job->wait_bound_us);
         } else {
         prof_begin(job, 0, st, 2);
         launch_gram(job->d_items, job->n_items_b11, job->gram_i8, st);
@@ -1505,7 +1511,7 @@ static int job_run(gauss_job* job, bool solve)
             // 36-window step, 0.09 ms of an 8-rank share's).  The late windows' tiles follow the launch on the main queue.
             hipStream_t lo = job->ctx->side;
             HIPCHK(hipStreamWaitEvent(lo, ev.gram, 0));
-            launch_wait_count(job->d_b11_done + 8, job->merged_runs * (unsigned long long)job->n_items_b21_early, job->d_status + 4 * job->n, 1, lo);
+            launch_wait_count(job->d_b11_done + 8, job->merged_runs * (unsigned long long)job->n_items_b21_early, job->d_status + 4 * job->n, 1, lo, job->wait_bound_us);
             launch_epilogue(job->d_probs, job->d_tilemap + job->n_tiles_b11, job->n_tiles_b21_early, job->max_pop, job->gram_i8, lo);
             HIPCHK(hipEventRecord(ev.epi, lo));
             prof_begin(job, 2, st);

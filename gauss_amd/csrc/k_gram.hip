@@ -433,11 +433,12 @@ __global__ __launch_bounds__(64) void wait_count_kernel(const unsigned long long
     for (int i = 0; i < n_status; i++) status[i] = 1;                 // the job-wide failure flag (gauss_job_fetch reports the run as failed)
 }
 
-void launch_wait_count(const unsigned long long* d_count, unsigned long long target, int* d_status, int n_status, hipStream_t s)
+void launch_wait_count(const unsigned long long* d_count, unsigned long long target, int* d_status, int n_status, hipStream_t s,
+                       double bound_us)
 {
-    // two seconds of wall_clock64 ticks (100 MHz); GAUSS_WAIT_COUNT_TIMEOUT_US overrides; a NEGATIVE value is the tests' way into
+    // two seconds of wall_clock64 ticks (100 MHz), or the caller's larger bound; GAUSS_WAIT_COUNT_TIMEOUT_US overrides; a NEGATIVE value is the tests' way into
     // the give-up path: the wait is for a count that never comes and ends after that many microseconds
-    unsigned long long ticks = 200000000ull;
+    unsigned long long ticks = bound_us > 2e6 ? (unsigned long long)(bound_us * 100.0) : 200000000ull;     // (the caller's bound for very large jobs)
     if (const char* e = getenv("GAUSS_WAIT_COUNT_TIMEOUT_US")) {
         const long long us = atoll(e);
         if (us < 0) target = ~0ull;
