@@ -256,7 +256,7 @@ def test_merged_launch_gives_up_instead_of_hanging(ctx, monkeypatch):
         wins.append(dict(mode=1, pop_off=p["off"], pop_wgt=p["w"], z1=rng.standard_normal(len(mi)), dev=(store.ptr, store.ptr, len(mi), len(ui), store.ld),
                          packed=dict(fmt=1, rows_m=mi, rows_u=ui, pop_src_off=src_off)))
     monkeypatch.setenv("GAUSS_CHAIN_ASIDE", "2")              # the merged form on a job this small ...
-    monkeypatch.setenv("GAUSS_CHAIN_MERGED", "1")             # ... whatever the session's environment says
+    monkeypatch.setenv("GAUSS_CHAIN_MERGED", "2")             # ... whatever the session's environment says (2: also for int8 jobs)
     job = hotpath.Job(wins, ctx=ctx, on_device=True)
     monkeypatch.setenv("GAUSS_WAIT_COUNT_TIMEOUT_US", "-2000")     # wait 2 ms for a count that never comes
     job.run()
