@@ -575,10 +575,12 @@ def run_impute(args, rig):
                                 % (tails_alone["steps"], tails_alone["ms_per_step"])) if tails_alone else "the headline run's stage timers",
             },
             "stage_ms_per_step": per_step,
-            "stage_note": "HIP-event time per stage on the stream it runs on.  With the chain beside the Gram kernel (default for "
-                          "jobs whose B21 launch can cover it): gram = both launches, ld_epilogue = B11's + B21's tiles, `factor` = the "
-                          "small-footprint chain on the chain queue UNDER the second Gram launch (hidden: not part of the step's "
-                          "critical path); otherwise ld_epilogue = B11's tiles and B21's run on the side stream beside `factor`",
+            "stage_note": "HIP-event time per stage on the queue it runs on.  With the chain beside the Gram kernel (default for jobs whose "
+                          "B21 items can cover it): gram = the ONE launch per step (B11's items first, counted off for the chain queue); "
+                          "ld_epilogue = B11's tiles (chain queue, under the Gram launch) + the LATE windows' B21 tiles on the main queue -- "
+                          "the early windows' B21 tiles run on the low-priority queue in the Gram launch's last round and are not on this "
+                          "timer; `factor` = the small-footprint chain on the chain queue UNDER the Gram launch (hidden: not part of the "
+                          "step's critical path); otherwise ld_epilogue = B11's tiles and B21's run on the side queue beside `factor`",
         }
         # the HBM-bound kernels (K1 pack, K4 LD epilogue), timed stand-alone in the one-stream pass (in the
         # headline run B11's epilogue tiles run beside the Gram kernel): algorithmic bytes = the 2-bit source rows in
