@@ -2512,6 +2512,7 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
             bool last;
             { std::lock_guard<std::mutex> lock(mu); last = (--left[b] == 0); }
             if (last) cv.notify_all();
+            if (last && getenv("GAUSS_CHROM_TRACE")) fprintf(stderr, "[chrom] data layer of batch %d done at %.2f ms\n", b, (now_s() - t_begin) * 1e3);
         });
     });
 
