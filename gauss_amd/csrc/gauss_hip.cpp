@@ -680,6 +680,7 @@ static void job_free(gauss_job* job);
 static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_device, gauss_job** out, const StreamSetup* stream = nullptr)
 {
     const bool streamed = stream != nullptr;
+    const auto tb0 = std::chrono::steady_clock::now();
     gauss_job* job = new gauss_job();
     // every early return below (bad arguments, a failed HIP call) releases the job and what it owns
     std::unique_ptr<gauss_job, void (*)(gauss_job*)> guard(job, job_free);
@@ -1162,8 +1163,10 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
     for (WsOff& w : wo) w.slab += slab_base;
     go.slab += slab_base;
     job->ws_bytes = slab_base + wslab.off;
-    job->tab_bytes = blob.size();
+    job->tab_bytes = rup(blob.size(), 16);                               // (copied in 16-byte words, below)
 
+    static const bool job_trace = getenv("GAUSS_JOB_TRACE") != nullptr;
+    const auto tj0 = std::chrono::steady_clock::now();
     hipError_t e = ctx_dev_alloc(ctx, job->ws_bytes, (void**)&job->d_ws);
     if (e != hipSuccess) { job->d_ws = nullptr; return fail(GAUSS_E_NOMEM, "hipMalloc(%zu bytes workspace) failed: %s", wa.off, hipGetErrorString(e)); }
     e = ctx_dev_alloc(ctx, job->tab_bytes, (void**)&job->d_tab);
@@ -1182,6 +1185,7 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
     job->h_results = job->h_res2[0];
     job->h_status = job->h_st2[0];
     job->done = job->done2[0];
+    const auto tj1 = std::chrono::steady_clock::now();
     HIPCHK(hipEventCreate(&job->begin));
     for (int k = 0; k < 2; k++)
         for (hipEvent_t* e : {&job->rev[k].gram, &job->rev[k].side, &job->rev[k].pack, &job->rev[k].rows, &job->rev[k].epi})
@@ -1344,8 +1348,19 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
         else if (job->merged && (int)n < job->n_items_b11 + job->n_items_b21_early) it.flags |= 32;      // ... in b11_done[8] (the early windows' B21 items)
         memcpy(blob.data() + o_items + sizeof(Item) * n, &it, sizeof(Item));
     }
+    const auto tj2 = std::chrono::steady_clock::now();
     memcpy(job->h_pin, blob.data(), blob.size());
-    HIPCHK(hipMemcpyAsync(job->d_tab, job->h_pin, blob.size(), hipMemcpyHostToDevice, st));
+    // The table image crosses PCIe by kernel, not by hipMemcpyAsync: while a background upload keeps the DMA engines busy
+    // (gauss_store_upload_async: a chromosome's first call) the runtime made the CALLER wait for an engine -- one job creation in
+    // five stalled for 11-16 ms on these few MB (GAUSS_JOB_TRACE=1, round 4), the GPU idle meanwhile.
+    launch_h2d_copy(job->d_tab, job->h_pin, job->tab_bytes, st);
+    HIPCHK(hipGetLastError());
+    if (job_trace) {
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "[job] %d windows: plan %.2f ms, allocations %.2f ms (workspace %.1f MB, tables %.2f MB, pinned %.2f MB), events + zeroing + tables %.2f ms, table copy queued in %.2f ms\n",
+                job->n, ms(tb0, tj0), ms(tj0, tj1), job->ws_bytes / 1e6, job->tab_bytes / 1e6, (pin_tab + 2 * (pin_res + pin_st)) / 1e6, ms(tj1, tj2),
+                ms(tj2, std::chrono::steady_clock::now()));
+    }
     job->d_probs = (Prob*)(job->d_tab + o_probs);
     job->d_items = (Item*)(job->d_tab + o_items);
     job->d_rowmap = (int2*)(job->d_tab + o_rowmap);
@@ -1407,10 +1422,17 @@ static int job_run_finish(gauss_job* job, hipStream_t st)
     // the result mirrors travel with the run, so that gauss_job_fetch waits for THIS job only (an event), not for
     // whatever else has been queued on the stream since (the next job of a pipeline)
     const int par = (int)(job->run_seq & 1u);
-    if (job->n_results)
-        HIPCHK(hipMemcpyAsync(job->h_res2[par], job->d_results, sizeof(double) * job->n_results, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(job->h_st2[par], job->d_status, sizeof(int) * (4 * job->n + 4), hipMemcpyDeviceToHost, st));
+    static const bool job_trace = getenv("GAUSS_JOB_TRACE") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    // By kernel into the pinned mirrors, not by hipMemcpyAsync: beside a background upload (a chromosome's first call) one run in
+    // eight made the caller wait 10-18 ms for a DMA engine here, and every run of a 36-window job 5 ms (GAUSS_JOB_TRACE=1, round 4).
+    // Both mirrors have room for the 16-byte word the copy rounds up to (pin_res in job_build; the status block is 16 (n + 1) bytes);
+    // the event below is a system-scope release, so the host reads what the kernel wrote.
+    if (job->n_results) launch_h2d_copy(job->h_res2[par], job->d_results, rup(sizeof(double) * job->n_results, 16), st);
+    launch_h2d_copy(job->h_st2[par], job->d_status, sizeof(int) * (4 * job->n + 4), st);
+    HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(job->done2[par], st));
+    if (job_trace) fprintf(stderr, "[job] run: result copies queued in %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     job->done = job->done2[par];
     job->run_seq++;
     job->ran = true;
@@ -1424,8 +1446,10 @@ static int job_run(gauss_job* job, bool solve)
     if (job->run_seq - job->fetch_seq >= 2u)
         return fail(GAUSS_E_INVALID, "gauss_job_run: two runs of this job are in flight already; fetch one first");
     const gauss_job::RunEvents& ev = job->rev[job->run_seq & 1u];      // this run's cross-queue events (the parity's own set)
+    const auto t_run0 = std::chrono::steady_clock::now();
     HIPCHK(hipEventRecord(job->begin, st));
     HIPCHK(hipMemsetAsync(job->d_status, 0, sizeof(int) * (4 * job->n + 4), st));
+    if (getenv("GAUSS_JOB_TRACE")) fprintf(stderr, "[job] run: begin mark + status zeroing queued in %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_run0).count());
     // fused tail: the factorisation chain needs B11 only and the closing product is the first reader of B21, so B21's
     // tiles of the epilogue (85 % of them) go to the side stream and run beside the chain; the row tables and the
     // certificate, which only the epilogue and the factorisation read, go there too and slip in while the Gram kernel
@@ -1729,10 +1753,17 @@ static int job_run_streamed(gauss_job* job, StreamSetup& su)
     launch_impute_gemm(job->d_probs, job->d_gemmmap, job->n_gemm, job->gemm_ut, job->d_finmap, job->n_fin, st);
     HIPCHK(hipGetLastError());
     const int par = (int)(job->run_seq & 1u);
-    if (job->n_results)
-        HIPCHK(hipMemcpyAsync(job->h_res2[par], job->d_results, sizeof(double) * job->n_results, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(job->h_st2[par], job->d_status, sizeof(int) * (4 * job->n + 4), hipMemcpyDeviceToHost, st));
+    static const bool job_trace = getenv("GAUSS_JOB_TRACE") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    // By kernel into the pinned mirrors, not by hipMemcpyAsync: beside a background upload (a chromosome's first call) one run in
+    // eight made the caller wait 10-18 ms for a DMA engine here, and every run of a 36-window job 5 ms (GAUSS_JOB_TRACE=1, round 4).
+    // Both mirrors have room for the 16-byte word the copy rounds up to (pin_res in job_build; the status block is 16 (n + 1) bytes);
+    // the event below is a system-scope release, so the host reads what the kernel wrote.
+    if (job->n_results) launch_h2d_copy(job->h_res2[par], job->d_results, rup(sizeof(double) * job->n_results, 16), st);
+    launch_h2d_copy(job->h_st2[par], job->d_status, sizeof(int) * (4 * job->n + 4), st);
+    HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(job->done2[par], st));
+    if (job_trace) fprintf(stderr, "[job] run: result copies queued in %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     job->done = job->done2[par];
     job->run_seq++;
     job->ran = true;
@@ -2341,8 +2372,14 @@ static int store_upload_async(gauss_ctx* ctx, const RowSource2& src, int64_t byt
     hipStream_t us = ctx->upload;
     u->th = std::thread([ctx, u, src, device, us]() {
         (void)hipSetDevice(device);
-        // a background upload runs beside whatever the context computes: its chunks cross PCIe by kernel (upload_rows)
-        static const bool by_kernel = env_int("GAUSS_FILL_BY_KERNEL", 1) != 0;
+        // A background upload runs beside whatever the context computes.  Up to 4 GB (a chromosome's rows: the upload is over
+        // after 20 ms, most of it before the first large batch) its chunks travel by hipMemcpyAsync: measured on a chromosome's
+        // first call (round 4, tools/cold_trace.sh), with the copy kernel the first batch's 4.9 ms of GPU work ended with the
+        // upload, 13.6 ms after it began -- a stream of copy kernels at raised wave priority holds the Gram kernel back -- and
+        // beside the DMA engines it takes 5.0 ms.  Above (a whole-genome panel: seconds of PCIe traffic beside full-size Gram
+        // launches, where hipMemcpyAsync was measured to stall, tools/h2d_under_load_probe.py) by kernel.  GAUSS_UPLOAD_BY_KERNEL=0 / 1.
+        const int bk = env_int("GAUSS_UPLOAD_BY_KERNEL", -1);
+        const bool by_kernel = bk >= 0 ? bk != 0 : u->bytes > ((size_t)4 << 30);
         const int rc = upload_rows(ctx, u->d, src, u->bytes, us, [u, us](size_t upto) {
             hipEvent_t ev = nullptr;
             if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, us) != hipSuccess) return;

@@ -34,6 +34,7 @@
 #include <thread>
 #include <vector>
 
+#include <sys/mman.h>
 #include <sys/resource.h>
 #include <sys/stat.h>
 #include <sys/file.h>
@@ -135,7 +136,98 @@ struct MapKey {
         return chr < r.chr;
     }
 };
-typedef std::map<MapKey, std::unique_ptr<Snp>> SnpMap;
+// A window's SNP map lives in blocks of its own instead of the C library's heap.  A 100 000-SNP chromosome enters ~126 000 Snp
+// objects and as many map nodes (~480 B a SNP, ~60 MB over the 36 windows); on the FIRST call of a process every page of that is
+// touched for the first time -- ~14 000 minor faults, 40 ms of kernel time next to 50 ms of user time for the whole data layer,
+// spread over the worker threads' fresh malloc arenas (measured).  Blocks are 2 MB, 2 MB-aligned,
+// advised as huge pages and populated in one call (one fault or one batched population instead of 512 traps); a window frees
+// nothing one by one -- its blocks go back to a process-wide list when the window is closed, so later calls touch no new page.
+static const size_t ARENA_BLOCK = (size_t)2 << 20;
+
+struct BlockPool {
+    std::mutex mu;
+    std::vector<void*> idle;
+    size_t keep;
+    BlockPool()
+    {
+        const char* e = getenv("GAUSS_HOST_ARENA_KEEP_MB");            // idle blocks kept for the next call (default 256 MB)
+        keep = (size_t)(e ? std::max(0, atoi(e)) : 256) * ((size_t)1 << 20) / ARENA_BLOCK;
+    }
+    void* get()
+    {
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            if (!idle.empty()) { void* b = idle.back(); idle.pop_back(); return b; }
+        }
+        char* raw = (char*)mmap(nullptr, 2 * ARENA_BLOCK, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (raw == (char*)MAP_FAILED) throw std::bad_alloc();
+        char* b = (char*)(((uintptr_t)raw + ARENA_BLOCK - 1) & ~(uintptr_t)(ARENA_BLOCK - 1));
+        if (b > raw) munmap(raw, (size_t)(b - raw));
+        if (b + ARENA_BLOCK < raw + 2 * ARENA_BLOCK) munmap(b + ARENA_BLOCK, (size_t)(raw + 2 * ARENA_BLOCK - (b + ARENA_BLOCK)));
+#ifdef MADV_HUGEPAGE
+        madvise(b, ARENA_BLOCK, MADV_HUGEPAGE);                         // advice only: without huge pages the block is 512 small ones
+#endif
+#ifdef MADV_POPULATE_WRITE
+        madvise(b, ARENA_BLOCK, MADV_POPULATE_WRITE);                   // Linux 5.14+; an older kernel faults the pages in on first use
+#endif
+        return b;
+    }
+    void put(void* b)
+    {
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            if (idle.size() < keep) { idle.push_back(b); return; }
+        }
+        munmap(b, ARENA_BLOCK);
+    }
+};
+static BlockPool& block_pool() { static BlockPool* bp = new BlockPool(); return *bp; }     // never destroyed: windows may outlive static destructors
+
+struct Arena {
+    std::vector<void*> blocks, big;
+    char* cur = nullptr;
+    size_t left = 0;
+    Arena() = default;
+    Arena(const Arena&) = delete;
+    Arena& operator=(const Arena&) = delete;
+    void* alloc(size_t n)
+    {
+        n = (n + 15) & ~(size_t)15;
+        if (n > ARENA_BLOCK / 8) { void* q = ::operator new(n); big.push_back(q); return q; }
+        if (n > left) { cur = (char*)block_pool().get(); blocks.push_back(cur); left = ARENA_BLOCK; }
+        void* q = cur;
+        cur += n; left -= n;
+        return q;
+    }
+    ~Arena()
+    {
+        for (void* b : blocks) block_pool().put(b);
+        for (void* q : big) ::operator delete(q);
+    }
+};
+
+template <class T>
+struct ArenaAlloc {
+    typedef T value_type;
+    Arena* a;
+    explicit ArenaAlloc(Arena* arena) : a(arena) {}
+    template <class U> ArenaAlloc(const ArenaAlloc<U>& o) : a(o.a) {}
+    T* allocate(size_t n) { return (T*)a->alloc(n * sizeof(T)); }
+    void deallocate(T*, size_t) {}                                      // the blocks go back as a whole
+    template <class U> bool operator==(const ArenaAlloc<U>& o) const { return a == o.a; }
+    template <class U> bool operator!=(const ArenaAlloc<U>& o) const { return a != o.a; }
+};
+
+struct SnpDestroy { void operator()(Snp* s) const { s->~Snp(); } };     // storage is the arena's
+typedef std::unique_ptr<Snp, SnpDestroy> SnpPtr;
+struct SnpMapArena { Arena arena; };
+typedef std::map<MapKey, SnpPtr, std::less<MapKey>, ArenaAlloc<std::pair<const MapKey, SnpPtr>>> SnpMapBase;
+struct SnpMap : private SnpMapArena, public SnpMapBase {               // the arena is built before the map and outlives it
+    SnpMap() : SnpMapBase(std::less<MapKey>(), ArenaAlloc<std::pair<const MapKey, SnpPtr>>(&arena)) {}
+    SnpMap(const SnpMap&) = delete;
+    SnpMap& operator=(const SnpMap&) = delete;
+    SnpPtr make() { return SnpPtr(new (arena.alloc(sizeof(Snp))) Snp()); }
+};
 
 struct Args {                       // Arguments, gauss.h:18-69 with the defaults of gauss.cpp:18-35
     int chr = 0;
@@ -303,7 +395,7 @@ static int ReadInputZ(SnpMap& m, const Args& a, bool All)
             if ((a.chr > 0) && (a.chr != r.chr)) continue;
             if ((a.start_bp - a.wing_size) > r.bp || (a.end_bp + a.wing_size) < r.bp) continue;
         }
-        std::unique_ptr<Snp> s(new Snp());
+        SnpPtr s = m.make();
         s->rsid = r.rsid; s->chr = r.chr; s->bp = r.bp; s->a1 = r.a1; s->a2 = r.a2; s->z = r.z;
         s->info = 1.0;     // gauss.cpp:142
         s->type = 2;       // gauss.cpp:176
@@ -380,7 +472,7 @@ static int merge_index_entry(SnpMap& m, const Args& a, bool All, const std::stri
     auto pos = m.lower_bound(MapKey{chr, bp, std::string(), std::string()});
     if (pos == m.end() || pos->first.chr != chr || pos->first.bp != bp) {
         if (!All) {       // gauss.cpp:373-385; ReadReferenceIndexAll never adds unmeasured SNPs
-            std::unique_ptr<Snp> s(new Snp());
+            SnpPtr s = m.make();
             s->rsid = rsid; s->chr = chr; s->bp = bp; s->a1 = a1; s->a2 = a2; s->type = 0; s->fpos = fpos;
             m.emplace_hint(pos, MapKey{chr, bp, a1, a2}, std::move(s));
         }
@@ -392,13 +484,13 @@ static int merge_index_entry(SnpMap& m, const Args& a, bool All, const std::stri
         it1->second->rsid = rsid; it1->second->type = 1; it1->second->fpos = fpos;
     } else if (it1 == m.end() && it2 != m.end()) {
         // GWAS alleles are swapped relative to the panel: adopt the panel's order, flip z
-        std::unique_ptr<Snp> s = std::move(it2->second);
+        SnpPtr s = std::move(it2->second);
         m.erase(it2);
         s->rsid = rsid; s->a1 = a1; s->a2 = a2; s->z = s->z * (-1); s->type = 1; s->fpos = fpos;
         m[MapKey{chr, bp, a1, a2}] = std::move(s);
     } else if (it1 == m.end() && it2 == m.end()) {
         if (!All) {       // gauss.cpp:373-385; ReadReferenceIndexAll never adds unmeasured SNPs
-            std::unique_ptr<Snp> s(new Snp());
+            SnpPtr s = m.make();
             s->rsid = rsid; s->chr = chr; s->bp = bp; s->a1 = a1; s->a2 = a2; s->type = 0; s->fpos = fpos;
             m[MapKey{chr, bp, a1, a2}] = std::move(s);
         }
@@ -598,7 +690,7 @@ static int ReadAnnotation(SnpMap& m, const Args& a)
             it1->second->geneid = geneid;
             it1->second->categ[categ_num] = wgt;
         } else if (it1 == m.end() && it2 != m.end()) {
-            std::unique_ptr<Snp> s = std::move(it2->second);
+            SnpPtr s = std::move(it2->second);
             m.erase(it2);
             s->a1 = a1; s->a2 = a2;
             s->af1ref = 1 - s->af1ref;
@@ -2181,6 +2273,12 @@ static void parallel_for(int n, int nt, F fn)
     for (std::thread& x : th) x.join();
 }
 
+static bool env_flag(const char* name, bool dflt)
+{
+    const char* e = getenv(name);
+    return e ? atoi(e) != 0 : dflt;
+}
+
 static double now_s()
 {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -2431,7 +2529,13 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
     for (size_t i = 0; i < wins.size(); i++) if (wins[i].owner == rank) mine.push_back((int)i);
     st.n_windows = (int)wins.size();
     st.n_windows_mine = (int)mine.size();
-    if (n_batches < 1) n_batches = mine.size() >= 16 ? 4 : (mine.size() >= 9 ? 3 : (mine.size() >= 4 ? 2 : 1));
+    // First use of the panel on this context: its rows travel to HBM while the batches compute (below), in panel order, and a
+    // batch starts when the rows it names have landed -- so the early batches are smaller then (six batches, the first three
+    // 0.3 / 0.5 / 0.8 of a share): the GPU starts on the first fifth of the rows and stays busy behind the upload.
+    void* dev_probe0 = nullptr;
+    const bool first_use = !panel_is_resident(ctx, reference_data_file, &dev_probe0);
+    const bool auto_batches = n_batches < 1;
+    if (n_batches < 1) n_batches = mine.size() >= 16 ? (first_use && env_flag("GAUSS_CHROM_COLD_BATCHES", true) ? 6 : 4) : (mine.size() >= 9 ? 3 : (mine.size() >= 4 ? 2 : 1));
     n_batches = std::max(1, std::min<int>(n_batches, std::max<size_t>(mine.size(), 1)));
     // contiguous batches by cost.  The first batch is the one nothing overlaps with on the way in (its data layer)
     // and the last one on the way out (its tables), so with four or more batches those two get 0.3 of a share.
@@ -2439,6 +2543,7 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
     {
         std::vector<double> share((size_t)n_batches, 1.0);
         if (n_batches >= 4) { share.front() = 0.3; share.back() = 0.3; }    // measured: 0.5 / 0.5 46.3 ms, 0.3 / 0.3 45.3 ms per chromosome
+        if (auto_batches && first_use && n_batches == 6) { share[1] = 0.5; share[2] = 0.8; }
         if (const char* e = getenv("GAUSS_CHROM_SHARES")) {          // experiment: "0.2,1,1,0.5"
             std::vector<double> v;
             for (const char* q = e; *q;) { char* end = nullptr; const double x = strtod(q, &end); if (end == q) break; v.push_back(x); q = (*end == ',') ? end + 1 : end; }
@@ -2474,8 +2579,7 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
         // first use of the panel on this context: the upload's copy threads (page faults on the mapping, or preads) run
         // beside the data layer, and more than four data-layer threads slow BOTH down (cold call 73-84 ms with 4, 103-124
         // with 8, 115-132 with 16; the data layer of a chromosome is 36 x 2 ms, well hidden either way)
-        void* dev_probe = nullptr;
-        if (!panel_is_resident(ctx, reference_data_file, &dev_probe)) nthreads = std::min(nthreads, 4);
+        if (first_use) nthreads = std::min(nthreads, 4);
     }
     if (const char* e = getenv("GAUSS_CHROM_THREADS")) nthreads = std::max(1, atoi(e));
     // the result tables are built after the upload has finished: they keep the full count (a first call built its tables on the
@@ -2537,7 +2641,8 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
     {
         const int64_t panel_bytes = pk->n_snp() * panel_row_bytes;
         const char* e = getenv("GAUSS_CHROM_ASYNC_UPLOAD");
-        const bool async_upload = e ? atoi(e) != 0 : panel_bytes > ((int64_t)4 << 30);
+        (void)panel_bytes;
+        const bool async_upload = e ? atoi(e) != 0 : true;
         // 0 (default): in one go before the first batch; 1: piece by piece, always one batch ahead; 2: TWO pieces -- the rows of
         // the first batches (about half of the chromosome's work) before the first batch is queued, the rest while the GPU
         // computes those batches.  Measured on the chr22 panel, first call of a fresh process (tools/cold_probe2.sh, round 4):
@@ -2689,7 +2794,8 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
                 if (fill_to((top + 1) * panel_row_bytes) != 0) { rc_fatal = -1; break; }      // (already there unless the estimate fell short)
             }
             double tc = now_s();
-            if (gauss_job_create(ctx, descs.data(), (int)descs.size(), 1, &jobs[b]) != 0 || gauss_job_run(jobs[b]) != 0) {
+            double t_created = 0;
+            if (gauss_job_create(ctx, descs.data(), (int)descs.size(), 1, &jobs[b]) != 0 || ((t_created = now_s()), gauss_job_run(jobs[b])) != 0) {
                 // could not even queue the batch: fall back to single windows at retire time
                 if (jobs[b]) { gauss_job_destroy(jobs[b]); jobs[b] = nullptr; }
                 for (int k : live[b]) {
@@ -2704,6 +2810,7 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
                 }
             }
             st.t_job_create += now_s() - tc;
+            if (getenv("GAUSS_CHROM_TRACE")) fprintf(stderr, "[chrom] batch %d queued at %.2f ms (job create %.2f ms, run %.2f ms)\n", b, (now_s() - t_begin) * 1e3, (t_created - tc) * 1e3, (now_s() - t_created) * 1e3);
         }
         // the next batch's rows travel while this one computes (two pieces: everything else, once the first piece's batches are queued)
         if (piece_mode == 2) { if (b == piece_a_last && fill_to(0) != 0) { rc_fatal = -1; break; } }
@@ -2716,6 +2823,12 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
         gauss_job *jf = nullptr, *jl = nullptr;
         for (gauss_job* j : jobs) if (j) { if (!jf) jf = j; jl = j; }
         if (jf && gauss_job_span_ms(jf, jl, &st.gpu_span_ms) != 0) st.gpu_span_ms = 0.0;
+        if (jf && getenv("GAUSS_CHROM_TRACE"))
+            for (size_t b = 0; b < jobs.size(); b++) {
+                double to_end = 0, own = 0;
+                if (jobs[b] && gauss_job_span_ms(jf, jobs[b], &to_end) == 0 && gauss_job_span_ms(jobs[b], jobs[b], &own) == 0)
+                    fprintf(stderr, "[chrom] batch %zu on the GPU: starts %.2f ms after the first batch, runs %.2f ms\n", b, to_end - own, own);
+            }
     }
     for (gauss_job* j : jobs) if (j) gauss_job_destroy(j);
     // whoever finds this panel resident later (another study, an LD call on rows this chromosome never touched) must
