@@ -142,14 +142,18 @@ struct MapKey {
 // spread over the worker threads' fresh malloc arenas (measured).  Blocks are 2 MB, 2 MB-aligned,
 // advised as huge pages and populated in one call (one fault or one batched population instead of 512 traps); a window frees
 // nothing one by one -- its blocks go back to a process-wide list when the window is closed, so later calls touch no new page.
-static const size_t ARENA_BLOCK = (size_t)2 << 20;
-
 struct BlockPool {
     std::mutex mu;
     std::vector<void*> idle;
     size_t keep;
+    size_t ARENA_BLOCK = (size_t)2 << 20;
     BlockPool()
     {
+        if (const char* b = getenv("GAUSS_HOST_ARENA_BLOCK_KB")) {     // tests: small blocks, so that a window spans many
+            size_t kb = 64;
+            while (kb < (size_t)std::max(64, atoi(b)) && kb < 2048) kb *= 2;
+            ARENA_BLOCK = kb << 10;
+        }
         const char* e = getenv("GAUSS_HOST_ARENA_KEEP_MB");            // idle blocks kept for the next call (default 256 MB)
         keep = (size_t)(e ? std::max(0, atoi(e)) : 256) * ((size_t)1 << 20) / ARENA_BLOCK;
     }
@@ -193,8 +197,9 @@ struct Arena {
     void* alloc(size_t n)
     {
         n = (n + 15) & ~(size_t)15;
-        if (n > ARENA_BLOCK / 8) { void* q = ::operator new(n); big.push_back(q); return q; }
-        if (n > left) { cur = (char*)block_pool().get(); blocks.push_back(cur); left = ARENA_BLOCK; }
+        BlockPool& bp = block_pool();
+        if (n > bp.ARENA_BLOCK / 8) { void* q = ::operator new(n); big.push_back(q); return q; }
+        if (n > left) { cur = (char*)bp.get(); blocks.push_back(cur); left = bp.ARENA_BLOCK; }
         void* q = cur;
         cur += n; left -= n;
         return q;
@@ -2621,36 +2626,32 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
     });
 
     // ---- the panel's rows in HBM ----
-    // First use of this panel on this context.  Small panels (a chromosome: 0.8 GB, 21 ms) are uploaded here, in one go,
-    // while the feeder thread above is already in the first batch's data layer; a panel of several GB (the whole 33KG
-    // panel is 82 GB: 2 s) is only STARTED here and the batches wait for the rows they name (gauss_store_wait): the rows
-    // travel in panel order, the batches follow the chromosome.  Measured on the chr22 panel, first call of a process:
-    // upload, then feeder 108-118 ms; feeder beside the upload (this order) see DESIGN.md; asynchronous upload 105-155 ms
-    // (its copy threads and the cold data layer slow each other down more than the overlap gains on 0.8 GB).
-    // Round 3, second form (GAUSS_CHROM_PIECEWISE_UPLOAD=1, off by default; panels sorted by position): the store is only
-    // RESERVED here and this thread brings the rows up piece by piece, always one batch ahead of the GPU -- the rows batch
-    // b + 1 will read (up to the panel row of its last window's end, a binary search) travel while batch b computes (by kernel:
-    // hipMemcpyAsync does not run beside a kernel that holds every CU, k_misc.hip:h2d_copy_kernel); before a batch is queued its
-    // exact top row is checked against what has landed.  Measured on the chr22 panel, first call of a process: 96-103 ms against
-    // 77-86 ms in one go -- the pieces cross PCIe at 55 GB/s beside the Gram kernel, but filling the staging buffers out of the
-    // page cache shares the host's cores with the data layer and the result tables, and that is what the first call waits for.
+    // First use of this panel on this context: the upload is only STARTED here (gauss_store_upload_fd_async: staged through two
+    // pinned buffers, 846 MB of a chromosome in ~20 ms) and every batch waits for the rows it names (gauss_store_wait) -- the rows
+    // travel in panel order, the batches follow the chromosome, so batch 0 starts when the first fifth of the rows has landed.
+    // Measured on the chr22 panel as the bench's first call (round 4, tools/cold_trace.sh): in one go before the first batch
+    // (GAUSS_CHROM_ASYNC_UPLOAD=0) 63-64 ms, beside the batches 46-55 ms against 40.5 warm.  That only pays since the data layer
+    // no longer fights the upload for the host (windows' SNP maps in pooled blocks, above: cold data layer 44 -> 11 ms; rounds 2
+    // and 3 measured the asynchronous form slower, 105-155 ms, for that reason).
+    // Other forms, off by default (panels sorted by position): GAUSS_CHROM_PIECEWISE_UPLOAD=1 -- the store is only RESERVED here
+    // and this thread brings the rows up piece by piece, always one batch ahead of the GPU (the rows batch b + 1 will read, up to
+    // the panel row of its last window's end, travel while batch b computes; before a batch is queued its exact top row is checked
+    // against what has landed); =2 -- two pieces, the first batches' rows before batch 0.
     void* d_rows = nullptr;
     int piece_mode = 0;
     const int64_t panel_row_bytes = pk->row_bytes();
     ResidentPanel piecewise;                                       // .filled set: this call fills the store piece by piece
     {
-        const int64_t panel_bytes = pk->n_snp() * panel_row_bytes;
         const char* e = getenv("GAUSS_CHROM_ASYNC_UPLOAD");
-        (void)panel_bytes;
-        const bool async_upload = e ? atoi(e) != 0 : true;
-        // 0 (default): in one go before the first batch; 1: piece by piece, always one batch ahead; 2: TWO pieces -- the rows of
+        const char* ep = getenv("GAUSS_CHROM_PIECEWISE_UPLOAD");
+        const bool async_upload = e ? atoi(e) != 0 : !(ep && atoi(ep) != 0);      // (asking for pieces means: not in the background)
+        // 0 (default): one upload (beside the batches, or before the first with GAUSS_CHROM_ASYNC_UPLOAD=0); 1: piece by piece, always one batch ahead; 2: TWO pieces -- the rows of
         // the first batches (about half of the chromosome's work) before the first batch is queued, the rest while the GPU
         // computes those batches.  Measured on the chr22 panel, first call of a fresh process (tools/cold_probe2.sh, round 4):
         // one go 71-86 ms, two pieces 83-85, per batch 84-86 -- a FIRST piece of 503 MB takes 31-34 ms (15 GB/s) where the
         // second one, beside the Gram kernel, takes 13-16 ms for 343 MB: whatever is staged first in a process is slow (cold page
         // cache walk, cold allocator, the data layer's threads on the same sixteen cores), so splitting the upload only moves
         // GPU work behind a slower first piece.
-        const char* ep = getenv("GAUSS_CHROM_PIECEWISE_UPLOAD");
         piece_mode = async_upload || !pk->header().sorted || chr <= 0 ? 0 : (ep ? atoi(ep) : 0);
         if (piece_mode == 2 && n_batches < 3) piece_mode = 0;
         const bool reserve_only = piece_mode != 0;

@@ -280,6 +280,46 @@ def test_gpu_native_chromosome_run_equals_the_python_farm(ctx, tmp_path):
 
 
 @pytest.mark.gpu
+def test_gpu_native_chromosome_first_use_of_a_panel(ctx, tmp_path, monkeypatch):
+    """First use of a panel on a context: its rows travel to HBM WHILE the batches compute (background upload, a batch waits for
+    the rows it names, gauss_store_wait), in six graded batches when the rank holds sixteen windows or more; a later call finds
+    the panel resident and runs four.  Either way, and for every form of the upload (DMA copies, the copy kernel, in one go
+    before the first batch), the table is the same, bit for bit."""
+    st = make_study(tmp_path)
+    p = st["paths"]
+    gpk = str(tmp_path / "panel.gpk")
+    assert api.pack_panel(p["index.gz"], p["data.gz"], p["desc.txt"], gpk) > 0
+    kw = dict(kind=api.KIND_DISTMIX, pop_wgt_df=WGT, window_size=125_000, input_file=p["gwas.txt"], reference_data_file=gpk,
+              reference_pop_desc_file=p["desc.txt"], ctx=ctx, chr=22, start_bp=1_000_001, end_bp=4_000_000, wing_size=200_000)
+    api.panel_evict(ctx=ctx)
+    first = api.impute_chromosome(**kw)
+    assert first.stats["n_windows_mine"] == 24 and first.stats["n_failed"] == 0
+    assert first.stats["panel_bytes_uploaded"] > 0 and first.stats["n_batches"] == 6
+    warm = api.impute_chromosome(**kw)
+    assert warm.stats["panel_bytes_uploaded"] == 0 and warm.stats["n_batches"] == 4
+
+    def same(a, b):
+        assert list(a.columns) == list(b.columns)
+        for c in a.columns:
+            x, y = a.columns[c], b.columns[c]
+            assert np.array_equal(x, y, equal_nan=True) if x.dtype.kind == "f" else np.array_equal(x, y), c
+
+    same(first, warm)
+    assert first.stats["imputed"] == warm.stats["imputed"] > 0
+    for env in (dict(GAUSS_UPLOAD_BY_KERNEL="1"), dict(GAUSS_CHROM_ASYNC_UPLOAD="0"), dict(GAUSS_CHROM_COLD_BATCHES="0")):
+        api.panel_evict(ctx=ctx)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        again = api.impute_chromosome(**kw)
+        for k in env:
+            monkeypatch.delenv(k)
+        assert again.stats["panel_bytes_uploaded"] > 0, env
+        assert again.stats["n_batches"] == (4 if "GAUSS_CHROM_COLD_BATCHES" in env else 6), env
+        same(again, warm)
+    api.panel_evict(ctx=ctx)
+
+
+@pytest.mark.gpu
 def test_gpu_native_chromosome_isolates_a_failing_window(ctx, tmp_path):
     """A window whose data layer fails (here: the GWAS file lists one SNP with both allele orders inside that
     window, the reference's "duplicates" error, gauss.cpp:388-391) is reported, the other windows still come back."""

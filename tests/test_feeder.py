@@ -360,6 +360,53 @@ def test_fast_text_panel_writer_equals_the_line_by_line_writer(study, packed, tm
     assert open(out, "rb").read() == open(packed, "rb").read()
 
 
+def test_window_snp_maps_live_in_pooled_blocks(study, packed):
+    """A window's SNP objects and map nodes are carved out of pooled 2 MB blocks (gauss_host.cpp, BlockPool): many windows
+    open at once on several threads, closed in another order, opened again out of the returned blocks -- the SNP lists are
+    the same every time, and with no block kept between windows and blocks so small that a window spans several
+    (GAUSS_HOST_ARENA_KEEP_MB=0, GAUSS_HOST_ARENA_BLOCK_KB=64: a child process) as well."""
+    from concurrent.futures import ThreadPoolExecutor
+    inp, idx, dat, desc = _files(study)
+    spans = [(1_000_001 + 150_000 * k, 1_000_000 + 150_000 * (k + 1)) for k in range(12)]
+
+    def prep(span):
+        return api.Prepared(api.KIND_DISTMIX, chr=22, start_bp=span[0], end_bp=span[1], wing_size=300_000, pop_wgt_df=WGT,
+                            input_file=inp, reference_index_file="(packed)", reference_data_file=packed, reference_pop_desc_file=desc)
+
+    def image(pr):
+        d = pr.snps()
+        return (list(d["rsid"]), list(d["bp"]), d["z"].to_numpy().copy(), pr.measured_rows().copy(), pr.unmeasured_rows().copy())
+
+    first = []
+    for rep in range(3):
+        with ThreadPoolExecutor(max_workers=4) as pool:
+            prs = list(pool.map(prep, spans))
+        got = [image(pr) for pr in prs]
+        for pr in (prs[::2] + prs[1::2]):                  # not the order they were opened in
+            pr.close()
+        if rep == 0:
+            first = got
+            assert sum(len(g[0]) for g in got) > 500
+        for a, b in zip(first, got):
+            assert a[0] == b[0] and a[1] == b[1] and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from gauss_amd import api\n"
+            "n = 0\n"
+            "for k in range(3):\n"
+            "    pr = api.Prepared(api.KIND_DISTMIX, chr=22, start_bp=1_000_001, end_bp=4_000_000, wing_size=250_000, pop_wgt_df=%r,\n"
+            "                      input_file=%r, reference_index_file='(packed)', reference_data_file=%r, reference_pop_desc_file=%r)\n"
+            "    n += len(pr.snps()); pr.close()\n"
+            "print(n)\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), WGT, inp, packed, desc)
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GAUSS_HOST_ARENA_KEEP_MB="0", GAUSS_HOST_ARENA_BLOCK_KB="64"), capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    pr = api.Prepared(api.KIND_DISTMIX, chr=22, start_bp=1_000_001, end_bp=4_000_000, wing_size=250_000, pop_wgt_df=WGT, input_file=inp,
+                      reference_index_file="(packed)", reference_data_file=packed, reference_pop_desc_file=desc)
+    assert int(out.stdout.strip()) == 3 * len(pr.snps()) and len(pr.snps()) * 400 > 2 * 65536       # (several 64 KB blocks' worth of SNP objects)
+    pr.close()
+
+
 # ---- feeder edge cases the reference's drivers hit (no GPU involved) --------------------------------------
 def _prep(kind, inp, idx, dat, desc, **kw):
     base = dict(chr=22, start_bp=1_400_000, end_bp=2_000_000, wing_size=250_000, study_pop="EUR", input_file=inp,
