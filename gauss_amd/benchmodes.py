@@ -229,10 +229,10 @@ def e2e_block(args, rig, ch=None, steps=5):
                 "imputed_snps": int(tot("imputed")), "table_rows": int(len(z)), "all_finite": bool(np.all(np.isfinite(z))),
                 "windows": int(np.max(st["n_windows"]) if isinstance(st["n_windows"], list) else st["n_windows"]),
                 "warm_s_median": warm_s, "warm_s_all": warm, "imputed_snps_per_s_warm": tot("imputed") / warm_s,
-                "cold_s": cold_s, "imputed_snps_per_s_cold": tot("imputed") / cold_s,
+                "cold_s": cold_s, "imputed_snps_per_s_cold": tot("imputed") / cold_s, "cold_over_warm": cold_s / warm_s,
                 "gpu_span_ms": span, "warm_over_gpu_span": warm_s * 1e3 / span if span else None,
                 "warm_definition": "panel rows already resident in HBM (a session imputing study after study); cold = first call, "
-                                   "panel upload through pinned double buffers included",
+                                   "panel upload through pinned double buffers included (the rows travel while the first batches compute on what has landed)",
                 "stats_last_warm_run": st, "stats_cold_run": cold.stats if cold is not None else None,
                 "make_files_s": make_s,
             }

@@ -127,14 +127,28 @@ int64_t PackedPanel::lower_bound(int chr, int64_t bp) const
 }
 
 namespace {
+// white space as isspace() in the "C" locale, from a table: a panel line is ~33 kB and every byte of it passes through here
+struct WsTable { bool t[256]; WsTable() { for (int c = 0; c < 256; c++) t[c] = (c == ' ' || (c >= 9 && c <= 13)); } };
+static const WsTable kWs;
 struct Fields {
     const char* p; const char* e;
     bool next(const char*& b, int& n)
     {
-        while (p < e && isspace((unsigned char)*p)) p++;
+        while (p < e && kWs.t[(unsigned char)*p]) p++;
         if (p >= e) return false;
         b = p;
-        while (p < e && !isspace((unsigned char)*p)) p++;
+        // long tokens (a population's genotype digits) end at a blank in practice: memchr finds it, then make sure that no
+        // other white-space character came first
+        const char* q = (const char*)memchr(p, ' ', (size_t)(e - p));
+        const char* lim = q ? q : e;
+        const char* r = p;
+        if (lim - r > 64) {
+            for (const char* t = r; t < lim; t++) if (kWs.t[(unsigned char)*t]) { lim = t; break; }
+            r = lim;
+        } else {
+            while (r < lim && !kWs.t[(unsigned char)*r]) r++;
+        }
+        p = r;
         n = (int)(p - b);
         return true;
     }
@@ -175,39 +189,18 @@ int64_t pack_panel(const std::string& index_path, const std::string& data_path, 
     if (!idx.open(index_path)) { err = "ERROR: can't open reference index file '" + index_path + "'"; return -1; }
     { BgzfReader probe; if (!probe.open(data_path)) { err = "ERROR: can't open reference data file '" + data_path + "'"; return -1; } }
 
+    // ---- pass 1: the index (one short line per SNP) -- with it every section's place in the output file is known ----
     std::vector<PkSnp> snps;
     std::vector<char> strings;
-    std::vector<double> af;
-    std::vector<int32_t> cnt;
-    const std::string geno_tmp = out_path + ".geno.tmp";
-    FILE* gf = fopen(geno_tmp.c_str(), "wb");
-    if (!gf) { err = "can't write '" + geno_tmp + "'"; return -1; }
+    std::vector<long long> fpos;
     auto add_str = [&](const char* b, int n) { const uint32_t o = (uint32_t)strings.size(); strings.insert(strings.end(), b, b + n); strings.push_back(0); return o; };
     bool sorted = true;
-
-    // The index is read sequentially in blocks of BLK lines; the data lines of a block (one ~33 kB text line per SNP,
-    // found by its BGZF virtual offset) are inflated, parsed and 2-bit packed by a pool of threads, each with its own
-    // reader, straight into the block's slots -- the conversion is a one-off per panel, but a genome-wide 33KG panel has
-    // millions of lines (0.29 ms per line on one thread).
-    const int BLK = 16384;
-    const unsigned hw = std::thread::hardware_concurrency();
-    const int nt = (int)std::max(1u, std::min(16u, hw ? hw : 4u));
-    std::vector<BgzfReader> readers((size_t)nt);
-    for (BgzfReader& r : readers)
-        if (!r.open(data_path)) { err = "ERROR: can't open reference data file '" + data_path + "'"; fclose(gf); remove(geno_tmp.c_str()); return -1; }
-    struct Pending { long long fpos; std::string rsid; };
-    std::vector<Pending> pend;
-    std::vector<uint8_t> rows;
-    std::vector<double> baf;
-    std::vector<int32_t> bcnt;
-    std::string line;
-    bool eof = false;
-    while (!eof) {
-        pend.clear();
-        while ((int)pend.size() < BLK) {
+    {
+        std::string line;
+        for (;;) {
             const int last = idx.getline(line);
-            if (last == -2) { err = "Error: can't read reference index file '" + index_path + "'"; fclose(gf); remove(geno_tmp.c_str()); return -1; }
-            if (last == -1 && line.empty()) { eof = true; break; }
+            if (last == -2) { err = "Error: can't read reference index file '" + index_path + "'"; return -1; }
+            if (last == -1 && line.empty()) break;
             Fields t{line.data(), line.data() + line.size()};
             const char *b_rs, *b_chr, *b_bp, *b_a1, *b_a2, *b_af, *b_fp;
             int n_rs, n_chr, n_bp, n_a1, n_a2, n_af, n_fp;
@@ -219,104 +212,131 @@ int64_t pack_panel(const std::string& index_path, const std::string& data_path, 
                 sn.rsid = add_str(b_rs, n_rs); sn.a1 = add_str(b_a1, n_a1); sn.a2 = add_str(b_a2, n_a2);
                 if (!snps.empty() && (sn.chr < snps.back().chr || (sn.chr == snps.back().chr && sn.bp < snps.back().bp))) sorted = false;
                 snps.push_back(sn);
-                pend.push_back(Pending{strtoll(std::string(b_fp, n_fp).c_str(), nullptr, 10), std::string(b_rs, n_rs)});
+                fpos.push_back(strtoll(std::string(b_fp, n_fp).c_str(), nullptr, 10));
             }
             line.clear();
-            if (last == -1) { eof = true; break; }
+            if (last == -1) break;
         }
-        const int nb = (int)pend.size();
-        if (nb == 0) break;
-        rows.assign((size_t)nb * row_bytes, 0);
-        baf.assign((size_t)nb * P, 0.0);
-        bcnt.assign((size_t)nb * P, 0);
-        std::atomic<int> next{0};
-        std::mutex emu;
-        std::string first_err;
-        auto work = [&](int tid) {
-            BgzfReader& dat = readers[tid];
-            std::string dline;
-            // runs of consecutive SNPs per grab: neighbouring lines share BGZF blocks (a 33 kB line is half a block),
-            // interleaving single lines over the threads would make every thread inflate every block
-            const int RUN = 128;
-            for (int c0 = next.fetch_add(RUN); c0 < nb; c0 = next.fetch_add(RUN))
-            for (int i = c0; i < std::min(nb, c0 + RUN); i++) {
-                dat.seek(pend[i].fpos);
-                dline.clear();
-                dat.getline(dline);
-                Fields d{dline.data(), dline.data() + dline.size()};
-                uint8_t* row = rows.data() + (size_t)i * row_bytes;
-                for (int k = 0; k < P; k++) {
-                    const char* g; int n;
-                    if (!d.next(g, n) || n != (int)pops[k].size) {
-                        std::lock_guard<std::mutex> lock(emu);
-                        if (first_err.empty()) first_err = "panel line of " + pend[i].rsid + ": population " + pops[k].name + " does not have " + std::to_string(pops[k].size) + " genotypes";
-                        return;
-                    }
-                    int32_t c = 0;
-                    uint8_t* dst = row + pops[k].byte_off;
-                    for (int q = 0; q < n; q++) {
-                        const unsigned code = (unsigned)(g[q] - '0');
-                        if (code > 3) {
-                            std::lock_guard<std::mutex> lock(emu);
-                            if (first_err.empty()) first_err = "panel line of " + pend[i].rsid + " has a genotype outside 0..3";
-                            return;
-                        }
-                        c += (int32_t)code;
-                        dst[q >> 2] |= (uint8_t)(code << (2 * (q & 3)));
-                    }
-                    bcnt[(size_t)i * P + k] = c;
-                }
-                for (int k = 0; k < P; k++) {
-                    const char* g; int n;
-                    double v = 0.0;                           // a missing column reads as 0, like the text feeder
-                    if (d.next(g, n)) v = strtod(std::string(g, n).c_str(), nullptr);
-                    baf[(size_t)i * P + k] = v;
-                }
-            }
-        };
-        std::vector<std::thread> th;
-        for (int t = 1; t < std::min(nt, nb); t++) th.emplace_back(work, t);
-        work(0);
-        for (std::thread& x : th) x.join();
-        if (!first_err.empty()) { err = first_err; fclose(gf); remove(geno_tmp.c_str()); return -1; }
-        af.insert(af.end(), baf.begin(), baf.end());
-        cnt.insert(cnt.end(), bcnt.begin(), bcnt.end());
-        if (fwrite(rows.data(), 1, rows.size(), gf) != rows.size()) { err = "short write to '" + geno_tmp + "'"; fclose(gf); remove(geno_tmp.c_str()); return -1; }
     }
-    fclose(gf);
+    const size_t S = snps.size();
 
     PkHeader h;
     memset(&h, 0, sizeof(h));
     memcpy(h.magic, kMagic, 8);
-    h.version = 1; h.n_pop = (uint32_t)P; h.n_snp = snps.size(); h.row_bytes = row_bytes; h.sorted = sorted ? 1u : 0u;
+    h.version = 1; h.n_pop = (uint32_t)P; h.n_snp = S; h.row_bytes = row_bytes; h.sorted = sorted ? 1u : 0u;
     size_t off = sizeof(PkHeader);
     h.off_pops = off; off = align_up(off + (size_t)P * sizeof(PkPop), 64);
-    h.off_snps = off; off = align_up(off + snps.size() * sizeof(PkSnp), 64);
+    h.off_snps = off; off = align_up(off + S * sizeof(PkSnp), 64);
     h.off_strings = off; off = align_up(off + strings.size(), 64);
-    h.off_af = off; off = align_up(off + af.size() * sizeof(double), 64);
-    h.off_cnt = off; off = align_up(off + cnt.size() * sizeof(int32_t), 4096);
-    h.off_geno = off; off += snps.size() * (size_t)row_bytes;
+    h.off_af = off; off = align_up(off + S * (size_t)P * sizeof(double), 64);
+    h.off_cnt = off; off = align_up(off + S * (size_t)P * sizeof(int32_t), 4096);
+    h.off_geno = off; off += S * (size_t)row_bytes;
     h.file_bytes = off;
 
-    FILE* out = fopen(out_path.c_str(), "wb");
-    if (!out) { err = "can't write '" + out_path + "'"; remove(geno_tmp.c_str()); return -1; }
-    auto put_at = [&](size_t at, const void* p, size_t n) { fseek(out, (long)at, SEEK_SET); return n == 0 || fwrite(p, 1, n, out) == n; };
-    bool ok = put_at(0, &h, sizeof(h)) && put_at(h.off_pops, pops.data(), (size_t)P * sizeof(PkPop)) &&
-              put_at(h.off_snps, snps.data(), snps.size() * sizeof(PkSnp)) && put_at(h.off_strings, strings.data(), strings.size()) &&
-              put_at(h.off_af, af.data(), af.size() * sizeof(double)) && put_at(h.off_cnt, cnt.data(), cnt.size() * sizeof(int32_t));
-    if (ok) {
-        fseek(out, (long)h.off_geno, SEEK_SET);
-        FILE* in = fopen(geno_tmp.c_str(), "rb");
-        std::vector<uint8_t> buf(1 << 20);
-        size_t n;
-        while (in && (n = fread(buf.data(), 1, buf.size(), in)) > 0) ok = ok && fwrite(buf.data(), 1, n, out) == n;
-        if (in) fclose(in); else ok = false;
-        if (snps.empty()) { const char z = 0; ok = ok && put_at(h.file_bytes ? h.file_bytes - 1 : 0, &z, h.file_bytes ? 1 : 0); }
+    const int fd = ::open(out_path.c_str(), O_CREAT | O_TRUNC | O_WRONLY, 0644);
+    if (fd < 0) { err = "can't write '" + out_path + "'"; return -1; }
+    auto fail_out = [&](const std::string& why) { err = why; ::close(fd); remove(out_path.c_str()); return (int64_t)-1; };
+    if (ftruncate(fd, (off_t)h.file_bytes) != 0) return fail_out("can't size '" + out_path + "'");
+    auto put_at = [&](size_t at, const void* src, size_t n) {
+        const char* q = (const char*)src;
+        while (n > 0) {
+            const ssize_t w = pwrite(fd, q, n, (off_t)at);
+            if (w <= 0) return false;
+            q += w; at += (size_t)w; n -= (size_t)w;
+        }
+        return true;
+    };
+
+    // ---- pass 2: the data lines (one ~33 kB text line per SNP, found by its BGZF virtual offset) are inflated, parsed and
+    // 2-bit packed by a pool of threads, each with its own reader, in runs of consecutive SNPs (neighbouring lines share BGZF
+    // blocks -- a 33 kB line is half a block -- so interleaving single lines would make every thread inflate every block); a
+    // run's rows go straight to their place in the output file (pwrite), the allele tables into the SNP's slots.  The
+    // conversion is a one-off per panel, but a genome-wide 33KG panel has millions of lines. ----
+    std::vector<double> af(S * (size_t)P, 0.0);
+    std::vector<int32_t> cnt(S * (size_t)P, 0);
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int nt = (int)std::max<size_t>(1, std::min<size_t>(std::min(16u, hw ? hw : 4u), (S + 127) / 128));
+    std::vector<BgzfReader> readers((size_t)nt);
+    for (BgzfReader& r : readers)
+        if (!r.open(data_path)) return fail_out("ERROR: can't open reference data file '" + data_path + "'");
+    const size_t RUN = 128;
+    std::atomic<size_t> next{0};
+    std::mutex emu;
+    std::string first_err;
+    std::atomic<bool> stop{false};
+    auto work = [&](int tid) {
+        BgzfReader& dat = readers[(size_t)tid];
+        std::string dline;
+        std::vector<uint8_t> rows(RUN * row_bytes);
+        auto give_up = [&](const std::string& why) {
+            std::lock_guard<std::mutex> lock(emu);
+            if (first_err.empty()) first_err = why;
+            stop = true;
+        };
+        for (size_t c0 = next.fetch_add(RUN); c0 < S && !stop; c0 = next.fetch_add(RUN)) {
+            const size_t c1 = std::min(S, c0 + RUN);
+            memset(rows.data(), 0, (c1 - c0) * row_bytes);
+            for (size_t i = c0; i < c1; i++) {
+                dat.seek(fpos[i]);
+                dline.clear();
+                dat.getline(dline);
+                Fields d{dline.data(), dline.data() + dline.size()};
+                uint8_t* row = rows.data() + (i - c0) * row_bytes;
+                for (int k = 0; k < P; k++) {
+                    const char* g; int n;
+                    if (!d.next(g, n) || n != (int)pops[k].size)
+                        return give_up(std::string("panel line of ") + (strings.data() + snps[i].rsid) + ": population " + pops[k].name + " does not have " + std::to_string(pops[k].size) + " genotypes");
+                    int32_t c = 0;
+                    uint8_t* dst = row + pops[k].byte_off;
+                    int q = 0;
+                    bool bad = false;
+                    // eight genotype digits at a time: one 64-bit word, '0' taken off every byte, the eight 2-bit codes folded
+                    // into 16 bits in three shift-or steps (byte j of the word is digit q + j: little endian)
+                    for (; q + 8 <= n; q += 8) {
+                        uint64_t x;
+                        memcpy(&x, g + q, 8);
+                        x -= 0x3030303030303030ull;
+                        if (x & 0xFCFCFCFCFCFCFCFCull) { bad = true; break; }       // a byte outside '0'..'3' (a borrow shows up here too)
+                        c += (int32_t)((x * 0x0101010101010101ull) >> 56);
+                        x = (x | (x >> 6)) & 0x000F000F000F000Full;
+                        x = (x | (x >> 12)) & 0x000000FF000000FFull;
+                        x = (x | (x >> 24)) & 0xFFFFull;
+                        dst[q >> 2] = (uint8_t)x;
+                        dst[(q >> 2) + 1] = (uint8_t)(x >> 8);
+                    }
+                    for (; !bad && q < n; q++) {
+                        const unsigned code = (unsigned)(g[q] - '0');
+                        if (code > 3) { bad = true; break; }
+                        c += (int32_t)code;
+                        dst[q >> 2] |= (uint8_t)(code << (2 * (q & 3)));
+                    }
+                    if (bad) return give_up(std::string("panel line of ") + (strings.data() + snps[i].rsid) + " has a genotype outside 0..3");
+                    cnt[i * (size_t)P + k] = c;
+                }
+                for (int k = 0; k < P; k++) {
+                    const char* g; int n;
+                    double v = 0.0;                           // a missing column reads as 0, like the text feeder
+                    if (d.next(g, n)) { char tmp[64]; const int m = std::min(n, 63); memcpy(tmp, g, (size_t)m); tmp[m] = 0; v = strtod(tmp, nullptr); }
+                    af[i * (size_t)P + k] = v;
+                }
+            }
+            if (!put_at(h.off_geno + c0 * (size_t)row_bytes, rows.data(), (c1 - c0) * (size_t)row_bytes)) return give_up("short write to '" + out_path + "'");
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; t++) th.emplace_back(work, t);
+        work(0);
+        for (std::thread& x : th) x.join();
     }
-    ok = (fclose(out) == 0) && ok;
-    remove(geno_tmp.c_str());
-    if (!ok) { err = "short write to '" + out_path + "'"; return -1; }
-    return (int64_t)snps.size();
+    if (!first_err.empty()) return fail_out(first_err);
+
+    bool ok = put_at(0, &h, sizeof(h)) && put_at(h.off_pops, pops.data(), (size_t)P * sizeof(PkPop)) &&
+              put_at(h.off_snps, snps.data(), S * sizeof(PkSnp)) && put_at(h.off_strings, strings.data(), strings.size()) &&
+              put_at(h.off_af, af.data(), af.size() * sizeof(double)) && put_at(h.off_cnt, cnt.data(), cnt.size() * sizeof(int32_t));
+    ok = (::close(fd) == 0) && ok;
+    if (!ok) { err = "short write to '" + out_path + "'"; remove(out_path.c_str()); return -1; }
+    return (int64_t)S;
 }
 
 }  // namespace gauss_host
