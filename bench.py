@@ -585,6 +585,15 @@ def run_impute(args, rig):
         # the HBM-bound kernels (K1 pack, K4 LD epilogue), timed stand-alone in the one-stream pass (in the
         # headline run B11's epilogue tiles run beside the Gram kernel): algorithmic bytes = the 2-bit source rows in
         # ((M + U) N / 4 per window) for pack, the fp64 LD entries out ((M^2 + U M) 8 per window) for the epilogue
+        if tails_alone is not None and tails_alone["stage_ms_per_step"].get("gram", 0) > 0:
+            # `frac` above is the launch as it runs in the timed step, with the factorisation chain, B11's epilogue tiles and the
+            # early windows' B21 tiles running beside it on purpose (their vector instructions cost it matrix-pipe time; the
+            # step is shorter for it).  The one-stream pass runs the same launch with nothing beside it.
+            g1 = tails_alone["stage_ms_per_step"]["gram"] / gram_lps
+            out["roofline"]["alone_launch_ms"] = g1
+            out["roofline"]["frac_alone"] = work["ld_flops"] / gram_lps / (g1 * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS
+            out["roofline"]["alone_note"] = ("the same launch in the one-stream pass (GAUSS_SIDE_STREAM=0: nothing runs beside it; the step "
+                                             "is %.2f ms that way against %.2f)" % (tails_alone["ms_per_step"], tmax / args.steps * 1e3))
         if tails_alone is not None:
             n_m = np.array([len(mi) for _, mi, _ in my_wins], dtype=np.float64)
             n_u = np.array([len(ui) for _, _, ui in my_wins], dtype=np.float64)
