@@ -404,7 +404,10 @@ static int ReadInputZ(SnpMap& m, const Args& a, bool All)
         s->rsid = r.rsid; s->chr = r.chr; s->bp = r.bp; s->a1 = r.a1; s->a2 = r.a2; s->z = r.z;
         s->info = 1.0;     // gauss.cpp:142
         s->type = 2;       // gauss.cpp:176
-        m[MapKey{r.chr, r.bp, r.a1, r.a2}] = std::move(s);
+        // (a study file sorted by position appends: no descent through the tree; a later row of the same key still replaces the earlier one)
+        MapKey key{r.chr, r.bp, r.a1, r.a2};
+        auto it = (m.empty() || m.rbegin()->first < key) ? m.emplace_hint(m.end(), std::move(key), SnpPtr()) : m.try_emplace(std::move(key)).first;
+        it->second = std::move(s);
     }
     return 0;
 }
@@ -516,6 +519,55 @@ static int ReadReferenceIndex(SnpMap& m, const Args& a, bool All)
         if (!All && a.chr > 0 && pk.header().sorted) {
             i0 = pk.lower_bound(a.chr, a.start_bp - a.wing_size);
             i1 = pk.lower_bound(a.chr, a.end_bp + a.wing_size + 1);
+        }
+        if (All && pk.header().sorted) {
+            // ReadReferenceIndexAll never adds a SNP (gauss.cpp:478-512): only panel entries at a position the map already holds
+            // can change anything, and an entry only touches map entries of its own position.  So instead of looking every
+            // panel SNP up in the map (100 000 ordered lookups for a chromosome's panel against 13 000 study SNPs) walk the map's
+            // positions and find each one's panel entries by binary search; entries of one position keep the panel's order.
+            // (positions with several study SNPs or several panel entries -- multi-allelic sites -- go through
+            // merge_index_entry; one study SNP against one panel entry, the rule, is settled on the spot: same alleles, swapped
+            // alleles, or different alleles, exactly the three outcomes merge_index_entry has for it)
+            std::vector<std::pair<int, long long>> slow;
+            for (auto it = m.begin(); it != m.end();) {
+                const int chr = it->first.chr;
+                const long long bp = it->first.bp;
+                auto nx = std::next(it);
+                const bool single = (nx == m.end() || nx->first.chr != chr || nx->first.bp != bp);
+                if (!single) {
+                    slow.emplace_back(chr, bp);
+                    while (nx != m.end() && nx->first.chr == chr && nx->first.bp == bp) ++nx;
+                    it = nx;
+                    continue;
+                }
+                const int64_t i = pk.lower_bound(chr, bp);
+                const bool have = i < pk.n_snp() && pk.snp(i).chr == chr && pk.snp(i).bp == bp;
+                if (have && ((i + 1 < pk.n_snp() && pk.snp(i + 1).chr == chr && pk.snp(i + 1).bp == bp) ||
+                             strcmp(pk.str(pk.snp(i).a1), pk.str(pk.snp(i).a2)) == 0)) {       // (equal alleles: both lookups of merge_index_entry hit the same entry)
+                    slow.emplace_back(chr, bp); it = nx; continue;
+                }
+                if (have) {
+                    const PkSnp& s = pk.snp(i);
+                    const char *pa1 = pk.str(s.a1), *pa2 = pk.str(s.a2);
+                    if (it->first.a1 == pa1 && it->first.a2 == pa2) {
+                        it->second->rsid = pk.str(s.rsid); it->second->type = 1; it->second->fpos = i;
+                    } else if (it->first.a1 == pa2 && it->first.a2 == pa1) {
+                        // GWAS alleles are swapped relative to the panel: adopt the panel's order, flip z (the new key sorts inside this position: `nx` stays the next position)
+                        SnpPtr sp = std::move(it->second);
+                        m.erase(it);
+                        sp->rsid = pk.str(s.rsid); sp->a1 = pa1; sp->a2 = pa2; sp->z = sp->z * (-1); sp->type = 1; sp->fpos = i;
+                        m[MapKey{chr, bp, pa1, pa2}] = std::move(sp);
+                    }
+                }
+                it = nx;
+            }
+            for (const auto& cb : slow)
+                for (int64_t i = pk.lower_bound(cb.first, cb.second); i < pk.n_snp(); i++) {
+                    const PkSnp& s = pk.snp(i);
+                    if (s.chr != cb.first || s.bp != cb.second) break;
+                    if (merge_index_entry(m, a, All, pk.str(s.rsid), s.chr, s.bp, pk.str(s.a1), pk.str(s.a2), i)) return -1;
+                }
+            return 0;
         }
         for (int64_t i = i0; i < i1; i++) {
             const PkSnp& s = pk.snp(i);
@@ -673,24 +725,61 @@ static int MakeSnpVecMix(std::vector<Snp*>& v, SnpMap& m, const Args& a)
 }
 
 // ReadAnnotation (gauss.cpp:1275-1361)
-static int ReadAnnotation(SnpMap& m, const Args& a)
+// Parsed image of an annotation file, kept per process like the study file's (path + size + mtime): a gene-level call over
+// the same annotation parses it once.  Rows carry what the reference's loop variables hold after each line (gauss.cpp:1308-1330:
+// a field that fails to parse keeps the previous line's value, an unknown category name the previous number).
+struct AnnotRow { int chr, categ_num; long long bp; double wgt; std::string a1, a2, geneid; };
+struct AnnotCache { std::vector<AnnotRow> rows; };
+
+static std::shared_ptr<const AnnotCache> load_annotation_cached(const std::string& path, std::string& err)
 {
-    std::ifstream in(a.annotation_file.c_str());
-    if (!in) return herr("ERROR: can't open snp annotation data file '%s'", a.annotation_file.c_str());
+    static std::mutex mu;
+    static std::map<std::string, std::shared_ptr<const AnnotCache>> cache;
+    struct stat st;
+    if (stat(path.c_str(), &st) != 0) { err = "ERROR: can't open snp annotation data file '" + path + "'"; return nullptr; }
+    char key[64];
+    snprintf(key, sizeof(key), "|%lld|%lld.%ld", (long long)st.st_size, (long long)st.st_mtim.tv_sec, (long)st.st_mtim.tv_nsec);
+    const std::string k = path + key;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(k);
+    if (it != cache.end()) return it->second;
+    std::ifstream in(path.c_str());
+    if (!in) { err = "ERROR: can't open snp annotation data file '" + path + "'"; return nullptr; }
+    std::shared_ptr<AnnotCache> c = std::make_shared<AnnotCache>();
     std::string line, rsid, a1, a2, geneid, categ;
     int chr = 0, categ_num = 0; long long bp = 0; double wgt = 0;
     std::getline(in, line);
     while (std::getline(in, line)) {
         Tok t(line);
         if (t.str(rsid) && t.i32(chr) && t.i64(bp) && t.str(a1) && t.str(a2) && t.str(geneid) && t.str(categ)) t.dbl(wgt);
-        auto it1 = m.find(MapKey{chr, bp, a1, a2});
-        auto it2 = m.find(MapKey{chr, bp, a2, a1});
         if (categ == "PROTEIN") categ_num = 0;
         else if (categ == "TFBS") categ_num = 1;
         else if (categ == "WTH_HAIR") categ_num = 2;
         else if (categ == "WTH_TARGET") categ_num = 3;
         else if (categ == "CIS_EQTL") categ_num = 4;
         else if (categ == "TRANS_EQTL") categ_num = 5;      // unknown names keep the previous number (gauss.cpp:1319-1330)
+        c->rows.push_back(AnnotRow{chr, categ_num, bp, wgt, a1, a2, geneid});
+    }
+    if (cache.size() >= 4) cache.clear();
+    cache[k] = c;
+    return c;
+}
+
+static int ReadAnnotation(SnpMap& m, const Args& a)
+{
+    std::string err;
+    std::shared_ptr<const AnnotCache> an = load_annotation_cached(a.annotation_file, err);
+    if (!an) return herr("%s", err.c_str());
+    for (const AnnotRow& r : an->rows) {
+        const int chr = r.chr, categ_num = r.categ_num;
+        const long long bp = r.bp;
+        const double wgt = r.wgt;
+        const std::string &a1 = r.a1, &a2 = r.a2, &geneid = r.geneid;
+        // nothing of the study at this position (most of a genome-wide annotation): neither allele order can be there
+        auto pos = m.lower_bound(MapKey{chr, bp, std::string(), std::string()});
+        if (pos == m.end() || pos->first.chr != chr || pos->first.bp != bp) continue;
+        auto it1 = m.find(MapKey{chr, bp, a1, a2});
+        auto it2 = m.find(MapKey{chr, bp, a2, a1});
         if (it1 != m.end() && it2 == m.end()) {
             it1->second->geneid = geneid;
             it1->second->categ[categ_num] = wgt;
@@ -968,6 +1057,7 @@ static int prepare(gauss_prepared& p)
     if (ReadReferenceIndex(p.snp_map, a, gene)) return -1;
     tt[3] = tnow();
     if (gene && ReadAnnotation(p.snp_map, a)) return -1;
+    const double t_annot = tnow();
     if (mix) { if (MakeSnpVecMix(p.snp_vec, p.snp_map, a)) return -1; }
     else if (MakeSnpVec(p.snp_vec, p.snp_map, a)) return -1;
     tt[4] = tnow();
@@ -1056,8 +1146,8 @@ static int prepare(gauss_prepared& p)
     tt[5] = tnow();
     tt[6] = tnow();       // the SNP-list table (gauss_prepared_snps) is built on first request
     if (trace)
-        fprintf(stderr, "[prepare] desc %.2f  gwas %.2f  index %.2f  af-filter %.2f  partition %.2f  snp-table %.2f ms (map %zu, kept %zu)\n",
-                tt[1] - tt[0], tt[2] - tt[1], tt[3] - tt[2], tt[4] - tt[3], tt[5] - tt[4], tt[6] - tt[5], p.snp_map.size(), p.snp_vec.size());
+        fprintf(stderr, "[prepare] desc %.2f  gwas %.2f  index %.2f  annotation %.2f  af-filter %.2f  partition %.2f  snp-table %.2f ms (map %zu, kept %zu)\n",
+                tt[1] - tt[0], tt[2] - tt[1], tt[3] - tt[2], t_annot - tt[3], tt[4] - t_annot, tt[5] - tt[4], tt[6] - tt[5], p.snp_map.size(), p.snp_vec.size());
     return 0;
 }
 

@@ -330,6 +330,63 @@ def test_packed_panel_jepeg_and_errors(study, packed, tmp_path):
     assert "populations" in str(ei.value)
 
 
+def test_gene_drivers_index_merge_on_odd_positions(tmp_path):
+    """jepeg / jepegmix merge the genome-wide index into the study's SNP map (ReadReferenceIndexAll, gauss.cpp:431-518).  On a
+    packed panel that merge walks the map's positions (gauss_host.cpp:ReadReferenceIndex) instead of the panel: positions with
+    two panel entries, with two study SNPs, with swapped alleles, study-only and panel-only positions, and an annotation that
+    names the swapped order must come out exactly as the text feeder's panel-order scan leaves them -- and a site listed
+    under both allele orders in the study is the reference's duplicate error in both."""
+    pops = [("AAA", 40, "EUR"), ("BBB", 36, "ASN")]
+    sizes = [q[1] for q in pops]
+    rng = np.random.default_rng(5)
+    #        bp       a1   a2
+    pan = [(1000, "A", "C"), (2000, "A", "C"), (2000, "A", "G"), (3000, "A", "G"), (4000, "T", "C"), (5000, "G", "A"),
+           (6000, "A", "C"), (7000, "C", "T"), (7000, "C", "G"), (8000, "A", "T"), (9000, "G", "C")]
+    S = len(pan)
+    G = rng.integers(0, 3, size=(S, sum(sizes)), dtype=np.uint8)
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    af = np.stack([G[:, off[k]:off[k + 1]].sum(1) / (2.0 * sizes[k]) for k in range(len(pops))], 1)
+    rsid = np.array([f"rs{i}" for i in range(S)])
+    d = str(tmp_path)
+    idx, dat, desc, gpk = d + "/index.gz", d + "/data.gz", d + "/desc.txt", d + "/p.gpk"
+    panel.write_pop_desc(desc, pops)
+    panel.write_panel(idx, dat, rsid, np.full(S, 22), np.array([q[0] for q in pan]), np.array([q[1] for q in pan]),
+                      np.array([q[2] for q in pan]), G, af, sizes)
+    assert api.pack_panel(idx, dat, desc, gpk) == S
+    #          bp     a1   a2    (1000 same; 2000 one study SNP, two panel entries; 3000 two study SNPs, one panel entry; 4000 swapped;
+    #                             4500 study only; 6000 different alleles; 7000 two and two; 8000 swapped; 9000 same)
+    gw = [(1000, "A", "C"), (2000, "A", "G"), (3000, "A", "G"), (3000, "A", "T"), (4000, "C", "T"), (4500, "A", "C"),
+          (6000, "A", "G"), (7000, "C", "T"), (7000, "G", "C"), (8000, "T", "A"), (9000, "G", "C")]
+    z = rng.standard_normal(len(gw))
+    gwas = d + "/gwas.txt"
+    panel.write_gwas(gwas, [f"g{i}" for i in range(len(gw))], [22] * len(gw), [q[0] for q in gw], [q[1] for q in gw], [q[2] for q in gw], z)
+    ann = d + "/annot.txt"
+    panel.write_annotation(ann, [("x", 22, 1000, "A", "C", "GENE1", "PROTEIN", 1.5), ("x", 22, 2000, "G", "A", "GENE1", "TFBS", 0.5),
+                                 ("x", 22, 4000, "C", "T", "GENE1", "CIS_EQTL", 1.0), ("x", 22, 7000, "C", "T", "GENE2", "PROTEIN", 2.0),
+                                 ("x", 22, 7000, "C", "G", "GENE2", "NO_SUCH", 0.7), ("x", 22, 8000, "A", "T", "GENE2", "WTH_HAIR", 0.3),
+                                 ("x", 22, 9000, "G", "C", "GENE2", "TRANS_EQTL", 0.9), ("x", 22, 9500, "G", "C", "GENE3", "TFBS", 0.9)])
+    for kind, kw in ((api.KIND_JEPEG, dict(study_pop="EUR")), (api.KIND_JEPEGMIX, dict(pop_wgt_df=(["AAA", "BBB"], [0.6, 0.4])))):
+        base = dict(input_file=gwas, annotation_file=ann, reference_index_file=idx, reference_pop_desc_file=desc, af1_cutoff=0.0001, **kw)
+        a = api.Prepared(kind, reference_data_file=dat, **base)
+        b = api.Prepared(kind, reference_data_file=gpk, **base)
+        _same_prepared(a, b)
+        da = b.snps()
+        assert len(da) >= 8 and set(da["type"]) == {1}                    # (study-only SNPs have no panel line: the AF filter drops them)
+        assert b.n_gene >= 1
+        a.close(); b.close()
+        b2 = api.Prepared(kind, reference_data_file=gpk, **base)         # the annotation comes from the cache now
+        assert list(b2.snps()["geneid"]) == list(da["geneid"])
+        b2.close()
+    # a study that lists one site under both allele orders: "duplicates" from both feeders
+    bad = d + "/gwas_dup.txt"
+    panel.write_gwas(bad, ["g0", "g1"], [22, 22], [1000, 1000], ["A", "C"], ["C", "A"], [0.5, -0.5])
+    for data in (dat, gpk):
+        with pytest.raises(api.GaussError) as ei:
+            api.Prepared(api.KIND_JEPEG, study_pop="EUR", input_file=bad, annotation_file=ann, reference_index_file=idx,
+                         reference_data_file=data, reference_pop_desc_file=desc)
+        assert "duplicates" in str(ei.value)
+
+
 def test_python_packed_writer_is_byte_identical_to_the_converter(study, packed, tmp_path):
     """panel.write_packed_panel (arrays -> GAUSSPK1) and api.pack_panel (BGZF text -> GAUSSPK1) must agree byte
     for byte: two independent writers of the same format."""
