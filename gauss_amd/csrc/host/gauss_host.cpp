@@ -139,40 +139,31 @@ struct MapKey {
 // A window's SNP map lives in blocks of its own instead of the C library's heap.  A 100 000-SNP chromosome enters ~126 000 Snp
 // objects and as many map nodes (~480 B a SNP, ~60 MB over the 36 windows); on the FIRST call of a process every page of that is
 // touched for the first time -- ~14 000 minor faults, 40 ms of kernel time next to 50 ms of user time for the whole data layer,
-// spread over the worker threads' fresh malloc arenas (measured, DESIGN.md section 9e item 8).  Blocks are 2 MB, 2 MB-aligned,
+// spread over the worker threads' fresh malloc arenas (measured, DESIGN.md section 9e item 9).  Blocks are 2 MB, 2 MB-aligned,
 // advised as huge pages and populated in one call (one fault or one batched population instead of 512 traps); a window frees
 // nothing one by one -- its blocks go back to a process-wide list when the window is closed, so later calls touch no new page.
 struct BlockPool {
     std::mutex mu;
     std::vector<void*> idle;
     size_t keep;
-    size_t ARENA_BLOCK = (size_t)2 << 20;
-    BlockPool()
-    {
-        if (const char* b = getenv("GAUSS_HOST_ARENA_BLOCK_KB")) {     // tests: small blocks, so that a window spans many
-            size_t kb = 64;
-            while (kb < (size_t)std::max(64, atoi(b)) && kb < 2048) kb *= 2;
-            ARENA_BLOCK = kb << 10;
-        }
-        const char* e = getenv("GAUSS_HOST_ARENA_KEEP_MB");            // idle blocks kept for the next call (default 256 MB)
-        keep = (size_t)(e ? std::max(0, atoi(e)) : 256) * ((size_t)1 << 20) / ARENA_BLOCK;
-    }
+    size_t block;
+    BlockPool(size_t block_bytes, size_t keep_bytes) : keep(keep_bytes / block_bytes), block(block_bytes) {}
     void* get()
     {
         {
             std::lock_guard<std::mutex> lock(mu);
             if (!idle.empty()) { void* b = idle.back(); idle.pop_back(); return b; }
         }
-        char* raw = (char*)mmap(nullptr, 2 * ARENA_BLOCK, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        char* raw = (char*)mmap(nullptr, 2 * block, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
         if (raw == (char*)MAP_FAILED) throw std::bad_alloc();
-        char* b = (char*)(((uintptr_t)raw + ARENA_BLOCK - 1) & ~(uintptr_t)(ARENA_BLOCK - 1));
+        char* b = (char*)(((uintptr_t)raw + block - 1) & ~(uintptr_t)(block - 1));
         if (b > raw) munmap(raw, (size_t)(b - raw));
-        if (b + ARENA_BLOCK < raw + 2 * ARENA_BLOCK) munmap(b + ARENA_BLOCK, (size_t)(raw + 2 * ARENA_BLOCK - (b + ARENA_BLOCK)));
+        if (b + block < raw + 2 * block) munmap(b + block, (size_t)(raw + 2 * block - (b + block)));
 #ifdef MADV_HUGEPAGE
-        madvise(b, ARENA_BLOCK, MADV_HUGEPAGE);                         // advice only: without huge pages the block is 512 small ones
+        if (block >= ((size_t)2 << 20)) madvise(b, block, MADV_HUGEPAGE);   // advice only: without huge pages the block is 512 small ones
 #endif
 #ifdef MADV_POPULATE_WRITE
-        madvise(b, ARENA_BLOCK, MADV_POPULATE_WRITE);                   // Linux 5.14+; an older kernel faults the pages in on first use
+        madvise(b, block, MADV_POPULATE_WRITE);                         // Linux 5.14+; an older kernel faults the pages in on first use
 #endif
         return b;
     }
@@ -182,13 +173,35 @@ struct BlockPool {
             std::lock_guard<std::mutex> lock(mu);
             if (idle.size() < keep) { idle.push_back(b); return; }
         }
-        munmap(b, ARENA_BLOCK);
+        munmap(b, block);
     }
 };
-static BlockPool& block_pool() { static BlockPool* bp = new BlockPool(); return *bp; }     // never destroyed: windows may outlive static destructors
+// Two sizes: a window's FIRST block is small (128 KB: a fine-grained run -- thousands of windows of a few hundred SNPs -- must not
+// hold 2 MB apiece), everything after it comes in 2 MB blocks.  GAUSS_HOST_ARENA_KEEP_MB: idle memory kept for the next call
+// (default 256 MB in large blocks + 32 MB in small ones); GAUSS_HOST_ARENA_BLOCK_KB (tests): the large block's size, so that a
+// small window spans several.  Never destroyed: windows may outlive static destructors.
+struct BlockPools {
+    BlockPool* small_;
+    BlockPool* large_;
+    BlockPools()
+    {
+        size_t large = (size_t)2 << 20;
+        if (const char* b = getenv("GAUSS_HOST_ARENA_BLOCK_KB")) {
+            size_t kb = 64;
+            while (kb < (size_t)std::max(64, atoi(b)) && kb < 2048) kb *= 2;
+            large = kb << 10;
+        }
+        const char* e = getenv("GAUSS_HOST_ARENA_KEEP_MB");
+        const size_t keep = (size_t)(e ? std::max(0, atoi(e)) : 256) << 20;
+        large_ = new BlockPool(large, keep);
+        small_ = new BlockPool(std::min<size_t>(large, (size_t)128 << 10), keep / 8);
+    }
+};
+static BlockPools& block_pools() { static BlockPools* bp = new BlockPools(); return *bp; }
 
 struct Arena {
-    std::vector<void*> blocks, big;
+    std::vector<std::pair<void*, BlockPool*>> blocks;
+    std::vector<void*> big;
     char* cur = nullptr;
     size_t left = 0;
     Arena() = default;
@@ -197,16 +210,21 @@ struct Arena {
     void* alloc(size_t n)
     {
         n = (n + 15) & ~(size_t)15;
-        BlockPool& bp = block_pool();
-        if (n > bp.ARENA_BLOCK / 8) { void* q = ::operator new(n); big.push_back(q); return q; }
-        if (n > left) { cur = (char*)bp.get(); blocks.push_back(cur); left = bp.ARENA_BLOCK; }
+        if (n > left) {
+            BlockPools& bp = block_pools();
+            BlockPool* from = blocks.empty() ? bp.small_ : bp.large_;
+            if (n > from->block / 8) { void* q = ::operator new(n); big.push_back(q); return q; }
+            cur = (char*)from->get();
+            blocks.emplace_back(cur, from);
+            left = from->block;
+        }
         void* q = cur;
         cur += n; left -= n;
         return q;
     }
     ~Arena()
     {
-        for (void* b : blocks) block_pool().put(b);
+        for (auto& b : blocks) b.second->put(b.first);
         for (void* q : big) ::operator delete(q);
     }
 };
@@ -2523,8 +2541,10 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
     std::string err;
     std::shared_ptr<PackedPanel> pk = open_packed_shared(reference_data_file, err);
     if (!pk) return herr("%s", err.c_str());
+    const double t_opened = now_s();
     std::shared_ptr<const GwasCache> gw = load_gwas_cached(input_file, err);
     if (!gw) return herr("%s", err.c_str());
+    const double t_study = now_s();
     std::vector<long long> gbp;
     for (const GwasRow& r : gw->rows)
         if (chr <= 0 || r.chr == chr) gbp.push_back(r.bp);
@@ -2658,6 +2678,9 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
     }
     st.n_batches = n_batches;
     st.t_plan = now_s() - t_begin;
+    if (getenv("GAUSS_CHROM_TRACE"))
+        fprintf(stderr, "[chrom] plan %.2f ms: panel opened %.2f, study file %.2f, windows + owners + batches %.2f\n", st.t_plan * 1e3,
+                (t_opened - t_begin) * 1e3, (t_study - t_opened) * 1e3, (now_s() - t_study) * 1e3);
 
     // ---- feeder thread: the data layer, batch by batch ----
     int rc_upload = 0;
