@@ -1,0 +1,156 @@
+"""Randomised GPU parity: jobs of random windows -- shapes, population tables, weights, ridge, kinds (impute / QCAT), storage
+forms (host bytes, ASCII digits, a resident 2-bit row store named by row lists) -- through the C ABI against the CPU oracle.
+
+What the fixed-shape tests of test_gpu_parity.py / test_gpu_edges.py pin down case by case is drawn at random here, several
+windows to a job (so that the planner's sharing of measured rows, its tile lists and the per-window tails meet shapes nobody chose
+by hand).  Sizes stay where the loop-literal oracle takes well under a second per window.  Reference: dist.cpp:129-227,
+distmix.cpp:138-253, qcat.cpp:166-245, util.cpp:49-124."""
+import numpy as np
+import pytest
+
+import oracle
+from gauss_amd import hotpath, synth
+from gauss_amd import panel as panel_mod
+
+pytestmark = pytest.mark.gpu
+
+LD_TOL = 1e-12
+Z_TOL = 1e-8
+R_TOL = 1e-7
+
+
+def _study(rng):
+    """A random population table (1 ... 7 populations of 2 ... 700 samples, sometimes one large one that needs several K
+    segments) and a block of polymorphic SNPs over it."""
+    npop = int(rng.integers(1, 8))
+    sizes = [int(rng.integers(2, 90)) if rng.random() < 0.6 else int(rng.integers(90, 700)) for _ in range(npop)]
+    if rng.random() < 0.25:
+        sizes[int(rng.integers(0, npop))] = int(rng.integers(2100, 4600))       # longer than one K segment (2048 / 4096)
+    pops = [(f"P{k:02d}", sizes[k], "EUR" if k % 2 else "ASN") for k in range(npop)]
+    n_snp = int(rng.integers(60, 420))
+    bp = np.sort(rng.choice(np.arange(1, 600_000), size=n_snp, replace=False))
+    G, _ = synth.synth_genotypes(bp, pops, seed=int(rng.integers(1, 1 << 30)))
+    G = np.ascontiguousarray(G[G.min(1) != G.max(1)])
+    off = synth.pop_offsets(sizes)
+    return G, off, sizes
+
+
+def _window(rng, G, off, P):
+    S = G.shape[0]
+    M = int(rng.integers(11, min(S - 12, 300)))
+    U = int(rng.integers(11, min(S - M, 260) + 1))
+    idx = rng.permutation(S)[: M + U]
+    mi, ui = np.sort(idx[:M]), np.sort(idx[M:])
+    mode = int(rng.integers(0, 2))
+    w = None
+    if mode == 1:
+        w = rng.uniform(0.0, 0.4, size=P)
+        if P > 2 and rng.random() < 0.3:
+            w[int(rng.integers(0, P))] = 0.0                 # a population the study does not weight
+        if not np.any(w > 0):
+            w[0] = 0.3
+    lam = float(rng.choice([0.1, 0.1, 0.03, 0.5]))
+    qcat = None
+    if rng.random() < 0.3:
+        n_head = int(rng.integers(0, M // 3 + 1))
+        n_pred = int(rng.integers(1, M - n_head + 1))
+        qcat = (n_head, n_pred, 0.01)
+    z1 = rng.standard_normal(M) * 2.0
+    odd = None
+    r = rng.random()
+    if qcat is None and r < 0.12:
+        # duplicated measured SNPs and no ridge: B11 is singular, MakePosDef (util.cpp:302-318) lifts the zero eigenvalues
+        k = int(rng.integers(1, 4))
+        mi = np.concatenate([mi, mi[:k]])                    # (not sorted any more: row lists need not be)
+        z1 = np.concatenate([z1, z1[:k]])
+        lam, odd = 0.0, "clamp"
+    elif qcat is None and r < 0.2:
+        odd = "flat"                                         # one measured SNP heterozygous everywhere: 0 / 0 in CalCor, the window is NaN
+    return dict(mi=mi, ui=ui, mode=mode, w=w, lam=lam, qcat=qcat, z1=z1, odd=odd)
+
+
+@pytest.mark.parametrize("seed", list(range(96)))
+def test_random_jobs_match_the_oracle(ctx, seed):
+    rng = np.random.default_rng(1000 + seed)
+    G, off, sizes = _study(rng)
+    P = len(sizes)
+    if np.min(sizes) < 2:
+        pytest.skip("degenerate table")
+    form = ["bytes", "ascii", "store"][seed % 3]
+    n_win = int(rng.integers(1, 5))
+    specs = [_window(rng, G, off, P) for _ in range(n_win)]
+    if form == "store" and n_win > 1 and specs[0]["odd"] is None and rng.random() < 0.7:
+        # neighbours of a chromosome: the second window continues the first one's measured SNPs (shared measured rows)
+        a = specs[0]
+        k = len(a["mi"]) // 2
+        rest = np.setdiff1d(np.arange(G.shape[0]), a["mi"])
+        extra = np.sort(rng.choice(rest[rest > a["mi"][k]], size=min(40, int(np.sum(rest > a["mi"][k]))), replace=False)) if np.any(rest > a["mi"][k]) else np.array([], int)
+        mi = np.sort(np.concatenate([a["mi"][k:], extra]))
+        if len(mi) > 10:
+            specs[1] = dict(specs[1], mi=mi, z1=rng.standard_normal(len(mi)), mode=a["mode"], w=a["w"], qcat=None, odd=None, lam=0.1,
+                            ui=np.setdiff1d(specs[1]["ui"], mi))
+            if len(specs[1]["ui"]) < 11:
+                specs[1]["ui"] = np.setdiff1d(np.arange(G.shape[0]), mi)[:30]
+    store = None
+    wins = []
+    if form == "store":
+        # a flat row must be in the store itself: give it a row of its own at the end of G
+        for s in specs:
+            if s["odd"] == "flat":
+                G = np.vstack([G, np.ones((1, G.shape[1]), dtype=G.dtype)])
+                s["mi"] = np.concatenate([s["mi"][:-1], [G.shape[0] - 1]])
+        G = np.ascontiguousarray(G)
+        rows2, src_off = panel_mod.pack2bit(G, off)
+        store = hotpath.RowStore(rows2, ctx=ctx)
+    for s in specs:
+        gm, gu = np.ascontiguousarray(G[s["mi"]]), np.ascontiguousarray(G[s["ui"]])
+        if s["odd"] == "flat" and form != "store":
+            gm[len(gm) // 2, :] = 1
+        s["gm"], s["gu"] = gm, gu
+        d = dict(mode=s["mode"], pop_off=off, pop_wgt=s["w"], z1=s["z1"], lam=s["lam"])
+        if s["qcat"]:
+            d["qcat"] = s["qcat"]
+        if form == "store":
+            d["dev"] = (store.ptr, store.ptr, len(s["mi"]), len(s["ui"]), store.ld)
+            d["packed"] = dict(fmt=1, rows_m=s["mi"].astype(np.int32), rows_u=s["ui"].astype(np.int32), pop_src_off=src_off)
+        else:
+            d["geno_m"] = gm + (48 if form == "ascii" else 0)
+            d["geno_u"] = gu + (48 if form == "ascii" else 0)
+        wins.append(d)
+    job = hotpath.Job(wins, ctx=ctx, on_device=(form == "store"), want_mats=True)
+    job.run()
+    res = job.fetch()
+    job.run()                                                   # and again: nothing of the first run is left behind
+    res2 = job.fetch()
+    job.close()
+    for s, got, again in zip(specs, res, res2):
+        gm, gu = s["gm"], s["gu"]
+        ztol, ldtol = (1e-5, 1e-9) if s["odd"] == "clamp" else (Z_TOL, LD_TOL)      # (the clamp path compares two eigen-solvers: test_makeposdef_clamp_path)
+        for key in got:
+            if isinstance(got[key], np.ndarray):
+                assert np.array_equal(got[key], again[key], equal_nan=True), key
+        if s["qcat"]:
+            n_head, n_pred, cut = s["qcat"]
+            want = oracle.run_qcat(s["mode"], gm, gu, off, s["w"], s["z1"], n_head, n_pred, lam=s["lam"], eig_cutoff=cut, want_mats=True)
+            assert got["num_eig"] == want["num_eig"]
+            assert np.array_equal(np.isnan(got["r"]), np.isnan(want["r"]))
+            ok = ~np.isnan(want["r"])
+            assert np.max(np.abs(got["r"][ok] - want["r"][ok]) / np.maximum(1.0, np.abs(want["r"][ok])), initial=0.0) <= R_TOL
+        else:
+            want = oracle.run_impute(s["mode"], gm, gu, off, s["w"], s["z1"], lam=s["lam"], want_mats=True)
+            if s["odd"] == "clamp":
+                assert want["mpd"] == 1 and (got["status"] & 1)
+            if s["odd"] == "flat" and s["mode"] == 0:           # (pooled Pearson: 0 / 0; the weighted covariance of a flat row is just 0)
+                assert np.all(np.isnan(want["z"])) and (got["status"] & 2)
+            assert np.array_equal(np.isnan(got["z"]), np.isnan(want["z"]))
+            ok = ~np.isnan(want["z"])
+            assert np.max(np.abs(got["z"][ok] - want["z"][ok]) / np.maximum(1.0, np.abs(want["z"][ok])), initial=0.0) <= ztol
+            assert np.max(np.abs(got["info"][ok] - want["info"][ok]) / np.maximum(1e-300, np.abs(want["info"][ok])), initial=0.0) <= ztol
+        for key in ("b11", "b21"):
+            a, b = got[key], want[key]
+            assert a.shape == b.shape
+            assert np.array_equal(np.isnan(a), np.isnan(b)), key
+            fin = ~np.isnan(b)
+            assert np.max(np.abs(a[fin] - b[fin]), initial=0.0) <= ldtol, key
+    if store is not None:
+        store.close()
