@@ -154,3 +154,76 @@ def test_random_jobs_match_the_oracle(ctx, seed):
             assert np.max(np.abs(a[fin] - b[fin]), initial=0.0) <= ldtol, key
     if store is not None:
         store.close()
+
+
+def _same_ld(got, want, tol=LD_TOL):
+    assert got.shape == want.shape
+    nan = np.isnan(want)
+    assert np.array_equal(np.isnan(got), nan)
+    assert np.max(np.abs(got[~nan] - want[~nan]), initial=0.0) <= tol
+
+
+@pytest.mark.parametrize("seed", list(range(32)))
+def test_random_ld_calls_match_the_oracle(ctx, seed):
+    """The LD-only entry points on random studies: computeLD's matrix (computeLD.cpp:95-116, pooled and weighted, any diagonal),
+    the gene-LD batch of jepeg / jepegmix on random gene boundaries (gene.cpp:288-315), the raw LD export with random recodings
+    (prep_qcat.cpp:104-132, prep_qcatmix.cpp:136-221), per-population Pearson for prep_zmix5 (zmix.cpp:158-176), and the
+    single-window streamed call on host bytes (dist.cpp:129-227), which every Rcpp driver binds."""
+    rng = np.random.default_rng(5000 + seed)
+    G, off, sizes = _study(rng)
+    P = len(sizes)
+    S = G.shape[0]
+    w = rng.uniform(0.01, 0.4, size=P)
+    diag = float(rng.choice([1.0, 1.1, 1.5]))
+    kind = seed % 5
+    if kind == 0:
+        rows = np.sort(rng.choice(S, size=int(rng.integers(2, min(S, 200))), replace=False))
+        sub = np.ascontiguousarray(G[rows])
+        if rng.random() < 0.5:
+            _same_ld(hotpath.ld_matrix(sub, off, w, mode=hotpath.MODE_WEIGHTED, diag=1.0, ctx=ctx), oracle.compute_ld(sub, off, w))
+        else:
+            _same_ld(hotpath.ld_matrix(sub, off, None, mode=hotpath.MODE_POOLED, diag=diag, ctx=ctx), oracle.ld_pooled(sub, off, diag))
+    elif kind == 1:
+        n_cut = int(rng.integers(1, min(40, S - 1)))
+        gene_off = np.r_[0, np.sort(rng.choice(np.arange(1, S), size=n_cut, replace=False)), S].astype(np.int32)
+        mode = int(rng.integers(0, 2))
+        blocks = hotpath.gene_ld_batch(G, off, gene_off, pop_wgt=(w if mode else None), mode=mode, diag=diag, ctx=ctx)
+        assert len(blocks) == len(gene_off) - 1
+        for g, blk in enumerate(blocks):
+            rows = G[gene_off[g]:gene_off[g + 1]]
+            if mode == 0:
+                want = oracle.ld_pooled(rows, off, diag)
+            else:
+                want = oracle.compute_ld(rows, off, w)
+                np.fill_diagonal(want, diag)
+            _same_ld(blk, want)
+    elif kind == 2:
+        M = int(rng.integers(11, min(S - 12, 160)))
+        mi = np.sort(rng.choice(S, size=M, replace=False))
+        ui = np.sort(rng.choice(S, size=int(rng.integers(11, min(S, 180))), replace=False))      # may overlap the measured set, as in prep_qcat
+        codings = tuple(sorted(rng.choice(3, size=int(rng.integers(1, 4)), replace=False).tolist()))
+        mode = int(rng.integers(0, 2))
+        gm, gu = np.ascontiguousarray(G[mi]), np.ascontiguousarray(G[ui])
+        got = hotpath.ld_window(mode, gm, gu, off, w if mode else None, lam=0.0, codings=sum(1 << c for c in codings), ctx=ctx)
+        want = oracle.ld_blocks(mode, gm, gu, off, w if mode else None, diag=1.0, codings=codings)
+        _same_ld(got["b11"], want["b11"])
+        _same_ld(got["b21"], want["b21"])
+    elif kind == 3:
+        rows = np.sort(rng.choice(S, size=int(rng.integers(2, min(S, 120))), replace=False))
+        sub = np.ascontiguousarray(G[rows])
+        _same_ld(hotpath.ld_per_pop(sub, off, ctx=ctx), oracle.ld_per_pop(sub, off))
+    else:
+        s = _window(rng, G, off, P)
+        s["mi"] = np.unique(s["mi"])
+        gm, gu = np.ascontiguousarray(G[s["mi"]]), np.ascontiguousarray(G[s["ui"]])
+        z1 = s["z1"][: len(gm)]
+        buf = np.zeros((len(gu), G.shape[1] + 29), dtype=np.uint8)        # unmeasured rows with a row stride of their own
+        buf[:, : G.shape[1]] = gu
+        got = hotpath.impute_window(s["mode"], gm, buf[:, : G.shape[1]], off, s["w"], z1, lam=0.1, want_mats=True, ctx=ctx)
+        want = oracle.run_impute(s["mode"], gm, gu, off, s["w"], z1, lam=0.1, want_mats=True)
+        _same_ld(got["b11"], want["b11"])
+        _same_ld(got["b21"], want["b21"])
+        assert np.array_equal(np.isnan(got["z"]), np.isnan(want["z"]))
+        ok = ~np.isnan(want["z"])
+        assert np.max(np.abs(got["z"][ok] - want["z"][ok]) / np.maximum(1.0, np.abs(want["z"][ok])), initial=0.0) <= Z_TOL
+        assert np.max(np.abs(got["info"][ok] - want["info"][ok]) / np.maximum(1e-300, np.abs(want["info"][ok])), initial=0.0) <= Z_TOL
