@@ -473,7 +473,8 @@ def run_impute(args, rig):
                 continue
             wr = workload.pieces_of(wins, shares_e[r])
             rr = Runner(rig, window_descs(ch, wr, store, ld2, args.mode), 1)
-            dtr, str_, res_r = rr.timed(e_steps, e_warm)
+            # as a rank of a real N > 1 run is timed: no per-stage events inside the timed steps (Runner.timed), stages from extra steps
+            dtr, str_, res_r = rr.timed(e_steps, e_warm, events_in_region=False)
             parts_e.append({piece: (q["z"], q["info"]) for piece, q in zip(shares_e[r], rr.results_in_order(res_r))})
             per_rank.append({"rank": r, "windows": len(wr), "ms_per_step": dtr / e_steps * 1e3,
                              "executed_flops": rr.stats["executed_flops"], "work_items": rr.stats["items"], "algorithmic_flops": rr.work["ld_flops"],
@@ -489,8 +490,9 @@ def run_impute(args, rig):
                "load_imbalance": max(load_e) / (sum(load_e) / len(load_e)), "shard": shard_mode(args, emu_world),
                "cut_windows": sum(1 for sh in shares_e for _, u0, _ in sh if u0 > 0),
                "pieces_bit_identical_to_one_job": pieces_equal_whole(parts_e, res, wins) if args.emulate_rank < 0 else None,
-               "note": "each rank's share timed alone on ONE GPU, one after the other: an emulation of the per-rank step time, "
-                       "not a multi-GPU measurement (no 8-GPU node is available to the builder)"}
+               "note": "each rank's share timed alone on ONE GPU, one after the other, the way a rank of an N > 1 run is timed (no "
+                       "per-stage events inside the timed steps; stage_ms from three extra steps): an emulation of the per-rank step "
+                       "time, not a multi-GPU measurement (no 8-GPU node is available to the builder)"}
 
     e2e = None
     if rig.world == 1 and args.mode == "distmix" and not args.no_e2e and not args.windows and args.streams == 1:
