@@ -306,6 +306,7 @@ struct gauss_job {
     std::vector<char> h_tab;                               // host image of the tables while they are being built
     char* h_pin = nullptr;                                 // pinned block: [table image | results | status]
     hipEvent_t begin = nullptr;                            // recorded when gauss_job_run starts queuing
+    hipEvent_t zeroed = nullptr;                           // the workspace has been zeroed (on the upload queue: job_build)
     hipEvent_t done = nullptr;                             // recorded after the result copies of gauss_job_run
     // Cross-queue events of a run, one set per run parity (two runs of a job may be in flight, see run_seq below):
     //   gram  B11's Gram launch (chain-aside) / the Gram kernel (otherwise) has been queued behind on the main queue
@@ -1192,8 +1193,22 @@ static int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_d
             HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
 
     hipStream_t st = ctx->stream;
-    // zero once: operand padding, B21 padding and the solve matrices rely on it
-    HIPCHK(hipMemsetAsync(job->d_ws, 0, slab_base, st));
+    // zero once: operand padding, B21 padding and the solve matrices rely on it.  On the (otherwise idle) upload queue, not on the
+    // main queue: a pipeline creates the job of batch b + 1 while batch b computes, and 1-2 GB of zeroes at the head of the next
+    // batch were a 0.3-0.4 ms gap between the batches of a chromosome (gauss_host_impute_chromosome: 36.4 ms of GPU span for
+    // 35.0 ms of batches); beside the previous batch's Gram launch they cost nothing.  The main queue waits for the event IN ORDER,
+    // i.e. behind whatever it is computing now.  While a background upload is using that queue the zeroes stay where they were.
+    hipStream_t zs = st;
+    {
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        if (ctx->upload && ctx->uploads.empty() && env_int("GAUSS_ZERO_ASIDE", 1) != 0) zs = ctx->upload;
+    }
+    HIPCHK(hipMemsetAsync(job->d_ws, 0, slab_base, zs));
+    if (zs != st) {
+        HIPCHK(hipEventCreateWithFlags(&job->zeroed, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(job->zeroed, zs));
+        HIPCHK(hipStreamWaitEvent(st, job->zeroed, 0));
+    }
     if (streamed) {
         job->sevp.resize(job->sgroups.size(), nullptr);
         for (hipEvent_t& e : job->sevp) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1942,6 +1957,7 @@ static void job_release(gauss_job* job)
     ctx_pin_release(ctx, job->h_pin);
     job->d_ws = nullptr; job->d_tab = nullptr; job->h_pin = nullptr;
     if (job->begin) hipEventDestroy(job->begin);
+    if (job->zeroed) { hipEventDestroy(job->zeroed); job->zeroed = nullptr; }
     for (int k = 0; k < 2; k++) if (job->done2[k]) hipEventDestroy(job->done2[k]);
     for (int k = 0; k < 2; k++)
         for (hipEvent_t* e : {&job->rev[k].gram, &job->rev[k].side, &job->rev[k].pack, &job->rev[k].rows, &job->rev[k].epi})
@@ -2039,6 +2055,17 @@ int gauss_hip_init(int device, gauss_ctx** out_ctx)
         HIPCHK(hipStreamCreateWithPriority(&c->upload, hipStreamNonBlocking, hi));       // see gauss_store_fill
         c->prepin = std::thread([c]() {
             (void)hipSetDevice(c->device);
+            {
+                // the upload queue's first KERNEL (job_build zeroes new workspaces there; background fills copy by kernel) makes
+                // the runtime set up its compute queue: 100 ms when it happened in the middle of a chromosome's first call
+                // (GAUSS_CHROM_TRACE: one job creation of 103 ms, round 4) -- done here, off everybody's path
+                void* d = nullptr;
+                if (hipMalloc(&d, 256) == hipSuccess) {
+                    (void)hipMemsetAsync(d, 0, 256, c->upload);
+                    (void)hipStreamSynchronize(c->upload);
+                    (void)hipFree(d);
+                } else (void)hipGetLastError();
+            }
             for (int b = 0; b < 2; b++) {
                 void* p = nullptr;                             // (outside c->mu: the main thread may be building its first job meanwhile)
                 if (hipHostMalloc(&p, UPLOAD_CHUNK, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); break; }
