@@ -1902,7 +1902,9 @@ static int job_fetch(gauss_job* job)
             // QCAT never repairs B11 (MakePosDef is commented out, qcat.cpp:206); CountPC only counts
             int num_eig = p.M;
             if (job->h_status[4 * i + 0]) bits = GAUSS_ST_NONFINITE;          // B11 has no Cholesky factor
-            else if (job->h_status[4 * i + 1]) { int rc = job_count_small_eigs(job, i, &num_eig); if (rc) return rc; }
+            // (no factor: B11 is indefinite -- weights summing far above 1 -- or not finite.  The reference still counts: CountPC runs
+            // before the factorisation, qcat.cpp:203, and an eigenvalue below the cutoff, negative ones included, is not counted)
+            if (job->h_status[4 * i + 0] || job->h_status[4 * i + 1]) { int rc = job_count_small_eigs(job, i, &num_eig); if (rc) return rc; }
             if (bits & GAUSS_ST_NONFINITE)
                 for (int u = 0; u < 2 * p.n_rhs; u++) job->h_results[pl.res_off + u] = NAN;
             if (pl.out_r) memcpy(pl.out_r, job->h_results + pl.res_off, sizeof(double) * p.n_rhs);

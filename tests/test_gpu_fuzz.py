@@ -5,6 +5,8 @@ What the fixed-shape tests of test_gpu_parity.py / test_gpu_edges.py pin down ca
 windows to a job (so that the planner's sharing of measured rows, its tile lists and the per-window tails meet shapes nobody chose
 by hand).  Sizes stay where the loop-literal oracle takes well under a second per window.  Reference: dist.cpp:129-227,
 distmix.cpp:138-253, qcat.cpp:166-245, util.cpp:49-124."""
+import os
+
 import numpy as np
 import pytest
 
@@ -69,7 +71,14 @@ def _window(rng, G, off, P):
     return dict(mi=mi, ui=ui, mode=mode, w=w, lam=lam, qcat=qcat, z1=z1, odd=odd)
 
 
-@pytest.mark.parametrize("seed", list(range(96)))
+# Seeds that found something when 2 000 were run (round 4), kept in every run: 829 -- a QCAT window whose weights (sum 1.48) make
+# B11 indefinite: no Cholesky factor, r is NaN, and the reference's CountPC (util.cpp:355-388, called before the factorisation,
+# qcat.cpp:203) still counts the eigenvalues above the cutoff (51 of 52; the library said 52 until then); 355, 1199 -- clamp
+# windows whose weights turn a self-covariance negative (the oracle reports -1: every output NaN, in both).
+REGRESSION_SEEDS = [355, 829, 1199]
+
+
+@pytest.mark.parametrize("seed", sorted(set(list(range(int(os.environ.get("GAUSS_FUZZ_SEEDS", "96")))) + REGRESSION_SEEDS)))       # a long run: GAUSS_FUZZ_SEEDS=2000
 def test_random_jobs_match_the_oracle(ctx, seed):
     rng = np.random.default_rng(1000 + seed)
     G, off, sizes = _study(rng)
@@ -138,7 +147,10 @@ def test_random_jobs_match_the_oracle(ctx, seed):
             assert np.max(np.abs(got["r"][ok] - want["r"][ok]) / np.maximum(1.0, np.abs(want["r"][ok])), initial=0.0) <= R_TOL
         else:
             want = oracle.run_impute(s["mode"], gm, gu, off, s["w"], s["z1"], lam=s["lam"], want_mats=True)
-            if s["odd"] == "clamp":
+            if s["odd"] == "clamp" and want["mpd"] < 0:
+                # weights summing above 1 can make a self-covariance negative: its square root is NaN in the reference, every output NaN
+                assert np.all(np.isnan(want["z"])) and np.all(np.isnan(got["z"])) and (got["status"] & 2)
+            elif s["odd"] == "clamp":
                 assert want["mpd"] == 1 and (got["status"] & 1)
             if s["odd"] == "flat" and s["mode"] == 0:           # (pooled Pearson: 0 / 0; the weighted covariance of a flat row is just 0)
                 assert np.all(np.isnan(want["z"])) and (got["status"] & 2)
@@ -163,7 +175,7 @@ def _same_ld(got, want, tol=LD_TOL):
     assert np.max(np.abs(got[~nan] - want[~nan]), initial=0.0) <= tol
 
 
-@pytest.mark.parametrize("seed", list(range(32)))
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("GAUSS_FUZZ_LD_SEEDS", "32")))))
 def test_random_ld_calls_match_the_oracle(ctx, seed):
     """The LD-only entry points on random studies: computeLD's matrix (computeLD.cpp:95-116, pooled and weighted, any diagonal),
     the gene-LD batch of jepeg / jepegmix on random gene boundaries (gene.cpp:288-315), the raw LD export with random recodings
