@@ -239,3 +239,57 @@ def test_random_ld_calls_match_the_oracle(ctx, seed):
         ok = ~np.isnan(want["z"])
         assert np.max(np.abs(got["z"][ok] - want["z"][ok]) / np.maximum(1.0, np.abs(want["z"][ok])), initial=0.0) <= Z_TOL
         assert np.max(np.abs(got["info"][ok] - want["info"][ok]) / np.maximum(1e-300, np.abs(want["info"][ok])), initial=0.0) <= Z_TOL
+
+
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("GAUSS_FUZZ_DRIVER_SEEDS", "20")))))
+def test_random_driver_calls_match_the_python_drivers(ctx, tmp_path, seed):
+    """The reference's entry points end to end on random studies: files -> C++ host layer -> HIP -> table against the Python
+    restatement of the drivers on the CPU oracle (oracle/feeder_py.py), for dist / distmix / qcat / qcatmix, the text panel and its
+    packed form, random windows, wings and AF cutoffs, swapped alleles, study-only SNPs -- and a window that fails the ">10" guard
+    (dist.cpp:145-151) must fail in both."""
+    from oracle import feeder_py as fp
+    from gauss_amd import api
+    from test_gpu_drivers import _cmp_impute, _cmp_qcat
+    rng = np.random.default_rng(9000 + seed)
+    npop = int(rng.integers(2, 7))
+    sups = ["EUR", "ASN", "AFR"]
+    pops = [(f"P{k:02d}", int(rng.integers(40, 200)), sups[int(rng.integers(0, 3))]) for k in range(npop)]
+    pops[0] = (pops[0][0], pops[0][1], "EUR")
+    st = panel_mod.make_synthetic_study(str(tmp_path), pops, n_snp=int(rng.integers(150, 520)), bp_lo=1_000_000, bp_hi=2_200_000,
+                                        frac_measured=float(rng.uniform(0.15, 0.6)), frac_swapped=float(rng.uniform(0, 0.4)),
+                                        frac_not_in_panel=float(rng.uniform(0, 0.1)), seed=100 + seed)
+    p = st["paths"]
+    inp, idx, dat, desc = p["gwas.txt"], p["index.gz"], p["data.gz"], p["desc.txt"]
+    gpk = str(tmp_path / "f.gpk")
+    assert api.pack_panel(idx, dat, desc, gpk) > 0
+    lo = int(rng.integers(1_000_000, 1_700_000))
+    hi = lo + int(rng.integers(120_000, 500_000))
+    wing = int(rng.integers(0, 300_000))
+    cutoff = float(rng.choice([0.01, 0.03, 0.08]))
+    kind = ["dist", "distmix", "qcat", "qcatmix"][seed % 4]
+    mix = kind in ("distmix", "qcatmix")
+    if mix:
+        names = [q[0].lower() for q in pops if rng.random() < 0.75] or [pops[0][0]]
+        who = (names, [float(x) for x in rng.uniform(0.05, 0.5, len(names))])
+    else:
+        who = "EUR"
+    want, werr = None, None
+    try:
+        want = getattr(fp, kind)(22, lo, hi, wing, who, inp, idx, dat, desc, af1_cutoff=cutoff)
+    except ValueError as e:
+        werr = str(e)
+    for data in (dat, gpk):
+        got, gerr = None, None
+        try:
+            got = getattr(api, kind)(22, lo, hi, wing, who, inp, idx, data, desc, af1_cutoff=cutoff, ctx=ctx)
+        except api.GaussError as e:
+            gerr = str(e)
+        assert (gerr is None) == (werr is None), (gerr, werr)
+        if werr is not None:
+            assert "Not enough number of SNPs" in gerr and "Not enough number of SNPs" in werr
+            continue
+        afcol = "af1mix" if mix else "af1ref"
+        if kind in ("dist", "distmix"):
+            _cmp_impute(got, want, afcol)
+        else:
+            _cmp_qcat(got, want, afcol)
