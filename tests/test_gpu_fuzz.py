@@ -293,3 +293,121 @@ def test_random_driver_calls_match_the_python_drivers(ctx, tmp_path, seed):
             _cmp_impute(got, want, afcol)
         else:
             _cmp_qcat(got, want, afcol)
+
+
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("GAUSS_FUZZ_GENE_SEEDS", "12")))))
+def test_random_gene_and_ld_driver_calls_match_the_python_drivers(ctx, tmp_path, seed):
+    """jepeg / jepegmix (gene.cpp, jepeg.cpp:28-153) and computeLD (computeLD.cpp:26-166) end to end on random studies with a
+    random annotation, text panel and packed form (the packed form walks the study's positions in the genome-wide index merge:
+    gauss_host.cpp:ReadReferenceIndex)."""
+    from oracle import feeder_py as fp
+    from gauss_amd import api
+    rng = np.random.default_rng(12000 + seed)
+    npop = int(rng.integers(2, 7))
+    sups = ["EUR", "ASN", "AFR"]
+    pops = [(f"P{k:02d}", int(rng.integers(40, 200)), sups[int(rng.integers(0, 3))]) for k in range(npop)]
+    pops[0] = (pops[0][0], pops[0][1], "EUR")
+    st = panel_mod.make_synthetic_study(str(tmp_path), pops, n_snp=int(rng.integers(200, 600)), bp_lo=1_000_000, bp_hi=2_200_000,
+                                        frac_measured=float(rng.uniform(0.25, 0.6)), frac_swapped=float(rng.uniform(0, 0.4)),
+                                        frac_not_in_panel=float(rng.uniform(0, 0.1)), n_genes=int(rng.integers(5, 40)), seed=300 + seed)
+    p = st["paths"]
+    inp, idx, dat, desc, ann = p["gwas.txt"], p["index.gz"], p["data.gz"], p["desc.txt"], p["annot.txt"]
+    gpk = str(tmp_path / "f.gpk")
+    assert api.pack_panel(idx, dat, desc, gpk) > 0
+    names = [q[0].lower() for q in pops if rng.random() < 0.75] or [pops[0][0]]
+    wgt = (names, [float(x) for x in rng.uniform(0.05, 0.5, len(names))])
+    kind = seed % 3
+    cat = ["PFS", "TFB", "STR", "TAR", "CIS", "TRN"]
+    for data in (dat, gpk):
+        if kind == 2:
+            lo = int(rng.integers(1_000_000, 1_600_000)) if data == dat else lo
+            hi = lo + int(rng.integers(150_000, 500_000)) if data == dat else hi
+            try:
+                want = fp.computeLD(22, lo, hi, wgt, inp, idx, dat, desc)
+            except ValueError:
+                with pytest.raises(api.GaussError, match="Not enough number of SNPs loaded - computeLD not performed"):
+                    api.computeLD(22, lo, hi, wgt, inp, idx, data, desc, ctx=ctx)
+                continue
+            got = api.computeLD(22, lo, hi, wgt, inp, idx, data, desc, ctx=ctx)
+            assert list(got["snplist"]["rsid"]) == want["rsid"]
+            assert np.array_equal(got["snplist"]["af1mix"].to_numpy(), np.array(want["af1mix"]))
+            assert got["cormat"].shape == want["cormat"].shape and np.max(np.abs(got["cormat"] - want["cormat"]), initial=0.0) <= 1e-12
+            continue
+        if kind == 1:
+            df, want = api.jepegmix(wgt, inp, ann, idx, data, desc, ctx=ctx), fp.jepegmix(wgt, inp, ann, idx, dat, desc)
+        else:
+            df, want = api.jepeg("EUR", inp, ann, idx, data, desc, ctx=ctx), fp.jepeg("EUR", inp, ann, idx, dat, desc)
+        assert len(df) == len(want)
+        for i, w in enumerate(want):
+            r = df.iloc[i]
+            assert r["num_snp"] == w["num_snp"] and r["df"] == w["df"] and r["geneid"] == w["geneid"]
+            if w["df"]:
+                assert abs(r["chisq"] - w["chisq"]) <= 1e-8 * max(1.0, abs(w["chisq"]))
+                assert abs(r["jepeg_pval"] - w["jepeg_pval"]) <= 1e-7 * w["jepeg_pval"] + 1e-300
+                assert r["top_categ"] == cat[w["top_categ"]] and r["top_snp"] == w["top_snp_id"]
+            else:
+                assert r["chisq"] == -1.0 and r["jepeg_pval"] == -1.0 and r["top_categ"] == "." and r["top_snp"] == "."
+
+
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("GAUSS_FUZZ_CHROM_SEEDS", "10")))))
+def test_random_chromosome_runs_equal_per_window_calls(ctx, tmp_path, seed):
+    """gauss_host_impute_chromosome (native windows loop: plan, batches, resident panel, first-use upload beside the batches,
+    tables) on random studies -- window size, batch count, rank count, kind drawn at random -- against the reference-style entry
+    point called window by window on the same packed panel: same rows, same bits; windows the ">10" guards skip are reported,
+    not failed; several ranks merge into the one-rank table."""
+    import pandas as pd
+    from gauss_amd import api
+    rng = np.random.default_rng(15000 + seed)
+    npop = int(rng.integers(2, 7))
+    sups = ["EUR", "ASN", "AFR"]
+    pops = [(f"P{k:02d}", int(rng.integers(40, 260)), sups[int(rng.integers(0, 3))]) for k in range(npop)]
+    pops[0] = (pops[0][0], pops[0][1], "EUR")
+    st = panel_mod.make_synthetic_study(str(tmp_path), pops, n_snp=int(rng.integers(500, 1500)), bp_lo=1_000_000, bp_hi=4_000_000,
+                                        frac_measured=float(rng.uniform(0.2, 0.5)), frac_swapped=float(rng.uniform(0, 0.3)),
+                                        frac_not_in_panel=float(rng.uniform(0, 0.05)), seed=500 + seed)
+    p = st["paths"]
+    gpk = str(tmp_path / "f.gpk")
+    assert api.pack_panel(p["index.gz"], p["data.gz"], p["desc.txt"], gpk) > 0
+    kind_name = ["DISTMIX", "DIST", "QCATMIX", "QCAT"][seed % 4]
+    kind = getattr(api, "KIND_" + kind_name)
+    mix = kind_name.endswith("MIX")
+    names = [q[0].lower() for q in pops if rng.random() < 0.75] or [pops[0][0]]
+    who = (names, [float(x) for x in rng.uniform(0.05, 0.4, len(names))]) if mix else "EUR"
+    sel = dict(pop_wgt_df=who) if mix else dict(study_pop="EUR")
+    wing = int(rng.integers(50_000, 300_000))
+    wsize = int(rng.choice([125_000, 200_000, 300_000, 500_000, 750_000]))
+    nb = int(rng.integers(0, 6))                                  # 0: the driver's own choice
+    kw = dict(input_file=p["gwas.txt"], reference_data_file=gpk, reference_pop_desc_file=p["desc.txt"], window_size=wsize, ctx=ctx, **sel)
+    api.panel_evict(ctx=ctx)
+    res = api.impute_chromosome(kind, 22, 1_000_001, 4_000_000, wing, n_batches=nb, **kw)      # first use: the panel travels beside the batches
+    assert res.stats["n_failed"] == 0 and res.stats["panel_bytes_uploaded"] > 0
+    fn = {"DIST": api.dist, "DISTMIX": api.distmix, "QCAT": api.qcat, "QCATMIX": api.qcatmix}[kind_name]
+    frames = []
+    for s, e, owner, status, m, u in res.windows:
+        a = (22, int(s), int(e), wing, who, p["gwas.txt"], p["index.gz"], gpk, p["desc.txt"])
+        if status != 0:
+            assert status == 1
+            with pytest.raises(api.GaussError, match="Not enough number of SNPs"):
+                fn(*a, ctx=ctx)
+            continue
+        frames.append(fn(*a, ctx=ctx))
+    got = res.frame()
+    if frames:
+        want = pd.concat(frames, ignore_index=True)
+        assert list(got.columns) == list(want.columns) and len(got) == len(want)
+        for c in want.columns:
+            if want[c].dtype.kind == "f":
+                assert np.array_equal(got[c].to_numpy(), want[c].to_numpy(), equal_nan=True), c
+            else:
+                assert list(got[c]) == list(want[c]), c
+    else:
+        assert len(got) == 0
+    # resident now; two or three ranks, another batch count: merged, the same table
+    world = int(rng.integers(2, 4))
+    parts = [api.impute_chromosome(kind, 22, 1_000_001, 4_000_000, wing, rank=r, world=world, n_batches=int(rng.integers(0, 4)), **kw) for r in range(world)]
+    assert all(q.stats["panel_bytes_uploaded"] == 0 for q in parts)
+    merged = api.ChromResult.merge(parts)
+    for c in res.columns:
+        x, y = res.columns[c], merged.columns[c]
+        assert np.array_equal(x, y, equal_nan=True) if x.dtype.kind == "f" else np.array_equal(x, y), c
+    api.panel_evict(ctx=ctx)
