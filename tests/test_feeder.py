@@ -341,7 +341,8 @@ def test_gene_drivers_index_merge_on_odd_positions(tmp_path):
     rng = np.random.default_rng(5)
     #        bp       a1   a2
     pan = [(1000, "A", "C"), (2000, "A", "C"), (2000, "A", "G"), (3000, "A", "G"), (4000, "T", "C"), (5000, "G", "A"),
-           (6000, "A", "C"), (7000, "C", "T"), (7000, "C", "G"), (8000, "A", "T"), (9000, "G", "C")]
+           (6000, "A", "C"), (7000, "C", "T"), (7000, "C", "G"), (8000, "A", "T"), (9000, "G", "C"),
+           (9100, "ACGTACGTACGTACGTACGTA", "A"), (9200, "T", "TGGGGGGGGGGGGGGGGGGGGGGGG")]         # indels: alleles longer than a small string
     S = len(pan)
     G = rng.integers(0, 3, size=(S, sum(sizes)), dtype=np.uint8)
     off = np.concatenate([[0], np.cumsum(sizes)])
@@ -356,7 +357,8 @@ def test_gene_drivers_index_merge_on_odd_positions(tmp_path):
     #          bp     a1   a2    (1000 same; 2000 one study SNP, two panel entries; 3000 two study SNPs, one panel entry; 4000 swapped;
     #                             4500 study only; 6000 different alleles; 7000 two and two; 8000 swapped; 9000 same)
     gw = [(1000, "A", "C"), (2000, "A", "G"), (3000, "A", "G"), (3000, "A", "T"), (4000, "C", "T"), (4500, "A", "C"),
-          (6000, "A", "G"), (7000, "C", "T"), (7000, "G", "C"), (8000, "T", "A"), (9000, "G", "C")]
+          (6000, "A", "G"), (7000, "C", "T"), (7000, "G", "C"), (8000, "T", "A"), (9000, "G", "C"),
+          (9100, "A", "ACGTACGTACGTACGTACGTA"), (9200, "T", "TGGGGGGGGGGGGGGGGGGGGGGGG")]
     z = rng.standard_normal(len(gw))
     gwas = d + "/gwas.txt"
     panel.write_gwas(gwas, [f"g{i}" for i in range(len(gw))], [22] * len(gw), [q[0] for q in gw], [q[1] for q in gw], [q[2] for q in gw], z)
@@ -364,19 +366,31 @@ def test_gene_drivers_index_merge_on_odd_positions(tmp_path):
     panel.write_annotation(ann, [("x", 22, 1000, "A", "C", "GENE1", "PROTEIN", 1.5), ("x", 22, 2000, "G", "A", "GENE1", "TFBS", 0.5),
                                  ("x", 22, 4000, "C", "T", "GENE1", "CIS_EQTL", 1.0), ("x", 22, 7000, "C", "T", "GENE2", "PROTEIN", 2.0),
                                  ("x", 22, 7000, "C", "G", "GENE2", "NO_SUCH", 0.7), ("x", 22, 8000, "A", "T", "GENE2", "WTH_HAIR", 0.3),
-                                 ("x", 22, 9000, "G", "C", "GENE2", "TRANS_EQTL", 0.9), ("x", 22, 9500, "G", "C", "GENE3", "TFBS", 0.9)])
+                                 ("x", 22, 9000, "G", "C", "GENE2", "TRANS_EQTL", 0.9), ("x", 22, 9500, "G", "C", "GENE3", "TFBS", 0.9),
+                                 ("x", 22, 9100, "ACGTACGTACGTACGTACGTA", "A", "GENE3", "PROTEIN", 1.1),
+                                 ("x", 22, 9200, "TGGGGGGGGGGGGGGGGGGGGGGGG", "T", "GENE3", "CIS_EQTL", 0.4)])
     for kind, kw in ((api.KIND_JEPEG, dict(study_pop="EUR")), (api.KIND_JEPEGMIX, dict(pop_wgt_df=(["AAA", "BBB"], [0.6, 0.4])))):
         base = dict(input_file=gwas, annotation_file=ann, reference_index_file=idx, reference_pop_desc_file=desc, af1_cutoff=0.0001, **kw)
         a = api.Prepared(kind, reference_data_file=dat, **base)
         b = api.Prepared(kind, reference_data_file=gpk, **base)
         _same_prepared(a, b)
         da = b.snps()
-        assert len(da) >= 8 and set(da["type"]) == {1}                    # (study-only SNPs have no panel line: the AF filter drops them)
+        assert len(da) >= 10 and set(da["type"]) == {1}                   # (study-only SNPs have no panel line: the AF filter drops them)
+        assert "ACGTACGTACGTACGTACGTA" in set(da["a1"]) and "TGGGGGGGGGGGGGGGGGGGGGGGG" in (set(da["a1"]) | set(da["a2"]))
         assert b.n_gene >= 1
         a.close(); b.close()
         b2 = api.Prepared(kind, reference_data_file=gpk, **base)         # the annotation comes from the cache now
         assert list(b2.snps()["geneid"]) == list(da["geneid"])
         b2.close()
+    # the window feeders on the same odd sites (ReadReferenceIndex, gauss.cpp:293-399: panel SNPs the study lacks are entered too)
+    for kind, kw in ((api.KIND_DIST, dict(study_pop="EUR")), (api.KIND_DISTMIX, dict(pop_wgt_df=(["AAA", "BBB"], [0.6, 0.4])))):
+        base = dict(chr=22, start_bp=500, end_bp=9500, wing_size=0, input_file=gwas, reference_index_file=idx, reference_pop_desc_file=desc,
+                    af1_cutoff=0.0001, **kw)
+        a = api.Prepared(kind, reference_data_file=dat, **base)
+        b = api.Prepared(kind, reference_data_file=gpk, **base)
+        _same_prepared(a, b)                                      # (no wing: the packed feeder leaves nothing out)
+        assert {0, 1} <= set(b.snps()["type"])
+        a.close(); b.close()
     # a study that lists one site under both allele orders: "duplicates" from both feeders
     bad = d + "/gwas_dup.txt"
     panel.write_gwas(bad, ["g0", "g1"], [22, 22], [1000, 1000], ["A", "C"], ["C", "A"], [0.5, -0.5])
