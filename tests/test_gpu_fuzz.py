@@ -19,6 +19,9 @@ pytestmark = pytest.mark.gpu
 LD_TOL = 1e-12
 Z_TOL = 1e-8
 R_TOL = 1e-7
+# GAUSS_FUZZ_BIG=1 (a long run, a few seconds of oracle per window): up to 1 400 SNPs, windows of up to 700 measured and 800 unmeasured
+# SNPs (several 128-row tiles, a dozen 64-column factor blocks), up to eight windows to a job
+BIG = os.environ.get("GAUSS_FUZZ_BIG", "0") != "0"
 
 
 def _study(rng):
@@ -29,7 +32,7 @@ def _study(rng):
     if rng.random() < 0.25:
         sizes[int(rng.integers(0, npop))] = int(rng.integers(2100, 4600))       # longer than one K segment (2048 / 4096)
     pops = [(f"P{k:02d}", sizes[k], "EUR" if k % 2 else "ASN") for k in range(npop)]
-    n_snp = int(rng.integers(60, 420))
+    n_snp = int(rng.integers(60, 420)) if not BIG else int(rng.integers(400, 1400))
     bp = np.sort(rng.choice(np.arange(1, 600_000), size=n_snp, replace=False))
     G, _ = synth.synth_genotypes(bp, pops, seed=int(rng.integers(1, 1 << 30)))
     G = np.ascontiguousarray(G[G.min(1) != G.max(1)])
@@ -39,8 +42,8 @@ def _study(rng):
 
 def _window(rng, G, off, P):
     S = G.shape[0]
-    M = int(rng.integers(11, min(S - 12, 300)))
-    U = int(rng.integers(11, min(S - M, 260) + 1))
+    M = int(rng.integers(11, min(S - 12, 700 if BIG else 300)))
+    U = int(rng.integers(11, min(S - M, 800 if BIG else 260) + 1))
     idx = rng.permutation(S)[: M + U]
     mi, ui = np.sort(idx[:M]), np.sort(idx[M:])
     mode = int(rng.integers(0, 2))
@@ -86,7 +89,7 @@ def test_random_jobs_match_the_oracle(ctx, seed):
     if np.min(sizes) < 2:
         pytest.skip("degenerate table")
     form = ["bytes", "ascii", "store"][seed % 3]
-    n_win = int(rng.integers(1, 5))
+    n_win = int(rng.integers(1, 9 if BIG else 5))
     specs = [_window(rng, G, off, P) for _ in range(n_win)]
     if form == "store" and n_win > 1 and specs[0]["odd"] is None and rng.random() < 0.7:
         # neighbours of a chromosome: the second window continues the first one's measured SNPs (shared measured rows)
@@ -156,6 +159,9 @@ def test_random_jobs_match_the_oracle(ctx, seed):
                 assert np.all(np.isnan(want["z"])) and (got["status"] & 2)
             assert np.array_equal(np.isnan(got["z"]), np.isnan(want["z"]))
             ok = ~np.isnan(want["z"])
+            # imputed z of several hundred = a nearly singular B11 (more SNPs than samples and a small ridge): Cholesky and the
+            # reference's full-pivot LU then agree to cond(B11) x eps, not to 1e-8 (seen: 1.7e-8 at |z| = 540; the bar is 1e-5)
+            ztol = ztol * max(1.0, float(np.max(np.abs(want["z"][ok]), initial=0.0)) / 20.0)
             assert np.max(np.abs(got["z"][ok] - want["z"][ok]) / np.maximum(1.0, np.abs(want["z"][ok])), initial=0.0) <= ztol
             assert np.max(np.abs(got["info"][ok] - want["info"][ok]) / np.maximum(1e-300, np.abs(want["info"][ok])), initial=0.0) <= ztol
         for key in ("b11", "b21"):
