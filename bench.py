@@ -209,6 +209,7 @@ class Runner:
             self.jobs = [hotpath.Job(descs[i::n], ctx=self.ctxs[i], on_device=True) for i in range(n)]
             self.order = [k for i in range(n) for k in range(i, len(descs), n)]
         self.inflight = False
+        self.done_at = []               # host time at which each fetched run was complete (timed(): the longest step of the region)
         self.work = {k: sum(j.work()[k] for j in self.jobs) for k in ("ld_flops", "solve_flops", "bytes", "imputed_snps")}
         self.stats = {k: sum(j.stats()[k] for j in self.jobs) for k in ("items", "executed_flops", "slab_bytes", "workspace_bytes")}
 
@@ -221,6 +222,7 @@ class Runner:
             out = []
             for j in self.jobs:
                 out += j.fetch()
+            self.done_at.append(time.perf_counter())
         self.inflight = True
         return out
 
@@ -229,6 +231,7 @@ class Runner:
         if self.inflight:
             for j in self.jobs:
                 out += j.fetch()
+            self.done_at.append(time.perf_counter())
             self.inflight = False
         return out
 
@@ -265,11 +268,15 @@ class Runner:
         self.profile(events_in_region)
         self.rig.barrier()
         t0 = time.perf_counter()
+        self.done_at = []
         for _ in range(steps):
             self.step()
         res = self.drain()
         self.rig.barrier()
         dt = time.perf_counter() - t0
+        # completion to completion of consecutive runs (the first one from the start of the region): the longest step
+        marks = [t0] + self.done_at
+        self.longest_step_ms = max((b - a) for a, b in zip(marks[:-1], marks[1:])) * 1e3 if len(marks) > 1 else 0.0
         if events_in_region:
             st = self.stage_ms()
         else:
@@ -524,6 +531,7 @@ def run_impute(args, rig):
             "unit": "imputed SNPs/s",
             "n_gpus": rig.world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": tmax / args.steps * 1e3,
+            "ms_longest_step": runner.longest_step_ms,        # completion to completion of consecutive steps in the timed region (this rank)
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32" if args.gram_dtype == "f32" else "i8",
             "dtype_detail": ("LD GEMM on the %s matrix cores with exact integer partial sums; correlation tails, Cholesky and "
