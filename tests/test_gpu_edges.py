@@ -5,6 +5,7 @@ import pytest
 
 import oracle
 from gauss_amd import hotpath, synth
+from gauss_amd import panel as panel_mod
 from helpers import relerr, small_panel
 
 pytestmark = pytest.mark.gpu
@@ -648,3 +649,48 @@ def test_standalone_solver_against_the_oracle(ctx, mode, monkeypatch):
         wn = wins[k]
         one = hotpath.impute_window(mode, wn["geno_m"], wn["geno_u"], off, p["w"], wn["z1"], ctx=ctx)
         assert np.array_equal(one["z"], res[k]["z"]) and np.array_equal(one["info"], res[k]["info"]), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("asynchronous", [False, True])
+def test_row_store_beyond_four_gigabytes(ctx, asynchronous):
+    """A whole-genome panel is tens of GB in one row store (the 33KG panel: 82 GB): byte offsets of rows past 4 GB must be
+    64-bit everywhere -- the staged upload's chunk offsets, the background upload's copy kernel (stores above 4 GB travel by
+    kernel) and its per-chunk marks, the pack kernel's row gather.  A 5.4 GB store of 8 KB rows holds the same 2-bit rows at
+    row 0 and at row 600 000 (4.9 GB in): a window that names the high rows must give the bits of the one that names the low
+    rows, which is checked against the oracle."""
+    p = small_panel(n_snp=230, scale=0.02, seed=77)
+    G, off = p["G"], p["off"]
+    rows2, src_off = panel_mod.pack2bit(G, off)
+    S, rb = rows2.shape
+    ld, n_rows, hi0 = 8192, 660_000, 600_000
+    assert n_rows * ld > (5 << 30) and hi0 * ld > (4 << 30) and rb <= ld
+    big = np.zeros((n_rows, ld), dtype=np.uint8)                    # (untouched pages cost nothing on the host)
+    big[:S, :rb] = rows2
+    big[hi0:hi0 + S, :rb] = rows2
+    store = hotpath.RowStore(big, ctx=ctx, asynchronous=asynchronous)
+    try:
+        rng = np.random.default_rng(5)
+        idx = rng.permutation(S)
+        mi, ui = np.sort(idx[:90]), np.sort(idx[90:200])
+        z1 = rng.standard_normal(len(mi))
+        if asynchronous:
+            store.wait(hi0 + S)                                     # the rows the job names have landed (the rest may still travel)
+        wins = []
+        for base in (0, hi0):
+            wins.append(dict(mode=1, pop_off=off, pop_wgt=p["w"], z1=z1, dev=(store.ptr, store.ptr, len(mi), len(ui), store.ld),
+                             packed=dict(fmt=1, rows_m=(mi + base).astype(np.int32), rows_u=(ui + base).astype(np.int32), pop_src_off=src_off)))
+        job = hotpath.Job(wins, ctx=ctx, on_device=True, want_mats=True)
+        job.run()
+        lo, hi = job.fetch()
+        job.close()
+        if asynchronous:
+            store.wait(0)
+        for key in ("z", "info", "b11", "b21"):
+            assert np.array_equal(lo[key], hi[key], equal_nan=True), key
+        want = oracle.run_impute(1, G[mi], G[ui], off, p["w"], z1, want_mats=True)
+        assert np.max(np.abs(lo["b21"] - want["b21"])) <= 1e-12
+        assert np.max(np.abs(lo["z"] - want["z"]) / np.maximum(1.0, np.abs(want["z"]))) <= 1e-8
+        assert np.all(np.isfinite(hi["z"])) and np.any(hi["z"] != 0)
+    finally:
+        store.close()
