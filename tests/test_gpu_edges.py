@@ -694,3 +694,29 @@ def test_row_store_beyond_four_gigabytes(ctx, asynchronous):
         assert np.all(np.isfinite(hi["z"])) and np.any(hi["z"] != 0)
     finally:
         store.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [0, 1])
+def test_window_with_thirty_thousand_unmeasured_snps(ctx, mode):
+    """A sparse array imputed against a dense panel: few measured SNPs, tens of thousands of unmeasured ones in one window (235
+    row tiles of B21, one column tile) -- every z / info against the oracle."""
+    from gauss_amd import synth
+    pops = [("AAA", 170, "EUR"), ("BBB", 230, "EUR"), ("CCC", 200, "ASN")]
+    rng = np.random.default_rng(99)
+    S = 30_060
+    bp = np.sort(rng.choice(np.arange(1, 3_000_000), size=S, replace=False))
+    G, _ = synth.synth_genotypes(bp, pops, seed=31)
+    G = np.ascontiguousarray(G[G.min(1) != G.max(1)])
+    off = synth.pop_offsets([q[1] for q in pops])
+    mi = np.sort(rng.choice(G.shape[0], size=44, replace=False))
+    ui = np.setdiff1d(np.arange(G.shape[0]), mi)
+    assert len(ui) > 29_000
+    gm, gu = np.ascontiguousarray(G[mi]), np.ascontiguousarray(G[ui])
+    z1 = rng.standard_normal(len(mi)) * 2.0
+    w = np.array([0.4, 0.35, 0.3]) if mode else None
+    got = hotpath.impute_window(mode, gm, gu, off, w, z1, ctx=ctx)
+    want = oracle.run_impute(mode, gm, gu, off, w, z1)
+    assert got["status"] == 0 and got["z"].shape == (len(ui),)
+    assert np.max(np.abs(got["z"] - want["z"]) / np.maximum(1.0, np.abs(want["z"]))) <= 1e-8
+    assert relerr(got["info"], want["info"]) <= 1e-8
