@@ -720,3 +720,33 @@ def test_window_with_thirty_thousand_unmeasured_snps(ctx, mode):
     assert got["status"] == 0 and got["z"].shape == (len(ui),)
     assert np.max(np.abs(got["z"] - want["z"]) / np.maximum(1.0, np.abs(want["z"]))) <= 1e-8
     assert relerr(got["info"], want["info"]) <= 1e-8
+
+
+@pytest.mark.gpu
+def test_sixty_four_populations_and_one_too_many(ctx):
+    """The population table's limit: 64 populations (sizes 2 ... 60, weighted and pooled) against the oracle, 65 refused."""
+    from gauss_amd import synth
+    rng = np.random.default_rng(64)
+    pops = [(f"P{k:02d}", int(rng.integers(2, 61)), "EUR") for k in range(64)]
+    bp = np.sort(rng.choice(np.arange(1, 500_000), size=260, replace=False))
+    G, _ = synth.synth_genotypes(bp, pops, seed=3)
+    G = np.ascontiguousarray(G[G.min(1) != G.max(1)])
+    off = synth.pop_offsets([q[1] for q in pops])
+    w = rng.uniform(0.0, 0.03, size=64)
+    gm, gu = np.ascontiguousarray(G[:120]), np.ascontiguousarray(G[120:240])
+    z1 = rng.standard_normal(120)
+    for mode, ww in ((1, w), (0, None)):
+        got = hotpath.impute_window(mode, gm, gu, off, ww, z1, want_mats=True, ctx=ctx)
+        want = oracle.run_impute(mode, gm, gu, off, ww, z1, want_mats=True)
+        nan = np.isnan(want["b21"])
+        assert np.array_equal(np.isnan(got["b21"]), nan)
+        assert np.max(np.abs(got["b21"][~nan] - want["b21"][~nan]), initial=0.0) <= 1e-12
+        ok = ~np.isnan(want["z"])
+        assert np.array_equal(np.isnan(got["z"]), ~ok)
+        assert np.max(np.abs(got["z"][ok] - want["z"][ok]) / np.maximum(1.0, np.abs(want["z"][ok])), initial=0.0) <= 1e-8
+    pops65 = pops + [("P64", 10, "EUR")]
+    off65 = synth.pop_offsets([q[1] for q in pops65])
+    G65 = np.ascontiguousarray(np.hstack([G, G[:, :10]]))
+    from gauss_amd import _lib
+    with pytest.raises(_lib.GaussHipError, match="n_pop must be in 1..64"):
+        hotpath.impute_window(0, G65[:120], G65[120:240], off65, None, z1, ctx=ctx)
