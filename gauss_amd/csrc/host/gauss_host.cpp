@@ -377,7 +377,10 @@ static void set_pop_wgt_map(Args& a, const char* const* names, const double* w, 
 // (gauss.cpp:146-152).  Rows are in file order and carry the reference's parsing-state semantics: a field that
 // fails to parse keeps the value of the previous line (the variables live outside the loop there too).
 struct GwasRow { std::string rsid, a1, a2; int chr; long long bp; double z; };
-struct GwasCache { std::vector<GwasRow> rows; };
+struct GwasCache {
+    std::vector<GwasRow> rows;
+    std::vector<uint32_t> by_pos;      // row numbers ordered by (chr, bp), file order among equals: a window takes its range by binary search
+};
 
 static std::shared_ptr<const GwasCache> load_gwas_cached(const std::string& path, std::string& err)
 {
@@ -402,6 +405,12 @@ static std::shared_ptr<const GwasCache> load_gwas_cached(const std::string& path
         if (t.str(rsid) && t.i32(chr) && t.i64(bp) && t.str(a1) && t.str(a2)) t.dbl(z);
         c->rows.push_back(GwasRow{rsid, a1, a2, chr, bp, z});
     }
+    c->by_pos.resize(c->rows.size());
+    for (size_t i = 0; i < c->rows.size(); i++) c->by_pos[i] = (uint32_t)i;
+    std::stable_sort(c->by_pos.begin(), c->by_pos.end(), [&](uint32_t x, uint32_t y) {
+        const GwasRow &a = c->rows[x], &b = c->rows[y];
+        return a.chr < b.chr || (a.chr == b.chr && a.bp < b.bp);
+    });
     if (cache.size() >= 8) cache.clear();          // a handful of studies per process at most
     cache[k] = c;
     return c;
@@ -413,7 +422,18 @@ static int ReadInputZ(SnpMap& m, const Args& a, bool All)
     std::string err;
     std::shared_ptr<const GwasCache> gw = load_gwas_cached(a.input_file, err);
     if (!gw) return herr("%s", err.c_str());
-    for (const GwasRow& r : gw->rows) {
+    // A window of one chromosome: its rows are a range of the (chr, bp)-ordered index (the reference scans the whole file for every
+    // window, gauss.cpp:133-140).  Rows of one position keep their file order, so a key listed twice ends with its later row either way.
+    size_t q0 = 0, q1 = gw->rows.size();
+    const bool ranged = !All && a.chr > 0;
+    if (ranged) {
+        const long long lo = a.start_bp - a.wing_size, hi = a.end_bp + a.wing_size;
+        auto before = [&](uint32_t x, long long bp) { const GwasRow& r = gw->rows[x]; return r.chr < a.chr || (r.chr == a.chr && r.bp < bp); };
+        q0 = (size_t)(std::lower_bound(gw->by_pos.begin(), gw->by_pos.end(), lo, before) - gw->by_pos.begin());
+        q1 = (size_t)(std::lower_bound(gw->by_pos.begin(), gw->by_pos.end(), hi + 1, before) - gw->by_pos.begin());
+    }
+    for (size_t q = q0; q < q1; q++) {
+        const GwasRow& r = gw->rows[ranged ? gw->by_pos[q] : q];
         if (!All) {
             if ((a.chr > 0) && (a.chr != r.chr)) continue;
             if ((a.start_bp - a.wing_size) > r.bp || (a.end_bp + a.wing_size) < r.bp) continue;
@@ -585,6 +605,36 @@ static int ReadReferenceIndex(SnpMap& m, const Args& a, bool All)
                     if (s.chr != cb.first || s.bp != cb.second) break;
                     if (merge_index_entry(m, a, All, pk.str(s.rsid), s.chr, s.bp, pk.str(s.a1), pk.str(s.a2), i)) return -1;
                 }
+            return 0;
+        }
+        if (!All && a.chr > 0 && pk.header().sorted) {
+            // One window of a sorted panel: the panel's SNPs and the map ascend together, so the map position of each panel SNP is
+            // found by walking an iterator forward instead of descending the tree for every one of the ~3 000 (`at` = first map entry
+            // at or after the SNP's position).  A position the map holds nothing at -- the rule: an unmeasured SNP -- is entered (or,
+            // in a wing of a dist / distmix window, left out) on the spot; a position that holds something, or one the previous panel
+            // SNP shared (multi-allelic sites: its entry was put in FRONT of `at`), goes through merge_index_entry and `at` is found anew.
+            auto key_before = [](const MapKey& k, int chr, long long bp) { return k.chr < chr || (k.chr == chr && k.bp < bp); };
+            auto at = m.end();
+            bool have_at = false;
+            int pchr = -1;
+            long long pbp = -1;
+            for (int64_t i = i0; i < i1; i++) {
+                const PkSnp& s = pk.snp(i);
+                if ((a.start_bp - a.wing_size) > s.bp || (a.end_bp + a.wing_size) < s.bp || s.chr != a.chr) continue;      // (merge_index_entry's own filter)
+                const bool same_site = (s.chr == pchr && s.bp == pbp);
+                pchr = s.chr; pbp = s.bp;
+                if (!have_at || same_site) { at = m.lower_bound(MapKey{s.chr, s.bp, std::string(), std::string()}); have_at = true; }
+                else while (at != m.end() && key_before(at->first, s.chr, s.bp)) ++at;
+                if (at == m.end() || at->first.chr != s.chr || at->first.bp != s.bp) {
+                    if (a.drop_wing_unmeasured && (s.bp < a.start_bp || s.bp > a.end_bp)) continue;
+                    SnpPtr sp = m.make();                      // gauss.cpp:373-385
+                    sp->rsid = pk.str(s.rsid); sp->chr = s.chr; sp->bp = s.bp; sp->a1 = pk.str(s.a1); sp->a2 = pk.str(s.a2); sp->type = 0; sp->fpos = i;
+                    m.emplace_hint(at, MapKey{s.chr, s.bp, sp->a1, sp->a2}, std::move(sp));
+                    continue;
+                }
+                if (merge_index_entry(m, a, All, pk.str(s.rsid), s.chr, s.bp, pk.str(s.a1), pk.str(s.a2), i)) return -1;
+                have_at = false;                               // (an entry of this position may have been erased and entered again)
+            }
             return 0;
         }
         for (int64_t i = i0; i < i1; i++) {
@@ -2542,6 +2592,14 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
     std::shared_ptr<PackedPanel> pk = open_packed_shared(reference_data_file, err);
     if (!pk) return herr("%s", err.c_str());
     const double t_opened = now_s();
+    // First use of the panel: its rows start travelling NOW, before the study file is even parsed (2 ms for a chromosome's study) --
+    // the upload below then finds the store under way.  (Only the default, background form; an error shows up at that later call.)
+    void* dev_probe0 = nullptr;
+    const bool first_use = !panel_is_resident(ctx, reference_data_file, &dev_probe0);
+    int64_t early_uploaded = 0;
+    if (first_use && !getenv("GAUSS_CHROM_ASYNC_UPLOAD") && !getenv("GAUSS_CHROM_PIECEWISE_UPLOAD") && env_flag("GAUSS_CHROM_EARLY_UPLOAD", true)) {
+        if (panel_make_resident(ctx, reference_data_file, &dev_probe0, &early_uploaded, true, false) != 0) early_uploaded = 0;
+    }
     std::shared_ptr<const GwasCache> gw = load_gwas_cached(input_file, err);
     if (!gw) return herr("%s", err.c_str());
     const double t_study = now_s();
@@ -2647,8 +2705,6 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
     // First use of the panel on this context: its rows travel to HBM while the batches compute (below), in panel order, and a
     // batch starts when the rows it names have landed -- so the early batches are smaller then (six batches, the first three
     // 0.3 / 0.5 / 0.8 of a share): the GPU starts on the first fifth of the rows and stays busy behind the upload.
-    void* dev_probe0 = nullptr;
-    const bool first_use = !panel_is_resident(ctx, reference_data_file, &dev_probe0);
     const bool auto_batches = n_batches < 1;
     if (n_batches < 1) n_batches = mine.size() >= 16 ? (first_use && env_flag("GAUSS_CHROM_COLD_BATCHES", true) ? 6 : 4) : (mine.size() >= 9 ? 3 : (mine.size() >= 4 ? 2 : 1));
     n_batches = std::max(1, std::min<int>(n_batches, std::max<size_t>(mine.size(), 1)));
@@ -2769,7 +2825,8 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
         if (piece_mode == 2 && n_batches < 3) piece_mode = 0;
         const bool reserve_only = piece_mode != 0;
         const double tu = now_s();
-        if (!mine.empty() && panel_make_resident(ctx, reference_data_file, &d_rows, &st.panel_bytes_uploaded, async_upload, reserve_only)) rc_upload = -1;
+        if ((!mine.empty() || early_uploaded > 0) && panel_make_resident(ctx, reference_data_file, &d_rows, &st.panel_bytes_uploaded, async_upload, reserve_only)) rc_upload = -1;
+        st.panel_bytes_uploaded += early_uploaded;             // (started before the study file was parsed, above)
         if (!rc_upload && reserve_only && panel_entry(ctx, reference_data_file, piecewise) && !piecewise.filled) piecewise = ResidentPanel();
         st.t_panel_upload = now_s() - tu;
     }
