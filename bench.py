@@ -71,6 +71,7 @@ def parse_args(argv=None):
     ap.add_argument("--text-snps", type=int, default=20_000, help="end_to_end.from_text: SNPs of the text panel")
     ap.add_argument("--no-tails-alone", action="store_true", help="skip the one-stream pass that times the fp64 tails and the HBM-bound kernels stand-alone (probes)")
     ap.add_argument("--no-e2e", action="store_true", help="N = 1: skip the end_to_end block (files on disk -> result table)")
+    ap.add_argument("--no-other-configs", action="store_true", help="N = 1: skip the other_configs block (configs[1], [2], [4] at <= 5 timed steps each)")
     ap.add_argument("--emulate-world", type=int, default=-1,
                     help="single GPU: time every rank's share of an N-rank strong-scaling run one after the other "
                          "(what one rank of N would do per step); printed as `emulated_strong_scaling`, never as `value`.  "
@@ -352,8 +353,9 @@ def parity_spot(ch, wins, spot, res, mode):
                     "window, a spread of its unmeasured ones); |dz| / max(1, |z|) and |dinfo| / info"}
 
 
-def run_impute(args, rig):
-    """--mode distmix / dist: the headline."""
+def run_impute(args, rig, quiet=False, light=False):
+    """--mode distmix / dist: the headline.  quiet: return the line instead of printing it; light: a smaller CPU-baseline sample
+    without the all-cores pass (the `other_configs` leg of the default line, which has seconds, not half a minute)."""
     from gauss_amd import workload
     torch = rig.torch
     strong = args.scaling == "strong"
@@ -369,10 +371,11 @@ def run_impute(args, rig):
     store, ld2 = pack_store(rig, ch, panel, ld)
     keep0 = None
     if rig.rank == 0 and not args.no_cpu_baseline and rig.world == 1:
-        k0 = next((k for k, w in enumerate(wins) if len(w[1]) >= 600 and len(w[2]) >= 600), 0)
+        n0 = 250 if light else 600
+        k0 = next((k for k, w in enumerate(wins) if len(w[1]) >= n0 and len(w[2]) >= n0), 0)
         _, mi, ui = wins[k0]                                  # this window also feeds the CPU baseline sample
-        keep0 = (k0, panel.index_select(0, torch.from_numpy(mi[:600]).cuda()).cpu().numpy(),
-                 panel.index_select(0, torch.from_numpy(ui[:600]).cuda()).cpu().numpy())
+        keep0 = (k0, panel.index_select(0, torch.from_numpy(mi[:n0]).cuda()).cpu().numpy(),
+                 panel.index_select(0, torch.from_numpy(ui[:n0]).cuda()).cpu().numpy())
     spot = None
     if rig.rank == 0 and rig.world == 1 and not args.no_parity_spot and wins:
         spot = spot_inputs(torch, panel, wins)
@@ -389,6 +392,9 @@ def run_impute(args, rig):
     work, stats = runner.work, runner.stats
 
     dt, st, res = runner.timed(args.steps, args.warmup, events_in_region=rig.world == 1)
+    # how the library queued the timed runs (gauss_hip_counters): merged = ONE Gram launch with the chain beside it; demoted = two
+    # launches because the context shared its device with another one; giveups = merged runs repaired inside their fetch
+    launch_form = rig.ctx.counters()
     res = runner.results_in_order(res) if runner.jobs else []
     gram_ms, gram_n = st["gram"]
     tmax = rig.reduce(dt, "max")
@@ -437,16 +443,7 @@ def run_impute(args, rig):
         else:
             os.environ["GAUSS_SIDE_STREAM"] = old_env
         rig.ctx.set_gram_dtype(args.gram_dtype)
-        # the Gram kernel in the headline run's two-launch form if that run used it (the split is decided when a job is built):
-        # a rocprofv3 profile of this command then holds one kind of gram_kernel launch
-        old_split = os.environ.get("GAUSS_GRAM_SPLIT")
-        if gram_n > args.steps:
-            os.environ["GAUSS_GRAM_SPLIT"] = "1"
         r1 = Runner(rig, window_descs(ch, my_wins, store, ld2, args.mode, rows_of), 1)
-        if old_split is None:
-            os.environ.pop("GAUSS_GRAM_SPLIT", None)
-        else:
-            os.environ["GAUSS_GRAM_SPLIT"] = old_split
         n1 = max(3, min(10, args.steps))
         dt1, st1, _ = r1.timed(n1, 2)
         tails_alone = {"steps": n1, "ms_per_step": dt1 / n1 * 1e3, "stage_ms_per_step": {k: v[0] / n1 for k, v in st1.items()}}
@@ -532,6 +529,10 @@ def run_impute(args, rig):
             "n_gpus": rig.world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": tmax / args.steps * 1e3,
             "ms_longest_step": runner.longest_step_ms,        # completion to completion of consecutive steps in the timed region (this rank)
+            # exact check values of the timed job's z / info (sums of the raw bit patterns, summed over the ranks): two builds that
+            # return the same bits for the same seeded panel print the same pair
+            "launch_form": launch_form,
+            "result_digest": [sum(d["digest"][0] for d in digests) % (1 << 61), sum(d["digest"][1] for d in digests) % (1 << 61)],
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32" if args.gram_dtype == "f32" else "i8",
             "dtype_detail": ("LD GEMM on the %s matrix cores with exact integer partial sums; correlation tails, Cholesky and "
@@ -642,8 +643,11 @@ def run_impute(args, rig):
         if spot is not None and res:
             out["parity_spot"] = parity_spot(ch, wins, spot, res, 0 if args.mode == "dist" else 1)
         if keep0 is not None:
-            out["cpu_baseline"] = cpu_baseline(ch, wins, keep0, work, 0 if args.mode == "dist" else 1)
-        print(json.dumps(out), flush=True)
+            out["cpu_baseline"] = cpu_baseline(ch, wins, keep0, work, 0 if args.mode == "dist" else 1, light=light)
+        if e2e is not None and "_other_configs" in e2e:
+            out["other_configs"] = e2e.pop("_other_configs")
+        if not quiet:
+            print(json.dumps(out), flush=True)
     runner.close()
     return out
 
@@ -750,7 +754,7 @@ def usable_cores():
     return max(1, n)
 
 
-def cpu_baseline(ch, wins, keep0, work, mode=1):
+def cpu_baseline(ch, wins, keep0, work, mode=1, light=False):
     """The loop-literal CPU oracle (1 thread, like the reference) on a bounded sample, scaled to the workload in two
     parts.  (1) The pair loops: the reference's cost is N inner iterations per SNP pair (util.cpp:103-124),
     M(M+1)/2 + U + U*M pairs per window (distmix.cpp:180-217) -- the sample run's time, less its own dense tail, scaled
@@ -780,7 +784,7 @@ def cpu_baseline(ch, wins, keep0, work, mode=1):
         return time.perf_counter() - t1
 
     ms_all = np.array([len(a) for _, a, _ in wins], dtype=np.float64)
-    sizes = sorted({int(m), int(round(ms_all.mean())), int(ms_all.max())})
+    sizes = sorted({int(m)} if light else {int(m), int(round(ms_all.mean())), int(ms_all.max())})
     tails = {s: dense_tail_s(s) for s in sizes}
     c3 = float(np.mean([tails[s] / s ** 3 for s in sizes]))
     tail_total = float(c3 * np.sum(ms_all ** 3))
@@ -794,6 +798,11 @@ def cpu_baseline(ch, wins, keep0, work, mode=1):
     # one process per window on every core the host gives us ("a windows-in-parallel run on all cores"): as
     # many concurrent copies as there are windows to hand out, at most one per usable core
     par = max(1, min(usable_cores(), len(wins)))
+    if light:
+        return {"value": work["imputed_snps"] / est, "unit": "imputed SNPs/s", "cores": 1, "kind": "port", "host_cores": os.cpu_count(),
+                "sample": f"oracle run_{'distmix' if mode else 'dist'} on a sub-window of window {k0} (M={m}, U={u}, N={N}): {t:.2f} s for "
+                          f"{pairs_sample:.0f} SNP pairs, pair loops scaled by the workload's {pairs_total:.3g} pairs, dense tail c M^3 from "
+                          f"M = {m}: estimated {est:.0f} s per chromosome (bounded sample of the other_configs leg)"}
     t0 = time.perf_counter()
     with ThreadPoolExecutor(max_workers=par) as pool:
         list(pool.map(lambda _: oracle.run_impute(mode, gm_h, gu_h, ch["off"], ch["w"], z1), range(par)))
@@ -817,11 +826,12 @@ def cpu_baseline(ch, wins, keep0, work, mode=1):
 
 def cpu_baseline_computeld(sample):
     """computeLD's pair loops (computeLD.cpp:95-116) in the CPU oracle on a bounded sample of the window's rows,
-    scaled by the pair count M (M + 1) / 2 + M to the whole window: LD matrices per second on one core."""
+    scaled by the pair count M (M + 1) / 2 + M to the whole window: LD matrices per second on one core.  The sample's LD matrix is
+    left in sample["oracle_ld"] (the parity spot of the other_configs leg compares the GPU's entries with it)."""
     import oracle
     g = np.ascontiguousarray(sample["geno"])
     t0 = time.perf_counter()
-    oracle.compute_ld(g, sample["off"], sample["w"])
+    sample["oracle_ld"] = oracle.compute_ld(g, sample["off"], sample["w"])
     t = time.perf_counter() - t0
     m, M = g.shape[0], sample["M"]
     est = t * (M * (M + 1) / 2 + M) / (m * (m + 1) / 2 + m)

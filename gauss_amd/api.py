@@ -47,7 +47,7 @@ HOST_SYMBOLS = [
 class ChromStats(C.Structure):
     """gauss_chrom_stats (include/gauss_host.h)"""
     _fields_ = [("n_windows", C.c_int32), ("n_windows_mine", C.c_int32), ("n_skipped", C.c_int32), ("n_failed", C.c_int32),
-                ("n_batches", C.c_int32), ("pad_", C.c_int32), ("imputed", C.c_int64), ("panel_bytes_uploaded", C.c_int64),
+                ("n_batches", C.c_int32), ("n_merged_giveups", C.c_int32), ("imputed", C.c_int64), ("panel_bytes_uploaded", C.c_int64),
                 ("t_total", C.c_double), ("t_plan", C.c_double), ("t_panel_upload", C.c_double), ("t_feeder_wait", C.c_double),
                 ("t_job_create", C.c_double), ("t_gpu_wait", C.c_double), ("t_tables", C.c_double), ("gpu_span_ms", C.c_double)]
 
@@ -495,7 +495,7 @@ def impute_chromosome(kind, chr, start_bp, end_bp, wing_size, input_file, refere
     windows = _named(h, out)["windows"]
     msgs = [h.gauss_table_message(out, k).decode() for k in range(h.gauss_table_n_messages(out))]
     h.gauss_table_free(out)
-    stats = {k: getattr(st, k) for k, _ in ChromStats._fields_ if k != "pad_"}
+    stats = {k: getattr(st, k) for k, _ in ChromStats._fields_}
     return ChromResult(cols, windows, stats, msgs)
 
 

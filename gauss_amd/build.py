@@ -16,7 +16,12 @@ ARCH = "gfx950"
 
 # translation unit -> extra flags
 HIP_UNITS = {
-    "gauss_hip.cpp": [],                         # host only: planner, jobs, C ABI
+    # host only: contexts + queue registry, planner, runs, row stores, C ABI
+    "gauss_ctx.cpp": [],
+    "gauss_plan.cpp": [],
+    "gauss_run.cpp": [],
+    "gauss_store.cpp": [],
+    "gauss_abi.cpp": [],
     "k_gram.hip": [],
     "k_pack_epilogue.hip": ["-ffp-contract=off"],   # reference-order fp64 tails: no fused multiply-add
     "k_solve.hip": [],
@@ -113,7 +118,7 @@ def build_hip(force=False, verbose=False):
     import json
     os.makedirs(OBJDIR, exist_ok=True)
     hipcc = _hipcc()
-    hdrs = [os.path.join(CSRC, "gauss_internal.h"), os.path.join(CSRC, "k_gram_common.h"), os.path.join(CSRC, "k_solve_common.h"), os.path.join(HERE, "..", "include", "gauss_hip.h")]
+    hdrs = [os.path.join(CSRC, "gauss_internal.h"), os.path.join(CSRC, "gauss_job.h"), os.path.join(CSRC, "k_gram_common.h"), os.path.join(CSRC, "k_solve_common.h"), os.path.join(HERE, "..", "include", "gauss_hip.h")]
     # an object is rebuilt when its recorded identity (source + headers + command line + compiler) differs -- not by mtime: a
     # flag change or a checkout that restores old timestamps must not link stale objects under a fresh source hash
     ids_path = os.path.join(OBJDIR, "unit_ids.json")

@@ -139,9 +139,9 @@ struct Item {
     int k0;                  // first column of the run
     int nseg;                // segments in the run
     int rows_a, rows_b;      // live rows of the two tiles (the rest is zero padding)
-    int flags;               // bit 0: ti == tj (diagonal tile); bit 1: slabs are uint16 pairs (Prob::slab16); bit 3: no 16-column
-                             // edge routine (GAUSS_GRAM_EDGE16=0: every live 32-column half takes the 32 x 32 MFMA); bit 4: a B11
-                             // item of a merged launch: counts itself off in the launch's `b11_done` (k_gram.hip)
+    int flags;               // bit 0: ti == tj (diagonal tile); bit 1: slabs are uint16 pairs (Prob::slab16); bit 4: a B11 item of a
+                             // job built for a merged launch: counts itself off in the launch's `b11_done[0]` when one is passed
+                             // (k_gram.hip); bit 5: a B21 item of an "early" window, counted in `b11_done[8]`
 };
 static_assert(sizeof(Item) == 64, "work items are fetched as one 64-byte descriptor");
 

@@ -54,6 +54,13 @@ using gauss_host::PkSnp;
 // ------------------------------------------------------------------------------------------
 static thread_local std::string g_err;
 
+// Diagnostics on stderr: GAUSS_TRACE=chrom,prep (any subset, or "all"; libgauss_hip reads job, upload, stream from the same variable)
+static bool host_trace(const char* what)
+{
+    const char* e = getenv("GAUSS_TRACE");
+    return e && *e && (strstr(e, "all") != nullptr || strstr(e, what) != nullptr);
+}
+
 static int herr(const char* fmt, ...)
 {
     char buf[1024];
@@ -992,8 +999,8 @@ static int auto_pack_mode()
     return e ? (atoi(e) != 0 ? 1 : 0) : -1;
 }
 
-static int panel_make_resident(gauss_ctx* ctx, const std::string& path, void** dev, int64_t* uploaded, bool async = false, bool reserve_only = false);
-static bool panel_is_resident(gauss_ctx* ctx, const std::string& path, void** dev);
+static int panel_make_resident(gauss_ctx* ctx, const std::string& path, void** dev, int64_t* uploaded, bool async = false);
+static bool panel_is_resident(gauss_ctx* ctx, const std::string& path, void** dev, bool wait = true);
 
 // ------------------------------------------------------------------------------------------
 // prepared window / gene set
@@ -1105,7 +1112,7 @@ static int prepare(gauss_prepared& p)
     const bool gene = (kind == GAUSS_KIND_JEPEG || kind == GAUSS_KIND_JEPEGMIX);
     const bool qcat = (kind == GAUSS_KIND_QCAT || kind == GAUSS_KIND_QCATMIX);
     const bool prep = (kind == GAUSS_KIND_PREP_QCAT || kind == GAUSS_KIND_PREP_RECESSIVE);
-    static const bool trace = getenv("GAUSS_PREP_TRACE") != nullptr;
+    static const bool trace = host_trace("prep");
     auto tnow = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double tt[8] = {0};
     tt[0] = tnow();
@@ -1637,7 +1644,7 @@ int gauss_host_prepare(int kind, int chr, int64_t start_bp, int64_t end_bp, int6
         std::string err;
         a.pk = open_packed_shared(a.reference_data_file, err);
         if (!a.pk) return herr("%s", err.c_str());
-        a.drop_wing_unmeasured = (kind == GAUSS_KIND_DIST || kind == GAUSS_KIND_DISTMIX) && !getenv("GAUSS_KEEP_WING_SNPS");
+        a.drop_wing_unmeasured = (kind == GAUSS_KIND_DIST || kind == GAUSS_KIND_DISTMIX);
     }
     a.af1_cutoff = std::isnan(af1_cutoff) ? (kind == GAUSS_KIND_QCAT ? 0.05 : 0.01) : af1_cutoff;   // dist.cpp:53-57, qcat.cpp:53-57
     const bool mix = (kind == GAUSS_KIND_COMPUTELD || kind == GAUSS_KIND_DISTMIX || kind == GAUSS_KIND_JEPEGMIX ||
@@ -2304,9 +2311,6 @@ struct ResidentPanel {
     std::shared_ptr<PackedPanel> pk;       // keeps the mapping (and so the file identity) alive
     void* dev = nullptr;
     int64_t bytes = 0;
-    // a store that is filled piece by piece (the chromosome driver's first call on a panel): rows [0, filled) have landed
-    std::shared_ptr<std::mutex> fill_mu;
-    std::shared_ptr<int64_t> filled;
 };
 // Keyed by the context's id, not its address: ids are never reused, so a context created at the address of a destroyed
 // one cannot inherit a stale entry (whose device pointer may even belong to another GPU).  The destroy hook drops a
@@ -2332,70 +2336,30 @@ static std::string file_key(const std::string& path)
     return path + key;
 }
 
-// Rows [0, upto) of a piecewise store are brought up (whole 32 MB pieces, in order); *uploaded += bytes moved now.
-static int panel_fill_to(gauss_ctx* ctx, const ResidentPanel& rp, int64_t upto, int64_t* uploaded)
-{
-    if (!rp.filled) return 0;                                       // uploaded in one go
-    const int64_t piece = (int64_t)32 << 20;
-    upto = std::min(rp.bytes, upto <= 0 ? rp.bytes : (upto + piece - 1) / piece * piece);
-    std::lock_guard<std::mutex> lock(*rp.fill_mu);
-    if (*rp.filled >= upto) return 0;
-    // (from the FILE, not from the mapping: no page faults on the process's address space beside the data layer's threads)
-    if (gauss_store_fill_fd(ctx, rp.dev, rp.pk->fd(), rp.pk->geno_file_offset(), *rp.filled, upto - *rp.filled) != 0) return herr("%s", gauss_last_error());
-    if (uploaded) *uploaded += upto - *rp.filled;
-    *rp.filled = upto;
-    return 0;
-}
-
 // returns the device pointer of the panel's row 0 (uploading the section on first use); *uploaded = bytes moved now
-// async: the upload is only STARTED (gauss_store_upload_async); readers call gauss_store_wait for the rows they need
-// reserve_only: the store is only ALLOCATED; the caller brings the rows up piece by piece (panel_fill_to) ahead of the jobs
-// that read them.  Whoever asks for the panel later without reserve_only gets all of it.
-static int panel_make_resident(gauss_ctx* ctx, const std::string& path, void** dev, int64_t* uploaded, bool async, bool reserve_only)
+// async: the upload is only STARTED (gauss_store_upload_fd_async); whoever reads rows calls gauss_store_wait for the ones it
+// needs first (panel_ready for all of them) -- a cheap no-op once the upload has been retired
+static int panel_make_resident(gauss_ctx* ctx, const std::string& path, void** dev, int64_t* uploaded, bool async)
 {
     if (uploaded) *uploaded = 0;
     const std::pair<uint64_t, std::string> key(gauss_hip_context_id(ctx), file_key(path));
-    ResidentPanel found;
-    bool have = false;
-    {
-        std::lock_guard<std::mutex> lock(g_res_mu);
-        auto it = g_resident.find(key);
-        if (it != g_resident.end()) { found = it->second; have = true; }
-    }
-    if (have) {
-        *dev = found.dev;
-        return reserve_only ? 0 : panel_fill_to(ctx, found, 0, uploaded);
-    }
-    {
-        std::lock_guard<std::mutex> lock(g_res_mu);
-        auto it = g_resident.find(key);
-        if (it != g_resident.end()) {
-            // a racing first use: the other caller made the entry between the two looks.  Its MODE stands (whole / async /
-            // reserved), but this caller's NEED is its own: whoever asks without reserve_only gets every row (below)
-            found = it->second; have = true;
-        } else {
-            gauss_hip_add_destroy_hook(resident_ctx_destroyed, nullptr);
-            std::string err;
-            ResidentPanel rp;
-            rp.pk = open_packed_shared(path, err);
-            if (!rp.pk) return herr("%s", err.c_str());
-            rp.bytes = rp.pk->n_snp() * rp.pk->row_bytes();
-            if (rp.bytes <= 0) return herr("packed panel '%s' holds no SNPs", path.c_str());
-            if (reserve_only) {
-                if (gauss_store_alloc(ctx, rp.bytes, &rp.dev) != 0) return herr("%s", gauss_last_error());
-                rp.fill_mu = std::make_shared<std::mutex>();
-                rp.filled = std::make_shared<int64_t>(0);
-            } else if ((async ? gauss_store_upload_fd_async(ctx, rp.pk->fd(), rp.pk->geno_file_offset(), rp.bytes, &rp.dev)
-                              : gauss_store_upload_fd(ctx, rp.pk->fd(), rp.pk->geno_file_offset(), rp.bytes, &rp.dev)) != 0)
-                return herr("%s", gauss_last_error());
-            if (uploaded && !reserve_only) *uploaded = rp.bytes;
-            *dev = rp.dev;
-            g_resident[key] = rp;
-            return 0;
-        }
-    }
-    *dev = found.dev;
-    return reserve_only ? 0 : panel_fill_to(ctx, found, 0, uploaded);
+    std::lock_guard<std::mutex> lock(g_res_mu);
+    auto it = g_resident.find(key);
+    if (it != g_resident.end()) { *dev = it->second.dev; return 0; }
+    gauss_hip_add_destroy_hook(resident_ctx_destroyed, nullptr);
+    std::string err;
+    ResidentPanel rp;
+    rp.pk = open_packed_shared(path, err);
+    if (!rp.pk) return herr("%s", err.c_str());
+    rp.bytes = rp.pk->n_snp() * rp.pk->row_bytes();
+    if (rp.bytes <= 0) return herr("packed panel '%s' holds no SNPs", path.c_str());
+    if ((async ? gauss_store_upload_fd_async(ctx, rp.pk->fd(), rp.pk->geno_file_offset(), rp.bytes, &rp.dev)
+               : gauss_store_upload_fd(ctx, rp.pk->fd(), rp.pk->geno_file_offset(), rp.bytes, &rp.dev)) != 0)
+        return herr("%s", gauss_last_error());
+    if (uploaded) *uploaded = rp.bytes;
+    *dev = rp.dev;
+    g_resident[key] = rp;
+    return 0;
 }
 
 // the entry of a panel that is (being made) resident on this context
@@ -2409,13 +2373,19 @@ static bool panel_entry(gauss_ctx* ctx, const std::string& path, ResidentPanel& 
     return true;
 }
 
-static bool panel_is_resident(gauss_ctx* ctx, const std::string& path, void** dev)
+// Is the panel in HBM on this context?  `wait`: and have all its rows landed -- a background upload that another call (or
+// another thread of this one) started is waited for, so that whoever gets the pointer may read any row (a failed upload:
+// the entry is dropped and the answer is no).  The chromosome driver asks without waiting: its batches wait for the rows they
+// name, one by one.
+static bool panel_is_resident(gauss_ctx* ctx, const std::string& path, void** dev, bool wait)
 {
     ResidentPanel rp;
     if (!panel_entry(ctx, path, rp)) return false;
-    if (rp.filled) {                                  // a store that is still being filled piece by piece is not resident yet
-        std::lock_guard<std::mutex> lock(*rp.fill_mu);
-        if (*rp.filled < rp.bytes) return false;
+    if (wait && gauss_store_wait(ctx, rp.dev, 0) != 0) {
+        const std::string keep = gauss_last_error();
+        gauss_host_panel_evict(ctx, path.c_str());
+        herr("%s", keep.c_str());
+        return false;
     }
     *dev = rp.dev;
     return true;
@@ -2454,7 +2424,10 @@ int gauss_host_panel_resident(gauss_ctx* ctx, const char* packed_file, int64_t* 
     if (!ctx || !packed_file) return herr("bad arguments");
     if (!PackedPanel::is_packed(packed_file)) return herr("'%s' is not a packed panel", packed_file);
     void* dev = nullptr;
-    return panel_make_resident(ctx, packed_file, &dev, bytes_uploaded);
+    if (panel_make_resident(ctx, packed_file, &dev, bytes_uploaded) != 0) return -1;
+    // (an upload that another call started in the background: resident means every row has landed)
+    if (gauss_store_wait(ctx, dev, 0) != 0) return herr("%s", gauss_last_error());
+    return 0;
 }
 
 int gauss_host_panel_device_rows(gauss_ctx* ctx, const char* packed_file, const void** out_device_ptr)
@@ -2584,8 +2557,11 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
         return herr("gauss_host_impute_chromosome: kind must be dist, distmix, qcat or qcatmix");
     if (window_size < 1 || end_bp < start_bp || world < 1 || rank < 0 || rank >= world) return herr("bad window / rank arguments");
     const double t_begin = now_s() - t_autopack;
+    const bool chrom_trace = host_trace("chrom");
     gauss_chrom_stats st;
     memset(&st, 0, sizeof(st));
+    int64_t counters0[4] = {0, 0, 0, 0};
+    (void)gauss_hip_counters(ctx, counters0);
 
     // ---- plan: windows, costs, owners (identical on every rank) ----
     std::string err;
@@ -2595,11 +2571,26 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
     // First use of the panel: its rows start travelling NOW, before the study file is even parsed (2 ms for a chromosome's study) --
     // the upload below then finds the store under way.  (Only the default, background form; an error shows up at that later call.)
     void* dev_probe0 = nullptr;
-    const bool first_use = !panel_is_resident(ctx, reference_data_file, &dev_probe0);
+    const bool first_use = !panel_is_resident(ctx, reference_data_file, &dev_probe0, false);
+    const bool async_upload = env_flag("GAUSS_CHROM_ASYNC_UPLOAD", true);      // =0: in one go before the first batch
     int64_t early_uploaded = 0;
-    if (first_use && !getenv("GAUSS_CHROM_ASYNC_UPLOAD") && !getenv("GAUSS_CHROM_PIECEWISE_UPLOAD") && env_flag("GAUSS_CHROM_EARLY_UPLOAD", true)) {
-        if (panel_make_resident(ctx, reference_data_file, &dev_probe0, &early_uploaded, true, false) != 0) early_uploaded = 0;
-    }
+    if (first_use && async_upload && panel_make_resident(ctx, reference_data_file, &dev_probe0, &early_uploaded, true) != 0) early_uploaded = 0;
+    // Whatever way this call ends, nobody may find the panel "resident" while rows are still on their way: every exit that does
+    // not reach the wait at the end of the call (a study file that cannot be read, bad arguments to the planner, a failed batch)
+    // waits for the background upload here -- or, if that failed, drops the half-made store.
+    struct UploadGuard {
+        gauss_ctx* ctx; const char* path; void* dev = nullptr; bool settled = false;
+        ~UploadGuard()
+        {
+            if (!dev || settled) return;
+            if (gauss_store_wait(ctx, dev, 0) != 0) {
+                const std::string keep = gauss_host_last_error();
+                gauss_host_panel_evict(ctx, path);
+                herr("%s", keep.c_str());
+            }
+        }
+    } upload_guard{ctx, reference_data_file};
+    if (early_uploaded > 0) upload_guard.dev = dev_probe0;
     std::shared_ptr<const GwasCache> gw = load_gwas_cached(input_file, err);
     if (!gw) return herr("%s", err.c_str());
     const double t_study = now_s();
@@ -2706,7 +2697,7 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
     // batch starts when the rows it names have landed -- so the early batches are smaller then (six batches, the first three
     // 0.3 / 0.5 / 0.8 of a share): the GPU starts on the first fifth of the rows and stays busy behind the upload.
     const bool auto_batches = n_batches < 1;
-    if (n_batches < 1) n_batches = mine.size() >= 16 ? (first_use && env_flag("GAUSS_CHROM_COLD_BATCHES", true) ? 6 : 4) : (mine.size() >= 9 ? 3 : (mine.size() >= 4 ? 2 : 1));
+    if (n_batches < 1) n_batches = mine.size() >= 16 ? (first_use && async_upload ? 6 : 4) : (mine.size() >= 9 ? 3 : (mine.size() >= 4 ? 2 : 1));
     n_batches = std::max(1, std::min<int>(n_batches, std::max<size_t>(mine.size(), 1)));
     // contiguous batches by cost.  The first batch is the one nothing overlaps with on the way in (its data layer)
     // and the last one on the way out (its tables), so with four or more batches those two get 0.3 of a share.
@@ -2715,11 +2706,6 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
         std::vector<double> share((size_t)n_batches, 1.0);
         if (n_batches >= 4) { share.front() = 0.3; share.back() = 0.3; }    // measured: 0.5 / 0.5 46.3 ms, 0.3 / 0.3 45.3 ms per chromosome
         if (auto_batches && first_use && n_batches == 6) { share[1] = 0.5; share[2] = 0.8; }
-        if (const char* e = getenv("GAUSS_CHROM_SHARES")) {          // experiment: "0.2,1,1,0.5"
-            std::vector<double> v;
-            for (const char* q = e; *q;) { char* end = nullptr; const double x = strtod(q, &end); if (end == q) break; v.push_back(x); q = (*end == ',') ? end + 1 : end; }
-            if ((int)v.size() == n_batches) share = v;
-        }
         double ssum = 0;
         for (double v : share) ssum += v;
         double total = 0;
@@ -2734,7 +2720,7 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
     }
     st.n_batches = n_batches;
     st.t_plan = now_s() - t_begin;
-    if (getenv("GAUSS_CHROM_TRACE"))
+    if (chrom_trace)
         fprintf(stderr, "[chrom] plan %.2f ms: panel opened %.2f, study file %.2f, windows + owners + batches %.2f\n", st.t_plan * 1e3,
                 (t_opened - t_begin) * 1e3, (t_study - t_opened) * 1e3, (now_s() - t_study) * 1e3);
 
@@ -2755,11 +2741,9 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
         // with 8, 115-132 with 16; the data layer of a chromosome is 36 x 2 ms, well hidden either way)
         if (first_use) nthreads = std::min(nthreads, 4);
     }
-    if (const char* e = getenv("GAUSS_CHROM_THREADS")) nthreads = std::max(1, atoi(e));
     // the result tables are built after the upload has finished: they keep the full count (a first call built its tables on the
     // four threads meant for the time of the upload: 20 ms of tables instead of 11)
     int nthreads_tables = (int)std::max(1u, std::min(8u, (hw ? hw : 4u) / (unsigned)std::max(1, std::min(world, 8))));
-    if (const char* e = getenv("GAUSS_CHROM_THREADS")) nthreads_tables = std::max(1, atoi(e));
     // One pool over ALL windows in batch order (not one fork-join per batch: a batch of five windows would leave
     // eleven of sixteen threads idle); a batch is ready when its last window is.
     std::vector<std::pair<int, int>> order;                       // (batch, slot)
@@ -2790,76 +2774,28 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
             bool last;
             { std::lock_guard<std::mutex> lock(mu); last = (--left[b] == 0); }
             if (last) cv.notify_all();
-            if (last && getenv("GAUSS_CHROM_TRACE")) fprintf(stderr, "[chrom] data layer of batch %d done at %.2f ms\n", b, (now_s() - t_begin) * 1e3);
+            if (last && chrom_trace) fprintf(stderr, "[chrom] data layer of batch %d done at %.2f ms\n", b, (now_s() - t_begin) * 1e3);
         });
     });
 
     // ---- the panel's rows in HBM ----
-    // First use of this panel on this context: the upload is only STARTED here (gauss_store_upload_fd_async: staged through two
+    // First use of this panel on this context: the upload was only STARTED above (gauss_store_upload_fd_async: staged through two
     // pinned buffers, 846 MB of a chromosome in ~20 ms) and every batch waits for the rows it names (gauss_store_wait) -- the rows
     // travel in panel order, the batches follow the chromosome, so batch 0 starts when the first fifth of the rows has landed.
     // Measured on the chr22 panel as the bench's first call (round 4, tools/cold_trace.sh): in one go before the first batch
     // (GAUSS_CHROM_ASYNC_UPLOAD=0) 63-64 ms, beside the batches 46-55 ms against 40.5 warm.  That only pays since the data layer
     // no longer fights the upload for the host (windows' SNP maps in pooled blocks, above: cold data layer 44 -> 11 ms; rounds 2
-    // and 3 measured the asynchronous form slower, 105-155 ms, for that reason).
-    // Other forms, off by default (panels sorted by position): GAUSS_CHROM_PIECEWISE_UPLOAD=1 -- the store is only RESERVED here
-    // and this thread brings the rows up piece by piece, always one batch ahead of the GPU (the rows batch b + 1 will read, up to
-    // the panel row of its last window's end, travel while batch b computes; before a batch is queued its exact top row is checked
-    // against what has landed); =2 -- two pieces, the first batches' rows before batch 0.
+    // and 3 measured the asynchronous form slower, 105-155 ms, for that reason).  (Round 4 also measured the store reserved and
+    // filled piece by piece one batch ahead of the GPU, and in two pieces: 75-88 ms, never ahead of the other forms, and gone.)
     void* d_rows = nullptr;
-    int piece_mode = 0;
     const int64_t panel_row_bytes = pk->row_bytes();
-    ResidentPanel piecewise;                                       // .filled set: this call fills the store piece by piece
     {
-        const char* e = getenv("GAUSS_CHROM_ASYNC_UPLOAD");
-        const char* ep = getenv("GAUSS_CHROM_PIECEWISE_UPLOAD");
-        const bool async_upload = e ? atoi(e) != 0 : !(ep && atoi(ep) != 0);      // (asking for pieces means: not in the background)
-        // 0 (default): one upload (beside the batches, or before the first with GAUSS_CHROM_ASYNC_UPLOAD=0); 1: piece by piece, always one batch ahead; 2: TWO pieces -- the rows of
-        // the first batches (about half of the chromosome's work) before the first batch is queued, the rest while the GPU
-        // computes those batches.  Measured on the chr22 panel, first call of a fresh process (tools/cold_probe2.sh, round 4):
-        // one go 71-86 ms, two pieces 83-85, per batch 84-86 -- a FIRST piece of 503 MB takes 31-34 ms (15 GB/s) where the
-        // second one, beside the Gram kernel, takes 13-16 ms for 343 MB: whatever is staged first in a process is slow (cold page
-        // cache walk, cold allocator, the data layer's threads on the same sixteen cores), so splitting the upload only moves
-        // GPU work behind a slower first piece.
-        piece_mode = async_upload || !pk->header().sorted || chr <= 0 ? 0 : (ep ? atoi(ep) : 0);
-        if (piece_mode == 2 && n_batches < 3) piece_mode = 0;
-        const bool reserve_only = piece_mode != 0;
         const double tu = now_s();
-        if ((!mine.empty() || early_uploaded > 0) && panel_make_resident(ctx, reference_data_file, &d_rows, &st.panel_bytes_uploaded, async_upload, reserve_only)) rc_upload = -1;
+        if ((!mine.empty() || early_uploaded > 0) && panel_make_resident(ctx, reference_data_file, &d_rows, &st.panel_bytes_uploaded, async_upload)) rc_upload = -1;
         st.panel_bytes_uploaded += early_uploaded;             // (started before the study file was parsed, above)
-        if (!rc_upload && reserve_only && panel_entry(ctx, reference_data_file, piecewise) && !piecewise.filled) piecewise = ResidentPanel();
+        if (!rc_upload && d_rows) upload_guard.dev = d_rows;   // (made by this call or by another one that is still uploading)
         st.t_panel_upload = now_s() - tu;
     }
-    // rows [0, fill_est(b)) cover every SNP up to the end of batch b's last window (with its wing)
-    auto fill_est = [&](int b) -> int64_t {
-        int64_t e_bp = 0;
-        for (int k : batches[(size_t)b]) e_bp = std::max<int64_t>(e_bp, wins[(size_t)k].e + wing_size);
-        return pk->lower_bound(chr, e_bp + 1) * panel_row_bytes;
-    };
-    auto fill_to = [&](int64_t upto) -> int {
-        if (!piecewise.filled) return 0;
-        const double tu = now_s();
-        const int64_t before = st.panel_bytes_uploaded;
-        const int rc = panel_fill_to(ctx, piecewise, upto, &st.panel_bytes_uploaded);
-        st.t_panel_upload += now_s() - tu;
-        if (getenv("GAUSS_CHROM_TRACE"))
-            fprintf(stderr, "[chrom] fill to %lld: %.1f MB in %.2f ms (at %.2f ms)\n", (long long)upto, (st.panel_bytes_uploaded - before) / 1e6,
-                    (now_s() - tu) * 1e3, (now_s() - t_begin) * 1e3);
-        return rc;
-    };
-    // two pieces: the first one covers the batches that hold the first ~45 % of this rank's work
-    int piece_a_last = 0;
-    if (piece_mode == 2) {
-        double total = 0, acc = 0;
-        for (int i : mine) total += wins[(size_t)i].cost;
-        for (int b = 0; b < n_batches; b++) {
-            for (int k : batches[(size_t)b]) acc += wins[(size_t)k].cost;
-            piece_a_last = b;
-            if (acc >= 0.45 * total) break;
-        }
-        piece_a_last = std::min(piece_a_last, n_batches - 2);            // (something is left for the second piece)
-    }
-    if (!rc_upload && n_batches > 0 && fill_to(fill_est(piece_mode == 2 ? std::max(0, piece_a_last) : 0)) != 0) rc_upload = -1;
 
     // ---- GPU pipeline ----
     std::vector<gauss_job*> jobs((size_t)n_batches, nullptr);
@@ -2933,7 +2869,7 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
         const double t_fin = now_s();
         append_batch(b);
         st.t_tables += now_s() - tt;
-        if (getenv("GAUSS_CHROM_TRACE")) {
+        if (chrom_trace) {
             struct rusage ru1;
             getrusage(RUSAGE_SELF, &ru1);
             fprintf(stderr, "[chrom] retire batch %d: tables %.2f ms (finish %.2f, append %.2f), %ld minor faults, %d windows\n", b, (now_s() - tt) * 1e3,
@@ -2962,7 +2898,6 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
                 const double tu = now_s();
                 if (gauss_store_wait(ctx, d_rows, (top + 1) * panel_row_bytes) != 0) { herr("%s", gauss_last_error()); rc_fatal = -1; upload_failed = true; break; }
                 st.t_panel_upload += now_s() - tu;
-                if (fill_to((top + 1) * panel_row_bytes) != 0) { rc_fatal = -1; break; }      // (already there unless the estimate fell short)
             }
             double tc = now_s();
             double t_created = 0;
@@ -2981,11 +2916,8 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
                 }
             }
             st.t_job_create += now_s() - tc;
-            if (getenv("GAUSS_CHROM_TRACE")) fprintf(stderr, "[chrom] batch %d queued at %.2f ms (job create %.2f ms, run %.2f ms)\n", b, (now_s() - t_begin) * 1e3, (t_created - tc) * 1e3, (now_s() - t_created) * 1e3);
+            if (chrom_trace) fprintf(stderr, "[chrom] batch %d queued at %.2f ms (job create %.2f ms, run %.2f ms)\n", b, (now_s() - t_begin) * 1e3, (t_created - tc) * 1e3, (now_s() - t_created) * 1e3);
         }
-        // the next batch's rows travel while this one computes (two pieces: everything else, once the first piece's batches are queued)
-        if (piece_mode == 2) { if (b == piece_a_last && fill_to(0) != 0) { rc_fatal = -1; break; } }
-        else if (b + 1 < n_batches && fill_to(fill_est(b + 1)) != 0) { rc_fatal = -1; break; }
         if (b > 0) retire(b - 1);
     }
     if (!rc_fatal && n_batches > 0) retire(n_batches - 1);
@@ -2994,7 +2926,7 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
         gauss_job *jf = nullptr, *jl = nullptr;
         for (gauss_job* j : jobs) if (j) { if (!jf) jf = j; jl = j; }
         if (jf && gauss_job_span_ms(jf, jl, &st.gpu_span_ms) != 0) st.gpu_span_ms = 0.0;
-        if (jf && getenv("GAUSS_CHROM_TRACE"))
+        if (jf && chrom_trace)
             for (size_t b = 0; b < jobs.size(); b++) {
                 double to_end = 0, own = 0;
                 if (jobs[b] && gauss_job_span_ms(jf, jobs[b], &to_end) == 0 && gauss_job_span_ms(jobs[b], jobs[b], &own) == 0)
@@ -3005,7 +2937,7 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
     // whoever finds this panel resident later (another study, an LD call on rows this chromosome never touched) must
     // find all of it: the upload is complete before the call returns
     if (d_rows && !upload_failed && gauss_store_wait(ctx, d_rows, 0) != 0) { if (!rc_fatal) herr("%s", gauss_last_error()); rc_fatal = -1; upload_failed = true; }
-    if (!upload_failed && fill_to(0) != 0 && !rc_fatal) rc_fatal = -1;      // (rows past this chromosome's last window, if any)
+    upload_guard.settled = true;                                // waited for (or failed and evicted below)
     if (rc_fatal) {
         // tables of windows that retired before the failure
         for (auto& bs : slots) for (Slot& sl : bs) { delete sl.tab; sl.tab = nullptr; }
@@ -3047,6 +2979,10 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
     }
     st.t_tables += now_s() - tt;
     st.t_total = now_s() - t_begin;
+    {
+        int64_t c1[4] = {0, 0, 0, 0};
+        if (gauss_hip_counters(ctx, c1) == 0) st.n_merged_giveups = (int32_t)(c1[2] - counters0[2]);
+    }
     if (stats) *stats = st;
     *out = all.release();
     return 0;

@@ -364,7 +364,7 @@ __device__ __forceinline__ void gram_item(const Item& it, uint8_t* lds)
     const bool diag = (it.flags & 1) != 0;
     if (diag && wr == 1 && wc == 0) na = 0;
     // f32 path: a last half of at most 16 live B rows goes to the 16-column edge routine (GAUSS_GRAM_EDGE16 compiled in)
-    if (std::is_same<ACC, f32x16>::value && GAUSS_GRAM_EDGE16 && na > 0 && !(it.flags & 8)) {
+    if (std::is_same<ACC, f32x16>::value && GAUSS_GRAM_EDGE16 && na > 0) {
         int nb16 = (it.rows_b - wc * 64 + 15) / 16;
         nb16 = nb16 < 0 ? 0 : (nb16 > 4 ? 4 : nb16);
         if (nb16 & 1) {

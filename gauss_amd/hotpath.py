@@ -40,6 +40,13 @@ class Context:
         check(self.lib.gauss_hip_trim_cache(self.handle, C.byref(n)))
         return n.value
 
+    def counters(self):
+        """gauss_hip_counters: runs queued merged / demoted to two launches, merged runs that gave up (re-run inside the
+        fetch), re-runs that failed too."""
+        out = (C.c_int64 * 4)()
+        check(self.lib.gauss_hip_counters(self.handle, out))
+        return dict(merged=int(out[0]), demoted=int(out[1]), giveups=int(out[2]), rerun_failed=int(out[3]))
+
     def close(self):
         if self.handle:
             # jobs and row stores that are still alive are released here (gauss_hip.h, lifetime rule)

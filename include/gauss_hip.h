@@ -187,6 +187,17 @@ int gauss_hip_add_destroy_hook(void (*fn)(gauss_ctx* ctx, uint64_t id, void* use
  * before it reports GAUSS_E_NOMEM; gauss_hip_trim_cache gives the memory back at once (it waits for the context's
  * streams first), e.g. before another context or another library needs the device. */
 int gauss_hip_trim_cache(gauss_ctx* ctx, int64_t* out_bytes_freed);
+/* How the runs of this context's jobs were queued, since the context was made:
+ *   out4[0] runs queued in the merged form (ONE Gram launch whose B11 items count themselves off for a waiting kernel at the
+ *           head of the chain queue);
+ *   out4[1] runs of jobs built for that form that were queued as two launches joined by an event instead, because the
+ *           context could not be sure of a hardware queue per stream (the runtime shares queues once a priority class holds
+ *           more streams than GPU_MAX_HW_QUEUES -- a second context on the device is enough);
+ *   out4[2] merged runs whose waiting kernel gave up at its bound; gauss_job_fetch ran each of them again in the
+ *           two-launch form inside the same call;
+ *   out4[3] of those, the ones whose second form failed too (gauss_job_fetch returned GAUSS_E_DEVICE).
+ * One call of the reference is one window or an error (dist.cpp:30-126): a give-up is never handed to the caller as results. */
+int gauss_hip_counters(gauss_ctx* ctx, int64_t* out4);
 const char* gauss_last_error(void);
 const char* gauss_hip_version(void);
 /* Hash of the sources this library was built from (gauss_amd/build.py:source_hash): profiles/<tag>_provenance.json record it,

@@ -205,7 +205,9 @@ int gauss_prepared_store_rows(const gauss_prepared* p, const int32_t** rows_m, c
                               const int32_t** pop_src_off, int* n_pop_selected);
 
 typedef struct gauss_chrom_stats {
-    int32_t n_windows, n_windows_mine, n_skipped, n_failed, n_batches, pad_;
+    int32_t n_windows, n_windows_mine, n_skipped, n_failed, n_batches;
+    int32_t n_merged_giveups;      /* batches whose merged Gram launch gave up waiting and were run again in the two-launch form
+                                      inside their fetch (gauss_hip_counters; 0 in a healthy run)                              */
     int64_t imputed;               /* unmeasured SNPs imputed by this rank                                  */
     int64_t panel_bytes_uploaded;  /* 0 when the panel was already resident                                 */
     double t_total, t_plan, t_panel_upload;
@@ -266,7 +268,7 @@ int gauss_host_prepare(int kind, int chr, int64_t start_bp, int64_t end_bp, int6
  * rsid chr bp a1 a2 af1 z info type fpos geneid
  * dist / distmix on a PACKED panel: wing SNPs of the panel that no study SNP shares a position with are not listed
  * (the reference enters them as type 0, filters them, and then neither imputes nor prints them: dist.cpp:91-93,132-140;
- * GAUSS_KEEP_WING_SNPS=1 lists them as the text feeder does).  The window's result table is the same either way. */
+ * the text feeder lists them).  The window's result table is the same either way. */
 const gauss_table* gauss_prepared_snps(const gauss_prepared* p);
 int gauss_prepared_counts(const gauss_prepared* p, int* n_measured, int* n_unmeasured,
                           int* n_samples, int* n_pop, int* n_gene);

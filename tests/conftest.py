@@ -27,8 +27,12 @@ def pytest_sessionstart(session):
 
 @pytest.fixture(scope="session")
 def ctx():
-    """One HIP context for the whole GPU session; fails loudly if the library is missing."""
+    """One HIP context for the whole GPU session -- the process's default context, so that entry points called without
+    ctx= share it: a second live context on the device makes the library queue its runs in the two-launch form (its streams
+    would share hardware queues with the first one's, gauss_ctx.cpp), and the suite is meant to exercise the defaults.
+    Fails loudly if the library is missing."""
     from gauss_amd import hotpath
-    c = hotpath.Context(0)
+    c = hotpath.default_context()
     yield c
     c.close()
+    hotpath._default_ctx = None

@@ -306,7 +306,7 @@ def test_gpu_native_chromosome_first_use_of_a_panel(ctx, tmp_path, monkeypatch):
 
     same(first, warm)
     assert first.stats["imputed"] == warm.stats["imputed"] > 0
-    for env in (dict(GAUSS_UPLOAD_BY_KERNEL="1"), dict(GAUSS_CHROM_ASYNC_UPLOAD="0"), dict(GAUSS_CHROM_COLD_BATCHES="0")):
+    for env in (dict(GAUSS_UPLOAD_BY_KERNEL="1"), dict(GAUSS_CHROM_ASYNC_UPLOAD="0")):
         api.panel_evict(ctx=ctx)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -314,8 +314,37 @@ def test_gpu_native_chromosome_first_use_of_a_panel(ctx, tmp_path, monkeypatch):
         for k in env:
             monkeypatch.delenv(k)
         assert again.stats["panel_bytes_uploaded"] > 0, env
-        assert again.stats["n_batches"] == (4 if "GAUSS_CHROM_COLD_BATCHES" in env else 6), env
+        assert again.stats["n_batches"] == (4 if "GAUSS_CHROM_ASYNC_UPLOAD" in env else 6), env      # in one go: nothing to grade the batches for
+        assert again.stats["n_merged_giveups"] == 0
         same(again, warm)
+    api.panel_evict(ctx=ctx)
+
+
+@pytest.mark.gpu
+def test_gpu_native_chromosome_failed_first_call_leaves_no_half_uploaded_panel(ctx, tmp_path):
+    """the chromosome driver starts the panel's upload in the background BEFORE it parses the study file.  A first call
+    that fails right after (a study file that does not exist) used to return with the upload still running and the panel listed
+    as resident: an LD call on that panel a moment later could read rows that had not landed.  Every exit of the driver now waits
+    for the upload it started (or drops the store if the upload failed), and whoever asks for a resident panel's pointer waits
+    for its rows: computeLD right after the failed call returns the matrix of a fresh context."""
+    st = make_study(tmp_path)
+    p = st["paths"]
+    gpk = str(tmp_path / "panel.gpk")
+    assert api.pack_panel(p["index.gz"], p["data.gz"], p["desc.txt"], gpk) > 0
+    ld_kw = dict(chr=22, start_bp=1_000_001, end_bp=1_600_000, pop_wgt_df=WGT, input_file=p["gwas.txt"], reference_index_file="(packed)",
+                 reference_data_file=gpk, reference_pop_desc_file=p["desc.txt"])
+    api.panel_evict(ctx=ctx)
+    want = api.computeLD(ctx=ctx, **ld_kw)
+    api.panel_evict(ctx=ctx)
+    with pytest.raises(Exception):
+        api.impute_chromosome(kind=api.KIND_DISTMIX, pop_wgt_df=WGT, window_size=125_000, input_file=str(tmp_path / "no_such_study.txt"),
+                              reference_data_file=gpk, reference_pop_desc_file=p["desc.txt"], ctx=ctx, chr=22, start_bp=1_000_001,
+                              end_bp=4_000_000, wing_size=200_000)
+    got = api.computeLD(ctx=ctx, **ld_kw)            # the panel is resident (its upload was started): every row must have landed
+    assert np.array_equal(got["cormat"], want["cormat"])
+    assert api.impute_chromosome(kind=api.KIND_DISTMIX, pop_wgt_df=WGT, window_size=125_000, input_file=p["gwas.txt"], reference_data_file=gpk,
+                                 reference_pop_desc_file=p["desc.txt"], ctx=ctx, chr=22, start_bp=1_000_001, end_bp=4_000_000,
+                                 wing_size=200_000).stats["panel_bytes_uploaded"] == 0
     api.panel_evict(ctx=ctx)
 
 

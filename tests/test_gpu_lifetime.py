@@ -235,42 +235,147 @@ def test_streamed_window_call_strided_rows_and_error_paths(ctx, monkeypatch):
     assert np.array_equal(again["z"], want["z"]) and np.array_equal(again["info"], want["info"])
 
 
-@pytest.mark.gpu
-def test_merged_launch_gives_up_instead_of_hanging(ctx, monkeypatch):
-    """The chain queue of a merged Gram launch waits for a COUNT of finished B11 items (k_gram.hip: wait_count_kernel), and
-    that wait is bounded: made to wait for a count that never comes (the test hook), it gives up after its bound, the run is reported as failed by
-    gauss_job_fetch (no hang, no silent garbage), and the same job runs correctly afterwards -- the counter's target is per
-    launch, so a failed run does not shift the next one's."""
-    from gauss_amd import hotpath, panel
-    import oracle
-    from helpers import small_panel
-    p = small_panel(n_snp=1500, scale=0.05, seed=17)
-    rows2, src_off = panel.pack2bit(p["G"], p["off"])
-    store = hotpath.RowStore(rows2, ctx=ctx)
-    rng = np.random.default_rng(3)
-    n = p["G"].shape[0]
+def _merged_job_windows(store, src_off, p, rng, n_win=3):
     wins = []
-    for k in range(3):
+    for k in range(n_win):
         mi = np.arange(100 * k, 100 * k + 700, 2, dtype=np.int32)
         ui = np.arange(100 * k + 1, 100 * k + 601, 2, dtype=np.int32)
         wins.append(dict(mode=1, pop_off=p["off"], pop_wgt=p["w"], z1=rng.standard_normal(len(mi)), dev=(store.ptr, store.ptr, len(mi), len(ui), store.ld),
                          packed=dict(fmt=1, rows_m=mi, rows_u=ui, pop_src_off=src_off)))
-    monkeypatch.setenv("GAUSS_CHAIN_ASIDE", "2")              # the merged form on a job this small ...
-    monkeypatch.setenv("GAUSS_CHAIN_MERGED", "2")             # ... whatever the session's environment says (2: also for int8 jobs)
-    job = hotpath.Job(wins, ctx=ctx, on_device=True)
-    monkeypatch.setenv("GAUSS_WAIT_COUNT_TIMEOUT_US", "-2000")     # wait 2 ms for a count that never comes
-    job.run()
-    with pytest.raises(Exception) as ei:
-        job.fetch()
-    assert "gave up waiting" in str(ei.value)
-    monkeypatch.delenv("GAUSS_WAIT_COUNT_TIMEOUT_US")
-    job.run()
-    res = job.fetch()
-    job.close()
+    return wins
+
+
+def _check_against_oracle(p, wins, res):
+    import oracle
     for w, r in zip(wins, res):
         gm, gu = p["G"][w["packed"]["rows_m"]], p["G"][w["packed"]["rows_u"]]
         want = oracle.run_impute(1, np.ascontiguousarray(gm), np.ascontiguousarray(gu), p["off"], p["w"], w["z1"])
         assert r["status"] == 0
         assert np.max(np.abs(r["z"] - want["z"]) / np.maximum(1.0, np.abs(want["z"]))) <= 1e-8
         assert np.max(np.abs(r["info"] - want["info"]) / want["info"]) <= 1e-8
+
+
+@pytest.mark.gpu
+def test_merged_launch_that_gives_up_is_run_again_in_the_two_launch_form(ctx, monkeypatch):
+    """The chain queue of a merged Gram launch waits for a COUNT of finished B11 items (k_gram.hip: wait_count_kernel), and
+    that wait is bounded.  Made to wait for a count that never comes (the test hook), it gives up after its bound and raises the
+    run's failure flag; gauss_job_fetch then runs the job once more in the two-launch form -- no kernel of which waits for
+    another queue -- inside the same call: the caller gets its windows (one call returns its window or an error,
+    dist.cpp:30-126), the context counts the give-up, and the same job runs merged again afterwards (the counter's target is per
+    launch, so a failed run does not shift the next one's).  With two runs in flight both are repaired."""
+    from gauss_amd import hotpath, panel
+    from helpers import small_panel
+    p = small_panel(n_snp=1500, scale=0.05, seed=17)
+    rows2, src_off = panel.pack2bit(p["G"], p["off"])
+    store = hotpath.RowStore(rows2, ctx=ctx)
+    wins = _merged_job_windows(store, src_off, p, np.random.default_rng(3))
+    monkeypatch.setenv("GAUSS_CHAIN_ASIDE", "2")              # the merged form on a job this small ...
+    monkeypatch.setenv("GAUSS_CHAIN_MERGED", "2")             # ... whatever the session's environment or the queue registry says
+    job = hotpath.Job(wins, ctx=ctx, on_device=True)
+    c0 = ctx.counters()
+    monkeypatch.setenv("GAUSS_WAIT_COUNT_TIMEOUT_US", "-2000")     # wait 2 ms for a count that never comes
+    job.run()
+    res = job.fetch()
+    c1 = ctx.counters()
+    assert c1["giveups"] == c0["giveups"] + 1 and c1["rerun_failed"] == c0["rerun_failed"], (c0, c1)
+    _check_against_oracle(p, wins, res)
+    job.run()
+    job.run()                                                # two failing runs in flight
+    a, b = job.fetch(), job.fetch()
+    c2 = ctx.counters()
+    assert c2["giveups"] == c1["giveups"] + 2 and c2["rerun_failed"] == c0["rerun_failed"], (c1, c2)
+    monkeypatch.delenv("GAUSS_WAIT_COUNT_TIMEOUT_US")
+    job.run()
+    again = job.fetch()
+    c3 = ctx.counters()
+    assert c3["giveups"] == c2["giveups"] and c3["merged"] == c2["merged"] + 1, (c2, c3)
+    job.close()
+    for r in (a, b, again):
+        for x, y in zip(res, r):
+            assert np.array_equal(x["z"], y["z"]) and np.array_equal(x["info"], y["info"])
+    store.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("force", [False, True])
+def test_two_contexts_run_merged_jobs_at_the_same_time(ctx, monkeypatch, force):
+    """Two contexts on device 0, two host threads, each running a 3-window job built for the merged Gram launch, at the same
+    time.  The runtime gives a priority stream a hardware queue of its own only while its class holds at most
+    GPU_MAX_HW_QUEUES streams (profiles/r05_queue_map.txt): with two contexts the streams share queues, and a kernel that
+    spins for another queue's progress could sit in front of the work it waits for.  So (force = False, the default) both
+    contexts queue their runs as two launches joined by an event while the other one is alive -- counted as `demoted` -- and
+    the first context goes back to merged runs once it is alone again.  With the merged form forced on both (=2) whatever
+    happens on the shared queues must end in the right bits: a run whose waiting kernel gives up is repaired inside its fetch.
+    Either way: the bits of the single-context run, and no run takes anywhere near the two seconds of a give-up unless one
+    was counted."""
+    import threading
+    import time
+    from gauss_amd import hotpath, panel
+    from helpers import small_panel
+    p = small_panel(n_snp=1500, scale=0.05, seed=19)
+    rows2, src_off = panel.pack2bit(p["G"], p["off"])
+    monkeypatch.setenv("GAUSS_CHAIN_ASIDE", "2")
+    monkeypatch.setenv("GAUSS_CHAIN_MERGED", "2" if force else "1")
+    rng = np.random.default_rng(4)
+    store = hotpath.RowStore(rows2, ctx=ctx)
+    wins = _merged_job_windows(store, src_off, p, rng)
+    solo = hotpath.Job(wins, ctx=ctx, on_device=True)
+    c_before = ctx.counters()
+    solo.run()
+    want = solo.fetch()
+    c_solo = ctx.counters()
+    assert c_solo["merged"] == c_before["merged"] + 1, (c_before, c_solo)      # alone on the device: the merged form
+    _check_against_oracle(p, wins, want)
+
+    other = hotpath.Context(0)
+    store2 = hotpath.RowStore(rows2, ctx=other)
+    wins2 = [dict(w, dev=(store2.ptr, store2.ptr, w["dev"][2], w["dev"][3], store2.ld)) for w in wins]
+    jobs = [solo, hotpath.Job(wins2, ctx=other, on_device=True)]
+    n_runs = 12
+    slowest = [0.0, 0.0]
+    results = [[], []]
+    errors = []
+    gate = threading.Barrier(2)
+
+    def worker(k):
+        try:
+            gate.wait()
+            for _ in range(n_runs):
+                t0 = time.perf_counter()
+                jobs[k].run()
+                results[k].append(jobs[k].fetch())
+                slowest[k] = max(slowest[k], time.perf_counter() - t0)
+        except Exception as ex:      # pragma: no cover
+            errors.append((k, repr(ex)))
+
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    ca, cb = ctx.counters(), other.counters()
+    for k in range(2):
+        for r in results[k]:
+            for x, y in zip(want, r):
+                assert np.array_equal(x["z"], y["z"]) and np.array_equal(x["info"], y["info"]), k
+    gave_up = (ca["giveups"] - c_solo["giveups"]) + cb["giveups"]
+    assert ca["rerun_failed"] == c_solo["rerun_failed"] and cb["rerun_failed"] == 0
+    if not force:
+        assert ca["demoted"] - c_solo["demoted"] == n_runs and cb["demoted"] == n_runs, (ca, cb)
+        assert ca["merged"] == c_solo["merged"] and cb["merged"] == 0 and gave_up == 0, (ca, cb)
+    else:
+        assert ca["merged"] - c_solo["merged"] == n_runs and cb["merged"] == n_runs, (ca, cb)
+    if gave_up == 0:
+        assert max(slowest) < 1.0, slowest                       # nothing stalled
+    jobs[1].close()
+    store2.close()
+    other.close()
+    if not force:
+        solo.run()
+        back = solo.fetch()
+        assert ctx.counters()["merged"] == ca["merged"] + 1      # alone again: merged again
+        for x, y in zip(want, back):
+            assert np.array_equal(x["z"], y["z"]) and np.array_equal(x["info"], y["info"])
+    solo.close()
     store.close()

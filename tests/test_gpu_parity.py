@@ -455,11 +455,14 @@ def test_ld_and_gene_batches_over_row_stores_equal_the_byte_calls(ctx, mode):
 
 
 @pytest.mark.parametrize("mode", [0, 1])
-def test_solve_forms_agree(ctx, mode, monkeypatch):
-    """The fused path (k_solve.hip) has job-size dependent forms of the same arithmetic: the early products of a row of
-    the inverse in one workgroup or one per class, the factorisation with or without panel launches, and the closing
-    product in tiles of 128 or 64 right-hand sides.  The same windows through every combination: each within 1e-8 of the oracle and
-    bit-identical to the others (every form sums in the same order)."""
+def test_solve_forms_agree(ctx, mode):
+    """The fused path (k_solve.hip) has job-size dependent forms of the same arithmetic: the factorisation with or without
+    panel launches (jobs of up to 20 windows form their panel tiles inside the update launches, gauss_job.h:
+    OWN_PANEL_MAX_WINDOWS) and the closing product in tiles of 64 or 128 right-hand sides (jobs with fewer than 1 600 tiles
+    of 128 take 64, GEMM_SMALL_TILES).  The same four windows alone (small-job forms) and among 27 filler windows that push the
+    job over both thresholds (large-job forms): each within 1e-8 of the oracle and bit-identical to the other (every form
+    sums in the same order).  Rows of the inverse with one early product (uncut) and with several (cut into class sums) occur
+    in both: the windows have 1 to 5 factor blocks."""
     p = small_panel(n_snp=420, scale=0.03, seed=5)
     G, off = p["G"], p["off"]
     rng = np.random.default_rng(2)
@@ -468,23 +471,26 @@ def test_solve_forms_agree(ctx, mode, monkeypatch):
         idx = rng.permutation(G.shape[0])
         gm, gu = np.ascontiguousarray(G[np.sort(idx[:m])]), np.ascontiguousarray(G[np.sort(idx[m:m + u])])
         wins.append(dict(mode=mode, geno_m=gm, geno_u=gu, pop_off=off, pop_wgt=p["w"], z1=rng.standard_normal(m) * 2))
+    # filler: 27 windows of 300 measured SNPs and 2 560 unmeasured rows (rows may repeat among the unmeasured: each is imputed
+    # on its own) = 27 x 20 x 3 = 1 620 tiles of the closing product at 128 right-hand sides, 31 windows in the job
+    filler = []
+    for k in range(27):
+        idx = rng.permutation(G.shape[0])
+        gm = np.ascontiguousarray(G[np.sort(idx[:300])])
+        gu = np.ascontiguousarray(G[rng.integers(0, G.shape[0], size=2560)])
+        filler.append(dict(mode=mode, geno_m=gm, geno_u=gu, pop_off=off, pop_wgt=p["w"], z1=rng.standard_normal(300)))
     out = {}
-    for name, env in (("split", {"GAUSS_SOLVE_SPLIT_MIN": "2", "GAUSS_GEMM_SMALL_TILES": "1000000", "GAUSS_OWN_PANEL_MAX_WINDOWS": "20"}),
-                      ("rows", {"GAUSS_SOLVE_SPLIT_MIN": "0", "GAUSS_GEMM_SMALL_TILES": "0", "GAUSS_OWN_PANEL_MAX_WINDOWS": "0"}),
-                      ("mixed", {"GAUSS_SOLVE_SPLIT_MIN": "3", "GAUSS_GEMM_SMALL_TILES": "0", "GAUSS_OWN_PANEL_MAX_WINDOWS": "0"})):
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        job = hotpath.Job(wins, ctx=ctx)
+    for name, batch in (("small", wins), ("large", wins + filler)):
+        job = hotpath.Job(batch, ctx=ctx)
         job.run()
-        out[name] = job.fetch()
+        out[name] = job.fetch()[:len(wins)]
         job.close()
-    for w, a, b, c in zip(wins, out["split"], out["rows"], out["mixed"]):
+    for w, a, b in zip(wins, out["small"], out["large"]):
         want = oracle.run_impute(mode, w["geno_m"], w["geno_u"], off, p["w"], w["z1"])
-        for r in (a, b, c):
+        for r in (a, b):
             assert r["status"] == 0
             assert relerr(r["info"], want["info"]) <= Z_TOL
             assert np.max(np.abs(r["z"] - want["z"]) / np.maximum(1.0, np.abs(want["z"]))) <= Z_TOL
-        assert np.array_equal(a["info"], c["info"]) and np.array_equal(a["z"], c["z"])
         assert np.array_equal(a["info"], b["info"]) and np.array_equal(a["z"], b["z"])
 
 
@@ -741,13 +747,14 @@ def test_shared_measured_rows_give_the_bits_of_separate_windows(ctx, monkeypatch
 @pytest.mark.gpu
 def test_chain_beside_the_gram_kernel_gives_the_same_bits(ctx, monkeypatch):
     """The factorisation chain in its small-footprint form (k_solve_lite.hip), queued beside the Gram launch of B21's items
-    (GAUSS_CHAIN_ASIDE=2 forces it), against the chain behind one Gram launch (=0): z, info, status, B11 and B21 bit for bit.
-    Windows of 2 to 9 factor blocks (M not a multiple of 64), shared and unshared measured rows, a QCAT window, a window
-    whose lambda is too small for the certificate (the shifted matrix is factored too), and one whose B11 is not positive
-    definite at all (lambda = 0 on duplicated rows: the clamp path reruns it).  Also with the row tables and the certificate made
-    on the side queue (GAUSS_ROWS_ASIDE=1): every reader joins that queue first, so the bits are the same.  The chain beside the
-    Gram kernel comes in two launch forms -- ONE Gram launch whose B11 items count themselves off for the chain queue (default,
-    k_gram.hip: wait_count_kernel), or two launches joined by an event (GAUSS_CHAIN_MERGED=0) -- both are driven."""
+    (GAUSS_CHAIN_ASIDE=2 forces it on a job this small), against the chain behind one Gram launch (=0): z, info, status, B11 and
+    B21 bit for bit.  Windows of 2 to 9 factor blocks (M not a multiple of 64), shared and unshared measured rows, a QCAT window,
+    a window whose lambda is too small for the certificate (the shifted matrix is factored too), and one whose B11 is not
+    positive definite at all (lambda = 0 on duplicated rows: the clamp path reruns it).  The chain beside the Gram kernel comes
+    in two launch forms -- ONE Gram launch whose B11 items count themselves off for the chain queue (k_gram.hip:
+    wait_count_kernel; GAUSS_CHAIN_MERGED=2 asks for it whatever the queue registry says, and the context's counters must show
+    that the runs were queued that way), or two launches joined by an event (GAUSS_CHAIN_MERGED=0) -- with the early windows'
+    epilogue tiles on the low-priority queue or all behind the launch (GAUSS_EPI_EARLY=0); all are driven."""
     p = small_panel(n_snp=2600, scale=0.05, seed=41)
     G = p["G"].copy()
     G[7] = G[3]                                    # two identical SNPs: singular B11 at lambda = 0
@@ -769,11 +776,10 @@ def test_chain_beside_the_gram_kernel_gives_the_same_bits(ctx, monkeypatch):
     wins[4] = dict(wins[4], lam=1e-7)              # no certificate: the exact test factors B11 - eps I as well
     wins[0] = dict(wins[0], lam=0.0)               # singular: status says clamp, the host reruns the window
 
-    def run(aside, share, split=False, rows_aside=False, merged=True):
-        monkeypatch.setenv("GAUSS_CHAIN_MERGED", "1" if merged else "0")     # B11's and B21's items as ONE launch (counted items) or two
-        monkeypatch.setenv("GAUSS_ROWS_ASIDE", "1" if rows_aside else "0")   # row tables + certificate on the side queue (job_run joins them)
-        monkeypatch.setenv("GAUSS_CHAIN_ASIDE", "2" if aside else ("1" if split else "0"))
-        monkeypatch.setenv("GAUSS_GRAM_SPLIT", "1" if split else "0")       # two Gram launches, chain behind them (bench's one-stream pass)
+    def run(aside, share, merged=True, early=True):
+        monkeypatch.setenv("GAUSS_CHAIN_MERGED", "2" if merged else "0")     # B11's and B21's items as ONE launch (counted items) or two
+        monkeypatch.setenv("GAUSS_EPI_EARLY", "1" if early else "0")
+        monkeypatch.setenv("GAUSS_CHAIN_ASIDE", "2" if aside else "0")
         monkeypatch.setenv("GAUSS_SHARE_MEASURED", "1" if share else "0")
         job = hotpath.Job(wins, ctx=ctx, on_device=True, want_mats=True)
         job.run()
@@ -790,8 +796,13 @@ def test_chain_beside_the_gram_kernel_gives_the_same_bits(ctx, monkeypatch):
     for share in (False, True):
         behind = run(False, share)
         assert any(r["status"] != 0 for r in behind)
-        for other in (run(True, share), run(True, share, merged=False), run(False, share, split=True), run(True, share, rows_aside=True),
-                      run(True, share, rows_aside=True, merged=False), run(False, share, rows_aside=True)):
+        c0 = ctx.counters()
+        forms = [run(True, share), run(True, share, early=False)]
+        c1 = ctx.counters()
+        assert c1["merged"] - c0["merged"] == 4 and c1["giveups"] == c0["giveups"], (c0, c1)      # two runs each, queued merged
+        forms.append(run(True, share, merged=False))
+        assert ctx.counters()["merged"] == c1["merged"]
+        for other in forms:
             for k, (x, y) in enumerate(zip(behind, other)):
                 for key in x:
                     if isinstance(x[key], np.ndarray):

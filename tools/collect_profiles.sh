@@ -9,11 +9,15 @@
 set -e -o pipefail
 TAG=${1:-r01}
 ROOT=$(pwd)
-OUT=$ROOT/gpurun_out/prof_$TAG
-rm -rf "$OUT"; mkdir -p "$OUT"
+# every collection gets a directory of its own and none is ever deleted: the one trace that shows an outlier (profiles/README.md:
+# a 57 ms Gram launch among 37, rounds 3 and 4) must survive the next collection
+OUT=$ROOT/gpurun_out/prof_${TAG}_$(date -u +%Y%m%dT%H%M%SZ)
+mkdir -p "$OUT"
+(rocm-smi --showclocks --showperflevel --showtemp 2>&1 || true) > "$OUT/smi_before.txt"
 cd /tmp && export TMPDIR=/tmp
 cd "$ROOT"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 bench.py --steps 20 --warmup 5 --no-e2e > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.log"
+(rocm-smi --showclocks --showperflevel --showtemp 2>&1 || true) > "$OUT/smi_after_trace.txt"
 echo "stats done" && tail -1 "$OUT/bench_under_rocprof.json" | head -c 600 && echo
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-i8-variant --no-e2e --emulate-world 0 --no-parity-spot > "$OUT/pmc_fetch.json" 2> "$OUT/pmc_fetch.log"
 echo "fetch done"

@@ -1,5 +1,5 @@
 import sys, time, ctypes as C
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from gauss_amd import hotpath, _lib
 t0=time.perf_counter(); ctx = hotpath.Context(0); print('ctx %.1f ms' % ((time.perf_counter()-t0)*1e3))
 lib = ctx.lib

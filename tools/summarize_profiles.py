@@ -1,6 +1,6 @@
 """Boil the rocprofv3 output of tools/collect_profiles.sh down to the small CSVs kept under profiles/.
 
-usage: summarize_profiles.py <tag> <dir>     (dir = gpurun_out/prof_<tag>)
+usage: summarize_profiles.py <tag> <dir>     (dir = gpurun_out/prof_<tag>_<utc>: collect_profiles.sh never reuses or deletes one)
 Writes <dir>/summary/{tag}_kernel_stats.csv, {tag}_pmc_traffic.csv, {tag}_sq_mfma.csv, {tag}_step_timeline.txt, {tag}_bench_under_rocprof.json and
 {tag}_provenance.json (source hash + git head of the profiled code);
 copy those into profiles/ (tracked)."""
@@ -109,6 +109,64 @@ def by_grid(tag, d, out):
             fh.write(f"{k},{g},{len(v)},{sum(v) / len(v):.1f},{min(v):.1f},{max(v):.1f},{sum(v) / 1e3:.3f}\n")
 
 
+def outliers(tag, d, out):
+    """A Gram launch that takes more than 1.2 x the median of its grid's launches (profiles/README.md: one launch of 57 ms among 37
+    under --kernel-trace in rounds 3 and 4, never outside the profiler) gets a report of its own, so that the evidence outlives the
+    collection: every dispatch of every queue that overlaps the launch (1 ms of margin either side) with start / end relative to
+    the launch's start, per queue the longest interval without a running dispatch inside the launch, and the clocks rocm-smi
+    showed before and after the traced run.  Returns the number of outliers (0: the report says so)."""
+    f = find(os.path.join(d, "stats"), "*kernel_trace.csv")
+    path = os.path.join(out, f"{tag}_outlier.txt")
+    if not f:
+        return 0
+    rows = []
+    with open(f) as fh:
+        for r in csv.DictReader(fh):
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"]), r.get("Queue_Id", ""),
+                         r.get("Grid_Size_X") or r.get("Grid_Size") or "", r.get("Dispatch_Id", "")))
+    rows.sort()
+    by = defaultdict(list)
+    for r in rows:
+        if "gram_kernel" in r[2]:
+            by[(r[2], r[4])].append(r)
+    found = []
+    for key, v in by.items():
+        if len(v) < 5:
+            continue
+        dur = sorted(e - s for s, e, *_ in v)
+        med = dur[len(dur) // 2]
+        found += [(r, med, len(v)) for r in v if (r[1] - r[0]) > 1.2 * med]
+    with open(path, "w") as fh:
+        fh.write("# Gram launches longer than 1.2 x the median of their grid in the --kernel-trace run of this collection (tools/summarize_profiles.py)\n")
+        if not found:
+            fh.write("none: %s\n" % "; ".join("%s grid %s: %d launches, median %.3f ms, longest %.3f ms" % (k[0], k[1], len(v), sorted(e - s for s, e, *_ in v)[len(v) // 2] / 1e6,
+                                                                                                            max(e - s for s, e, *_ in v) / 1e6) for k, v in by.items() if len(v) >= 5))
+        for (s0, e0, name, q0, grid, did), med, n in found:
+            fh.write("\n== %s grid %s dispatch %s on queue %s: %.3f ms (median of %d launches %.3f ms)\n" % (name, grid, did, q0, (e0 - s0) / 1e6, n, med / 1e6))
+            near = [r for r in rows if r[1] >= s0 - 1_000_000 and r[0] <= e0 + 1_000_000]
+            fh.write("dispatches overlapping it (ms from its start):\n")
+            for s, e, nm, q, g, di in near:
+                fh.write("  queue %-3s %-44s grid %-10s start %9.3f end %9.3f (%8.3f ms)\n" % (q, nm[:44], g, (s - s0) / 1e6, (e - s0) / 1e6, (e - s) / 1e6))
+            fh.write("per queue, the longest stretch INSIDE the launch with no dispatch of that queue running:\n")
+            for q in sorted({r[3] for r in near}):
+                iv = sorted((max(s, s0), min(e, e0)) for s, e, _, qq, _, _ in near if qq == q and e > s0 and s < e0)
+                t, gap, at = s0, 0, s0
+                for s, e in iv:
+                    if s - t > gap:
+                        gap, at = s - t, t
+                    t = max(t, e)
+                if e0 - t > gap:
+                    gap, at = e0 - t, t
+                fh.write("  queue %-3s idle %.3f ms from %.3f ms\n" % (q, gap / 1e6, (at - s0) / 1e6))
+        for nm in ("smi_before.txt", "smi_after_trace.txt"):
+            sp = os.path.join(d, nm)
+            if os.path.exists(sp):
+                fh.write("\n-- %s\n" % nm)
+                with open(sp) as sf:
+                    fh.write("".join(l for l in sf if any(w in l.lower() for w in ("sclk", "mclk", "fclk", "perf", "temp")))[:4000])
+    return len(found)
+
+
 def provenance(tag, out):
     """Which code the profiles were taken on: the source hash compiled into the profiled library (gauss_hip_source_hash)
     and the git head the development container recorded for those sources (gauss_amd/lib/build_stamp.json; the GPU box
@@ -129,6 +187,17 @@ def provenance(tag, out):
         stamp["csrc_hash_of_loaded_library"] = _lib.load().gauss_hip_source_hash().decode()
     except Exception as ex:      # the summary can be rebuilt off the GPU box
         stamp["csrc_hash_of_loaded_library"] = None
+    # the end_to_end figures also depend on libgauss_host.so: its identity is the hash of its sources (it has no compiled-in one)
+    try:
+        import hashlib
+        h = hashlib.sha256()
+        hdir = os.path.join(root, "gauss_amd", "csrc", "host")
+        for f in sorted(os.listdir(hdir)) + ["../../../include/gauss_host.h"]:
+            with open(os.path.join(hdir, f), "rb") as fh:
+                h.update(os.path.basename(f).encode() + b"\0" + fh.read())
+        stamp["host_src_hash"] = h.hexdigest()[:16]
+    except Exception:
+        stamp["host_src_hash"] = None
     stamp["tag"] = tag
     stamp["collected_utc"] = datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%M:%SZ")
     stamp["commands"] = "tools/collect_profiles.sh " + tag
@@ -146,6 +215,9 @@ def main():
     if ks:
         shutil.copy(ks, os.path.join(out, f"{tag}_kernel_stats.csv"))
     by_grid(tag, d, out)
+    n_out = outliers(tag, d, out)
+    if n_out:
+        print("NOTE: %d Gram launch(es) over 1.2 x the median: see %s_outlier.txt (keep %s)" % (n_out, tag, d))
     bj = os.path.join(d, "bench_under_rocprof.json")
     if os.path.exists(bj):
         with open(bj) as fh:
