@@ -68,7 +68,7 @@ def parse_args(argv=None):
     ap.add_argument("--verify-shards", action="store_true",
                     help="N > 1, strong: rank 0 also runs every window itself and checks the ranks' z / info bit for bit")
     ap.add_argument("--no-from-text", action="store_true", help="end_to_end: skip the leg that starts from a BGZF TEXT panel")
-    ap.add_argument("--text-snps", type=int, default=20_000, help="end_to_end.from_text: SNPs of the text panel")
+    ap.add_argument("--text-snps", type=int, default=100_000, help="end_to_end.from_text: SNPs of the text panel (default: the whole chromosome)")
     ap.add_argument("--no-tails-alone", action="store_true", help="skip the one-stream pass that times the fp64 tails and the HBM-bound kernels stand-alone (probes)")
     ap.add_argument("--no-e2e", action="store_true", help="N = 1: skip the end_to_end block (files on disk -> result table)")
     ap.add_argument("--no-other-configs", action="store_true", help="N = 1: skip the other_configs block (configs[1], [2], [4] at <= 5 timed steps each)")
@@ -840,6 +840,39 @@ def cpu_baseline_computeld(sample):
                       f"{est:.1f} s per window"}
 
 
+def jepegmix_checks(pr, blocks, go, sizes, spot_genes, n_table, warm_s):
+    """cpu_baseline + parity_spot of the jepegmix leg: CorG's pair loops (gene.cpp:571-586: CalWgtCov per SNP pair of a gene) of the
+    first `spot_genes` genes in the CPU oracle, scaled by pair count to all genes, one core; and the GPU's gene LD blocks of the
+    same genes against those oracle matrices (the k x k tail is host code in both, tests/test_oracle.py).  The oracle is the
+    checker here, never the thing measured."""
+    import oracle
+    G = pr.geno_m()                                               # one byte per genotype, the rows the GPU batch multiplied
+    off, w = np.ascontiguousarray(pr.pop_off(), np.int32), np.ascontiguousarray(pr.pop_wgt(), np.float64)
+    pick = [g for g in range(len(sizes)) if sizes[g] >= 2][:spot_genes]
+    worst, t_or, pairs_s = 0.0, 0.0, 0
+    for g in pick:
+        rows = np.ascontiguousarray(G[go[g]:go[g + 1]])
+        t0 = time.perf_counter()
+        want = oracle.compute_ld(rows, off, w)
+        t_or += time.perf_counter() - t0
+        got = blocks[g]
+        n = rows.shape[0]
+        iu = np.triu_indices(n, 1)
+        worst = max(worst, float(np.max(np.abs(got[iu] - want[iu]))) if n > 1 else 0.0)
+        pairs_s += n * (n + 1) // 2
+    pairs_all = int((sizes * (sizes + 1) // 2).sum())
+    est = t_or * pairs_all / max(pairs_s, 1)
+    return {
+        "cpu_baseline": {"value": n_table / est if est > 0 else None, "unit": "genes/s", "cores": 1, "kind": "port", "host_cores": os.cpu_count(),
+                         "sample": f"oracle CalWgtCov pair loops (gene.cpp:571-586) of {len(pick)} genes ({pairs_s} SNP pairs, N = {G.shape[1]}): {t_or:.2f} s, "
+                                   f"scaled by pair count to all {len(sizes)} genes ({pairs_all} pairs): {est:.1f} s per call; the k x k tails (microseconds) "
+                                   "and the reference's text feeder are not included"},
+        "parity_spot": {"genes": len(pick), "max_abs_ld_diff": worst, "tolerance": 1e-12, "ok": bool(worst <= 1e-12),
+                        "what": "off-diagonal entries of the GPU's gene LD blocks (gauss_gene_ld_batch_rows on the resident 2-bit panel) "
+                                "vs oracle.compute_ld on the same genotype rows at full N"},
+    }
+
+
 def main(argv=None):
     args = parse_args(argv)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -854,12 +887,18 @@ def main(argv=None):
         if args.mode == "e2e":
             out = benchmodes.run_e2e(args, rig)
         else:
-            out, sample = {"computeLD": benchmodes.run_computeld, "jepegmix": benchmodes.run_jepegmix, "window": benchmodes.run_window}[args.mode](args, rig)
+            if args.mode == "jepegmix":
+                out, sample = benchmodes.run_jepegmix(args, rig, checks=None if args.no_cpu_baseline else jepegmix_checks)
+            else:
+                out, sample = {"computeLD": benchmodes.run_computeld, "window": benchmodes.run_window}[args.mode](args, rig)
             if out is not None and sample is not None and not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline_computeld(sample)
             if out is not None:
                 print(json.dumps(out), flush=True)
     rig.close()           # not in a `finally`: a rank that failed must not wait in a barrier for the others
+    if isinstance(out, dict) and isinstance(out.get("other_configs"), dict) and not out["other_configs"].get("all_parity_ok", True):
+        print("bench.py: a parity_spot of the other_configs block failed", file=sys.stderr)
+        sys.exit(4)
     if isinstance(out, dict) and isinstance(out.get("parity_spot"), dict) and not out["parity_spot"]["ok"]:
         print("bench.py: the timed job's results differ from the CPU oracle beyond %g (parity_spot)" % SPOT_TOL, file=sys.stderr)
         sys.exit(4)

@@ -2697,24 +2697,32 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
     // batch starts when the rows it names have landed -- so the early batches are smaller then (six batches, the first three
     // 0.3 / 0.5 / 0.8 of a share): the GPU starts on the first fifth of the rows and stays busy behind the upload.
     const bool auto_batches = n_batches < 1;
-    if (n_batches < 1) n_batches = mine.size() >= 16 ? (first_use && async_upload ? 6 : 4) : (mine.size() >= 9 ? 3 : (mine.size() >= 4 ? 2 : 1));
+    // (A LEAD batch of one window -- so that the GPU starts after ONE window's data layer instead of a 0.3-share batch's -- was
+    // measured in round 5 and is not built: the GPU started 0.8 ms earlier and the chromosome's span grew by 0.9 ms, a job of one
+    // window has nothing to hide its factorisation chain under; 8-rank shares 7.4-8.4 ms against 7.8-8.2.  DESIGN.md 9e item 10.)
+    const size_t lead = 0;
+    const size_t n_rest = mine.size() - lead;
+    if (n_batches < 1) n_batches = (int)lead + (n_rest >= 16 ? (first_use && async_upload ? 6 : 4) : (n_rest >= 9 ? 3 : (n_rest >= 4 ? 2 : 1)));
     n_batches = std::max(1, std::min<int>(n_batches, std::max<size_t>(mine.size(), 1)));
     // contiguous batches by cost.  The first batch is the one nothing overlaps with on the way in (its data layer)
     // and the last one on the way out (its tables), so with four or more batches those two get 0.3 of a share.
     std::vector<std::vector<int>> batches((size_t)n_batches);
     {
-        std::vector<double> share((size_t)n_batches, 1.0);
-        if (n_batches >= 4) { share.front() = 0.3; share.back() = 0.3; }    // measured: 0.5 / 0.5 46.3 ms, 0.3 / 0.3 45.3 ms per chromosome
-        if (auto_batches && first_use && n_batches == 6) { share[1] = 0.5; share[2] = 0.8; }
+        const int nb = n_batches - (int)lead;                      // batches behind the lead window
+        std::vector<double> share((size_t)std::max(nb, 1), 1.0);
+        if (nb >= 4) { share.front() = 0.3; share.back() = 0.3; }    // measured: 0.5 / 0.5 46.3 ms, 0.3 / 0.3 45.3 ms per chromosome
+        if (auto_batches && first_use && nb == 6) { share[1] = 0.5; share[2] = 0.8; }
         double ssum = 0;
         for (double v : share) ssum += v;
         double total = 0;
-        for (int i : mine) total += wins[i].cost;
+        for (size_t q = lead; q < mine.size(); q++) total += wins[mine[q]].cost;
         double acc = 0, edge = share[0] / ssum;
         int b = 0;
-        for (int i : mine) {
-            while (b + 1 < n_batches && total > 0 && acc / total >= edge - 1e-12 && !batches[b].empty()) { b++; edge += share[b] / ssum; }
-            batches[b].push_back(i);
+        if (lead) batches[0].push_back(mine[0]);
+        for (size_t q = lead; q < mine.size(); q++) {
+            const int i = mine[q];
+            while (b + 1 < nb && total > 0 && acc / total >= edge - 1e-12 && !batches[(size_t)b + lead].empty()) { b++; edge += share[b] / ssum; }
+            batches[(size_t)b + lead].push_back(i);
             acc += wins[i].cost;
         }
     }
@@ -2734,7 +2742,10 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
     const unsigned hw = std::thread::hardware_concurrency();
     // 8 rather than 16: a warm chromosome takes the same 45 ms, a process's first call 88 instead of 110 ms (the first
     // hipMalloc of the workspaces and the cold allocator share the host with these threads; tools/cold_probe.sh)
-    int nthreads = (int)std::max(1u, std::min(8u, (hw ? hw : 4u) / (unsigned)std::max(1, std::min(world, 8))));
+    // (the ranks of THIS node share its cores: torchrun exports LOCAL_WORLD_SIZE; `world` may span nodes)
+    const char* lws = getenv("LOCAL_WORLD_SIZE");
+    const unsigned local_ranks = (unsigned)std::max(1, lws ? atoi(lws) : 1);
+    int nthreads = (int)std::max(1u, std::min(8u, (hw ? hw : 4u) / local_ranks));
     {
         // first use of the panel on this context: the upload's copy threads (page faults on the mapping, or preads) run
         // beside the data layer, and more than four data-layer threads slow BOTH down (cold call 73-84 ms with 4, 103-124
@@ -2743,7 +2754,7 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
     }
     // the result tables are built after the upload has finished: they keep the full count (a first call built its tables on the
     // four threads meant for the time of the upload: 20 ms of tables instead of 11)
-    int nthreads_tables = (int)std::max(1u, std::min(8u, (hw ? hw : 4u) / (unsigned)std::max(1, std::min(world, 8))));
+    int nthreads_tables = (int)std::max(1u, std::min(8u, (hw ? hw : 4u) / local_ranks));
     // One pool over ALL windows in batch order (not one fork-join per batch: a batch of five windows would leave
     // eleven of sixteen threads idle); a batch is ready when its last window is.
     std::vector<std::pair<int, int>> order;                       // (batch, slot)

@@ -284,7 +284,13 @@ int64_t pack_panel(const std::string& index_path, const std::string& data_path, 
                 uint8_t* row = rows.data() + (i - c0) * row_bytes;
                 for (int k = 0; k < P; k++) {
                     const char* g; int n;
-                    if (!d.next(g, n) || n != (int)pops[k].size)
+                    // A population's genotype string is pops[k].size digits and a blank: taken by LENGTH (a byte-by-byte search for
+                    // the token's end walked all 33 kB of every line); the digit test of the packing loop below rejects a blank or any
+                    // other character inside it, and a line that is not shaped like that goes through the tokeniser for its message.
+                    while (d.p < d.e && kWs.t[(unsigned char)*d.p]) d.p++;
+                    const int want = (int)pops[k].size;
+                    if (d.e - d.p >= want && (d.p + want == d.e || kWs.t[(unsigned char)d.p[want]])) { g = d.p; n = want; d.p += want; }
+                    else if (!d.next(g, n) || n != want)
                         return give_up(std::string("panel line of ") + (strings.data() + snps[i].rsid) + ": population " + pops[k].name + " does not have " + std::to_string(pops[k].size) + " genotypes");
                     int32_t c = 0;
                     uint8_t* dst = row + pops[k].byte_off;
@@ -310,7 +316,13 @@ int64_t pack_panel(const std::string& index_path, const std::string& data_path, 
                         c += (int32_t)code;
                         dst[q >> 2] |= (uint8_t)(code << (2 * (q & 3)));
                     }
-                    if (bad) return give_up(std::string("panel line of ") + (strings.data() + snps[i].rsid) + " has a genotype outside 0..3");
+                    if (bad) {
+                        // (a white-space character inside the string: the token is shorter than the population)
+                        for (int t = 0; t < n; t++)
+                            if (kWs.t[(unsigned char)g[t]])
+                                return give_up(std::string("panel line of ") + (strings.data() + snps[i].rsid) + ": population " + pops[k].name + " does not have " + std::to_string(pops[k].size) + " genotypes");
+                        return give_up(std::string("panel line of ") + (strings.data() + snps[i].rsid) + " has a genotype outside 0..3");
+                    }
                     cnt[i * (size_t)P + k] = c;
                 }
                 for (int k = 0; k < P; k++) {

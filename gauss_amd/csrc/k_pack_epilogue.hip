@@ -19,9 +19,23 @@ namespace gauss {
 // ------------------------------------------------------------------------------------------
 struct __attribute__((packed)) U32u { uint32_t v; };
 
+// (Round 5 measured two ways of making this kernel faster, neither of which moved it: several rows per workgroup -- tables staged
+// once, fewer starts -- took 1.53 ms against 1.07 for one row each, the launch's load balance and latency hiding suffer; a third
+// fewer vector instructions -- the 2-bit decode by spreading, a branch-free e4m3 encoding, quad instead of wave reductions: kept,
+// they are simpler -- left it at 1.04-1.07 ms.  It moves 0.9 GB in + 3.3 GB out in that time, 4.0 TB/s, where torch's copy_
+// kernel reaches 4.6 TB/s on a 1 : 1 stream and its 1 : 4 expanding copy 3.9 (tools/hbm_write_probe.py: fill_ alone 6.5): the
+// kernel sits at what a write-heavy mixed stream gets out of this memory system.)
 __global__ __launch_bounds__(256) void pack_stats_kernel(const Prob* __restrict__ probs,
                                                          const int2* __restrict__ rowmap)
 {
+    __shared__ int s_sx[64];
+    __shared__ int s_sxx[64];
+    // word -> source block tables staged in LDS: looked up once per 16 samples, and a chain of dependent global
+    // loads (word table -> offsets -> data) would set the pace of the whole kernel
+    constexpr int PACK_LDS_WORDS = 8192;
+    __shared__ uint8_t s_word[PACK_LDS_WORDS];
+    __shared__ int s_pk[65], s_src[65], s_len[64];
+    __shared__ double s_cov[64], s_mm[64], s_wmu[64];
     const int2 rm = rowmap[blockIdx.x];
     const Prob& pb = probs[rm.x];
     const int r = rm.y;
@@ -44,13 +58,6 @@ __global__ __launch_bounds__(256) void pack_stats_kernel(const Prob* __restrict_
     }
     uint4* dst = reinterpret_cast<uint4*>((um ? pb.packed_u : pb.packed) + (size_t)prow * pb.Kp);
 
-    __shared__ int s_sx[64];
-    __shared__ int s_sxx[64];
-    // word -> source block tables staged in LDS: looked up once per 16 samples, and a chain of dependent global
-    // loads (word table -> offsets -> data) would set the pace of the whole kernel
-    constexpr int PACK_LDS_WORDS = 8192;
-    __shared__ uint8_t s_word[PACK_LDS_WORDS];
-    __shared__ int s_pk[65], s_src[65], s_len[64];
     if (threadIdx.x < 64) { s_sx[threadIdx.x] = 0; s_sxx[threadIdx.x] = 0; }
     const int nwords = pb.Kp >> 4;                 // a multiple of 4 (Kp is a multiple of 64)
     const bool fmt2 = pb.geno_fmt != 0;
@@ -89,6 +96,13 @@ __global__ __launch_bounds__(256) void pack_stats_kernel(const Prob* __restrict_
             uint32_t c;
             if (pb.gram_i8) {
                 c = x;                                   // i8 MFMA path: operands are the raw codes
+            } else if (fmt2) {
+                // 2-bit sources hold codes 0..3 (recoding only lowers them): 0 -> 0x00, 1 -> 0x38, 2 -> 0x40, 3 -> 0x44 without a
+                // branch or a multiply -- this kernel is bound by its vector instructions (86 % of the VALU issue slots, round 4's
+                // counters), not by HBM
+                const uint32_t lo = x & 0x01010101u, hi = (x >> 1) & 0x01010101u;
+                const uint32_t one = lo & ~hi, three = lo & hi;
+                c = (hi << 6) | ((one << 6) - (one << 3)) | (three << 2);
             } else if ((x & 0x0C0C0C0Cu) == 0 && (x & (x >> 1) & 0x01010101u) == 0) {
                 // every byte in {0,1,2}: 1 -> 0x38, 2 -> 0x40
                 c = (x & 0x01010101u) * 0x38u + ((x >> 1) & 0x01010101u) * 0x40u;
@@ -115,16 +129,15 @@ __global__ __launch_bounds__(256) void pack_stats_kernel(const Prob* __restrict_
             const uint32_t r1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s1, 0xB1, 0xF, 0xF, true);
             if (live) dst[w] = odd ? make_uint4(r0, r1, v[1], v[3]) : make_uint4(v[0], v[2], r0, r1);
         }
-        // per-population sums: the 64 lanes of a wave cover 1 KiB of one row, almost always inside one
-        // population -- reduce across the wave first instead of 64 colliding LDS atomics
-        const int p0 = __builtin_amdgcn_readfirstlane(p);
-        if (__all(p == p0)) {
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { sx += __shfl_xor(sx, o); sxx += __shfl_xor(sxx, o); }
-            if ((threadIdx.x & 63) == 0 && sx) { atomicAdd(&s_sx[p0], sx); atomicAdd(&s_sxx[p0], sxx); }
-        } else if (sx) {
-            atomicAdd(&s_sx[p], sx); atomicAdd(&s_sxx[p], sxx);
-        }
+        // per-population sums: a lane quad holds four consecutive words = one 64-sample chunk, and a chunk never straddles two
+        // populations (blocks are padded to 64 samples; lane pairs and quads are always in the loop together): two DPP steps add
+        // the quad up, its first lane adds to the population's LDS counters.  (Round 4 reduced across the whole wave when it sat
+        // inside one population: twelve ds_bpermute + their adds per word, a fifth of the kernel's vector instructions.)
+        sx += __builtin_amdgcn_update_dpp(0, sx, 0xB1, 0xF, 0xF, true);        // quad_perm [1, 0, 3, 2]
+        sxx += __builtin_amdgcn_update_dpp(0, sxx, 0xB1, 0xF, 0xF, true);
+        sx += __builtin_amdgcn_update_dpp(0, sx, 0x4E, 0xF, 0xF, true);        // quad_perm [2, 3, 0, 1]
+        sxx += __builtin_amdgcn_update_dpp(0, sxx, 0x4E, 0xF, 0xF, true);
+        if ((threadIdx.x & 3) == 0 && sx) { atomicAdd(&s_sx[p], sx); atomicAdd(&s_sxx[p], sxx); }
     };
 
     const int nloop = (nwords + 255) & ~255;
@@ -157,8 +170,9 @@ __global__ __launch_bounds__(256) void pack_stats_kernel(const Prob* __restrict_
                 uint32_t v[4];
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    const uint32_t b = (bits[j] >> (8 * q)) & 0xFFu;
-                    v[q] = (b & 3u) | (((b >> 2) & 3u) << 8) | (((b >> 4) & 3u) << 16) | (((b >> 6) & 3u) << 24);
+                    uint32_t b = (bits[j] >> (8 * q)) & 0xFFu;            // four 2-bit codes -> one code per byte, by spreading
+                    b = (b | (b << 12)) & 0x000F000Fu;
+                    v[q] = (b | (b << 6)) & 0x03030303u;
                 }
                 finish_word(ww[j], lv[j], pp[j], v);
             }
@@ -175,8 +189,9 @@ __global__ __launch_bounds__(256) void pack_stats_kernel(const Prob* __restrict_
                 const uint32_t bits = live ? *reinterpret_cast<const uint32_t*>(src + s_src[run] + (o >> 2)) : 0u;
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    const uint32_t b = (bits >> (8 * q)) & 0xFFu;
-                    v[q] = (b & 3u) | (((b >> 2) & 3u) << 8) | (((b >> 4) & 3u) << 16) | (((b >> 6) & 3u) << 24);
+                    uint32_t b = (bits >> (8 * q)) & 0xFFu;
+                    b = (b | (b << 12)) & 0x000F000Fu;
+                    v[q] = (b | (b << 6)) & 0x03030303u;
                 }
             } else {
                 int valid = s_len[run] - o;
@@ -223,7 +238,6 @@ __global__ __launch_bounds__(256) void pack_stats_kernel(const Prob* __restrict_
         }
         return;
     }
-    __shared__ double s_cov[64], s_mm[64], s_wmu[64];
     if (threadIdx.x < P) {
         const int p = threadIdx.x;
         const int m = pb.pop_raw_off[p + 1] - pb.pop_raw_off[p];

@@ -109,34 +109,56 @@ def write_bgzf_parallel(path, data, threads=8, level=1):
     return np.array(offs, dtype=np.int64), addr
 
 
-def write_panel_fast(index_path, data_path, rsid, chr_, bp, a1, a2, G, af, pop_sizes, threads=8, level=1):
+def write_panel_fast(index_path, data_path, rsid, chr_, bp, a1, a2, G, af, pop_sizes, threads=8, level=1, slab=20_000):
     """write_panel for panels of chromosome size (tens of thousands of 33 kB lines): the genotype part of every line is built
     as one array operation, the members are deflated on a thread pool.  Same format, same virtual offsets
-    (gauss.cpp:328-330, 755-763).  Returns the bytes of inflated data text."""
-    G = np.asarray(G, dtype=np.uint8)
-    S, N = G.shape
+    (gauss.cpp:328-330, 755-763).  G: the (S, N) genotype matrix, or a callable G(a, b) that returns rows [a, b) (a chromosome's
+    text is 3.4 GB: it is built and deflated `slab` lines at a time, every slab starting a new BGZF member -- members are
+    independent, so the file is what one pass would write except for one short member per slab).  Returns the bytes of
+    inflated data text."""
+    from concurrent.futures import ThreadPoolExecutor
+    S = len(bp)
     P = len(pop_sizes)
+    N = int(sum(pop_sizes))
     off = np.concatenate([[0], np.cumsum(pop_sizes)]).astype(int)
-    geno = np.full((S, N + P), ord(" "), dtype=np.uint8)      # P genotype strings, a blank behind each
-    for k in range(P):
-        geno[:, off[k] + k:off[k + 1] + k] = G[:, off[k]:off[k + 1]] + ord("0")
-    tails = [(" ".join(repr(float(x)) for x in af[s]) + "\n").encode() for s in range(S)]
-    lens = np.array([N + P + len(t) for t in tails], dtype=np.int64)
-    line_off = np.concatenate([[0], np.cumsum(lens)])
-    buf = bytearray(int(line_off[-1]))
-    mv = memoryview(buf)
-    for s_ in range(S):
-        o = int(line_off[s_])
-        mv[o:o + N + P] = geno[s_].tobytes()
-        mv[o + N + P:o + int(lens[s_])] = tails[s_]
-    del geno
-    member_off, _ = write_bgzf_parallel(data_path, buf, threads, level)
-    blk = line_off[:-1] // _BLOCK
-    fpos = (member_off[blk] << 16) | (line_off[:-1] - blk * _BLOCK)
-    cnt = G.sum(axis=1, dtype=np.int64)
-    idx = "".join(f"{rsid[s_]} {chr_[s_]} {bp[s_]} {a1[s_]} {a2[s_]} {cnt[s_] / (2.0 * N):.6f} {int(fpos[s_])}\n" for s_ in range(S)).encode()
-    write_bgzf_parallel(index_path, idx, threads, level)
-    return int(line_off[-1])
+    rows = G if callable(G) else (lambda a, b: np.asarray(G[a:b], dtype=np.uint8))
+    idx_lines = []
+    total, addr = 0, 0
+    with open(data_path, "wb") as f, ThreadPoolExecutor(max_workers=max(1, threads)) as pool:
+        for s0 in range(0, S, slab):
+            s1 = min(S, s0 + slab)
+            Gs = np.asarray(rows(s0, s1), dtype=np.uint8)
+            n = s1 - s0
+            geno = np.full((n, N + P), ord(" "), dtype=np.uint8)      # P genotype strings, a blank behind each
+            for k in range(P):
+                geno[:, off[k] + k:off[k + 1] + k] = Gs[:, off[k]:off[k + 1]] + ord("0")
+            tails = [(" ".join(repr(float(x)) for x in af[s0 + i]) + "\n").encode() for i in range(n)]
+            lens = np.array([N + P + len(t) for t in tails], dtype=np.int64)
+            line_off = np.concatenate([[0], np.cumsum(lens)])
+            buf = bytearray(int(line_off[-1]))
+            mv = memoryview(buf)
+            for i in range(n):
+                o = int(line_off[i])
+                mv[o:o + N + P] = geno[i].tobytes()
+                mv[o + N + P:o + int(lens[i])] = tails[i]
+            del geno
+            starts = list(range(0, len(mv), _BLOCK))
+            members = list(pool.map(lambda o: _bgzf_member(bytes(mv[o:o + _BLOCK]), level), starts, chunksize=64))
+            member_off = np.empty(len(members), dtype=np.int64)
+            for j, m in enumerate(members):
+                member_off[j] = addr
+                f.write(m)
+                addr += len(m)
+            blk = line_off[:-1] // _BLOCK
+            fpos = (member_off[blk] << 16) | (line_off[:-1] - blk * _BLOCK)
+            cnt = Gs.sum(axis=1, dtype=np.int64)
+            idx_lines.append("".join(f"{rsid[s0 + i]} {chr_[s0 + i]} {bp[s0 + i]} {a1[s0 + i]} {a2[s0 + i]} {cnt[i] / (2.0 * N):.6f} {int(fpos[i])}\n"
+                                     for i in range(n)))
+            total += int(line_off[-1])
+            del buf, mv, members
+        f.write(_bgzf_member(b"", level))                  # empty member = BGZF end-of-file marker
+    write_bgzf_parallel(index_path, "".join(idx_lines).encode(), threads, level)
+    return total
 
 
 def write_gwas(path, rsid, chr_, bp, a1, a2, z):

@@ -3,6 +3,8 @@ reference feeder (oracle/feeder_py.py), and the BGZF codec against the reference
 (oracle/_ref/libref_bgzf.so, compiled from /root/reference/src/bgzf.c where that tree exists)."""
 import ctypes as C
 import os
+import sys
+import subprocess
 
 import numpy as np
 import pytest
@@ -70,6 +72,32 @@ def test_bgzf_against_reference_codec(study, tmp_path):
     n = api.load_host().gauss_host_bgzf_copy(data.encode(), out.encode())
     assert n == len(idx)
     assert ref_read_all(out) == want
+
+
+@pytest.mark.parametrize("env", [{"GAUSS_NO_LIBDEFLATE": "1"}, {"GAUSS_BGZF_NO_MMAP": "1"}, {"GAUSS_NO_LIBDEFLATE": "1", "GAUSS_BGZF_NO_MMAP": "1"}])
+def test_bgzf_reader_fallbacks_read_the_same_bytes(study, tmp_path, env):
+    """README: GAUSS_NO_LIBDEFLATE=1 (inflate with zlib when libdeflate cannot be loaded) and GAUSS_BGZF_NO_MMAP=1 (FILE* reads
+    when the file cannot be mapped) are the reader's fall-backs.  Each in a process of its own (the inflater is chosen once per
+    process): the C++ reader + writer round trip of the panel's data file, and one window of the text feeder, give the bytes and
+    the table the default reader gives."""
+    data = study["paths"]["data.gz"]
+    inp, idx, dat, desc = _files(study)
+    code = (
+        "import sys, hashlib; sys.path.insert(0, %r)\n"
+        "from gauss_amd import api\n"
+        "n = api.load_host().gauss_host_bgzf_copy(%r.encode(), sys.argv[1].encode())\n"
+        "pr = api.Prepared(api.KIND_DIST, 22, 1_200_001, 1_800_000, 200_000, study_pop='EUR', input_file=%r, reference_index_file=%r,\n"
+        "                  reference_data_file=%r, reference_pop_desc_file=%r)\n"
+        "h = hashlib.sha256(pr.geno_m().tobytes() + pr.geno_u().tobytes()).hexdigest()\n"
+        "print(n, pr.M, pr.U, h)\n" % (ROOT, data, inp, idx, dat, desc))
+    outs = []
+    for k, e in enumerate(({}, env)):
+        out = str(tmp_path / f"copy{k}.gz")
+        run = subprocess.run([sys.executable, "-c", code, out], env=dict(os.environ, GAUSS_AUTO_PACK="0", **e), capture_output=True, text=True, timeout=300)
+        assert run.returncode == 0, run.stderr[-2000:]
+        outs.append((run.stdout.strip(), "\n".join(fp.Bgzf(out).lines())))
+    assert outs[0] == outs[1]
+    assert int(outs[0][0].split()[1]) > 10
 
 
 def _check_prepared(pr, exp_vec, exp_meas, exp_unme, mix):
@@ -429,6 +457,15 @@ def test_fast_text_panel_writer_equals_the_line_by_line_writer(study, packed, tm
     out = str(tmp_path / "fast.gpk")
     assert api.pack_panel(idx, dat, study["paths"]["desc.txt"], out) == len(study["G"])
     assert open(out, "rb").read() == open(packed, "rb").read()
+    # slab by slab (a chromosome's 3.4 GB of text is never held whole): rows through a callable, every slab a fresh member
+    idx2, dat2 = str(tmp_path / "slab_index.gz"), str(tmp_path / "slab_data.gz")
+    G = study["G"]
+    n2 = panel.write_panel_fast(idx2, dat2, study["rsid"], np.full(len(G), 22), study["bp"], study["a1"], study["a2"], lambda a, b: G[a:b],
+                                study["af"], sizes, threads=3, slab=97)
+    assert gzip.open(dat2).read() == text and n2 == len(text)
+    out2 = str(tmp_path / "slab.gpk")
+    assert api.pack_panel(idx2, dat2, study["paths"]["desc.txt"], out2) == len(G)
+    assert open(out2, "rb").read() == open(packed, "rb").read()
 
 
 def test_window_snp_maps_live_in_pooled_blocks(study, packed):

@@ -407,7 +407,7 @@ def test_per_population_ld_matches_oracle(ctx):
 
 
 @pytest.mark.parametrize("wscale,lam", [(1.0, 0.1), (3.0, 0.1), (3.0, 2e-5), (8.0, 1e-3), (40.0, 1e-3), (1.0, 0.0)])
-def test_shift_certificate_never_changes_the_answer(ctx, wscale, lam):
+def test_shift_certificate_never_changes_the_answer(ctx, wscale, lam, monkeypatch):
     """The factorisation of B11 - eps I is skipped when lambda - (sum w - 1)+ * sum_p w_p |mu_p / sd|^2 certifies
     lambda_min(B11) > eps (k_solve.hip:shift_cert_kernel).  Whatever the certificate decides -- weights far above
     1, lambda next to eps, lambda = 0 -- z, info and the MakePosDef decision must equal the oracle's, which runs
@@ -416,6 +416,13 @@ def test_shift_certificate_never_changes_the_answer(ctx, wscale, lam):
     gm, gu, z1 = split_window(p, 40)
     w = p["w"] * wscale
     got = hotpath.impute_window(1, gm, gu, p["off"], w, z1, lam=lam, ctx=ctx)
+    # GAUSS_NO_SHIFT_CERT=1 (README: the supported fallback that never trusts the bound and always factors B11 - eps I too): the
+    # same decision and the same bits, window by window
+    monkeypatch.setenv("GAUSS_NO_SHIFT_CERT", "1")
+    exact = hotpath.impute_window(1, gm, gu, p["off"], w, z1, lam=lam, ctx=ctx)
+    monkeypatch.delenv("GAUSS_NO_SHIFT_CERT")
+    assert exact["status"] == got["status"]
+    assert np.array_equal(exact["z"], got["z"], equal_nan=True) and np.array_equal(exact["info"], got["info"], equal_nan=True)
     want = oracle.run_impute(1, gm, gu, p["off"], w, z1, lam=lam, want_mats=True)
     if want["mpd"] < 0:       # weights far above 1 can turn a self-covariance negative: NaN everywhere, like the reference
         assert got["status"] & 2 and np.all(np.isnan(got["z"])) and np.all(np.isnan(want["z"]))
