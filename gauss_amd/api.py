@@ -38,7 +38,7 @@ HOST_SYMBOLS = [
     "gauss_prepared_geno_u", "gauss_prepared_pop_off", "gauss_prepared_pop_wgt", "gauss_prepared_z1",
     "gauss_prepared_gene_off", "gauss_prepared_window_desc", "gauss_prepared_finish", "gauss_prepared_free",
     "gauss_host_bgzf_copy", "gauss_host_set_threads",
-    "gauss_host_panel_resident", "gauss_host_panel_evict", "gauss_host_impute_chromosome", "gauss_host_panel_cache", "gauss_table_n_messages",
+    "gauss_host_panel_resident", "gauss_host_panel_evict", "gauss_host_impute_chromosome", "gauss_host_impute_genome", "gauss_host_panel_cache", "gauss_table_n_messages",
     "gauss_table_message", "gauss_table_strcol_fixed", "gauss_host_panel_device_rows", "gauss_prepared_store_rows",
     "gauss_host_jepeg_gene_tail", "gauss_host_plan_cost",
 ]
@@ -145,6 +145,8 @@ def load_host():
     h.gauss_prepared_store_rows.argtypes = [_vp, ipp, ipp, ipp, C.POINTER(C.c_int)]
     h.gauss_host_impute_chromosome.argtypes = [_vp, C.c_int, C.c_int, _i64, _i64, _i64, _i64, _cp, _strs, _dp, C.c_int, _cp, _cp, _cp, _cp,
                                                _dbl, C.c_int, C.c_int, C.c_int, C.POINTER(_vp), C.POINTER(ChromStats)]
+    h.gauss_host_impute_genome.argtypes = [_vp, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(_i64), C.POINTER(_i64), _i64, _i64, _cp, _strs, _dp,
+                                           C.c_int, _cp, _cp, _cp, _cp, _dbl, C.c_int, C.c_int, C.c_int, C.POINTER(_vp), C.POINTER(ChromStats)]
     h.gauss_host_panel_cache.argtypes = [_cp, _cp, _cp, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int64)]
     h.gauss_table_n_messages.argtypes = [_vp]
     h.gauss_table_message.restype = _cp
@@ -497,6 +499,43 @@ def impute_chromosome(kind, chr, start_bp, end_bp, wing_size, input_file, refere
     h.gauss_table_free(out)
     stats = {k: getattr(st, k) for k, _ in ChromStats._fields_}
     return ChromResult(cols, windows, stats, msgs)
+
+
+def impute_genome(kind, chromosomes, wing_size, input_file, reference_data_file, reference_pop_desc_file, study_pop=None,
+                  pop_wgt_df=None, af1_cutoff=None, window_size=1_000_000, rank=0, world=1, depth=2, ctx=None, reference_index_file=None,
+                  raise_on_error=True):
+    """gauss_host_impute_genome: gauss_host_impute_chromosome for every (chr, start_bp, end_bp) of `chromosomes`, `depth` calls in
+    flight on the context at a time (host threads of the library), so that one call's host part runs under the other's GPU work.
+    Returns one ChromResult per chromosome, identical to what impute_chromosome returns for it (raise_on_error=False: None in
+    the place of a chromosome that failed, and the first failure's message as a second return value)."""
+    h = load_host()
+    names, w, n = (None, None, 0) if pop_wgt_df is None else _pop_wgt(pop_wgt_df)
+    nc = len(chromosomes)
+    chrs = np.ascontiguousarray([c[0] for c in chromosomes], dtype=np.int32)
+    lo = np.ascontiguousarray([c[1] for c in chromosomes], dtype=np.int64)
+    hi = np.ascontiguousarray([c[2] for c in chromosomes], dtype=np.int64)
+    outs = (_vp * nc)()
+    sts = (ChromStats * nc)()
+    rc = h.gauss_host_impute_genome(_ctx(ctx), int(kind), nc, chrs.ctypes.data_as(C.POINTER(C.c_int32)), lo.ctypes.data_as(C.POINTER(_i64)),
+                                    hi.ctypes.data_as(C.POINTER(_i64)), int(wing_size), int(window_size), _enc(study_pop), names,
+                                    None if w is None else w.ctypes.data_as(_dp), n, _enc(input_file), _enc(reference_index_file),
+                                    _enc(reference_data_file), _enc(reference_pop_desc_file), _af(af1_cutoff), int(rank), int(world), int(depth),
+                                    outs, sts)
+    res = []
+    for c in range(nc):
+        if not outs[c]:
+            res.append(None)
+            continue
+        out = _vp(outs[c])
+        cols = _columns(h, out)
+        windows = _named(h, out)["windows"]
+        msgs = [h.gauss_table_message(out, k).decode() for k in range(h.gauss_table_n_messages(out))]
+        h.gauss_table_free(out)
+        res.append(ChromResult(cols, windows, {k: getattr(sts[c], k) for k, _ in ChromStats._fields_}, msgs))
+    if not raise_on_error:
+        return res, (h.gauss_host_last_error().decode() if rc != 0 else None)
+    _hcheck(rc)
+    return res
 
 
 class Prepared:

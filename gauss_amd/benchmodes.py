@@ -157,6 +157,29 @@ def emulate_world_e2e(rig, ch, files, wing, warm_one_s, world=8, calls=3):
         cores = os.cpu_count() or 1
     per = sweep(world)                   # the ranks share THIS box's cores (16 for the one-GPU lease: two host threads a rank)
     ample = sweep(0)                     # a rank with eight host threads of its own (an 8-GPU node has >= 16 cores per GPU)
+
+    def genome(r, w, n_chrom, local_world):
+        """gauss_host_impute_genome: n_chrom chromosomes (the chr22 files stand in for each), two calls in flight; ms per chromosome"""
+        old = os.environ.get("LOCAL_WORLD_SIZE")
+        if local_world:
+            os.environ["LOCAL_WORLD_SIZE"] = str(local_world)
+        try:
+            kw = dict(chromosomes=[(22, lo, hi)] * n_chrom, wing_size=wing, input_file=files["gwas"], reference_data_file=files["panel"],
+                      reference_pop_desc_file=files["desc"], rank=r, world=w, depth=2, ctx=rig.ctx, **sa)
+            api.impute_genome(**dict(kw, chromosomes=kw["chromosomes"][:3]))       # warm-up
+            t0 = time.perf_counter()
+            res = api.impute_genome(**kw)
+            dt = (time.perf_counter() - t0) / n_chrom
+        finally:
+            if old is None:
+                os.environ.pop("LOCAL_WORLD_SIZE", None)
+            else:
+                os.environ["LOCAL_WORLD_SIZE"] = old
+        return dt * 1e3, float(np.mean([q.stats["gpu_span_ms"] for q in res])), int(res[0].stats["imputed"])
+    n_genome = 22                        # a genome's worth of chromosome-sized calls: the pipeline's start-up and tail are paid once
+    one_ms, one_span, one_imputed = genome(0, 1, n_genome, 0)
+    g_per = [genome(r, world, n_genome, world) for r in range(world)]
+    g_slow = max(q[0] for q in g_per)
     slow = max(q["warm_ms"] for q in per)
     slow_a = max(q["warm_ms"] for q in ample)
     return {"world": world, "calls_per_rank": calls, "per_rank_warm_ms": [q["warm_ms"] for q in per], "slowest": slow,
@@ -166,6 +189,16 @@ def emulate_world_e2e(rig, ch, files, wing, warm_one_s, world=8, calls=3):
             "with_eight_host_threads_per_rank": {"per_rank_warm_ms": [q["warm_ms"] for q in ample], "slowest": slow_a,
                                                  "predicted_efficiency": warm_one_s * 1e3 / (world * slow_a),
                                                  "host_ms_not_overlapped": [q["host_ms_not_overlapped"] for q in ample]},
+            "genome_pipeline": {
+                "what": "gauss_host_impute_genome: chromosome after chromosome with TWO calls in flight on the rank's context (the chr22 files "
+                        "stand in for every one of %d chromosomes), a share of <= 8 windows as one batch: one call's host part runs under the "
+                        "other's GPU work" % n_genome,
+                "chromosomes": n_genome,
+                "per_rank_ms_per_chromosome": [q[0] for q in g_per], "per_rank_gpu_span_ms": [q[1] for q in g_per], "slowest": g_slow,
+                "one_rank_ms_per_chromosome": one_ms, "one_rank_gpu_span_ms": one_span,
+                "predicted_efficiency": one_ms / (world * g_slow),
+                "imputed_per_chromosome": one_imputed, "imputed_snps_per_s_one_rank": one_imputed / (one_ms * 1e-3),
+                "imputed_snps_per_s_predicted_world": one_imputed / (g_slow * 1e-3)},
             "imputed_total": int(sum(q["imputed"] for q in per)), "per_rank": per,
             "note": "every rank's share of gauss_host_impute_chromosome(rank, world) timed alone on one GPU, panel resident; the headline "
                     "figures give a rank 1/world of this box's cores (LOCAL_WORLD_SIZE = world, as under torchrun on one node), "

@@ -2532,6 +2532,8 @@ double gauss_host_plan_cost(int n_measured, int n_unmeasured) { return issued_co
 // column "window"; named matrix "windows" [n_windows x 6]: start_bp end_bp owner status measured unmeasured
 // (status 0 done, 1 skipped by the ">10" guards, 2 failed, -1 another rank's).
 // ------------------------------------------------------------------------------------------
+static thread_local int tl_calls_in_flight = 1;       // > 1: this thread's call is one of several the genome driver keeps in flight
+
 int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t start_bp, int64_t end_bp, int64_t wing_size,
                                  int64_t window_size, const char* study_pop, const char* const* pop_names,
                                  const double* pop_wgts, int n_pop_wgt, const char* input_file, const char* reference_index_file,
@@ -2697,6 +2699,10 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
     // batch starts when the rows it names have landed -- so the early batches are smaller then (six batches, the first three
     // 0.3 / 0.5 / 0.8 of a share): the GPU starts on the first fifth of the rows and stays busy behind the upload.
     const bool auto_batches = n_batches < 1;
+    // A share of a few windows whose call is one of SEVERAL in flight on this context (gauss_host_impute_genome: the other thread's
+    // call keeps the GPU busy while this one's data layer runs) goes as ONE batch: a job of one or two windows has nothing to
+    // hide its factorisation chain under, and the pipeline's overlap comes from the neighbouring call.
+    if (n_batches < 1 && tl_calls_in_flight > 1 && mine.size() <= 8) n_batches = 1;
     // (A LEAD batch of one window -- so that the GPU starts after ONE window's data layer instead of a 0.3-share batch's -- was
     // measured in round 5 and is not built: the GPU started 0.8 ms earlier and the chromosome's span grew by 0.9 ms, a job of one
     // window has nothing to hide its factorisation chain under; 8-rank shares 7.4-8.4 ms against 7.8-8.2.  DESIGN.md 9e item 10.)
@@ -2996,6 +3002,57 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
     }
     if (stats) *stats = st;
     *out = all.release();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// A genome: the loop over chromosomes above the loop over windows.  One rank's share of ONE chromosome is a few
+// milliseconds of GPU work behind ~2.5 ms of host work that nothing overlaps (plan, the first batch's data layer and job, the
+// last batch's tables): at 8 ranks the host part is a third of the call (bench.py end_to_end.emulated_world8: 7.8-8.6 ms per
+// rank for 5.3 ms of GPU span).  Here `depth` host threads (default 2) take the chromosomes in order, each running
+// gauss_host_impute_chromosome on the SAME context: while one call's data layer runs, the other call's batches keep the GPU busy
+// (jobs of different calls simply follow each other on the context's queues; the library's job and row-store calls are
+// thread-safe per context).  Measured on the chr22 study, rank r of 8 (tools/e2e_pipeline_probe.py): 8.0-8.3 ms per call one
+// after the other, 5.7 ms with two in flight, for 5.3-5.4 ms of GPU span -- the host latency is hidden.
+// Tables and stats come back per chromosome; a chromosome that fails leaves out[c] = NULL and its message in the returned error
+// (the first failure's), the others still complete.
+// ------------------------------------------------------------------------------------------
+int gauss_host_impute_genome(gauss_ctx* ctx, int kind, int n_chrom, const int32_t* chr, const int64_t* start_bp, const int64_t* end_bp,
+                             int64_t wing_size, int64_t window_size, const char* study_pop, const char* const* pop_names,
+                             const double* pop_wgts, int n_pop_wgt, const char* input_file, const char* reference_index_file,
+                             const char* reference_data_file, const char* reference_pop_desc_file, double af1_cutoff,
+                             int rank, int world, int depth, gauss_table** out, gauss_chrom_stats* stats)
+{
+    if (!ctx || n_chrom < 1 || !chr || !start_bp || !end_bp || !out) return herr("bad arguments to gauss_host_impute_genome");
+    depth = std::max(1, std::min(depth <= 0 ? 2 : depth, std::min(n_chrom, 4)));
+    for (int c = 0; c < n_chrom; c++) out[c] = nullptr;
+    std::atomic<int> next{0};
+    std::mutex emu;
+    std::string first_err;
+    int n_failed = 0;
+    auto work = [&]() {
+        tl_calls_in_flight = depth;
+        for (int c = next.fetch_add(1); c < n_chrom; c = next.fetch_add(1)) {
+            gauss_chrom_stats st;
+            memset(&st, 0, sizeof(st));
+            const int rc = gauss_host_impute_chromosome(ctx, kind, chr[c], start_bp[c], end_bp[c], wing_size, window_size, study_pop, pop_names,
+                                                        pop_wgts, n_pop_wgt, input_file, reference_index_file, reference_data_file,
+                                                        reference_pop_desc_file, af1_cutoff, rank, world, 0, &out[c], &st);
+            if (stats) stats[c] = st;
+            if (rc != 0) {
+                std::lock_guard<std::mutex> lock(emu);
+                n_failed++;
+                if (first_err.empty()) first_err = "chromosome " + std::to_string(chr[c]) + " (call " + std::to_string(c) + "): " + gauss_host_last_error();
+                out[c] = nullptr;
+            }
+        }
+        tl_calls_in_flight = 1;
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < depth; t++) th.emplace_back(work);
+    work();
+    for (std::thread& x : th) x.join();
+    if (n_failed) return herr("%s%s", first_err.c_str(), n_failed > 1 ? " (and more)" : "");
     return 0;
 }
 

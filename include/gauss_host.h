@@ -238,6 +238,19 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
                                  const double* pop_wgts, int n_pop_wgt, const char* input_file, const char* reference_index_file,
                                  const char* reference_data_file, const char* reference_pop_desc_file, double af1_cutoff,
                                  int rank, int world, int n_batches, gauss_table** out, gauss_chrom_stats* stats);
+/* The loop over chromosomes above that loop over windows: gauss_host_impute_chromosome for chromosome chr[c] over
+ * [start_bp[c], end_bp[c]], c = 0 .. n_chrom-1, the same study / panel files and arguments for all of them (the reference's user
+ * passes the same files and another `chr` per call, dist.cpp:30-60), with `depth` calls in flight on the context at any time
+ * (<= 0: 2; host threads of the library): while one call's host part runs -- plan, data layer, job tables, result tables: ~2.5 ms
+ * that nothing overlaps when a rank's share of a chromosome is a few windows -- the other call's batches keep the GPU busy.
+ * out[c] / stats[c] (stats may be NULL) receive chromosome c's table and statistics exactly as gauss_host_impute_chromosome
+ * returns them (same bits); a chromosome that fails leaves out[c] = NULL, the others still complete, and the call returns -1
+ * with the first failure's message.  The caller frees every table. */
+int gauss_host_impute_genome(gauss_ctx* ctx, int kind, int n_chrom, const int32_t* chr, const int64_t* start_bp, const int64_t* end_bp,
+                             int64_t wing_size, int64_t window_size, const char* study_pop, const char* const* pop_names,
+                             const double* pop_wgts, int n_pop_wgt, const char* input_file, const char* reference_index_file,
+                             const char* reference_data_file, const char* reference_pop_desc_file, double af1_cutoff,
+                             int rank, int world, int depth, gauss_table** out, gauss_chrom_stats* stats);
 /* The host part of jepeg()/jepegmix() for ONE gene, given the CorG block the GPU produced (diagonal 1 + lambda):
  * Gene::RunJepeg bookkeeping + CalJepegPval from W on (gene.cpp:88-185, 317-550).  corg [n x n], has / wgt [n x 6]
  * row-major (category present, category weight).  top_categ / top_snp are indices (-1 when df = 0).  No GPU needed. */

@@ -349,6 +349,40 @@ def test_gpu_native_chromosome_failed_first_call_leaves_no_half_uploaded_panel(c
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world", [1, 2])
+def test_gpu_native_genome_driver_equals_the_chromosome_calls(ctx, tmp_path, world):
+    """gauss_host_impute_genome: the loop over chromosomes with two calls in flight on one context (host threads of the library:
+    one call's data layer and tables run under the other call's GPU work).  Every chromosome's table and window matrix are what
+    gauss_host_impute_chromosome returns for it alone, bit for bit, for one rank and for the ranks of a two-rank run; a
+    chromosome whose arguments are bad fails alone."""
+    st = make_study(tmp_path)
+    p = st["paths"]
+    gpk = str(tmp_path / "panel.gpk")
+    assert api.pack_panel(p["index.gz"], p["data.gz"], p["desc.txt"], gpk) > 0
+    kw = dict(kind=api.KIND_DISTMIX, pop_wgt_df=WGT, window_size=250_000, input_file=p["gwas.txt"], reference_data_file=gpk,
+              reference_pop_desc_file=p["desc.txt"], ctx=ctx, wing_size=200_000)
+    chroms = [(22, 1_000_001, 2_500_000), (22, 2_500_001, 4_000_000), (22, 1_000_001, 4_000_000), (22, 1_750_001, 3_250_000),
+              (21, 1_000_001, 2_000_000), (22, 1_000_001, 1_500_000)]
+    for rank in range(world):
+        want = [api.impute_chromosome(chr=c, start_bp=a, end_bp=b, rank=rank, world=world, **kw) for c, a, b in chroms]
+        for depth in (1, 2, 3):
+            got = api.impute_genome(chromosomes=chroms, rank=rank, world=world, depth=depth, **kw)
+            assert len(got) == len(want)
+            for g, w in zip(got, want):
+                assert list(g.columns) == list(w.columns)
+                for c in g.columns:
+                    x, y = g.columns[c], w.columns[c]
+                    assert np.array_equal(x, y, equal_nan=True) if x.dtype.kind == "f" else np.array_equal(x, y), (depth, c)
+                assert np.array_equal(g.windows, w.windows)
+                assert g.stats["imputed"] == w.stats["imputed"] and g.stats["n_failed"] == 0
+    bad = chroms[:2] + [(22, 3_000_000, 2_000_000)] + chroms[2:4]
+    got, err = api.impute_genome(chromosomes=bad, depth=2, raise_on_error=False, **kw)
+    assert got[2] is None and "call 2" in err and all(g is not None for k, g in enumerate(got) if k != 2)
+    assert np.array_equal(got[3].columns["z"], want[2].columns["z"]) if world == 1 else True
+    api.panel_evict(ctx=ctx)
+
+
+@pytest.mark.gpu
 def test_gpu_native_chromosome_isolates_a_failing_window(ctx, tmp_path):
     """A window whose data layer fails (here: the GWAS file lists one SNP with both allele orders inside that
     window, the reference's "duplicates" error, gauss.cpp:388-391) is reported, the other windows still come back."""

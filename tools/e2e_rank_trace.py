@@ -1,6 +1,6 @@
 """Where one rank's share of the files -> table path spends its time: gauss_host_impute_chromosome(rank, world) on the chr22-sized
 packed panel with GAUSS_TRACE=chrom, warm, as `bench.py`'s end_to_end.emulated_world8 times it.
-    python tools/e2e_rank_trace.py [rank] [world] > gpurun_out/e2e_rank_trace.txt 2>&1"""
+    python tools/e2e_rank_trace.py [rank] [world] [n_batches] > gpurun_out/e2e_rank_trace.txt 2>&1"""
 import argparse
 import os
 import sys
@@ -14,6 +14,7 @@ sys.path.insert(0, ROOT)
 def main():
     rank = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     world = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+    n_batches = int(sys.argv[3]) if len(sys.argv) > 3 else 0
     import bench
     from gauss_amd import api, benchmodes, workload
     args = bench.parse_args(["--no-cpu-baseline"])
@@ -24,7 +25,7 @@ def main():
     sa = benchmodes.study_args(ch, files)
     lo, hi = benchmodes.chromosome_span(ch)
     kw = dict(chr=22, start_bp=lo, end_bp=hi, wing_size=args.wing, input_file=files["gwas"], reference_data_file=files["panel"],
-              reference_pop_desc_file=files["desc"], rank=rank, world=world, n_batches=0, ctx=rig.ctx, **sa)
+              reference_pop_desc_file=files["desc"], rank=rank, world=world, n_batches=n_batches, ctx=rig.ctx, **sa)
     for k in range(3):
         api.impute_chromosome(**kw)
     os.environ["GAUSS_TRACE"] = "chrom,job"
