@@ -153,6 +153,11 @@ struct gauss_ctx {
     size_t landing_bytes = 0;
     std::vector<hipEvent_t> ev_pool;         // "chunk g has landed" events, reused by every streamed call
     std::mutex stream_mu;                    // one streamed call at a time per context (they share landing buffer and worker)
+    // One run is queued at a time per context: a run's kernels go onto several queues, and a merged run's waiting kernels are only
+    // sound if every queue sees the runs in the SAME order -- two host threads that interleaved their launches (the genome driver
+    // keeps two chromosome calls in flight on one context) could put run B's wait for its Gram items on the chain queue in front of
+    // run A's chain, which run A's product -- in front of run B's Gram launch on the main queue -- waits for: a cycle.
+    std::mutex run_mu;
     hipStream_t upload = nullptr;            // asynchronous row-store uploads (gauss_store_upload_async)
     std::map<const void*, std::shared_ptr<StoreUpload>> uploads;      // by device pointer (guarded by mu); shared: a waiter keeps its entry alive
     int gram_i8 = 0;

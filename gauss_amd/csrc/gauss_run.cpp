@@ -70,6 +70,7 @@ static int job_queue_run(gauss_job* job, bool solve, int par, bool allow_merged)
     hipStream_t st = ctx->stream;
     const gauss_job::RunEvents& ev = job->rev[par];      // this run's cross-queue events (the parity's own set)
     job->queue_touched = true;
+    std::lock_guard<std::mutex> run_lock(ctx->run_mu);         // every queue sees this context's runs in the same order (gauss_job.h)
     // ONE Gram launch whose B11 items count themselves off for a spinning kernel at the head of the chain queue is only sound
     // while that kernel cannot sit in front of work it waits for, i.e. while every priority stream of the library on this
     // device owns its hardware queue (gauss_ctx.cpp).  The decision and the queuing are one step: a context whose streams

@@ -379,3 +379,54 @@ def test_two_contexts_run_merged_jobs_at_the_same_time(ctx, monkeypatch, force):
             assert np.array_equal(x["z"], y["z"]) and np.array_equal(x["info"], y["info"])
     solo.close()
     store.close()
+
+
+@pytest.mark.gpu
+def test_threads_share_one_context_with_merged_runs(ctx, monkeypatch):
+    """Several host threads queue merged runs on ONE context at the same time (what gauss_host_impute_genome does with its two
+    chromosome calls in flight).  A run's kernels go onto three queues and its waiting kernels rely on every queue seeing the
+    context's runs in the same order; the library queues one run at a time per context (gauss_ctx::run_mu).  Three threads, their
+    own job each, ten runs each: every result the single-threaded one, no give-up, nothing near a stall."""
+    import threading
+    import time
+    from gauss_amd import hotpath, panel
+    from helpers import small_panel
+    p = small_panel(n_snp=1500, scale=0.05, seed=23)
+    rows2, src_off = panel.pack2bit(p["G"], p["off"])
+    monkeypatch.setenv("GAUSS_CHAIN_ASIDE", "2")
+    monkeypatch.setenv("GAUSS_CHAIN_MERGED", "2")
+    store = hotpath.RowStore(rows2, ctx=ctx)
+    wins = _merged_job_windows(store, src_off, p, np.random.default_rng(6))
+    jobs = [hotpath.Job(wins, ctx=ctx, on_device=True) for _ in range(3)]
+    jobs[0].run()
+    want = jobs[0].fetch()
+    c0 = ctx.counters()
+    results, errors, slowest = [[], [], []], [], [0.0] * 3
+    gate = threading.Barrier(3)
+
+    def worker(k):
+        try:
+            gate.wait()
+            for _ in range(10):
+                t0 = time.perf_counter()
+                jobs[k].run()
+                results[k].append(jobs[k].fetch())
+                slowest[k] = max(slowest[k], time.perf_counter() - t0)
+        except Exception as ex:      # pragma: no cover
+            errors.append((k, repr(ex)))
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(3)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    c1 = ctx.counters()
+    assert not errors, errors
+    assert c1["merged"] - c0["merged"] == 30 and c1["giveups"] == c0["giveups"], (c0, c1)
+    assert max(slowest) < 1.0, slowest
+    for k in range(3):
+        for r in results[k]:
+            for x, y in zip(want, r):
+                assert np.array_equal(x["z"], y["z"]) and np.array_equal(x["info"], y["info"])
+    for j in jobs:
+        j.close()
+    store.close()
