@@ -1058,23 +1058,20 @@ __global__ __launch_bounds__(256, 2) void impute_gemm_kernel(const Prob* __restr
                 b[n][0] = *reinterpret_cast<const f64x2*>(rb + 16 * n * GLD);
                 b[n][1] = *reinterpret_cast<const f64x2*>(rb + 16 * n * GLD + 2);
             }
-            // every row tile's X fragments are requested up front, whether or not the tile is live at this stage (the image holds all
-            // 128 rows): read inside the `st < lim[i]` branches each pair of ds_read_b128 sat right in front of the sixteen MFMAs that
-            // need it, four times a stage with nothing of this wave to cover the LDS latency (round 5: matrix pipes busy 0.70)
-            f64x2 a[4][2];
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                a[i][0] = *reinterpret_cast<const f64x2*>(xa + 16 * i * GLD);
-                a[i][1] = *reinterpret_cast<const f64x2*>(xa + 16 * i * GLD + 2);
-            }
+            // (Round 5 tried to take the X fragment reads out from in front of their MFMAs -- all four row tiles' fragments requested at
+            // the top of the stage, or tile i + 1's before tile i's sixteen MFMAs; the ISA then waits with lgkmcnt(5), (4), ... instead
+            // of four exposed LDS round trips a stage -- and the product got SLOWER, 1.22-1.24 ms against 1.12: with two workgroups per
+            // CU the other workgroup's wave fills exactly those gaps, and the early reads only lengthen the fragments' lifetimes.)
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 if (st < lim[i]) {                              // wave-uniform
+                    const f64x2 a0 = *reinterpret_cast<const f64x2*>(xa + 16 * i * GLD);
+                    const f64x2 a1 = *reinterpret_cast<const f64x2*>(xa + 16 * i * GLD + 2);
 #pragma unroll
                     for (int ks = 0; ks < 4; ks++)
 #pragma unroll
                         for (int n = 0; n < NU; n++)
-                            acc[i][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][ks >> 1][ks & 1], b[n][ks >> 1][ks & 1],
+                            acc[i][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(ks < 2 ? a0[ks & 1] : a1[ks & 1], b[n][ks >> 1][ks & 1],
                                                                              acc[i][n], 0, 0, 0);
                 }
             }
