@@ -223,3 +223,30 @@ ChromTable distmix_chromosome_body(int chr, long long start_bp, long long end_bp
   gauss_table_free(t);
   return out;
 }
+
+// ---- section 5f: a genome per call (two chromosome calls in flight on the context) ----
+std::vector<long long> distmix_genome_body(const std::vector<int>& chr, const std::vector<long long>& start_bp, const std::vector<long long>& end_bp,
+                                           long long wing_size, long long window_size, const std::vector<std::string>& names,
+                                           const std::vector<double>& wgts, const std::string& input_file, const std::string& packed_panel,
+                                           const std::string& desc, int rank, int world) {
+  const int n = (int)chr.size();
+  std::vector<int32_t> c(chr.begin(), chr.end());
+  std::vector<int64_t> lo(start_bp.begin(), start_bp.end()), hi(end_bp.begin(), end_bp.end());
+  std::vector<const char*> np;
+  for (auto& s : names) np.push_back(s.c_str());
+  std::vector<gauss_table*> t((size_t)n, nullptr);
+  std::vector<gauss_chrom_stats> st((size_t)n);
+  const int rc = gauss_host_impute_genome(gauss_hip_ctx(), GAUSS_KIND_DISTMIX, n, c.data(), lo.data(), hi.data(), wing_size, window_size, NULL,
+                                          np.data(), wgts.data(), (int)np.size(), input_file.c_str(), NULL, packed_panel.c_str(), desc.c_str(), NAN,
+                                          rank, world, /*depth*/2, t.data(), st.data());
+  std::vector<long long> imputed;
+  for (int k = 0; k < n; k++) {
+    imputed.push_back(t[(size_t)k] ? (long long)st[(size_t)k].imputed : -1);       // -1: this chromosome's call failed, the others are complete
+    if (st[(size_t)k].n_merged_giveups) (void)0;                                    // batches repaired inside their fetch (normally 0)
+    gauss_table_free(t[(size_t)k]);
+  }
+  int64_t counters[4];
+  (void)gauss_hip_counters(gauss_hip_ctx(), counters);                              // merged / demoted / give-ups / failed re-runs
+  if (rc != 0) (void)gauss_host_last_error();
+  return imputed;
+}
