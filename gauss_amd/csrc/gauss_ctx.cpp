@@ -70,6 +70,36 @@ bool queues_exclusive(int device)
     return r.hi[d] <= cap && r.lo[d] <= cap;
 }
 
+// Do kernels of `waiter_q` and `setter_q` run side by side?  A one-wave kernel on waiter_q waits (a few milliseconds at most) for
+// a counter that a kernel queued AFTERWARDS on setter_q advances.  On different hardware queues the second kernel runs at once and the
+// first returns; on a shared queue the second sits behind the first, which gives up at its bound.  This is the situation a merged
+// Gram launch must never be in (its waiting kernels are queued on the chain and low-priority queues, what they wait for on the main
+// queue), seen directly -- whatever the runtime's mapping rule, and whoever else holds priority streams in the process.
+static bool queues_side_by_side(gauss_ctx* c, hipStream_t waiter_q, hipStream_t setter_q)
+{
+    void* d = nullptr;
+    if (hipMalloc(&d, 256) != hipSuccess) { (void)hipGetLastError(); return false; }
+    unsigned long long* cnt = (unsigned long long*)d;
+    int* st = (int*)((char*)d + 128);
+    bool ok = hipMemset(d, 0, 256) == hipSuccess;
+    if (ok) {
+        // first launches load the code object and make the runtime set up both queues: not part of what is timed
+        launch_count_up(cnt, waiter_q);
+        launch_count_up(cnt, setter_q);
+        ok = hipStreamSynchronize(waiter_q) == hipSuccess && hipStreamSynchronize(setter_q) == hipSuccess;
+    }
+    if (ok) {
+        launch_wait_count_for(cnt, 3, st, waiter_q, 5000.0);       // counter is 2 now; 5 ms bound
+        launch_count_up(cnt, setter_q);
+        ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(waiter_q) == hipSuccess && hipStreamSynchronize(setter_q) == hipSuccess;
+    }
+    int gave_up = 1;
+    if (ok) ok = hipMemcpy(&gave_up, st, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
+    (void)hipFree(d);
+    (void)hipGetLastError();
+    return ok && gave_up == 0;
+}
+
 int ctx_stream_create(gauss_ctx* c, hipStream_t* out, StreamClass cls)
 {
     if (cls == STREAM_NORMAL) { HIPCHK(hipStreamCreateWithFlags(out, hipStreamNonBlocking)); return GAUSS_OK; }
@@ -240,6 +270,7 @@ int gauss_hip_init(int device, gauss_ctx** out_ctx)
         ctx_stream_destroy(c, &c->stream, c->main_cls);
         return rc;
     }
+    if (c->chain && c->side) c->queues_probed_distinct = queues_side_by_side(c, c->chain, c->stream) && queues_side_by_side(c, c->side, c->stream);
     c->prepin = std::thread([c]() {
         (void)hipSetDevice(c->device);
         {
@@ -350,6 +381,18 @@ int gauss_hip_counters(gauss_ctx* ctx, int64_t* out4)
     out4[1] = ctx->n_runs_demoted.load();
     out4[2] = ctx->n_merged_giveups.load();
     out4[3] = ctx->n_rerun_failed.load();
+    return GAUSS_OK;
+}
+
+int gauss_hip_queues(gauss_ctx* ctx, int32_t* out4)
+{
+    if (!ctx || !out4) return fail(GAUSS_E_INVALID, "bad arguments to gauss_hip_queues");
+    QueueRegistry& r = registry();
+    std::lock_guard<std::mutex> lock(r.count_mu);
+    out4[0] = r.hi[ctx->device & 63];
+    out4[1] = r.lo[ctx->device & 63];
+    out4[2] = hw_queue_cap();
+    out4[3] = ctx->queues_probed_distinct ? 1 : 0;
     return GAUSS_OK;
 }
 

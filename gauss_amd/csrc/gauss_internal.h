@@ -196,6 +196,8 @@ void launch_gram(const Item* d_items, int n_items, int dtype_i8, hipStream_t s, 
 // bound_us: give-up bound in microseconds (at least two seconds are always granted)
 void launch_wait_count(const unsigned long long* d_count, unsigned long long target, int* d_status, int n_status, hipStream_t s,
                        double bound_us = 0.0);
+void launch_wait_count_for(const unsigned long long* d_count, unsigned long long target, int* d_status, hipStream_t s, double bound_us);
+void launch_count_up(unsigned long long* d_count, hipStream_t s);
 void launch_epilogue(const Prob* d_probs, const int2* d_tilemap, int n_tiles, int max_pop, int dtype_i8, hipStream_t s);
 void launch_epilogue_b11_lite(const Prob* d_probs, const int2* d_tilemap, int n_tiles, int dtype_i8, hipStream_t s);
 void launch_pop_cor(const Prob* d_probs, int prob, int npair, double* d_out, hipStream_t s);

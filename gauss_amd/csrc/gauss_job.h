@@ -170,6 +170,8 @@ struct gauss_ctx {
     std::thread prepin;                      // makes the upload staging buffers in the background (gauss_hip_init)
     std::mutex prepin_mu;                    // guards `prepin` (joinable / join): ctx_join_prepin
     int n_hi = 0, n_lo = 0;                  // streams of this context in the device's high / low priority pools (queue registry)
+    bool queues_probed_distinct = false;     // gauss_hip_init SAW a kernel on the chain queue and one on the low-priority queue run beside a
+                                             // later kernel of the main queue (queues_side_by_side): the three are different hardware queues
     // how the runs of this context's jobs were queued (gauss_hip_counters)
     std::atomic<long long> n_runs_merged{0}, n_runs_demoted{0}, n_merged_giveups{0}, n_rerun_failed{0};
 };

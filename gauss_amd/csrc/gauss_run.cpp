@@ -76,7 +76,7 @@ static int job_queue_run(gauss_job* job, bool solve, int par, bool allow_merged)
     // device owns its hardware queue (gauss_ctx.cpp).  The decision and the queuing are one step: a context whose streams
     // would start sharing queues waits (exclusively) until no run is being queued and the spinning kernels have drained.
     std::shared_lock<std::shared_mutex> qlock(queue_registry_mutex());
-    const bool merged = job->merged && allow_merged && solve && (job->force_merged || queues_exclusive(ctx->device));
+    const bool merged = job->merged && allow_merged && solve && (job->force_merged || (ctx->queues_probed_distinct && queues_exclusive(ctx->device)));
     if (job->merged && solve) (merged ? ctx->n_runs_merged : ctx->n_runs_demoted)++;
     const auto t_run0 = std::chrono::steady_clock::now();
     HIPCHK(hipEventRecord(job->begin, st));

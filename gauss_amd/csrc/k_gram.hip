@@ -433,6 +433,23 @@ __global__ __launch_bounds__(64) void wait_count_kernel(const unsigned long long
     for (int i = 0; i < n_status; i++) status[i] = 1;                 // the job-wide failure flag (gauss_job_fetch reports the run as failed)
 }
 
+// the other half of the context's queue probe (gauss_ctx.cpp: queues_side_by_side): one lane adds 1 to a counter
+__global__ __launch_bounds__(64) void count_up_kernel(unsigned long long* __restrict__ count)
+{
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(count, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+void launch_count_up(unsigned long long* d_count, hipStream_t s)
+{
+    hipLaunchKernelGGL(count_up_kernel, dim3(1), dim3(64), 0, s, d_count);
+}
+
+// wait_count_kernel with an explicit bound (no two-second floor, no test hook): the queue probe waits a few milliseconds at most
+void launch_wait_count_for(const unsigned long long* d_count, unsigned long long target, int* d_status, hipStream_t s, double bound_us)
+{
+    hipLaunchKernelGGL(wait_count_kernel, dim3(1), dim3(64), 0, s, d_count, target, (unsigned long long)(bound_us * 100.0), d_status, 1);
+}
+
 void launch_wait_count(const unsigned long long* d_count, unsigned long long target, int* d_status, int n_status, hipStream_t s,
                        double bound_us)
 {

@@ -47,6 +47,13 @@ class Context:
         check(self.lib.gauss_hip_counters(self.handle, out))
         return dict(merged=int(out[0]), demoted=int(out[1]), giveups=int(out[2]), rerun_failed=int(out[3]))
 
+    def queues(self):
+        """gauss_hip_queues: the library's priority streams on this device, the runtime's hardware queues per class, and whether
+        this context's chain / low-priority / main queues were SEEN to run side by side when it was made."""
+        out = (C.c_int32 * 4)()
+        check(self.lib.gauss_hip_queues(self.handle, out))
+        return dict(hi_streams=int(out[0]), lo_streams=int(out[1]), hw_queues_per_class=int(out[2]), probed_distinct=bool(out[3]))
+
     def close(self):
         if self.handle:
             # jobs and row stores that are still alive are released here (gauss_hip.h, lifetime rule)

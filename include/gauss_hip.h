@@ -198,6 +198,12 @@ int gauss_hip_trim_cache(gauss_ctx* ctx, int64_t* out_bytes_freed);
  *   out4[3] of those, the ones whose second form failed too (gauss_job_fetch returned GAUSS_E_DEVICE).
  * One call of the reference is one window or an error (dist.cpp:30-126): a give-up is never handed to the caller as results. */
 int gauss_hip_counters(gauss_ctx* ctx, int64_t* out4);
+/* What the merged form's condition rests on, for diagnostics: out4[0] / out4[1] the library's live high- / low-priority streams on
+ * the context's device (all contexts of the process), out4[2] the hardware queues the runtime makes per priority class
+ * (GPU_MAX_HW_QUEUES, default 4; 0: unknown), out4[3] = 1 if gauss_hip_init SAW the context's chain and low-priority queues run a
+ * kernel beside a later kernel of its main queue (a probe of a few microseconds: three different hardware queues), else 0.  A run
+ * is queued merged only while out4[3] = 1 and both stream counts are within out4[2]. */
+int gauss_hip_queues(gauss_ctx* ctx, int32_t* out4);
 const char* gauss_last_error(void);
 const char* gauss_hip_version(void);
 /* Hash of the sources this library was built from (gauss_amd/build.py:source_hash): profiles/<tag>_provenance.json record it,

@@ -327,7 +327,11 @@ def test_two_contexts_run_merged_jobs_at_the_same_time(ctx, monkeypatch, force):
     assert c_solo["merged"] == c_before["merged"] + 1, (c_before, c_solo)      # alone on the device: the merged form
     _check_against_oracle(p, wins, want)
 
+    q0 = ctx.queues()
+    assert q0["probed_distinct"] and q0["hi_streams"] <= q0["hw_queues_per_class"], q0      # the session's context was made alone on the device
     other = hotpath.Context(0)
+    q1 = other.queues()
+    assert q1["hi_streams"] > q1["hw_queues_per_class"], q1                               # two contexts: more priority streams than hardware queues
     store2 = hotpath.RowStore(rows2, ctx=other)
     wins2 = [dict(w, dev=(store2.ptr, store2.ptr, w["dev"][2], w["dev"][3], store2.ld)) for w in wins]
     jobs = [solo, hotpath.Job(wins2, ctx=other, on_device=True)]

@@ -21,7 +21,7 @@ ctxs = []
 for k in range(%(n)d):
     sys.stderr.write("##### creating context %%d\n" %% k); sys.stderr.flush()
     ctxs.append(hotpath.Context(0))
-    sys.stderr.write("##### context %%d made\n" %% k); sys.stderr.flush()
+    sys.stderr.write("##### context %%d made: gauss_hip_queues says %%s\n" %% (k, ctxs[-1].queues())); sys.stderr.flush()
 for k, c in enumerate(ctxs):
     sys.stderr.write("##### closing context %%d\n" %% k); sys.stderr.flush()
     c.close()
