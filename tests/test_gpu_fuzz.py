@@ -418,4 +418,17 @@ def test_random_chromosome_runs_equal_per_window_calls(ctx, tmp_path, seed):
     for c in res.columns:
         x, y = res.columns[c], merged.columns[c]
         assert np.array_equal(x, y, equal_nan=True) if x.dtype.kind == "f" else np.array_equal(x, y), c
+    # the genome driver: random stretches of the chromosome as its "chromosomes", two or three calls in flight on the context, for one
+    # of the ranks -- every table what the chromosome call returns for that stretch alone
+    cuts = np.sort(rng.choice(np.arange(1_000_001, 4_000_000, 125_000), size=int(rng.integers(2, 5)), replace=False))
+    chroms = [(22, int(a), int(b) - 1) for a, b in zip(cuts[:-1], cuts[1:])] + [(22, 1_000_001, 4_000_000)]
+    gr = int(rng.integers(0, world))
+    alone = [api.impute_chromosome(kind, c, a, b, wing, rank=gr, world=world, **kw) for c, a, b in chroms]
+    many = api.impute_genome(kind, chroms, wing, p["gwas.txt"], gpk, p["desc.txt"], window_size=wsize, rank=gr, world=world,
+                             depth=int(rng.integers(2, 4)), ctx=ctx, **sel)
+    for g, w in zip(many, alone):
+        assert np.array_equal(g.windows, w.windows)
+        for c in w.columns:
+            x, y = g.columns[c], w.columns[c]
+            assert np.array_equal(x, y, equal_nan=True) if x.dtype.kind == "f" else np.array_equal(x, y), c
     api.panel_evict(ctx=ctx)
