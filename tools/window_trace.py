@@ -10,8 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np  # noqa: E402
 from gauss_amd import hotpath, synth  # noqa: E402
 
-KNOBS = ("GAUSS_STREAM_WINDOW", "GAUSS_STREAM_CHUNK_TILES", "GAUSS_STREAM_LAST_TILES", "GAUSS_STREAM_CHAIN_ASIDE",
-         "GAUSS_STREAM_PACK_ASIDE", "GAUSS_STREAM_TRACE")
+KNOBS = ("GAUSS_STREAM_WINDOW", "GAUSS_TRACE")      # (round 5: the chunking knobs of the round-3 A/Bs are constants now)
 configs = sys.argv[1:] or ["-"]
 reps = int(os.environ.get("REPS", "15"))
 pops = [p for p in synth.POPS_33KG if p[0] in synth.PGC2_WEIGHTS]
