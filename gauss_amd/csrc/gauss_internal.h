@@ -64,7 +64,7 @@ struct Prob {
     GP(const uint8_t) raw_u;   // [U x ld_raw]
     // Row arrays come in two parts: the measured rows [0, Mp) behind `X`, the unmeasured rows [Mp, Sp) behind `X_u`
     // (indexed from 0).  Ordinarily X_u = X + Mp rows of one array.  In a job whose windows share their measured SNPs
-    // (gauss_hip.cpp: shared measured rows) X points INTO the job-wide arrays of the chromosome's measured SNPs, at this
+    // (gauss_plan.cpp: shared measured rows) X points INTO the job-wide arrays of the chromosome's measured SNPs, at this
     // window's first one (g0): rows the windows have in common are packed once, and the tile pairs of B11 -- formed on
     // job-wide row tiles, `gpair_*` / `slab_g` -- are multiplied once for all the windows they lie in.
     GP(uint8_t) packed;        // [Mp x Kp]

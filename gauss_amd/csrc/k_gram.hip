@@ -8,7 +8,7 @@
 // Exactness: operands are genotype codes (0..15 admitted, 0..2 in practice); a segment (the run of samples whose
 // products one accumulator sums before it is flushed) never spans more than 8192 samples of ONE population -- the
 // planner cuts longer populations, at SEG_MAX = 2048 for jobs of fewer than four windows (more work items) and at
-// 4096 otherwise (gauss_hip.cpp:seg_max_for; any cap up to 8192 is admissible) -- so every partial sum is an integer
+// 4096 otherwise (gauss_plan.cpp:seg_max_for; any cap up to 8192 is admissible) -- so every partial sum is an integer
 // <= 15 * 15 * 8192 < 2^24 and the
 // f32 MFMA accumulation (bitwise a k-ordered fmaf chain) is exact in any summation order.  The k order inside a
 // chunk is therefore permuted freely to make the LDS reads wide.
@@ -385,7 +385,7 @@ __device__ __forceinline__ void gram_item(const Item& it, uint8_t* lds)
 // (k_solve_lite.hip); the common paths need 104, the 16-column edge path would take 107 if left alone.
 //
 // `b11_done` (may be null): items with flag bit 4 -- B11's tile pairs of a job whose factorisation chain runs beside this launch
-// (gauss_hip.cpp:job_run) -- and items with flag bit 5 -- B21's tile pairs of the windows whose epilogue tiles fill this launch's
+// (gauss_run.cpp:job_queue_run) -- and items with flag bit 5 -- B21's tile pairs of the windows whose epilogue tiles fill this launch's
 // last round -- count themselves off there (counters [0] and [8]) when their slabs are out, so that the chain queue can start on B11 while
 // this SAME launch goes on with B21's items: no second launch, no drained chip between the two.  The hand-off follows the
 // producer recipe for data another kernel reads (MI355X_MICROARCH.md, inter-workgroup visibility): every storing wave waits for

@@ -423,7 +423,7 @@ __device__ __forceinline__ void epilogue_tile(const Prob& pb, int pair_in, int l
     const bool sym = gb11 || (ti < mt); // measured x measured tile (ti <= tj)
     const int Mld = pb.Mld;
     // status[3]: lambda_min(B11) > eps is certified.  Only B11's tiles read it (B21's tiles may run while the chain queue,
-    // which makes the certificate in a merged launch, is still busy: gauss_hip.cpp:job_run)
+    // which makes the certificate in a merged launch, is still busy: gauss_run.cpp:job_queue_run)
     const bool need_a1 = !sym || !(pb.npanel > 0 && pb.status[3] != 0);
     const int tid = threadIdx.x;
     const bool weighted = pb.mode != 0;
@@ -609,7 +609,7 @@ void launch_epilogue(const Prob* d_probs, const int2* d_tilemap, int n_tiles, in
 // ------------------------------------------------------------------------------------------
 // B11's epilogue tiles in a small-footprint form: 256 threads, 18 KB of LDS, <= 96 registers, so that a workgroup fits into
 // what gram_kernel's four workgroups per CU leave free and the tiles run BESIDE the Gram launch of B21's items, ahead of
-// the factorisation chain on the chain queue (gauss_hip.cpp:job_run, k_solve_lite.hip).  Entry for entry the arithmetic of
+// the factorisation chain on the chain queue (gauss_run.cpp:job_queue_run, k_solve_lite.hip).  Entry for entry the arithmetic of
 // epilogue_tile -- integer sum of a population's partials, util.cpp:118 / :119 in population order, util.cpp:123,
 // distmix.cpp:196 (pooled: util.cpp:66-68) -- hence the same bits.  What differs is the staging: the tile is walked in
 // 2 column halves x 4 passes of 32 rows (thread = one row pair x 4 columns), and the per-population tables come through

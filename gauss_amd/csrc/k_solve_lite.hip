@@ -9,7 +9,7 @@
 // chain of dependent launches runs at 2.6 x its stand-alone latency while the Gram kernel loses nothing measurable.  The
 // chain is latency-bound (18 dependent block steps for the tallest window of chr22, whatever the batch), so latency hidden
 // under a 30 ms Gram launch is free: gauss_job_run sends B11's Gram items, B11's epilogue tiles and then this chain ahead,
-// and the chain runs on the context's chain queue under the Gram launch of B21's items (gauss_hip.cpp:job_run).
+// and the chain runs on the context's chain queue under the Gram launch of B21's items (gauss_run.cpp:job_queue_run).
 //
 // Same arithmetic as k_solve.hip, operation for operation -- the two families give the same bits (tests/test_gpu_parity.py)
 // -- only the staging differs:

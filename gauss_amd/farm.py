@@ -155,7 +155,7 @@ CHAIN_STEP_COST = 2.0e8
 
 def adjacency_saving(n_samples, m_a, m_b, shared):
     """What a rank saves when it holds BOTH of two neighbouring windows (m_a, m_b measured SNPs, the last `shared` of a's being the
-    first of b's): the job then keeps one list of measured rows for the two (gauss_hip.cpp: shared measured rows, clusters) and
+    first of b's): the job then keeps one list of measured rows for the two (gauss_plan.cpp: shared measured rows, clusters) and
     multiplies the B11 tile pairs that lie in both windows once.  Counted the way the job builder decides it: window b joins
     a's cluster at row offset m_a - shared if that adds no more tile pairs than tiles of its own would; the saving is the
     difference, priced like B11's other pairs (piece_cost's setup per pair of full tiles, less the average edge skipping)."""

@@ -125,7 +125,7 @@ def shard_balanced(wins, n_samples, world, granule=64, contiguous=False):
     if contiguous:
         return farm.balance_windows(mu, n_samples, world, granule)
     # GAUSS_PLAN_ADJACENCY=1: the planner also prices neighbouring windows on one rank (farm.adjacency_saving: their common B11
-    # tile pairs are multiplied once, gauss_hip.cpp clusters).  Measured on the 8-rank emulation (round 4): nine neighbour pairs end
+    # tile pairs are multiplied once, gauss_plan.cpp clusters).  Measured on the 8-rank emulation (round 4): nine neighbour pairs end
     # up together and the MEAN share drops 1 % (5.40 -> 5.35 ms), but the slowest share stays at 5.44-5.46 ms -- the ranks' times
     # scatter +-2 % around any flop model, more than the saving -- so the predicted efficiency does not move and it is off.
     shared = None

@@ -668,7 +668,7 @@ def test_two_runs_of_a_job_in_flight(ctx):
 @pytest.mark.gpu
 def test_shared_measured_rows_give_the_bits_of_separate_windows(ctx, monkeypatch):
     """Windows of a chromosome name their measured SNPs as runs of one ascending list of store rows: the job packs those
-    rows once and multiplies B11's tile pairs once on job-wide row tiles (gauss_hip.cpp, shared measured rows) -- LD
+    rows once and multiplies B11's tile pairs once on job-wide row tiles (gauss_plan.cpp, shared measured rows) -- LD
     entries depend on the SNP pair only (distmix.cpp:190-200), so z, info, B11 and B21 must equal, bit for bit, what the
     same windows give when every window packs and multiplies its own copy.  Window starts fall inside row tiles (not
     multiples of 128), windows overlap by half, one window ends the list, one QCAT window shares the job."""
