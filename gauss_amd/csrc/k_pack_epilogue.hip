@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void pack_stats_kernel(const Prob* __restrict_
         int sx = 0, sxx = 0;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            uint32_t x = v[q] & 0x0F0F0F0Fu;         // '0'..'9' and 0..15 both decode as byte & 0x0F
+            uint32_t x = fmt2 ? v[q] : (v[q] & 0x0F0F0F0Fu);         // '0'..'9' and 0..15 both decode as byte & 0x0F (2-bit sources: 0..3 already)
             if (code) {
                 // ConvertGenotypesToDominant / ToRecessive (gauss.cpp:1196-1250): only codes 0..2 are mapped
                 const uint32_t ge4 = ((x >> 2) | (x >> 3)) & 0x01010101u;
@@ -96,16 +96,12 @@ __global__ __launch_bounds__(256) void pack_stats_kernel(const Prob* __restrict_
             uint32_t c;
             if (pb.gram_i8) {
                 c = x;                                   // i8 MFMA path: operands are the raw codes
-            } else if (fmt2) {
-                // 2-bit sources hold codes 0..3 (recoding only lowers them): 0 -> 0x00, 1 -> 0x38, 2 -> 0x40, 3 -> 0x44 without a
-                // branch or a multiply -- this kernel is bound by its vector instructions (86 % of the VALU issue slots, round 4's
-                // counters), not by HBM
-                const uint32_t lo = x & 0x01010101u, hi = (x >> 1) & 0x01010101u;
-                const uint32_t one = lo & ~hi, three = lo & hi;
-                c = (hi << 6) | ((one << 6) - (one << 3)) | (three << 2);
-            } else if ((x & 0x0C0C0C0Cu) == 0 && (x & (x >> 1) & 0x01010101u) == 0) {
-                // every byte in {0,1,2}: 1 -> 0x38, 2 -> 0x40
-                c = (x & 0x01010101u) * 0x38u + ((x >> 1) & 0x01010101u) * 0x40u;
+            } else if (fmt2 || (x & 0x08080808u) == 0) {
+                // codes 0..7 -- all a 2-bit source can hold, and the rule for byte sources -- through v_perm_b32 as an eight-entry
+                // byte table: selector byte t picks byte t of {0x4E4C4A48 : 0x44403800} = the e4m3 codes of 0..7 (0x00, 0x38, 0x40, 0x44,
+                // 0x48, 0x4A, 0x4C, 0x4E).  One instruction a dword: this kernel is bound by its vector instructions (86 % of the VALU
+                // issue slots in round 4's counters, 80 % after round 5's first cuts), not by HBM
+                c = __builtin_amdgcn_perm(0x4E4C4A48u, 0x44403800u, x);
             } else {
                 c = 0;
 #pragma unroll
