@@ -958,8 +958,8 @@ __global__ __launch_bounds__(256, 2) void solve_last_kernel(const Prob* __restri
 //   R   right-hand sides, one per row: the window's B21 rows (QCAT: first the B11 columns of the tested measured SNPs)
 //   X   = L^-1, block (kb, p) at pb.V[p][64 kb ..][64], lower block triangle; y = L^-1 z1 is column M of [X | y]
 //   w_u = X r_u  (= L^-1 b21_u^T);   z_u = w_u . y,  info_u = w_u . w_u,  v_u = sum(w_u)
-// One workgroup = UT right-hand sides x 128 rows of X (k), 4 waves of 64 (k) x UT / 2 (4 x 4 or 4 x 2
-// v_mfma_f64_16x16x4_f64 tiles; 8 LDS fragment reads per 16 MFMAs at UT = 128); K runs over the columns
+// One workgroup = UT right-hand sides x 128 rows of X (k), NW waves of 64 (k) x 2 UT / NW (4 x 2 v_mfma_f64_16x16x4_f64 tiles a
+// wave in both shipped forms: UT = 128 with 8 waves, UT = 64 with 4); K runs over the columns
 // j < 64 (block + 1) of X in stages of 16, double buffered in LDS, the next stage's tiles in flight in registers.
 // Nothing of W is stored: each workgroup reduces its tile to three sums per right-hand side in a fixed order and
 // parks them in pb.Gsum[k block][rhs][3]; impute_finish_kernel adds the k blocks in order.  A right-hand side's sums
@@ -972,12 +972,18 @@ constexpr int GLD = GK + 2;            // LDS row stride in doubles: 144 B puts 
 constexpr int GT = 128;                // tile edge (rows of X, and right-hand sides)
 static const size_t GEMM_SMEM = (size_t)(2 * 2 * GT * GLD + GT) * sizeof(double);
 
-struct GemmRegs { f64x2 v[4]; };       // 8 doubles: half a 16-column tile row
+template <int LQ> struct GemmRegsT { f64x2 v[LQ]; };       // 2 LQ doubles of a tile row's 16-column stage
 
-template <int UT>
-__global__ __launch_bounds__(256, 2) void impute_gemm_kernel(const Prob* __restrict__ probs, const int2* __restrict__ gmap)
+// NW waves per workgroup: 4 (wave tile 64 k x UT / 2) or 8 (64 k x UT / 4: half the accumulators a wave, four waves a SIMD instead
+// of two on the same 74 KB of LDS).  Round 5: the 128-wide form with eight waves takes 1.07 ms per 36-window step against 1.13
+// with four (the same sums in the same order: same bits); the 64-wide form of small jobs keeps four.
+template <int UT, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void impute_gemm_kernel(const Prob* __restrict__ probs, const int2* __restrict__ gmap)
 {
-    constexpr int NU = UT / 32;                                 // 16-column tiles of a wave along u
+    constexpr int NU = UT / (8 * NW);                           // 16-column tiles of a wave along u
+    constexpr int TPR = NW / 2;                                 // threads per tile row of a stage (64 NW threads, 128 rows)
+    constexpr int LQ = 8 / TPR;                                 // f64x2 loads per thread and operand
+    typedef GemmRegsT<LQ> GemmRegs;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int2 gm = gmap[blockIdx.x];
     const Prob& pb = probs[gm.x];
@@ -988,8 +994,8 @@ __global__ __launch_bounds__(256, 2) void impute_gemm_kernel(const Prob* __restr
     const int k0 = kblock * GT, u0 = upanel * UT;
     double* ys = smem + 2 * 2 * GT * GLD;
 
-    // ---- operand rows of this thread: row tid / 2 of both tiles, columns 8 (tid % 2) .. + 7 of a stage
-    const int trow = tid >> 1, tcol = (tid & 1) * 8;
+    // ---- operand rows of this thread: row tid / TPR of both tiles, columns 2 LQ (tid % TPR) .. of a stage
+    const int trow = tid / TPR, tcol = (tid % TPR) * 2 * LQ;
     const int xk = k0 + trow;                                   // row of X
     const bool x_live = xk < ld;
     const int u = u0 + trow;                                    // right-hand side
@@ -1003,7 +1009,7 @@ __global__ __launch_bounds__(256, 2) void impute_gemm_kernel(const Prob* __restr
         const auto xp = pb.V + ((size_t)(j0 >> 6) * ld + xk) * NR + (j0 & 63) + tcol;
         const auto rp = rrow + j0 + tcol;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
+        for (int q = 0; q < LQ; q++) {
             rx.v[q] = x_live ? f64x2{xp[2 * q], xp[2 * q + 1]} : f64x2{0.0, 0.0};
             rr.v[q] = r_live ? f64x2{rp[2 * q], rp[2 * q + 1]} : f64x2{0.0, 0.0};
         }
@@ -1012,7 +1018,7 @@ __global__ __launch_bounds__(256, 2) void impute_gemm_kernel(const Prob* __restr
         double* xa = smem + (size_t)buf * 2 * GT * GLD + trow * GLD + tcol;
         double* rb = xa + GT * GLD;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
+        for (int q = 0; q < LQ; q++) {
             *reinterpret_cast<f64x2*>(xa + 2 * q) = rx.v[q];
             *reinterpret_cast<f64x2*>(rb + 2 * q) = rr.v[q];
         }
@@ -1166,11 +1172,11 @@ void launch_impute_gemm(const Prob* d_probs, const int2* d_gmap, int n_tiles, in
     if (n_tiles <= 0) return;
     static DeviceOnce attr_once;
     attr_once.run([&] {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(impute_gemm_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_SMEM);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(impute_gemm_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_SMEM);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(impute_gemm_kernel<128, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_SMEM);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(impute_gemm_kernel<64, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_SMEM);
     });
-    if (u_tile == 64) hipLaunchKernelGGL(impute_gemm_kernel<64>, dim3(n_tiles), dim3(256), GEMM_SMEM, s, d_probs, d_gmap);
-    else hipLaunchKernelGGL(impute_gemm_kernel<128>, dim3(n_tiles), dim3(256), GEMM_SMEM, s, d_probs, d_gmap);
+    if (u_tile == 64) hipLaunchKernelGGL((impute_gemm_kernel<64, 4>), dim3(n_tiles), dim3(256), GEMM_SMEM, s, d_probs, d_gmap);
+    else hipLaunchKernelGGL((impute_gemm_kernel<128, 8>), dim3(n_tiles), dim3(512), GEMM_SMEM, s, d_probs, d_gmap);
     hipLaunchKernelGGL(impute_finish_kernel, dim3(n_chunks), dim3(256), 0, s, d_probs, d_fmap);
 }
 
