@@ -38,7 +38,7 @@ HOST_SYMBOLS = [
     "gauss_prepared_geno_u", "gauss_prepared_pop_off", "gauss_prepared_pop_wgt", "gauss_prepared_z1",
     "gauss_prepared_gene_off", "gauss_prepared_window_desc", "gauss_prepared_finish", "gauss_prepared_free",
     "gauss_host_bgzf_copy", "gauss_host_set_threads",
-    "gauss_host_panel_resident", "gauss_host_panel_evict", "gauss_host_impute_chromosome", "gauss_host_impute_genome", "gauss_host_panel_cache", "gauss_table_n_messages",
+    "gauss_host_panel_resident", "gauss_host_panel_evict", "gauss_host_impute_chromosome", "gauss_host_impute_genome", "gauss_host_chrom_window_view", "gauss_host_panel_cache", "gauss_table_n_messages",
     "gauss_table_message", "gauss_table_strcol_fixed", "gauss_host_panel_device_rows", "gauss_prepared_store_rows",
     "gauss_host_jepeg_gene_tail", "gauss_host_plan_cost",
 ]
@@ -147,6 +147,7 @@ def load_host():
                                                _dbl, C.c_int, C.c_int, C.c_int, C.POINTER(_vp), C.POINTER(ChromStats)]
     h.gauss_host_impute_genome.argtypes = [_vp, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(_i64), C.POINTER(_i64), _i64, _i64, _cp, _strs, _dp,
                                            C.c_int, _cp, _cp, _cp, _cp, _dbl, C.c_int, C.c_int, C.c_int, C.POINTER(_vp), C.POINTER(ChromStats)]
+    h.gauss_host_chrom_window_view.argtypes = [C.c_int, C.c_int, _i64, _i64, _i64, _cp, _strs, _dp, C.c_int, _cp, _cp, _cp, _dbl, C.POINTER(_vp)]
     h.gauss_host_panel_cache.argtypes = [_cp, _cp, _cp, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int64)]
     h.gauss_table_n_messages.argtypes = [_vp]
     h.gauss_table_message.restype = _cp
@@ -499,6 +500,22 @@ def impute_chromosome(kind, chr, start_bp, end_bp, wing_size, input_file, refere
     h.gauss_table_free(out)
     stats = {k: getattr(st, k) for k, _ in ChromStats._fields_}
     return ChromResult(cols, windows, stats, msgs)
+
+
+def chrom_window_view(kind, chr, start_bp, end_bp, wing_size, input_file, packed_file, reference_pop_desc_file, study_pop=None,
+                      pop_wgt_df=None, af1_cutoff=None):
+    """gauss_host_chrom_window_view (no GPU): one window as the chromosome driver builds it on a sorted packed panel.
+    Returns (snps DataFrame, dict of named vectors rows_m / rows_u / z1 / counts, guard message or None)."""
+    h = load_host()
+    names, w, n = (None, None, 0) if pop_wgt_df is None else _pop_wgt(pop_wgt_df)
+    out = _vp()
+    _hcheck(h.gauss_host_chrom_window_view(int(kind), int(chr), int(start_bp), int(end_bp), int(wing_size), _enc(study_pop), names,
+                                           None if w is None else w.ctypes.data_as(_dp), n, _enc(input_file), _enc(packed_file),
+                                           _enc(reference_pop_desc_file), _af(af1_cutoff), C.byref(out)))
+    named = {k: v.reshape(-1) for k, v in _named(h, out).items()}
+    msgs = [h.gauss_table_message(out, k).decode() for k in range(h.gauss_table_n_messages(out))]
+    df = _table(h, out)[0]
+    return df, named, (msgs[0] if msgs else None)
 
 
 def impute_genome(kind, chromosomes, wing_size, input_file, reference_data_file, reference_pop_desc_file, study_pop=None,

@@ -269,6 +269,7 @@ int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_device, 
         if (rc) return rc;
         job->plans[i].p.gram_i8 = job->gram_i8;
     }
+    const auto tb1 = std::chrono::steady_clock::now();
     // Shared measured rows: every window reads its measured SNPs from the same resident store under the same populations.
     // The job keeps ONE list of measured rows, made of CLUSTERS: a window whose rows continue a run of the current cluster
     // (the next window of a chromosome: half its measured SNPs are the previous window's) joins it at that offset -- when
@@ -397,6 +398,8 @@ int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_device, 
     // ---- table arena (host mirrored) ----
     Arena ta;
     std::vector<char>& blob = job->h_tab;
+    blob.reserve((size_t)n_prob * ((size_t)320 << 10) + ((size_t)64 << 10));      // (~0.3 MB a window: grown in place, not copied over and over)
+    const auto tb2 = std::chrono::steady_clock::now();
     struct TabOff { size_t raw_off, pk_off, w, wf, md, seg_pop, k0, k1, seg0, ti, tj, lut, wp, z1, goff, gout, wr, rpk, rsrc, rm, ru, ch; };
     std::vector<TabOff> to((size_t)n_prob);
     for (int i = 0; i < n_prob; i++) {
@@ -425,7 +428,7 @@ int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_device, 
         to[i].ch = put(blob, ta, pl.chunk_live);
     }
     // work lists
-    struct ItemH { int prob, pair, group, len; };
+    struct ItemH { int prob, pair, group, len, b11; };     // b11: an item of B11 (job-wide pairs, or a window's own measured x measured pairs)
     std::vector<ItemH> items;
     std::vector<char> late_window;                         // early epilogue: windows whose B21 items end the merged launch
     std::vector<int2> rowmap, tilemap, tilemap_b21, panelmap, dpanelmap, gemmmap, finmap;
@@ -446,7 +449,7 @@ int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_device, 
         const Plan& g = *job->gplan;
         for (int pr = 0; pr < g.p.npair; pr++)
             for (size_t k = 0; k < g.groups.size(); k++)
-                items.push_back(ItemH{job->n, pr, (int)k, g.seg_k1[g.groups[k].second - 1] - g.seg_k0[g.groups[k].first]});
+                items.push_back(ItemH{job->n, pr, (int)k, g.seg_k1[g.groups[k].second - 1] - g.seg_k0[g.groups[k].first], 1});
         for (int r = 0; r < g.p.M; r++)
             if (g.rows_m[(size_t)r] >= 0) rowmap.push_back(make_int2(job->n, r));      // (padding rows between clusters stay zero)
     }
@@ -461,17 +464,18 @@ int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_device, 
         const Prob& p = job->plans[i].p;
         const int mt_i = p.Mp / TILE;
         for (int pr = 0; pr < p.npair; pr++) {
-            if (shm && job->plans[i].pair_ti[pr] < mt_i) continue;       // a B11 pair: done on the job-wide tiles
+            const int b11 = job->plans[i].pair_ti[pr] < mt_i ? 1 : 0;
+            if (shm && b11) continue;                                    // a B11 pair: done on the job-wide tiles
             if (fine_every > 0 && ++pair_no % fine_every == 0 && job->plans[i].groups.size() < job->plans[i].fine.size()) {
                 for (size_t g = 0; g < job->plans[i].fine.size(); g++) {
                     const std::pair<int, int>& gr = job->plans[i].fine[g];
-                    items.push_back(ItemH{i, pr, -1 - (int)g, job->plans[i].seg_k1[gr.second - 1] - job->plans[i].seg_k0[gr.first]});
+                    items.push_back(ItemH{i, pr, -1 - (int)g, job->plans[i].seg_k1[gr.second - 1] - job->plans[i].seg_k0[gr.first], b11});
                 }
                 continue;
             }
             for (size_t g = 0; g < job->plans[i].groups.size(); g++) {
                 const std::pair<int, int>& gr = job->plans[i].groups[g];
-                items.push_back(ItemH{i, pr, (int)g, job->plans[i].seg_k1[gr.second - 1] - job->plans[i].seg_k0[gr.first]});
+                items.push_back(ItemH{i, pr, (int)g, job->plans[i].seg_k1[gr.second - 1] - job->plans[i].seg_k0[gr.first], b11});
             }
         }
         for (int r = shm ? p.M : 0; r < p.M + p.U; r++) rowmap.push_back(make_int2(i, r));
@@ -502,11 +506,34 @@ int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_device, 
         }
         if (p.mode != 0) job->max_pop = std::max(job->max_pop, p.P);
     }
-    // longest segments first: the tail of the launch is then made of short items
-    std::stable_sort(items.begin(), items.end(), [](const ItemH& a, const ItemH& b) { return a.len > b.len; });
-    // B11's items of the job (job-wide pairs, or the windows' own measured x measured pairs)
-    auto is_b11 = [&](const ItemH& h) {
-        return h.prob == job->n || job->plans[(size_t)h.prob].pair_ti[(size_t)h.pair] < job->plans[(size_t)h.prob].p.Mp / TILE;
+    // The launch order: longest segments first (the tail of the launch is then made of short items), inside up to three classes --
+    // B11's items, the early windows' B21 items, the late windows' (below).  One stable counting pass over (class, length): lengths
+    // are whole K chunks and a job has a handful of distinct ones (three stable sorts through the plans' tables were 0.3 ms of the
+    // 0.53 ms a three-window job took to plan; a rank of eight waits for exactly that before its GPU starts).
+    auto is_b11 = [&](const ItemH& h) { return h.b11 != 0; };
+    std::vector<uint8_t> item_class(items.size(), 0);
+    auto order_items = [&]() {
+        int L = 0;
+        bool whole = true;
+        for (const ItemH& h : items) { L = std::max(L, h.len / KC); whole = whole && h.len % KC == 0 && h.len >= 0; }
+        if (!whole || (size_t)L > 4 * items.size() + 1024) {            // (never on a plan of this file: lengths are multiples of KC)
+            std::vector<size_t> idx(items.size());
+            for (size_t n = 0; n < idx.size(); n++) idx[n] = n;
+            std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) {
+                return item_class[a] != item_class[b] ? item_class[a] < item_class[b] : items[a].len > items[b].len; });
+            std::vector<ItemH> out(items.size());
+            for (size_t n = 0; n < idx.size(); n++) out[n] = items[idx[n]];
+            items.swap(out);
+            return;
+        }
+        const size_t nb = (size_t)3 * (size_t)(L + 1);
+        std::vector<uint32_t> start(nb + 1, 0u);
+        auto bucket = [&](size_t n) { return (size_t)item_class[n] * (size_t)(L + 1) + (size_t)(L - items[n].len / KC); };
+        for (size_t n = 0; n < items.size(); n++) start[bucket(n) + 1]++;
+        for (size_t b = 0; b < nb; b++) start[b + 1] += start[b];
+        std::vector<ItemH> out(items.size());
+        for (size_t n = 0; n < items.size(); n++) out[start[bucket(n)]++] = items[n];
+        items.swap(out);
     };
     {
         // Chain beside the Gram kernel (k_solve_lite.hip): B11's items become a launch of their own, B11's epilogue tiles and
@@ -528,10 +555,11 @@ int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_device, 
         }
         job->chain_aside = !streamed && mode != 0 && !panelmap.empty() && !tilemap_b21.empty() && !genes && job->ctx->chain &&
                            job->ctx->side && (mode == 2 || t_b21 >= 1.2 * t_chain);
-        if (job->chain_aside) {
-            std::stable_sort(items.begin(), items.end(), [&](const ItemH& a, const ItemH& b) { return is_b11(a) && !is_b11(b); });
-            for (const ItemH& h : items) job->n_items_b11 += is_b11(h) ? 1 : 0;
-        }
+        if (job->chain_aside)
+            for (size_t n = 0; n < items.size(); n++) {
+                item_class[n] = is_b11(items[n]) ? 0 : 1;
+                job->n_items_b11 += is_b11(items[n]) ? 1 : 0;
+            }
         // Merged launch (round 4): B11's items and B21's items are ONE launch, B11's first; they count themselves off and the
         // chain queue starts when the count is complete (k_gram.hip: wait_count_kernel) -- the chip is never drained between
         // the two halves (two launches: 37.1 ms, one: 36.6 on the 36-window job).  GAUSS_CHAIN_MERGED=0: two launches + event.
@@ -563,11 +591,14 @@ int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_device, 
             std::stable_sort(by_work.begin(), by_work.end(), [&](int a, int b) { return w21[(size_t)a] < w21[(size_t)b]; });
             for (int k = 0; k + 1 < job->n && acc < want; k++) { late_window[(size_t)by_work[(size_t)k]] = 1; acc += w21[(size_t)by_work[(size_t)k]]; n_late++; }
             if (n_late > 0 && acc < tot) {
-                auto is_late = [&](const ItemH& h) { return !is_b11(h) && late_window[(size_t)h.prob] != 0; };
-                std::stable_sort(items.begin() + job->n_items_b11, items.end(), [&](const ItemH& a, const ItemH& b) { return !is_late(a) && is_late(b); });
-                for (size_t n = (size_t)job->n_items_b11; n < items.size(); n++) job->n_items_b21_early += is_late(items[n]) ? 0 : 1;
+                for (size_t n = 0; n < items.size(); n++) {
+                    if (is_b11(items[n])) continue;
+                    if (late_window[(size_t)items[n].prob]) item_class[n] = 2;
+                    else job->n_items_b21_early++;
+                }
             } else late_window.assign((size_t)job->n + 1, 0);
         }
+        order_items();
     }
     std::vector<int> sgroup_of_item;
     if (streamed) {
@@ -628,7 +659,7 @@ int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_device, 
     const size_t o_rowmap = put(blob, ta, rowmap);
     job->n_tiles_b11 = (int)tilemap.size();
     if (job->n_items_b21_early > 0) {
-        std::stable_sort(tilemap_b21.begin(), tilemap_b21.end(), [&](const int2& a, const int2& b) { return !late_window[(size_t)a.x] && late_window[(size_t)b.x]; });
+        std::stable_partition(tilemap_b21.begin(), tilemap_b21.end(), [&](const int2& a) { return !late_window[(size_t)a.x]; });
         for (const int2& t : tilemap_b21) job->n_tiles_b21_early += late_window[(size_t)t.x] ? 0 : 1;
     }
     tilemap.insert(tilemap.end(), tilemap_b21.begin(), tilemap_b21.end());
@@ -943,8 +974,8 @@ int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_device, 
     HIPCHK(hipGetLastError());
     if (job_trace) {
         auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-        fprintf(stderr, "[job] %d windows: plan %.2f ms, allocations %.2f ms (workspace %.1f MB, tables %.2f MB, pinned %.2f MB), events + zeroing + tables %.2f ms, table copy queued in %.2f ms\n",
-                job->n, ms(tb0, tj0), ms(tj0, tj1), job->ws_bytes / 1e6, job->tab_bytes / 1e6, (pin_tab + 2 * (pin_res + pin_st)) / 1e6, ms(tj1, tj2),
+        fprintf(stderr, "[job] %d windows: plan %.2f ms (the windows' plans %.2f, shared rows + row checks %.2f, tables + work items %.2f), allocations %.2f ms (workspace %.1f MB, tables %.2f MB, pinned %.2f MB), events + zeroing + tables %.2f ms, table copy queued in %.2f ms\n",
+                job->n, ms(tb0, tj0), ms(tb0, tb1), ms(tb1, tb2), ms(tb2, tj0), ms(tj0, tj1), job->ws_bytes / 1e6, job->tab_bytes / 1e6, (pin_tab + 2 * (pin_res + pin_st)) / 1e6, ms(tj1, tj2),
                 ms(tj2, std::chrono::steady_clock::now()));
     }
     job->d_probs = (Prob*)(job->d_tab + o_probs);

@@ -633,7 +633,10 @@ static int ReadReferenceIndex(SnpMap& m, const Args& a, bool All)
                 if (!have_at || same_site) { at = m.lower_bound(MapKey{s.chr, s.bp, std::string(), std::string()}); have_at = true; }
                 else while (at != m.end() && key_before(at->first, s.chr, s.bp)) ++at;
                 if (at == m.end() || at->first.chr != s.chr || at->first.bp != s.bp) {
-                    if (a.drop_wing_unmeasured && (s.bp < a.start_bp || s.bp > a.end_bp)) continue;
+                    // (a wing SNP is only left out when it is the panel's one entry at its position: a panel that lists a site twice
+                    // makes the second entry find the first -- gauss.cpp:356-361 turns that into a measured SNP -- so both are entered)
+                    const bool alone = !(i + 1 < i1 && pk.snp(i + 1).chr == s.chr && pk.snp(i + 1).bp == s.bp);
+                    if (a.drop_wing_unmeasured && alone && (s.bp < a.start_bp || s.bp > a.end_bp)) continue;
                     SnpPtr sp = m.make();                      // gauss.cpp:373-385
                     sp->rsid = pk.str(s.rsid); sp->chr = s.chr; sp->bp = s.bp; sp->a1 = pk.str(s.a1); sp->a2 = pk.str(s.a2); sp->type = 0; sp->fpos = i;
                     m.emplace_hint(at, MapKey{s.chr, s.bp, sp->a1, sp->a2}, std::move(sp));
@@ -644,12 +647,10 @@ static int ReadReferenceIndex(SnpMap& m, const Args& a, bool All)
             }
             return 0;
         }
+        // (an unsorted panel, or a call over every chromosome: every entry goes through the map; wing SNPs are not left out here --
+        // entries of one position need not be neighbours, so "the panel's one entry at its position" cannot be told on the spot)
         for (int64_t i = i0; i < i1; i++) {
             const PkSnp& s = pk.snp(i);
-            if (a.drop_wing_unmeasured && !All && (s.bp < a.start_bp || s.bp > a.end_bp)) {
-                auto pos = m.lower_bound(MapKey{s.chr, s.bp, std::string(), std::string()});
-                if (pos == m.end() || pos->first.chr != s.chr || pos->first.bp != s.bp) continue;
-            }
             if (merge_index_entry(m, a, All, pk.str(s.rsid), s.chr, s.bp, pk.str(s.a1), pk.str(s.a2), i)) return -1;
         }
         return 0;
@@ -2514,6 +2515,322 @@ static double issued_cost_per_sample(int m, int u)
 double gauss_host_plan_cost(int n_measured, int n_unmeasured) { return issued_cost_per_sample(n_measured, n_unmeasured); }
 
 // ------------------------------------------------------------------------------------------
+// The chromosome driver's window: prepare()'s data layer as ONE merge of two sorted arrays.
+//
+// prepare() restates the reference literally: every SNP of the extended window becomes an object with five strings in a std::map
+// keyed by (chr, bp, a1, a2) (ReadInputZ, ReadReferenceIndex, MakeSnpVec: gauss.cpp:121-190, 293-399, 543-693) -- 0.65-1.0 ms
+// for a window of 3 000 SNPs, paid again by every window of a chromosome, and with one rank of eight holding four windows it is
+// what the GPU waits for.  A window of a SORTED packed panel needs none of it.  The study's rows
+// (cached, ordered by position) and the panel's SNP table (ordered by position) ascend together; a position is settled where
+// the two walks meet:
+//
+//   panel entry alone at its position, no study row there ......... type 0 (an unmeasured SNP)
+//   one panel entry, one study row, same alleles .................. type 1, the study's z
+//   one panel entry, one study row, alleles swapped ............... type 1, -z (the panel's order is adopted, gauss.cpp:362-372)
+//   one panel entry, one study row, other alleles ................. the panel entry is type 0; the study SNP has no panel row
+//   study rows without a panel entry .............................. type 2: no panel row, the AF filter drops them (gauss.cpp:574)
+//   anything else (a site the panel or the study lists more than once, equal alleles): the position's rows go through the
+//   very map code of prepare() -- a map of that one position, whose entries only ever meet entries of their own position
+//   (merge_index_entry looks up (chr, bp, a1, a2) and (chr, bp, a2, a1)) -- and come out in the map's order.
+//
+// Every string of the output (rsid, a1, a2) is the panel's: a type-1 SNP takes the panel's rsid and, matched or swapped, has
+// the panel's alleles.  So a SNP is a panel row number, z, info, af and a type -- 48 bytes, no allocation -- and the tables
+// read the strings out of the panel's pool when they are built.  Type-0 SNPs of the wings are not entered (the partition reads
+// type 0 inside the prediction window only, dist.cpp:132-140 / qcat.cpp:140-152, and the tables are cut to it).
+// What a window costs now: DESIGN.md section 9e item 11.  tests/test_feeder.py holds it against prepare() on random
+// studies with multi-allelic, duplicated, swapped and study-only sites, for all four kinds.
+// ------------------------------------------------------------------------------------------
+struct ChromSetup {                     // what prepare() derives from a call's arguments alone: once per call, not once per window
+    int kind = 0;
+    bool mix = false, qcat = false;
+    Args a;                             // population table, flags, weights, cutoffs (start_bp / end_bp are the windows', not set here)
+    std::vector<int> sel;               // the selected populations, panel order
+    std::vector<int32_t> pop_off, pop_src_off;
+    std::vector<double> pop_wgt;
+    double two_subj = 0;                // 2 x the selected samples (gauss.cpp:589)
+    std::shared_ptr<const GwasCache> gw;
+};
+
+struct LeanSnp {
+    int64_t row;                        // panel row = fpos of the packed feeder
+    long long bp;
+    double z, info, af;
+    int32_t type, qcat_m;
+    double qcat_t, qcat_chisq;
+};
+
+struct LeanWindow {
+    const ChromSetup* cs = nullptr;
+    long long start_bp = 0, end_bp = 0;
+    std::vector<LeanSnp> v;             // prepare()'s snp_vec: after the AF filter, map order
+    std::vector<int32_t> measured, unmeasured;      // into v, matrix row order
+    std::vector<int32_t> store_rows_m, store_rows_u;
+    std::vector<double> z1, out_z, out_info, out_r;
+    int n_head = 0, n_predm = 0;
+    int32_t num_eig = 0, status = 0;
+    std::unique_ptr<gauss_table> pre;   // the output table, built while the GPU works (lean_table_prebuild); the results are filled in after
+    std::vector<int32_t> out_row;       // v -> row of the table, -1 outside the prediction window
+};
+
+// 0, or -1 with the message prepare() would have given every window (the caller then lets prepare() give it)
+static int chrom_setup(ChromSetup& cs, int kind, int chr, int64_t wing_size, const char* study_pop, const char* const* pop_names,
+                       const double* pop_wgts, int n_pop_wgt, const char* input_file, const std::string& packed_path,
+                       const char* desc_file, double af1_cutoff, const std::shared_ptr<PackedPanel>& pk,
+                       const std::shared_ptr<const GwasCache>& gw)
+{
+    cs.kind = kind;
+    cs.mix = (kind == GAUSS_KIND_DISTMIX || kind == GAUSS_KIND_QCATMIX);
+    cs.qcat = (kind == GAUSS_KIND_QCAT || kind == GAUSS_KIND_QCATMIX);
+    Args& a = cs.a;
+    a.chr = chr; a.wing_size = wing_size;
+    if (study_pop) a.study_pop = study_pop;
+    a.input_file = input_file; a.reference_data_file = packed_path; a.reference_pop_desc_file = desc_file;
+    a.pk = pk;
+    a.drop_wing_unmeasured = (kind == GAUSS_KIND_DIST || kind == GAUSS_KIND_DISTMIX);
+    a.af1_cutoff = std::isnan(af1_cutoff) ? (kind == GAUSS_KIND_QCAT ? 0.05 : 0.01) : af1_cutoff;
+    if (cs.mix) {
+        if (!pop_names || !pop_wgts || n_pop_wgt < 1) return herr("pop_wgt_df is empty");
+        set_pop_wgt_map(a, pop_names, pop_wgts, n_pop_wgt);
+    } else if (!study_pop) return herr("study_pop is NULL");
+    if (read_ref_desc(a)) return -1;
+    if (pk->n_pop() != a.num_pops) return herr("packed panel has %d populations, the description file %d", pk->n_pop(), a.num_pops);
+    for (int k = 0; k < a.num_pops; k++)
+        if (a.ref_pop_vec[k] != pk->pop(k).name || a.ref_pop_size_vec[k] != (int)pk->pop(k).size)
+            return herr("packed panel population %d is %s (%u samples), the description file says %s (%d)", k,
+                        pk->pop(k).name, pk->pop(k).size, a.ref_pop_vec[k].c_str(), a.ref_pop_size_vec[k]);
+    if (cs.mix) init_pop_flag_wgt_vec(a);
+    else if (init_pop_flag_vec(a)) return -1;
+    cs.pop_off.assign(1, 0);
+    double num_subj = 0;
+    for (int k = 0; k < a.num_pops; k++)
+        if (a.pop_flag_vec[k]) {
+            cs.sel.push_back(k);
+            cs.pop_off.push_back(cs.pop_off.back() + a.ref_pop_size_vec[k]);
+            cs.pop_src_off.push_back((int32_t)pk->pop(k).byte_off);
+            num_subj += a.ref_pop_size_vec[k];
+        }
+    cs.two_subj = 2 * num_subj;
+    if (cs.mix) cs.pop_wgt = a.pop_wgt_vec;
+    else cs.pop_wgt.assign(cs.pop_off.size() - 1, 1.0);
+    cs.gw = gw;
+    return 0;
+}
+
+static int lean_window_build(LeanWindow& w, const ChromSetup& cs, long long start_bp, long long end_bp)
+{
+    const Args& a = cs.a;
+    const PackedPanel& pk = *a.pk;
+    const GwasCache& gw = *cs.gw;
+    w.cs = &cs; w.start_bp = start_bp; w.end_bp = end_bp;
+    const long long lo = start_bp - a.wing_size, hi = end_bp + a.wing_size;
+    auto before = [&](uint32_t x, long long bp) { const GwasRow& r = gw.rows[x]; return r.chr < a.chr || (r.chr == a.chr && r.bp < bp); };
+    size_t q = (size_t)(std::lower_bound(gw.by_pos.begin(), gw.by_pos.end(), lo, before) - gw.by_pos.begin());
+    const size_t q1 = (size_t)(std::lower_bound(gw.by_pos.begin(), gw.by_pos.end(), hi + 1, before) - gw.by_pos.begin());
+    int64_t i = pk.lower_bound(a.chr, lo);
+    const int64_t i1 = pk.lower_bound(a.chr, hi + 1);
+    w.v.reserve((size_t)std::max<int64_t>(i1 - i, 0));
+    const double cutoff = a.af1_cutoff;
+    // MakeSnpVec / MakeSnpVecMix on the panel's tabulated counts and frequencies (MakeSnpVecPacked above), then the list
+    auto keep = [&](int64_t row, long long bp, int type, double z, double info) {
+        if (type == 0 && (bp < start_bp || bp > end_bp)) return;       // a wing's unmeasured SNP: nothing reads it
+        double af = 0;
+        if (!cs.mix) {
+            double allele_counter = 0;                                  // gauss.cpp:574-591 (integer-valued sums)
+            const int32_t* c = pk.cnt(row);
+            for (int k : cs.sel) allele_counter += (double)c[k];
+            af = allele_counter / cs.two_subj;
+            af = std::ceil(af * 100000.0) / 100000.0;
+        } else {
+            const double* f = pk.af(row);                               // gauss.cpp:676-682
+            int j = 0;
+            for (int k : cs.sel) af += f[k] * a.pop_wgt_vec[j++];
+        }
+        if (!((af > cutoff) && (af < (1 - cutoff)))) return;
+        w.v.push_back(LeanSnp{row, bp, z, info, af, type, 0, 0.0, 0.0});
+    };
+    std::unique_ptr<Args> range;                                        // merge_index_entry's window filter, for the odd positions
+    while (i < i1) {
+        const PkSnp& s = pk.snp(i);
+        const long long bp = s.bp;
+        int64_t ie = i + 1;
+        while (ie < i1 && pk.snp(ie).bp == bp) ie++;
+        while (q < q1 && gw.rows[gw.by_pos[q]].bp < bp) q++;            // study-only positions
+        size_t qe = q;
+        while (qe < q1 && gw.rows[gw.by_pos[qe]].bp == bp) qe++;
+        if (ie - i == 1 && qe == q) { keep(i, bp, 0, 0.0, -1.0); i = ie; continue; }    // the rule: nothing of the study here (no string is read)
+        const char *pa1 = pk.str(s.a1), *pa2 = pk.str(s.a2);
+        if (ie - i == 1 && qe - q == 1 && strcmp(pa1, pa2) != 0) {
+            {
+                const GwasRow& r = gw.rows[gw.by_pos[q]];
+                if (r.a1 == pa1 && r.a2 == pa2) keep(i, bp, 1, r.z, 1.0);
+                else if (r.a1 == pa2 && r.a2 == pa1) keep(i, bp, 1, r.z * (-1), 1.0);
+                else keep(i, bp, 0, 0.0, -1.0);
+            }
+        } else {
+            // the position as prepare() handles it: ReadInputZ's rows (a key listed twice ends with its later row), then the
+            // panel's entries in panel order
+            SnpMap m;
+            for (size_t k = q; k < qe; k++) {
+                const GwasRow& r = gw.rows[gw.by_pos[k]];
+                SnpPtr sp = m.make();
+                sp->rsid = r.rsid; sp->chr = r.chr; sp->bp = r.bp; sp->a1 = r.a1; sp->a2 = r.a2; sp->z = r.z;
+                sp->info = 1.0; sp->type = 2;
+                m.try_emplace(MapKey{r.chr, r.bp, r.a1, r.a2}).first->second = std::move(sp);
+            }
+            if (!range) { range.reset(new Args()); range->chr = 0; range->start_bp = lo; range->end_bp = hi; range->wing_size = 0; }
+            for (int64_t j = i; j < ie; j++) {
+                const PkSnp& sj = pk.snp(j);
+                if (m.empty()) {
+                    if (a.drop_wing_unmeasured && ie - i == 1 && (bp < start_bp || bp > end_bp)) continue;
+                    SnpPtr sp = m.make();                              // gauss.cpp:373-385
+                    sp->rsid = pk.str(sj.rsid); sp->chr = sj.chr; sp->bp = sj.bp; sp->a1 = pk.str(sj.a1); sp->a2 = pk.str(sj.a2); sp->type = 0; sp->fpos = j;
+                    m.emplace(MapKey{sj.chr, sj.bp, sp->a1, sp->a2}, std::move(sp));
+                } else if (merge_index_entry(m, *range, false, pk.str(sj.rsid), sj.chr, sj.bp, pk.str(sj.a1), pk.str(sj.a2), j)) return -1;
+            }
+            for (auto& kv : m) {
+                const Snp& sn = *kv.second;
+                if (sn.fpos < 0 || sn.fpos >= pk.n_snp()) continue;     // a study SNP without a panel row
+                keep(sn.fpos, bp, sn.type, sn.z, sn.info);
+            }
+        }
+        i = ie; q = qe;
+    }
+    // the partition: dist.cpp:132-140, qcat.cpp:140-152
+    for (size_t r = 0; r < w.v.size(); r++) {
+        const LeanSnp& sn = w.v[r];
+        if (sn.type == 0) { w.unmeasured.push_back((int32_t)r); w.store_rows_u.push_back((int32_t)sn.row); }   // (inside the prediction window: keep())
+        else if (sn.type == 1) {
+            w.measured.push_back((int32_t)r); w.store_rows_m.push_back((int32_t)sn.row); w.z1.push_back(sn.z);
+            if (sn.bp < start_bp) w.n_head++;
+            else if (sn.bp <= end_bp) w.n_predm++;
+        }
+    }
+    return 0;
+}
+
+// gauss_prepared_window_desc for the four window kinds (same guards, same texts); geno_m / geno_u are set by the caller
+static int lean_window_desc(LeanWindow& w, gauss_window_desc* d)
+{
+    const ChromSetup& cs = *w.cs;
+    const Args& a = cs.a;
+    const int M = (int)w.measured.size(), U = (int)w.unmeasured.size();
+    if (cs.qcat) {
+        if (cs.kind == GAUSS_KIND_QCAT && M <= a.min_num_measured_snp)
+            return herr("Not enough number of SNPs loaded - QCAT not performed (measured %d, unmeasured %d)", M, U);
+        if (cs.kind == GAUSS_KIND_QCATMIX && (M <= a.min_num_measured_snp || U <= a.min_num_unmeasured_snp))
+            return herr("Not enough number of SNPs loaded - QCAT performed (measured %d, unmeasured %d)", M, U);
+    } else if (M <= a.min_num_measured_snp || U <= a.min_num_unmeasured_snp)
+        return herr("Not enough number of SNPs loaded - %s not performed (measured %d, unmeasured %d)",
+                    cs.kind == GAUSS_KIND_DIST ? "DIST" : "DISTMIX", M, U);
+    memset(d, 0, sizeof(*d));
+    d->mode = cs.mix ? GAUSS_MODE_WEIGHTED : GAUSS_MODE_POOLED;
+    d->n_pop = (int)cs.pop_off.size() - 1;
+    d->pop_off = cs.pop_off.data(); d->pop_wgt = cs.pop_wgt.data();
+    d->n_measured = M; d->n_unmeasured = U;
+    d->geno_format = GAUSS_GENO_2BIT;
+    d->ld = a.pk->row_bytes();
+    d->rows_m = w.store_rows_m.data(); d->rows_u = w.store_rows_u.data();
+    d->pop_src_off = cs.pop_src_off.data();
+    d->z1 = w.z1.data(); d->lambda = a.lambda; d->min_abs_eig = a.min_abs_eig;
+    d->out_status = &w.status;
+    if (cs.qcat) {
+        w.out_r.assign((size_t)w.n_predm + U, 0.0);
+        w.num_eig = M;
+        d->kind = GAUSS_WIN_QCAT;
+        d->n_head_measured = w.n_head; d->n_pred_measured = w.n_predm; d->eig_cutoff = a.eig_cutoff;
+        d->out_r = w.out_r.data(); d->out_num_eig = &w.num_eig;
+        if (w.n_predm + U < 1) return herr("QCAT window has no SNP to test");
+        return 0;
+    }
+    w.out_z.assign(U, 0.0); w.out_info.assign(U, 0.0);
+    d->out_z = w.out_z.data(); d->out_info = w.out_info.data();
+    return 0;
+}
+
+// gauss_prepared_finish + dist_output / qcat_output in two steps.  Everything a table holds that does not wait for the GPU -- the
+// strings, positions, frequencies, the measured SNPs' z and p-values -- is built while the window's batch computes
+// (lean_table_prebuild, before the driver waits for the batch); what the results change is filled in after (lean_window_finish):
+// the last batch's tables are otherwise the tail of the call that nothing overlaps.
+static void lean_table_prebuild(LeanWindow& w)
+{
+    if (w.pre) return;
+    const ChromSetup& cs = *w.cs;
+    const PackedPanel& pk = *cs.a.pk;
+    std::unique_ptr<gauss_table> t(new gauss_table());
+    Column rsid{"rsid", GAUSS_COL_STR, {}, {}, {}}, chr{"chr", GAUSS_COL_INT, {}, {}, {}}, bp{"bp", GAUSS_COL_INT, {}, {}, {}};
+    Column a1{"a1", GAUSS_COL_STR, {}, {}, {}}, a2{"a2", GAUSS_COL_STR, {}, {}, {}};
+    Column af{cs.mix ? "af1mix" : "af1ref", GAUSS_COL_DBL, {}, {}, {}}, z{"z", GAUSS_COL_DBL, {}, {}, {}};
+    Column pval{"pval", GAUSS_COL_DBL, {}, {}, {}}, info{"info", GAUSS_COL_DBL, {}, {}, {}}, type{"type", GAUSS_COL_INT, {}, {}, {}};
+    Column qm{"qcat_m", GAUSS_COL_INT, {}, {}, {}}, qt{"qcat_t", GAUSS_COL_DBL, {}, {}, {}};
+    Column qc{"qcat_chisq", GAUSS_COL_DBL, {}, {}, {}}, qp{"qcat_pval", GAUSS_COL_DBL, {}, {}, {}};
+    size_t n_out = 0;
+    w.out_row.assign(w.v.size(), -1);
+    for (size_t r = 0; r < w.v.size(); r++) {
+        const int ibp = (int)w.v[r].bp;                                           // dist.cpp:92, qcat.cpp:95
+        if (ibp >= w.start_bp && ibp <= w.end_bp) w.out_row[r] = (int32_t)n_out++;
+    }
+    for (Column* c : {&rsid, &a1, &a2}) c->s.reserve(n_out);
+    for (Column* c : {&chr, &bp, &type}) c->i.reserve(n_out);
+    for (Column* c : {&af, &z}) c->d.reserve(n_out);
+    if (cs.qcat) { qm.i.reserve(n_out); for (Column* c : {&qt, &qc, &qp}) c->d.reserve(n_out); }
+    else for (Column* c : {&pval, &info}) c->d.reserve(n_out);
+    for (size_t r = 0; r < w.v.size(); r++) {
+        if (w.out_row[r] < 0) continue;
+        const LeanSnp& sn = w.v[r];
+        const PkSnp& ps = pk.snp(sn.row);
+        rsid.s.emplace_back(pk.str(ps.rsid)); chr.i.push_back(ps.chr); bp.i.push_back((int)sn.bp);
+        a1.s.emplace_back(pk.str(ps.a1)); a2.s.emplace_back(pk.str(ps.a2));
+        af.d.push_back(sn.af); z.d.push_back(sn.z); type.i.push_back(sn.type);
+        if (cs.qcat) {
+            qm.i.push_back(sn.qcat_m); qt.d.push_back(sn.qcat_t); qc.d.push_back(sn.qcat_chisq);
+            qp.d.push_back(pchisq_upper(sn.qcat_chisq, 1));                       // qcat.cpp:107
+        } else {
+            pval.d.push_back(2 * pnorm_upper(fabs(sn.z)));                        // dist.cpp:101
+            info.d.push_back(sn.info);
+        }
+    }
+    t->cols.reserve(12);
+    if (cs.qcat) for (Column* c : {&rsid, &chr, &bp, &a1, &a2, &af, &z, &qm, &qt, &qc, &qp, &type}) t->cols.push_back(std::move(*c));
+    else for (Column* c : {&rsid, &chr, &bp, &a1, &a2, &af, &z, &pval, &info, &type}) t->cols.push_back(std::move(*c));
+    w.pre = std::move(t);
+}
+
+static gauss_table* lean_window_finish(LeanWindow& w)
+{
+    const ChromSetup& cs = *w.cs;
+    lean_table_prebuild(w);
+    gauss_table& t = *w.pre;
+    if (cs.qcat) {
+        Column &qm = t.cols[7], &qt = t.cols[8], &qc = t.cols[9], &qp = t.cols[10];
+        const int m = w.num_eig;
+        for (size_t k = 0; k < w.out_r.size(); k++) {                            // qcat.cpp:216-243
+            const size_t vi = (size_t)((k < (size_t)w.n_predm) ? w.measured[(size_t)w.n_head + k] : w.unmeasured[k - (size_t)w.n_predm]);
+            LeanSnp& sn = w.v[vi];
+            const double r = w.out_r[k];
+            sn.qcat_m = m;
+            sn.qcat_t = std::sqrt((double)(m - 3)) * r;
+            sn.qcat_chisq = (m - 3) * r * r;
+            const int32_t row = w.out_row[vi];
+            if (row < 0) continue;
+            qm.i[(size_t)row] = sn.qcat_m; qt.d[(size_t)row] = sn.qcat_t; qc.d[(size_t)row] = sn.qcat_chisq;
+            qp.d[(size_t)row] = pchisq_upper(sn.qcat_chisq, 1);                   // qcat.cpp:107
+        }
+    } else {
+        Column &z = t.cols[6], &pval = t.cols[7], &info = t.cols[8];
+        for (size_t i = 0; i < w.unmeasured.size() && i < w.out_z.size(); i++) {  // dist.cpp:200-202
+            LeanSnp& sn = w.v[(size_t)w.unmeasured[i]];
+            sn.z = w.out_z[i];
+            sn.info = w.out_info[i];
+            const int32_t row = w.out_row[(size_t)w.unmeasured[i]];
+            if (row < 0) continue;
+            z.d[(size_t)row] = sn.z; info.d[(size_t)row] = sn.info;
+            pval.d[(size_t)row] = 2 * pnorm_upper(fabs(sn.z));                    // dist.cpp:101
+        }
+    }
+    return w.pre.release();
+}
+
+// ------------------------------------------------------------------------------------------
 // A whole chromosome: the caller-level loop over windows that the reference leaves to the R user
 // (docs/articles/dist_example.md:144-153 calls one window), as ONE native call per rank.
 //
@@ -2532,6 +2849,68 @@ double gauss_host_plan_cost(int n_measured, int n_unmeasured) { return issued_co
 // column "window"; named matrix "windows" [n_windows x 6]: start_bp end_bp owner status measured unmeasured
 // (status 0 done, 1 skipped by the ">10" guards, 2 failed, -1 another rank's).
 // ------------------------------------------------------------------------------------------
+// A test / debugging view of ONE window as the chromosome driver builds it (no GPU involved): the SNP list with the columns of
+// gauss_prepared_snps (fpos = panel row) and the named matrices "rows_m", "rows_u", "z1", "counts" = [M, U, n_head, n_predm].
+// tests/test_feeder.py holds it against gauss_host_prepare on the same arguments.
+int gauss_host_chrom_window_view(int kind, int chr, int64_t start_bp, int64_t end_bp, int64_t wing_size, const char* study_pop,
+                                 const char* const* pop_names, const double* pop_wgts, int n_pop_wgt, const char* input_file,
+                                 const char* packed_file, const char* reference_pop_desc_file, double af1_cutoff, gauss_table** out)
+{
+    if (!out || !input_file || !packed_file || !reference_pop_desc_file) return herr("bad arguments");
+    if (kind != GAUSS_KIND_DIST && kind != GAUSS_KIND_DISTMIX && kind != GAUSS_KIND_QCAT && kind != GAUSS_KIND_QCATMIX)
+        return herr("gauss_host_chrom_window_view: kind must be dist, distmix, qcat or qcatmix");
+    std::string err;
+    std::shared_ptr<PackedPanel> pk = open_packed_shared(packed_file, err);
+    if (!pk) return herr("%s", err.c_str());
+    if (chr <= 0 || !pk->header().sorted) return herr("the chromosome driver builds its own windows on a sorted packed panel and one chromosome only");
+    std::shared_ptr<const GwasCache> gw = load_gwas_cached(input_file, err);
+    if (!gw) return herr("%s", err.c_str());
+    const double t0 = now_s();
+    ChromSetup cs;
+    if (chrom_setup(cs, kind, chr, wing_size, study_pop, pop_names, pop_wgts, n_pop_wgt, input_file, packed_file, reference_pop_desc_file,
+                    af1_cutoff, pk, gw)) return -1;
+    const double t1 = now_s();
+    LeanWindow w;
+    if (lean_window_build(w, cs, start_bp, end_bp)) return -1;
+    if (host_trace("prep"))
+        fprintf(stderr, "[window] setup %.3f ms (once per call in the driver), build %.3f ms (list %zu, measured %zu, unmeasured %zu)\n",
+                (t1 - t0) * 1e3, (now_s() - t1) * 1e3, w.v.size(), w.measured.size(), w.unmeasured.size());
+    std::unique_ptr<gauss_table> t(new gauss_table());
+    Column& rsid = t->add("rsid", GAUSS_COL_STR);
+    for (const LeanSnp& sn : w.v) rsid.s.emplace_back(pk->str(pk->snp(sn.row).rsid));
+    Column& cchr = t->add("chr", GAUSS_COL_INT);
+    for (const LeanSnp& sn : w.v) cchr.i.push_back(pk->snp(sn.row).chr);
+    Column& bp = t->add("bp", GAUSS_COL_INT);
+    for (const LeanSnp& sn : w.v) bp.i.push_back((int)sn.bp);
+    Column& a1 = t->add("a1", GAUSS_COL_STR);
+    for (const LeanSnp& sn : w.v) a1.s.emplace_back(pk->str(pk->snp(sn.row).a1));
+    Column& a2 = t->add("a2", GAUSS_COL_STR);
+    for (const LeanSnp& sn : w.v) a2.s.emplace_back(pk->str(pk->snp(sn.row).a2));
+    Column& af = t->add(cs.mix ? "af1mix" : "af1ref", GAUSS_COL_DBL);
+    for (const LeanSnp& sn : w.v) af.d.push_back(sn.af);
+    Column& z = t->add("z", GAUSS_COL_DBL);
+    for (const LeanSnp& sn : w.v) z.d.push_back(sn.z);
+    Column& info = t->add("info", GAUSS_COL_DBL);
+    for (const LeanSnp& sn : w.v) info.d.push_back(sn.info);
+    Column& type = t->add("type", GAUSS_COL_INT);
+    for (const LeanSnp& sn : w.v) type.i.push_back(sn.type);
+    Column& fpos = t->add("fpos", GAUSS_COL_DBL);
+    for (const LeanSnp& sn : w.v) fpos.d.push_back((double)sn.row);
+    auto named = [&](const char* name, const std::vector<double>& v) {
+        NamedMat nm;
+        nm.name = name; nm.nrow = (int)v.size(); nm.ncol = 1; nm.d = v;
+        t->named.push_back(std::move(nm));
+    };
+    named("rows_m", std::vector<double>(w.store_rows_m.begin(), w.store_rows_m.end()));
+    named("rows_u", std::vector<double>(w.store_rows_u.begin(), w.store_rows_u.end()));
+    named("z1", w.z1);
+    named("counts", std::vector<double>{(double)w.measured.size(), (double)w.unmeasured.size(), (double)w.n_head, (double)w.n_predm});
+    gauss_window_desc d;
+    if (lean_window_desc(w, &d)) t->messages.push_back(gauss_host_last_error());     // the guard's text, as the driver would report it
+    *out = t.release();
+    return 0;
+}
+
 static thread_local int tl_calls_in_flight = 1;       // > 1: this thread's call is one of several the genome driver keeps in flight
 
 int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t start_bp, int64_t end_bp, int64_t wing_size,
@@ -2740,7 +3119,14 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
 
     // ---- feeder thread: the data layer, batch by batch ----
     int rc_upload = 0;
-    struct Slot { std::unique_ptr<gauss_prepared> p; gauss_window_desc d; bool ok = false; gauss_table* tab = nullptr; };
+    struct Slot { std::unique_ptr<gauss_prepared> p; std::unique_ptr<LeanWindow> lw; gauss_window_desc d; bool ok = false; gauss_table* tab = nullptr; };
+    // The windows of a sorted packed panel are built by the merge above (LeanWindow); an unsorted panel or a call over every
+    // chromosome goes window by window through prepare(), and so does a call whose arguments prepare() would refuse (it then
+    // gives every window its message).
+    ChromSetup cs;
+    const bool lean = chr > 0 && pk->header().sorted &&
+                      chrom_setup(cs, kind, chr, wing_size, study_pop, pop_names, pop_wgts, n_pop_wgt, input_file, packed_path,
+                                  reference_pop_desc_file, af1_cutoff, pk, gw) == 0;
     std::vector<std::vector<Slot>> slots((size_t)n_batches);
     for (int b = 0; b < n_batches; b++) slots[b].resize(batches[b].size());
     std::mutex mu;
@@ -2775,7 +3161,15 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
             Win& w = wins[batches[b][k]];
             Slot& sl = slots[b][k];
             gauss_prepared* p = nullptr;
-            if (gauss_host_prepare(kind, chr, w.s, w.e, wing_size, study_pop, pop_names, pop_wgts, n_pop_wgt, input_file, nullptr,
+            if (lean) {
+                std::unique_ptr<LeanWindow> lw(new LeanWindow());
+                if (lean_window_build(*lw, cs, w.s, w.e)) { w.status = 2; w.why = gauss_host_last_error(); }
+                else {
+                    w.M = (int)lw->measured.size(); w.U = (int)lw->unmeasured.size();
+                    if (lean_window_desc(*lw, &sl.d)) { w.status = 1; w.why = gauss_host_last_error(); }      // the ">10" guards (dist.cpp:145-151)
+                    else { sl.lw = std::move(lw); sl.ok = true; }
+                }
+            } else if (gauss_host_prepare(kind, chr, w.s, w.e, wing_size, study_pop, pop_names, pop_wgts, n_pop_wgt, input_file, nullptr,
                                    "(packed)", reference_data_file, reference_pop_desc_file, af1_cutoff, &p)) {
                 w.status = 2; w.why = gauss_host_last_error();
             } else {
@@ -2855,6 +3249,10 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
     };
     auto retire = [&](int b) {
         // results of batch b -> SNP objects -> per-window tables (host threads; the GPU is on batch b+1 meanwhile)
+        // (what the tables hold that the results do not change is built BEFORE the wait: the last batch has no batch b+1 to hide under)
+        double tp = now_s();
+        parallel_for((int)slots[b].size(), nthreads_tables, [&](int k) { if (slots[b][k].ok && slots[b][k].lw) lean_table_prebuild(*slots[b][k].lw); });
+        st.t_tables += now_s() - tp;
         double tw = now_s();
         int rc = jobs[b] ? gauss_job_fetch(jobs[b]) : 0;
         st.t_gpu_wait += now_s() - tw;
@@ -2879,9 +3277,11 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
             Slot& sl = slots[b][k];
             if (!sl.ok) return;
             gauss_table* t = nullptr;
-            if (gauss_prepared_finish(sl.p.get(), &t) == 0) { sl.tab = t; wins[batches[b][k]].status = 0; }
+            if (sl.lw) { sl.tab = lean_window_finish(*sl.lw); wins[batches[b][k]].status = 0; }
+            else if (gauss_prepared_finish(sl.p.get(), &t) == 0) { sl.tab = t; wins[batches[b][k]].status = 0; }
             else { wins[batches[b][k]].status = 2; wins[batches[b][k]].why = gauss_host_last_error(); }
             sl.p.reset();
+            sl.lw.reset();
         });
         const double t_fin = now_s();
         append_batch(b);
@@ -2908,9 +3308,9 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
                 // the highest panel row this batch reads; its job may start once the upload has passed it
                 int64_t top = -1;
                 for (int k : live[b]) {
-                    const gauss_prepared* q = slots[b][(size_t)k].p.get();
-                    for (int32_t r : q->store_rows_m) top = std::max<int64_t>(top, r);
-                    for (int32_t r : q->store_rows_u) top = std::max<int64_t>(top, r);
+                    const Slot& sq = slots[b][(size_t)k];
+                    for (int32_t r : sq.lw ? sq.lw->store_rows_m : sq.p->store_rows_m) top = std::max<int64_t>(top, r);
+                    for (int32_t r : sq.lw ? sq.lw->store_rows_u : sq.p->store_rows_u) top = std::max<int64_t>(top, r);
                 }
                 const double tu = now_s();
                 if (gauss_store_wait(ctx, d_rows, (top + 1) * panel_row_bytes) != 0) { herr("%s", gauss_last_error()); rc_fatal = -1; upload_failed = true; break; }

@@ -251,6 +251,14 @@ int gauss_host_impute_genome(gauss_ctx* ctx, int kind, int n_chrom, const int32_
                              const double* pop_wgts, int n_pop_wgt, const char* input_file, const char* reference_index_file,
                              const char* reference_data_file, const char* reference_pop_desc_file, double af1_cutoff,
                              int rank, int world, int depth, gauss_table** out, gauss_chrom_stats* stats);
+/* A test / debugging view (no GPU): ONE window as gauss_host_impute_chromosome builds it on a sorted packed panel -- by a merge of
+ * the study's rows and the panel's SNP table, both ordered by position, instead of the reference's per-SNP objects in a std::map
+ * (gauss.cpp:121-190, 293-399, 543-693: what gauss_host_prepare restates).  Columns as gauss_prepared_snps (fpos = panel row; a
+ * wing's unmeasured SNPs, which nothing reads, are not listed), named matrices "rows_m", "rows_u", "z1" and "counts" =
+ * [measured, unmeasured, n_head, n_predm]; the ">10" guard's text, if the window trips it, is message 0. */
+int gauss_host_chrom_window_view(int kind, int chr, int64_t start_bp, int64_t end_bp, int64_t wing_size, const char* study_pop,
+                                 const char* const* pop_names, const double* pop_wgts, int n_pop_wgt, const char* input_file,
+                                 const char* packed_file, const char* reference_pop_desc_file, double af1_cutoff, gauss_table** out);
 /* The host part of jepeg()/jepegmix() for ONE gene, given the CorG block the GPU produced (diagonal 1 + lambda):
  * Gene::RunJepeg bookkeeping + CalJepegPval from W on (gene.cpp:88-185, 317-550).  corg [n x n], has / wgt [n x 6]
  * row-major (category present, category weight).  top_categ / top_snp are indices (-1 when df = 0).  No GPU needed. */

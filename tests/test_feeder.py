@@ -731,3 +731,196 @@ def test_panel_cache_concurrent_callers_pack_once(tmp_path):
     assert all(q.returncode == 0 for q in procs)
     assert len({o[0] for o in outs}) == 1
     assert sorted(int(o[1]) for o in outs) == [0, 0, 0, 400]                  # exactly one of them did the packing
+
+
+# ---- the chromosome driver's own window (gauss_host.cpp:LeanWindow): a merge of two sorted tables ---------------------
+def _view_equals_prepared(kind, mix, kw, gpk):
+    """gauss_host_chrom_window_view against gauss_host_prepare on the same packed panel: the SNP list (without the wings' type-0
+    SNPs, which the driver's window does not enter and nothing reads), the panel rows of the measured / unmeasured SNPs, z1,
+    the QCAT counts and the guard's text -- or the same error from both."""
+    args = dict(kw, reference_data_file=gpk, reference_index_file="(packed)")
+    vkw = dict(chr=kw["chr"], start_bp=kw["start_bp"], end_bp=kw["end_bp"], wing_size=kw["wing_size"], input_file=kw["input_file"],
+               packed_file=gpk, reference_pop_desc_file=kw["reference_pop_desc_file"], study_pop=kw.get("study_pop"),
+               pop_wgt_df=kw.get("pop_wgt_df"), af1_cutoff=kw.get("af1_cutoff"))
+    try:
+        pr = api.Prepared(kind, **args)
+    except api.GaussError as e:
+        with pytest.raises(api.GaussError) as ei:
+            api.chrom_window_view(kind, **vkw)
+        assert str(ei.value) == str(e)
+        return "error"
+    df, named, msg = api.chrom_window_view(kind, **vkw)
+    dp = pr.snps()
+    lo, hi = kw["start_bp"], kw["end_bp"]
+    keep = (dp["type"].to_numpy() != 0) | ((dp["bp"].to_numpy() >= lo) & (dp["bp"].to_numpy() <= hi))
+    renum = np.cumsum(keep) - 1
+    dpk = dp[keep].reset_index(drop=True)
+    assert len(dpk) == len(df)
+    for c in df.columns:
+        if df[c].dtype.kind == "f":
+            assert np.array_equal(df[c].to_numpy(), dpk[c].to_numpy(), equal_nan=True), c
+            assert np.array_equal(np.signbit(df[c].to_numpy()), np.signbit(dpk[c].to_numpy())), c       # (-0.0 of a flipped z = 0)
+        else:
+            assert list(df[c]) == list(dpk[c]), c
+    fpos = dp["fpos"].to_numpy()
+    assert np.array_equal(named["rows_m"], fpos[pr.measured_rows()]) and np.array_equal(named["rows_u"], fpos[pr.unmeasured_rows()])
+    assert np.all(keep[pr.measured_rows()]) and np.all(keep[pr.unmeasured_rows()])
+    assert np.array_equal(named["z1"], pr.z1())
+    assert list(named["counts"]) == [pr.M, pr.U, pr.n_head, pr.n_pred]
+    try:
+        pr.window_desc()
+        assert msg is None
+    except api.GaussError as e:
+        assert msg == str(e)
+    pr.close()
+    return "ok"
+
+
+@pytest.mark.parametrize("kind", ["DIST", "DISTMIX", "QCAT", "QCATMIX"])
+def test_chrom_window_view_equals_prepare(study, packed, kind):
+    inp, idx, dat, desc = _files(study)
+    mix = kind in ("DISTMIX", "QCATMIX")
+    for lo, hi, wing in ((1_400_000, 2_000_000, 250_000), (1_000_000, 2_600_000, 0), (1_000_000, 1_030_000, 5_000), (5_000_000, 6_000_000, 1000)):
+        kw = dict(chr=22, start_bp=lo, end_bp=hi, wing_size=wing, study_pop=None if mix else "EUR", pop_wgt_df=WGT if mix else None,
+                  input_file=inp, reference_pop_desc_file=desc)
+        assert _view_equals_prepared(getattr(api, "KIND_" + kind), mix, kw, packed) == "ok"
+    # arguments prepare() refuses are refused with its words
+    kw = dict(chr=22, start_bp=1_400_000, end_bp=2_000_000, wing_size=0, study_pop=None if mix else "NOPE",
+              pop_wgt_df=None, input_file=inp, reference_pop_desc_file=desc)
+    assert _view_equals_prepared(getattr(api, "KIND_" + kind), mix, kw, packed) == "error"
+
+
+def _odd_study(d, seed):
+    """A small panel and study full of the sites the merge has to hand to the map code: positions the panel lists two or three times
+    (other alleles, the same alleles, swapped alleles), equal alleles, study rows listed twice, under other alleles, under both
+    orders, study-only positions, rows of other chromosomes on both sides."""
+    rng = np.random.default_rng(seed)
+    pops = [("AAA", 40, "EUR"), ("BBB", 36, "ASN"), ("CCC", 28, "EUR")]
+    sizes = [q[1] for q in pops]
+    alle = list("ACGT") + ["AT", "ACGTACGTACGTACGTACGTACG"]
+    sites = np.sort(rng.choice(np.arange(1000, 60_000, 100), size=int(rng.integers(60, 140)), replace=False))
+    pan = []
+    for bp in sites:
+        k = int(rng.choice([1, 1, 1, 1, 2, 2, 3]))
+        first = None
+        for j in range(k):
+            a1, a2 = rng.choice(alle, 2, replace=bool(rng.random() < 0.08))
+            if first is not None and rng.random() < 0.3:
+                a1, a2 = first if rng.random() < 0.5 else first[::-1]        # the same site again, or under the other order
+            first = first or (a1, a2)
+            pan.append((22, int(bp), str(a1), str(a2)))
+    pan = [(21, 5000, "A", "C"), (21, 7000, "G", "T")] + pan + [(23, 100, "A", "C")]
+    S = len(pan)
+    G = rng.integers(0, 3, size=(S, sum(sizes)), dtype=np.uint8)
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    af = np.stack([G[:, off[k]:off[k + 1]].sum(1) / (2.0 * sizes[k]) for k in range(len(pops))], 1)
+    idx, dat, desc, gpk, gwas = (os.path.join(d, n) for n in ("index.gz", "data.gz", "desc.txt", "p.gpk", "gwas.txt"))
+    panel.write_pop_desc(desc, pops)
+    panel.write_panel(idx, dat, np.array([f"rs{i}" for i in range(S)]), np.array([q[0] for q in pan]), np.array([q[1] for q in pan]),
+                      np.array([q[2] for q in pan]), np.array([q[3] for q in pan]), G, af, sizes)
+    assert api.pack_panel(idx, dat, desc, gpk) == S
+    gw = []
+    both_orders = bool(rng.random() < 0.25)                       # the reference's "duplicates" error, somewhere in the study
+    for c, bp, a1, a2 in pan:
+        u = rng.random()
+        if u < 0.35:
+            continue
+        if u < 0.6: gw.append((c, bp, a1, a2))
+        elif u < 0.75: gw.append((c, bp, a2, a1))
+        elif u < 0.85: gw.append((c, bp, a1, str(rng.choice(alle))))
+        elif u < 0.93: gw += [(c, bp, a1, a2), (c, bp, a1, a2)]     # listed twice: the later row counts
+        else: gw += [(c, bp, a1, a2), (c, bp, str(rng.choice(alle)), str(rng.choice(alle)))]
+    if both_orders:
+        c, bp, a1, a2 = pan[int(rng.integers(2, S - 1))]
+        if a1 != a2:
+            gw += [(c, bp, a1, a2), (c, bp, a2, a1)]
+    gw += [(22, int(b), "A", "G") for b in rng.choice(np.arange(1050, 60_000, 100), size=6, replace=False)]        # study only
+    gw += [(21, 5000, "A", "C"), (20, 30_000, "A", "C")]
+    order = rng.permutation(len(gw))
+    z = np.round(rng.standard_normal(len(gw)) * 2, 4)
+    z[rng.random(len(gw)) < 0.05] = 0.0
+    panel.write_gwas(gwas, [f"g{i}" for i in range(len(gw))], [gw[i][0] for i in order], [gw[i][1] for i in order],
+                     [gw[i][2] for i in order], [gw[i][3] for i in order], z)
+    return dict(idx=idx, dat=dat, desc=desc, gpk=gpk, gwas=gwas, sites=sites)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_chrom_window_on_odd_sites_equals_prepare_and_the_text_feeder(tmp_path, seed):
+    """Random panels / studies made of the odd sites (above): the driver's window, the packed feeder and the text feeder agree on every
+    one of them, for the four window kinds and several window placements -- and fail with the same words where the reference does."""
+    st = _odd_study(str(tmp_path), seed)
+    rng = np.random.default_rng(1000 + seed)
+    outcomes = set()
+    for kind in ("DIST", "DISTMIX", "QCAT", "QCATMIX"):
+        mix = kind in ("DISTMIX", "QCATMIX")
+        for _ in range(3):
+            lo = int(rng.integers(500, 30_000))
+            hi = lo + int(rng.integers(5_000, 30_000))
+            wing = int(rng.choice([0, 3_000, 20_000]))
+            kw = dict(chr=22, start_bp=lo, end_bp=hi, wing_size=wing, study_pop=None if mix else "EUR",
+                      pop_wgt_df=(["AAA", "BBB", "ccc"], [0.5, 0.3, 0.2]) if mix else None, input_file=st["gwas"],
+                      reference_pop_desc_file=st["desc"], af1_cutoff=float(rng.choice([0.0001, 0.05, 0.2])))
+            k = getattr(api, "KIND_" + kind)
+            outcomes.add(_view_equals_prepared(k, mix, kw, st["gpk"]))
+            # the packed feeder against the text feeder (a site the panel lists twice in a WING is a measured SNP in both)
+            try:
+                a = api.Prepared(k, **dict(kw, reference_index_file=st["idx"], reference_data_file=st["dat"]))
+            except api.GaussError as e:
+                with pytest.raises(api.GaussError) as ei:
+                    api.Prepared(k, **dict(kw, reference_index_file=st["idx"], reference_data_file=st["gpk"]))
+                assert str(ei.value) == str(e)
+                continue
+            b = api.Prepared(k, **dict(kw, reference_index_file=st["idx"], reference_data_file=st["gpk"]))
+            da, db = a.snps(), b.snps()
+            if kind in ("DIST", "DISTMIX"):
+                # (the packed feeder leaves out a wing's type-0 SNP that is its position's only panel entry; the ones it does enter --
+                # nothing reads them -- must be the text feeder's, in its order)
+                keep = (da["type"].to_numpy() != 0) | ((da["bp"].to_numpy() >= lo) & (da["bp"].to_numpy() <= hi))
+                db_keys = set(zip(db["bp"], db["a1"], db["a2"]))
+                keep |= np.array([(x, y, w) in db_keys for x, y, w in zip(da["bp"], da["a1"], da["a2"])], dtype=bool)
+                da = da[keep].reset_index(drop=True)
+            for c in da.columns:
+                if c == "fpos":
+                    continue
+                if da[c].dtype.kind == "f":
+                    assert np.array_equal(da[c].to_numpy(), db[c].to_numpy(), equal_nan=True), (kind, c)
+                else:
+                    assert list(da[c]) == list(db[c]), (kind, c)
+            assert (a.M, a.U) == (b.M, b.U) and np.array_equal(a.z1(), b.z1())
+            assert np.array_equal(a.geno_m(), b.geno_m()) and np.array_equal(a.geno_u(), b.geno_u())
+            a.close(); b.close()
+    assert outcomes <= {"ok", "error"}
+
+
+def test_a_site_the_panel_lists_twice_in_a_wing_is_measured_everywhere(tmp_path):
+    """gauss.cpp:356-361: the second of two identical panel entries FINDS the first one in the SNP map and turns it into a type-1
+    SNP (z = 0, info = -1) -- also in a wing, where the packed feeders leave a lone unmeasured SNP out.  Text feeder, packed feeder
+    and the driver's window agree on it."""
+    pops = [("AAA", 40, "EUR"), ("BBB", 36, "ASN")]
+    sizes = [q[1] for q in pops]
+    rng = np.random.default_rng(3)
+    pan = [(1000, "A", "C"), (1000, "A", "C"), (1500, "G", "T")] + [(2000 + 100 * i, "A", "G") for i in range(30)]
+    S = len(pan)
+    G = rng.integers(0, 3, size=(S, sum(sizes)), dtype=np.uint8)
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    af = np.stack([G[:, off[k]:off[k + 1]].sum(1) / (2.0 * sizes[k]) for k in range(len(pops))], 1)
+    d = str(tmp_path)
+    idx, dat, desc, gpk, gwas = d + "/index.gz", d + "/data.gz", d + "/desc.txt", d + "/p.gpk", d + "/gwas.txt"
+    panel.write_pop_desc(desc, pops)
+    panel.write_panel(idx, dat, np.array([f"rs{i}" for i in range(S)]), np.full(S, 22), np.array([q[0] for q in pan]),
+                      np.array([q[1] for q in pan]), np.array([q[2] for q in pan]), G, af, sizes)
+    assert api.pack_panel(idx, dat, desc, gpk) == S
+    meas = list(range(3, S, 2))
+    panel.write_gwas(gwas, [f"g{i}" for i in meas], [22] * len(meas), [pan[i][0] for i in meas], [pan[i][1] for i in meas],
+                     [pan[i][2] for i in meas], rng.standard_normal(len(meas)))
+    kw = dict(chr=22, start_bp=2000, end_bp=9000, wing_size=1500, study_pop="EUR", input_file=gwas, reference_pop_desc_file=desc, af1_cutoff=0.0001)
+    a = api.Prepared(api.KIND_DIST, reference_index_file=idx, reference_data_file=dat, **kw)
+    b = api.Prepared(api.KIND_DIST, reference_index_file=idx, reference_data_file=gpk, **kw)
+    df, named, msg = api.chrom_window_view(api.KIND_DIST, 22, 2000, 9000, 1500, gwas, gpk, desc, study_pop="EUR", af1_cutoff=0.0001)
+    for t in (a.snps(), b.snps(), df):
+        row = t[t["bp"] == 1000]
+        assert len(row) == 1 and int(row["type"].iloc[0]) == 1 and row["rsid"].iloc[0] == "rs1" and float(row["z"].iloc[0]) == 0.0 and float(row["info"].iloc[0]) == -1.0
+    assert 1500 in set(a.snps()["bp"]) and 1500 not in set(b.snps()["bp"]) and 1500 not in set(df["bp"])      # the lone wing SNP
+    assert a.M == b.M == int(named["counts"][0]) == len(meas) + 1 and msg is None
+    assert np.array_equal(a.z1(), b.z1()) and np.array_equal(a.z1(), named["z1"]) and a.z1()[0] == 0.0
+    a.close(); b.close()

@@ -53,6 +53,21 @@ def main():
             mu = (pr.M, pr.U)
             pr.close()
         print("pass %d: %d windows, %.2f ms total, mean %.3f ms, max %.3f ms (last window M, U = %s)" % (r, len(wins), sum(ts), np.mean(ts), max(ts), mu))
+    # the chromosome driver's own window (a merge of the two sorted tables), through its test view: setup + build + the view's table
+    h = api.load_host()
+    import ctypes as C
+    names, w, n = api._pop_wgt(wgt)
+    for r in range(reps):
+        ts = []
+        for s, e in wins:
+            out = C.c_void_p()
+            t0 = time.perf_counter()
+            rc = h.gauss_host_chrom_window_view(api.KIND_DISTMIX, 22, s, e, 500_000, None, names, w.ctypes.data_as(C.POINTER(C.c_double)), n,
+                                                gwas.encode(), gpk.encode(), desc.encode(), float("nan"), C.byref(out))
+            ts.append((time.perf_counter() - t0) * 1e3)
+            assert rc == 0
+            h.gauss_table_free(out)
+        print("driver's window, pass %d: %.2f ms total, mean %.3f ms, max %.3f ms" % (r, sum(ts), np.mean(ts), max(ts)))
 
 
 if __name__ == "__main__":
