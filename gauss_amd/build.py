@@ -174,12 +174,13 @@ def build_host(force=False, verbose=False):
     os.makedirs(OBJDIR, exist_ok=True)
     hip_so = build_hip(force=False, verbose=verbose)
     hdir = os.path.join(CSRC, "host")
-    srcs = [os.path.join(hdir, f) for f in ("gauss_host.cpp", "bgzf_io.cpp", "packed_panel.cpp")]
-    deps = srcs + [os.path.join(hdir, "bgzf_io.h"), os.path.join(hdir, "packed_panel.h"), os.path.join(HERE, "..", "include", "gauss_host.h"),
+    # (host_internal.h: what the four host_*.cpp share; -fvisibility=hidden: only the C ABI of include/gauss_host.h is exported)
+    srcs = [os.path.join(hdir, f) for f in ("host_feeder.cpp", "host_tables.cpp", "host_calls.cpp", "host_chrom.cpp", "bgzf_io.cpp", "packed_panel.cpp")]
+    deps = srcs + [os.path.join(hdir, "host_internal.h"), os.path.join(hdir, "bgzf_io.h"), os.path.join(hdir, "packed_panel.h"), os.path.join(HERE, "..", "include", "gauss_host.h"),
                    os.path.join(HERE, "..", "include", "gauss_hip.h"), hip_so]
     so = os.path.join(LIBDIR, "libgauss_host.so")
     if force or _newer(so, deps):
-        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", so] + srcs + [
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-fvisibility-inlines-hidden", "-Wall", "-o", so] + srcs + [
             "-L" + LIBDIR, "-lgauss_hip", "-Wl,-rpath,$ORIGIN", "-lz", "-lpthread", "-ldl"]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)

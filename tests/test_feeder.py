@@ -360,7 +360,7 @@ def test_packed_panel_jepeg_and_errors(study, packed, tmp_path):
 
 def test_gene_drivers_index_merge_on_odd_positions(tmp_path):
     """jepeg / jepegmix merge the genome-wide index into the study's SNP map (ReadReferenceIndexAll, gauss.cpp:431-518).  On a
-    packed panel that merge walks the map's positions (gauss_host.cpp:ReadReferenceIndex) instead of the panel: positions with
+    packed panel that merge walks the map's positions (host_feeder.cpp:ReadReferenceIndex) instead of the panel: positions with
     two panel entries, with two study SNPs, with swapped alleles, study-only and panel-only positions, and an annotation that
     names the swapped order must come out exactly as the text feeder's panel-order scan leaves them -- and a site listed
     under both allele orders in the study is the reference's duplicate error in both."""
@@ -469,7 +469,7 @@ def test_fast_text_panel_writer_equals_the_line_by_line_writer(study, packed, tm
 
 
 def test_window_snp_maps_live_in_pooled_blocks(study, packed):
-    """A window's SNP objects and map nodes are carved out of pooled 2 MB blocks (gauss_host.cpp, BlockPool): many windows
+    """A window's SNP objects and map nodes are carved out of pooled 2 MB blocks (host_internal.h: BlockPool): many windows
     open at once on several threads, closed in another order, opened again out of the returned blocks -- the SNP lists are
     the same every time, and with no block kept between windows and blocks so small that a window spans several
     (GAUSS_HOST_ARENA_KEEP_MB=0, GAUSS_HOST_ARENA_BLOCK_KB=64: a child process) as well."""
@@ -733,7 +733,7 @@ def test_panel_cache_concurrent_callers_pack_once(tmp_path):
     assert sorted(int(o[1]) for o in outs) == [0, 0, 0, 400]                  # exactly one of them did the packing
 
 
-# ---- the chromosome driver's own window (gauss_host.cpp:LeanWindow): a merge of two sorted tables ---------------------
+# ---- the chromosome driver's own window (host_chrom.cpp:LeanWindow): a merge of two sorted tables ---------------------
 def _view_equals_prepared(kind, mix, kw, gpk):
     """gauss_host_chrom_window_view against gauss_host_prepare on the same packed panel: the SNP list (without the wings' type-0
     SNPs, which the driver's window does not enter and nothing reads), the panel rows of the measured / unmeasured SNPs, z1,

@@ -307,7 +307,7 @@ def test_random_driver_calls_match_the_python_drivers(ctx, tmp_path, seed):
 def test_random_gene_and_ld_driver_calls_match_the_python_drivers(ctx, tmp_path, seed):
     """jepeg / jepegmix (gene.cpp, jepeg.cpp:28-153) and computeLD (computeLD.cpp:26-166) end to end on random studies with a
     random annotation, text panel and packed form (the packed form walks the study's positions in the genome-wide index merge:
-    gauss_host.cpp:ReadReferenceIndex)."""
+    host_feeder.cpp:ReadReferenceIndex)."""
     from oracle import feeder_py as fp
     from gauss_amd import api
     rng = np.random.default_rng(12000 + seed)

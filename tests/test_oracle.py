@@ -149,7 +149,7 @@ def _same_tail(a, b):
 
 def test_jepeg_gene_tail_c_oracle_and_product_host_tail_vs_independent_numpy():
     """Three statements of gene.cpp:317-550 must agree: the C oracle (loop-literal), the product's host tail
-    (gauss_host.cpp:jepeg_tail, reached through gauss_host_jepeg_gene_tail, no GPU) and the independent numpy /
+    (host_tables.cpp:jepeg_tail, reached through gauss_host_jepeg_gene_tail, no GPU) and the independent numpy /
     LAPACK / scipy statement in oracle_np.py that was written from the reference alone.  Cases include collinear
     categories (|r| > 0.8 pruning from the last category down), low-variance categories, imputed SNPs (info < 1),
     genes whose every category is pruned (df = 0) and single-SNP genes."""

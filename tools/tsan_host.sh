@@ -8,7 +8,7 @@ set -e
 cd "$(dirname "$0")/.."
 mkdir -p gauss_amd/lib/tsan gpurun_out
 g++ -O1 -g -std=c++17 -fPIC -shared -fsanitize=thread -fno-omit-frame-pointer \
-    -o gauss_amd/lib/tsan/libgauss_host.so gauss_amd/csrc/host/gauss_host.cpp gauss_amd/csrc/host/bgzf_io.cpp \
+    -o gauss_amd/lib/tsan/libgauss_host.so gauss_amd/csrc/host/host_*.cpp gauss_amd/csrc/host/bgzf_io.cpp \
     gauss_amd/csrc/host/packed_panel.cpp -Lgauss_amd/lib -lgauss_hip -Wl,-rpath,"$(pwd)/gauss_amd/lib" -lz -lpthread -ldl
 cat > gpurun_out/tsan_run.py <<PY
 import os, sys, tempfile
