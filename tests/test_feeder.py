@@ -790,7 +790,7 @@ def test_chrom_window_view_equals_prepare(study, packed, kind):
     assert _view_equals_prepared(getattr(api, "KIND_" + kind), mix, kw, packed) == "error"
 
 
-def _odd_study(d, seed):
+def _odd_study(d, seed, n_sites=None):
     """A small panel and study full of the sites the merge has to hand to the map code: positions the panel lists two or three times
     (other alleles, the same alleles, swapped alleles), equal alleles, study rows listed twice, under other alleles, under both
     orders, study-only positions, rows of other chromosomes on both sides."""
@@ -798,14 +798,14 @@ def _odd_study(d, seed):
     pops = [("AAA", 40, "EUR"), ("BBB", 36, "ASN"), ("CCC", 28, "EUR")]
     sizes = [q[1] for q in pops]
     alle = list("ACGT") + ["AT", "ACGTACGTACGTACGTACGTACG"]
-    sites = np.sort(rng.choice(np.arange(1000, 60_000, 100), size=int(rng.integers(60, 140)), replace=False))
+    sites = np.sort(rng.choice(np.arange(1000, 60_000, 100), size=int(n_sites or rng.integers(60, 140)), replace=False))
     pan = []
     for bp in sites:
         k = int(rng.choice([1, 1, 1, 1, 2, 2, 3]))
         first = None
         for j in range(k):
-            a1, a2 = rng.choice(alle, 2, replace=bool(rng.random() < 0.08))
-            if first is not None and rng.random() < 0.3:
+            a1, a2 = rng.choice(alle, 2, replace=bool(rng.random() < (0.08 if n_sites is None else 0.01)))   # (equal alleles + a study row of them: "duplicates")
+            if first is not None and rng.random() < (0.3 if n_sites is None else 0.04):   # (a large study: rarely, or every window trips the duplicate check)
                 a1, a2 = first if rng.random() < 0.5 else first[::-1]        # the same site again, or under the other order
             first = first or (a1, a2)
             pan.append((22, int(bp), str(a1), str(a2)))
@@ -820,7 +820,7 @@ def _odd_study(d, seed):
                       np.array([q[2] for q in pan]), np.array([q[3] for q in pan]), G, af, sizes)
     assert api.pack_panel(idx, dat, desc, gpk) == S
     gw = []
-    both_orders = bool(rng.random() < 0.25)                       # the reference's "duplicates" error, somewhere in the study
+    both_orders = bool(rng.random() < (0.25 if n_sites is None else 0.5))      # the reference's "duplicates" error, somewhere in the study
     for c, bp, a1, a2 in pan:
         u = rng.random()
         if u < 0.35:
@@ -830,6 +830,12 @@ def _odd_study(d, seed):
         elif u < 0.85: gw.append((c, bp, a1, str(rng.choice(alle))))
         elif u < 0.93: gw += [(c, bp, a1, a2), (c, bp, a1, a2)]     # listed twice: the later row counts
         else: gw += [(c, bp, a1, a2), (c, bp, str(rng.choice(alle)), str(rng.choice(alle)))]
+    if n_sites is not None:
+        # a large study: one window at most may trip the duplicate check (the injected site below) -- a row whose swapped twin is also
+        # listed goes, and so does a row of equal alleles that the panel lists too
+        have = set(gw)
+        pset = set(pan)
+        gw = [r for r in gw if not ((r[2] != r[3] and (r[0], r[1], r[3], r[2]) in have) or (r[2] == r[3] and r in pset))]
     if both_orders:
         c, bp, a1, a2 = pan[int(rng.integers(2, S - 1))]
         if a1 != a2:

@@ -432,3 +432,51 @@ def test_random_chromosome_runs_equal_per_window_calls(ctx, tmp_path, seed):
             x, y = g.columns[c], w.columns[c]
             assert np.array_equal(x, y, equal_nan=True) if x.dtype.kind == "f" else np.array_equal(x, y), c
     api.panel_evict(ctx=ctx)
+
+
+@pytest.mark.parametrize("seed", list(range(SEED0, SEED0 + int(os.environ.get("GAUSS_FUZZ_ODD_SEEDS", "8")))))
+def test_chromosome_runs_on_odd_sites_equal_per_window_calls(ctx, tmp_path, seed):
+    """The chromosome driver builds its windows by a merge of the sorted study and panel tables and hands every odd position -- a site
+    the panel or the study lists more than once, equal alleles, both allele orders -- to the map code of the one-window entry points
+    (host_chrom.cpp:LeanWindow).  On panels made of such sites (tests/test_feeder.py:_odd_study) the driver's table is, bit for bit,
+    what the one-window calls give; a window whose study trips the reference's duplicate check fails in both, alone."""
+    import pandas as pd
+    from gauss_amd import api
+    from test_feeder import _odd_study
+    st = _odd_study(str(tmp_path), 500 + seed, n_sites=420)
+    rng = np.random.default_rng(22000 + seed)
+    kind_name = ["DISTMIX", "DIST", "QCATMIX", "QCAT"][seed % 4]
+    kind = getattr(api, "KIND_" + kind_name)
+    mix = kind_name.endswith("MIX")
+    who = (["AAA", "BBB", "ccc"], [0.5, 0.3, 0.2]) if mix else "EUR"
+    sel = dict(pop_wgt_df=who) if mix else dict(study_pop="EUR")
+    wing = int(rng.choice([0, 2_000, 8_000]))
+    wsize = int(rng.choice([8_000, 15_000, 30_000]))
+    cutoff = float(rng.choice([0.0001, 0.05]))
+    api.panel_evict(ctx=ctx)
+    res = api.impute_chromosome(kind, 22, 1_000, 60_000, wing, input_file=st["gwas"], reference_data_file=st["gpk"], reference_pop_desc_file=st["desc"],
+                                window_size=wsize, af1_cutoff=cutoff, n_batches=int(rng.integers(0, 4)), ctx=ctx, **sel)
+    fn = {"DIST": api.dist, "DISTMIX": api.distmix, "QCAT": api.qcat, "QCATMIX": api.qcatmix}[kind_name]
+    frames, n_done = [], 0
+    for s, e, owner, status, m, u in res.windows:
+        a = (22, int(s), int(e), wing, who, st["gwas"], st["idx"], st["gpk"], st["desc"])
+        if status != 0:
+            with pytest.raises(api.GaussError, match="Not enough number of SNPs" if status == 1 else "duplicates"):
+                fn(*a, af1_cutoff=cutoff, ctx=ctx)
+            continue
+        frames.append(fn(*a, af1_cutoff=cutoff, ctx=ctx))
+        n_done += 1
+    assert res.stats["n_failed"] == sum(1 for w in res.windows if w[3] == 2) == len(res.messages)
+    assert n_done >= 1 or res.stats["n_failed"] >= 1                      # (the windows are large enough to pass the ">10" guards)
+    print("odd sites seed %d: %s, %d windows done, %d failed on duplicates, %d skipped, %d rows" %
+          (seed, kind_name, n_done, res.stats["n_failed"], res.stats["n_skipped"], len(res.columns["bp"])))
+    got = res.frame()
+    want = pd.concat(frames, ignore_index=True) if frames else None
+    assert len(got) == (len(want) if want is not None else 0)
+    if want is not None:
+        assert list(got.columns) == list(want.columns)
+        for c in want.columns:
+            if want[c].dtype.kind == "f":
+                assert np.array_equal(got[c].to_numpy(), want[c].to_numpy(), equal_nan=True), c
+            else:
+                assert list(got[c]) == list(want[c]), c
