@@ -761,7 +761,12 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
     // window has nothing to hide its factorisation chain under; 8-rank shares 7.4-8.4 ms against 7.8-8.2.  DESIGN.md 9e item 10.)
     const size_t lead = 0;
     const size_t n_rest = mine.size() - lead;
-    if (n_batches < 1) n_batches = (int)lead + (n_rest >= 16 ? (first_use && async_upload ? 6 : 4) : (n_rest >= 9 ? 3 : (n_rest >= 4 ? 2 : 1)));
+    // How many batches: a batch boundary costs ~0.35 ms of GPU span (the chip drains and fills), a batch in front of the GPU one
+    // window's data layer and job tables (~0.2 ms a window since the driver builds its own windows).  Measured on the chr22 study,
+    // warm (tools/e2e_rank_trace.py, ms per call with 1 / 2 / 3 / 4 batches): 4-5 windows (a rank of eight) 5.9 / 6.3 / - / -;
+    // 9 windows 11.6 / 11.0 / 11.3 / 11.1; 18 windows 20.8 / 19.7 / 19.6 / 19.9; 36 windows - / 39.4 / 38.1 / 37.5 (six: 37.8).
+    if (n_batches < 1)
+        n_batches = (int)lead + (n_rest >= 28 ? (first_use && async_upload ? 6 : 4) : (n_rest >= 20 ? 3 : (n_rest >= 9 ? 2 : 1)));
     n_batches = std::max(1, std::min<int>(n_batches, std::max<size_t>(mine.size(), 1)));
     // contiguous batches by cost.  The first batch is the one nothing overlaps with on the way in (its data layer)
     // and the last one on the way out (its tables), so with four or more batches those two get 0.3 of a share.

@@ -282,18 +282,18 @@ def test_gpu_native_chromosome_run_equals_the_python_farm(ctx, tmp_path):
 @pytest.mark.gpu
 def test_gpu_native_chromosome_first_use_of_a_panel(ctx, tmp_path, monkeypatch):
     """First use of a panel on a context: its rows travel to HBM WHILE the batches compute (background upload, a batch waits for
-    the rows it names, gauss_store_wait), in six graded batches when the rank holds sixteen windows or more; a later call finds
+    the rows it names, gauss_store_wait), in six graded batches when the rank holds twenty-eight windows or more; a later call finds
     the panel resident and runs four.  Either way, and for every form of the upload (DMA copies, the copy kernel, in one go
     before the first batch), the table is the same, bit for bit."""
     st = make_study(tmp_path)
     p = st["paths"]
     gpk = str(tmp_path / "panel.gpk")
     assert api.pack_panel(p["index.gz"], p["data.gz"], p["desc.txt"], gpk) > 0
-    kw = dict(kind=api.KIND_DISTMIX, pop_wgt_df=WGT, window_size=125_000, input_file=p["gwas.txt"], reference_data_file=gpk,
+    kw = dict(kind=api.KIND_DISTMIX, pop_wgt_df=WGT, window_size=100_000, input_file=p["gwas.txt"], reference_data_file=gpk,
               reference_pop_desc_file=p["desc.txt"], ctx=ctx, chr=22, start_bp=1_000_001, end_bp=4_000_000, wing_size=200_000)
     api.panel_evict(ctx=ctx)
     first = api.impute_chromosome(**kw)
-    assert first.stats["n_windows_mine"] == 24 and first.stats["n_failed"] == 0
+    assert first.stats["n_windows_mine"] == 30 and first.stats["n_failed"] == 0
     assert first.stats["panel_bytes_uploaded"] > 0 and first.stats["n_batches"] == 6
     warm = api.impute_chromosome(**kw)
     assert warm.stats["panel_bytes_uploaded"] == 0 and warm.stats["n_batches"] == 4
