@@ -505,6 +505,120 @@ static gauss_table* lean_window_finish(LeanWindow& w)
 }
 
 // ------------------------------------------------------------------------------------------
+// The chromosome driver's plan: windows, their costs, their owners (identical on every rank: no communication)
+// ------------------------------------------------------------------------------------------
+struct ChromWin { int64_t s, e; double cost; int owner, status, M, U; std::string why; };
+
+// The windows of [start_bp, end_bp] with their predicted sizes: measured SNPs from the study (rows of the extended window), panel
+// SNPs of the prediction window from the packed index, unmeasured = the difference.  One chromosome: counts are ranges of the
+// study's (chr, bp)-ordered index (no copy, no sort: that copy and sort were most of the plan's 0.13 ms).
+static void plan_windows(std::vector<ChromWin>& wins, const GwasCache& gw, const PackedPanel& pk, int chr, int64_t start_bp, int64_t end_bp,
+                         int64_t wing_size, int64_t window_size)
+{
+    std::vector<long long> gbp;                                   // a call over every chromosome: positions of all rows, sorted
+    if (chr <= 0) {
+        for (const GwasRow& r : gw.rows) gbp.push_back(r.bp);
+        std::sort(gbp.begin(), gbp.end());
+    }
+    auto before = [&](uint32_t x, long long bp) { const GwasRow& r = gw.rows[x]; return r.chr < chr || (r.chr == chr && r.bp < bp); };
+    auto rows_in = [&](long long lo, long long hi) -> double {    // study rows with lo <= bp <= hi
+        if (chr <= 0) return (double)(std::upper_bound(gbp.begin(), gbp.end(), hi) - std::lower_bound(gbp.begin(), gbp.end(), lo));
+        return (double)(std::lower_bound(gw.by_pos.begin(), gw.by_pos.end(), hi + 1, before) - std::lower_bound(gw.by_pos.begin(), gw.by_pos.end(), lo, before));
+    };
+    for (int64_t s0 = start_bp; s0 <= end_bp; s0 += window_size) {
+        ChromWin w;
+        w.s = s0; w.e = std::min(end_bp, s0 + window_size - 1);
+        const double m = rows_in((long long)(w.s - wing_size), (long long)(w.e + wing_size));
+        double u = 0;
+        if (pk.header().sorted && chr > 0) {
+            const double in_panel = (double)(pk.lower_bound(chr, w.e + 1) - pk.lower_bound(chr, w.s));
+            u = std::max(0.0, in_panel - rows_in((long long)w.s, (long long)w.e));
+        }
+        w.cost = issued_cost_per_sample((int)m, (int)u) + 1.0;   // what the Gram kernel issues for the window, per sample (above)
+        w.owner = 0; w.status = -1; w.M = (int)m; w.U = (int)u;
+        wins.push_back(w);
+    }
+}
+
+static void plan_owners(std::vector<ChromWin>& wins, const PackedPanel& pk_, int world)
+{
+    const PackedPanel* pk = &pk_;
+    {   // Whole windows by longest processing time first (ties by index), then a local search -- the idea of
+        // farm.level_windows without the cuts, on a simpler cost model: a window costs its LD flops per sample (the
+        // Python planner also prices B11's factorisation and the per-SNP tail, so the two plans may pick different
+        // owners; each is used consistently by every rank of its own driver).  A rank's load is the cost of its windows
+        // plus the factorisation chain of its tallest one (the chain is latency bound on the few windows a rank
+        // holds: DESIGN.md section 6; farm.CHAIN_STEP_COST, here per sample).
+        std::vector<int> order(wins.size());
+        for (size_t i = 0; i < order.size(); i++) order[i] = (int)i;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return wins[a].cost > wins[b].cost; });
+        std::vector<double> load((size_t)world, 0.0);
+        for (int i : order) {
+            int r = 0;
+            for (int k = 1; k < world; k++) if (load[k] < load[r]) r = k;
+            wins[i].owner = r; load[r] += wins[i].cost;
+        }
+        double n_samples = 0;
+        for (uint32_t q = 0; q < pk->header().n_pop; q++) n_samples += pk->pop((int)q).size;
+        const double chain = 2.0e8 / std::max(1.0, n_samples);       // (a tie-breaker since the chain runs under the Gram kernel: farm.CHAIN_STEP_COST)
+        // Local search of moves (a window of the fullest rank goes to another rank) and trades.  Per rank: the summed cost
+        // and the block counts of its windows (the chain term needs the tallest one, also "the tallest without window
+        // x"), so a candidate costs O(1); candidates are counted and the search stops at a fixed budget -- the same
+        // on every rank, which must all arrive at the same plan (no wall-clock limits) -- so a chromosome cut into
+        // thousands of windows plans in milliseconds too (it used to be cubic in the window count).
+        auto nblk = [&](int i) { return (wins[i].M + 63) / 64; };
+        std::vector<double> rcost((size_t)world, 0.0);
+        std::vector<std::multiset<int>> rtall((size_t)world);
+        std::vector<std::vector<int>> rwin((size_t)world);
+        auto rebuild = [&]() {
+            for (int r = 0; r < world; r++) { rcost[r] = 0; rtall[r].clear(); rwin[r].clear(); }
+            for (size_t i = 0; i < wins.size(); i++) {
+                const int r = wins[i].owner;
+                rcost[r] += wins[i].cost; rtall[r].insert(nblk((int)i)); rwin[r].push_back((int)i);
+            }
+        };
+        auto load_of = [&](int r, int drop, int add) {            // rank r's load without window `drop`, with window `add`
+            double c = rcost[r];
+            int tall = 0;
+            if (drop >= 0) {
+                c -= wins[drop].cost;
+                auto it = rtall[r].end();
+                if (!rtall[r].empty()) {
+                    --it;                                          // the tallest; if that is `drop` itself, the next one
+                    if (*it == nblk(drop)) { if (it != rtall[r].begin()) { --it; tall = *it; } }
+                    else tall = *it;
+                }
+            } else if (!rtall[r].empty()) tall = *rtall[r].rbegin();
+            if (add >= 0) { c += wins[add].cost; tall = std::max(tall, nblk(add)); }
+            return c + chain * tall;
+        };
+        rebuild();
+        long long budget = 4000000;                                // candidate evaluations
+        for (size_t it = 0; world > 1 && it < 4 * wins.size() && budget > 0; it++) {
+            int hi = 0; double top = -1;
+            for (int r = 0; r < world; r++) { const double l = load_of(r, -1, -1); if (l > top) { top = l; hi = r; } }
+            double best = top * (1 - 1e-9); int ba = -1, bb = -1, br = -1;
+            for (int a : rwin[hi]) {
+                for (int r = 0; r < world && budget > 0; r++) {
+                    if (r == hi) continue;
+                    budget -= 1 + (long long)rwin[r].size();
+                    double m = std::max(load_of(hi, a, -1), load_of(r, -1, a));          // move a to r
+                    if (m < best) { best = m; ba = a; bb = -1; br = r; }
+                    for (int b2 : rwin[r]) {                                              // trade a for b2
+                        m = std::max(load_of(hi, a, b2), load_of(r, b2, a));
+                        if (m < best) { best = m; ba = a; bb = b2; br = r; }
+                    }
+                }
+            }
+            if (ba < 0) break;
+            wins[ba].owner = br;
+            if (bb >= 0) wins[bb].owner = hi;
+            rebuild();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // A whole chromosome: the caller-level loop over windows that the reference leaves to the R user
 // (docs/articles/dist_example.md:144-153 calls one window), as ONE native call per rank.
 //
@@ -649,101 +763,9 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
     std::shared_ptr<const GwasCache> gw = load_gwas_cached(input_file, err);
     if (!gw) return herr("%s", err.c_str());
     const double t_study = now_s();
-    std::vector<long long> gbp;
-    for (const GwasRow& r : gw->rows)
-        if (chr <= 0 || r.chr == chr) gbp.push_back(r.bp);
-    std::sort(gbp.begin(), gbp.end());
-    struct Win { int64_t s, e; double cost; int owner, status, M, U; std::string why; };
-    std::vector<Win> wins;
-    for (int64_t s0 = start_bp; s0 <= end_bp; s0 += window_size) {
-        Win w;
-        w.s = s0; w.e = std::min(end_bp, s0 + window_size - 1);
-        const double m = (double)(std::upper_bound(gbp.begin(), gbp.end(), (long long)(w.e + wing_size)) -
-                                  std::lower_bound(gbp.begin(), gbp.end(), (long long)(w.s - wing_size)));
-        double u = 0;
-        if (pk->header().sorted && chr > 0) {
-            const double in_panel = (double)(pk->lower_bound(chr, w.e + 1) - pk->lower_bound(chr, w.s));
-            const double m_pred = (double)(std::upper_bound(gbp.begin(), gbp.end(), (long long)w.e) -
-                                           std::lower_bound(gbp.begin(), gbp.end(), (long long)w.s));
-            u = std::max(0.0, in_panel - m_pred);
-        }
-        w.cost = issued_cost_per_sample((int)m, (int)u) + 1.0;   // what the Gram kernel issues for the window, per sample (above)
-        w.owner = 0; w.status = -1; w.M = (int)m; w.U = (int)u;
-        wins.push_back(w);
-    }
-    {   // Whole windows by longest processing time first (ties by index), then a local search -- the idea of
-        // farm.level_windows without the cuts, on a simpler cost model: a window costs its LD flops per sample (the
-        // Python planner also prices B11's factorisation and the per-SNP tail, so the two plans may pick different
-        // owners; each is used consistently by every rank of its own driver).  A rank's load is the cost of its windows
-        // plus the factorisation chain of its tallest one (the chain is latency bound on the few windows a rank
-        // holds: DESIGN.md section 6; farm.CHAIN_STEP_COST, here per sample).
-        std::vector<int> order(wins.size());
-        for (size_t i = 0; i < order.size(); i++) order[i] = (int)i;
-        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return wins[a].cost > wins[b].cost; });
-        std::vector<double> load((size_t)world, 0.0);
-        for (int i : order) {
-            int r = 0;
-            for (int k = 1; k < world; k++) if (load[k] < load[r]) r = k;
-            wins[i].owner = r; load[r] += wins[i].cost;
-        }
-        double n_samples = 0;
-        for (uint32_t q = 0; q < pk->header().n_pop; q++) n_samples += pk->pop((int)q).size;
-        const double chain = 2.0e8 / std::max(1.0, n_samples);       // (a tie-breaker since the chain runs under the Gram kernel: farm.CHAIN_STEP_COST)
-        // Local search of moves (a window of the fullest rank goes to another rank) and trades.  Per rank: the summed cost
-        // and the block counts of its windows (the chain term needs the tallest one, also "the tallest without window
-        // x"), so a candidate costs O(1); candidates are counted and the search stops at a fixed budget -- the same
-        // on every rank, which must all arrive at the same plan (no wall-clock limits) -- so a chromosome cut into
-        // thousands of windows plans in milliseconds too (it used to be cubic in the window count).
-        auto nblk = [&](int i) { return (wins[i].M + 63) / 64; };
-        std::vector<double> rcost((size_t)world, 0.0);
-        std::vector<std::multiset<int>> rtall((size_t)world);
-        std::vector<std::vector<int>> rwin((size_t)world);
-        auto rebuild = [&]() {
-            for (int r = 0; r < world; r++) { rcost[r] = 0; rtall[r].clear(); rwin[r].clear(); }
-            for (size_t i = 0; i < wins.size(); i++) {
-                const int r = wins[i].owner;
-                rcost[r] += wins[i].cost; rtall[r].insert(nblk((int)i)); rwin[r].push_back((int)i);
-            }
-        };
-        auto load_of = [&](int r, int drop, int add) {            // rank r's load without window `drop`, with window `add`
-            double c = rcost[r];
-            int tall = 0;
-            if (drop >= 0) {
-                c -= wins[drop].cost;
-                auto it = rtall[r].end();
-                if (!rtall[r].empty()) {
-                    --it;                                          // the tallest; if that is `drop` itself, the next one
-                    if (*it == nblk(drop)) { if (it != rtall[r].begin()) { --it; tall = *it; } }
-                    else tall = *it;
-                }
-            } else if (!rtall[r].empty()) tall = *rtall[r].rbegin();
-            if (add >= 0) { c += wins[add].cost; tall = std::max(tall, nblk(add)); }
-            return c + chain * tall;
-        };
-        rebuild();
-        long long budget = 4000000;                                // candidate evaluations
-        for (size_t it = 0; world > 1 && it < 4 * wins.size() && budget > 0; it++) {
-            int hi = 0; double top = -1;
-            for (int r = 0; r < world; r++) { const double l = load_of(r, -1, -1); if (l > top) { top = l; hi = r; } }
-            double best = top * (1 - 1e-9); int ba = -1, bb = -1, br = -1;
-            for (int a : rwin[hi]) {
-                for (int r = 0; r < world && budget > 0; r++) {
-                    if (r == hi) continue;
-                    budget -= 1 + (long long)rwin[r].size();
-                    double m = std::max(load_of(hi, a, -1), load_of(r, -1, a));          // move a to r
-                    if (m < best) { best = m; ba = a; bb = -1; br = r; }
-                    for (int b2 : rwin[r]) {                                              // trade a for b2
-                        m = std::max(load_of(hi, a, b2), load_of(r, b2, a));
-                        if (m < best) { best = m; ba = a; bb = b2; br = r; }
-                    }
-                }
-            }
-            if (ba < 0) break;
-            wins[ba].owner = br;
-            if (bb >= 0) wins[bb].owner = hi;
-            rebuild();
-        }
-    }
+    std::vector<ChromWin> wins;
+    plan_windows(wins, *gw, *pk, chr, start_bp, end_bp, wing_size, window_size);
+    plan_owners(wins, *pk, world);
     std::vector<int> mine;
     for (size_t i = 0; i < wins.size(); i++) if (wins[i].owner == rank) mine.push_back((int)i);
     st.n_windows = (int)wins.size();
@@ -837,7 +859,7 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
     std::thread feeder([&]() {
         parallel_for((int)order.size(), nthreads, [&](int q) {
             const int b = order[q].first, k = order[q].second;
-            Win& w = wins[batches[b][k]];
+            ChromWin& w = wins[batches[b][k]];
             Slot& sl = slots[b][k];
             gauss_prepared* p = nullptr;
             if (lean) {
@@ -942,7 +964,7 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
                 Slot& sl = slots[b][k];
                 gauss_job* one = nullptr;
                 if (gauss_job_create(ctx, &sl.d, 1, 1, &one) != 0 || gauss_job_run(one) != 0 || gauss_job_fetch(one) != 0) {
-                    Win& w = wins[batches[b][k]];
+                    ChromWin& w = wins[batches[b][k]];
                     w.status = 2; w.why = std::string(gauss_last_error()) + " (batch error: " + why + ")";
                     sl.ok = false;
                 }
@@ -1004,7 +1026,7 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
                     Slot& sl = slots[b][k];
                     gauss_job* one = nullptr;
                     if (gauss_job_create(ctx, &sl.d, 1, 1, &one) != 0 || gauss_job_run(one) != 0 || gauss_job_fetch(one) != 0) {
-                        Win& w = wins[batches[b][k]];
+                        ChromWin& w = wins[batches[b][k]];
                         w.status = 2; w.why = gauss_last_error();
                         sl.ok = false;
                     }
@@ -1065,7 +1087,7 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
         nm.name = "windows"; nm.nrow = (int)wins.size(); nm.ncol = 6;
         nm.d.assign((size_t)nm.nrow * 6, 0.0);
         for (int i = 0; i < nm.nrow; i++) {
-            const Win& w = wins[i];
+            const ChromWin& w = wins[i];
             const double v[6] = {(double)w.s, (double)w.e, (double)w.owner, (double)w.status, (double)w.M, (double)w.U};
             for (int c = 0; c < 6; c++) nm.d[(size_t)c * nm.nrow + i] = v[c];
             if (w.status == 1) st.n_skipped++;
