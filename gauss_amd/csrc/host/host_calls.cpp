@@ -21,10 +21,25 @@ static int packed_row_source(gauss_ctx* ctx, const gauss_prepared& p, const uint
 
 extern "C" {
 
+static int host_prepare(int kind, int chr, int64_t start_bp, int64_t end_bp, int64_t wing_size, const char* study_pop,
+                        const char* const* pop_names, const double* pop_wgts, int n_pop_wgt, const char* input_file,
+                        const char* annotation_file, const char* reference_index_file, const char* reference_data_file,
+                        const char* reference_pop_desc_file, double af1_cutoff, bool annotated_only, gauss_prepared** out);
+
 int gauss_host_prepare(int kind, int chr, int64_t start_bp, int64_t end_bp, int64_t wing_size, const char* study_pop,
                        const char* const* pop_names, const double* pop_wgts, int n_pop_wgt, const char* input_file,
                        const char* annotation_file, const char* reference_index_file, const char* reference_data_file,
                        const char* reference_pop_desc_file, double af1_cutoff, gauss_prepared** out)
+{
+    // (the whole study enters the SNP map, as in the reference: gauss_prepared_snps lists it)
+    return host_prepare(kind, chr, start_bp, end_bp, wing_size, study_pop, pop_names, pop_wgts, n_pop_wgt, input_file, annotation_file,
+                        reference_index_file, reference_data_file, reference_pop_desc_file, af1_cutoff, false, out);
+}
+
+static int host_prepare(int kind, int chr, int64_t start_bp, int64_t end_bp, int64_t wing_size, const char* study_pop,
+                        const char* const* pop_names, const double* pop_wgts, int n_pop_wgt, const char* input_file,
+                        const char* annotation_file, const char* reference_index_file, const char* reference_data_file,
+                        const char* reference_pop_desc_file, double af1_cutoff, bool annotated_only, gauss_prepared** out)
 {
     if (!out) return herr("out is NULL");
     if (kind < 0 || kind > GAUSS_KIND_PREP_RECESSIVE) return herr("bad kind %d", kind);
@@ -61,6 +76,7 @@ int gauss_host_prepare(int kind, int chr, int64_t start_bp, int64_t end_bp, int6
         set_pop_wgt_map(a, pop_names, pop_wgts, n_pop_wgt);
     } else if (!study_pop) return herr("study_pop is NULL");
     if ((kind == GAUSS_KIND_JEPEG || kind == GAUSS_KIND_JEPEGMIX) && !annotation_file) return herr("annotation_file is NULL");
+    a.annotated_only = annotated_only && (kind == GAUSS_KIND_JEPEG || kind == GAUSS_KIND_JEPEGMIX);
     if (prepare(*p)) return -1;
     *out = p.release();
     return 0;
@@ -650,7 +666,14 @@ static int run_jepeg(gauss_ctx* ctx, int kind, const char* study_pop, const char
 {
     if (!ctx || !out) return herr("bad arguments");
     gauss_prepared* p = nullptr;
-    if (gauss_host_prepare(kind, 0, 0, 0, 0, study_pop, names, wgts, nw, input, annotation, index, data, desc, af1_cutoff, &p)) return -1;
+    // The gene table is made of annotated SNPs alone, and every step of the data layer after ReadInputZ works on the entries of one
+    // position at a time: only the study SNPs at positions the annotation names enter the SNP map (plus the positions the study
+    // lists more than once or under equal alleles -- the only ones where the reference's duplicate check can fire, so a study that
+    // fails there still fails).  A chromosome's study is four times its annotated SNPs: the data layer of a jepegmix() call
+    // 3.6 -> 1.2 ms.  GAUSS_JEPEG_FULL_MAP=1: the whole study, as gauss_host_prepare does it (same table, bit for bit:
+    // tests/test_gpu_drivers.py).
+    const bool full_map = env_flag("GAUSS_JEPEG_FULL_MAP", false);
+    if (host_prepare(kind, 0, 0, 0, 0, study_pop, names, wgts, nw, input, annotation, index, data, desc, af1_cutoff, !full_map, &p)) return -1;
     std::unique_ptr<gauss_prepared> hold(p);
     const Args& a = p->args;
     const int S = (int)p->measured.size();

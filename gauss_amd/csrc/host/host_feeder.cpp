@@ -110,10 +110,20 @@ std::shared_ptr<const GwasCache> load_gwas_cached(const std::string& path, std::
         const GwasRow &a = c->rows[x], &b = c->rows[y];
         return a.chr < b.chr || (a.chr == b.chr && a.bp < b.bp);
     });
+    for (size_t q = 0; q < c->by_pos.size(); q++) {
+        const GwasRow& r = c->rows[c->by_pos[q]];
+        const bool twice = (q + 1 < c->by_pos.size() && c->rows[c->by_pos[q + 1]].chr == r.chr && c->rows[c->by_pos[q + 1]].bp == r.bp);
+        if ((twice || r.a1 == r.a2) && (c->odd_positions.empty() || c->odd_positions.back() != std::make_pair(r.chr, r.bp)))
+            c->odd_positions.emplace_back(r.chr, r.bp);
+    }
     if (cache.size() >= 8) cache.clear();          // a handful of studies per process at most
     cache[k] = c;
     return c;
 }
+
+struct AnnotCache;
+static std::shared_ptr<const AnnotCache> load_annotation_cached(const std::string& path, std::string& err);
+static const std::vector<std::pair<int, long long>>& annotation_positions(const AnnotCache& an);
 
 // ReadInputZ (gauss.cpp:121-190)
 int ReadInputZ(SnpMap& m, const Args& a, bool All)
@@ -131,8 +141,20 @@ int ReadInputZ(SnpMap& m, const Args& a, bool All)
         q0 = (size_t)(std::lower_bound(gw->by_pos.begin(), gw->by_pos.end(), lo, before) - gw->by_pos.begin());
         q1 = (size_t)(std::lower_bound(gw->by_pos.begin(), gw->by_pos.end(), hi + 1, before) - gw->by_pos.begin());
     }
+    // the gene drivers' map: annotated positions and the study's odd ones (Args::annotated_only)
+    const std::vector<std::pair<int, long long>>* named = nullptr;
+    std::shared_ptr<const AnnotCache> an;
+    if (All && a.annotated_only && !a.annotation_file.empty()) {
+        an = load_annotation_cached(a.annotation_file, err);
+        if (!an) return herr("%s", err.c_str());
+        named = &annotation_positions(*an);
+    }
     for (size_t q = q0; q < q1; q++) {
         const GwasRow& r = gw->rows[ranged ? gw->by_pos[q] : q];
+        if (named) {
+            const std::pair<int, long long> at(r.chr, r.bp);
+            if (!std::binary_search(named->begin(), named->end(), at) && !std::binary_search(gw->odd_positions.begin(), gw->odd_positions.end(), at)) continue;
+        }
         if (!All) {
             if ((a.chr > 0) && (a.chr != r.chr)) continue;
             if ((a.start_bp - a.wing_size) > r.bp || (a.end_bp + a.wing_size) < r.bp) continue;
@@ -497,7 +519,12 @@ static int MakeSnpVecMix(std::vector<Snp*>& v, SnpMap& m, const Args& a)
 // the same annotation parses it once.  Rows carry what the reference's loop variables hold after each line (gauss.cpp:1308-1330:
 // a field that fails to parse keeps the previous line's value, an unknown category name the previous number).
 struct AnnotRow { int chr, categ_num; long long bp; double wgt; std::string a1, a2, geneid; };
-struct AnnotCache { std::vector<AnnotRow> rows; };
+struct AnnotCache {
+    std::vector<AnnotRow> rows;
+    std::vector<std::pair<int, long long>> positions;      // the (chr, bp) the file names, sorted, each once
+};
+
+static const std::vector<std::pair<int, long long>>& annotation_positions(const AnnotCache& an) { return an.positions; }
 
 static std::shared_ptr<const AnnotCache> load_annotation_cached(const std::string& path, std::string& err)
 {
@@ -528,6 +555,9 @@ static std::shared_ptr<const AnnotCache> load_annotation_cached(const std::strin
         else if (categ == "TRANS_EQTL") categ_num = 5;      // unknown names keep the previous number (gauss.cpp:1319-1330)
         c->rows.push_back(AnnotRow{chr, categ_num, bp, wgt, a1, a2, geneid});
     }
+    for (const AnnotRow& r : c->rows) c->positions.emplace_back(r.chr, r.bp);
+    std::sort(c->positions.begin(), c->positions.end());
+    c->positions.erase(std::unique(c->positions.begin(), c->positions.end()), c->positions.end());
     if (cache.size() >= 4) cache.clear();
     cache[k] = c;
     return c;

@@ -265,6 +265,10 @@ struct Args {                       // Arguments, gauss.h:18-69 with the default
     // (dist.cpp:132-140 imputes type-0 SNPs of the prediction window only; the output is cut to it, dist.cpp:91-93) --
     // nothing ever reads it, so it is not entered at all (about half of an extended window's panel SNPs)
     bool drop_wing_unmeasured = false;
+    // jepeg / jepegmix drivers: only study SNPs at positions the annotation names (and the study's odd positions, above) enter the SNP
+    // map -- every step after ReadInputZ touches entries of ONE position at a time, the gene table is made of annotated SNPs alone,
+    // and a chromosome's study is four times the annotated SNPs (host_calls.cpp:run_jepeg; GAUSS_JEPEG_FULL_MAP=1: the whole study)
+    bool annotated_only = false;
     int total_num_categ = 6;
     double categ_cor_cutoff = 0.8;
     int denorm_norm_w = 3;
@@ -317,6 +321,9 @@ struct GwasRow { std::string rsid, a1, a2; int chr; long long bp; double z; };
 struct GwasCache {
     std::vector<GwasRow> rows;
     std::vector<uint32_t> by_pos;      // row numbers ordered by (chr, bp), file order among equals: a window takes its range by binary search
+    // positions the study lists more than once, or under equal alleles: the only ones where the reference's duplicate check
+    // (gauss.cpp:386-392) can fire -- the gene drivers keep them in their SNP map whatever the annotation names (sorted)
+    std::vector<std::pair<int, long long>> odd_positions;
 };
 
 // ------------------------------------------------------------------------------------------

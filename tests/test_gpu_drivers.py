@@ -246,3 +246,58 @@ def test_prep_zmix_selectors_end_to_end(ctx, study, packed, use_packed, variant,
     assert np.max(np.abs(g[~nan] - w[~nan])) <= 1e-12
     if variant == "zmix5_sup":
         assert len(want["groups"]) < len(POPS) and "norm_var" in got["snps"]
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_gene_drivers_annotated_positions_only_equal_the_whole_study(ctx, tmp_path, monkeypatch, seed):
+    """jepeg() / jepegmix() enter only the study SNPs at positions the annotation names (plus the positions the study lists more than
+    once or under equal alleles) into their SNP map (host_calls.cpp:run_jepeg); GAUSS_JEPEG_FULL_MAP=1 enters the whole study, as
+    the reference does (gauss.cpp:121-190).  Same gene table, bit for bit, text panel and packed -- on a plain synthetic study and
+    on studies made of odd sites (tests/test_feeder.py:_odd_study: repeated, swapped, multi-allelic sites; a study that trips the
+    reference's duplicate check must trip it either way, also at a position no gene names)."""
+    from test_feeder import _odd_study
+    rng = np.random.default_rng(700 + seed)
+    if seed < 2:
+        pops = [("P00", 60, "EUR"), ("P01", 45, "ASN"), ("P02", 52, "EUR")]
+        st = panel.make_synthetic_study(str(tmp_path), pops, n_snp=500, bp_lo=1_000_000, bp_hi=2_000_000, frac_measured=0.5,
+                                        frac_swapped=0.3, frac_not_in_panel=0.05, n_genes=30, seed=40 + seed)
+        p = st["paths"]
+        inp, idx, dat, desc, ann = p["gwas.txt"], p["index.gz"], p["data.gz"], p["desc.txt"], p["annot.txt"]
+        gpk = str(tmp_path / "f.gpk")
+        assert api.pack_panel(idx, dat, desc, gpk) > 0
+        wgt = (["p00", "P01", "p02"], [0.5, 0.2, 0.3])
+    else:
+        st = _odd_study(str(tmp_path), 900 + seed, n_sites=300 if seed % 2 else None)
+        inp, idx, dat, desc, gpk = st["gwas"], st["idx"], st["dat"], st["desc"], st["gpk"]
+        # an annotation over the study's own rows: some under the study's allele order, some under the other one, some sites twice,
+        # a few positions the study does not have; about half of the study's positions stay unnamed
+        rows = [l.split() for l in open(inp).read().splitlines()[1:]]
+        ann_rows = []
+        cats = ["PROTEIN", "TFBS", "WTH_HAIR", "WTH_TARGET", "CIS_EQTL", "TRANS_EQTL", "NO_SUCH"]
+        for r in rows:
+            if r[1] != "22" or rng.random() < 0.5:
+                continue
+            a1, a2 = (r[3], r[4]) if rng.random() < 0.7 else (r[4], r[3])
+            for _ in range(int(rng.integers(1, 3))):
+                ann_rows.append(("x", 22, int(r[2]), a1, a2, f"GENE{int(r[2]) // 4000:03d}", str(rng.choice(cats)), float(np.round(rng.uniform(0.2, 2.0), 3))))
+        ann_rows += [("x", 22, 999_999, "A", "C", "GENE999", "TFBS", 1.0), ("x", 21, 5000, "A", "C", "GENE998", "TFBS", 1.0)]
+        ann = str(tmp_path / "annot.txt")
+        panel.write_annotation(ann, ann_rows)
+        wgt = (["AAA", "BBB", "ccc"], [0.5, 0.3, 0.2])
+    for data in (dat, gpk):
+        for call, who in ((api.jepeg, "EUR"), (api.jepegmix, wgt)):
+            res = []
+            for full in ("0", "1"):
+                monkeypatch.setenv("GAUSS_JEPEG_FULL_MAP", full)
+                try:
+                    res.append(call(who, inp, ann, idx, data, desc, af1_cutoff=0.0001, ctx=ctx))
+                except api.GaussError as e:
+                    res.append(str(e))
+            if isinstance(res[1], str):
+                assert res[0] == res[1] and "duplicates" in res[1]
+                print("seed %d %s %s: both fail (%s)" % (seed, call.__name__, "packed" if data == gpk else "text", res[1][:40]))
+            else:
+                assert not isinstance(res[0], str), res[0]
+                _same_frame(res[0], res[1])
+                assert len(res[0]) >= 1
+                print("seed %d %s %s: %d genes, %d with df > 0" % (seed, call.__name__, "packed" if data == gpk else "text", len(res[0]), int((res[0]["df"] > 0).sum())))
