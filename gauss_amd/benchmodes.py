@@ -598,7 +598,7 @@ def jepegmix_measure(rig, ch, files, tmp, steps, checks=None, spot_genes=24):
             "breakdown": {"cold_call_s": cold, "warm_call_s_median": warm, "host_data_layer_s": t_host,
                           "gpu_gene_ld_batch_ms": gpu["ms_per_call"], "note": "host bound: the SNP map and the annotation merge dominate; host_data_layer_s is gauss_host_prepare "
                           "on the WHOLE study (what the reference builds); the driver itself enters only the study SNPs at positions the annotation "
-                          "names (host_calls.cpp:run_jepeg, ~1.6 ms of the call); the GPU batch is pack + Gram on the tile pairs that genes touch"},
+                          "names (host_calls.cpp:run_jepeg, ~1.0 ms of the call); the GPU batch is pack + Gram on the tile pairs that genes touch"},
             "roofline": {"kernel": "gauss_gene_ld_batch_rows (pack_stats + gram on gene tile pairs + gene_epilogue_kernel)", "bound": "hbm",
                          "achieved": (bytes_in + bytes_out) / (gpu["ms_per_call"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (bytes_in + bytes_out) / (gpu["ms_per_call"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,

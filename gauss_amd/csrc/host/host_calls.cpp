@@ -670,7 +670,7 @@ static int run_jepeg(gauss_ctx* ctx, int kind, const char* study_pop, const char
     // position at a time: only the study SNPs at positions the annotation names enter the SNP map (plus the positions the study
     // lists more than once or under equal alleles -- the only ones where the reference's duplicate check can fire, so a study that
     // fails there still fails).  A chromosome's study is four times its annotated SNPs: the data layer of a jepegmix() call
-    // 3.6 -> 1.2 ms.  GAUSS_JEPEG_FULL_MAP=1: the whole study, as gauss_host_prepare does it (same table, bit for bit:
+    // 3.9 -> 1.0 ms.  GAUSS_JEPEG_FULL_MAP=1: the whole study, as gauss_host_prepare does it (same table, bit for bit:
     // tests/test_gpu_drivers.py).
     const bool full_map = env_flag("GAUSS_JEPEG_FULL_MAP", false);
     if (host_prepare(kind, 0, 0, 0, 0, study_pop, names, wgts, nw, input, annotation, index, data, desc, af1_cutoff, !full_map, &p)) return -1;

@@ -141,24 +141,7 @@ int ReadInputZ(SnpMap& m, const Args& a, bool All)
         q0 = (size_t)(std::lower_bound(gw->by_pos.begin(), gw->by_pos.end(), lo, before) - gw->by_pos.begin());
         q1 = (size_t)(std::lower_bound(gw->by_pos.begin(), gw->by_pos.end(), hi + 1, before) - gw->by_pos.begin());
     }
-    // the gene drivers' map: annotated positions and the study's odd ones (Args::annotated_only)
-    const std::vector<std::pair<int, long long>>* named = nullptr;
-    std::shared_ptr<const AnnotCache> an;
-    if (All && a.annotated_only && !a.annotation_file.empty()) {
-        an = load_annotation_cached(a.annotation_file, err);
-        if (!an) return herr("%s", err.c_str());
-        named = &annotation_positions(*an);
-    }
-    for (size_t q = q0; q < q1; q++) {
-        const GwasRow& r = gw->rows[ranged ? gw->by_pos[q] : q];
-        if (named) {
-            const std::pair<int, long long> at(r.chr, r.bp);
-            if (!std::binary_search(named->begin(), named->end(), at) && !std::binary_search(gw->odd_positions.begin(), gw->odd_positions.end(), at)) continue;
-        }
-        if (!All) {
-            if ((a.chr > 0) && (a.chr != r.chr)) continue;
-            if ((a.start_bp - a.wing_size) > r.bp || (a.end_bp + a.wing_size) < r.bp) continue;
-        }
+    auto enter = [&](const GwasRow& r) {
         SnpPtr s = m.make();
         s->rsid = r.rsid; s->chr = r.chr; s->bp = r.bp; s->a1 = r.a1; s->a2 = r.a2; s->z = r.z;
         s->info = 1.0;     // gauss.cpp:142
@@ -167,6 +150,36 @@ int ReadInputZ(SnpMap& m, const Args& a, bool All)
         MapKey key{r.chr, r.bp, r.a1, r.a2};
         auto it = (m.empty() || m.rbegin()->first < key) ? m.emplace_hint(m.end(), std::move(key), SnpPtr()) : m.try_emplace(std::move(key)).first;
         it->second = std::move(s);
+    };
+    // The gene drivers' map (Args::annotated_only): the study's rows at the positions the annotation names and at the study's odd
+    // ones, each position's rows found in the (chr, bp)-ordered index -- positions ascending, a position's rows in file order (a
+    // key listed twice ends with its later row, as in the file-order loop below; rows of different keys never meet).
+    if (All && a.annotated_only && !a.annotation_file.empty()) {
+        std::shared_ptr<const AnnotCache> an = load_annotation_cached(a.annotation_file, err);
+        if (!an) return herr("%s", err.c_str());
+        const std::vector<std::pair<int, long long>>& named = annotation_positions(*an);
+        const std::vector<std::pair<int, long long>>& odd = gw->odd_positions;
+        auto before = [&](uint32_t x, const std::pair<int, long long>& at) { const GwasRow& r = gw->rows[x]; return r.chr < at.first || (r.chr == at.first && r.bp < at.second); };
+        size_t i = 0, j = 0;
+        while (i < named.size() || j < odd.size()) {
+            std::pair<int, long long> at;
+            if (j >= odd.size() || (i < named.size() && named[i] <= odd[j])) { at = named[i]; if (j < odd.size() && odd[j] == at) j++; i++; }
+            else at = odd[j++];
+            for (auto it = std::lower_bound(gw->by_pos.begin(), gw->by_pos.end(), at, before); it != gw->by_pos.end(); ++it) {
+                const GwasRow& r = gw->rows[*it];
+                if (r.chr != at.first || r.bp != at.second) break;
+                enter(r);
+            }
+        }
+        return 0;
+    }
+    for (size_t q = q0; q < q1; q++) {
+        const GwasRow& r = gw->rows[ranged ? gw->by_pos[q] : q];
+        if (!All) {
+            if ((a.chr > 0) && (a.chr != r.chr)) continue;
+            if ((a.start_bp - a.wing_size) > r.bp || (a.end_bp + a.wing_size) < r.bp) continue;
+        }
+        enter(r);
     }
     return 0;
 }
@@ -576,8 +589,13 @@ static int ReadAnnotation(SnpMap& m, const Args& a)
         // nothing of the study at this position (most of a genome-wide annotation): neither allele order can be there
         auto pos = m.lower_bound(MapKey{chr, bp, std::string(), std::string()});
         if (pos == m.end() || pos->first.chr != chr || pos->first.bp != bp) continue;
-        auto it1 = m.find(MapKey{chr, bp, a1, a2});
-        auto it2 = m.find(MapKey{chr, bp, a2, a1});
+        // the entries of this position follow `pos`: the two allele orders are looked for among them (what two more descents
+        // through the tree with freshly built keys would find)
+        auto it1 = m.end(), it2 = m.end();
+        for (auto it = pos; it != m.end() && it->first.chr == chr && it->first.bp == bp; ++it) {
+            if (it->first.a1 == a1 && it->first.a2 == a2) it1 = it;
+            if (it->first.a1 == a2 && it->first.a2 == a1) it2 = it;
+        }
         if (it1 != m.end() && it2 == m.end()) {
             it1->second->geneid = geneid;
             it1->second->categ[categ_num] = wgt;
