@@ -673,8 +673,10 @@ static int run_jepeg(gauss_ctx* ctx, int kind, const char* study_pop, const char
     // 3.9 -> 1.0 ms.  GAUSS_JEPEG_FULL_MAP=1: the whole study, as gauss_host_prepare does it (same table, bit for bit:
     // tests/test_gpu_drivers.py).
     const bool full_map = env_flag("GAUSS_JEPEG_FULL_MAP", false);
+    const double t_begin = now_s();
     if (host_prepare(kind, 0, 0, 0, 0, study_pop, names, wgts, nw, input, annotation, index, data, desc, af1_cutoff, !full_map, &p)) return -1;
     std::unique_ptr<gauss_prepared> hold(p);
+    const double t_prepared = now_s();
     const Args& a = p->args;
     const int S = (int)p->measured.size();
     const int ng = p->gene_off.empty() ? 0 : (int)p->gene_off.size() - 1;
@@ -698,10 +700,13 @@ static int run_jepeg(gauss_ctx* ctx, int kind, const char* study_pop, const char
                                        (int)p->pop_off.size() - 1, p->gene_off.data(), ng, 1.0 + a.lambda, blocks.data()) != 0)
             return herr("%s", gauss_last_error());
     }
+    const double t_ld = now_s();
     std::unique_ptr<gauss_table> t(new gauss_table());
     Column geneid{"geneid", GAUSS_COL_STR, {}, {}, {}}, chisq{"chisq", GAUSS_COL_DBL, {}, {}, {}}, df{"df", GAUSS_COL_INT, {}, {}, {}};
     Column jp{"jepeg_pval", GAUSS_COL_DBL, {}, {}, {}}, ns{"num_snp", GAUSS_COL_INT, {}, {}, {}}, tc{"top_categ", GAUSS_COL_STR, {}, {}, {}};
     Column tcp{"top_categ_pval", GAUSS_COL_DBL, {}, {}, {}}, ts{"top_snp", GAUSS_COL_STR, {}, {}, {}}, tsp{"top_snp_pval", GAUSS_COL_DBL, {}, {}, {}};
+    // (the k x k tails on host threads were measured: 1.1 ms serial, 0.45 ms on eight threads, and the call no shorter -- thread
+    // start-up and its jitter cost what the tails gain at 350 genes)
     for (int g = 0; g < ng; g++) {
         std::vector<Snp*> gs(p->measured.begin() + p->gene_off[g], p->measured.begin() + p->gene_off[g + 1]);
         const GeneResult r = jepeg_tail(gs, blocks.data() + boff[g], a);
@@ -710,6 +715,9 @@ static int run_jepeg(gauss_ctx* ctx, int kind, const char* study_pop, const char
         ts.s.push_back(r.top_snp); tsp.d.push_back(r.top_snp_pval);
     }
     t->cols = {geneid, chisq, df, jp, ns, tc, tcp, ts, tsp};          // jepeg.cpp:143-151
+    if (host_trace("prep"))
+        fprintf(stderr, "[jepeg] data layer %.2f ms, gene LD blocks on the GPU %.2f ms, %d k x k tails + table %.2f ms\n", (t_prepared - t_begin) * 1e3,
+                (t_ld - t_prepared) * 1e3, ng, (now_s() - t_ld) * 1e3);
     *out = t.release();
     return 0;
 }
