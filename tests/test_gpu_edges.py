@@ -1,3 +1,4 @@
+import os
 """GPU edge cases: tile / block / panel boundaries, tiny and ragged inputs, many populations, large
 genotype codes, error reporting, and size-independent properties at the BASELINE sizes."""
 import numpy as np
@@ -532,7 +533,7 @@ def test_sixteen_column_edge_of_the_gram_kernel(ctx):
                 job.close()
             out[dt] = res
     finally:
-        ctx.set_gram_dtype("f32")
+        ctx.set_gram_dtype(os.environ.get("GAUSS_GRAM_DTYPE", "f32"))      # (back to the session's form: a suite run under GAUSS_GRAM_DTYPE=i8 stays on it)
     for a, b in zip(out["f32"], out["i8"]):
         for key in ("z", "info", "b11", "b21"):
             assert np.array_equal(a[key], b[key], equal_nan=True), key

@@ -298,7 +298,7 @@ def test_merged_launch_that_gives_up_is_run_again_in_the_two_launch_form(ctx, mo
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("force", [False, True])
-def test_two_contexts_run_merged_jobs_at_the_same_time(ctx, monkeypatch, force):
+def test_two_contexts_run_merged_jobs_at_the_same_time(ctx, monkeypatch, request, force):
     """Two contexts on device 0, two host threads, each running a 3-window job built for the merged Gram launch, at the same
     time.  The runtime gives a priority stream a hardware queue of its own only while its class holds at most
     GPU_MAX_HW_QUEUES streams (profiles/r05_queue_map.txt): with two contexts the streams share queues, and a kernel that
@@ -316,6 +316,10 @@ def test_two_contexts_run_merged_jobs_at_the_same_time(ctx, monkeypatch, force):
     rows2, src_off = panel.pack2bit(p["G"], p["off"])
     monkeypatch.setenv("GAUSS_CHAIN_ASIDE", "2")
     monkeypatch.setenv("GAUSS_CHAIN_MERGED", "2" if force else "1")
+    # (the merged launch is the f32 kernel's default form: under a suite-wide GAUSS_GRAM_DTYPE=i8 this test still runs it, and hands the
+    # session's context back as it found it)
+    ctx.set_gram_dtype("f32")
+    request.addfinalizer(lambda: ctx.set_gram_dtype(os.environ.get("GAUSS_GRAM_DTYPE", "f32")))
     rng = np.random.default_rng(4)
     store = hotpath.RowStore(rows2, ctx=ctx)
     wins = _merged_job_windows(store, src_off, p, rng)
@@ -330,6 +334,7 @@ def test_two_contexts_run_merged_jobs_at_the_same_time(ctx, monkeypatch, force):
     q0 = ctx.queues()
     assert q0["probed_distinct"] and q0["hi_streams"] <= q0["hw_queues_per_class"], q0      # the session's context was made alone on the device
     other = hotpath.Context(0)
+    other.set_gram_dtype("f32")          # (the merged launch is the f32 kernel's form: a suite run under GAUSS_GRAM_DTYPE=i8 still tests it here)
     q1 = other.queues()
     assert q1["hi_streams"] > q1["hw_queues_per_class"], q1                               # two contexts: more priority streams than hardware queues
     store2 = hotpath.RowStore(rows2, ctx=other)

@@ -1,3 +1,4 @@
+import os
 """GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
 
 Bars (BASELINE.json north_star): integer Gram counts bit-exact; LD values, z and info within
@@ -199,7 +200,7 @@ def test_int8_gram_path_is_bit_identical_to_f32_path(ctx):
             r1 = hotpath.impute_window(1, gm, gu, p["off"], p["w"], z1, want_mats=True, ctx=ctx)
             base[dt] = (ld, r0, r1)
     finally:
-        ctx.set_gram_dtype("f32")
+        ctx.set_gram_dtype(os.environ.get("GAUSS_GRAM_DTYPE", "f32"))      # (back to the session's form: a suite run under GAUSS_GRAM_DTYPE=i8 stays on it)
     (lda, a0, a1), (ldb, b0, b1) = base["f32"], base["i8"]
     assert np.array_equal(lda, ldb)
     for a, b in ((a0, b0), (a1, b1)):
