@@ -231,11 +231,63 @@ int gauss_prepared_finish(gauss_prepared* p, gauss_table** out)
     return 0;
 }
 
+// dist() / distmix() / qcat() / qcatmix(): ONE window per call, the reference's own usage (docs/articles/dist_example.md:144-153).
+//
+// On a sorted packed panel the window is built as the chromosome driver builds its windows (host_chrom.cpp:LeanWindow -- a merge of
+// the study's rows and the panel's SNP table instead of per-SNP objects in a map: ~0.1 ms against 0.7-1.0), its genotype rows are
+// read from the panel's resident copy in HBM (made on the first call when the panel's genotype section is at most 4 GB -- a
+// chromosome of the 33KG panel is 0.85 GB -- like the LD-only calls do, packed_row_source) instead of being gathered on the host and
+// copied per call (24 MB a window), and the window runs as a job of one on those rows.  Measured on the chr22 study, window after
+// window (tools/window_calls_probe.py): 5.9 ms per call -> 2.5.  An unsorted panel, a text panel without a cached packed form, a
+// call over every chromosome or GAUSS_HOST_FULL_MAP=1 take the literal path: gauss_host_prepare + gauss_impute_window on host rows.
 static int run_impute(gauss_ctx* ctx, int kind, int chr, int64_t start_bp, int64_t end_bp, int64_t wing, const char* study_pop,
                       const char* const* names, const double* wgts, int nw, const char* input, const char* index,
                       const char* data, const char* desc, double af1_cutoff, gauss_table** out)
 {
     if (!ctx || !out) return herr("bad arguments");
+    if (!input || !index || !data || !desc) return herr("file name is NULL");
+    // the packed form of the panel, if there is one (as gauss_host_prepare resolves it)
+    std::string packed = data;
+    if (auto_pack_mode() != 0 && !PackedPanel::is_packed(packed)) {
+        std::string cached, err;
+        const int rc = resolve_packed_panel(index, data, desc, auto_pack_mode() == 1, cached, err);
+        if (rc < 0) return herr("%s", err.c_str());
+        if (rc == 0) packed = cached;
+    }
+    const bool lean_kind = (kind == GAUSS_KIND_DIST || kind == GAUSS_KIND_DISTMIX || kind == GAUSS_KIND_QCAT || kind == GAUSS_KIND_QCATMIX);
+    if (lean_kind && chr > 0 && !env_flag("GAUSS_HOST_FULL_MAP", false) && PackedPanel::is_packed(packed)) {
+        std::string err;
+        std::shared_ptr<PackedPanel> pk = open_packed_shared(packed, err);
+        if (!pk) return herr("%s", err.c_str());
+        if (pk->header().sorted) {
+            ChromSetup cs;                                       // (errors in prepare()'s order: arguments, description file, populations, study file)
+            if (chrom_setup(cs, kind, chr, wing, study_pop, names, wgts, nw, input, packed, desc, af1_cutoff, pk, nullptr)) return -1;
+            cs.gw = load_gwas_cached(input, err);
+            if (!cs.gw) return herr("%s", err.c_str());
+            LeanWindow w;
+            if (lean_window_build(w, cs, start_bp, end_bp)) return -1;
+            gauss_window_desc d;
+            if (lean_window_desc(w, &d)) return -1;
+            void* dev = nullptr;
+            const int64_t bytes = pk->n_snp() * pk->row_bytes();
+            const bool resident = panel_is_resident(ctx, packed, &dev) ||
+                                  (bytes <= ((int64_t)4 << 30) && panel_make_resident(ctx, packed, &dev, nullptr) == 0 && gauss_store_wait(ctx, dev, 0) == 0);
+            if (resident) {
+                d.geno_m = d.geno_u = (const uint8_t*)dev;
+                gauss_job* job = nullptr;
+                int rc = gauss_job_create(ctx, &d, 1, 1, &job);
+                if (rc == 0) rc = gauss_job_run(job);
+                if (rc == 0) rc = gauss_job_fetch(job);
+                if (job) gauss_job_destroy(job);
+                if (rc != 0) return herr("%s", gauss_last_error());
+            } else {
+                d.geno_m = d.geno_u = pk->geno();                 // a panel too large to keep in HBM: the window's rows from the mapped file
+                if (gauss_impute_window(ctx, &d) != 0) return herr("%s", gauss_last_error());
+            }
+            *out = lean_window_finish(w);
+            return 0;
+        }
+    }
     gauss_prepared* p = nullptr;
     if (gauss_host_prepare(kind, chr, start_bp, end_bp, wing, study_pop, names, wgts, nw, input, nullptr, index, data, desc, af1_cutoff, &p)) return -1;
     std::unique_ptr<gauss_prepared> hold(p);
@@ -670,9 +722,9 @@ static int run_jepeg(gauss_ctx* ctx, int kind, const char* study_pop, const char
     // position at a time: only the study SNPs at positions the annotation names enter the SNP map (plus the positions the study
     // lists more than once or under equal alleles -- the only ones where the reference's duplicate check can fire, so a study that
     // fails there still fails).  A chromosome's study is four times its annotated SNPs: the data layer of a jepegmix() call
-    // 3.9 -> 1.0 ms.  GAUSS_JEPEG_FULL_MAP=1: the whole study, as gauss_host_prepare does it (same table, bit for bit:
+    // 3.9 -> 1.0 ms.  GAUSS_HOST_FULL_MAP=1: the whole study, as gauss_host_prepare does it (same table, bit for bit:
     // tests/test_gpu_drivers.py).
-    const bool full_map = env_flag("GAUSS_JEPEG_FULL_MAP", false);
+    const bool full_map = env_flag("GAUSS_HOST_FULL_MAP", false);
     const double t_begin = now_s();
     if (host_prepare(kind, 0, 0, 0, 0, study_pop, names, wgts, nw, input, annotation, index, data, desc, af1_cutoff, !full_map, &p)) return -1;
     std::unique_ptr<gauss_prepared> hold(p);

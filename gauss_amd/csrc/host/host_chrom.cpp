@@ -188,6 +188,8 @@ static double issued_cost_per_sample(int m, int u)
 }
 double gauss_host_plan_cost(int n_measured, int n_unmeasured) { return issued_cost_per_sample(n_measured, n_unmeasured); }
 
+}  // extern "C"
+
 // ------------------------------------------------------------------------------------------
 // The chromosome driver's window: prepare()'s data layer as ONE merge of two sorted arrays.
 //
@@ -214,40 +216,8 @@ double gauss_host_plan_cost(int n_measured, int n_unmeasured) { return issued_co
 // What a window costs now: DESIGN.md section 9e item 11.  tests/test_feeder.py holds it against prepare() on random
 // studies with multi-allelic, duplicated, swapped and study-only sites, for all four kinds.
 // ------------------------------------------------------------------------------------------
-struct ChromSetup {                     // what prepare() derives from a call's arguments alone: once per call, not once per window
-    int kind = 0;
-    bool mix = false, qcat = false;
-    Args a;                             // population table, flags, weights, cutoffs (start_bp / end_bp are the windows', not set here)
-    std::vector<int> sel;               // the selected populations, panel order
-    std::vector<int32_t> pop_off, pop_src_off;
-    std::vector<double> pop_wgt;
-    double two_subj = 0;                // 2 x the selected samples (gauss.cpp:589)
-    std::shared_ptr<const GwasCache> gw;
-};
-
-struct LeanSnp {
-    int64_t row;                        // panel row = fpos of the packed feeder
-    long long bp;
-    double z, info, af;
-    int32_t type, qcat_m;
-    double qcat_t, qcat_chisq;
-};
-
-struct LeanWindow {
-    const ChromSetup* cs = nullptr;
-    long long start_bp = 0, end_bp = 0;
-    std::vector<LeanSnp> v;             // prepare()'s snp_vec: after the AF filter, map order
-    std::vector<int32_t> measured, unmeasured;      // into v, matrix row order
-    std::vector<int32_t> store_rows_m, store_rows_u;
-    std::vector<double> z1, out_z, out_info, out_r;
-    int n_head = 0, n_predm = 0;
-    int32_t num_eig = 0, status = 0;
-    std::unique_ptr<gauss_table> pre;   // the output table, built while the GPU works (lean_table_prebuild); the results are filled in after
-    std::vector<int32_t> out_row;       // v -> row of the table, -1 outside the prediction window
-};
-
 // 0, or -1 with the message prepare() would have given every window (the caller then lets prepare() give it)
-static int chrom_setup(ChromSetup& cs, int kind, int chr, int64_t wing_size, const char* study_pop, const char* const* pop_names,
+int chrom_setup(ChromSetup& cs, int kind, int chr, int64_t wing_size, const char* study_pop, const char* const* pop_names,
                        const double* pop_wgts, int n_pop_wgt, const char* input_file, const std::string& packed_path,
                        const char* desc_file, double af1_cutoff, const std::shared_ptr<PackedPanel>& pk,
                        const std::shared_ptr<const GwasCache>& gw)
@@ -290,7 +260,7 @@ static int chrom_setup(ChromSetup& cs, int kind, int chr, int64_t wing_size, con
     return 0;
 }
 
-static int lean_window_build(LeanWindow& w, const ChromSetup& cs, long long start_bp, long long end_bp)
+int lean_window_build(LeanWindow& w, const ChromSetup& cs, long long start_bp, long long end_bp)
 {
     const Args& a = cs.a;
     const PackedPanel& pk = *a.pk;
@@ -383,7 +353,7 @@ static int lean_window_build(LeanWindow& w, const ChromSetup& cs, long long star
 }
 
 // gauss_prepared_window_desc for the four window kinds (same guards, same texts); geno_m / geno_u are set by the caller
-static int lean_window_desc(LeanWindow& w, gauss_window_desc* d)
+int lean_window_desc(LeanWindow& w, gauss_window_desc* d)
 {
     const ChromSetup& cs = *w.cs;
     const Args& a = cs.a;
@@ -425,7 +395,7 @@ static int lean_window_desc(LeanWindow& w, gauss_window_desc* d)
 // strings, positions, frequencies, the measured SNPs' z and p-values -- is built while the window's batch computes
 // (lean_table_prebuild, before the driver waits for the batch); what the results change is filled in after (lean_window_finish):
 // the last batch's tables are otherwise the tail of the call that nothing overlaps.
-static void lean_table_prebuild(LeanWindow& w)
+void lean_table_prebuild(LeanWindow& w)
 {
     if (w.pre) return;
     const ChromSetup& cs = *w.cs;
@@ -469,7 +439,7 @@ static void lean_table_prebuild(LeanWindow& w)
     w.pre = std::move(t);
 }
 
-static gauss_table* lean_window_finish(LeanWindow& w)
+gauss_table* lean_window_finish(LeanWindow& w)
 {
     const ChromSetup& cs = *w.cs;
     lean_table_prebuild(w);
@@ -503,6 +473,8 @@ static gauss_table* lean_window_finish(LeanWindow& w)
     }
     return w.pre.release();
 }
+
+extern "C" {
 
 // ------------------------------------------------------------------------------------------
 // The chromosome driver's plan: windows, their costs, their owners (identical on every rank: no communication)
@@ -825,7 +797,7 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
     // chromosome goes window by window through prepare(), and so does a call whose arguments prepare() would refuse (it then
     // gives every window its message).
     ChromSetup cs;
-    const bool lean = chr > 0 && pk->header().sorted &&
+    const bool lean = chr > 0 && pk->header().sorted && !env_flag("GAUSS_HOST_FULL_MAP", false) &&
                       chrom_setup(cs, kind, chr, wing_size, study_pop, pop_names, pop_wgts, n_pop_wgt, input_file, packed_path,
                                   reference_pop_desc_file, af1_cutoff, pk, gw) == 0;
     std::vector<std::vector<Slot>> slots((size_t)n_batches);

@@ -267,7 +267,7 @@ struct Args {                       // Arguments, gauss.h:18-69 with the default
     bool drop_wing_unmeasured = false;
     // jepeg / jepegmix drivers: only study SNPs at positions the annotation names (and the study's odd positions, above) enter the SNP
     // map -- every step after ReadInputZ touches entries of ONE position at a time, the gene table is made of annotated SNPs alone,
-    // and a chromosome's study is four times the annotated SNPs (host_calls.cpp:run_jepeg; GAUSS_JEPEG_FULL_MAP=1: the whole study)
+    // and a chromosome's study is four times the annotated SNPs (host_calls.cpp:run_jepeg; GAUSS_HOST_FULL_MAP=1: the whole study)
     bool annotated_only = false;
     int total_num_categ = 6;
     double categ_cor_cutoff = 0.8;
@@ -385,6 +385,48 @@ inline double now_s()
 {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
+
+// ---- the chromosome driver's window (host_chrom.cpp: a merge of the sorted study and panel tables); also behind the one-window
+// entry points of host_calls.cpp ----
+struct ChromSetup {                     // what prepare() derives from a call's arguments alone: once per call, not once per window
+    int kind = 0;
+    bool mix = false, qcat = false;
+    Args a;                             // population table, flags, weights, cutoffs (start_bp / end_bp are the windows', not set here)
+    std::vector<int> sel;               // the selected populations, panel order
+    std::vector<int32_t> pop_off, pop_src_off;
+    std::vector<double> pop_wgt;
+    double two_subj = 0;                // 2 x the selected samples (gauss.cpp:589)
+    std::shared_ptr<const GwasCache> gw;
+};
+
+struct LeanSnp {
+    int64_t row;                        // panel row = fpos of the packed feeder
+    long long bp;
+    double z, info, af;
+    int32_t type, qcat_m;
+    double qcat_t, qcat_chisq;
+};
+
+struct LeanWindow {
+    const ChromSetup* cs = nullptr;
+    long long start_bp = 0, end_bp = 0;
+    std::vector<LeanSnp> v;             // prepare()'s snp_vec: after the AF filter, map order
+    std::vector<int32_t> measured, unmeasured;      // into v, matrix row order
+    std::vector<int32_t> store_rows_m, store_rows_u;
+    std::vector<double> z1, out_z, out_info, out_r;
+    int n_head = 0, n_predm = 0;
+    int32_t num_eig = 0, status = 0;
+    std::unique_ptr<gauss_table> pre;   // the output table, built while the GPU works (lean_table_prebuild); the results are filled in after
+    std::vector<int32_t> out_row;       // v -> row of the table, -1 outside the prediction window
+};
+
+int chrom_setup(ChromSetup& cs, int kind, int chr, int64_t wing_size, const char* study_pop, const char* const* pop_names,
+                const double* pop_wgts, int n_pop_wgt, const char* input_file, const std::string& packed_path, const char* desc_file,
+                double af1_cutoff, const std::shared_ptr<PackedPanel>& pk, const std::shared_ptr<const GwasCache>& gw);
+int lean_window_build(LeanWindow& w, const ChromSetup& cs, long long start_bp, long long end_bp);
+int lean_window_desc(LeanWindow& w, gauss_window_desc* d);
+void lean_table_prebuild(LeanWindow& w);
+gauss_table* lean_window_finish(LeanWindow& w);
 
 // ---- routines that cross translation units ----
 int read_ref_desc(Args& a);

@@ -251,7 +251,7 @@ def test_prep_zmix_selectors_end_to_end(ctx, study, packed, use_packed, variant,
 @pytest.mark.parametrize("seed", range(6))
 def test_gene_drivers_annotated_positions_only_equal_the_whole_study(ctx, tmp_path, monkeypatch, seed):
     """jepeg() / jepegmix() enter only the study SNPs at positions the annotation names (plus the positions the study lists more than
-    once or under equal alleles) into their SNP map (host_calls.cpp:run_jepeg); GAUSS_JEPEG_FULL_MAP=1 enters the whole study, as
+    once or under equal alleles) into their SNP map (host_calls.cpp:run_jepeg); GAUSS_HOST_FULL_MAP=1 enters the whole study, as
     the reference does (gauss.cpp:121-190).  Same gene table, bit for bit, text panel and packed -- on a plain synthetic study and
     on studies made of odd sites (tests/test_feeder.py:_odd_study: repeated, swapped, multi-allelic sites; a study that trips the
     reference's duplicate check must trip it either way, also at a position no gene names)."""
@@ -288,7 +288,7 @@ def test_gene_drivers_annotated_positions_only_equal_the_whole_study(ctx, tmp_pa
         for call, who in ((api.jepeg, "EUR"), (api.jepegmix, wgt)):
             res = []
             for full in ("0", "1"):
-                monkeypatch.setenv("GAUSS_JEPEG_FULL_MAP", full)
+                monkeypatch.setenv("GAUSS_HOST_FULL_MAP", full)
                 try:
                     res.append(call(who, inp, ann, idx, data, desc, af1_cutoff=0.0001, ctx=ctx))
                 except api.GaussError as e:
@@ -301,3 +301,58 @@ def test_gene_drivers_annotated_positions_only_equal_the_whole_study(ctx, tmp_pa
                 _same_frame(res[0], res[1])
                 assert len(res[0]) >= 1
                 print("seed %d %s %s: %d genes, %d with df > 0" % (seed, call.__name__, "packed" if data == gpk else "text", len(res[0]), int((res[0]["df"] > 0).sum())))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_window_calls_and_chromosome_driver_equal_the_literal_data_layer(ctx, tmp_path, monkeypatch, seed):
+    """dist() / distmix() / qcat() / qcatmix() on a sorted packed panel build their window as a merge of the study's rows and the
+    panel's SNP table and read its genotype rows from the panel's resident copy (host_calls.cpp:run_impute), and so does the
+    chromosome driver; GAUSS_HOST_FULL_MAP=1 takes the literal path -- the reference's per-SNP objects in a map (gauss_host_prepare),
+    the window's rows gathered on the host.  Same tables bit for bit and the same errors, on a plain study and on studies made of
+    odd sites (repeated, swapped, multi-allelic, duplicate-error sites)."""
+    from test_feeder import _odd_study
+    rng = np.random.default_rng(1700 + seed)
+    if seed < 2:
+        pops = [("P00", 60, "EUR"), ("P01", 45, "ASN"), ("P02", 52, "EUR")]
+        st = panel.make_synthetic_study(str(tmp_path), pops, n_snp=900, bp_lo=1_000_000, bp_hi=2_000_000, frac_measured=0.4,
+                                        frac_swapped=0.3, frac_not_in_panel=0.05, seed=60 + seed)
+        p = st["paths"]
+        inp, idx, dat, desc = p["gwas.txt"], p["index.gz"], p["data.gz"], p["desc.txt"]
+        gpk = str(tmp_path / "f.gpk")
+        assert api.pack_panel(idx, dat, desc, gpk) > 0
+        wgt, span, wsize = (["p00", "P01", "p02"], [0.5, 0.2, 0.3]), (1_000_001, 2_000_000), 250_000
+    else:
+        st = _odd_study(str(tmp_path), 1900 + seed, n_sites=400)
+        inp, idx, desc, gpk = st["gwas"], st["idx"], st["desc"], st["gpk"]
+        wgt, span, wsize = (["AAA", "BBB", "ccc"], [0.5, 0.3, 0.2]), (1_000, 60_000), 15_000
+    wing = int(rng.choice([0, wsize // 3]))
+    calls = {"dist": (api.dist, "EUR"), "distmix": (api.distmix, wgt), "qcat": (api.qcat, "EUR"), "qcatmix": (api.qcatmix, wgt)}
+    name = list(calls)[seed % 4]
+    fn, who = calls[name]
+    n_ok = 0
+    for s0 in range(span[0], span[1], wsize):
+        res = []
+        for full in ("0", "1"):
+            monkeypatch.setenv("GAUSS_HOST_FULL_MAP", full)
+            try:
+                res.append(fn(22, s0, min(span[1], s0 + wsize - 1), wing, who, inp, idx, gpk, desc, af1_cutoff=0.01, ctx=ctx))
+            except api.GaussError as e:
+                res.append(str(e))
+        if isinstance(res[1], str):
+            assert res[0] == res[1], res
+        else:
+            assert not isinstance(res[0], str), res[0]
+            _same_frame(res[0], res[1])
+            n_ok += 1
+    assert n_ok >= 1
+    kind = getattr(api, "KIND_" + name.upper())
+    sel = dict(pop_wgt_df=who) if name.endswith("mix") else dict(study_pop="EUR")
+    tabs = []
+    for full in ("0", "1"):
+        monkeypatch.setenv("GAUSS_HOST_FULL_MAP", full)
+        tabs.append(api.impute_chromosome(kind, 22, span[0], span[1], wing, input_file=inp, reference_data_file=gpk, reference_pop_desc_file=desc,
+                                          window_size=wsize, af1_cutoff=0.01, ctx=ctx, **sel))
+    assert np.array_equal(tabs[0].windows, tabs[1].windows) and tabs[0].messages == tabs[1].messages
+    for c in tabs[0].columns:
+        x, y = tabs[0].columns[c], tabs[1].columns[c]
+        assert np.array_equal(x, y, equal_nan=True) if x.dtype.kind == "f" else np.array_equal(x, y), c
