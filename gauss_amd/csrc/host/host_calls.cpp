@@ -682,6 +682,52 @@ int gauss_host_computeLD(gauss_ctx* ctx, int chr, int64_t start_bp, int64_t end_
                          gauss_table** out)
 {
     if (!ctx || !out) return herr("bad arguments");
+    // On a sorted packed panel: the window as a merge (host_chrom.cpp:LeanWindow, measured SNPs only), rows from the resident panel --
+    // as the one-window imputation calls above; GAUSS_HOST_FULL_MAP=1 or any other panel: the literal path below.
+    if (input_file && reference_index_file && reference_data_file && reference_pop_desc_file && chr > 0 && !env_flag("GAUSS_HOST_FULL_MAP", false)) {
+        std::string packed = reference_data_file, err;
+        if (auto_pack_mode() != 0 && !PackedPanel::is_packed(packed)) {
+            std::string cached;
+            const int rc = resolve_packed_panel(reference_index_file, reference_data_file, reference_pop_desc_file, auto_pack_mode() == 1, cached, err);
+            if (rc < 0) return herr("%s", err.c_str());
+            if (rc == 0) packed = cached;
+        }
+        std::shared_ptr<PackedPanel> pk;
+        if (PackedPanel::is_packed(packed) && !(pk = open_packed_shared(packed, err))) return herr("%s", err.c_str());
+        if (pk && pk->header().sorted) {
+            ChromSetup cs;
+            if (chrom_setup(cs, GAUSS_KIND_COMPUTELD, chr, 0, nullptr, pop_names, pop_wgts, n_pop_wgt, input_file, packed, reference_pop_desc_file,
+                            af1_cutoff, pk, nullptr)) return -1;
+            cs.gw = load_gwas_cached(input_file, err);
+            if (!cs.gw) return herr("%s", err.c_str());
+            LeanWindow w;
+            if (lean_window_build(w, cs, start_bp, end_bp)) return -1;
+            const int M = (int)w.measured.size();
+            if (M <= cs.a.min_num_measured_snp)                          // computeLD.cpp:89-93
+                return herr("Not enough number of SNPs loaded - computeLD not performed (measured %d)", M);
+            std::unique_ptr<gauss_table> t(new gauss_table());
+            t->matrix.assign((size_t)M * M, 0.0);
+            t->matrix_n = M;
+            void* dev = nullptr;
+            const int64_t bytes = pk->n_snp() * pk->row_bytes();
+            const bool resident = panel_is_resident(ctx, packed, &dev) ||
+                                  (bytes <= ((int64_t)4 << 30) && panel_make_resident(ctx, packed, &dev, nullptr) == 0 && gauss_store_wait(ctx, dev, 0) == 0);
+            if (gauss_ld_rows(ctx, GAUSS_MODE_WEIGHTED, resident ? (const uint8_t*)dev : pk->geno(), pk->row_bytes(), GAUSS_GENO_2BIT, w.store_rows_m.data(), M,
+                              cs.pop_off.data(), cs.pop_src_off.data(), cs.pop_wgt.data(), (int)cs.pop_off.size() - 1, 1.0, resident ? 1 : 0,
+                              t->matrix.data()) != 0) return herr("%s", gauss_last_error());
+            Column rsid{"rsid", GAUSS_COL_STR, {}, {}, {}}, chrc{"chr", GAUSS_COL_INT, {}, {}, {}}, bp{"bp", GAUSS_COL_INT, {}, {}, {}};
+            Column a1{"a1", GAUSS_COL_STR, {}, {}, {}}, a2{"a2", GAUSS_COL_STR, {}, {}, {}}, af{"af1mix", GAUSS_COL_DBL, {}, {}, {}};
+            for (int32_t vi : w.measured) {                              // computeLD.cpp:134-149
+                const LeanSnp& sn = w.v[(size_t)vi];
+                const PkSnp& ps = pk->snp(sn.row);
+                rsid.s.emplace_back(pk->str(ps.rsid)); chrc.i.push_back(ps.chr); bp.i.push_back((int)sn.bp);
+                a1.s.emplace_back(pk->str(ps.a1)); a2.s.emplace_back(pk->str(ps.a2)); af.d.push_back(sn.af);
+            }
+            t->cols = {rsid, chrc, bp, a1, a2, af};
+            *out = t.release();
+            return 0;
+        }
+    }
     gauss_prepared* p = nullptr;
     if (gauss_host_prepare(GAUSS_KIND_COMPUTELD, chr, start_bp, end_bp, 0, nullptr, pop_names, pop_wgts, n_pop_wgt, input_file,
                            nullptr, reference_index_file, reference_data_file, reference_pop_desc_file, af1_cutoff, &p)) return -1;

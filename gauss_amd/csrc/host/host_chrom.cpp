@@ -223,7 +223,8 @@ int chrom_setup(ChromSetup& cs, int kind, int chr, int64_t wing_size, const char
                        const std::shared_ptr<const GwasCache>& gw)
 {
     cs.kind = kind;
-    cs.mix = (kind == GAUSS_KIND_DISTMIX || kind == GAUSS_KIND_QCATMIX);
+    cs.mix = (kind == GAUSS_KIND_DISTMIX || kind == GAUSS_KIND_QCATMIX || kind == GAUSS_KIND_COMPUTELD);
+    cs.measured_only = (kind == GAUSS_KIND_COMPUTELD);
     cs.qcat = (kind == GAUSS_KIND_QCAT || kind == GAUSS_KIND_QCATMIX);
     Args& a = cs.a;
     a.chr = chr; a.wing_size = wing_size;
@@ -276,7 +277,7 @@ int lean_window_build(LeanWindow& w, const ChromSetup& cs, long long start_bp, l
     const double cutoff = a.af1_cutoff;
     // MakeSnpVec / MakeSnpVecMix on the panel's tabulated counts and frequencies (MakeSnpVecPacked above), then the list
     auto keep = [&](int64_t row, long long bp, int type, double z, double info) {
-        if (type == 0 && (bp < start_bp || bp > end_bp)) return;       // a wing's unmeasured SNP: nothing reads it
+        if (type == 0 && (cs.measured_only || bp < start_bp || bp > end_bp)) return;       // a wing's unmeasured SNP (computeLD: any): nothing reads it
         double af = 0;
         if (!cs.mix) {
             double allele_counter = 0;                                  // gauss.cpp:574-591 (integer-valued sums)

@@ -391,6 +391,7 @@ inline double now_s()
 struct ChromSetup {                     // what prepare() derives from a call's arguments alone: once per call, not once per window
     int kind = 0;
     bool mix = false, qcat = false;
+    bool measured_only = false;         // computeLD: unmeasured SNPs are never read (computeLD.cpp:80-86) -- not entered at all
     Args a;                             // population table, flags, weights, cutoffs (start_bp / end_bp are the windows', not set here)
     std::vector<int> sel;               // the selected populations, panel order
     std::vector<int32_t> pop_off, pop_src_off;

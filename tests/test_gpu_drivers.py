@@ -345,6 +345,24 @@ def test_window_calls_and_chromosome_driver_equal_the_literal_data_layer(ctx, tm
             _same_frame(res[0], res[1])
             n_ok += 1
     assert n_ok >= 1
+    # computeLD() on the same windows (measured SNPs only: computeLD.cpp:80-86)
+    n_ld = 0
+    for s0 in range(span[0], span[1], 2 * wsize):
+        res = []
+        for full in ("0", "1"):
+            monkeypatch.setenv("GAUSS_HOST_FULL_MAP", full)
+            try:
+                res.append(api.computeLD(22, s0, min(span[1], s0 + 2 * wsize - 1), wgt, inp, idx, gpk, desc, af1_cutoff=0.01, ctx=ctx))
+            except api.GaussError as e:
+                res.append(str(e))
+        if isinstance(res[1], str):
+            assert res[0] == res[1], res
+        else:
+            assert not isinstance(res[0], str), res[0]
+            _same_frame(res[0]["snplist"], res[1]["snplist"])
+            assert np.array_equal(res[0]["cormat"], res[1]["cormat"])
+            n_ld += 1
+    assert n_ld >= 1
     kind = getattr(api, "KIND_" + name.upper())
     sel = dict(pop_wgt_df=who) if name.endswith("mix") else dict(study_pop="EUR")
     tabs = []
