@@ -565,11 +565,21 @@ def jepegmix_measure(rig, ch, files, tmp, steps, checks=None, spot_genes=24):
     t0 = time.perf_counter()
     tab = api.jepegmix(**kw)
     cold = time.perf_counter() - t0
-    ts = []
-    for _ in range(steps):
-        t0 = time.perf_counter()
-        tab = api.jepegmix(**kw)
-        ts.append(time.perf_counter() - t0)
+    # (the cyclic collector off while the calls are timed, as `timeit` does: at the end of the default run the process holds a few
+    # million Python objects -- the text leg's SNP names, the CPU baseline's samples -- and a generation-2 pass over them inside a
+    # 3 ms call is not the call's time: 5.2 ms against 3.3 measured with it on)
+    import gc
+    gc_was = gc.isenabled()
+    gc.disable()
+    try:
+        ts = []
+        for _ in range(steps):
+            t0 = time.perf_counter()
+            tab = api.jepegmix(**kw)
+            ts.append(time.perf_counter() - t0)
+    finally:
+        if gc_was:
+            gc.enable()
     warm = float(np.median(ts))
     # the host data layer alone (no GPU call): what bounds the run
     t0 = time.perf_counter()
