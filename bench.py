@@ -268,6 +268,7 @@ class Runner:
         self.drain()
         self.profile(events_in_region)
         self.rig.barrier()
+        c0 = [c.counters() for c in self.ctxs]
         t0 = time.perf_counter()
         self.done_at = []
         for _ in range(steps):
@@ -275,6 +276,9 @@ class Runner:
         res = self.drain()
         self.rig.barrier()
         dt = time.perf_counter() - t0
+        # how the library queued the runs of the TIMED region only (the contexts' counters are cumulative: warm-up and earlier legs excluded)
+        c1 = [c.counters() for c in self.ctxs]
+        self.launch_form = {k: sum(b[k] - a[k] for a, b in zip(c0, c1)) for k in c1[0]}
         # completion to completion of consecutive runs (the first one from the start of the region): the longest step
         marks = [t0] + self.done_at
         self.longest_step_ms = max((b - a) for a, b in zip(marks[:-1], marks[1:])) * 1e3 if len(marks) > 1 else 0.0
@@ -394,7 +398,7 @@ def run_impute(args, rig, quiet=False, light=False):
     dt, st, res = runner.timed(args.steps, args.warmup, events_in_region=rig.world == 1)
     # how the library queued the timed runs (gauss_hip_counters): merged = ONE Gram launch with the chain beside it; demoted = two
     # launches because the context shared its device with another one; giveups = merged runs repaired inside their fetch
-    launch_form = rig.ctx.counters()
+    launch_form = runner.launch_form
     res = runner.results_in_order(res) if runner.jobs else []
     gram_ms, gram_n = st["gram"]
     tmax = rig.reduce(dt, "max")
@@ -629,7 +633,11 @@ def run_impute(args, rig, quiet=False, light=False):
             # nothing about the fp64 kernels' own speed
             out["roofline_solve"] = None
             out["roofline_solve_note"] = "measured at N = 1 only (a one-stream pass of the same job)"
-        out["roofline"].update(pmc_traffic(len(wins) == 36 and len(ch["bp"]) == 100_000 and rig.world == 1))
+        # the launch the headline runs: ONE launch of the job's full grid (work items x 256 threads).  Counters exist for that grid from
+        # the one-stream pass (counter collection serialises the queues: the merged form itself cannot run under it, its evidence is
+        # the kernel trace, profiles/README.md); in the two-launch form the two halves' rows add up to the step's traffic
+        out["roofline"].update(pmc_traffic(len(wins) == 36 and len(ch["bp"]) == 100_000 and rig.world == 1, largest=True,
+                                           grid=stats["items"] * 256 if gram_lps == 1 else None))
         if shard_check is not None:
             out["config"]["shards_bit_identical_to_one_rank"] = shard_check
         if weak is not None:
@@ -647,13 +655,20 @@ def run_impute(args, rig, quiet=False, light=False):
         if e2e is not None and "_other_configs" in e2e:
             out["other_configs"] = e2e.pop("_other_configs")
         if not quiet:
-            print(json.dumps(out), flush=True)
+            emit_line(out, headline=True)
     runner.close()
     return out
 
 
 def rank_of(rig):
     return rig.rank
+
+
+def emit_line(out, headline):
+    """The detail goes to bench_detail.json beside this file and, tagged {"detail": ...}, to stderr; stdout gets the ONE final line,
+    which gauss_amd/benchline.py keeps under 6 KB (round 5's 28 KB line was more than the driver's reader took)."""
+    from gauss_amd import benchline
+    return benchline.emit(out, headline=headline, detail_path=os.path.join(ROOT, "bench_detail.json"))
 
 
 def shard_mode(args, world):
@@ -693,14 +708,16 @@ def pieces_equal_whole(parts, ref, wins):
     return True
 
 
-def pmc_traffic(applicable, kernel="gauss::gram_kernel<float>", largest=False):
-    """HBM-side bytes per launch of the Gram kernel from the committed rocprofv3 PMC passes
-    (profiles/*_pmc_traffic.csv: separate FETCH_SIZE / WRITE_SIZE runs of this same command, gfx950
-    correction applied).  PMC counters cannot be collected from inside the timed run, so the number is only quoted
-    while it describes the code that is running: the newest profile's recorded source hash
-    (profiles/<tag>_provenance.json, tools/summarize_profiles.py) must equal the hash compiled into the loaded
-    library (gauss_hip_source_hash); otherwise traffic is null and traffic_stale says why.  Null too when the run
-    is not the profiled workload."""
+def pmc_traffic(applicable, kernel="gauss::gram_kernel<float>", largest=False, grid=None):
+    """HBM-side bytes per launch of a kernel from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic*.csv: separate
+    FETCH_SIZE / WRITE_SIZE runs of this same command, gfx950 correction applied).  PMC counters cannot be collected from inside
+    the timed run, so the number is only quoted while it describes the code that is running: the newest profile's recorded
+    source hash (profiles/<tag>_provenance.json, tools/summarize_profiles.py) must equal the hash compiled into the loaded
+    library (gauss_hip_source_hash); otherwise traffic is null and traffic_stale says why.  Null too when the run is not the
+    profiled workload.
+    grid (threads): the row of <tag>_pmc_traffic_by_grid.csv whose launch has exactly this grid -- the Gram kernel is launched on
+    several grids by the profiled command (the full grid, the halves of the two-launch form the runs are demoted to under counter
+    collection, the emulated shares) and an average over them describes none; traffic_form says which launch the row is."""
     import csv
     import glob
     if not applicable:
@@ -723,11 +740,20 @@ def pmc_traffic(applicable, kernel="gauss::gram_kernel<float>", largest=False):
         return {"traffic": None, "traffic_source": src, "traffic_stale": True,
                 "traffic_note": f"{src} was collected on sources {profiled or 'unknown (no provenance file)'}, this library is {running}: "
                                 "not quoted; re-collect with tools/collect_profiles.sh"}
+    fg = f.replace("_pmc_traffic.csv", "_pmc_traffic_by_grid.csv")
+    if grid is not None and os.path.exists(fg):
+        for r in csv.DictReader(open(fg)):
+            if r["kernel"] == kernel and int(r["grid_threads"]) == int(grid):
+                return {"traffic": float(r["hbm_bytes_per_launch_corrected"]), "traffic_source": os.path.relpath(fg, ROOT), "traffic_stale": False,
+                        "traffic_sources_hash": profiled, "traffic_form": r.get("launch_form") or None, "traffic_grid_threads": int(grid)}
+        return {"traffic": None, "traffic_source": os.path.relpath(fg, ROOT), "traffic_stale": False,
+                "traffic_note": f"no launch of {kernel} with a grid of {int(grid)} threads in the profiled run"}
     best = None
     for r in csv.DictReader(open(f)):
         if r["kernel"] == kernel or r["kernel"] == kernel.split("<")[0]:
             best = float(r["hbm_bytes_largest_launch_corrected"] if largest and r.get("hbm_bytes_largest_launch_corrected") else r["hbm_bytes_per_launch_corrected"])
-    return {"traffic": best, "traffic_source": src, "traffic_stale": False, "traffic_sources_hash": profiled}
+    return {"traffic": best, "traffic_source": src, "traffic_stale": False, "traffic_sources_hash": profiled,
+            "traffic_form": "largest launch of the kernel in the profiled run" if largest else "average over the kernel's launches in the profiled run"}
 
 
 def usable_cores():
@@ -894,7 +920,7 @@ def main(argv=None):
             if out is not None and sample is not None and not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline_computeld(sample)
             if out is not None:
-                print(json.dumps(out), flush=True)
+                emit_line(out, headline=False)
     rig.close()           # not in a `finally`: a rank that failed must not wait in a barrier for the others
     if isinstance(out, dict) and isinstance(out.get("other_configs"), dict) and not out["other_configs"].get("all_parity_ok", True):
         print("bench.py: a parity_spot of the other_configs block failed", file=sys.stderr)

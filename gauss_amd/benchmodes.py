@@ -409,7 +409,8 @@ def run_e2e(args, rig):
             "config": {"workload": "distmix() chr22 end to end (BASELINE.json configs[3] from files): " + blk["what"]},
             "end_to_end": blk,
         }
-        print(json.dumps(out), flush=True)
+        import bench
+        bench.emit_line(out, headline=False)
     return out
 
 

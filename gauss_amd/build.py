@@ -13,6 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "lib", "obj")
 ARCH = "gfx950"
+EXPORTS_MAP = os.path.join(CSRC, "exports.map")     # both libraries export `gauss_*` only
 
 # translation unit -> extra flags
 HIP_UNITS = {
@@ -53,7 +54,10 @@ def hipcc_version():
 
 
 def _unit_cmd(hipcc, unit, src, obj):
-    cmd = [hipcc, "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj, "-Wno-unused-result", "-Wno-unused-value"] + HIP_UNITS[unit] + EXTRA_FLAGS
+    # -fvisibility=hidden: the library exports the C ABI of include/gauss_hip.h and nothing else (gauss_job.h brackets the header with
+    # a visibility pragma); loaded into an R process beside other packages, un-namespaced internals (fail, trace_on) would collide
+    cmd = [hipcc, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-fvisibility-inlines-hidden", "-c", src, "-o", obj,
+           "-Wno-unused-result", "-Wno-unused-value"] + HIP_UNITS[unit] + EXTRA_FLAGS
     if unit.endswith(".hip"):
         cmd.insert(3, f"--offload-arch={ARCH}")
     else:   # plain host C++ against the HIP runtime API (no device pass)
@@ -72,7 +76,7 @@ def source_hash():
     a library built from the same sources with other flags is a different library."""
     import hashlib
     h = hashlib.sha256()
-    names = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp", ".h")))
+    names = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp", ".h", ".map")))
     for f in names + ["../../include/gauss_hip.h"]:
         p = os.path.join(CSRC, f)
         h.update(os.path.basename(f).encode() + b"\0")
@@ -172,11 +176,11 @@ def build_hip(force=False, verbose=False):
     if force or old.get("csrc_hash") != sh or not os.path.exists(vobj):
         vsrc = os.path.join(OBJDIR, "gauss_version.cpp")
         with open(vsrc, "w") as fh:
-            fh.write('extern "C" const char* gauss_hip_source_hash(void) { return "%s"; }\n' % sh)
+            fh.write('extern "C" __attribute__((visibility("default"))) const char* gauss_hip_source_hash(void) { return "%s"; }\n' % sh)
         subprocess.check_call(["g++", "-O1", "-fPIC", "-c", vsrc, "-o", vobj])
     so = os.path.join(LIBDIR, "libgauss_hip.so")
     if force or relink or _newer(so, objs):
-        subprocess.check_call([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", so] + objs)
+        subprocess.check_call([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-Wl,--version-script=" + EXPORTS_MAP, "-o", so] + objs)
     head, dirty = git_head()
     if head is None:            # no git here (the GPU box): keep what the development container wrote for these sources
         head, dirty = (old.get("git_head"), old.get("git_dirty")) if old.get("csrc_hash") == sh else (None, None)
@@ -192,14 +196,14 @@ def build_host(force=False, verbose=False):
     hdir = os.path.join(CSRC, "host")
     # (host_internal.h: what the four host_*.cpp share; -fvisibility=hidden: only the C ABI of include/gauss_host.h is exported)
     srcs = [os.path.join(hdir, f) for f in ("host_feeder.cpp", "host_tables.cpp", "host_calls.cpp", "host_chrom.cpp", "bgzf_io.cpp", "packed_panel.cpp")]
-    deps = srcs + [os.path.join(hdir, "host_internal.h"), os.path.join(hdir, "bgzf_io.h"), os.path.join(hdir, "packed_panel.h"), os.path.join(HERE, "..", "include", "gauss_host.h"),
+    deps = srcs + [EXPORTS_MAP, os.path.join(hdir, "host_internal.h"), os.path.join(hdir, "bgzf_io.h"), os.path.join(hdir, "packed_panel.h"), os.path.join(HERE, "..", "include", "gauss_host.h"),
                    os.path.join(HERE, "..", "include", "gauss_hip.h"), hip_so]
     so = os.path.join(LIBDIR, "libgauss_host.so")
     if force or _newer(so, deps):
         flags = ["-O2", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-fvisibility-inlines-hidden", "-Wall"]
         objs = [os.path.join(OBJDIR, "host_" + os.path.splitext(os.path.basename(f))[0] + ".o") for f in srcs]
         _run_all([(os.path.basename(f), ["g++"] + flags + ["-c", f, "-o", o]) for f, o in zip(srcs, objs)], verbose)
-        cmd = ["g++", "-shared", "-o", so] + objs + ["-L" + LIBDIR, "-lgauss_hip", "-Wl,-rpath,$ORIGIN", "-lz", "-lpthread", "-ldl"]
+        cmd = ["g++", "-shared", "-Wl,--version-script=" + EXPORTS_MAP, "-o", so] + objs + ["-L" + LIBDIR, "-lgauss_hip", "-Wl,-rpath,$ORIGIN", "-lz", "-lpthread", "-ldl"]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)

@@ -6,7 +6,10 @@
 //   gauss_abi.cpp    the C ABI of include/gauss_hip.h on top of the above
 #pragma once
 #include "gauss_internal.h"
+// the library is built with -fvisibility=hidden: only the C ABI of include/gauss_hip.h is exported (gauss_amd/build.py)
+#pragma GCC visibility push(default)
 #include "../../include/gauss_hip.h"
+#pragma GCC visibility pop
 
 #include <algorithm>
 #include <atomic>

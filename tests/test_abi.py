@@ -26,6 +26,31 @@ def test_header_symbols_are_all_bound_and_exported():
     assert b"gfx950" in lib.gauss_hip_version()
 
 
+def _header_symbols(name):
+    src = open(os.path.join(ROOT, "include", name)).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"//[^\n]*", "", src)
+    return sorted(set(re.findall(r"\b(gauss_[A-Za-z_0-9]+)\s*\(", src)))
+
+
+@pytest.mark.parametrize("lib,header", [("libgauss_hip.so", "gauss_hip.h"), ("libgauss_host.so", "gauss_host.h")])
+def test_libraries_export_the_c_abi_and_nothing_else(lib, header):
+    """`nm -D --defined-only` of both libraries lists exactly the functions their header declares: no C++ internals (round 5's
+    libgauss_hip.so exported `fail`, `trace_on`, `queues_exclusive`, ...), no libstdc++ instances, no kernel handles
+    (-fvisibility=hidden + gauss_amd/csrc/exports.map; the reference exports one routine table, RcppExports.cpp:333-358)."""
+    import shutil
+    import subprocess
+    from gauss_amd import build
+    build.build_hip()
+    build.build_host()
+    nm = shutil.which("nm")
+    if nm is None:
+        pytest.skip("nm not available")
+    out = subprocess.check_output([nm, "-D", "--defined-only", os.path.join(ROOT, "gauss_amd", "lib", lib)]).decode()
+    exported = sorted(l.split()[-1] for l in out.splitlines() if l.strip())
+    assert exported == _header_symbols(header)
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     from gauss_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)
