@@ -41,6 +41,7 @@ HOST_SYMBOLS = [
     "gauss_host_panel_resident", "gauss_host_panel_evict", "gauss_host_impute_chromosome", "gauss_host_impute_genome", "gauss_host_chrom_window_view", "gauss_host_panel_cache", "gauss_table_n_messages",
     "gauss_table_message", "gauss_table_strcol_fixed", "gauss_host_panel_device_rows", "gauss_prepared_store_rows",
     "gauss_host_jepeg_gene_tail", "gauss_host_plan_cost",
+    "gauss_host_jepeg_rank", "gauss_host_jepeg_genome", "gauss_prepared_jepeg_plan", "gauss_prepared_jepeg_finish",
 ]
 
 
@@ -97,6 +98,11 @@ def load_host():
     h.gauss_host_distmix.argtypes = [_vp, C.c_int, _i64, _i64, _i64, _strs, _dp, C.c_int] + files4 + [_dbl, C.POINTER(_vp)]
     h.gauss_host_jepeg.argtypes = [_vp, _cp, _cp] + files4 + [_dbl, C.POINTER(_vp)]
     h.gauss_host_jepegmix.argtypes = [_vp, _strs, _dp, C.c_int, _cp] + files4 + [_dbl, C.POINTER(_vp)]
+    h.gauss_host_jepeg_rank.argtypes = [_vp, C.c_int, _cp, _strs, _dp, C.c_int, _cp] + files4 + [_dbl, C.c_int, C.c_int, C.POINTER(_vp)]
+    h.gauss_host_jepeg_genome.argtypes = [_vp, C.c_int, C.c_int, _cp, _strs, _dp, C.c_int, _strs, _strs, _strs, _strs, _cp, _dbl, C.c_int, C.c_int,
+                                          C.POINTER(_vp), C.POINTER(C.c_int32)]
+    h.gauss_prepared_jepeg_plan.argtypes = [_vp, C.c_int, C.POINTER(C.c_int32)]
+    h.gauss_prepared_jepeg_finish.argtypes = [_vp, C.c_int, C.c_int, _dp, C.POINTER(_vp)]
     h.gauss_host_prep_zmix5.argtypes = [_vp, _cp, _cp, _cp, _cp, _dbl, C.c_int, C.POINTER(_vp)]
     h.gauss_host_prep_zmix5_sup.argtypes = [_vp, _cp, _cp, _cp, _cp, _dbl, C.c_int, C.POINTER(_vp)]
     h.gauss_host_prep_zmix.argtypes = [_vp, _cp, _cp, _cp, _cp, C.c_int, C.POINTER(_vp)]
@@ -382,6 +388,41 @@ def jepegmix(pop_wgt_df, input_file, annotation_file, reference_index_file, refe
     return _table(h, out)[0]
 
 
+def jepeg_rank(kind, input_file, annotation_file, reference_index_file, reference_data_file, reference_pop_desc_file,
+               study_pop=None, pop_wgt_df=None, af1_cutoff=None, rank=0, world=1, ctx=None):
+    """gauss_host_jepeg_rank: rank `rank` of `world`'s contiguous gene range of a jepeg() (KIND_JEPEG, study_pop) or jepegmix()
+    (KIND_JEPEGMIX, pop_wgt_df) call.  Returns (table of the range's genes, (first gene, one past the last, genes in all)); the
+    ranks' tables concatenated in rank order are the one-rank table."""
+    h = load_host()
+    names, w, n = (None, None, 0) if pop_wgt_df is None else _pop_wgt(pop_wgt_df)
+    out = _vp()
+    _hcheck(h.gauss_host_jepeg_rank(_ctx(ctx), int(kind), _enc(study_pop), names, None if w is None else w.ctypes.data_as(_dp), n,
+                                    _enc(input_file), _enc(annotation_file), _enc(reference_index_file), _enc(reference_data_file),
+                                    _enc(reference_pop_desc_file), _af(af1_cutoff), int(rank), int(world), C.byref(out)))
+    rng = tuple(int(v) for v in _named(h, out)["gene_range"].reshape(-1))
+    return _table(h, out)[0], rng
+
+
+def jepeg_genome(kind, calls, reference_pop_desc_file, study_pop=None, pop_wgt_df=None, af1_cutoff=None, rank=0, world=1, ctx=None,
+                 raise_on_error=True):
+    """gauss_host_jepeg_genome: `calls` = [(input_file, annotation_file, reference_index_file, reference_data_file)], one jepeg() /
+    jepegmix() call each (the reference's user: one per chromosome), dealt whole to the ranks.  Returns (tables, owner): tables[c] is
+    call c's gene table on the rank that ran it and None elsewhere; owner[c] that rank."""
+    h = load_host()
+    names, w, n = (None, None, 0) if pop_wgt_df is None else _pop_wgt(pop_wgt_df)
+    nc = len(calls)
+    arr = lambda k: (C.c_char_p * nc)(*[_enc(c[k]) for c in calls])
+    outs = (_vp * nc)()
+    owner = (C.c_int32 * nc)()
+    rc = h.gauss_host_jepeg_genome(_ctx(ctx), int(kind), nc, _enc(study_pop), names, None if w is None else w.ctypes.data_as(_dp), n,
+                                   arr(0), arr(1), arr(2), arr(3), _enc(reference_pop_desc_file), _af(af1_cutoff), int(rank), int(world),
+                                   outs, owner)
+    tabs = [(_table(h, _vp(outs[c]))[0] if outs[c] else None) for c in range(nc)]
+    if rc != 0 and raise_on_error:
+        _hcheck(rc)
+    return tabs, [int(o) for o in owner]
+
+
 def _columns(h, t):
     """gauss_table -> {name: numpy array}; string columns come across as ONE fixed-width bytes array each
     (dtype "S<w>"), not as Python strings: a chromosome's table has ~10^5 rows."""
@@ -644,6 +685,21 @@ class Prepared:
     def finish(self):
         out = _vp()
         _hcheck(self.h.gauss_prepared_finish(self.handle, C.byref(out)))
+        return _table(self.h, out)[0]
+
+    def jepeg_plan(self, world):
+        """gauss_prepared_jepeg_plan: first[r] = rank r's first gene (contiguous ranges of equal cost), first[world] = genes in all."""
+        first = (C.c_int32 * (int(world) + 1))()
+        _hcheck(self.h.gauss_prepared_jepeg_plan(self.handle, int(world), first))
+        return [int(v) for v in first]
+
+    def jepeg_finish(self, g0, g1, blocks):
+        """gauss_prepared_jepeg_finish: the gene table of genes [g0, g1) from their CorG blocks (a list of n_g x n_g arrays, or
+        their concatenation; diagonal 1 + lambda)."""
+        flat = np.ascontiguousarray(np.concatenate([np.asarray(b, dtype=np.float64).reshape(-1) for b in blocks]) if len(blocks)
+                                    else np.zeros(1), dtype=np.float64)
+        out = _vp()
+        _hcheck(self.h.gauss_prepared_jepeg_finish(self.handle, int(g0), int(g1), flat.ctypes.data_as(_dp), C.byref(out)))
         return _table(self.h, out)[0]
 
     def close(self):

@@ -100,7 +100,10 @@ def _other(name, c):
         out["timed_with_gc_off"] = c.get("timed_with_gc_off", True)
         e = c.get("emulated_world8")
         if isinstance(e, dict):
-            out["emulated_world8"] = pick(e, ("world", "slowest_ms", "one_rank_ms", "predicted_efficiency", "tables_identical_to_one_rank", "split"))
+            out["emulated_world8"] = pick(e, ("world", "slowest_ms", "one_rank_ms", "predicted_efficiency", "tables_identical_to_one_rank"))
+            wc = e.get("whole_calls")
+            if isinstance(wc, dict):
+                out["emulated_world8"]["whole_calls"] = pick(wc, ("calls", "slowest_ms", "one_rank_ms", "predicted_efficiency"))
     if name == "int8_exact":
         out.update(pick(c, ("bit_identical_to_f32_path", "gram_ms", "kernel")))
     return out

@@ -444,6 +444,74 @@ def impute_chromosome(kind, chr, start_bp, end_bp, wing_size, input_file, refere
             "windows": windows, "owner": owner}
 
 
+def _dist_state(group):
+    try:
+        import torch.distributed as dist_mod
+        if dist_mod.is_available() and dist_mod.is_initialized():
+            return dist_mod, dist_mod.get_rank(group), dist_mod.get_world_size(group)
+    except ImportError:     # pragma: no cover
+        pass
+    return None, 0, 1
+
+
+def jepeg(kind, input_file, annotation_file, reference_index_file, reference_data_file, reference_pop_desc_file, study_pop=None,
+          pop_wgt_df=None, af1_cutoff=None, compute=None, group=None, ctx=None):
+    """jepeg() / jepegmix() (kind = api.KIND_JEPEG / KIND_JEPEGMIX) with the GENES of the one call split over the ranks of `group`
+    (BASELINE.json configs[4]).  Genes are independent (jepeg.cpp:114-131, gauss.cpp:1383-1439): every rank
+    runs the same host data layer on the same files, derives the same plan (contiguous gene ranges of equal cost,
+    gauss_prepared_jepeg_plan) and computes CorG and the k x k tails of its range only -- no data-path collective; the ranks'
+    tables are gathered on rank 0 and concatenated in rank order, which is gene order.  Returns on rank 0 (or the single process)
+    {"table": DataFrame, "ranges": [(g0, g1)] per rank}; None on the other ranks.
+
+    compute = None: the native call on this rank's GPU (gauss_host_jepeg_rank).  compute = fn(prepared, g0, g1) -> list of CorG
+    blocks (n_g x n_g, diagonal 1 + lambda): the Python form of the same split, for harnesses that compute CorG themselves (the
+    CPU tests put the oracle there); plan and tails are the library's (gauss_prepared_jepeg_plan / _finish)."""
+    import pandas as pd
+    dist, rank, world = _dist_state(group)
+    if compute is None:
+        tab, (g0, g1, ng) = api.jepeg_rank(kind, input_file, annotation_file, reference_index_file, reference_data_file,
+                                           reference_pop_desc_file, study_pop=study_pop, pop_wgt_df=pop_wgt_df, af1_cutoff=af1_cutoff,
+                                           rank=rank, world=world, ctx=ctx or hotpath.default_context())
+    else:
+        pr = api.Prepared(kind, study_pop=study_pop, pop_wgt_df=pop_wgt_df, input_file=input_file, annotation_file=annotation_file,
+                          reference_index_file=reference_index_file, reference_data_file=reference_data_file,
+                          reference_pop_desc_file=reference_pop_desc_file, af1_cutoff=af1_cutoff)
+        try:
+            first = pr.jepeg_plan(world)
+            g0, g1, ng = first[rank], first[rank + 1], first[-1]
+            tab = pr.jepeg_finish(g0, g1, compute(pr, g0, g1) if g1 > g0 else [])
+        finally:
+            pr.close()
+    local = {"table": tab, "range": (g0, g1), "genes": ng}
+    if dist is None or world == 1:
+        return {"table": tab, "ranges": [(g0, g1)]}
+    parts = [None] * world if rank == 0 else None
+    dist.gather_object(local, parts, dst=0, group=group)
+    if rank != 0:
+        return None
+    ranges = [p["range"] for p in parts]
+    # every rank derived the same plan: the ranges tile [0, genes) in rank order
+    assert ranges[0][0] == 0 and ranges[-1][1] == parts[0]["genes"] and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:])), ranges
+    return {"table": pd.concat([p["table"] for p in parts], ignore_index=True), "ranges": ranges}
+
+
+def jepeg_genome(kind, calls, reference_pop_desc_file, study_pop=None, pop_wgt_df=None, af1_cutoff=None, group=None, ctx=None):
+    """One jepeg() / jepegmix() call per entry of `calls` = [(input_file, annotation_file, reference_index_file,
+    reference_data_file)] -- the reference's user runs one per chromosome -- dealt WHOLE to the ranks (gauss_host_jepeg_genome: longest
+    annotation first onto the least loaded rank; the same deal on every rank, no communication).  A call is host-bound, so this is
+    the split that scales.  Returns on rank 0 {"tables": [DataFrame per call], "owner": [rank per call]}; None elsewhere."""
+    dist, rank, world = _dist_state(group)
+    tabs, owner = api.jepeg_genome(kind, calls, reference_pop_desc_file, study_pop=study_pop, pop_wgt_df=pop_wgt_df,
+                                   af1_cutoff=af1_cutoff, rank=rank, world=world, ctx=ctx or hotpath.default_context())
+    if dist is None or world == 1:
+        return {"tables": tabs, "owner": owner}
+    parts = [None] * world if rank == 0 else None
+    dist.gather_object(tabs, parts, dst=0, group=group)
+    if rank != 0:
+        return None
+    return {"tables": [parts[owner[c]][c] for c in range(len(calls))], "owner": owner}
+
+
 def _gwas_positions(path, chr):
     bp = []
     with open(path) as f:

@@ -103,6 +103,36 @@ int gauss_host_jepegmix(gauss_ctx* ctx, const char* const* pop_names, const doub
                         const char* reference_index_file, const char* reference_data_file,
                         const char* reference_pop_desc_file, double af1_cutoff, gauss_table** out);
 
+/* jepeg() / jepegmix() on several GPUs (BASELINE.json configs[4], SURVEY.md section 8e: "genes: contiguous gene ranges or one
+ * gene-batch per GPU").  Genes are independent (jepeg.cpp:114-131 builds and tests one Gene at a time; jepegmix.cpp:119-140;
+ * grouping at gauss.cpp:1383-1439), so rank `rank` of `world` runs the host data layer on the same files as every other rank,
+ * derives the same plan -- contiguous gene ranges of equal cost, a gene costing its SNP pairs n (n + 1) plus a constant for its
+ * k x k tail -- and computes CorG (GPU) and the tails of ITS range only: no communication.  The tables of ranks 0 .. world-1,
+ * concatenated in rank order, are gauss_host_jepeg(mix)'s table row for row, bit for bit.  The result carries the named matrix
+ * "gene_range" [1 x 3] = first gene, one past the last gene, genes in all.  kind = GAUSS_KIND_JEPEG (study_pop) or
+ * GAUSS_KIND_JEPEGMIX (pop_names / pop_wgts); rank 0 of world 1 is the reference's call. */
+int gauss_host_jepeg_rank(gauss_ctx* ctx, int kind, const char* study_pop, const char* const* pop_names, const double* pop_wgts,
+                          int n_pop_wgt, const char* input_file, const char* annotation_file, const char* reference_index_file,
+                          const char* reference_data_file, const char* reference_pop_desc_file, double af1_cutoff,
+                          int rank, int world, gauss_table** out);
+/* The loop over calls above that: n_calls independent jepeg() / jepegmix() calls -- the reference's user runs one per chromosome
+ * file set (jepeg.cpp:28-34 takes one input / annotation / panel per call) -- dealt WHOLE to the ranks, longest first by the size of
+ * the annotation file onto the least loaded rank (every rank sees the same files and derives the same deal; no communication).  A
+ * call is host-bound (3.4 ms, of which 0.6 ms GPU), so whole calls per rank is the split that scales; the gene split above divides
+ * only the GPU batch and the tails.  out[c] = call c's table on its owner, NULL on the other ranks; owner_out[c] (may be NULL) = the
+ * rank that ran it.  reference_index_files may be NULL when every data file is a packed panel.  A call that fails leaves out[c] NULL,
+ * the others still run, and the function returns -1 with the first failure's message. */
+int gauss_host_jepeg_genome(gauss_ctx* ctx, int kind, int n_calls, const char* study_pop, const char* const* pop_names,
+                            const double* pop_wgts, int n_pop_wgt, const char* const* input_files, const char* const* annotation_files,
+                            const char* const* reference_index_files, const char* const* reference_data_files,
+                            const char* reference_pop_desc_file, double af1_cutoff, int rank, int world, gauss_table** out,
+                            int32_t* owner_out);
+/* The two halves of gauss_host_jepeg_rank for a harness that computes CorG itself (the CPU tests put the oracle there): the plan
+ * -- first[r] = rank r's first gene, first[world] = genes in all -- and the gene table of genes [g0, g1) from their CorG blocks
+ * (concatenated n_g x n_g, row-major, diagonal 1 + lambda = 1.1).  No GPU needed. */
+int gauss_prepared_jepeg_plan(const gauss_prepared* p, int world, int32_t* first);
+int gauss_prepared_jepeg_finish(const gauss_prepared* p, int g0, int g1, const double* blocks, gauss_table** out);
+
 /* QCAT / QCATMIX: same feeder as dist / distmix, the window core is
  * run_qcat (qcat.cpp:134-262) / run_qcatmix (qcatmix.cpp:144-297).  af1_cutoff NaN -> 0.05 for qcat
  * (qcat.cpp:53-57), 0.01 for qcatmix (qcatmix.cpp:61-65).  Output columns: rsid chr bp a1 a2
