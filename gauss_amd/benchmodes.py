@@ -505,6 +505,7 @@ def run_computeld(args, rig):
                 "blocking_gauss_ld_host_bytes": {"ms_per_call": t_block * 1e3, "ld_matrices_per_s": 1.0 / t_block,
                                                  "note": f"{host.nbytes / 1e6:.1f} MB of genotype bytes over PCIe per call, {M * M * 8 / 1e6:.1f} MB back"},
                 "one_resident_window": {"ms_per_step": dt1 * 1e3, "gram_ms": g1 * 1e3, "gram_tflops": flops / g1 / 1e12,
+                                        "frac": flops / g1 / 1e12 / FP32_MFMA_PEAK_TFLOPS,
                                         "stage_ms": {k: v[0] / steps for k, v in st1.items()}},
                 "batched_resident_windows": {"windows": B, "ms_per_step": dtb * 1e3, "gram_ms": gb * 1e3, "gram_tflops": ach,
                                              "ld_matrices_per_s": B / dtb, "stage_ms": {k: v[0] / steps for k, v in stb.items()}},

@@ -18,6 +18,7 @@ static WinSpec spec_from_desc(const gauss_window_desc& d)
     w.kind = d.kind; w.n_head = d.n_head_measured; w.n_predm = d.n_pred_measured; w.eig_cutoff = d.eig_cutoff;
     w.u_codings = d.u_codings;
     w.geno_fmt = d.geno_format; w.rows_m = d.rows_m; w.rows_u = d.rows_u; w.pop_src_off = d.pop_src_off;
+    w.out_b11 = d.out_b11; w.out_b21 = d.out_b21;
     return w;
 }
 extern "C" {

@@ -216,6 +216,14 @@ void launch_counts(const Prob* d_probs, int prob, int npair, long long* d_out, h
 void launch_pack2bit(const uint8_t* d_in, long long ld_in, uint8_t* d_out, long long ld_out, int n_snp,
                      const int* d_pop_off, const int* d_blk_off, int n_pop, hipStream_t s);
 void launch_h2d_copy(void* d_dst, const void* pinned_src, size_t bytes, hipStream_t s);
+// Matrix exports (raw LD export / want_mats): `n` device matrices [rows x pitch] are written as compact [rows x width] doubles into the
+// job's pinned export mirror by ONE kernel (the stores cross PCIe), instead of a pitched copy per matrix and a compaction on the host.
+struct ExportD {
+    const double* src;      // device matrix, row pitch `pitch` doubles
+    double* dst;            // compact [rows x width] in the pinned mirror (device-visible host memory)
+    int rows, width, pitch, pad_;
+};
+void launch_export_rows(const ExportD* d_exports, int n, long long max_elems, hipStream_t s);
 void launch_synth(uint8_t* d_out, int n_snp, long long ld, const int* d_pop_off, int n_pop,
                   int n_samples, const float* d_thr, const float* d_rho, uint64_t seed,
                   hipStream_t s);

@@ -341,6 +341,16 @@ struct gauss_job {
     unsigned run_seq = 0, fetch_seq = 0;
     double* h_results = nullptr;                           // mirror of the run being fetched
     int* h_status = nullptr;
+    // Matrix exports (out_b11 / out_b21 of LD-export, QCAT and want_mats windows): the run writes them compact into a pinned mirror
+    // by kernel, chunk by chunk with an event behind each chunk, and gauss_job_fetch copies a chunk to the caller's memory as soon
+    // as its event has completed (a few host threads for large jobs) -- the link, the host copies and the rest of the run overlap.
+    // Empty when the job exports nothing or the mirror would not fit the pinned budget (then fetch_matrix per matrix, as before).
+    struct Export { int plan, which; size_t off; int rows, width, pitch; double* user; };     // which: 0 = B11, 1 = B21; off in doubles
+    std::vector<Export> exports;
+    std::vector<std::pair<int, int>> exp_chunks;           // [first, last) exports of every chunk
+    std::vector<hipEvent_t> exp_ev;                        // chunk c is in the mirror
+    double* h_export = nullptr;                            // inside h_pin
+    ExportD* d_exports = nullptr;
     bool prof = false;
     std::vector<ProfSlot> slots;
     double prof_ms[5] = {0, 0, 0, 0, 0};
@@ -394,6 +404,8 @@ struct WinSpec {
     const int32_t* pair_i = nullptr;         // LD-only: only these SNP pairs are wanted (tile pairs they touch), else all
     const int32_t* pair_j = nullptr;
     int64_t n_pairs = 0;
+    double* out_b11 = nullptr;               // matrices the caller wants back (the job plans their export at build time)
+    double* out_b21 = nullptr;
 };
 
 // ---- gauss_plan.cpp ----

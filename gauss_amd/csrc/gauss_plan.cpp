@@ -10,12 +10,29 @@
 // a batch of windows has plenty of items already, and longer segments mean fewer partial slabs
 // for the epilogue to read back.  Either way a partial sum stays an exact f32 integer
 // (15 * 15 * 8192 < 2^24).
-static int seg_max_for(size_t n_windows)
+static int seg_max_for(const std::vector<WinSpec>& specs)
 {
     // 4096 for batched jobs (8192 until the chain moved beside the Gram kernel: with B11's and B21's items in launches of their
     // own the shorter items balance each launch's last round better -- 5 / 9 / 18 / 36 windows: step 4.86 -> 4.75, 8.97 -> 8.93,
     // 19.47 -> 19.29, 41.00 -> 40.96 ms -- for 19 % more work items)
-    return n_windows >= 4 ? 4096 : SEG_MAX;
+    if (specs.size() >= 4) return 4096;
+    // One to three windows: a work item per (tile pair, segment), so the segment length decides how many workgroups the launch
+    // has.  A window with few tile pairs -- computeLD()'s one 3 Mb window: 529 SNPs, 15 pairs -- left three quarters of the chip's
+    // 1 024 workgroup slots empty at 2 048 samples a segment; segments are cut so that the job has ~1 300 items, down to 384 samples
+    // (below that the epilogue's reads of the partial slabs cost what the Gram launch gains).  Measured on that window, Gram
+    // launch / LD epilogue in us: 2048: 196 / 59 (46 TFLOP/s); 1024: 154 / 67; 768: 140 / 69; 512: 127 / 74; 384: 120 / 81
+    // (75 TFLOP/s); 256: 116 / 92.  Any cut is exact (integer partial sums); listed-pair and gene jobs keep 2 048.
+    double pairs = 0, kp = 0;
+    for (const WinSpec& w : specs) {
+        if (w.gene_off || w.pair_i || w.M < 1 || w.n_pop < 1 || w.n_pop > 64 || !w.pop_off) return SEG_MAX;      // (plan_problem reports what is wrong)
+        int nc = 0;
+        for (int c = 0; c < 3; c++) nc += (w.u_codings >> c) & 1;
+        const double mt = (w.M + TILE - 1) / TILE, ut = ((double)w.U * std::max(nc, 1) + TILE - 1) / TILE;
+        pairs += mt * (mt + 1) / 2 + ut * mt;
+        kp = std::max(kp, (double)w.pop_off[w.n_pop] + 32.0 * w.n_pop);
+    }
+    const double want = pairs * kp / 1300.0;
+    return (int)std::min<double>(SEG_MAX, std::max<double>(384.0, std::floor(want / KC) * KC));
 }
 // Consecutive segments are chained into one work item until the run reaches this many samples
 // (a fresh item costs a pipeline fill: descriptor, first operand tiles, barrier).  0 = no chaining.
@@ -232,6 +249,7 @@ int plan_problem(const WinSpec& w, Plan& pl, int seg_max, int group_target)
     pl.U_user = w.U;
     if (w.z1) pl.z1.assign(w.z1, w.z1 + w.M);
     pl.h_geno_m = w.geno_m; pl.h_geno_u = w.geno_u; pl.user_ld = w.ld;
+    pl.out_b11 = w.out_b11; pl.out_b21 = w.out_b21;
     return GAUSS_OK;
 }
 
@@ -264,10 +282,25 @@ int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_device, 
     job->on_device = on_device;
     job->gram_i8 = ctx->gram_i8;
     job->plans.resize(job->n);
+    const int seg_max = seg_max_for(specs);
     for (int i = 0; i < job->n; i++) {
-        int rc = plan_problem(specs[i], job->plans[i], seg_max_for(specs.size()), group_target_for(specs.size()));
+        int rc = plan_problem(specs[i], job->plans[i], seg_max, group_target_for(specs.size()));
         if (rc) return rc;
         job->plans[i].p.gram_i8 = job->gram_i8;
+    }
+    // Matrix exports (gauss_job.h): which matrices the caller wants back, and where each lands in the pinned mirror
+    size_t exp_doubles = 0;
+    if (!streamed) {
+        for (int i = 0; i < job->n; i++) {
+            const Plan& pl = job->plans[i];
+            const Prob& p = pl.p;
+            const bool has = p.kind == GAUSS_WIN_LD || p.npanel > 0;          // (the windows gauss_job_fetch exports matrices for)
+            if (!has) continue;
+            if (pl.out_b11) { job->exports.push_back(gauss_job::Export{i, 0, exp_doubles, p.M, p.M, p.Mld, pl.out_b11}); exp_doubles += (size_t)p.M * p.M; }
+            if (pl.out_b21 && p.U > 0) { job->exports.push_back(gauss_job::Export{i, 1, exp_doubles, p.U, p.M, p.Mld, pl.out_b21}); exp_doubles += (size_t)p.U * p.M; }
+            exp_doubles = rup(exp_doubles, 32);                                // every window's block starts on a 256-byte boundary
+        }
+        if (exp_doubles * sizeof(double) > ((size_t)256 << 20)) { job->exports.clear(); exp_doubles = 0; }      // pinned budget: per matrix instead
     }
     const auto tb1 = std::chrono::steady_clock::now();
     // Shared measured rows: every window reads its measured SNPs from the same resident store under the same populations.
@@ -671,6 +704,7 @@ int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_device, 
     const size_t o_gemmmap = put(blob, ta, gemmmap);
     const size_t o_finmap = put(blob, ta, finmap);
     const size_t o_probs = ta.take(sizeof(Prob) * (size_t)n_prob);
+    const size_t o_exports = ta.take(sizeof(ExportD) * std::max<size_t>(job->exports.size(), 1));
     blob.resize(ta.off);
     job->n_items = (int)items.size();
     job->n_rows = (int)rowmap.size();
@@ -777,7 +811,8 @@ int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_device, 
     // DMA and a job over resident rows is created without waiting for the stream (another job may be running on it)
     const size_t pin_tab = rup(job->tab_bytes, 256), pin_res = rup(sizeof(double) * std::max<size_t>(res, 1), 256);
     const size_t pin_st = rup(sizeof(int) * (4 * job->n + 4), 256);
-    e = ctx_pin_alloc(ctx, pin_tab + 2 * (pin_res + pin_st), (void**)&job->h_pin);
+    const size_t pin_exp = rup(sizeof(double) * exp_doubles, 256);
+    e = ctx_pin_alloc(ctx, pin_tab + 2 * (pin_res + pin_st) + pin_exp, (void**)&job->h_pin);
     if (e != hipSuccess) { job->h_pin = nullptr; return fail(GAUSS_E_NOMEM, "hipHostMalloc(%zu bytes) failed", pin_tab + 2 * pin_res); }
     for (int k = 0; k < 2; k++) {
         job->h_res2[k] = (double*)(job->h_pin + pin_tab + k * (pin_res + pin_st));
@@ -787,6 +822,20 @@ int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_device, 
     job->h_results = job->h_res2[0];
     job->h_status = job->h_st2[0];
     job->done = job->done2[0];
+    if (!job->exports.empty()) {
+        job->h_export = (double*)(job->h_pin + pin_tab + 2 * (pin_res + pin_st));
+        // chunks of whole exports, >= 2 MB each (at most ~32): one kernel launch and one event per chunk
+        const size_t per = std::max<size_t>((size_t)1 << 18, (exp_doubles + 31) / 32);       // doubles
+        size_t acc = 0;
+        int first = 0;
+        const int nx = (int)job->exports.size();
+        for (int x = 0; x < nx; x++) {
+            acc += (size_t)job->exports[(size_t)x].rows * job->exports[(size_t)x].width;
+            if (acc >= per || x + 1 == nx) { job->exp_chunks.push_back(std::make_pair(first, x + 1)); first = x + 1; acc = 0; }
+        }
+        job->exp_ev.assign(job->exp_chunks.size(), nullptr);
+        for (hipEvent_t& ev : job->exp_ev) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
     const auto tj1 = std::chrono::steady_clock::now();
     HIPCHK(hipEventCreate(&job->begin));
     for (int k = 0; k < 2; k++)
@@ -965,6 +1014,15 @@ int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_device, 
         else if (job->merged && (int)n < job->n_items_b11 + job->n_items_b21_early) it.flags |= 32;      // ... in b11_done[8] (the early windows' B21 items)
         memcpy(blob.data() + o_items + sizeof(Item) * n, &it, sizeof(Item));
     }
+    for (size_t x = 0; x < job->exports.size(); x++) {
+        const gauss_job::Export& ex = job->exports[x];
+        const Plan& pl = job->plans[(size_t)ex.plan];
+        ExportD d;
+        d.src = ex.which ? pl.p.B21 : (pl.p.kind == GAUSS_WIN_LD ? pl.p.A : pl.d_b11_copy);
+        d.dst = job->h_export + ex.off;
+        d.rows = ex.rows; d.width = ex.width; d.pitch = ex.pitch; d.pad_ = 0;
+        memcpy(blob.data() + o_exports + sizeof(ExportD) * x, &d, sizeof(ExportD));
+    }
     const auto tj2 = std::chrono::steady_clock::now();
     memcpy(job->h_pin, blob.data(), blob.size());
     // The table image crosses PCIe by kernel, not by hipMemcpyAsync: while a background upload keeps the DMA engines busy
@@ -986,6 +1044,7 @@ int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_device, 
     job->d_dpanelmap = (int2*)(job->d_tab + o_dpanelmap);
     job->d_gemmmap = (int2*)(job->d_tab + o_gemmmap);
     job->d_finmap = (int2*)(job->d_tab + o_finmap);
+    job->d_exports = (ExportD*)(job->d_tab + o_exports);
     if (!on_device && !streamed) HIPCHK(hipStreamSynchronize(st));   // uploads from pageable user memory are complete
     std::vector<char>().swap(job->h_tab);
     { std::lock_guard<std::mutex> lock(ctx->mu); ctx->jobs.insert(job); }

@@ -44,6 +44,26 @@ void prof_collect(gauss_job* job, unsigned run_end)
 // ------------------------------------------------------------------------------------------
 // the result mirrors travel with the run, so that gauss_job_fetch waits for THIS job only (an event), not for
 // whatever else has been queued on the stream since (the next job of a pipeline)
+// Export chunks [c0, c1) into the pinned mirror by kernel (its stores cross PCIe at ~56 GB/s), an event behind each.
+// What was tried to hide the link time under the Gram kernel of a 32-window computeLD() batch, and measured (4.85-5.0 ms a step as it
+// is: kernels 3.3, link 1.3, last host copy + status 0.3): the early half of the windows as a Gram launch of its own with its
+// exports on the chain queue beside the second launch -- 4.75-4.8 ms (the export kernel's workgroups cost that launch 0.3-0.5 ms,
+// about what they hide; with 64 workgroups instead of 1 000 the launch keeps its speed and the exports starve at 17 GB/s);
+// one launch with the early items counted off (the imputation runs' form) -- the epilogue kernel's 1 024-thread workgroups do not
+// fit beside the Gram kernel's and ran when the launch was over; hipMemcpyAsync from a compacted device image -- the runtime
+// copies device -> pinned host with a blit KERNEL here (__amd_rocclr_copyBuffer), same contention.  None kept.
+static int queue_exports(gauss_job* job, size_t c0, size_t c1, hipStream_t st)
+{
+    for (size_t c = c0; c < c1 && c < job->exp_chunks.size(); c++) {
+        const int x0 = job->exp_chunks[c].first, x1 = job->exp_chunks[c].second;
+        long long mx = 0;
+        for (int x = x0; x < x1; x++) mx = std::max(mx, (long long)job->exports[(size_t)x].rows * job->exports[(size_t)x].width);
+        launch_export_rows(job->d_exports + x0, x1 - x0, mx, st);
+        HIPCHK(hipEventRecord(job->exp_ev[c], st));
+    }
+    return GAUSS_OK;
+}
+
 static int job_queue_results(gauss_job* job, int par, hipStream_t st)
 {
     HIPCHK(hipGetLastError());
@@ -53,6 +73,8 @@ static int job_queue_results(gauss_job* job, int par, hipStream_t st)
     // eight made the caller wait 10-18 ms for a DMA engine here, and every run of a 36-window job 5 ms (round 4).
     // Both mirrors have room for the 16-byte word the copy rounds up to (pin_res in job_build; the status block is 16 (n + 1) bytes);
     // the event below is a system-scope release, so the host reads what the kernel wrote.
+    // matrix exports first, chunk by chunk: gauss_job_fetch starts copying chunk c out while the later chunks still cross the link
+    { const int rc = queue_exports(job, 0, job->exp_chunks.size(), st); if (rc) return rc; }
     if (job->n_results) launch_h2d_copy(job->h_res2[par], job->d_results, rup(sizeof(double) * job->n_results, 16), st);
     launch_h2d_copy(job->h_st2[par], job->d_status, sizeof(int) * (4 * job->n + 4), st);
     HIPCHK(hipGetLastError());
@@ -455,6 +477,49 @@ static int job_count_small_eigs(gauss_job* job, int i, int* num_eig)
     return GAUSS_OK;
 }
 
+// The exported matrices of chunks [c0, c1) from the pinned mirror to the caller's memory, each chunk as soon as its event is complete.
+static int export_copy_out(gauss_job* job, size_t c0, size_t c1, std::atomic<size_t>* next)
+{
+    for (;;) {
+        const size_t c = next ? next->fetch_add(1) : c0++;
+        if (c >= c1) return GAUSS_OK;
+        const auto t0 = std::chrono::steady_clock::now();
+        if (hipEventSynchronize(job->exp_ev[c]) != hipSuccess) return GAUSS_E_DEVICE;
+        const auto t1 = std::chrono::steady_clock::now();
+        size_t bytes = 0;
+        for (int x = job->exp_chunks[c].first; x < job->exp_chunks[c].second; x++) {
+            const gauss_job::Export& ex = job->exports[(size_t)x];
+            memcpy(ex.user, job->h_export + ex.off, sizeof(double) * (size_t)ex.rows * ex.width);
+            bytes += sizeof(double) * (size_t)ex.rows * ex.width;
+        }
+        if (trace_on("job")) {
+            const auto t2 = std::chrono::steady_clock::now();
+            fprintf(stderr, "[job] export chunk %zu: waited %.3f ms, copied %.2f MB in %.3f ms\n", c, std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                    bytes / 1e6, std::chrono::duration<double, std::milli>(t2 - t1).count());
+        }
+    }
+}
+
+static int export_fetch_all(gauss_job* job)
+{
+    const size_t nc = job->exp_chunks.size();
+    if (!nc) return GAUSS_OK;
+    size_t bytes = 0;
+    for (const gauss_job::Export& ex : job->exports) bytes += sizeof(double) * (size_t)ex.rows * ex.width;
+    // one host thread copies ~10 GB/s; the link delivers ~50: large exports take a few helpers (the caller's thread is one of them)
+    const int helpers = bytes >= ((size_t)16 << 20) ? (int)std::min<size_t>(3, nc - 1) : 0;
+    std::atomic<size_t> next{0};
+    std::atomic<int> rc_all{0};
+    std::vector<std::thread> th;
+    const int device = job->ctx->device;
+    for (int t = 0; t < helpers; t++)
+        th.emplace_back([&, device]() { (void)hipSetDevice(device); const int rc = export_copy_out(job, 0, nc, &next); if (rc) rc_all = rc; });
+    const int rc = export_copy_out(job, 0, nc, &next);
+    for (std::thread& t : th) t.join();
+    if (rc || rc_all) return fail(GAUSS_E_DEVICE, "waiting for a matrix export failed");
+    return GAUSS_OK;
+}
+
 int job_fetch(gauss_job* job)
 {
     if (!job->ran || job->fetch_seq == job->run_seq) return fail(GAUSS_E_INVALID, "gauss_job_fetch: no run of this job is waiting to be fetched");
@@ -463,8 +528,18 @@ int job_fetch(gauss_job* job)
     const int par = (int)(job->fetch_seq & 1u);
     job->h_results = job->h_res2[par];
     job->h_status = job->h_st2[par];
+    // the exported matrices leave the pinned mirror chunk by chunk while the rest of the run is still on the queue (with a later run
+    // of the job in flight that run rewrites the mirror with the same values: it is left to finish first, as for any device read)
+    const bool exporting = !job->exports.empty();
+    if (exporting) {
+        if (job->run_seq - job->fetch_seq > 1u) HIPCHK(hipEventSynchronize(job->done));
+        const int rc = export_fetch_all(job);
+        if (rc) return rc;
+    }
     HIPCHK(hipEventSynchronize(job->done2[par]));
+    bool rerun = false;
     if (job->h_status[4 * job->n] != 0) {
+        rerun = true;
         // A waiting kernel of the merged launch gave up (k_gram.hip: wait_count_kernel raises this job-wide flag after its
         // bound): what the chain computed from then on is not valid.  The run is queued once more in the two-launch form,
         // which has no kernel that waits for another queue, into the same mirrors -- the job's inputs do not change between
@@ -484,6 +559,7 @@ int job_fetch(gauss_job* job)
         }
         if (job->run_seq - job->fetch_seq > 1u) job->done = job->done2[par ^ 1];      // (the later run's event stays the newest: it was synchronised above)
     }
+    if (rerun && exporting) { const int rc = export_fetch_all(job); if (rc) return rc; }      // what the failed merged run exported is void
     // With a later run of the job already queued, anything that reads the job's DEVICE buffers (matrix exports, the
     // clamp path, the eigenvalue count) first lets that run finish: the job's inputs do not change between runs, so
     // what it leaves on the device is what the fetched run left.
@@ -503,9 +579,9 @@ int job_fetch(gauss_job* job)
         int bits = 0;
         if (p.kind == GAUSS_WIN_LD) {
             // raw LD export: B11 sits unfactored in A[0] (diagonal 1 + lambda), B21 in its buffer
-            if (pl.out_b11)
+            if (pl.out_b11 && !exporting)
                 { int rc2 = fetch_matrix(pl.out_b11, p.A, p.M, p.M, p.Mld); if (rc2) return rc2; }
-            if (pl.out_b21 && p.U > 0)
+            if (pl.out_b21 && p.U > 0 && !exporting)
                 { int rc2 = fetch_matrix(pl.out_b21, p.B21, p.U, p.M, p.Mld); if (rc2) return rc2; }
             if (pl.out_status) *pl.out_status = 0;
             continue;
@@ -522,15 +598,17 @@ int job_fetch(gauss_job* job)
             if (pl.out_r) memcpy(pl.out_r, job->h_results + pl.res_off, sizeof(double) * p.n_rhs);
             if (pl.out_num_eig) *pl.out_num_eig = num_eig;
             if (pl.out_status) *pl.out_status = bits;
-            if (pl.out_b11)
+            if (pl.out_b11 && !exporting)
                 { int rc2 = fetch_matrix(pl.out_b11, pl.d_b11_copy, p.M, p.M, p.Mld); if (rc2) return rc2; }
-            if (pl.out_b21 && p.U > 0)
+            if (pl.out_b21 && p.U > 0 && !exporting)
                 { int rc2 = fetch_matrix(pl.out_b21, p.B21, p.U, p.M, p.Mld); if (rc2) return rc2; }
             continue;
         }
+        bool clamped = false;
         if (p.npanel > 0 && (job->h_status[4 * i + 0] || job->h_status[4 * i + 1])) {
             int rc = job_clamp_window(job, i, &bits);
             if (rc) return rc;
+            clamped = true;                    // B11's exported copy predates the clamp: fetched again below
         }
         if (p.npanel > 0) {
             if (bits & GAUSS_ST_NONFINITE) {
@@ -539,9 +617,9 @@ int job_fetch(gauss_job* job)
             }
             if (pl.out_z) memcpy(pl.out_z, job->h_results + pl.res_off, sizeof(double) * p.U);
             if (pl.out_info) memcpy(pl.out_info, job->h_results + pl.res_off + p.U, sizeof(double) * p.U);
-            if (pl.out_b11)
+            if (pl.out_b11 && (!exporting || clamped))
                 { int rc2 = fetch_matrix(pl.out_b11, pl.d_b11_copy, p.M, p.M, p.Mld); if (rc2) return rc2; }
-            if (pl.out_b21 && p.U > 0)
+            if (pl.out_b21 && p.U > 0 && !exporting)
                 { int rc2 = fetch_matrix(pl.out_b21, p.B21, p.U, p.M, p.Mld); if (rc2) return rc2; }
         }
         if (pl.out_status) *pl.out_status = bits;
@@ -585,6 +663,8 @@ void job_release(gauss_job* job)
             if (*e) { hipEventDestroy(*e); *e = nullptr; }
     for (hipEvent_t e : job->sevp) if (e) hipEventDestroy(e);
     job->sevp.clear();
+    for (hipEvent_t e : job->exp_ev) if (e) hipEventDestroy(e);
+    job->exp_ev.clear();
     job->begin = job->done = nullptr;
     job->done2[0] = job->done2[1] = nullptr;
     { std::lock_guard<std::mutex> lock(ctx->mu); ctx->jobs.erase(job); }

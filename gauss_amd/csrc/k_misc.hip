@@ -255,4 +255,38 @@ void launch_h2d_copy(void* d_dst, const void* pinned_src, size_t bytes, hipStrea
     hipLaunchKernelGGL(h2d_copy_kernel, dim3(n_wg), dim3(256), 0, s, (const h2d_u32x4*)pinned_src, (h2d_u32x4*)d_dst, n16);
 }
 
+// Matrix exports: export y of the launch, element e = r * width + c of its compact image <- src[r * pitch + c].  Consecutive
+// lanes write consecutive doubles of the pinned mirror (full 64-byte PCIe writes) and read all but contiguously; ~56 GB/s.
+__global__ __launch_bounds__(256) void export_rows_kernel(const ExportD* __restrict__ ex)
+{
+    __builtin_amdgcn_s_setprio(3);
+    const ExportD d = ex[blockIdx.y];
+    const long long n = (long long)d.rows * d.width;
+    const long long stride = (long long)gridDim.x * 256;
+    constexpr int UN = 4;
+    long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    for (; e + (UN - 1) * stride < n; e += UN * stride) {
+        double v[UN];
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+            const long long q = e + u * stride;
+            const int r = (int)(q / d.width), c = (int)(q - (long long)r * d.width);
+            v[u] = __builtin_nontemporal_load(d.src + (size_t)r * d.pitch + c);
+        }
+#pragma unroll
+        for (int u = 0; u < UN; u++) d.dst[e + u * stride] = v[u];
+    }
+    for (; e < n; e += stride) {
+        const int r = (int)(e / d.width), c = (int)(e - (long long)r * d.width);
+        d.dst[e] = __builtin_nontemporal_load(d.src + (size_t)r * d.pitch + c);
+    }
+}
+
+void launch_export_rows(const ExportD* d_exports, int n, long long max_elems, hipStream_t s)
+{
+    if (n <= 0 || max_elems <= 0) return;
+    const int gx = (int)std::max<long long>(1, std::min<long long>(std::max(1, 512 / n), (max_elems + 1023) / 1024));
+    hipLaunchKernelGGL(export_rows_kernel, dim3(gx, n), dim3(256), 0, s, d_exports);
+}
+
 }  // namespace gauss

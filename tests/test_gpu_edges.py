@@ -122,7 +122,7 @@ def test_clamped_window_inside_a_batch(ctx):
             lam = 0.0
         z1 = rng.standard_normal(gm.shape[0])
         wins.append(dict(mode=0, geno_m=np.ascontiguousarray(gm), geno_u=np.ascontiguousarray(gu), pop_off=off, z1=z1, lam=lam))
-        wants.append(oracle.run_impute(0, gm, gu, off, None, z1, lam=lam))
+        wants.append(oracle.run_impute(0, gm, gu, off, None, z1, lam=lam, want_mats=True))
     job = hotpath.Job(wins, ctx=ctx)
     job.run()
     res = job.fetch()
@@ -131,6 +131,19 @@ def test_clamped_window_inside_a_batch(ctx):
     for r, w in zip(res, wants):
         assert relerr(r["info"], w["info"]) <= 1e-5
         assert np.max(np.abs(r["z"] - w["z"]) / np.maximum(1.0, np.abs(w["z"]))) <= 1e-5
+    # the same batch with B11 / B21 wanted back: the matrices travel through the job's export mirror (gauss_run.cpp: queue_exports),
+    # the clamped window's B11 -- rewritten by MakePosDef's repair inside the fetch -- is fetched again after the repair; and with a
+    # second run of the job already queued the fetch of the first still returns the same matrices
+    job = hotpath.Job(wins, ctx=ctx, want_mats=True)
+    job.run()
+    job.run()
+    first = [dict(b11=r["b11"].copy(), b21=r["b21"].copy(), z=r["z"].copy()) for r in job.fetch()]
+    second = job.fetch()
+    job.close()
+    for a, b, r, w in zip(first, second, res, wants):
+        assert np.array_equal(a["b11"], b["b11"]) and np.array_equal(a["b21"], b["b21"]) and np.array_equal(a["z"], r["z"])
+        assert np.max(np.abs(a["b11"] - w["b11"])) <= (1e-9 if w["mpd"] else 1e-12)
+        assert np.max(np.abs(a["b21"] - w["b21"])) <= 1e-12
 
 
 def test_bad_arguments(ctx):
