@@ -50,7 +50,8 @@ class ChromStats(C.Structure):
     _fields_ = [("n_windows", C.c_int32), ("n_windows_mine", C.c_int32), ("n_skipped", C.c_int32), ("n_failed", C.c_int32),
                 ("n_batches", C.c_int32), ("n_merged_giveups", C.c_int32), ("imputed", C.c_int64), ("panel_bytes_uploaded", C.c_int64),
                 ("t_total", C.c_double), ("t_plan", C.c_double), ("t_panel_upload", C.c_double), ("t_feeder_wait", C.c_double),
-                ("t_job_create", C.c_double), ("t_gpu_wait", C.c_double), ("t_tables", C.c_double), ("gpu_span_ms", C.c_double)]
+                ("t_job_create", C.c_double), ("t_gpu_wait", C.c_double), ("t_tables", C.c_double), ("gpu_span_ms", C.c_double),
+                ("t_tables_tail", C.c_double)]
 
 
 class GaussError(RuntimeError):
@@ -434,12 +435,16 @@ def _columns(h, t):
         if ty == 0:
             w = C.c_int()
             buf = h.gauss_table_strcol_fixed(t, c, C.byref(w))
-            cols[name] = (np.frombuffer(C.string_at(buf, n * w.value), dtype=f"S{w.value}").copy() if (n and buf)
+            # (one copy: a view of the library's image, copied into the array the caller keeps)
+            cols[name] = (np.frombuffer((C.c_char * (n * w.value)).from_address(buf), dtype=f"S{w.value}").copy() if (n and buf)
                           else np.zeros(0, dtype="S1"))
         elif ty == 1:
-            cols[name] = np.ctypeslib.as_array(h.gauss_table_int(t, c), shape=(n,)).copy() if n else np.zeros(0, np.int32)
+            # (np.frombuffer over a ctypes view: a few microseconds a column; np.ctypeslib.as_array takes ~10)
+            cols[name] = (np.frombuffer((C.c_int32 * n).from_address(C.addressof(h.gauss_table_int(t, c).contents)), dtype=np.int32).copy()
+                          if n else np.zeros(0, np.int32))
         else:
-            cols[name] = np.ctypeslib.as_array(h.gauss_table_dbl(t, c), shape=(n,)).copy() if n else np.zeros(0)
+            cols[name] = (np.frombuffer((C.c_double * n).from_address(C.addressof(h.gauss_table_dbl(t, c).contents)), dtype=np.float64).copy()
+                          if n else np.zeros(0))
     return cols
 
 
@@ -527,19 +532,26 @@ def impute_chromosome(kind, chr, start_bp, end_bp, wing_size, input_file, refere
     (gauss_host_impute_chromosome): windows sharded over `world` ranks, this rank's windows pipelined through the
     GPU in batches against the resident packed panel.  reference_data_file: a packed panel, or the reference's BGZF
     text panel together with reference_index_file (packed on first use into the panel cache).  Returns a ChromResult."""
+    import time
+    t0 = time.perf_counter()
     h = load_host()
     names, w, n = (None, None, 0) if pop_wgt_df is None else _pop_wgt(pop_wgt_df)
     out, st = _vp(), ChromStats()
+    t1 = time.perf_counter()
     _hcheck(h.gauss_host_impute_chromosome(_ctx(ctx), int(kind), int(chr), int(start_bp), int(end_bp), int(wing_size),
                                            int(window_size), _enc(study_pop), names, None if w is None else w.ctypes.data_as(_dp), n,
                                            _enc(input_file), _enc(reference_index_file), _enc(reference_data_file),
                                            _enc(reference_pop_desc_file),
                                            _af(af1_cutoff), int(rank), int(world), int(n_batches), C.byref(out), C.byref(st)))
+    t2 = time.perf_counter()
     cols = _columns(h, out)
+    t3 = time.perf_counter()
     windows = _named(h, out)["windows"]
     msgs = [h.gauss_table_message(out, k).decode() for k in range(h.gauss_table_n_messages(out))]
     h.gauss_table_free(out)
     stats = {k: getattr(st, k) for k, _ in ChromStats._fields_}
+    # the wrapper's own time around the native call (ms): arguments in, columns out, the rest (named matrix, messages, free, stats)
+    stats["py_ms"] = dict(args=(t1 - t0) * 1e3, native=(t2 - t1) * 1e3, columns=(t3 - t2) * 1e3, rest=(time.perf_counter() - t3) * 1e3)
     return ChromResult(cols, windows, stats, msgs)
 
 

@@ -147,6 +147,9 @@ def compact(d):
         w8 = e.get("emulated_world8")
         if isinstance(w8, dict):
             blk["emulated_world8"] = pick(w8, ("world", "slowest", "one_rank_warm_ms", "predicted_efficiency", "result_identical_to_one_rank"))
+            ph = w8.get("phase_ms")
+            if isinstance(ph, dict):
+                blk["emulated_world8"]["phase_ms"] = {k: v for k, v in ph.items() if k != "why"}
             h = w8.get("host_ms_not_overlapped")
             if isinstance(h, list) and h:
                 blk["emulated_world8"]["host_ms_not_overlapped_max"] = max(h)

@@ -139,12 +139,15 @@ def emulate_world_e2e(rig, ch, files, wing, warm_one_s, world=8, calls=3):
                     res = api.impute_chromosome(**kw)
                     ts.append(time.perf_counter() - t0)
                 st = res.stats
+                py = st.get("py_ms", {})
                 k = int(np.argsort(ts)[len(ts) // 2])
                 per.append({"rank": r, "windows": int(st["n_windows_mine"]), "batches": int(st["n_batches"]), "imputed": int(st["imputed"]),
                             "warm_ms": ts[k] * 1e3, "warm_ms_all": [t * 1e3 for t in ts], "gpu_span_ms": float(st["gpu_span_ms"]),
                             "host_ms_not_overlapped": ts[-1] * 1e3 - float(st["gpu_span_ms"]),
                             "t_plan_ms": st["t_plan"] * 1e3, "t_feeder_wait_ms": st["t_feeder_wait"] * 1e3, "t_job_create_ms": st["t_job_create"] * 1e3,
-                            "t_gpu_wait_ms": st["t_gpu_wait"] * 1e3, "t_tables_ms": st["t_tables"] * 1e3})
+                            "t_gpu_wait_ms": st["t_gpu_wait"] * 1e3, "t_tables_ms": st["t_tables"] * 1e3,
+                            "t_tables_tail_ms": st.get("t_tables_tail", 0.0) * 1e3, "t_native_ms": st["t_total"] * 1e3,
+                            "py_wrapper_ms": ts[-1] * 1e3 - st["t_total"] * 1e3, "py_columns_ms": py.get("columns")})
         finally:
             if old is None:
                 os.environ.pop("LOCAL_WORLD_SIZE", None)
@@ -155,8 +158,17 @@ def emulate_world_e2e(rig, ch, files, wing, warm_one_s, world=8, calls=3):
         cores = len(os.sched_getaffinity(0))
     except Exception:
         cores = os.cpu_count() or 1
-    per = sweep(world)                   # the ranks share THIS box's cores (16 for the one-GPU lease: two host threads a rank)
-    ample = sweep(0)                     # a rank with eight host threads of its own (an 8-GPU node has >= 16 cores per GPU)
+    # (Python's cyclic collector off while these few-millisecond calls are timed, as for the jepegmix leg: the bench process holds
+    # millions of objects by now and a collection inside a 5 ms call is the harness's time, not the call's)
+    import gc
+    gc_was = gc.isenabled()
+    gc.disable()
+    try:
+        per = sweep(world)               # the ranks share THIS box's cores (16 for the one-GPU lease: two host threads a rank)
+        ample = sweep(0)                 # a rank with eight host threads of its own (an 8-GPU node has >= 16 cores per GPU)
+    finally:
+        if gc_was:
+            gc.enable()
 
     def genome(r, w, n_chrom, local_world):
         """gauss_host_impute_genome: n_chrom chromosomes (the chr22 files stand in for each), two calls in flight; ms per chromosome"""
@@ -182,7 +194,16 @@ def emulate_world_e2e(rig, ch, files, wing, warm_one_s, world=8, calls=3):
     g_slow = max(q[0] for q in g_per)
     slow = max(q["warm_ms"] for q in per)
     slow_a = max(q["warm_ms"] for q in ample)
-    return {"world": world, "calls_per_rank": calls, "per_rank_warm_ms": [q["warm_ms"] for q in per], "slowest": slow,
+    med = lambda k: float(np.median([q[k] for q in per if q.get(k) is not None]))
+    phases = {
+        # one rank's call, medians over the eight ranks (ms), in the order they happen; what the GPU does not overlap is 1 + 2 + 3 + 5 + 6
+        "1_plan": med("t_plan_ms"), "2_data_layer_wait": med("t_feeder_wait_ms"), "3_job_tables_and_queue": med("t_job_create_ms"),
+        "4_gpu_span": med("gpu_span_ms"), "5_tables_after_last_result": med("t_tables_tail_ms"), "6_python_wrapper": med("py_wrapper_ms"),
+        "why": "1: windows + owners, every rank derives the plan of all 36 windows; 2: the windows' merges (0 on a repeat call: window cache) "
+               "+ starting the host threads; 3: planner + work-item tables of the rank's ONE job (a rank's 4-5 windows: ~12 000 items) and "
+               "queuing ~45 launches -- the GPU starts at the first launch, so ~0.15 ms of it runs beside the GPU; 5: z / info / pval of the "
+               "unmeasured SNPs (pnorm on the host, two threads a rank on this box); 6: ctypes + ten numpy column copies"}
+    return {"world": world, "calls_per_rank": calls, "per_rank_warm_ms": [q["warm_ms"] for q in per], "slowest": slow, "phase_ms": phases,
             "one_rank_warm_ms": warm_one_s * 1e3, "predicted_efficiency": warm_one_s * 1e3 / (world * slow),
             "host_ms_not_overlapped": [q["host_ms_not_overlapped"] for q in per],
             "host_threads_per_rank": max(1, min(8, cores // world)), "usable_cores": cores,

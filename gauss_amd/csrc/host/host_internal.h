@@ -73,6 +73,8 @@ struct Column {
     std::vector<double> d;
 };
 
+void build_fixed_image(const Column& col);      // Column::fixed / fixed_w (host_tables.cpp)
+
 struct NamedMat {
     std::string name;
     int nrow = 0, ncol = 0;
@@ -419,7 +421,18 @@ struct LeanWindow {
     int32_t num_eig = 0, status = 0;
     std::unique_ptr<gauss_table> pre;   // the output table, built while the GPU works (lean_table_prebuild); the results are filled in after
     std::vector<int32_t> out_row;       // v -> row of the table, -1 outside the prediction window
+    // the chromosome driver builds no table per window: the window's rows are a slice [tab_off, tab_off + n_out) of the call's ONE table
+    size_t tab_off = 0;
+    int n_out = -1;                     // rows of the prediction window (lean_table_count)
 };
+// The slice form of lean_table_prebuild / lean_window_finish: the window's rows written straight into the columns of `all` (which must
+// hold the reference's column set, sized to cover the slice) -- everything the results do not change before the GPU is waited for,
+// the unmeasured SNPs' z / info / pval (QCAT: the four test columns) after.  Slices of different windows may be written concurrently.
+int lean_table_count(LeanWindow& w);
+void lean_table_prebuild_into(LeanWindow& w, gauss_table& all, size_t off);
+void lean_window_finish_into(LeanWindow& w, gauss_table& all);
+// A pristine copy of a built window (the inputs; nothing a call writes) -- what the window cache keeps and hands out
+std::unique_ptr<LeanWindow> lean_window_clone(const LeanWindow& w);
 
 int chrom_setup(ChromSetup& cs, int kind, int chr, int64_t wing_size, const char* study_pop, const char* const* pop_names,
                 const double* pop_wgts, int n_pop_wgt, const char* input_file, const std::string& packed_path, const char* desc_file,

@@ -363,20 +363,25 @@ int gauss_host_jepeg_gene_tail(int n, const double* corg, const double* z, const
 int gauss_table_n_messages(const gauss_table* t) { return t ? (int)t->messages.size() : 0; }
 const char* gauss_table_message(const gauss_table* t, int k) { return (t && k >= 0 && k < (int)t->messages.size()) ? t->messages[k].c_str() : nullptr; }
 
+}  // extern "C"
+void build_fixed_image(const Column& col)
+{
+    size_t w = 1;
+    for (const std::string& v : col.s) w = std::max(w, v.size());
+    if (col.fixed.size() == w * col.s.size() && col.fixed_w == (int)w && !col.s.empty()) return;       // made already (rows are not edited afterwards)
+    col.fixed.assign(w * col.s.size(), '\0');
+    for (size_t r = 0; r < col.s.size(); r++) memcpy(&col.fixed[r * w], col.s[r].data(), col.s[r].size());
+    col.fixed_w = (int)w;
+}
+extern "C" {
 // A whole string column as one fixed-width, NUL-padded byte matrix [nrow x *width] (numpy dtype "S<width>"):
 // 90 000 rows come across the boundary as one buffer instead of 90 000 Python strings.
 const char* gauss_table_strcol_fixed(const gauss_table* t, int c, int* width)
 {
     if (!t || c < 0 || c >= (int)t->cols.size() || t->cols[c].type != GAUSS_COL_STR) return nullptr;
     const Column& col = t->cols[c];
-    size_t w = 1;
-    for (const std::string& v : col.s) w = std::max(w, v.size());
-    if (col.fixed.size() != w * col.s.size() || col.fixed_w != (int)w) {
-        col.fixed.assign(w * col.s.size(), '\0');
-        for (size_t r = 0; r < col.s.size(); r++) memcpy(&col.fixed[r * w], col.s[r].data(), col.s[r].size());
-        col.fixed_w = (int)w;
-    }
-    if (width) *width = (int)w;
+    build_fixed_image(col);
+    if (width) *width = col.fixed_w;
     return col.fixed.data();
 }
 

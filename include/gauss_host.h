@@ -246,6 +246,7 @@ typedef struct gauss_chrom_stats {
     double t_gpu_wait;             /* main thread waiting for a batch's results                             */
     double t_tables;               /* building and concatenating the result tables                          */
     double gpu_span_ms;            /* device time from the first batch's start to the last batch's results  */
+    double t_tables_tail;          /* the part of t_tables behind the LAST batch's results (nothing overlaps it) */
 } gauss_chrom_stats;
 
 /* dist / distmix / qcat / qcatmix over every window [start_bp + k*window_size, ...] of [start_bp, end_bp] -- the

@@ -441,6 +441,52 @@ def test_gpu_native_chromosome_run_other_kinds_equal_per_window_calls(ctx, tmp_p
     api.panel_evict(ctx=ctx)
 
 
+@pytest.mark.gpu
+def test_gpu_native_chromosome_window_cache_returns_the_same_table(ctx, tmp_path, monkeypatch):
+    """The window cache (host_chrom.cpp: a built window is kept across calls, keyed by panel, study file and arguments): a repeat
+    call -- every window a cache hit, a COPY handed out -- returns the table of the first call bit for bit, and that table equals the
+    one built with the cache off; another kind, other weights or another wing on the same files miss (the key holds them) and equal
+    their own uncached results; a study file rewritten in place (same path, other content) is a different study."""
+    st = make_study(tmp_path)
+    p = st["paths"]
+    gpk = str(tmp_path / "panel.gpk")
+    api.pack_panel(p["index.gz"], p["data.gz"], p["desc.txt"], gpk)
+    base = dict(chr=22, start_bp=1_000_001, end_bp=4_000_000, input_file=p["gwas.txt"], reference_data_file=gpk,
+                reference_pop_desc_file=p["desc.txt"], window_size=500_000, ctx=ctx)
+
+    def same(a, b, owners=True):
+        assert list(a.columns) == list(b.columns)
+        for k in a.columns:
+            assert np.array_equal(a.columns[k], b.columns[k], equal_nan=(a.columns[k].dtype.kind == "f")), k
+        cols = [0, 1, 2, 3, 4, 5] if owners else [0, 1, 3, 4, 5]
+        assert np.array_equal(a.windows[:, cols], b.windows[:, cols])
+
+    variants = [dict(kind=api.KIND_DISTMIX, pop_wgt_df=WGT, wing_size=200_000),
+                dict(kind=api.KIND_DISTMIX, pop_wgt_df=(WGT[0], [0.2, 0.6, 0.261]), wing_size=200_000),
+                dict(kind=api.KIND_DISTMIX, pop_wgt_df=WGT, wing_size=100_000),
+                dict(kind=api.KIND_QCATMIX, pop_wgt_df=WGT, wing_size=200_000),
+                dict(kind=api.KIND_DIST, study_pop="EUR", wing_size=200_000)]
+    monkeypatch.setenv("GAUSS_WINDOW_CACHE", "0")
+    plain = [api.impute_chromosome(**base, **v) for v in variants]
+    monkeypatch.delenv("GAUSS_WINDOW_CACHE")
+    for v, want in zip(variants, plain):
+        first = api.impute_chromosome(**base, **v)              # builds and stores
+        again = api.impute_chromosome(**base, **v)              # every window a hit
+        same(first, want)
+        same(again, want)
+    # two ranks' shares come out of the same cache entries
+    halves = [api.impute_chromosome(**base, **variants[0], rank=r, world=2) for r in (0, 1)]
+    same(api.ChromResult.merge(halves), plain[0], owners=False)
+    # the same path with another study behind it
+    lines = open(p["gwas.txt"]).read().splitlines()
+    flipped = [lines[0]] + [" ".join(t[:5] + [repr(-float(t[5]))]) for t in (l.split() for l in lines[1:])]
+    open(p["gwas.txt"], "w").write("\n".join(flipped) + "\n")
+    neg = api.impute_chromosome(**base, **variants[0])
+    meas = plain[0].columns["type"] == 1
+    assert np.array_equal(neg.columns["z"][meas], -plain[0].columns["z"][meas])
+    api.panel_evict(ctx=ctx)
+
+
 def test_bench_pieces_are_put_together_per_window():
     """bench.py's shard check (pure Python): pieces (window, u0, u1) from several ranks must tile every window and
     reproduce the one-rank z / info bit for bit; a gap, an overlap or a changed bit is reported."""
