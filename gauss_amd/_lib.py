@@ -54,7 +54,7 @@ SYMBOLS = [
     "gauss_impute_window", "gauss_gene_ld_batch", "gauss_gram_counts", "gauss_job_create",
     "gauss_ld_rows", "gauss_gene_ld_batch_rows", "gauss_job_run", "gauss_job_fetch", "gauss_job_destroy", "gauss_job_span_ms", "gauss_job_profile",
     "gauss_job_profile_get", "gauss_job_work", "gauss_job_stats", "gauss_synth_device",
-    "gauss_store_upload_async", "gauss_store_upload_fd_async", "gauss_store_wait", "gauss_store_alloc", "gauss_store_fill", "gauss_store_fill_fd", "gauss_store_upload_fd", "gauss_hip_context_id", "gauss_hip_add_destroy_hook", "gauss_hip_trim_cache", "gauss_hip_source_hash", "gauss_hip_counters", "gauss_hip_queues",
+    "gauss_store_upload_async", "gauss_store_upload_fd_async", "gauss_store_wait", "gauss_store_alloc", "gauss_store_fill", "gauss_store_fill_fd", "gauss_store_upload_fd", "gauss_hip_context_id", "gauss_hip_add_destroy_hook", "gauss_hip_trim_cache", "gauss_hip_source_hash", "gauss_hip_counters", "gauss_job_counters", "gauss_hip_queues",
 ]
 
 
@@ -113,6 +113,7 @@ def load():
     lib.gauss_job_span_ms.argtypes = [C.c_void_p, C.c_void_p, _dp]
     lib.gauss_job_profile.argtypes = [C.c_void_p, C.c_int]
     lib.gauss_job_profile_get.argtypes = [C.c_void_p, C.c_int, _dp, C.POINTER(C.c_int64)]
+    lib.gauss_job_counters.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
     lib.gauss_job_work.argtypes = [C.c_void_p, _dp, _dp, _dp, C.POINTER(C.c_int64)]
     lib.gauss_job_stats.argtypes = [C.c_void_p, _dp]
     lib.gauss_hip_context_id.argtypes = [C.c_void_p]

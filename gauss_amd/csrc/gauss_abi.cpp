@@ -100,6 +100,13 @@ int gauss_job_work(gauss_job* job, double* out_ld_flops, double* out_solve_flops
     return GAUSS_OK;
 }
 
+int gauss_job_counters(gauss_job* job, int64_t* out4)
+{
+    if (!job || !out4) return fail(GAUSS_E_INVALID, "bad arguments to gauss_job_counters");
+    out4[0] = job->n_merged; out4[1] = job->n_demoted; out4[2] = job->n_giveups; out4[3] = job->n_rerun_failed;
+    return GAUSS_OK;
+}
+
 int gauss_job_stats(gauss_job* job, double* out4)
 {
     if (!job || !out4) return fail(GAUSS_E_INVALID, "bad arguments");

@@ -358,6 +358,7 @@ struct gauss_job {
     bool ran = false;
     bool ran_solve = true;                                 // what the last gauss_job_run asked for (the re-run after a give-up repeats it)
     unsigned prof_run = 0;                                 // run the stage timers being recorded belong to
+    long long n_merged = 0, n_demoted = 0, n_giveups = 0, n_rerun_failed = 0;      // this job's share of gauss_hip_counters (gauss_job_counters)
 };
 
 // What gauss_impute_window fixes BEFORE the window is planned, so that the copy worker can start at once: where the raw

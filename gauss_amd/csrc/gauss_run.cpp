@@ -99,7 +99,7 @@ static int job_queue_run(gauss_job* job, bool solve, int par, bool allow_merged)
     // would start sharing queues waits (exclusively) until no run is being queued and the spinning kernels have drained.
     std::shared_lock<std::shared_mutex> qlock(queue_registry_mutex());
     const bool merged = job->merged && allow_merged && solve && (job->force_merged || (ctx->queues_probed_distinct && queues_exclusive(ctx->device)));
-    if (job->merged && solve) (merged ? ctx->n_runs_merged : ctx->n_runs_demoted)++;
+    if (job->merged && solve) { (merged ? ctx->n_runs_merged : ctx->n_runs_demoted)++; (merged ? job->n_merged : job->n_demoted)++; }
     const auto t_run0 = std::chrono::steady_clock::now();
     HIPCHK(hipEventRecord(job->begin, st));
     HIPCHK(hipMemsetAsync(job->d_status, 0, sizeof(int) * (4 * job->n + 4), st));
@@ -547,12 +547,27 @@ int job_fetch(gauss_job* job)
         // results sit in the other parity's mirrors and stay valid).
         gauss_ctx* ctx = job->ctx;
         ctx->n_merged_giveups++;
+        job->n_giveups++;
         for (hipStream_t q : {ctx->stream, ctx->chain, ctx->side}) if (q) HIPCHK(hipStreamSynchronize(q));
+        // the stage timers of the run being replaced are void (its chain ran on nothing): dropped, so that the re-run's timers do not
+        // add to them; and the run number the timers are recorded under goes back to the newest queued run afterwards (a later run of
+        // the job may be in flight: its slots keep their number)
+        {
+            std::vector<ProfSlot> keep;
+            for (ProfSlot& ps : job->slots) {
+                if (ps.run == job->fetch_seq) { hipEventDestroy(ps.a); hipEventDestroy(ps.b); }
+                else keep.push_back(ps);
+            }
+            job->slots.swap(keep);
+        }
+        const unsigned prof_run_was = job->prof_run;
         job->prof_run = job->fetch_seq;
         int rc = job_queue_run(job, job->ran_solve, par, false);
+        job->prof_run = prof_run_was;
         if (!rc && hipEventSynchronize(job->done2[par]) != hipSuccess) rc = fail(GAUSS_E_DEVICE, "waiting for the re-run failed");
         if (rc || job->h_status[4 * job->n] != 0) {
             ctx->n_rerun_failed++;
+            job->n_rerun_failed++;
             job->fetch_seq++;
             const std::string why = rc ? g_err : std::string("its failure flag is set again");
             return fail(GAUSS_E_DEVICE, "the chain queue gave up waiting for B11's tile pairs of this run (merged Gram launch) and the re-run in the two-launch form failed: %s", why.c_str());

@@ -252,7 +252,14 @@ int gauss_store_wait(gauss_ctx* ctx, const void* device_ptr, int64_t bytes_neede
     {
         std::lock_guard<std::mutex> lock(ctx->mu);
         auto it = ctx->uploads.find(device_ptr);
-        if (it == ctx->uploads.end()) return GAUSS_OK;            // not an asynchronous store, or complete and retired
+        if (it == ctx->uploads.end()) {
+            // not an asynchronous store, or complete and retired -- but it must still BE a store of this context: a caller that
+            // kept the pointer of a store another call has freed since (two chromosome calls in flight on one resident panel whose
+            // background upload failed: the first to notice evicts it) is told so, instead of queuing a job over freed memory
+            if (!ctx->stores.count(device_ptr))
+                return fail(GAUSS_E_INVALID, "gauss_store_wait: not a row store of this context (freed by another call after a failed upload?)");
+            return GAUSS_OK;
+        }
         u = it->second;
     }
     const bool all = bytes_needed <= 0 || (size_t)bytes_needed >= u->bytes;

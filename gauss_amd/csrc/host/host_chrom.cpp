@@ -841,8 +841,6 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
     const bool chrom_trace = host_trace("chrom");
     gauss_chrom_stats st;
     memset(&st, 0, sizeof(st));
-    int64_t counters0[4] = {0, 0, 0, 0};
-    (void)gauss_hip_counters(ctx, counters0);
 
     // ---- plan: windows, costs, owners (identical on every rank) ----
     std::string err;
@@ -1240,6 +1238,11 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
                     fprintf(stderr, "[chrom] batch %zu on the GPU: starts %.2f ms after the first batch, runs %.2f ms\n", b, to_end - own, own);
             }
     }
+    // (the call's own jobs, not the context's counters: another call may be in flight on this context)
+    for (gauss_job* j : jobs) {
+        int64_t c4[4] = {0, 0, 0, 0};
+        if (j && gauss_job_counters(j, c4) == 0) st.n_merged_giveups += (int32_t)c4[2];
+    }
     for (gauss_job* j : jobs) if (j) gauss_job_destroy(j);
     // whoever finds this panel resident later (another study, an LD call on rows this chromosome never touched) must
     // find all of it: the upload is complete before the call returns
@@ -1296,10 +1299,6 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
     }
     st.t_tables += now_s() - tt;
     st.t_total = now_s() - t_begin;
-    {
-        int64_t c1[4] = {0, 0, 0, 0};
-        if (gauss_hip_counters(ctx, c1) == 0) st.n_merged_giveups = (int32_t)(c1[2] - counters0[2]);
-    }
     if (stats) *stats = st;
     *out = all.release();
     return 0;

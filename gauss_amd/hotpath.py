@@ -456,6 +456,12 @@ class Job:
         check(self.ctx.lib.gauss_job_fetch(self.handle))
         return [w.result() for w in self.wins]
 
+    def counters(self):
+        """gauss_job_counters: this job's own runs -- queued merged / demoted, give-ups repaired inside a fetch, re-runs that failed."""
+        out = (C.c_int64 * 4)()
+        check(self.ctx.lib.gauss_job_counters(self.handle, out))
+        return dict(merged=int(out[0]), demoted=int(out[1]), giveups=int(out[2]), rerun_failed=int(out[3]))
+
     def profile(self, enable=True):
         check(self.ctx.lib.gauss_job_profile(self.handle, 1 if enable else 0))
 

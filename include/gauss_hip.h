@@ -151,7 +151,8 @@ int gauss_store_fill_fd(gauss_ctx* ctx, void* device_ptr, int fd, int64_t file_o
  * gauss_store_wait(ctx, ptr, n) makes the context's main stream wait until the first n bytes have landed -- a job queued
  * afterwards that reads rows below that mark starts while the rest of the panel is still crossing PCIe -- and blocks the
  * host only until those bytes have been queued; n <= 0: the whole store, and the host waits for completion.  Stores
- * made by gauss_store_upload need no wait (it is a no-op on them). */
+ * made by gauss_store_upload need no wait (it is a no-op on them); a pointer that is not (or no longer) a row store of this
+ * context is an error (a store freed by another call is not waited for, nor read). */
 int gauss_store_upload_async(gauss_ctx* ctx, const void* host_rows, int64_t bytes, void** out_device_ptr);
 /* The rows are `bytes` bytes of an open file starting at file_offset (a packed panel's genotype section): read with
  * pread straight into the pinned staging buffers -- no page of the caller's address space is touched, so the upload
@@ -198,6 +199,9 @@ int gauss_hip_trim_cache(gauss_ctx* ctx, int64_t* out_bytes_freed);
  *   out4[3] of those, the ones whose second form failed too (gauss_job_fetch returned GAUSS_E_DEVICE).
  * One call of the reference is one window or an error (dist.cpp:30-126): a give-up is never handed to the caller as results. */
 int gauss_hip_counters(gauss_ctx* ctx, int64_t* out4);
+/* The same four counts for ONE job (its own runs only): what a caller with several jobs -- or several calls -- in flight on a
+ * context sums over ITS jobs (the context's counters are shared by everything that runs on it). */
+int gauss_job_counters(gauss_job* job, int64_t* out4);
 /* What the merged form's condition rests on, for diagnostics: out4[0] / out4[1] the library's live high- / low-priority streams on
  * the context's device (all contexts of the process), out4[2] the hardware queues the runtime makes per priority class
  * (GPU_MAX_HW_QUEUES, default 4; 0: unknown), out4[3] = 1 if gauss_hip_init SAW the context's chain and low-priority queues run a

@@ -1,6 +1,7 @@
-import os
 """GPU edge cases: tile / block / panel boundaries, tiny and ragged inputs, many populations, large
 genotype codes, error reporting, and size-independent properties at the BASELINE sizes."""
+import os
+
 import numpy as np
 import pytest
 

@@ -272,12 +272,20 @@ def test_merged_launch_that_gives_up_is_run_again_in_the_two_launch_form(ctx, mo
     monkeypatch.setenv("GAUSS_CHAIN_ASIDE", "2")              # the merged form on a job this small ...
     monkeypatch.setenv("GAUSS_CHAIN_MERGED", "2")             # ... whatever the session's environment or the queue registry says
     job = hotpath.Job(wins, ctx=ctx, on_device=True)
+    other = hotpath.Job(wins, ctx=ctx, on_device=True)        # a second job on the context: its own counters stay at zero
     c0 = ctx.counters()
     monkeypatch.setenv("GAUSS_WAIT_COUNT_TIMEOUT_US", "-2000")     # wait 2 ms for a count that never comes
+    job.profile(True)
     job.run()
     res = job.fetch()
     c1 = ctx.counters()
     assert c1["giveups"] == c0["giveups"] + 1 and c1["rerun_failed"] == c0["rerun_failed"], (c0, c1)
+    assert job.counters() == dict(merged=1, demoted=0, giveups=1, rerun_failed=0) and other.counters()["giveups"] == 0
+    # the stage timers describe the run that delivered (the two-launch re-run), not the sum of it and the void merged run
+    gram_ms, gram_launches = job.profile_get(0)
+    assert gram_launches == 2 and 0 < gram_ms < 50.0, (gram_ms, gram_launches)
+    job.profile(False)
+    other.close()
     _check_against_oracle(p, wins, res)
     job.run()
     job.run()                                                # two failing runs in flight
