@@ -280,7 +280,8 @@ def test_merged_launch_that_gives_up_is_run_again_in_the_two_launch_form(ctx, mo
     res = job.fetch()
     c1 = ctx.counters()
     assert c1["giveups"] == c0["giveups"] + 1 and c1["rerun_failed"] == c0["rerun_failed"], (c0, c1)
-    assert job.counters() == dict(merged=1, demoted=0, giveups=1, rerun_failed=0) and other.counters()["giveups"] == 0
+    assert job.counters() == dict(merged=1, demoted=1, giveups=1, rerun_failed=0)      # (the re-run is a run in the two-launch form)
+    assert other.counters() == dict(merged=0, demoted=0, giveups=0, rerun_failed=0)
     # the stage timers describe the run that delivered (the two-launch re-run), not the sum of it and the void merged run
     gram_ms, gram_launches = job.profile_get(0)
     assert gram_launches == 2 and 0 < gram_ms < 50.0, (gram_ms, gram_launches)
