@@ -39,6 +39,7 @@ if ROOT not in sys.path:
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 FP64_MFMA_PEAK_TFLOPS = 78.6    # v_mfma_f64_16x16x4_f64: 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz
+I8_MFMA_PEAK_TOPS = 5033.6      # v_mfma_i32_32x32x32_i8: 2 x the BF16 rate per clock (MI355X_MICROARCH.md, matrix cores) = 32 x the fp32 matrix peak
 HBM_PEAK_GBS = 8000.0
 METRIC = "imputed SNPs/sec (whole node) at 1/2/4/8 GPUs; LD-GEMM MFMA TFLOP/s vs peak"
 STAGES = ["gram", "pack_stats", "ld_epilogue", "factor", "solve"]
@@ -654,6 +655,21 @@ def run_impute(args, rig, quiet=False, light=False):
             out["cpu_baseline"] = cpu_baseline(ch, wins, keep0, work, 0 if args.mode == "dist" else 1, light=light)
         if e2e is not None and "_other_configs" in e2e:
             out["other_configs"] = e2e.pop("_other_configs")
+        if i8_variant is not None and isinstance(out.get("other_configs"), dict):
+            # the exact int8 Gram path as a mode of its own (gauss_hip_set_gram_dtype / GAUSS_GRAM_DTYPE=i8): the same job, the same
+            # bits, the LD GEMM on v_mfma_i32_32x32x32_i8; never the headline (`dtype` stays f32: the north star names the fp32 matrix cores)
+            out["other_configs"]["int8_exact"] = {
+                "metric": "imputed SNPs/s, the headline job with the LD GEMM on the int8 matrix cores (exact: identical bits)",
+                "value": i8_variant["imputed_snps_per_s_this_rank"], "unit": "imputed SNPs/s", "ms_per_step": i8_variant["ms_per_step"],
+                "steps": args.steps, "gram_ms": i8_variant["gram_ms"], "kernel": i8_variant["kernel"],
+                "bit_identical_to_f32_path": i8_variant["bit_identical_to_f32_path"],
+                "roofline": {"kernel": i8_variant["kernel"], "bound": "mfma", "achieved": i8_variant["gram_tops_algorithmic"],
+                             "peak": I8_MFMA_PEAK_TOPS, "unit": "TOP/s", "frac": i8_variant["gram_tops_algorithmic"] / I8_MFMA_PEAK_TOPS, "traffic": None,
+                             "note": "algorithmic LD ops (same count as the f32 flops) / Gram kernel time; the kernel is bound by operand "
+                                     "delivery (1 KB of LDS fragment reads per MFMA with 64 x 64 wave tiles), not by the int8 pipe"},
+                "parity_spot": {"ok": bool(i8_variant["bit_identical_to_f32_path"]),
+                                "what": "z / info of every window bit-identical to the f32 job's, whose parity_spot against the oracle is the headline's"}}
+            out["other_configs"]["all_parity_ok"] = bool(out["other_configs"].get("all_parity_ok", True) and i8_variant["bit_identical_to_f32_path"])
         if not quiet:
             emit_line(out, headline=True)
     runner.close()

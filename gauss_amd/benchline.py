@@ -49,14 +49,16 @@ def _roofline(r, extra=()):
     if not isinstance(r, dict):
         return None
     out = pick(r, ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "traffic_form") + tuple(extra))
+    if "traffic_form" in out:
+        out["traffic_form"] = clip(out["traffic_form"], 64)
     if "kernel" in r:
-        out["kernel"] = clip(r["kernel"], 60)
+        out["kernel"] = clip(r["kernel"], 48)
     if "traffic" not in out:
         out["traffic"] = None
     return out
 
 
-def _cpu(c, n_sample=200):
+def _cpu(c, n_sample=160):
     if not isinstance(c, dict):
         return None
     out = pick(c, ("value", "unit", "cores", "kind", "host_cores"))
@@ -82,7 +84,8 @@ def _other(name, c):
     r = c.get("roofline") or {}
     out["roofline"] = pick(r, ("bound", "achieved", "peak", "unit", "frac"))
     cb = c.get("cpu_baseline") or {}
-    out["cpu_baseline"] = pick(cb, ("value", "unit", "cores", "kind"))
+    if cb:
+        out["cpu_baseline"] = pick(cb, ("value", "unit", "cores", "kind"))
     ps = c.get("parity_spot") or {}
     out["parity_ok"] = bool(ps.get("ok", False))
     if name == "computeLD":
@@ -105,7 +108,7 @@ def _other(name, c):
             if isinstance(wc, dict):
                 out["emulated_world8"]["whole_calls"] = pick(wc, ("calls", "slowest_ms", "one_rank_ms", "predicted_efficiency"))
     if name == "int8_exact":
-        out.update(pick(c, ("bit_identical_to_f32_path", "gram_ms", "kernel")))
+        out.update(pick(c, ("bit_identical_to_f32_path", "gram_ms")))
     return out
 
 
@@ -117,11 +120,8 @@ def compact(d):
     cfg = d.get("config") or {}
     out["config"] = pick(cfg, ("windows", "snps", "samples", "imputed_snps_per_step", "windows_per_rank", "shard", "cut_windows", "load_imbalance",
                                "windows_flagged", "all_finite", "shards_bit_identical_to_one_rank"))
-    out["config"]["workload"] = clip(cfg.get("workload", ""), 300)
-    out["roofline"] = _roofline(d.get("roofline"), ("algorithmic_flops_per_launch", "avg_launch_ms", "launches", "launches_per_step", "frac_alone",
-                                                   "measured_on"))
-    if out["roofline"] and "measured_on" in out["roofline"]:
-        out["roofline"]["measured_on"] = clip(out["roofline"]["measured_on"], 80)
+    out["config"]["workload"] = clip(cfg.get("workload", ""), 200)
+    out["roofline"] = _roofline(d.get("roofline"), ("algorithmic_flops_per_launch", "avg_launch_ms", "launches", "launches_per_step", "frac_alone"))
     for k, extra in (("roofline_pack", ("algorithmic_bytes_per_launch", "launch_ms", "moved_gbs")),
                      ("roofline_epilogue", ("algorithmic_bytes_per_launch", "launch_ms", "moved_gbs")),
                      ("roofline_solve", ("algorithmic_flops_per_step", "ms_per_step"))):
