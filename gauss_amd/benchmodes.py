@@ -648,7 +648,7 @@ def jepegmix_measure(rig, ch, files, tmp, steps, checks=None, spot_genes=24):
 
 
 def jepeg_emulate_world(rig, kw, tab_one, warm_one_s, steps, world=8, n_calls=22):
-    """configs[4] names 8 GPUs.  Two splits exist (DESIGN.md section 6): (a) the GENES of one call over the ranks
+    """configs[4] names 8 GPUs.  Two splits exist (DESIGN.md section 8): (a) the GENES of one call over the ranks
     (gauss_host_jepeg_rank: every rank repeats the host data layer, which is most of the call, and computes CorG + tails of its
     contiguous gene range) and (b) WHOLE calls dealt to the ranks (gauss_host_jepeg_genome: one call per chromosome file set).  Both
     emulated on the one GPU, every rank's share timed alone, warm, collector off, median of `steps` calls: predicted efficiency =

@@ -31,7 +31,7 @@ static std::vector<std::pair<void (*)(gauss_ctx*, uint64_t, void*), void*>> g_de
 static std::atomic<uint64_t> g_next_ctx_id{1};
 
 // ------------------------------------------------------------------------------------------
-// Streams and hardware queues ("Streams and hardware queues"; profiles/r05_queue_map.txt is the runtime's own
+// Streams and hardware queues (DESIGN.md section 5 "the queue rule"; docs/HISTORY.md section 4 "Streams and hardware queues"; profiles/r05_queue_map.txt is the runtime's own
 // log of the mapping on MI355X, ROCm 7.2): a stream created with a priority takes a hardware queue of its own while its
 // priority class holds fewer than GPU_MAX_HW_QUEUES (default 4); from then on "Selected queue refCount": the least used
 // queue of the class is shared, and kernels of the streams that share it run in submission order.  One context makes three

@@ -179,7 +179,7 @@ struct gauss_ctx {
     std::atomic<long long> n_runs_merged{0}, n_runs_demoted{0}, n_merged_giveups{0}, n_rerun_failed{0};
 };
 
-// ---- streams and hardware queues (gauss_ctx.cpp; DESIGN.md section 4 "Streams and hardware queues") ----------------------
+// ---- streams and hardware queues (gauss_ctx.cpp; DESIGN.md section 5 "the queue rule"; docs/HISTORY.md section 4) ----------------------
 // The HIP runtime multiplexes streams onto a pool of hardware (HSA) queues PER PRIORITY CLASS: a new stream gets a queue of
 // its own until the class holds GPU_MAX_HW_QUEUES of them (default 4), after that the least used queue of the class is handed
 // out again.  Kernels of streams that share a hardware queue run in submission order -- so a kernel that SPINS for the

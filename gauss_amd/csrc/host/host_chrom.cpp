@@ -196,7 +196,7 @@ double gauss_host_plan_cost(int n_measured, int n_unmeasured) { return issued_co
 // prepare() restates the reference literally: every SNP of the extended window becomes an object with five strings in a std::map
 // keyed by (chr, bp, a1, a2) (ReadInputZ, ReadReferenceIndex, MakeSnpVec: gauss.cpp:121-190, 293-399, 543-693) -- 0.65-1.0 ms
 // for a window of 3 000 SNPs, paid again by every window of a chromosome, and with one rank of eight holding four windows it is
-// what the GPU waits for.  A window of a SORTED packed panel needs none of it.  The study's rows
+// what the GPU waits for (docs/HISTORY.md section 9e item 10).  A window of a SORTED packed panel needs none of it.  The study's rows
 // (cached, ordered by position) and the panel's SNP table (ordered by position) ascend together; a position is settled where
 // the two walks meet:
 //
@@ -213,7 +213,7 @@ double gauss_host_plan_cost(int n_measured, int n_unmeasured) { return issued_co
 // the panel's alleles.  So a SNP is a panel row number, z, info, af and a type -- 48 bytes, no allocation -- and the tables
 // read the strings out of the panel's pool when they are built.  Type-0 SNPs of the wings are not entered (the partition reads
 // type 0 inside the prediction window only, dist.cpp:132-140 / qcat.cpp:140-152, and the tables are cut to it).
-// What a window costs now: DESIGN.md section 9e item 11.  tests/test_feeder.py holds it against prepare() on random
+// What a window costs now: docs/HISTORY.md section 9e item 11.  tests/test_feeder.py holds it against prepare() on random
 // studies with multi-allelic, duplicated, swapped and study-only sites, for all four kinds.
 // ------------------------------------------------------------------------------------------
 // 0, or -1 with the message prepare() would have given every window (the caller then lets prepare() give it)
@@ -606,7 +606,7 @@ static void plan_owners(std::vector<ChromWin>& wins, const PackedPanel& pk_, int
         // Python planner also prices B11's factorisation and the per-SNP tail, so the two plans may pick different
         // owners; each is used consistently by every rank of its own driver).  A rank's load is the cost of its windows
         // plus the factorisation chain of its tallest one (the chain is latency bound on the few windows a rank
-        // holds: DESIGN.md section 6; farm.CHAIN_STEP_COST, here per sample).
+        // holds: DESIGN.md section 8; farm.CHAIN_STEP_COST, here per sample).
         std::vector<int> order(wins.size());
         for (size_t i = 0; i < order.size(); i++) order[i] = (int)i;
         std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return wins[a].cost > wins[b].cost; });
@@ -890,7 +890,7 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
     if (n_batches < 1 && tl_calls_in_flight > 1 && mine.size() <= 8) n_batches = 1;
     // (A LEAD batch of one window -- so that the GPU starts after ONE window's data layer instead of a 0.3-share batch's -- was
     // measured in round 5 and is not built: the GPU started 0.8 ms earlier and the chromosome's span grew by 0.9 ms, a job of one
-    // window has nothing to hide its factorisation chain under; 8-rank shares 7.4-8.4 ms against 7.8-8.2.  DESIGN.md 9e item 10.)
+    // window has nothing to hide its factorisation chain under; 8-rank shares 7.4-8.4 ms against 7.8-8.2.  docs/HISTORY.md section 9e item 10.)
     const size_t lead = 0;
     const size_t n_rest = mine.size() - lead;
     // How many batches: a batch boundary costs ~0.35 ms of GPU span (the chip drains and fills), a batch in front of the GPU one

@@ -135,7 +135,7 @@ struct MapKey {
 // A window's SNP map lives in blocks of its own instead of the C library's heap.  A 100 000-SNP chromosome enters ~126 000 Snp
 // objects and as many map nodes (~480 B a SNP, ~60 MB over the 36 windows); on the FIRST call of a process every page of that is
 // touched for the first time -- ~14 000 minor faults, 40 ms of kernel time next to 50 ms of user time for the whole data layer,
-// spread over the worker threads' fresh malloc arenas (measured).  Blocks are 2 MB, 2 MB-aligned,
+// spread over the worker threads' fresh malloc arenas (measured, docs/HISTORY.md section 9e item 9).  Blocks are 2 MB, 2 MB-aligned,
 // advised as huge pages and populated in one call (one fault or one batched population instead of 512 traps); a window frees
 // nothing one by one -- its blocks go back to a process-wide list when the window is closed, so later calls touch no new page.
 struct BlockPool {

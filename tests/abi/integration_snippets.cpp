@@ -250,3 +250,41 @@ std::vector<long long> distmix_genome_body(const std::vector<int>& chr, const st
   if (rc != 0) (void)gauss_host_last_error();
   return imputed;
 }
+
+// ---- section 5g: jepeg() / jepegmix() on several GPUs (gene ranges of one call; whole calls dealt to ranks) ----
+int jepegmix_rank_body(const std::vector<std::string>& names, const std::vector<double>& wgts, const std::string& input_file,
+                       const std::string& annotation_file, const std::string& index_file, const std::string& data_file,
+                       const std::string& desc, int rank, int world) {
+  std::vector<const char*> np;
+  for (auto& s : names) np.push_back(s.c_str());
+  gauss_table* t = nullptr;
+  if (gauss_host_jepeg_rank(gauss_hip_ctx(), GAUSS_KIND_JEPEGMIX, NULL, np.data(), wgts.data(), (int)np.size(), input_file.c_str(),
+                            annotation_file.c_str(), index_file.c_str(), data_file.c_str(), desc.c_str(), NAN, rank, world, &t) != 0)
+    Rcpp::stop(gauss_host_last_error());
+  int nr = 0, nc = 0;
+  const double* range = nullptr;
+  for (int k = 0; k < gauss_table_n_named(t); k++)
+    if (std::string(gauss_table_named_name(t, k)) == "gene_range") range = gauss_table_named(t, k, &nr, &nc);     // [first, one past last, genes in all]
+  const int genes_mine = range ? (int)(range[1] - range[0]) : 0;
+  gauss_table_free(t);
+  return genes_mine;
+}
+
+int jepegmix_genome_body(const std::vector<std::string>& names, const std::vector<double>& wgts, const std::vector<std::string>& inputs,
+                         const std::vector<std::string>& annots, const std::vector<std::string>& panels, const std::string& desc,
+                         int rank, int world) {
+  std::vector<const char*> np, in, an, pa;
+  for (auto& s : names) np.push_back(s.c_str());
+  for (auto& s : inputs) in.push_back(s.c_str());
+  for (auto& s : annots) an.push_back(s.c_str());
+  for (auto& s : panels) pa.push_back(s.c_str());
+  const int n = (int)in.size();
+  std::vector<gauss_table*> out((size_t)n, nullptr);
+  std::vector<int32_t> owner((size_t)n, -1);
+  const int rc = gauss_host_jepeg_genome(gauss_hip_ctx(), GAUSS_KIND_JEPEGMIX, n, NULL, np.data(), wgts.data(), (int)np.size(), in.data(), an.data(),
+                                         /*index files: packed panels need none*/NULL, pa.data(), desc.c_str(), NAN, rank, world, out.data(), owner.data());
+  int mine = 0;
+  for (int c = 0; c < n; c++) { if (out[(size_t)c]) mine++; gauss_table_free(out[(size_t)c]); }
+  if (rc != 0) (void)gauss_host_last_error();                     // the first failing call's message; the other calls are complete
+  return mine;
+}

@@ -187,7 +187,7 @@ def test_asynchronous_row_store_upload(ctx, tmp_path):
 
 @pytest.mark.gpu
 def test_streamed_window_call_strided_rows_and_error_paths(ctx, monkeypatch):
-    """The blocking call on host bytes is streamed (copy worker + landing buffer): same bits as
+    """The blocking call on host bytes is streamed (copy worker + landing buffer; docs/HISTORY.md section 9f): same bits as
     upload-then-run, also for matrices whose row stride is far from the row length (pitched chunk copies), for a 2-bit
     host store, and a call that fails after its copies have started leaves the context usable."""
     import ctypes as C

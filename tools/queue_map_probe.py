@@ -1,4 +1,4 @@
-"""Which hardware queue does each stream of a context get?  ("Streams and hardware queues")
+"""Which hardware queue does each stream of a context get?  (DESIGN.md section 5 "the queue rule"; docs/HISTORY.md section 4 "Streams and hardware queues")
 
 Runs a child with AMD_LOG_LEVEL=4 that creates contexts one after the other and keeps the runtime's own lines about
 its queue pool: "acquireQueue refCount: <hsa queue> (<users>)", "Selected queue refCount: ..." (an existing queue is
