@@ -424,27 +424,47 @@ def jepeg_genome(kind, calls, reference_pop_desc_file, study_pop=None, pop_wgt_d
     return tabs, [int(o) for o in owner]
 
 
-def _columns(h, t):
+class _TableOwner:
+    """Keeps a gauss_table alive for the numpy views handed out over its columns; frees it when the last view is gone."""
+
+    def __init__(self, h, t):
+        self.h, self.t = h, t
+
+    def __del__(self):
+        try:
+            if self.t:
+                self.h.gauss_table_free(self.t)
+                self.t = None
+        except Exception:
+            pass
+
+
+def _columns(h, t, owner=None):
     """gauss_table -> {name: numpy array}; string columns come across as ONE fixed-width bytes array each
-    (dtype "S<w>"), not as Python strings: a chromosome's table has ~10^5 rows."""
+    (dtype "S<w>"), not as Python strings: a chromosome's table has ~10^5 rows.
+    owner = None: the arrays are copies (the caller frees the table).  owner = a _TableOwner of `t`: the arrays are VIEWS of the
+    library's columns -- no copy; every array keeps the owner, and with it the table, alive."""
     cols = {}
     n = h.gauss_table_nrow(t)
+
+    def view(ctype, addr, count, dtype):
+        buf = (ctype * count).from_address(addr)
+        if owner is None:
+            return np.frombuffer(buf, dtype=dtype).copy()
+        buf._gauss_owner = owner                     # numpy array -> .base (this ctypes view) -> the table's owner
+        return np.frombuffer(buf, dtype=dtype)
+
     for c in range(h.gauss_table_ncol(t)):
         name = h.gauss_table_colname(t, c).decode()
         ty = h.gauss_table_coltype(t, c)
         if ty == 0:
             w = C.c_int()
             buf = h.gauss_table_strcol_fixed(t, c, C.byref(w))
-            # (one copy: a view of the library's image, copied into the array the caller keeps)
-            cols[name] = (np.frombuffer((C.c_char * (n * w.value)).from_address(buf), dtype=f"S{w.value}").copy() if (n and buf)
-                          else np.zeros(0, dtype="S1"))
+            cols[name] = view(C.c_char, buf, n * w.value, f"S{w.value}") if (n and buf) else np.zeros(0, dtype="S1")
         elif ty == 1:
-            # (np.frombuffer over a ctypes view: a few microseconds a column; np.ctypeslib.as_array takes ~10)
-            cols[name] = (np.frombuffer((C.c_int32 * n).from_address(C.addressof(h.gauss_table_int(t, c).contents)), dtype=np.int32).copy()
-                          if n else np.zeros(0, np.int32))
+            cols[name] = view(C.c_int32, C.addressof(h.gauss_table_int(t, c).contents), n, np.int32) if n else np.zeros(0, np.int32)
         else:
-            cols[name] = (np.frombuffer((C.c_double * n).from_address(C.addressof(h.gauss_table_dbl(t, c).contents)), dtype=np.float64).copy()
-                          if n else np.zeros(0))
+            cols[name] = view(C.c_double, C.addressof(h.gauss_table_dbl(t, c).contents), n, np.float64) if n else np.zeros(0)
     return cols
 
 
@@ -544,15 +564,17 @@ def impute_chromosome(kind, chr, start_bp, end_bp, wing_size, input_file, refere
                                            _enc(reference_pop_desc_file),
                                            _af(af1_cutoff), int(rank), int(world), int(n_batches), C.byref(out), C.byref(st)))
     t2 = time.perf_counter()
-    cols = _columns(h, out)
+    owner = _TableOwner(h, out)                                  # frees the table when the last reference to it is gone
+    cols = _columns(h, out, owner=owner)                         # views: the table lives as long as any of its columns
     t3 = time.perf_counter()
     windows = _named(h, out)["windows"]
     msgs = [h.gauss_table_message(out, k).decode() for k in range(h.gauss_table_n_messages(out))]
-    h.gauss_table_free(out)
     stats = {k: getattr(st, k) for k, _ in ChromStats._fields_}
     # the wrapper's own time around the native call (ms): arguments in, columns out, the rest (named matrix, messages, free, stats)
     stats["py_ms"] = dict(args=(t1 - t0) * 1e3, native=(t2 - t1) * 1e3, columns=(t3 - t2) * 1e3, rest=(time.perf_counter() - t3) * 1e3)
-    return ChromResult(cols, windows, stats, msgs)
+    res = ChromResult(cols, windows, stats, msgs)
+    res._owner = owner                                           # (a table without rows has no view to keep it)
+    return res
 
 
 def chrom_window_view(kind, chr, start_bp, end_bp, wing_size, input_file, packed_file, reference_pop_desc_file, study_pop=None,

@@ -358,7 +358,8 @@ int lean_window_desc(LeanWindow& w, gauss_window_desc* d)
 {
     const ChromSetup& cs = *w.cs;
     const Args& a = cs.a;
-    const int M = (int)w.measured.size(), U = (int)w.unmeasured.size();
+    const LeanWindow& src = lean_src(w);
+    const int M = (int)src.measured.size(), U = (int)src.unmeasured.size();
     if (cs.qcat) {
         if (cs.kind == GAUSS_KIND_QCAT && M <= a.min_num_measured_snp)
             return herr("Not enough number of SNPs loaded - QCAT not performed (measured %d, unmeasured %d)", M, U);
@@ -374,17 +375,17 @@ int lean_window_desc(LeanWindow& w, gauss_window_desc* d)
     d->n_measured = M; d->n_unmeasured = U;
     d->geno_format = GAUSS_GENO_2BIT;
     d->ld = a.pk->row_bytes();
-    d->rows_m = w.store_rows_m.data(); d->rows_u = w.store_rows_u.data();
+    d->rows_m = src.store_rows_m.data(); d->rows_u = src.store_rows_u.data();
     d->pop_src_off = cs.pop_src_off.data();
-    d->z1 = w.z1.data(); d->lambda = a.lambda; d->min_abs_eig = a.min_abs_eig;
+    d->z1 = src.z1.data(); d->lambda = a.lambda; d->min_abs_eig = a.min_abs_eig;
     d->out_status = &w.status;
     if (cs.qcat) {
-        w.out_r.assign((size_t)w.n_predm + U, 0.0);
+        w.out_r.assign((size_t)src.n_predm + U, 0.0);
         w.num_eig = M;
         d->kind = GAUSS_WIN_QCAT;
-        d->n_head_measured = w.n_head; d->n_pred_measured = w.n_predm; d->eig_cutoff = a.eig_cutoff;
+        d->n_head_measured = src.n_head; d->n_pred_measured = src.n_predm; d->eig_cutoff = a.eig_cutoff;
         d->out_r = w.out_r.data(); d->out_num_eig = &w.num_eig;
-        if (w.n_predm + U < 1) return herr("QCAT window has no SNP to test");
+        if (src.n_predm + U < 1) return herr("QCAT window has no SNP to test");
         return 0;
     }
     w.out_z.assign(U, 0.0); w.out_info.assign(U, 0.0);
@@ -453,6 +454,7 @@ std::unique_ptr<LeanWindow> lean_window_clone(const LeanWindow& w)
 int lean_table_count(LeanWindow& w)
 {
     if (w.n_out >= 0) return w.n_out;
+    if (w.base && w.base->n_out >= 0) { w.n_out = w.base->n_out; return w.n_out; }        // (counted once, when the window was cached)
     size_t n_out = 0;
     w.out_row.assign(w.v.size(), -1);
     for (size_t r = 0; r < w.v.size(); r++) {
@@ -472,11 +474,12 @@ void lean_table_prebuild_into(LeanWindow& w, gauss_table& all, size_t off)
     const PackedPanel& pk = *cs.a.pk;
     lean_table_count(w);
     w.tab_off = off;
+    const LeanWindow& src = lean_src(w);
     std::vector<Column>& c = all.cols;
-    for (size_t r = 0; r < w.v.size(); r++) {
-        if (w.out_row[r] < 0) continue;
-        const size_t o = off + (size_t)w.out_row[r];
-        const LeanSnp& sn = w.v[r];
+    for (size_t r = 0; r < src.v.size(); r++) {
+        if (src.out_row[r] < 0) continue;
+        const size_t o = off + (size_t)src.out_row[r];
+        const LeanSnp& sn = src.v[r];
         const PkSnp& ps = pk.snp(sn.row);
         c[LC_RSID].s[o] = pk.str(ps.rsid); c[LC_CHR].i[o] = ps.chr; c[LC_BP].i[o] = (int)sn.bp;
         c[LC_A1].s[o] = pk.str(ps.a1); c[LC_A2].s[o] = pk.str(ps.a2);
@@ -496,27 +499,25 @@ void lean_table_prebuild_into(LeanWindow& w, gauss_table& all, size_t off)
 void lean_window_finish_into(LeanWindow& w, gauss_table& all)
 {
     const ChromSetup& cs = *w.cs;
+    const LeanWindow& src = lean_src(w);
     std::vector<Column>& c = all.cols;
     const size_t off = w.tab_off;
     if (cs.qcat) {
         const int m = w.num_eig;
         for (size_t k = 0; k < w.out_r.size(); k++) {                            // qcat.cpp:216-243
-            const size_t vi = (size_t)((k < (size_t)w.n_predm) ? w.measured[(size_t)w.n_head + k] : w.unmeasured[k - (size_t)w.n_predm]);
-            LeanSnp& sn = w.v[vi];
+            const size_t vi = (size_t)((k < (size_t)src.n_predm) ? src.measured[(size_t)src.n_head + k] : src.unmeasured[k - (size_t)src.n_predm]);
             const double r = w.out_r[k];
-            sn.qcat_m = m;
-            sn.qcat_t = std::sqrt((double)(m - 3)) * r;
-            sn.qcat_chisq = (m - 3) * r * r;
-            const int32_t row = w.out_row[vi];
+            const double qt = std::sqrt((double)(m - 3)) * r, qc = (m - 3) * r * r;
+            const int32_t row = src.out_row[vi];
             if (row < 0) continue;
             const size_t o = off + (size_t)row;
-            c[7].i[o] = sn.qcat_m; c[8].d[o] = sn.qcat_t; c[9].d[o] = sn.qcat_chisq;
-            c[10].d[o] = pchisq_upper(sn.qcat_chisq, 1);                          // qcat.cpp:107
+            c[7].i[o] = m; c[8].d[o] = qt; c[9].d[o] = qc;
+            c[10].d[o] = pchisq_upper(qc, 1);                                     // qcat.cpp:107
         }
         return;
     }
-    for (size_t i = 0; i < w.unmeasured.size() && i < w.out_z.size(); i++) {      // dist.cpp:200-202
-        const int32_t row = w.out_row[(size_t)w.unmeasured[i]];
+    for (size_t i = 0; i < src.unmeasured.size() && i < w.out_z.size(); i++) {    // dist.cpp:200-202
+        const int32_t row = src.out_row[(size_t)src.unmeasured[i]];
         if (row < 0) continue;
         const size_t o = off + (size_t)row;
         const double zz = w.out_z[i];
@@ -765,10 +766,11 @@ int gauss_host_chrom_window_view(int kind, int chr, int64_t start_bp, int64_t en
 // opened panel (open_packed_shared) it is kept across calls, keyed by their identity: a session that imputes a study again (another
 // kind on the same windows, the same call after a failure further on, a benchmark's warm calls) finds its windows built.  What
 // a hit saves is the merge, 0.12-0.15 ms a window -- with one rank of eight holding four or five windows and two host threads, 0.35 ms
-// that the GPU waited for.  A hit hands out a COPY (the call writes results into its window); at most 128 windows are kept
+// that the GPU waited for.  A hit hands out a window that READS the cached lists (nothing is copied; the call's results and its slice
+// of the table are its own) and is settled on the calling thread, no host thread is started for it; at most 128 windows are kept
 // (~0.3 MB each), the cache is dropped whole when full.  GAUSS_WINDOW_CACHE=0: every window is built by the call that needs it.
 // ------------------------------------------------------------------------------------------
-struct LeanCacheEntry { std::shared_ptr<PackedPanel> pk; std::shared_ptr<const GwasCache> gw; std::unique_ptr<LeanWindow> w; };
+struct LeanCacheEntry { std::shared_ptr<PackedPanel> pk; std::shared_ptr<const GwasCache> gw; std::shared_ptr<const LeanWindow> w; };
 static std::mutex g_lw_mu;
 static std::map<std::string, std::shared_ptr<LeanCacheEntry>> g_lw_cache;
 
@@ -790,19 +792,27 @@ static std::string lean_cache_base(const ChromSetup& cs, const PackedPanel* pk)
     }
     return k;
 }
+// A hit: a window that owns nothing but the call's own state and reads the lists through `base` (host_internal.h: lean_src)
 static std::unique_ptr<LeanWindow> lean_cache_get(const std::string& base, long long s, long long e)
 {
     const std::string k = base + "|" + std::to_string(s) + "-" + std::to_string(e);
     std::shared_ptr<LeanCacheEntry> hit;
     { std::lock_guard<std::mutex> lock(g_lw_mu); auto it = g_lw_cache.find(k); if (it != g_lw_cache.end()) hit = it->second; }
-    return hit ? lean_window_clone(*hit->w) : nullptr;
+    if (!hit) return nullptr;
+    std::unique_ptr<LeanWindow> w(new LeanWindow());
+    w->base = hit->w;
+    w->start_bp = hit->w->start_bp; w->end_bp = hit->w->end_bp;
+    w->n_head = hit->w->n_head; w->n_predm = hit->w->n_predm;
+    return w;
 }
 static void lean_cache_put(const std::string& base, const LeanWindow& w, const std::shared_ptr<PackedPanel>& pk, const std::shared_ptr<const GwasCache>& gw)
 {
     std::shared_ptr<LeanCacheEntry> e = std::make_shared<LeanCacheEntry>();
     e->pk = pk; e->gw = gw;                       // the key holds their addresses: they stay alive (and unique) while the entry does
-    e->w = lean_window_clone(w);
-    e->w->cs = nullptr;
+    std::unique_ptr<LeanWindow> c = lean_window_clone(w);
+    c->cs = nullptr;
+    lean_table_count(*c);                         // which of its SNPs the table lists: once, here
+    e->w = std::shared_ptr<const LeanWindow>(c.release());
     const std::string k = base + "|" + std::to_string(w.start_bp) + "-" + std::to_string(w.end_bp);
     std::lock_guard<std::mutex> lock(g_lw_mu);
     if (g_lw_cache.size() >= 128) g_lw_cache.clear();
@@ -968,46 +978,54 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
     std::vector<int> left((size_t)n_batches);                     // windows of batch b still in the data layer (under mu)
     for (int b = 0; b < n_batches; b++) left[b] = (int)batches[b].size();
     auto batch_ready = [&](int b) { return left[b] == 0; };
-    std::thread feeder([&]() {
-        parallel_for((int)order.size(), nthreads, [&](int q) {
-            const int b = order[q].first, k = order[q].second;
-            ChromWin& w = wins[batches[b][k]];
-            Slot& sl = slots[b][k];
-            gauss_prepared* p = nullptr;
-            if (lean) {
-                std::unique_ptr<LeanWindow> lw = use_window_cache ? lean_cache_get(cache_base, w.s, w.e) : nullptr;
-                bool built = true;
-                if (lw) lw->cs = &cs;
-                else {
-                    lw.reset(new LeanWindow());
-                    built = lean_window_build(*lw, cs, w.s, w.e) == 0;
-                    if (built && use_window_cache) lean_cache_put(cache_base, *lw, pk, gw);
-                }
-                if (!built) { w.status = 2; w.why = gauss_host_last_error(); }
-                else {
-                    w.M = (int)lw->measured.size(); w.U = (int)lw->unmeasured.size();
-                    if (lean_window_desc(*lw, &sl.d)) { w.status = 1; w.why = gauss_host_last_error(); }      // the ">10" guards (dist.cpp:145-151)
-                    else { sl.lw = std::move(lw); sl.ok = true; }
-                }
-            } else if (gauss_host_prepare(kind, chr, w.s, w.e, wing_size, study_pop, pop_names, pop_wgts, n_pop_wgt, input_file, nullptr,
-                                   "(packed)", reference_data_file, reference_pop_desc_file, af1_cutoff, &p)) {
-                w.status = 2; w.why = gauss_host_last_error();
-            } else {
-                sl.p.reset(p);
-                w.M = (int)p->measured.size(); w.U = (int)p->unmeasured.size();
-                if (gauss_prepared_window_desc(p, &sl.d)) {       // the ">10" guards (dist.cpp:145-151)
-                    w.status = 1; w.why = gauss_host_last_error();
-                    sl.p.reset();
-                } else {
-                    sl.ok = true;                                 // geno_m / geno_u: the resident panel, set when the batch is queued
-                }
+    // one window through the data layer.  hit_only: take it from the window cache or leave it (returns false) -- the calling thread
+    // settles the hits before any host thread exists
+    auto process = [&](int q, bool hit_only) -> bool {
+        const int b = order[q].first, k = order[q].second;
+        ChromWin& w = wins[batches[b][k]];
+        Slot& sl = slots[b][k];
+        gauss_prepared* p = nullptr;
+        if (lean) {
+            std::unique_ptr<LeanWindow> lw = use_window_cache ? lean_cache_get(cache_base, w.s, w.e) : nullptr;
+            if (!lw && hit_only) return false;
+            bool built = true;
+            if (lw) lw->cs = &cs;
+            else {
+                lw.reset(new LeanWindow());
+                built = lean_window_build(*lw, cs, w.s, w.e) == 0;
+                if (built && use_window_cache) lean_cache_put(cache_base, *lw, pk, gw);
             }
-            bool last;
-            { std::lock_guard<std::mutex> lock(mu); last = (--left[b] == 0); }
-            if (last) cv.notify_all();
-            if (last && chrom_trace) fprintf(stderr, "[chrom] data layer of batch %d done at %.2f ms\n", b, (now_s() - t_begin) * 1e3);
-        });
-    });
+            if (!built) { w.status = 2; w.why = gauss_host_last_error(); }
+            else {
+                w.M = (int)lean_src(*lw).measured.size(); w.U = (int)lean_src(*lw).unmeasured.size();
+                if (lean_window_desc(*lw, &sl.d)) { w.status = 1; w.why = gauss_host_last_error(); }      // the ">10" guards (dist.cpp:145-151)
+                else { sl.lw = std::move(lw); sl.ok = true; }
+            }
+        } else if (hit_only) return false;
+        else if (gauss_host_prepare(kind, chr, w.s, w.e, wing_size, study_pop, pop_names, pop_wgts, n_pop_wgt, input_file, nullptr,
+                                    "(packed)", reference_data_file, reference_pop_desc_file, af1_cutoff, &p)) {
+            w.status = 2; w.why = gauss_host_last_error();
+        } else {
+            sl.p.reset(p);
+            w.M = (int)p->measured.size(); w.U = (int)p->unmeasured.size();
+            if (gauss_prepared_window_desc(p, &sl.d)) {       // the ">10" guards (dist.cpp:145-151)
+                w.status = 1; w.why = gauss_host_last_error();
+                sl.p.reset();
+            } else {
+                sl.ok = true;                                 // geno_m / geno_u: the resident panel, set when the batch is queued
+            }
+        }
+        bool last;
+        { std::lock_guard<std::mutex> lock(mu); last = (--left[b] == 0); }
+        if (last) cv.notify_all();
+        if (last && chrom_trace) fprintf(stderr, "[chrom] data layer of batch %d done at %.2f ms\n", b, (now_s() - t_begin) * 1e3);
+        return true;
+    };
+    std::vector<int> todo;                                      // the windows no cache entry settled
+    for (int q = 0; q < (int)order.size(); q++)
+        if (!(use_window_cache && process(q, true))) todo.push_back(q);
+    std::thread feeder;
+    if (!todo.empty()) feeder = std::thread([&]() { parallel_for((int)todo.size(), nthreads, [&](int i) { process(todo[(size_t)i], false); }); });
 
     // ---- the panel's rows in HBM ----
     // First use of this panel on this context: the upload was only STARTED above (gauss_store_upload_fd_async: staged through two
@@ -1197,8 +1215,8 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
                 int64_t top = -1;
                 for (int k : live[b]) {
                     const Slot& sq = slots[b][(size_t)k];
-                    for (int32_t r : sq.lw ? sq.lw->store_rows_m : sq.p->store_rows_m) top = std::max<int64_t>(top, r);
-                    for (int32_t r : sq.lw ? sq.lw->store_rows_u : sq.p->store_rows_u) top = std::max<int64_t>(top, r);
+                    for (int32_t r : sq.lw ? lean_src(*sq.lw).store_rows_m : sq.p->store_rows_m) top = std::max<int64_t>(top, r);
+                    for (int32_t r : sq.lw ? lean_src(*sq.lw).store_rows_u : sq.p->store_rows_u) top = std::max<int64_t>(top, r);
                 }
                 const double tu = now_s();
                 if (gauss_store_wait(ctx, d_rows, (top + 1) * panel_row_bytes) != 0) { herr("%s", gauss_last_error()); rc_fatal = -1; upload_failed = true; break; }
@@ -1226,7 +1244,7 @@ int gauss_host_impute_chromosome(gauss_ctx* ctx, int kind, int chr, int64_t star
         if (b > 0) retire(b - 1);
     }
     if (!rc_fatal && n_batches > 0) retire(n_batches - 1);
-    feeder.join();
+    if (feeder.joinable()) feeder.join();
     {
         gauss_job *jf = nullptr, *jl = nullptr;
         for (gauss_job* j : jobs) if (j) { if (!jf) jf = j; jl = j; }

@@ -424,7 +424,12 @@ struct LeanWindow {
     // the chromosome driver builds no table per window: the window's rows are a slice [tab_off, tab_off + n_out) of the call's ONE table
     size_t tab_off = 0;
     int n_out = -1;                     // rows of the prediction window (lean_table_count)
+    // A window handed out by the window cache owns none of the lists above: `base` is the cached (immutable) window they are read
+    // from -- lean_src() -- and this object holds the call's own state only (outputs, status, its slice of the table).  The chromosome
+    // driver's functions (lean_window_desc, lean_table_count, lean_table_prebuild_into, lean_window_finish_into) read through lean_src.
+    std::shared_ptr<const LeanWindow> base;
 };
+static inline const LeanWindow& lean_src(const LeanWindow& w) { return w.base ? *w.base : w; }
 // The slice form of lean_table_prebuild / lean_window_finish: the window's rows written straight into the columns of `all` (which must
 // hold the reference's column set, sized to cover the slice) -- everything the results do not change before the GPU is waited for,
 // the unmeasured SNPs' z / info / pval (QCAT: the four test columns) after.  Slices of different windows may be written concurrently.
