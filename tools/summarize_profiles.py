@@ -75,15 +75,21 @@ def gram_forms(grids):
 
 
 def pmc_all(dirname):
-    """kernel -> counter -> (sum over dispatches, dispatches)"""
+    """kernel -> counter -> (sum over dispatches, dispatches).  The f32 Gram kernel is ALSO listed per grid size, as
+    `gauss::gram_kernel<float>@<grid threads>`: the profiled command launches it on the full grid, on the two halves of the
+    two-launch form (the form the headline runs are demoted to under counter collection) and on the emulated shares, and per-launch
+    counts averaged over those describe none of them (ratios such as mfma_util are fine either way)."""
     f = find(dirname, "*counter_collection.csv")
     acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
     if f:
         with open(f) as fh:
             for row in csv.DictReader(fh):
-                a = acc[short(row["Kernel_Name"])][row["Counter_Name"]]
-                a[0] += float(row["Counter_Value"])
-                a[1] += 1
+                k = short(row["Kernel_Name"])
+                keys = [k] + ([f"{k}@{int(row.get('Grid_Size') or 0)}"] if k.startswith("gauss::gram_kernel<float>") else [])
+                for kk in keys:
+                    a = acc[kk][row["Counter_Name"]]
+                    a[0] += float(row["Counter_Value"])
+                    a[1] += 1
     return acc
 
 
@@ -105,7 +111,8 @@ def sq_mfma(tag, d, out):
              "SQ_VALU_MFMA_COEXEC_CYCLES"]
     with open(os.path.join(out, f"{tag}_sq_mfma.csv"), "w") as fh:
         fh.write("kernel,launches,parked_frac,issue_stall_frac,issuing_frac,mfma_util," +
-                 ",".join(c + "_per_launch" for c in cols + cols2) + "\n")
+                 ",".join(c + "_per_launch" for c in cols + cols2) + ",launch_form\n")
+        forms = gram_forms({int(k.split("@")[1]) for k in a if "@" in k})
         for k in sorted(a):
             if "gauss" not in k:
                 continue
@@ -118,6 +125,7 @@ def sq_mfma(tag, d, out):
             row += ["%.0f" % (v[c][0] / n) for c in cols]
             vb = b.get(k, {})
             row += ["%.0f" % (vb[c][0] / max(1, vb[c][1])) if c in vb else "" for c in cols2]
+            row.append('"%s"' % (forms.get(int(k.split("@")[1]), "") if "@" in k else ("all launches of the kernel in the profiled command" if k.startswith("gauss::gram_kernel") else "")))
             fh.write(",".join(row) + "\n")
 
 
