@@ -114,7 +114,7 @@ def e2e_measure(rig, ch, files, steps, wing, n_batches=0):
     return cold_s, cold, warm, res
 
 
-def emulate_world_e2e(rig, ch, files, wing, warm_one_s, world=8, calls=3):
+def emulate_world_e2e(rig, ch, files, wing, warm_one_s, world=8, calls=5):
     """The files -> table path as rank r of `world` would run it (gauss_host_impute_chromosome(rank, world): the same plan on every
     rank, this rank's windows through its own data layer, jobs and tables), every rank timed alone on the ONE GPU, warm (the panel
     resident), `calls` calls per rank, median.  predicted_efficiency = one-rank warm time / (world x the slowest rank's);
@@ -135,6 +135,7 @@ def emulate_world_e2e(rig, ch, files, wing, warm_one_s, world=8, calls=3):
                           reference_pop_desc_file=files["desc"], rank=r, world=world, n_batches=0, ctx=rig.ctx, **sa)
                 ts, res = [], None
                 for _ in range(calls):
+                    res = None                       # the previous call's table is dropped BEFORE the clock starts (freeing it is not this call's work)
                     t0 = time.perf_counter()
                     res = api.impute_chromosome(**kw)
                     ts.append(time.perf_counter() - t0)

@@ -25,9 +25,11 @@ def main():
     t1 = float(np.median(one[2:]))
     os.environ["LOCAL_WORLD_SIZE"] = "8"
     slow = 0
+    res = None
     for r in range(8):
         ts = []
         for _ in range(calls):
+            res = None
             t0 = time.perf_counter(); res = api.impute_chromosome(rank=r, world=8, **base); ts.append((time.perf_counter() - t0) * 1e3)
         st = res.stats
         med = float(np.median(ts)); slow = max(slow, med)
