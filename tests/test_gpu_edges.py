@@ -765,3 +765,33 @@ def test_sixty_four_populations_and_one_too_many(ctx):
     from gauss_amd import _lib
     with pytest.raises(_lib.GaussHipError, match="n_pop must be in 1..64"):
         hotpath.impute_window(0, G65[:120], G65[120:240], off65, None, z1, ctx=ctx)
+
+
+def test_matrix_exports_through_the_mirror_and_past_its_budget(ctx):
+    """A job's B11 / B21 leave through a pinned export mirror (gauss_run.cpp: queue_exports) while they fit 256 MB of it, and matrix
+    by matrix (one pitched copy each, compacted on the host) when they do not.  Five LD-export windows of 1 900 + 1 900 SNPs want
+    36 M doubles back (289 MB: past the budget); the same windows one job each go through the mirror; both forms return the same
+    bits, and the first window's matrices equal the oracle's pair loops on a corner."""
+    rng = np.random.default_rng(77)
+    off = np.array([0, 150, 330], dtype=np.int32)
+    w = np.array([0.6, 0.5])
+    wins = []
+    for k in range(5):
+        G = rand_geno(rng, 3800, 330, 0.1, 0.9)
+        wins.append(dict(mode=1, geno_m=np.ascontiguousarray(G[:1900]), geno_u=np.ascontiguousarray(G[1900:]), pop_off=off, pop_wgt=w,
+                         z1=np.zeros(1900), lam=0.0, ld_codings=1))
+    job = hotpath.Job(wins, ctx=ctx)
+    job.run()
+    big = [dict(b11=r["b11"].copy(), b21=r["b21"].copy()) for r in job.fetch()]
+    job.close()
+    for k, win in enumerate(wins):
+        one = hotpath.Job([win], ctx=ctx)
+        one.run()
+        r = one.fetch()[0]
+        one.close()
+        assert np.array_equal(r["b11"], big[k]["b11"]) and np.array_equal(r["b21"], big[k]["b21"]), k
+    gm, gu = wins[0]["geno_m"], wins[0]["geno_u"]
+    want = oracle.compute_ld(np.ascontiguousarray(np.vstack([gm[:40], gu[:40]])), off, w)
+    assert np.max(np.abs(big[0]["b11"][:40, :40] - want[:40, :40])) <= 1e-12
+    assert np.max(np.abs(big[0]["b21"][:40, :40] - want[40:, :40])) <= 1e-12
+    assert np.all(np.diag(big[0]["b11"]) == 1.0) and np.array_equal(big[0]["b11"], big[0]["b11"].T)
