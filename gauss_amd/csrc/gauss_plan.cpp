@@ -559,6 +559,7 @@ int job_build(gauss_ctx* ctx, const std::vector<WinSpec>& specs, int on_device, 
         auto halves = [](int r, int w) { const int n = (r - w * 64 + 31) / 32; return n < 0 ? 0 : (n > 2 ? 2 : n); };
         for (ItemH& h : items) {
             h.ord = h.len;
+            if (job->gram_i8) continue;          // (the int8 kernel is bound by operand delivery: it keeps items of one K range together -- 5.40 against 5.53 ms)
             const Plan& pl = plan_of(h.prob);
             const int ra = live_rows(pl, pl.pair_ti[h.pair]), rb = live_rows(pl, pl.pair_tj[h.pair]);
             int mx = 0;
