@@ -806,8 +806,9 @@ static gauss_table* jepeg_table(const gauss_prepared& p, int g0, int g1, const d
     Column geneid{"geneid", GAUSS_COL_STR, {}, {}, {}}, chisq{"chisq", GAUSS_COL_DBL, {}, {}, {}}, df{"df", GAUSS_COL_INT, {}, {}, {}};
     Column jp{"jepeg_pval", GAUSS_COL_DBL, {}, {}, {}}, ns{"num_snp", GAUSS_COL_INT, {}, {}, {}}, tc{"top_categ", GAUSS_COL_STR, {}, {}, {}};
     Column tcp{"top_categ_pval", GAUSS_COL_DBL, {}, {}, {}}, ts{"top_snp", GAUSS_COL_STR, {}, {}, {}}, tsp{"top_snp_pval", GAUSS_COL_DBL, {}, {}, {}};
-    // (the k x k tails on host threads were measured: 1.1 ms serial, 0.45 ms on eight threads, and the call no shorter -- thread
-    // start-up and its jitter cost what the tails gain at 350 genes)
+    // (the k x k tails on host threads were measured twice: round 5, eight threads: 1.1 -> 0.45 ms and the call no shorter; round 6,
+    // at most four threads, 16 genes a task, rows written in place: tails 1.12 -> 0.47 ms and the NEXT call's data layer 1.12 ->
+    // 1.35-1.5 ms -- the threads started per call move the calling thread off its warm core -- call 3.48 -> 3.35-3.5 ms: not kept)
     size_t o = 0;
     for (int g = g0; g < g1; g++) {
         std::vector<Snp*> gs(p.measured.begin() + p.gene_off[(size_t)g], p.measured.begin() + p.gene_off[(size_t)g + 1]);
