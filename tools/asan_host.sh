@@ -14,6 +14,6 @@ sys.path.insert(0, "$(pwd)")
 import gauss_amd.api as api
 api.HOST_LIB_PATH = "$(pwd)/gauss_amd/lib/asan/libgauss_host.so"
 import pytest
-sys.exit(pytest.main(["-x", "-q", "-m", "not gpu", "tests/test_feeder.py", "tests/test_farm.py", "-p", "no:cacheprovider"]))
+sys.exit(pytest.main(["-x", "-q", "-m", "not gpu", "tests/test_feeder.py", "tests/test_farm.py", "tests/test_farm_jepeg.py", "-p", "no:cacheprovider"]))
 PY
 LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0 UBSAN_OPTIONS=print_stacktrace=1 python gpurun_out/asan_run.py
