@@ -114,7 +114,7 @@ def e2e_measure(rig, ch, files, steps, wing, n_batches=0):
     return cold_s, cold, warm, res
 
 
-def emulate_world_e2e(rig, ch, files, wing, warm_one_s, world=8, calls=5):
+def emulate_world_e2e(rig, ch, files, wing, warm_one_s, world=8, calls=7):
     """The files -> table path as rank r of `world` would run it (gauss_host_impute_chromosome(rank, world): the same plan on every
     rank, this rank's windows through its own data layer, jobs and tables), every rank timed alone on the ONE GPU, warm (the panel
     resident), `calls` calls per rank, median.  predicted_efficiency = one-rank warm time / (world x the slowest rank's);
