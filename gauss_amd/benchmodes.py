@@ -134,6 +134,8 @@ def emulate_world_e2e(rig, ch, files, wing, warm_one_s, world=8, calls=7):
                 kw = dict(chr=22, start_bp=lo, end_bp=hi, wing_size=wing, input_file=files["gwas"], reference_data_file=files["panel"],
                           reference_pop_desc_file=files["desc"], rank=r, world=world, n_batches=0, ctx=rig.ctx, **sa)
                 ts, res = [], None
+                for _ in range(2):                   # this rank's windows into the window cache, its job shapes into the block caches: warm, as defined
+                    res = api.impute_chromosome(**kw)
                 for _ in range(calls):
                     res = None                       # the previous call's table is dropped BEFORE the clock starts (freeing it is not this call's work)
                     t0 = time.perf_counter()
