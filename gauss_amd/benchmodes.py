@@ -4,7 +4,6 @@ Everything here is harness code: it builds synthetic inputs in the reference's o
 panel), calls the product through its public entry points and times it; the CPU checker under oracle/ is never touched here.
 """
 import ctypes as C
-import json
 import os
 import shutil
 import tempfile

@@ -1,10 +1,8 @@
 """Where a batched LD-export step spends its time: run() / fetch() split, and the export chunks' waits and copies (GAUSS_TRACE=job)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import argparse
-import numpy as np
 import bench
-from gauss_amd import benchmodes, hotpath
+from gauss_amd import benchmodes
 
 args = bench.parse_args(["--mode", "computeLD", "--steps", "5"])
 rig = bench.Rig(args)
