@@ -681,10 +681,12 @@ def rank_of(rig):
 
 
 def emit_line(out, headline):
-    """The detail goes to bench_detail.json beside this file and, tagged {"detail": ...}, to stderr; stdout gets the ONE final line,
-    which gauss_amd/benchline.py keeps under 6 KB (round 5's 28 KB line was more than the driver's reader took)."""
+    """The detail goes to bench_detail.json beside this file and into gpurun_out/ (the directory that travels back from a GPU
+    box); stderr gets one short line saying so and stdout the ONE final line, which gauss_amd/benchline.py keeps under 6 KB
+    (round 5's 28 KB line was more than the driver's reader took; stdout + stderr together now stay under 7 KB)."""
     from gauss_amd import benchline
-    return benchline.emit(out, headline=headline, detail_path=os.path.join(ROOT, "bench_detail.json"))
+    return benchline.emit(out, headline=headline, detail_path=os.path.join(ROOT, "bench_detail.json"),
+                          also_dirs=(os.path.join(ROOT, "gpurun_out"),))
 
 
 def shard_mode(args, world):

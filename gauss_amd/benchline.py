@@ -2,7 +2,7 @@
 
 bench.py measures far more than the line's contract asks for (per-rank tables of the emulated 8-rank runs, the phase
 statistics of the files -> table calls, the definitions of every figure).  All of that is the DETAIL: it is written to
-`bench_detail.json` beside bench.py and printed as one `{"detail": ...}` line on stderr.  The final stdout line holds the
+`bench_detail.json` beside bench.py (and into `gpurun_out/`, which is what travels back from a GPU box); stderr only says where.  The final stdout line holds the
 contract's keys and the headline numbers of every block only, and `final_line` refuses to return more than LIMIT bytes
 (round 5's 28 KB line could not be parsed by the driver; tests/test_benchline.py builds the line from a committed sample
 of the detail and checks its size and keys).
@@ -207,19 +207,42 @@ def final_line(detail, headline=True):
     return s
 
 
-def emit(detail, headline=True, detail_path=None, stdout=None, stderr=None):
-    """Write the detail (file + one tagged stderr line), then the final line on stdout.  Returns the final line's dict."""
+def emit(detail, headline=True, detail_path=None, stdout=None, stderr=None, also_dirs=()):
+    """Write the detail to detail_path (and a copy into every directory of also_dirs that exists or can be made), say so in ONE short
+    stderr line, then print the final line on stdout.  Returns the final line's dict.
+
+    The detail itself is NOT printed: a reader that keeps the last few KB of stdout followed by stderr (the driver's record does:
+    `stdout ... ---- stderr ---- ...`) would find a 30 KB stderr line where the final line should be.  GAUSS_BENCH_DETAIL_STDERR=1
+    prints it on stderr, tagged {"detail": ...}, for a terminal user who wants it inline."""
+    import os
     import sys
     stdout = stdout or sys.stdout
     stderr = stderr or sys.stderr
+    written = []
     if detail_path:
-        try:
-            with open(detail_path, "w") as fh:
-                json.dump(detail, fh)
-            detail = dict(detail, detail_file=detail_path.rsplit("/", 1)[-1])
-        except OSError:
-            pass
-    print(json.dumps({"detail": detail}), file=stderr, flush=True)
+        name = detail_path.rsplit("/", 1)[-1]
+        detail = dict(detail, detail_file=name)
+        blob = json.dumps(detail)
+        paths = [detail_path]
+        for d in also_dirs:
+            try:
+                os.makedirs(d, exist_ok=True)
+                paths.append(os.path.join(d, name))
+            except OSError:
+                pass
+        for p in paths:
+            try:
+                with open(p, "w") as fh:
+                    fh.write(blob)
+                written.append(p)
+            except OSError:
+                pass
+        if not written:
+            detail = {k: v for k, v in detail.items() if k != "detail_file"}
+    if os.environ.get("GAUSS_BENCH_DETAIL_STDERR") == "1":
+        print(json.dumps({"detail": detail}), file=stderr, flush=True)
+    elif written:
+        print("bench.py: detail in %s" % ", ".join(written), file=stderr, flush=True)
     s = final_line(detail, headline)
     print(s, file=stdout, flush=True)
     return json.loads(s)

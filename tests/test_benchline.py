@@ -42,17 +42,29 @@ def test_final_line_is_small_and_complete(detail):
     assert line["other_configs"]["computeLD"]["one_resident_window"]["gram_tflops"] > 0
 
 
-def test_emit_prints_one_stdout_line_and_the_detail_elsewhere(detail, tmp_path):
+def test_emit_prints_one_stdout_line_and_the_detail_elsewhere(detail, tmp_path, monkeypatch):
+    """stdout: the ONE line; stderr: one short pointer (the driver's record is the tail of stdout FOLLOWED by stderr, so a bulky
+    stderr would push the line out of it); the detail: the file, and a copy in every also_dir."""
+    monkeypatch.delenv("GAUSS_BENCH_DETAIL_STDERR", raising=False)
     out, err = io.StringIO(), io.StringIO()
     path = str(tmp_path / "bench_detail.json")
-    line = benchline.emit(detail, headline=True, detail_path=path, stdout=out, stderr=err)
+    side = str(tmp_path / "gpurun_out")
+    line = benchline.emit(detail, headline=True, detail_path=path, stdout=out, stderr=err, also_dirs=(side,))
     lines = [l for l in out.getvalue().split("\n") if l]
     assert len(lines) == 1 and json.loads(lines[0]) == line and len(lines[0]) < benchline.LIMIT
+    assert len(err.getvalue()) < 400 and "bench_detail.json" in err.getvalue()
+    assert len(out.getvalue()) + len(err.getvalue()) < 7000
+    for p in (path, os.path.join(side, "bench_detail.json")):
+        with open(p) as fh:
+            assert json.load(fh)["value"] == detail["value"]
+    assert line["detail"] == "bench_detail.json"
+    # on request the detail is printed inline, on stderr, tagged
+    monkeypatch.setenv("GAUSS_BENCH_DETAIL_STDERR", "1")
+    out, err = io.StringIO(), io.StringIO()
+    benchline.emit(detail, headline=True, detail_path=path, stdout=out, stderr=err)
     tagged = json.loads(err.getvalue())
     assert list(tagged) == ["detail"] and tagged["detail"]["value"] == detail["value"]
-    with open(path) as fh:
-        assert json.load(fh)["value"] == detail["value"]
-    assert line["detail"] == "bench_detail.json"
+    assert len([l for l in out.getvalue().split("\n") if l]) == 1
 
 
 def test_a_block_that_outgrows_the_line_is_refused(detail):
