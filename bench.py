@@ -125,10 +125,18 @@ class Rig:
         self.red_dev = "cpu" if (self.rehearsal or self.world == 1) else "cuda"
         self.ctx = hotpath.Context(self.local)
 
+    def _dist_barrier(self):
+        # RCCL: name the device (otherwise every rank prints two warnings about guessing it -- 4 KB of stderr at 8 ranks,
+        # and the driver's record is the tail of stdout + stderr); gloo takes no device_ids
+        if self.rehearsal:
+            self.dist.barrier()
+        else:
+            self.dist.barrier(device_ids=[self.local])
+
     def barrier(self):
         self.torch.cuda.synchronize()
         if self.dist is not None:
-            self.dist.barrier()
+            self._dist_barrier()
         self.torch.cuda.synchronize()
 
     def reduce(self, x, op):
@@ -147,7 +155,7 @@ class Rig:
 
     def close(self):
         if self.dist is not None:
-            self.dist.barrier()
+            self._dist_barrier()
             self.dist.destroy_process_group()
 
 
