@@ -688,13 +688,27 @@ def rank_of(rig):
     return rig.rank
 
 
+LINE_OUT = None          # the process's real stdout once claim_stdout() has run
+
+
+def claim_stdout():
+    """From here on file descriptor 1 is stderr for everybody except emit_line: RCCL prints its version banner and gloo one
+    "[Gloo] Rank r is connected ..." line per rank on STDOUT from native code, and stdout is to carry ONE line."""
+    global LINE_OUT
+    if LINE_OUT is not None:
+        return
+    sys.stdout.flush()
+    LINE_OUT = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
+
 def emit_line(out, headline):
     """The detail goes to bench_detail.json beside this file and into gpurun_out/ (the directory that travels back from a GPU
     box); stderr gets one short line saying so and stdout the ONE final line, which gauss_amd/benchline.py keeps under 6 KB
     (round 5's 28 KB line was more than the driver's reader took; stdout + stderr together now stay under 7 KB)."""
     from gauss_amd import benchline
     return benchline.emit(out, headline=headline, detail_path=os.path.join(ROOT, "bench_detail.json"),
-                          also_dirs=(os.path.join(ROOT, "gpurun_out"),))
+                          also_dirs=(os.path.join(ROOT, "gpurun_out"),), stdout=LINE_OUT)
 
 
 def shard_mode(args, world):
@@ -929,6 +943,8 @@ def main(argv=None):
     args = parse_args(argv)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args))
+    if argv is None:
+        claim_stdout()
     rig = Rig(args)
     if args.mode in ("distmix", "dist"):
         out = run_impute(args, rig)
